@@ -1,0 +1,130 @@
+/* pymes_amd — C-ABI of the MI355X-native CCSD/DCSD amplitude-update engine.
+ *
+ * This is the drop-in boundary for the hot path of nickirk/pymes (reference @
+ * 2024_10_08).  The reference has no FFI: its seam is the module-level `einsum`
+ * callable (pymes/solver/ccsd.py:11, mp2.py:5; historically `ctf.einsum`,
+ * pymes/__init__.py:3) and the solver-class methods built on it.  Each entry point
+ * below names the reference function it replaces.  pymes_amd/_lib.py binds exactly
+ * these symbols with ctypes; INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; pymes_last_error()
+ *     then returns a thread-local message.  No exception crosses the boundary.
+ *   - all tensors are fp64, C-contiguous unless explicit strides (in elements) are
+ *     given; "dev" pointers are device (HBM) addresses, "host" pointers host memory.
+ *   - shapes follow the reference: T2 is [a,b,i,j] = (nv,nv,no,no), T1 is [a,i],
+ *     Fock is [n,n], V[p,q,r,s] = <pq|rs>, block names are partition.py's
+ *     (i,j,k,l occupied; a,b,c,d virtual).
+ *   - one context per host thread; all work of a context is ordered on one HIP stream.
+ */
+#ifndef PYMES_AMD_H
+#define PYMES_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pymes_ctx pymes_ctx;
+
+/* ---- library / context ------------------------------------------------------- */
+const char* pymes_last_error(void);
+const char* pymes_backend(void);                 /* "hip-gfx950" for the product library */
+int pymes_ctx_create(pymes_ctx** out, int device, int no, int nv, uint64_t workspace_bytes /* 0 = auto */);
+int pymes_ctx_destroy(pymes_ctx* ctx);
+int pymes_ctx_set_stream(pymes_ctx* ctx, void* hip_stream);
+int pymes_ctx_sync(pymes_ctx* ctx);
+int pymes_ctx_workspace(pymes_ctx* ctx, uint64_t* capacity_bytes, uint64_t* high_water_bytes);
+
+/* ---- device memory ------------------------------------------------------------ */
+int pymes_malloc(pymes_ctx* ctx, uint64_t bytes, void** dev_ptr);
+int pymes_free(pymes_ctx* ctx, void* dev_ptr);
+int pymes_upload(pymes_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);   /* synchronous */
+int pymes_download(pymes_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes); /* synchronous */
+int pymes_copy(pymes_ctx* ctx, void* dst_dev, const void* src_dev, uint64_t bytes);      /* stream-ordered */
+int pymes_memset_zero(pymes_ctx* ctx, void* dst_dev, uint64_t bytes);
+
+/* ---- generic tensor engine: the `einsum` seam (ccsd.py:11, mp2.py:5) ------------ */
+/* C[lc] = alpha * sum_{contracted} A[la] * B[lb] + beta * C[lc]; one-letter labels; strides
+ * may be NULL (contiguous); `batch` lists free labels to run as GEMM batches ("" = none). */
+int pymes_contract(pymes_ctx* ctx, double alpha,
+                   const double* A_dev, const char* la, const int64_t* dimA, const int64_t* strideA,
+                   const double* B_dev, const char* lb, const int64_t* dimB, const int64_t* strideB,
+                   double beta, double* C_dev, const char* lc, const int64_t* dimC, const int64_t* strideC,
+                   const char* batch);
+/* out[lo] = alpha * in[li] + beta * out[lo]; `lo` is a permutation of `li` */
+int pymes_permute(pymes_ctx* ctx, double alpha, const double* in_dev, const char* li, const int64_t* dim_in,
+                  const int64_t* stride_in, double beta, double* out_dev, const char* lo,
+                  const int64_t* stride_out);
+/* raw fp64 MFMA GEMM (kernel-level tests): C(m,n) = alpha*sum_k A(m,k)B(k,n) + beta*C(m,n),
+ * A(m,k) = A[m*a_sm + k*a_sk], B(k,n) = B[k*b_sk + n*b_sn], C(m,n) = C[m*ldc + n] */
+int pymes_dgemm(pymes_ctx* ctx, int64_t M, int64_t N, int64_t K, double alpha, const double* A_dev, int64_t a_sm,
+                int64_t a_sk, const double* B_dev, int64_t b_sk, int64_t b_sn, double beta, double* C_dev,
+                int64_t ldc);
+
+/* ---- integrals: pymes/integral/partition.py:4-39 -------------------------------- */
+/* V[n,n,n,n] (host: C-contiguous, strides ignored; device: element strides or NULL) -> 16 blocks */
+int pymes_set_V_pqrs(pymes_ctx* ctx, const double* V, int on_device, const int64_t* strides);
+/* a single block by its partition.py name ("abcd", "ijab", ...) */
+int pymes_set_V_block(pymes_ctx* ctx, const char* name, const double* data, int on_device,
+                      const int64_t* strides);
+/* V[p,q,r,s] = sum_Q B[Q,p,r] B[Q,q,s]  (density-fitted / synthetic input), B_host is [naux,n,n] */
+int pymes_set_V_from_factors(pymes_ctx* ctx, const double* B_host, int naux);
+/* device address of a block ("dressed" = output of pymes_ccsd_dress_V); NULL+error if absent */
+int pymes_V_block_ptr(pymes_ctx* ctx, const char* name, int dressed, double** dev_ptr, int64_t* n_elements);
+/* diag(f): eps_o[no], eps_v[nv] used by the denominators (ccsd.py:149-156) */
+int pymes_set_orbital_energies(pymes_ctx* ctx, const double* eps_o_host, const double* eps_v_host);
+
+/* ---- the CC hot path ------------------------------------------------------------- */
+/* pymes/solver/mp2.py:9-22: T2 = V_abij/(D+shift) into t2_dev; e_out = {direct, exchange} */
+int pymes_mp2(pymes_ctx* ctx, double level_shift, double* t2_dev, double* e_out_host);
+/* CCSD.get_T1_dressed_fock, ccsd.py:226-288 (f and fd are [n,n] on the device) */
+int pymes_ccsd_dress_fock(pymes_ctx* ctx, const double* f_dev, const double* t1_dev, double* fd_dev);
+/* CCSD.get_T1_dressed_V, ccsd.py:290-421; block_mask bit p = pattern id of the block
+ * (bit 3-pos set when index `pos` is virtual: "abcd"=15, "klij"=0, "ijab"=3, "abij"=12 ...) */
+int pymes_ccsd_dress_V(pymes_ctx* ctx, const double* t1_dev, uint32_t block_mask);
+/* CCSD.get_singles_residual, ccsd.py:423-438 */
+int pymes_ccsd_singles_residual(pymes_ctx* ctx, const double* fd_dev, const double* t1_dev, const double* t2_dev,
+                                double* r1_dev);
+/* CCD.get_residual, ccd.py:164-254 (and CCSD.get_doubles_residual, ccsd.py:440-456, with
+ * PYMES_USE_DRESSED).  flags: */
+#define PYMES_DCD 1u          /* is_dcd / is_dcsd */
+#define PYMES_USE_DRESSED 2u  /* read the T1-dressed blocks instead of the undressed ones */
+#define PYMES_SKIP_LADDER 4u  /* leave out V_abcd.T (ccd.py:187) — it is added per a-slab by pymes_ladder */
+int pymes_doubles_residual(pymes_ctx* ctx, const double* f_dev, const double* t2_dev, double* r2_dev,
+                           uint32_t flags);
+/* the particle-particle ladder on an a-slab (ccd.py:187): R[a0:a1] = beta*R[a0:a1] + V_abcd[a0:a1].T */
+int pymes_ladder(pymes_ctx* ctx, const double* t2_dev, double* r2_dev, int a_begin, int a_end, int dressed,
+                 double beta);
+/* ccsd.py:176-179 / ccd.py:123-124: dt = r/(D+shift) (as r * (1/(D+shift))), t += delta*dt; rank 2 or 4 */
+int pymes_cc_update(pymes_ctx* ctx, double* t_dev, double* dt_dev, const double* r_dev, double level_shift,
+                    double delta, int rank);
+/* CCSD.get_energy, ccsd.py:458-466: e_out = {one-body, direct, exchange}; f is the UNDRESSED Fock */
+int pymes_ccsd_energy(pymes_ctx* ctx, const double* f_dev, const double* t1_dev, const double* t2_dev,
+                      double* e_out_host);
+/* CCD.get_energy, ccd.py:256-262: e_out = {direct, exchange} */
+int pymes_ccd_energy(pymes_ctx* ctx, const double* t2_dev, double* e_out_host);
+
+/* ---- vector helpers for DIIS (pymes/mixer/diis.py:65-103) and norms ----------------- */
+/* out_host[p] = sum_i x[p][i]*y[p][i], npairs <= 16, deterministic reduction (synchronises) */
+int pymes_dots(pymes_ctx* ctx, int npairs, const double* const* x_dev, const double* const* y_dev, int64_t n,
+               double* out_host);
+/* out = sum_k c[k]*x[k], nx <= 8 */
+int pymes_lincomb(pymes_ctx* ctx, double* out_dev, int nx, const double* const* x_dev, const double* c_host,
+                  int64_t n);
+
+/* ---- measurement --------------------------------------------------------------------- */
+/* executed-work counters since the last reset: GEMM launches, executed GEMM flops
+ * (2*M*N*K*batch), permutation launches, bytes moved by explicit permutations */
+int pymes_stats(pymes_ctx* ctx, int reset, int64_t* gemm_calls, double* gemm_flops, int64_t* permute_calls,
+                double* permute_bytes);
+/* HIP-event timing of every fp64 GEMM launch on the context's stream (off by default) */
+int pymes_prof_enable(pymes_ctx* ctx, int on);
+int pymes_prof_reset(pymes_ctx* ctx);
+int pymes_prof_query(pymes_ctx* ctx, int64_t* launches, double* total_ms, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYMES_AMD_H */

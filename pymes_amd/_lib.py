@@ -1,0 +1,117 @@
+"""ctypes binding of include/pymes_amd.h.
+
+The product library is ``pymes_amd/lib/libpymes_amd.so`` (built by
+``__graft_entry__.build()`` / ``make -C pymes_amd/csrc``).  Loading fails loudly when
+the library is missing or is not the HIP build: there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_PATH = os.path.join(_HERE, "lib", "libpymes_amd.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_i64_p = C.POINTER(C.c_int64)
+c_pp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); exactly the declarations of include/pymes_amd.h
+SIGNATURES = {
+    "pymes_last_error": (C.c_char_p, []),
+    "pymes_backend": (C.c_char_p, []),
+    "pymes_ctx_create": (C.c_int, [c_pp, C.c_int, C.c_int, C.c_int, C.c_uint64]),
+    "pymes_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "pymes_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pymes_ctx_sync": (C.c_int, [C.c_void_p]),
+    "pymes_ctx_workspace": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "pymes_malloc": (C.c_int, [C.c_void_p, C.c_uint64, c_pp]),
+    "pymes_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pymes_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "pymes_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "pymes_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "pymes_memset_zero": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "pymes_contract": (C.c_int, [C.c_void_p, C.c_double,
+                                 C.c_void_p, C.c_char_p, c_i64_p, c_i64_p,
+                                 C.c_void_p, C.c_char_p, c_i64_p, c_i64_p,
+                                 C.c_double, C.c_void_p, C.c_char_p, c_i64_p, c_i64_p, C.c_char_p]),
+    "pymes_permute": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_char_p, c_i64_p, c_i64_p,
+                                C.c_double, C.c_void_p, C.c_char_p, c_i64_p]),
+    "pymes_dgemm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_void_p, C.c_int64,
+                              C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_void_p, C.c_int64]),
+    "pymes_set_V_pqrs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_i64_p]),
+    "pymes_set_V_block": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, c_i64_p]),
+    "pymes_set_V_from_factors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "pymes_V_block_ptr": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, c_pp, c_i64_p]),
+    "pymes_set_orbital_energies": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pymes_mp2": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, c_double_p]),
+    "pymes_ccsd_dress_fock": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pymes_ccsd_dress_V": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
+    "pymes_ccsd_singles_residual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pymes_doubles_residual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "pymes_ladder": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]),
+    "pymes_cc_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                  C.c_int]),
+    "pymes_ccsd_energy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_double_p]),
+    "pymes_ccd_energy": (C.c_int, [C.c_void_p, C.c_void_p, c_double_p]),
+    "pymes_dots": (C.c_int, [C.c_void_p, C.c_int, c_pp, c_pp, C.c_int64, c_double_p]),
+    "pymes_lincomb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_pp, c_double_p, C.c_int64]),
+    "pymes_stats": (C.c_int, [C.c_void_p, C.c_int, c_i64_p, c_double_p, c_i64_p, c_double_p]),
+    "pymes_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "pymes_prof_reset": (C.c_int, [C.c_void_p]),
+    "pymes_prof_query": (C.c_int, [C.c_void_p, c_i64_p, c_double_p, c_double_p]),
+}
+
+PYMES_DCD, PYMES_USE_DRESSED, PYMES_SKIP_LADDER = 1, 2, 4
+
+
+class PymesError(RuntimeError):
+    pass
+
+
+class Library:
+    """Loaded C-ABI library with typed entry points and error checking."""
+
+    def __init__(self, path=None, _testing_backend=None):
+        path = path or os.environ.get("PYMES_AMD_LIB", DEFAULT_PATH)
+        if not os.path.exists(path):
+            raise PymesError(
+                f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                "g.build()' or make -C pymes_amd/csrc).  pymes_amd has no CPU fallback.")
+        self.path = path
+        self.dll = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self.dll, name)      # AttributeError if a declared symbol is missing
+            fn.restype, fn.argtypes = res, args
+        self.backend = self.dll.pymes_backend().decode()
+        expected = _testing_backend or "hip-gfx950"
+        if self.backend != expected:
+            raise PymesError(f"{path} reports backend '{self.backend}', expected '{expected}'")
+
+    def call(self, name, *args):
+        rc = getattr(self.dll, name)(*args)
+        if rc != 0:
+            raise PymesError(f"{name}: {self.dll.pymes_last_error().decode()}")
+
+
+_default = None
+
+
+def default_library():
+    global _default
+    if _default is None:
+        _default = Library()
+    return _default
+
+
+def i64_array(values):
+    return (C.c_int64 * len(values))(*[int(v) for v in values]) if values is not None else None
+
+
+def ptr_array(ptrs):
+    return (C.c_void_p * len(ptrs))(*[int(p) for p in ptrs])
+
+
+def host_ptr(a):
+    assert isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(C.c_void_p)

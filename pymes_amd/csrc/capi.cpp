@@ -1,0 +1,299 @@
+// extern "C" surface of libpymes_amd (see include/pymes_amd.h).
+#include <cstring>
+#include <exception>
+#include <string>
+
+#include "../../include/pymes_amd.h"
+#include "engine.h"
+
+using pymes::Engine;
+using pymes::TView;
+
+struct pymes_ctx {
+    Engine* e;
+};
+
+namespace {
+thread_local std::string g_err;
+
+template <class F>
+int guarded(F&& f) {
+    try {
+        f();
+        return 0;
+    } catch (const std::exception& ex) {
+        g_err = ex.what();
+    } catch (...) {
+        g_err = "unknown error";
+    }
+    return 1;
+}
+Engine& E(pymes_ctx* c) {
+    if (!c || !c->e) throw pymes::Error("null context");
+    return *c->e;
+}
+void need(const void* p, const char* what) {
+    if (!p) throw pymes::Error(std::string("null pointer: ") + what);
+}
+TView view_of(const double* p, const char* labels, const int64_t* dim, const int64_t* stride) {
+    need(p, "tensor data");
+    need(labels, "labels");
+    need(dim, "dims");
+    return pymes::make_view(const_cast<double*>(p), static_cast<int>(std::strlen(labels)), dim, stride);
+}
+}  // namespace
+
+extern "C" {
+
+const char* pymes_last_error(void) { return g_err.c_str(); }
+const char* pymes_backend(void) { return dev::backend_name(); }
+
+int pymes_ctx_create(pymes_ctx** out, int device, int no, int nv, uint64_t workspace_bytes) {
+    return guarded([&] {
+        need(out, "out");
+        *out = nullptr;
+        Engine* e = new Engine(device, no, nv, static_cast<size_t>(workspace_bytes));
+        *out = new pymes_ctx{e};
+    });
+}
+int pymes_ctx_destroy(pymes_ctx* ctx) {
+    return guarded([&] {
+        if (!ctx) return;
+        delete ctx->e;
+        delete ctx;
+    });
+}
+int pymes_ctx_set_stream(pymes_ctx* ctx, void* s) {
+    return guarded([&] { E(ctx).stream = s; });
+}
+int pymes_ctx_sync(pymes_ctx* ctx) {
+    return guarded([&] { dev::stream_sync(E(ctx).stream); });
+}
+int pymes_ctx_workspace(pymes_ctx* ctx, uint64_t* cap, uint64_t* high) {
+    return guarded([&] {
+        if (cap) *cap = E(ctx).arena.capacity();
+        if (high) *high = E(ctx).arena.high_water();
+    });
+}
+
+int pymes_malloc(pymes_ctx* ctx, uint64_t bytes, void** p) {
+    return guarded([&] {
+        E(ctx);
+        need(p, "dev_ptr");
+        *p = dev::dmalloc(bytes);
+    });
+}
+int pymes_free(pymes_ctx* ctx, void* p) {
+    return guarded([&] {
+        dev::stream_sync(E(ctx).stream);
+        dev::dfree(p);
+    });
+}
+int pymes_upload(pymes_ctx* ctx, void* d, const void* h, uint64_t bytes) {
+    return guarded([&] {
+        if (bytes) dev::memcpy_h2d(d, h, bytes, E(ctx).stream);
+    });
+}
+int pymes_download(pymes_ctx* ctx, void* h, const void* d, uint64_t bytes) {
+    return guarded([&] {
+        if (bytes) dev::memcpy_d2h(h, d, bytes, E(ctx).stream);
+    });
+}
+int pymes_copy(pymes_ctx* ctx, void* d, const void* s, uint64_t bytes) {
+    return guarded([&] {
+        if (bytes) dev::memcpy_d2d(d, s, bytes, E(ctx).stream);
+    });
+}
+int pymes_memset_zero(pymes_ctx* ctx, void* d, uint64_t bytes) {
+    return guarded([&] {
+        if (bytes) dev::memset_zero(d, bytes, E(ctx).stream);
+    });
+}
+
+int pymes_contract(pymes_ctx* ctx, double alpha, const double* A, const char* la, const int64_t* dA,
+                   const int64_t* sA, const double* B, const char* lb, const int64_t* dB, const int64_t* sB,
+                   double beta, double* C, const char* lc, const int64_t* dC, const int64_t* sC,
+                   const char* batch) {
+    return guarded([&] {
+        E(ctx).contract(alpha, view_of(A, la, dA, sA), la, view_of(B, lb, dB, sB), lb, beta, view_of(C, lc, dC, sC),
+                        lc, batch ? batch : "");
+    });
+}
+int pymes_permute(pymes_ctx* ctx, double alpha, const double* in, const char* li, const int64_t* dim_in,
+                  const int64_t* stride_in, double beta, double* out, const char* lo, const int64_t* stride_out) {
+    return guarded([&] {
+        need(li, "li");
+        need(lo, "lo");
+        TView vin = view_of(in, li, dim_in, stride_in);
+        const int r = vin.rank;
+        if (static_cast<int>(std::strlen(lo)) != r) throw pymes::Error("permute: label strings differ in length");
+        int64_t dout[6];
+        for (int i = 0; i < r; ++i) {
+            const char* f = std::strchr(li, lo[i]);
+            if (!f) throw pymes::Error("permute: output label missing from input");
+            dout[i] = dim_in[f - li];
+        }
+        TView vout = pymes::make_view(out, r, dout, stride_out);
+        need(out, "out");
+        E(ctx).permute(alpha, vin, li, beta, vout, lo);
+    });
+}
+int pymes_dgemm(pymes_ctx* ctx, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t a_sm,
+                int64_t a_sk, const double* B, int64_t b_sk, int64_t b_sn, double beta, double* C, int64_t ldc) {
+    return guarded([&] {
+        Engine& e = E(ctx);
+        dev::Gemm g{};
+        g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
+        g.A = A; g.a_sm = a_sm; g.a_sk = a_sk;
+        g.B = B; g.b_sk = b_sk; g.b_sn = b_sn;
+        g.C = C; g.ldc = ldc;
+        g.nb1 = g.nb2 = 1;
+        g.splitk_ws = nullptr;
+        g.splitk_ws_doubles = 0;
+        dev::gemm(g, e.stream);
+        e.stats.gemm_calls++;
+        e.stats.gemm_flops += 2.0 * double(M) * double(N) * double(K);
+    });
+}
+
+int pymes_set_V_pqrs(pymes_ctx* ctx, const double* V, int on_device, const int64_t* strides) {
+    return guarded([&] {
+        need(V, "V");
+        E(ctx).set_V_full(V, on_device != 0, strides);
+    });
+}
+int pymes_set_V_block(pymes_ctx* ctx, const char* name, const double* data, int on_device, const int64_t* strides) {
+    return guarded([&] {
+        need(data, "data");
+        E(ctx).set_V_block(name, data, on_device != 0, strides);
+    });
+}
+int pymes_set_V_from_factors(pymes_ctx* ctx, const double* B, int naux) {
+    return guarded([&] {
+        need(B, "B");
+        E(ctx).set_V_from_factors(B, naux);
+    });
+}
+int pymes_V_block_ptr(pymes_ctx* ctx, const char* name, int dressed, double** p, int64_t* nel) {
+    return guarded([&] {
+        need(p, "dev_ptr");
+        *p = nullptr;
+        TView v = E(ctx).block(pymes::pattern_of_name(name), dressed != 0);
+        *p = v.p;
+        if (nel) *nel = v.size();
+    });
+}
+int pymes_set_orbital_energies(pymes_ctx* ctx, const double* eo, const double* ev) {
+    return guarded([&] {
+        need(eo, "eps_o");
+        need(ev, "eps_v");
+        E(ctx).set_orbital_energies(eo, ev);
+    });
+}
+
+int pymes_mp2(pymes_ctx* ctx, double shift, double* t2, double* e_out) {
+    return guarded([&] {
+        need(t2, "t2");
+        need(e_out, "e_out");
+        E(ctx).mp2(shift, t2, e_out);
+    });
+}
+int pymes_ccsd_dress_fock(pymes_ctx* ctx, const double* f, const double* t1, double* fd) {
+    return guarded([&] {
+        need(f, "f"); need(t1, "t1"); need(fd, "fd");
+        E(ctx).dress_fock(f, t1, fd);
+    });
+}
+int pymes_ccsd_dress_V(pymes_ctx* ctx, const double* t1, uint32_t mask) {
+    return guarded([&] {
+        need(t1, "t1");
+        E(ctx).dress_V(t1, mask);
+    });
+}
+int pymes_ccsd_singles_residual(pymes_ctx* ctx, const double* fd, const double* t1, const double* t2, double* r1) {
+    return guarded([&] {
+        need(fd, "fd"); need(t1, "t1"); need(t2, "t2"); need(r1, "r1");
+        E(ctx).singles_residual(fd, t1, t2, r1);
+    });
+}
+int pymes_doubles_residual(pymes_ctx* ctx, const double* f, const double* t2, double* r2, uint32_t flags) {
+    return guarded([&] {
+        need(f, "f"); need(t2, "t2"); need(r2, "r2");
+        E(ctx).doubles_residual(f, t2, r2, flags);
+    });
+}
+int pymes_ladder(pymes_ctx* ctx, const double* t2, double* r2, int a0, int a1, int dressed, double beta) {
+    return guarded([&] {
+        need(t2, "t2"); need(r2, "r2");
+        E(ctx).ladder(t2, r2, a0, a1, dressed != 0, beta);
+    });
+}
+int pymes_cc_update(pymes_ctx* ctx, double* t, double* dt, const double* r, double shift, double delta, int rank) {
+    return guarded([&] {
+        need(t, "t"); need(dt, "dt"); need(r, "r");
+        E(ctx).cc_update(t, dt, r, shift, delta, rank);
+    });
+}
+int pymes_ccsd_energy(pymes_ctx* ctx, const double* f, const double* t1, const double* t2, double* e_out) {
+    return guarded([&] {
+        need(f, "f"); need(t1, "t1"); need(t2, "t2"); need(e_out, "e_out");
+        E(ctx).ccsd_energy(f, t1, t2, e_out);
+    });
+}
+int pymes_ccd_energy(pymes_ctx* ctx, const double* t2, double* e_out) {
+    return guarded([&] {
+        need(t2, "t2"); need(e_out, "e_out");
+        E(ctx).ccd_energy(t2, e_out);
+    });
+}
+
+int pymes_dots(pymes_ctx* ctx, int npairs, const double* const* x, const double* const* y, int64_t n,
+               double* out) {
+    return guarded([&] {
+        need(x, "x"); need(y, "y"); need(out, "out");
+        dev::dots(npairs, x, y, n, out, E(ctx).stream);
+    });
+}
+int pymes_lincomb(pymes_ctx* ctx, double* out, int nx, const double* const* x, const double* c, int64_t n) {
+    return guarded([&] {
+        need(out, "out"); need(x, "x"); need(c, "c");
+        dev::lincomb(out, nx, x, c, n, E(ctx).stream);
+    });
+}
+
+int pymes_stats(pymes_ctx* ctx, int reset, int64_t* gemm_calls, double* gemm_flops, int64_t* permute_calls,
+                double* permute_bytes) {
+    return guarded([&] {
+        Engine& e = E(ctx);
+        if (gemm_calls) *gemm_calls = e.stats.gemm_calls;
+        if (gemm_flops) *gemm_flops = e.stats.gemm_flops;
+        if (permute_calls) *permute_calls = e.stats.permute_calls;
+        if (permute_bytes) *permute_bytes = e.stats.permute_bytes;
+        if (reset) e.stats = pymes::ContractStats{};
+    });
+}
+int pymes_prof_enable(pymes_ctx* ctx, int on) {
+    return guarded([&] {
+        E(ctx);
+        dev::prof_enable(on != 0);
+    });
+}
+int pymes_prof_reset(pymes_ctx* ctx) {
+    return guarded([&] {
+        E(ctx);
+        dev::prof_reset();
+    });
+}
+int pymes_prof_query(pymes_ctx* ctx, int64_t* launches, double* ms, double* flops) {
+    return guarded([&] {
+        E(ctx);
+        long l = 0;
+        double m = 0, f = 0;
+        dev::prof_query(&l, &m, &f);
+        if (launches) *launches = l;
+        if (ms) *ms = m;
+        if (flops) *flops = f;
+    });
+}
+
+}  // extern "C"

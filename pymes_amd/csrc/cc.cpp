@@ -1,0 +1,355 @@
+// Coupled-cluster term sequences on top of Engine::contract / permute.
+//
+// Every function cites the reference lines it reproduces (nickirk/pymes @ 2024_10_08).
+// The index algebra is restated for GEMM-friendly layouts; no symmetry of V or T is
+// assumed anywhere (the transcorrelated Hamiltonian has only V_pqrs = V_qpsr, and the
+// reference keeps V_ijab and V_abij separate, ccd.py:172).
+//
+// Matrix layouts used for the o^3 v^3 terms (all ov x ov matrices):
+//   Td[(a,i),(b,j)] = T[a,b,i,j]   "direct" pairing      (labels "aibj")
+//   Tx[(a,j),(b,i)] = T[a,b,i,j]   "crossed" pairing     (labels "ajbi")
+// so that every ring/exchange term of ccd.py:190-240 is a plain product of two such
+// matrices (possibly transposed), with no per-term transposition of the operands.
+#include <cstring>
+
+#include "engine.h"
+
+namespace pymes {
+
+namespace {
+constexpr int P_klij = 0, P_ijka = 1, P_ijak = 2, P_ijab = 3, P_iajk = 4, P_iajb = 5, P_iabj = 6, P_iabc = 7,
+              P_aibc = 11, P_abij = 12, P_abcd = 15;
+}
+
+// -----------------------------------------------------------------------------------
+// static (per-solve) permutations of the undressed V_ijab block.  The T1-dressed ijab
+// block is a plain copy of the undressed one (ccsd.py:355-357), so these stay valid for
+// the whole solve.
+// -----------------------------------------------------------------------------------
+double* Engine::get_static(const std::string& key) {
+    auto it = static_.find(key);
+    if (it != static_.end()) return it->second;
+    const int64_t o = no, v = nv;
+    TView Vijab = block(P_ijab);
+    double* p = static_cast<double*>(dev::dmalloc(sizeof(double) * o * o * v * v));
+    static_[key] = p;
+    // all keys: source labels of V_ijab are "klcd" (k,l occupied; c,d virtual)
+    if (key == "Vd") permute(1.0, Vijab, "klcd", 0.0, make_view(p, {v, o, v, o}), "ckdl");        // [(c,k),(d,l)]
+    else if (key == "Vx") permute(1.0, Vijab, "klcd", 0.0, make_view(p, {v, o, v, o}), "cldk");   // [(c,l),(d,k)]
+    else if (key == "Vk") permute(1.0, Vijab, "lkdc", 0.0, make_view(p, {o, v, o, v}), "kdlc");   // [(k,d,l),c]
+    else if (key == "Vk2") permute(1.0, Vijab, "lkdc", 0.0, make_view(p, {o, v, v, o}), "kcdl");  // [k,(c,d,l)]
+    else if (key == "Edir") permute(1.0, Vijab, "ijab", 0.0, make_view(p, {v, v, o, o}), "abij"); // V[i,j,a,b]
+    else if (key == "Eex") permute(1.0, Vijab, "ijba", 0.0, make_view(p, {v, v, o, o}), "abij");  // V[i,j,b,a]
+    else throw Error("unknown static tensor " + key);
+    return p;
+}
+
+// -----------------------------------------------------------------------------------
+// mp2.py:9-22
+// -----------------------------------------------------------------------------------
+void Engine::mp2(double shift, double* t2, double e_out[2]) {
+    const int64_t o = no, v = nv, n4 = v * v * o * o;
+    TView Vabij = block(P_abij);
+    dev::mp2_amplitudes(t2, Vabij.p, eps_o, eps_v, shift, no, nv, stream);                 // :16-18
+    ArenaScope scope(arena);
+    double* e2 = arena.alloc(n4);
+    permute(1.0, block(P_ijab), "jiab", 0.0, make_view(e2, {v, v, o, o}), "abij");          // 'abij,jiab' :20
+    const double* x[2] = {t2, t2};
+    const double* y[2] = {get_static("Edir"), e2};
+    double d[2];
+    dev::dots(2, x, y, n4, d, stream);
+    e_out[0] = 2.0 * d[0];                                                                  // :19
+    e_out[1] = -1.0 * d[1];                                                                 // :20
+}
+
+// -----------------------------------------------------------------------------------
+// ccd.py:164-254  (the doubles residual; also the CCSD one via dressed blocks, ccsd.py:440-456)
+// -----------------------------------------------------------------------------------
+void Engine::doubles_residual(const double* f, const double* t2, double* r2, unsigned flags) {
+    const bool dcd = flags & 1u, dressed = flags & 2u, skip_ladder = flags & 4u;
+    const bool quad = !dcd;
+    const int64_t o = no, v = nv, nn = n;
+    const double w = quad ? 1.0 : 0.5;                                                      // :213-220
+    TView T = make_view(const_cast<double*>(t2), {v, v, o, o});
+    TView R = make_view(r2, {v, v, o, o});
+    TView F = make_view(const_cast<double*>(f), {nn, nn});
+    TView Foo = slice(slice(F, 0, 0, o), 1, 0, o), Fvv = slice(slice(F, 0, o, nn), 1, o, nn);
+    TView Vklij = block(P_klij, dressed), Vabij = block(P_abij, dressed), Viajb = block(P_iajb, dressed),
+          Viabj = block(P_iabj, dressed);
+    TView Vijab = block(P_ijab);   // dressed ijab == undressed ijab (ccsd.py:355-357)
+
+    ArenaScope scope(arena);
+    auto ov2 = [&]() { return make_view(arena.alloc(o * o * v * v), {v, o, v, o}); };
+    TView Vd = make_view(get_static("Vd"), {v, o, v, o});
+    TView Vk = make_view(get_static("Vk"), {o, v, o, v});
+    TView Vk2 = make_view(get_static("Vk2"), {o, v, v, o});
+
+    // permuted amplitudes: Td, Tx and Tt_d = direct layout of 2T - T^(ab)   (:199)
+    TView Td = ov2(), Tx = ov2(), Ttd = ov2();
+    permute(1.0, T, "abij", 0.0, Td, "aibj");
+    permute(1.0, T, "abij", 0.0, Tx, "ajbi");
+    permute(2.0, T, "abij", 0.0, Ttd, "aibj");
+    permute(-1.0, T, "baij", 1.0, Ttd, "aibj");
+
+    // ---- terms kept in the natural [a,b,i,j] layout -------------------------------------
+    copy(Vabij, R);                                                                         // :185
+    {
+        ArenaScope s2(arena);
+        TView hole = make_view(arena.alloc(o * o * o * o), {o, o, o, o});
+        copy(Vklij, hole);                                                                  // :178
+        if (quad) contract(1.0, Vijab, "klcd", T, "cdij", 1.0, hole, "klij");                // :180
+        contract(1.0, hole, "klij", T, "abkl", 1.0, R, "abij");                             // :186
+    }
+    if (!skip_ladder) contract(1.0, block(P_abcd, dressed), "abcd", T, "cdij", 1.0, R, "abij");   // :187
+
+    // ---- X_ac, X_ki (:206-221) ------------------------------------------------------------
+    TView Xvv = make_view(arena.alloc(v * v), {v, v}), Xoo = make_view(arena.alloc(o * o), {o, o});
+    copy(Fvv, Xvv);
+    copy(Foo, Xoo);
+    // X_ac = f_ac - w sum_{dkl} Tt[a,d,k,l] V[l,k,d,c];  Tt[a,d,k,l] = Ttd[a,k,d,l]
+    contract(-w, Ttd, "akdl", Vk, "kdlc", 1.0, Xvv, "ac");
+    {
+        // X_ki = f_ki + w sum_{cdl} Tt[c,d,i,l] V[l,k,d,c];  Tt[c,d,i,l] = Ttd[c,i,d,l]
+        ArenaScope s2(arena);
+        TView Tp = make_view(arena.alloc(o * o * v * v), {o, v, v, o});
+        permute(1.0, Ttd, "cidl", 0.0, Tp, "icdl");
+        contract(w, Vk2, "kcdl", Tp, "icdl", 1.0, Xoo, "ki");
+    }
+
+    // ---- accumulators in the pair layouts ---------------------------------------------------
+    TView Rd = ov2(), Exd = ov2(), Exx = ov2();
+    {
+        // :202-204  R += Tt . (V . Tt)   in the direct layout
+        ArenaScope s2(arena);
+        TView Y = ov2();
+        contract(1.0, Vd, "ckdl", Ttd, "dlbj", 0.0, Y, "ckbj");
+        contract(1.0, Ttd, "aick", Y, "ckbj", 0.0, Rd, "aibj");
+    }
+    {
+        ArenaScope s2(arena);
+        TView Ud = ov2(), Wd = ov2();
+        permute(1.0, Viajb, "kaic", 0.0, Ud, "aick");     // Ud[(a,i),(c,k)] = V_iajb[k,a,i,c]
+        permute(1.0, Viabj, "kbcj", 0.0, Wd, "ckbj");     // Wd[(c,k),(b,j)] = V_iabj[k,b,c,j]
+        contract(-1.0, Ud, "aick", Td, "ckbj", 0.0, Exd, "aibj");                            // :233
+        contract(1.0, Ttd, "aick", Wd, "ckbj", 1.0, Exd, "aibj");                            // :235
+        contract(-1.0, Tx, "ajck", Ud, "bick", 0.0, Exx, "ajbi");                            // :234
+    }
+    contract(-1.0, Xoo, "ki", Td, "akbj", 1.0, Exd, "aibj", "a");                            // :232
+    TView Exn = make_view(arena.alloc(o * o * v * v), {v, v, o, o});
+    contract(1.0, Xvv, "ac", T, "cbij", 0.0, Exn, "abij");                                   // :231
+    TView Rx;
+    if (quad) {
+        TView Vx = make_view(get_static("Vx"), {v, o, v, o});
+        {
+            // :238-240  Z[(a,i),(c,l)] = sum_{dk} T[d,a,k,i] V[k,l,c,d];  Ex += Z . (T[b,c,l,j] - T[c,b,l,j])
+            ArenaScope s2(arena);
+            TView Z = ov2(), Q = ov2();
+            contract(1.0, Td, "dkai", Vx, "cldk", 0.0, Z, "aicl");
+            permute(-1.0, T, "cblj", 0.0, Q, "clbj");
+            permute(1.0, T, "bclj", 1.0, Q, "clbj");
+            contract(1.0, Z, "aicl", Q, "clbj", 1.0, Exd, "aibj");
+        }
+        // :190-191  R += (Tx . Vx^T) . Tx   in the crossed layout
+        Rx = ov2();
+        TView X1 = ov2();
+        contract(1.0, Tx, "ajdk", Vx, "cldk", 0.0, X1, "ajcl");
+        contract(1.0, X1, "ajcl", Tx, "clbi", 0.0, Rx, "ajbi");
+    }
+
+    // ---- assemble: R += P(Rd) + P(Rx) + Ex + Ex^T(1,0,3,2)   (:249-252) ----------------------
+    permute(1.0, Rd, "aibj", 1.0, R, "abij");
+    if (quad) permute(1.0, Rx, "ajbi", 1.0, R, "abij");
+    permute(1.0, Exd, "aibj", 1.0, R, "abij");
+    permute(1.0, Exd, "bjai", 1.0, R, "abij");
+    permute(1.0, Exx, "ajbi", 1.0, R, "abij");
+    permute(1.0, Exx, "biaj", 1.0, R, "abij");
+    permute(1.0, Exn, "abij", 1.0, R, "abij");
+    permute(1.0, Exn, "baji", 1.0, R, "abij");
+}
+
+void Engine::ladder(const double* t2, double* r2, int a0, int a1, bool dressed, double beta) {
+    const int64_t o = no, v = nv;
+    if (a0 < 0 || a1 > nv || a0 > a1) throw Error("ladder: bad a-range");
+    if (a0 == a1) return;
+    TView T = make_view(const_cast<double*>(t2), {v, v, o, o});
+    TView R = slice(make_view(r2, {v, v, o, o}), 0, a0, a1);
+    TView Vs = slice(block(P_abcd, dressed), 0, a0, a1);
+    contract(1.0, Vs, "abcd", T, "cdij", beta, R, "abij");                                   // ccd.py:187
+}
+
+// -----------------------------------------------------------------------------------
+// ccsd.py:226-288   dressed Fock matrix, term by term (grouped; no symmetry assumed)
+//   G = 2 G1 - G2,  G1[a,c] = t_bj V_iabc[j,a,b,c],  G2[a,c] = t_bj V_iabc[j,a,c,b]
+//   Mm = 2 J1 - J2, J1[k,c] = t_bj V_ijab[j,k,b,c],  J2[k,c] = t_bj V_ijab[j,k,c,b]
+//   L = 2 L1 - L2,  L1[k,i] = t_bj V_ijak[j,k,b,i],  L2[k,i] = t_bj V_ijka[j,k,i,b]
+//   K1[i,a] = t_bj V_iabj[j,a,b,i],  K2[a,i] = t_bj V_iajb[j,a,i,b]
+//   f~_ov = f_ov + 2 K1 - J2                                          (:257-258)
+//   f~_oo = f_oo + L + f_ov t + Mm t                                  (:275-279)
+//   f~_vv = f_vv + G - t f_ov - t Mm                                  (:282-286)
+//   f~_vo = f_vo - t f_oo + f_vv t - t (f_ov t) + 2 K1^T - K2 - t L + G t - t Mm t   (:260-272)
+// -----------------------------------------------------------------------------------
+void Engine::dress_fock(const double* f, const double* t1, double* fd) {
+    const int64_t o = no, v = nv, nn = n;
+    TView F = make_view(const_cast<double*>(f), {nn, nn}), D = make_view(fd, {nn, nn});
+    TView t = make_view(const_cast<double*>(t1), {v, o});
+    auto blk = [&](const TView& m, bool rv, bool cv) {
+        return slice(slice(m, 0, rv ? o : 0, rv ? nn : o), 1, cv ? o : 0, cv ? nn : o);
+    };
+    TView Foo = blk(F, 0, 0), Fov = blk(F, 0, 1), Fvv = blk(F, 1, 1);
+    TView Doo = blk(D, 0, 0), Dov = blk(D, 0, 1), Dvo = blk(D, 1, 0), Dvv = blk(D, 1, 1);
+    copy(F, D);
+    ArenaScope scope(arena);
+    auto mat = [&](int64_t r, int64_t c) { return make_view(arena.alloc(r * c), {r, c}); };
+    TView G = mat(v, v), Mm = mat(o, v), L = mat(o, o), K1 = mat(o, v), K2 = mat(v, o), J2 = mat(o, v);
+    contract(2.0, t, "bj", block(P_iabc), "jabc", 0.0, G, "ac");
+    contract(-1.0, t, "bj", block(P_iabc), "jacb", 1.0, G, "ac");
+    contract(1.0, t, "bj", block(P_ijab), "jkcb", 0.0, J2, "kc");
+    contract(2.0, t, "bj", block(P_ijab), "jkbc", 0.0, Mm, "kc");
+    axpby(-1.0, J2, 1.0, Mm);
+    contract(2.0, t, "bj", block(P_ijak), "jkbi", 0.0, L, "ki");
+    contract(-1.0, t, "bj", block(P_ijka), "jkib", 1.0, L, "ki");
+    contract(1.0, t, "bj", block(P_iabj), "jabi", 0.0, K1, "ia");
+    contract(1.0, t, "bj", block(P_iajb), "jaib", 0.0, K2, "ai");
+    // ov
+    axpby(2.0, K1, 1.0, Dov);
+    axpby(-1.0, J2, 1.0, Dov);
+    // oo
+    axpby(1.0, L, 1.0, Doo);
+    contract(1.0, Fov, "ib", t, "bj", 1.0, Doo, "ij");
+    contract(1.0, Mm, "ib", t, "bj", 1.0, Doo, "ij");
+    // vv
+    axpby(1.0, G, 1.0, Dvv);
+    contract(-1.0, t, "ai", Fov, "ib", 1.0, Dvv, "ab");
+    contract(-1.0, t, "ai", Mm, "ib", 1.0, Dvv, "ab");
+    // vo
+    contract(-1.0, t, "aj", Foo, "ji", 1.0, Dvo, "ai");
+    contract(1.0, Fvv, "ab", t, "bi", 1.0, Dvo, "ai");
+    TView ft = mat(o, o);   // (f_ov + Mm) t   -> shared by -t (f_ov t) and -t Mm t
+    contract(1.0, Fov, "jb", t, "bi", 0.0, ft, "ji");
+    contract(1.0, Mm, "jb", t, "bi", 1.0, ft, "ji");
+    axpby(1.0, L, 1.0, ft);            // ft = f_ov t + Mm t + L
+    contract(-1.0, t, "aj", ft, "ji", 1.0, Dvo, "ai");
+    permute(2.0, K1, "ia", 1.0, Dvo, "ai");
+    axpby(-1.0, K2, 1.0, Dvo);
+    contract(1.0, G, "ac", t, "ci", 1.0, Dvo, "ai");
+}
+
+// -----------------------------------------------------------------------------------
+// ccsd.py:290-421   exp(-T1) V exp(T1), block by block.
+// A bra index that is virtual in the target block picks up  -t[a,k] x (occupied source),
+// a ket index that is occupied in the target picks up  +(virtual source) x t[c,i]; sources
+// are always undressed blocks (checked term by term by the oracle).
+// Implemented as a recursion of one-index transforms: ket indices first (they shrink
+// v -> o), bra indices last.
+// -----------------------------------------------------------------------------------
+void Engine::dressed_into(int pattern, const std::vector<int>& pos, int k, const TView& t1v, const TView& dst) {
+    if (k == 0) {
+        copy(block(pattern), dst);
+        return;
+    }
+    dressed_into(pattern, pos, k - 1, t1v, dst);
+    const int x = pos[k - 1];
+    const int other = pattern ^ (1 << (3 - x));
+    ArenaScope scope(arena);
+    TView oth;
+    if (k - 1 == 0) {
+        oth = block(other);
+    } else {
+        oth = block_view(arena.alloc(block_size(other)), other);
+        dressed_into(other, pos, k - 1, t1v, oth);
+    }
+    switch (x) {
+        case 3: contract(1.0, oth, "pqrx", t1v, "xs", 1.0, dst, "pqrs"); break;
+        case 2: contract(1.0, oth, "pqxs", t1v, "xr", 1.0, dst, "pqrs", "pq"); break;
+        case 1: contract(-1.0, t1v, "qx", oth, "pxrs", 1.0, dst, "pqrs", "p"); break;
+        case 0: contract(-1.0, t1v, "px", oth, "xqrs", 1.0, dst, "pqrs"); break;
+        default: throw Error("bad index position");
+    }
+}
+
+void Engine::dress_V(const double* t1, uint32_t mask) {
+    TView t = make_view(const_cast<double*>(t1), {(int64_t)nv, (int64_t)no});
+    for (int pat = 0; pat < 16; ++pat) {
+        if (!(mask >> pat & 1u)) continue;
+        std::vector<int> pos;
+        if (!(pat >> 0 & 1)) pos.push_back(3);   // ket s occupied
+        if (!(pat >> 1 & 1)) pos.push_back(2);   // ket r occupied
+        if (pat >> 2 & 1) pos.push_back(1);      // bra q virtual
+        if (pat >> 3 & 1) pos.push_back(0);      // bra p virtual
+        TView dst = block_view(ensure_dressed(pat), pat);
+        dressed_into(pat, pos, static_cast<int>(pos.size()), t, dst);
+    }
+}
+
+// -----------------------------------------------------------------------------------
+// ccsd.py:423-438   singles residual (dressed Fock, UNDRESSED V, explicit T1 factors)
+// -----------------------------------------------------------------------------------
+void Engine::singles_residual(const double* fd, const double* t1, const double* t2, double* r1) {
+    const int64_t o = no, v = nv, nn = n;
+    TView D = make_view(const_cast<double*>(fd), {nn, nn});
+    TView Dov = slice(slice(D, 0, 0, o), 1, o, nn), Dvo = slice(slice(D, 0, o, nn), 1, 0, o);
+    TView t = make_view(const_cast<double*>(t1), {v, o});
+    TView T = make_view(const_cast<double*>(t2), {v, v, o, o});
+    TView R = make_view(r1, {v, o});
+    ArenaScope scope(arena);
+    // Tt'[a,b,i,j] = 2 T[a,b,i,j] - T[a,b,j,i]   (:430), held as Tq[a,i,b,j] and P1[j,b,c,i] = Tt'[b,c,i,j]
+    TView Tq = make_view(arena.alloc(o * o * v * v), {v, o, v, o});
+    TView P1 = make_view(arena.alloc(o * o * v * v), {o, v, v, o});
+    permute(2.0, T, "abij", 0.0, Tq, "aibj");
+    permute(-1.0, T, "abji", 1.0, Tq, "aibj");
+    permute(2.0, T, "bcij", 0.0, P1, "jbci");
+    permute(-1.0, T, "bcji", 1.0, P1, "jbci");
+    copy(Dvo, R);                                                                            // :431
+    contract(1.0, Tq, "aibj", Dov, "jb", 1.0, R, "ai");                                      // :432
+    contract(1.0, block(P_aibc), "ajbc", P1, "jbci", 1.0, R, "ai");                          // :433
+    TView S2 = make_view(arena.alloc(o * o), {o, o});
+    contract(1.0, block(P_ijab), "kjbc", P1, "jbci", 0.0, S2, "ki");
+    contract(-1.0, t, "ak", S2, "ki", 1.0, R, "ai");                                         // :434
+    contract(-1.0, Tq, "ajbk", block(P_ijka), "jkib", 1.0, R, "ai");                         // :435
+    TView S4 = make_view(arena.alloc(v * v), {v, v});
+    contract(1.0, Tq, "ajbk", block(P_ijab), "jkcb", 0.0, S4, "ac");
+    contract(-1.0, S4, "ac", t, "ci", 1.0, R, "ai");                                         // :436
+}
+
+// -----------------------------------------------------------------------------------
+// ccsd.py:176-179, ccd.py:123-124
+// -----------------------------------------------------------------------------------
+void Engine::cc_update(double* t, double* dt, const double* r, double shift, double delta, int rank) {
+    if (rank != 2 && rank != 4) throw Error("cc_update: rank must be 2 (T1) or 4 (T2)");
+    dev::cc_update(t, dt, r, eps_o, eps_v, shift, delta, no, nv, rank, stream);
+}
+
+// -----------------------------------------------------------------------------------
+// ccsd.py:458-466 and ccd.py:256-262
+// -----------------------------------------------------------------------------------
+void Engine::ccsd_energy(const double* f, const double* t1, const double* t2, double out[3]) {
+    const int64_t o = no, v = nv, nn = n, n4 = v * v * o * o;
+    ArenaScope scope(arena);
+    double* tau = arena.alloc(n4);
+    dev::tau_build(tau, t2, t1, no, nv, stream);                                              // :462
+    TView F = make_view(const_cast<double*>(f), {nn, nn});
+    TView g = make_view(arena.alloc(o * v), {v, o});
+    permute(1.0, slice(slice(F, 0, 0, o), 1, o, nn), "ia", 0.0, g, "ai");
+    const double* x[2] = {tau, tau};
+    const double* y[2] = {get_static("Edir"), get_static("Eex")};
+    double d[2], e1;
+    dev::dots(2, x, y, n4, d, stream);
+    const double* x1[1] = {g.p};
+    const double* y1[1] = {t1};
+    dev::dots(1, x1, y1, o * v, &e1, stream);
+    out[0] = 2.0 * e1;        // :465
+    out[1] = 2.0 * d[0];      // :463
+    out[2] = -1.0 * d[1];     // :464
+}
+
+void Engine::ccd_energy(const double* t2, double out[2]) {
+    const int64_t o = no, v = nv, n4 = v * v * o * o;
+    const double* x[2] = {t2, t2};
+    const double* y[2] = {get_static("Edir"), get_static("Eex")};
+    double d[2];
+    dev::dots(2, x, y, n4, d, stream);
+    out[0] = 2.0 * d[0];      // ccd.py:260
+    out[1] = -1.0 * d[1];     // ccd.py:261
+}
+
+}  // namespace pymes

@@ -1,0 +1,77 @@
+// Device abstraction used by the host engine (engine.cpp).
+//
+// Product build: implemented by kernels.hip (hand-written gfx950 kernels).
+// tests/hostsim/ implements the same functions with plain CPU loops so that the
+// HOST logic (contraction planner, CC term sequencing, C-ABI plumbing) can be
+// exercised under `pytest -m "not gpu"`, valgrind and ASan.  The host simulator is
+// never linked into libpymes_amd.so and the Python package cannot load it.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace dev {
+
+typedef void* stream_t;   // hipStream_t in the product build
+
+const char* backend_name();
+// throws std::runtime_error on failure
+void  set_device(int ordinal);
+void* dmalloc(size_t bytes);
+void  dfree(void* p);
+void  memcpy_h2d(void* d, const void* h, size_t bytes, stream_t s);
+void  memcpy_d2h(void* h, const void* d, size_t bytes, stream_t s);
+void  memcpy_d2d(void* d, const void* s_, size_t bytes, stream_t s);
+void  memset_zero(void* d, size_t bytes, stream_t s);
+void  stream_sync(stream_t s);
+size_t mem_free_bytes();
+
+// ---- timing of the dominant kernel (fp64 MFMA GEMM) with device events --------
+void   prof_enable(bool on);
+void   prof_reset();
+// number of GEMM launches recorded, summed milliseconds, summed executed flops
+void   prof_query(long* launches, double* ms, double* flops);
+
+// ---- fp64 GEMM  C = alpha * A * B + beta * C ---------------------------------
+// A(m,k) = A[z] + m*a_sm + k*a_sk   with exactly one of a_sm / a_sk equal to 1
+// B(k,n) = B[z] + k*b_sk + n*b_sn   with exactly one of b_sk / b_sn equal to 1
+// C(m,n) = C[z] + m*ldc + n
+// z = (z1, z2) two-level batch, per-operand strides may be 0.
+struct Gemm {
+    int64_t M, N, K;
+    double alpha, beta;
+    const double* A; int64_t a_sm, a_sk;
+    const double* B; int64_t b_sk, b_sn;
+    double* C; int64_t ldc;
+    int64_t nb1, nb2;                 // batch extents (>=1)
+    int64_t a_b1, a_b2, b_b1, b_b2, c_b1, c_b2;
+    double* splitk_ws;                // workspace for split-K partials (may be null)
+    int64_t splitk_ws_doubles;
+};
+void gemm(const Gemm& g, stream_t s);
+
+// ---- strided copy / permutation:  out = alpha * in + beta * out ----------------
+// rank <= 6, both tensors described by the same extents and their own strides.
+struct Permute {
+    int rank;
+    int64_t dim[6];
+    int64_t s_in[6], s_out[6];
+    double alpha, beta;
+    const double* in; double* out;
+};
+void permute(const Permute& p, stream_t s);
+
+// ---- element-wise / reduction helpers (HBM-bound) ------------------------------
+// t[a,b,i,j] = w[a,b,i,j] / (eo[i]+eo[j]-ev[a]-ev[b]+shift)          (mp2.py:16-18)
+void mp2_amplitudes(double* t, const double* w, const double* eo, const double* ev, double shift,
+                    int no, int nv, stream_t s);
+// dt = r * (1/(D+shift)) ; t += delta*dt   rank 4 (abij) or rank 2 (ai)   (ccsd.py:176-179)
+void cc_update(double* t, double* dt, const double* r, const double* eo, const double* ev, double shift,
+               double delta, int no, int nv, int rank, stream_t s);
+// out[p] = sum_i x_p[i]*y_p[i], p < npairs (<= 16); deterministic two-stage reduction; result on host
+void dots(int npairs, const double* const* x, const double* const* y, int64_t n, double* out_host,
+          stream_t s);
+// out = sum_k c[k] * x_k   (k < nx <= 8)
+void lincomb(double* out, int nx, const double* const* x, const double* c, int64_t n, stream_t s);
+// tau[a,b,i,j] = t2[a,b,i,j] + t1[a,i]*t1[b,j]                        (ccsd.py:462)
+void tau_build(double* tau, const double* t2, const double* t1, int no, int nv, stream_t s);
+}  // namespace dev

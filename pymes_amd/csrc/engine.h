@@ -1,0 +1,135 @@
+// Host engine of pymes_amd: device arena, strided tensor views, the einsum-style
+// binary contraction planner (TTGT: transpose only when needed, then the fp64 MFMA
+// GEMM), and the coupled-cluster term sequences built on top of it.
+//
+// The seam this replaces in the reference is the module-level `einsum` callable
+// (pymes/solver/ccsd.py:11, mp2.py:5; historically ctf.einsum, pymes/__init__.py:3)
+// plus the solver methods that call it.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "device_api.h"
+
+namespace pymes {
+
+struct TView {
+    double* p = nullptr;
+    int rank = 0;
+    int64_t dim[6] = {1, 1, 1, 1, 1, 1};
+    int64_t st[6] = {0, 0, 0, 0, 0, 0};
+    int64_t size() const {
+        int64_t n = 1;
+        for (int i = 0; i < rank; ++i) n *= dim[i];
+        return n;
+    }
+};
+
+TView make_view(double* p, std::initializer_list<int64_t> dims);
+TView make_view(const double* p, std::initializer_list<int64_t> dims);
+TView make_view(double* p, int rank, const int64_t* dims, const int64_t* strides /* may be null */);
+// slice [lo,hi) along one axis
+TView slice(const TView& t, int axis, int64_t lo, int64_t hi);
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// Bump allocator over one device slab; all work is stream-ordered on one stream, so a
+// region can be reused as soon as the kernels that touch it have been enqueued.
+class Arena {
+  public:
+    void init(size_t bytes);
+    void release();
+    double* alloc(int64_t doubles);
+    size_t mark() const { return top_; }
+    void reset(size_t m) { top_ = m; }
+    size_t capacity() const { return cap_; }
+    size_t high_water() const { return high_; }
+
+  private:
+    char* base_ = nullptr;
+    size_t cap_ = 0, top_ = 0, high_ = 0;
+};
+
+struct ArenaScope {
+    Arena& a;
+    size_t m;
+    explicit ArenaScope(Arena& ar) : a(ar), m(ar.mark()) {}
+    ~ArenaScope() { a.reset(m); }
+};
+
+struct ContractStats {
+    long gemm_calls = 0, permute_calls = 0;
+    double gemm_flops = 0.0;       // executed 2*M*N*K*batch
+    double permute_bytes = 0.0;    // bytes moved by explicit copies (read + write)
+};
+
+// block pattern id: bit (3-pos) set when the index at `pos` is virtual
+int pattern_of_name(const char* name);          // "abcd" -> 15, "klij" -> 0; throws on bad name
+std::string canonical_name(int pattern);         // the partition.py spelling for that pattern
+
+class Engine {
+  public:
+    Engine(int device, int no, int nv, size_t workspace_bytes);
+    ~Engine();
+
+    int no, nv, n;
+    dev::stream_t stream = nullptr;
+    Arena arena;
+    ContractStats stats;
+
+    // ---- generic tensor ops ---------------------------------------------------------
+    // C[sc] = alpha * sum A[sa] * B[sb] + beta * C[sc];  `batch` lists free labels that are
+    // looped as GEMM batches instead of being merged into M/N.
+    void contract(double alpha, const TView& A, const char* sa, const TView& B, const char* sb, double beta,
+                  const TView& C, const char* sc, const char* batch = "");
+    // out[so] = alpha * in[si] + beta * out[so]   (labels are a permutation of each other)
+    void permute(double alpha, const TView& in, const char* si, double beta, const TView& out, const char* so);
+    // out = alpha * in + beta * out, same index order (shapes must match)
+    void axpby(double alpha, const TView& in, double beta, const TView& out);
+    void copy(const TView& in, const TView& out) { axpby(1.0, in, 0.0, out); }
+    void zero(const TView& t);
+
+    // ---- integrals ------------------------------------------------------------------
+    void set_V_full(const double* V, bool on_device, const int64_t strides[4]);
+    void set_V_block(const char* name, const double* data, bool on_device, const int64_t strides[4]);
+    void set_V_from_factors(const double* B_host, int naux);
+    TView block(int pattern, bool dressed = false);       // throws if the block is absent
+    bool has_block(int pattern, bool dressed = false) const;
+    void set_orbital_energies(const double* eo_host, const double* ev_host);
+
+    // ---- CC path (cc.cpp) -----------------------------------------------------------
+    void mp2(double shift, double* t2, double e_out[2]);                                      // mp2.py:9-22
+    void dress_fock(const double* f, const double* t1, double* fd);                           // ccsd.py:226-288
+    void dress_V(const double* t1, uint32_t mask);                                            // ccsd.py:290-421
+    void singles_residual(const double* fd, const double* t1, const double* t2, double* r1);  // ccsd.py:423-438
+    // ccd.py:164-254; flags: bit0 = DCD/DCSD, bit1 = use dressed blocks, bit2 = skip ladder
+    void doubles_residual(const double* f, const double* t2, double* r2, unsigned flags);
+    // R[a0:a1,:,:,:] = beta*R + V_abcd[a0:a1] . T    (ccd.py:187; the sharded term)
+    void ladder(const double* t2, double* r2, int a0, int a1, bool dressed, double beta);
+    void cc_update(double* t, double* dt, const double* r, double shift, double delta, int rank);  // ccsd.py:176-179
+    void ccsd_energy(const double* f, const double* t1, const double* t2, double out[3]);     // ccsd.py:458-466
+    void ccd_energy(const double* t2, double out[2]);                                         // ccd.py:256-262
+    void invalidate_static();
+
+    double* eps_o = nullptr;
+    double* eps_v = nullptr;
+
+  private:
+    double* V_[16] = {nullptr};      // undressed blocks (owned)
+    double* Vd_[16] = {nullptr};     // dressed blocks (owned, allocated on demand)
+    std::map<std::string, double*> static_;   // cached permutations of static blocks (owned)
+    double* splitk_ws_ = nullptr;
+    int64_t splitk_doubles_ = 0;
+    double* get_static(const std::string& key);
+    void dressed_into(int pattern, const std::vector<int>& pos, int k, const TView& t1v, const TView& dst);
+    int64_t block_size(int pattern) const;
+    TView block_view(double* p, int pattern) const;
+    double* ensure_dressed(int pattern);
+};
+
+}  // namespace pymes

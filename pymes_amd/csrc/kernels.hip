@@ -1,0 +1,780 @@
+// Hand-written gfx950 (MI355X, CDNA4) kernels behind device_api.h.
+//
+//  * dgemm_kernel   fp64 GEMM on v_mfma_f64_16x16x4_f64, LDS-tiled (BK=16, double
+//                   buffered, register-staged 16-byte global loads), 256 threads =
+//                   4 waves (2x2), each wave FMxFN MFMA tiles; XCD-aware block
+//                   remap + grouped tile order; two-level batch; optional split-K.
+//                   Every O(N^5)/O(N^6) contraction of the CC path runs here
+//                   (ladder ccd.py:187, rings ccd.py:190-240, dressing ccsd.py:290-421).
+//  * permute kernels strided copy/transposition (32x32 LDS tile), out = a*in + b*out.
+//  * element-wise / reductions for the HBM-bound steps (mp2.py:16, ccsd.py:176-179,
+//    diis.py:65-103, ccsd.py:458-466).
+//
+// Wave = 64 lanes.  f64 MFMA operand maps (cdna guide §3): A lane l holds
+// A[i=l&15][k=l>>4], B lane l holds B[k=l>>4][j=l&15], D register r of lane l is
+// D[i=(l>>4)+4r][j=l&15].
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "device_api.h"
+
+#define HIP_CHECK(expr)                                                                   \
+    do {                                                                                  \
+        hipError_t err__ = (expr);                                                        \
+        if (err__ != hipSuccess)                                                          \
+            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(err__) + \
+                                     " at " __FILE__ ":" + std::to_string(__LINE__));     \
+    } while (0)
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int BK = 16;
+
+struct GemmK {
+    const double* A;
+    const double* B;
+    double* C;
+    long a_ld, b_ld, ldc;
+    int M, N, K;
+    double alpha, beta;
+    int tiles_m, tiles_n;
+    int nsplit, kchunk;
+    long nb2;
+    long a_b1, a_b2, b_b1, b_b2, c_b1, c_b2;
+    double* ws;   // split-K partials [z][ks][M][N]
+};
+
+// blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2): give each
+// XCD a contiguous range of logical ids so neighbouring tiles share an L2 (bijective).
+__device__ __forceinline__ long xcd_remap(long b, long nblk) {
+    const long q = nblk >> 3, r = nblk & 7;
+    const long xcd = b & 7, pos = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+}
+
+template <int BM, int BN, bool AKC, bool BKC, int VEC>
+__global__ void __launch_bounds__(kThreads, 2) dgemm_kernel(const GemmK g) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int WM = BM / 2, WN = BN / 2;      // wave tile (2x2 waves)
+    constexpr int FM = WM / 16, FN = WN / 16;    // MFMA tiles per wave
+    constexpr int A_PITCH = AKC ? (BK + 2) : (BM + 16);
+    constexpr int A_ROWS = AKC ? BM : BK;
+    constexpr int A_TILE = A_PITCH * A_ROWS;
+    constexpr int B_PITCH = BKC ? (BK + 2) : (BN + 16);
+    constexpr int B_ROWS = BKC ? BN : BK;
+    constexpr int B_TILE = B_PITCH * B_ROWS;
+    constexpr int LA = BM * BK / (kThreads * VEC);   // chunks per thread per tile
+    constexpr int LB = BN * BK / (kThreads * VEC);
+    constexpr int A_CH = (AKC ? BK : BM) / VEC;      // chunks per LDS row
+    constexpr int B_CH = (BKC ? BK : BN) / VEC;
+    constexpr int A_RSTEP = kThreads / A_CH;
+    constexpr int B_RSTEP = kThreads / B_CH;
+
+    double* As = smem;
+    double* Bs = smem + 2 * A_TILE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    // ---- block -> (batch z, k-split ks, tile tm/tn) -------------------------------
+    const long bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles = g.tiles_m * g.tiles_n;
+    const long per_batch = (long)tiles * g.nsplit;
+    const long z = bid / per_batch;
+    const int rem = (int)(bid - z * per_batch);
+    const int ks = rem / tiles;
+    const int t = rem - ks * tiles;
+    constexpr int GROUP = 8;
+    const int group_sz = GROUP * g.tiles_n;
+    const int grp = t / group_sz;
+    const int first_m = grp * GROUP;
+    const int gm = min(g.tiles_m - first_m, GROUP);
+    const int tin = t - grp * group_sz;
+    const int tm = first_m + tin % gm;
+    const int tn = tin / gm;
+    const long z1 = z / g.nb2, z2 = z - z1 * g.nb2;
+
+    const double* __restrict__ A = g.A + z1 * g.a_b1 + z2 * g.a_b2;
+    const double* __restrict__ B = g.B + z1 * g.b_b1 + z2 * g.b_b2;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = ks * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+
+    // ---- per-thread staging geometry (constant over the k loop) -------------------
+    const int a_r = tid / A_CH, a_c = (tid % A_CH) * VEC;
+    const int b_r = tid / B_CH, b_c = (tid % B_CH) * VEC;
+
+    double ra[LA * VEC], rb[LB * VEC];
+
+    auto load_tiles = [&](int kt) {
+        const int k0 = kbeg + kt * BK;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int r = a_r + i * A_RSTEP;
+            long off;
+            bool ok;
+            if (AKC) {   // LDS row = m, chunk along k
+                ok = (m0 + r < g.M) && (k0 + a_c < kend);
+                off = (long)(m0 + r) * g.a_ld + (k0 + a_c);
+            } else {     // LDS row = k, chunk along m
+                ok = (k0 + r < kend) && (m0 + a_c < g.M);
+                off = (long)(k0 + r) * g.a_ld + (m0 + a_c);
+            }
+            if constexpr (VEC == 2) {
+                v2d v = {0.0, 0.0};
+                if (ok) v = *reinterpret_cast<const v2d*>(A + off);
+                ra[2 * i] = v[0];
+                ra[2 * i + 1] = v[1];
+            } else {
+                ra[i] = ok ? A[off] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int r = b_r + i * B_RSTEP;
+            long off;
+            bool ok;
+            if (BKC) {   // LDS row = n, chunk along k
+                ok = (n0 + r < g.N) && (k0 + b_c < kend);
+                off = (long)(n0 + r) * g.b_ld + (k0 + b_c);
+            } else {     // LDS row = k, chunk along n
+                ok = (k0 + r < kend) && (n0 + b_c < g.N);
+                off = (long)(k0 + r) * g.b_ld + (n0 + b_c);
+            }
+            if constexpr (VEC == 2) {
+                v2d v = {0.0, 0.0};
+                if (ok) v = *reinterpret_cast<const v2d*>(B + off);
+                rb[2 * i] = v[0];
+                rb[2 * i + 1] = v[1];
+            } else {
+                rb[i] = ok ? B[off] : 0.0;
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        double* as = As + buf * A_TILE;
+        double* bs = Bs + buf * B_TILE;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int r = a_r + i * A_RSTEP;
+            if constexpr (VEC == 2) {
+                v2d v = {ra[2 * i], ra[2 * i + 1]};
+                *reinterpret_cast<v2d*>(as + r * A_PITCH + a_c) = v;
+            } else {
+                as[r * A_PITCH + a_c] = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int r = b_r + i * B_RSTEP;
+            if constexpr (VEC == 2) {
+                v2d v = {rb[2 * i], rb[2 * i + 1]};
+                *reinterpret_cast<v2d*>(bs + r * B_PITCH + b_c) = v;
+            } else {
+                bs[r * B_PITCH + b_c] = rb[i];
+            }
+        }
+    };
+
+    v4d acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+
+    // fragment read offsets inside a tile (k-step kk adds AKC ? 4*kk : 4*kk*PITCH)
+    const int a_frag = AKC ? ((wm * WM + l15) * A_PITCH + l4) : (l4 * A_PITCH + wm * WM + l15);
+    const int b_frag = BKC ? ((wn * WN + l15) * B_PITCH + l4) : (l4 * B_PITCH + wn * WN + l15);
+    constexpr int A_FSTEP = AKC ? 16 * A_PITCH : 16;     // next 16-row fragment
+    constexpr int B_FSTEP = BKC ? 16 * B_PITCH : 16;
+    constexpr int A_KSTEP = AKC ? 4 : 4 * A_PITCH;       // next k-step of 4
+    constexpr int B_KSTEP = BKC ? 4 : 4 * B_PITCH;
+
+    if (nkt > 0) {
+        load_tiles(0);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tiles(kt + 1);   // global loads in flight under the MFMAs
+        const double* as = As + cur * A_TILE + a_frag;
+        const double* bs = Bs + cur * B_TILE + b_frag;
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            double a[FM], b[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) a[i] = as[kk * A_KSTEP + i * A_FSTEP];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) b[j] = bs[kk * B_KSTEP + j * B_FSTEP];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue -------------------------------------------------------------------
+    const bool partial = g.nsplit > 1;
+    double* __restrict__ C;
+    long ldc;
+    double alpha = g.alpha, beta = g.beta;
+    if (partial) {
+        C = g.ws + (z * g.nsplit + ks) * (long)g.M * g.N;
+        ldc = g.N;
+        alpha = 1.0;
+        beta = 0.0;
+    } else {
+        C = g.C + z1 * g.c_b1 + z2 * g.c_b2;
+        ldc = g.ldc;
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * WN + j * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * WM + i * 16 + l4 + 4 * r;
+                if (m < g.M && n < g.N) {
+                    double* p = C + (long)m * ldc + n;
+                    double v = alpha * acc[i][j][r];
+                    if (beta != 0.0) v += beta * (*p);
+                    *p = v;
+                }
+            }
+        }
+    }
+}
+
+// C[z][m][n] = alpha * sum_ks ws[z][ks][m][n] + beta * C
+__global__ void splitk_reduce_kernel(const double* __restrict__ ws, double* __restrict__ C, long ldc, int M, int N,
+                                     int nsplit, long nb2, long c_b1, long c_b2, double alpha, double beta,
+                                     long total) {
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const long mn = (long)M * N;
+        const long z = idx / mn;
+        const long r = idx - z * mn;
+        const int m = (int)(r / N), n = (int)(r - (long)m * N);
+        double s = 0.0;
+        for (int k = 0; k < nsplit; ++k) s += ws[(z * nsplit + k) * mn + r];
+        const long z1 = z / nb2, z2 = z - z1 * nb2;
+        double* p = C + z1 * c_b1 + z2 * c_b2 + (long)m * ldc + n;
+        double v = alpha * s;
+        if (beta != 0.0) v += beta * (*p);
+        *p = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// permutation / strided copy
+// ------------------------------------------------------------------------------------
+struct PermK {
+    int rank;
+    long dim[6];
+    long s_in[6], s_out[6];
+    double alpha, beta;
+    const double* in;
+    double* out;
+};
+
+// generic: one element per thread, last (canonical) dim fastest
+__global__ void permute_direct_kernel(const PermK p, long total) {
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        long rem = idx, oi = 0, oo = 0;
+#pragma unroll
+        for (int d = 5; d >= 0; --d) {
+            if (d < p.rank) {
+                const long q = rem / p.dim[d];
+                const long c = rem - q * p.dim[d];
+                rem = q;
+                oi += c * p.s_in[d];
+                oo += c * p.s_out[d];
+            }
+        }
+        double v = p.alpha * p.in[oi];
+        if (p.beta != 0.0) v += p.beta * p.out[oo];
+        p.out[oo] = v;
+    }
+}
+
+// tiled transpose: canonical dims [rest..., Q, L] where in is unit-stride along Q
+// (dim index rank-2) and out is unit-stride along L (dim index rank-1).
+__global__ void __launch_bounds__(256) permute_tiled_kernel(const PermK p, int tiles_q, int tiles_l) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    long b = blockIdx.x;
+    const int tq = (int)(b % tiles_q);
+    b /= tiles_q;
+    const int tl = (int)(b % tiles_l);
+    b /= tiles_l;
+    long oi = 0, oo = 0;
+#pragma unroll
+    for (int d = 3; d >= 0; --d) {
+        if (d < p.rank - 2) {
+            const long q = b / p.dim[d];
+            const long c = b - q * p.dim[d];
+            b = q;
+            oi += c * p.s_in[d];
+            oo += c * p.s_out[d];
+        }
+    }
+    const int dq = p.rank - 2, dl = p.rank - 1;
+    const long q0 = (long)tq * 32, l0 = (long)tl * 32;
+    const long nq = p.dim[dq], nl = p.dim[dl];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long ql = q0 + tx, ll = l0 + ty + 8 * j;
+        if (ql < nq && ll < nl) tile[ty + 8 * j][tx] = p.in[oi + ql * p.s_in[dq] + ll * p.s_in[dl]];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long ll = l0 + tx, ql = q0 + ty + 8 * j;
+        if (ql < nq && ll < nl) {
+            double* o = p.out + oo + ql * p.s_out[dq] + ll * p.s_out[dl];
+            double v = p.alpha * tile[tx][ty + 8 * j];
+            if (p.beta != 0.0) v += p.beta * (*o);
+            *o = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// element-wise and reductions
+// ------------------------------------------------------------------------------------
+__global__ void mp2_amplitudes_kernel(double* __restrict__ t, const double* __restrict__ w,
+                                      const double* __restrict__ eo, const double* __restrict__ ev, double shift,
+                                      int no, int nv, long total) {
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        long r = idx;
+        const int j = (int)(r % no); r /= no;
+        const int i = (int)(r % no); r /= no;
+        const int b = (int)(r % nv);
+        const int a = (int)(r / nv);
+        t[idx] = w[idx] / ((eo[i] + eo[j] - ev[a] - ev[b]) + shift);
+    }
+}
+
+__global__ void cc_update_kernel(double* __restrict__ t, double* __restrict__ dt, const double* __restrict__ r_,
+                                 const double* __restrict__ eo, const double* __restrict__ ev, double shift,
+                                 double delta, int no, int nv, int rank, long total) {
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        double d;
+        if (rank == 4) {
+            long r = idx;
+            const int j = (int)(r % no); r /= no;
+            const int i = (int)(r % no); r /= no;
+            const int b = (int)(r % nv);
+            const int a = (int)(r / nv);
+            d = eo[i] + eo[j] - ev[a] - ev[b];
+        } else {
+            const int i = (int)(idx % no);
+            const int a = (int)(idx / no);
+            d = eo[i] - ev[a];
+        }
+        const double inv = 1.0 / (d + shift);
+        const double x = r_[idx] * inv;
+        dt[idx] = x;
+        t[idx] += delta * x;
+    }
+}
+
+constexpr int kDotBlocks = 1024;
+struct DotPtrs {
+    const double* x[16];
+    const double* y[16];
+};
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0)
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) r += sh[k];
+    __syncthreads();
+    return r;   // valid on thread 0
+}
+__global__ void __launch_bounds__(256) dots_stage1_kernel(const DotPtrs p, long n, double* __restrict__ partial) {
+    __shared__ double sh[4];
+    const int pair = blockIdx.y;
+    const double* __restrict__ x = p.x[pair];
+    const double* __restrict__ y = p.y[pair];
+    double s = 0.0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        s += x[i] * y[i];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) partial[pair * kDotBlocks + blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) dots_stage2_kernel(const double* __restrict__ partial, int nblocks,
+                                                          double* __restrict__ out) {
+    __shared__ double sh[4];
+    const int pair = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += partial[pair * kDotBlocks + i];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) out[pair] = s;
+}
+
+struct LinPtrs {
+    const double* x[8];
+    double c[8];
+};
+__global__ void lincomb_kernel(double* __restrict__ out, const LinPtrs p, int nx, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int k = 0; k < nx; ++k) s += p.x[k][i] * p.c[k];
+        out[i] = s;
+    }
+}
+
+__global__ void tau_kernel(double* __restrict__ tau, const double* __restrict__ t2, const double* __restrict__ t1,
+                           int no, int nv, long total) {
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        long r = idx;
+        const int j = (int)(r % no); r /= no;
+        const int i = (int)(r % no); r /= no;
+        const int b = (int)(r % nv);
+        const int a = (int)(r / nv);
+        tau[idx] = t2[idx] + t1[a * no + i] * t1[b * no + j];
+    }
+}
+
+inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
+    long g = (total + block - 1) / block;
+    return (int)std::max<long>(1, std::min<long>(g, cap));
+}
+
+// ---- profiling state ---------------------------------------------------------------
+struct Prof {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    double flops = 0.0;
+} g_prof;
+
+double* g_dot_ws = nullptr;     // [16*kDotBlocks + 16]
+double* g_dot_host = nullptr;   // pinned [16]
+
+template <int BM, int BN, bool AKC, bool BKC, int VEC>
+void launch_gemm(const GemmK& k, long nblocks, hipStream_t st) {
+    constexpr int A_T = (AKC ? (BK + 2) * BM : (BM + 16) * BK);
+    constexpr int B_T = (BKC ? (BK + 2) * BN : (BN + 16) * BK);
+    constexpr size_t lds = (size_t)2 * (A_T + B_T) * sizeof(double);
+    static bool attr_set = false;
+    auto fn = dgemm_kernel<BM, BN, AKC, BKC, VEC>;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)nblocks), dim3(kThreads), lds, st, k);
+    HIP_CHECK(hipGetLastError());
+}
+
+template <int BM, int BN>
+void dispatch_layout(const GemmK& k, bool akc, bool bkc, int vec, long nblocks, hipStream_t st) {
+    if (vec == 2) {
+        if (akc && bkc) launch_gemm<BM, BN, true, true, 2>(k, nblocks, st);
+        else if (akc) launch_gemm<BM, BN, true, false, 2>(k, nblocks, st);
+        else if (bkc) launch_gemm<BM, BN, false, true, 2>(k, nblocks, st);
+        else launch_gemm<BM, BN, false, false, 2>(k, nblocks, st);
+    } else {
+        if (akc && bkc) launch_gemm<BM, BN, true, true, 1>(k, nblocks, st);
+        else if (akc) launch_gemm<BM, BN, true, false, 1>(k, nblocks, st);
+        else if (bkc) launch_gemm<BM, BN, false, true, 1>(k, nblocks, st);
+        else launch_gemm<BM, BN, false, false, 1>(k, nblocks, st);
+    }
+}
+
+inline bool even(long x) { return (x & 1) == 0; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+namespace dev {
+
+const char* backend_name() { return "hip-gfx950"; }
+
+void set_device(int ordinal) { HIP_CHECK(hipSetDevice(ordinal)); }
+
+void* dmalloc(size_t bytes) {
+    void* p = nullptr;
+    HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
+    return p;
+}
+void dfree(void* p) {
+    if (p) HIP_CHECK(hipFree(p));
+}
+void memcpy_h2d(void* d, const void* h, size_t bytes, stream_t s) {
+    HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, (hipStream_t)s));
+    HIP_CHECK(hipStreamSynchronize((hipStream_t)s));
+}
+void memcpy_d2h(void* h, const void* d, size_t bytes, stream_t s) {
+    HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)s));
+    HIP_CHECK(hipStreamSynchronize((hipStream_t)s));
+}
+void memcpy_d2d(void* d, const void* s_, size_t bytes, stream_t s) {
+    HIP_CHECK(hipMemcpyAsync(d, s_, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+}
+void memset_zero(void* d, size_t bytes, stream_t s) { HIP_CHECK(hipMemsetAsync(d, 0, bytes, (hipStream_t)s)); }
+void stream_sync(stream_t s) { HIP_CHECK(hipStreamSynchronize((hipStream_t)s)); }
+size_t mem_free_bytes() {
+    size_t f = 0, t = 0;
+    HIP_CHECK(hipMemGetInfo(&f, &t));
+    return f;
+}
+
+void prof_enable(bool on) { g_prof.on = on; }
+void prof_reset() {
+    for (auto& e : g_prof.ev) g_prof.pool.push_back(e);
+    g_prof.ev.clear();
+    g_prof.flops = 0.0;
+}
+void prof_query(long* launches, double* ms, double* flops) {
+    double tot = 0.0;
+    for (auto& e : g_prof.ev) {
+        HIP_CHECK(hipEventSynchronize(e.second));
+        float t = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&t, e.first, e.second));
+        tot += t;
+    }
+    *launches = (long)g_prof.ev.size();
+    *ms = tot;
+    *flops = g_prof.flops;
+}
+
+void gemm(const Gemm& g, stream_t s) {
+    hipStream_t st = (hipStream_t)s;
+    if (g.M <= 0 || g.N <= 0 || g.nb1 <= 0 || g.nb2 <= 0) return;
+    if (g.M > 0x7fffffffL || g.N > 0x7fffffffL || g.K > 0x7fffffffL)
+        throw std::runtime_error("gemm: extent exceeds int32");
+    // an extent-1 dimension has no meaningful stride: normalise it to the unit-stride role
+    int64_t a_sm = g.a_sm, a_sk = g.a_sk, b_sk = g.b_sk, b_sn = g.b_sn;
+    if (a_sk != 1 && a_sm != 1) { if (g.K == 1) a_sk = 1; else if (g.M == 1) a_sm = 1; }
+    if (b_sk != 1 && b_sn != 1) { if (g.K == 1) b_sk = 1; else if (g.N == 1) b_sn = 1; }
+    if (!(a_sk == 1 || a_sm == 1)) throw std::runtime_error("gemm: A has no unit stride");
+    if (!(b_sk == 1 || b_sn == 1)) throw std::runtime_error("gemm: B has no unit stride");
+    const bool a_kcontig = (a_sk == 1);
+    const bool b_kcontig = (b_sk == 1);
+    GemmK k;
+    k.A = g.A; k.B = g.B; k.C = g.C;
+    k.a_ld = a_kcontig ? a_sm : a_sk;
+    k.b_ld = b_kcontig ? b_sn : b_sk;
+    k.ldc = g.ldc;
+    k.M = (int)g.M; k.N = (int)g.N; k.K = (int)g.K;
+    k.alpha = g.alpha; k.beta = g.beta;
+    k.nb2 = g.nb2;
+    k.a_b1 = g.a_b1; k.a_b2 = g.a_b2; k.b_b1 = g.b_b1; k.b_b2 = g.b_b2; k.c_b1 = g.c_b1; k.c_b2 = g.c_b2;
+    k.ws = nullptr;
+
+    // ---- tile shape: 128x128 unless a dimension is small -----------------------------
+    int BM = 128, BN = 128;
+    if (g.N <= 64) BN = 64;
+    if (g.M <= 64) BM = 64;
+    const long nbatch = g.nb1 * g.nb2;
+    auto ntiles = [&](int bm, int bn) { return ((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * nbatch; };
+    // under-filled chip (<1 block per CU at 128x128): use 64x64 tiles for 4x the blocks
+    if (BM == 128 && BN == 128 && ntiles(128, 128) < 256) { BM = 64; BN = 64; }
+    else if (BM == 128 && BN == 64 && ntiles(128, 64) < 256) { BM = 64; }
+    else if (BM == 64 && BN == 128 && ntiles(64, 128) < 256) { BN = 64; }
+    k.tiles_m = (int)((g.M + BM - 1) / BM);
+    k.tiles_n = (int)((g.N + BN - 1) / BN);
+    const long tiles = (long)k.tiles_m * k.tiles_n * nbatch;
+
+    // ---- split-K when the output has too few tiles to fill 256 CUs x 2 ----------------
+    int nsplit = 1;
+    const long ktiles = (g.K + BK - 1) / BK;
+    if (tiles < 256 && ktiles >= 16 && g.splitk_ws != nullptr) {
+        long want = (512 + tiles - 1) / tiles;
+        want = std::min<long>(want, ktiles / 8);          // >= 8 k-tiles (128 deep) per split
+        want = std::min<long>(want, 64);
+        const long fit = g.splitk_ws_doubles / std::max<long>(1, g.M * g.N * nbatch);
+        want = std::min<long>(want, fit);
+        if (want >= 2) nsplit = (int)want;
+    }
+    const long kt_per = (ktiles + nsplit - 1) / nsplit;
+    k.kchunk = (int)(kt_per * BK);
+    nsplit = (int)((ktiles + kt_per - 1) / kt_per);
+    if (nsplit < 1) nsplit = 1;
+    k.nsplit = nsplit;
+    if (nsplit > 1) k.ws = g.splitk_ws;
+
+    // ---- 16-byte global loads need even strides/extents and aligned bases --------------
+    int vec = 2;
+    {
+        const long a_contig_extent = a_kcontig ? g.K : g.M;
+        const long b_contig_extent = b_kcontig ? g.K : g.N;
+        if (!even(k.a_ld) || !even(k.b_ld) || !even(a_contig_extent) || !even(b_contig_extent) ||
+            !aligned16(g.A) || !aligned16(g.B) || !even(g.a_b1) || !even(g.a_b2) || !even(g.b_b1) ||
+            !even(g.b_b2))
+            vec = 1;
+    }
+    const long nblocks = tiles * nsplit;
+    if (nblocks > 0x7fffffffL) throw std::runtime_error("gemm: grid too large");
+
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (g_prof.on) {
+        if (!g_prof.pool.empty()) {
+            ev = g_prof.pool.back();
+            g_prof.pool.pop_back();
+        } else {
+            HIP_CHECK(hipEventCreate(&ev.first));
+            HIP_CHECK(hipEventCreate(&ev.second));
+        }
+        HIP_CHECK(hipEventRecord(ev.first, st));
+    }
+    if (BM == 128 && BN == 128) dispatch_layout<128, 128>(k, a_kcontig, b_kcontig, vec, nblocks, st);
+    else if (BM == 128 && BN == 64) dispatch_layout<128, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
+    else if (BM == 64 && BN == 128) dispatch_layout<64, 128>(k, a_kcontig, b_kcontig, vec, nblocks, st);
+    else dispatch_layout<64, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
+    if (nsplit > 1) {
+        const long total = g.M * g.N * nbatch;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, st, g.splitk_ws, g.C, g.ldc,
+                           (int)g.M, (int)g.N, nsplit, g.nb2, g.c_b1, g.c_b2, g.alpha, g.beta, total);
+        HIP_CHECK(hipGetLastError());
+    }
+    if (g_prof.on) {
+        HIP_CHECK(hipEventRecord(ev.second, st));
+        g_prof.ev.push_back(ev);
+        g_prof.flops += 2.0 * (double)g.M * (double)g.N * (double)g.K * (double)nbatch;
+    }
+}
+
+void permute(const Permute& p, stream_t s) {
+    hipStream_t st = (hipStream_t)s;
+    // canonicalise: drop extent-1 dims, sort by out-stride (descending), merge adjacent dims
+    struct D { long n, si, so; };
+    std::vector<D> d;
+    long total = 1;
+    for (int i = 0; i < p.rank; ++i) {
+        total *= p.dim[i];
+        if (p.dim[i] != 1) d.push_back({p.dim[i], p.s_in[i], p.s_out[i]});
+    }
+    if (total == 0) return;
+    std::stable_sort(d.begin(), d.end(), [](const D& a, const D& b) { return a.so > b.so; });
+    std::vector<D> m;
+    for (auto& x : d) {
+        if (!m.empty() && m.back().si == x.n * x.si && m.back().so == x.n * x.so) {
+            m.back().n *= x.n;
+            m.back().si = x.si;
+            m.back().so = x.so;
+        } else {
+            m.push_back(x);
+        }
+    }
+    if (m.empty()) m.push_back({1, 1, 1});
+    PermK k;
+    k.alpha = p.alpha; k.beta = p.beta; k.in = p.in; k.out = p.out;
+    // tiled path: out unit-stride on the last dim, in unit-stride on another dim
+    int q = -1;
+    const int r = (int)m.size();
+    if (r >= 2 && m[r - 1].so == 1 && m[r - 1].si != 1) {
+        for (int i = 0; i < r - 1; ++i)
+            if (m[i].si == 1) q = i;
+    }
+    if (q >= 0 && m[q].n >= 8 && m[r - 1].n >= 8) {
+        D dq = m[q];
+        m.erase(m.begin() + q);
+        m.insert(m.end() - 1, dq);          // [rest..., Q, L]
+        k.rank = r;
+        for (int i = 0; i < r; ++i) { k.dim[i] = m[i].n; k.s_in[i] = m[i].si; k.s_out[i] = m[i].so; }
+        for (int i = r; i < 6; ++i) { k.dim[i] = 1; k.s_in[i] = 0; k.s_out[i] = 0; }
+        const int tq = (int)((m[r - 2].n + 31) / 32), tl = (int)((m[r - 1].n + 31) / 32);
+        long rest = 1;
+        for (int i = 0; i < r - 2; ++i) rest *= m[i].n;
+        const long nblk = rest * tq * tl;
+        if (nblk > 0x7fffffffL) throw std::runtime_error("permute: grid too large");
+        hipLaunchKernelGGL(permute_tiled_kernel, dim3((unsigned)nblk), dim3(256), 0, st, k, tq, tl);
+    } else {
+        k.rank = r;
+        for (int i = 0; i < r; ++i) { k.dim[i] = m[i].n; k.s_in[i] = m[i].si; k.s_out[i] = m[i].so; }
+        for (int i = r; i < 6; ++i) { k.dim[i] = 1; k.s_in[i] = 0; k.s_out[i] = 0; }
+        hipLaunchKernelGGL(permute_direct_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, st, k, total);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+void mp2_amplitudes(double* t, const double* w, const double* eo, const double* ev, double shift, int no, int nv,
+                    stream_t s) {
+    const long total = (long)nv * nv * no * no;
+    if (!total) return;
+    hipLaunchKernelGGL(mp2_amplitudes_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, t, w, eo, ev,
+                       shift, no, nv, total);
+    HIP_CHECK(hipGetLastError());
+}
+
+void cc_update(double* t, double* dt, const double* r, const double* eo, const double* ev, double shift,
+               double delta, int no, int nv, int rank, stream_t s) {
+    const long total = rank == 4 ? (long)nv * nv * no * no : (long)nv * no;
+    if (!total) return;
+    hipLaunchKernelGGL(cc_update_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, t, dt, r, eo, ev,
+                       shift, delta, no, nv, rank, total);
+    HIP_CHECK(hipGetLastError());
+}
+
+void dots(int npairs, const double* const* x, const double* const* y, int64_t n, double* out_host, stream_t s) {
+    if (npairs <= 0) return;
+    if (npairs > 16) throw std::runtime_error("dots: at most 16 pairs per call");
+    hipStream_t st = (hipStream_t)s;
+    if (!g_dot_ws) {
+        g_dot_ws = (double*)dmalloc(sizeof(double) * (16 * kDotBlocks + 16));
+        HIP_CHECK(hipHostMalloc((void**)&g_dot_host, sizeof(double) * 16));
+    }
+    DotPtrs p;
+    for (int i = 0; i < npairs; ++i) { p.x[i] = x[i]; p.y[i] = y[i]; }
+    for (int i = npairs; i < 16; ++i) { p.x[i] = nullptr; p.y[i] = nullptr; }
+    const int nb = (int)std::max<long>(1, std::min<long>(kDotBlocks, (n + 255) / 256));
+    hipLaunchKernelGGL(dots_stage1_kernel, dim3(nb, npairs), dim3(256), 0, st, p, (long)n, g_dot_ws);
+    HIP_CHECK(hipGetLastError());
+    double* out_dev = g_dot_ws + 16 * kDotBlocks;
+    hipLaunchKernelGGL(dots_stage2_kernel, dim3(npairs), dim3(256), 0, st, g_dot_ws, nb, out_dev);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(g_dot_host, out_dev, sizeof(double) * npairs, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    for (int i = 0; i < npairs; ++i) out_host[i] = g_dot_host[i];
+}
+
+void lincomb(double* out, int nx, const double* const* x, const double* c, int64_t n, stream_t s) {
+    if (nx < 0 || nx > 8) throw std::runtime_error("lincomb: at most 8 terms");
+    if (n <= 0) return;
+    LinPtrs p;
+    for (int i = 0; i < 8; ++i) { p.x[i] = i < nx ? x[i] : nullptr; p.c[i] = i < nx ? c[i] : 0.0; }
+    hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, out, p, nx, (long)n);
+    HIP_CHECK(hipGetLastError());
+}
+
+void tau_build(double* tau, const double* t2, const double* t1, int no, int nv, stream_t s) {
+    const long total = (long)nv * nv * no * no;
+    if (!total) return;
+    hipLaunchKernelGGL(tau_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, tau, t2, t1, no, nv, total);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace dev

@@ -1,0 +1,301 @@
+"""Device context and device-resident fp64 arrays on top of the C-ABI (include/pymes_amd.h).
+
+``Context`` owns one ``pymes_ctx`` (one GPU, one HIP stream) for a fixed (no, nv).
+``DeviceArray`` is a thin handle (pointer + shape); numpy arrays enter and leave the
+device only through ``Context.array`` / ``DeviceArray.get``.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import PymesError, i64_array, ptr_array
+
+# partition.py block name <-> pattern id (bit 3-pos set when index `pos` is virtual)
+BLOCK_NAMES = ("abci", "iabj", "iajk", "aijk", "klij", "aibj", "ijak", "abic",
+               "iajb", "abcd", "iabc", "aijb", "ijka", "aibc", "ijab", "abij")
+
+
+def pattern_of(name):
+    return sum((1 << (3 - p)) for p, ch in enumerate(name) if ch in "abcd")
+
+
+class DeviceArray:
+    """fp64 C-contiguous array in HBM."""
+
+    def __init__(self, ctx, ptr, shape, owned=True, keepalive=None):
+        self.ctx, self.ptr, self.shape = ctx, int(ptr), tuple(int(s) for s in shape)
+        self._owned, self._keep = owned, keepalive
+        self.size = int(np.prod(self.shape)) if self.shape else 1
+
+    @property
+    def nbytes(self):
+        return 8 * self.size
+
+    def get(self):
+        out = np.empty(self.shape, dtype=np.float64)
+        self.ctx.lib.call("pymes_download", self.ctx.handle, _lib.host_ptr(out), C.c_void_p(self.ptr), self.nbytes)
+        return out
+
+    def set(self, host):
+        host = np.ascontiguousarray(host, dtype=np.float64)
+        if host.shape != self.shape:
+            raise ValueError(f"shape mismatch: {host.shape} vs {self.shape}")
+        self.ctx.lib.call("pymes_upload", self.ctx.handle, C.c_void_p(self.ptr), _lib.host_ptr(host), self.nbytes)
+        return self
+
+    def copy_from(self, other):
+        if other.size != self.size:
+            raise ValueError("size mismatch")
+        self.ctx.lib.call("pymes_copy", self.ctx.handle, C.c_void_p(self.ptr), C.c_void_p(other.ptr), self.nbytes)
+        return self
+
+    def zero_(self):
+        self.ctx.lib.call("pymes_memset_zero", self.ctx.handle, C.c_void_p(self.ptr), self.nbytes)
+        return self
+
+    def reshape(self, *shape):
+        shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
+        if int(np.prod(shape)) != self.size:
+            raise ValueError("cannot reshape")
+        return DeviceArray(self.ctx, self.ptr, shape, owned=False, keepalive=self)
+
+    def free(self):
+        if self._owned and self.ptr and self.ctx.handle:
+            self.ctx.lib.call("pymes_free", self.ctx.handle, C.c_void_p(self.ptr))
+        self.ptr, self._owned = 0, False
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    def __init__(self, no, nv, device=0, workspace_bytes=0, lib=None, stream=None, allocator=None):
+        self.lib = lib or _lib.default_library()
+        self.no, self.nv, self.n = int(no), int(nv), int(no) + int(nv)
+        self.device = int(device)
+        h = C.c_void_p()
+        self.handle = None
+        self.lib.call("pymes_ctx_create", C.byref(h), self.device, self.no, self.nv, int(workspace_bytes))
+        self.handle = h
+        self._allocator = allocator      # optional callable(n_doubles) -> (ptr, keepalive), e.g. torch-backed
+        if stream is not None:
+            self.set_stream(stream)
+
+    # ---- lifetime -----------------------------------------------------------------
+    def close(self):
+        if self.handle:
+            self.lib.call("pymes_ctx_destroy", self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        self.lib.call("pymes_ctx_set_stream", self.handle, C.c_void_p(int(hip_stream)))
+
+    def sync(self):
+        self.lib.call("pymes_ctx_sync", self.handle)
+
+    def workspace(self):
+        cap, high = C.c_uint64(), C.c_uint64()
+        self.lib.call("pymes_ctx_workspace", self.handle, C.byref(cap), C.byref(high))
+        return cap.value, high.value
+
+    # ---- arrays -------------------------------------------------------------------
+    def empty(self, shape):
+        shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        n = int(np.prod(shape)) if shape else 1
+        if self._allocator is not None:
+            ptr, keep = self._allocator(n)
+            return DeviceArray(self, ptr, shape, owned=False, keepalive=keep)
+        p = C.c_void_p()
+        self.lib.call("pymes_malloc", self.handle, 8 * max(n, 1), C.byref(p))
+        return DeviceArray(self, p.value, shape)
+
+    def zeros(self, shape):
+        return self.empty(shape).zero_()
+
+    def array(self, host):
+        host = np.ascontiguousarray(host, dtype=np.float64)
+        return self.empty(host.shape).set(host)
+
+    # ---- tensor engine ------------------------------------------------------------
+    def contract(self, spec, A, B, out=None, alpha=1.0, beta=0.0, batch=""):
+        """Binary einsum on the device, e.g. ``contract("abcd,cdij->abij", V, T)``."""
+        ins, lc = spec.replace(" ", "").split("->")
+        la, lb = ins.split(",")
+        dims = {}
+        for lab, arr in ((la, A), (lb, B)):
+            if len(lab) != len(arr.shape):
+                raise ValueError(f"labels '{lab}' do not match rank {len(arr.shape)}")
+            for ch, d in zip(lab, arr.shape):
+                if dims.setdefault(ch, d) != d:
+                    raise ValueError(f"extent mismatch for label '{ch}'")
+        shape_c = tuple(dims[ch] for ch in lc)
+        if out is None:
+            out = self.empty(shape_c)
+            beta = 0.0
+        elif out.shape != shape_c:
+            raise ValueError("output shape mismatch")
+        self.lib.call("pymes_contract", self.handle, float(alpha),
+                      C.c_void_p(A.ptr), la.encode(), i64_array(A.shape), None,
+                      C.c_void_p(B.ptr), lb.encode(), i64_array(B.shape), None,
+                      float(beta), C.c_void_p(out.ptr), lc.encode(), i64_array(out.shape), None, batch.encode())
+        return out
+
+    def permute(self, spec, A, out=None, alpha=1.0, beta=0.0):
+        """``permute("abij->aibj", T)``: out[lo] = alpha*A[li] + beta*out[lo]."""
+        li, lo = spec.replace(" ", "").split("->")
+        shape_o = tuple(A.shape[li.index(ch)] for ch in lo)
+        if out is None:
+            out = self.empty(shape_o)
+            beta = 0.0
+        self.lib.call("pymes_permute", self.handle, float(alpha), C.c_void_p(A.ptr), li.encode(), i64_array(A.shape),
+                      None, float(beta), C.c_void_p(out.ptr), lo.encode(), None)
+        return out
+
+    def dgemm(self, M, N, K, alpha, A, a_sm, a_sk, B, b_sk, b_sn, beta, Cmat, ldc):
+        self.lib.call("pymes_dgemm", self.handle, M, N, K, float(alpha), C.c_void_p(A.ptr), a_sm, a_sk,
+                      C.c_void_p(B.ptr), b_sk, b_sn, float(beta), C.c_void_p(Cmat.ptr), ldc)
+
+    # ---- integrals ----------------------------------------------------------------
+    def set_V_pqrs(self, V):
+        """partition.py:4-39 — V is a host numpy [n,n,n,n] or a DeviceArray of that shape."""
+        if isinstance(V, DeviceArray):
+            self.lib.call("pymes_set_V_pqrs", self.handle, C.c_void_p(V.ptr), 1, None)
+        else:
+            V = np.ascontiguousarray(V, dtype=np.float64)
+            if V.shape != (self.n,) * 4:
+                raise ValueError(f"V_pqrs must have shape {(self.n,) * 4}")
+            self.lib.call("pymes_set_V_pqrs", self.handle, _lib.host_ptr(V), 0, None)
+
+    def set_V_block(self, name, data):
+        if isinstance(data, DeviceArray):
+            self.lib.call("pymes_set_V_block", self.handle, name.encode(), C.c_void_p(data.ptr), 1, None)
+        else:
+            data = np.ascontiguousarray(data, dtype=np.float64)
+            self.lib.call("pymes_set_V_block", self.handle, name.encode(), _lib.host_ptr(data), 0, None)
+
+    def set_V_from_factors(self, B):
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        if B.ndim != 3 or B.shape[1:] != (self.n, self.n):
+            raise ValueError("B must be [naux, n, n]")
+        self.lib.call("pymes_set_V_from_factors", self.handle, _lib.host_ptr(B), int(B.shape[0]))
+
+    def block_shape(self, name):
+        return tuple(self.nv if ch in "abcd" else self.no for ch in name)
+
+    def V_block(self, name, dressed=False):
+        p, nel = C.c_void_p(), C.c_int64()
+        self.lib.call("pymes_V_block_ptr", self.handle, name.encode(), int(dressed), C.byref(p), C.byref(nel))
+        return DeviceArray(self, p.value, self.block_shape(name), owned=False, keepalive=self)
+
+    def set_orbital_energies(self, eps_o, eps_v):
+        eo = np.ascontiguousarray(eps_o, dtype=np.float64)
+        ev = np.ascontiguousarray(eps_v, dtype=np.float64)
+        assert eo.shape == (self.no,) and ev.shape == (self.nv,)
+        self.lib.call("pymes_set_orbital_energies", self.handle, _lib.host_ptr(eo), _lib.host_ptr(ev))
+
+    # ---- CC hot path ----------------------------------------------------------------
+    def mp2(self, t2, level_shift=0.0):
+        e = (C.c_double * 2)()
+        self.lib.call("pymes_mp2", self.handle, float(level_shift), C.c_void_p(t2.ptr), e)
+        return e[0], e[1]
+
+    def dress_fock(self, f, t1, out):
+        self.lib.call("pymes_ccsd_dress_fock", self.handle, C.c_void_p(f.ptr), C.c_void_p(t1.ptr), C.c_void_p(out.ptr))
+        return out
+
+    def dress_V(self, t1, names):
+        mask = 0
+        for nm in names:
+            mask |= 1 << pattern_of(nm)
+        self.lib.call("pymes_ccsd_dress_V", self.handle, C.c_void_p(t1.ptr), mask)
+
+    def singles_residual(self, fd, t1, t2, out):
+        self.lib.call("pymes_ccsd_singles_residual", self.handle, C.c_void_p(fd.ptr), C.c_void_p(t1.ptr),
+                      C.c_void_p(t2.ptr), C.c_void_p(out.ptr))
+        return out
+
+    def doubles_residual(self, f, t2, out, is_dcd=False, dressed=False, skip_ladder=False):
+        flags = (_lib.PYMES_DCD if is_dcd else 0) | (_lib.PYMES_USE_DRESSED if dressed else 0) | \
+                (_lib.PYMES_SKIP_LADDER if skip_ladder else 0)
+        self.lib.call("pymes_doubles_residual", self.handle, C.c_void_p(f.ptr), C.c_void_p(t2.ptr),
+                      C.c_void_p(out.ptr), flags)
+        return out
+
+    def ladder(self, t2, out, a_begin, a_end, dressed=False, beta=0.0):
+        self.lib.call("pymes_ladder", self.handle, C.c_void_p(t2.ptr), C.c_void_p(out.ptr), int(a_begin), int(a_end),
+                      int(dressed), float(beta))
+        return out
+
+    def cc_update(self, t, dt, r, level_shift=0.0, delta=1.0):
+        rank = len(t.shape)
+        self.lib.call("pymes_cc_update", self.handle, C.c_void_p(t.ptr), C.c_void_p(dt.ptr), C.c_void_p(r.ptr),
+                      float(level_shift), float(delta), rank)
+
+    def ccsd_energy(self, f, t1, t2):
+        e = (C.c_double * 3)()
+        self.lib.call("pymes_ccsd_energy", self.handle, C.c_void_p(f.ptr), C.c_void_p(t1.ptr), C.c_void_p(t2.ptr), e)
+        return e[0], e[1], e[2]
+
+    def ccd_energy(self, t2):
+        e = (C.c_double * 2)()
+        self.lib.call("pymes_ccd_energy", self.handle, C.c_void_p(t2.ptr), e)
+        return e[0], e[1]
+
+    # ---- vector helpers ---------------------------------------------------------------
+    def dots(self, xs, ys):
+        n = xs[0].size
+        assert all(x.size == n for x in xs) and all(y.size == n for y in ys) and len(xs) == len(ys)
+        out = np.empty(len(xs))
+        for lo in range(0, len(xs), 16):
+            hi = min(len(xs), lo + 16)
+            buf = (C.c_double * (hi - lo))()
+            self.lib.call("pymes_dots", self.handle, hi - lo, ptr_array([x.ptr for x in xs[lo:hi]]),
+                          ptr_array([y.ptr for y in ys[lo:hi]]), n, buf)
+            out[lo:hi] = buf[:]
+        return out
+
+    def norm(self, x):
+        return float(np.sqrt(self.dots([x], [x])[0]))
+
+    def lincomb(self, out, xs, coeffs):
+        assert len(xs) == len(coeffs) and all(x.size == out.size for x in xs)
+        first = True
+        for lo in range(0, len(xs), 7):
+            chunk, cc = list(xs[lo:lo + 7]), [float(c) for c in coeffs[lo:lo + 7]]
+            if not first:
+                chunk, cc = [out] + chunk, [1.0] + cc
+            cbuf = (C.c_double * len(cc))(*cc)
+            self.lib.call("pymes_lincomb", self.handle, C.c_void_p(out.ptr), len(chunk),
+                          ptr_array([x.ptr for x in chunk]), cbuf, out.size)
+            first = False
+        return out
+
+    # ---- measurement --------------------------------------------------------------------
+    def stats(self, reset=False):
+        gc, pc, gf, pb = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
+        self.lib.call("pymes_stats", self.handle, int(reset), C.byref(gc), C.byref(gf), C.byref(pc), C.byref(pb))
+        return {"gemm_calls": gc.value, "gemm_flops": gf.value, "permute_calls": pc.value, "permute_bytes": pb.value}
+
+    def prof_enable(self, on=True):
+        self.lib.call("pymes_prof_enable", self.handle, int(on))
+
+    def prof_reset(self):
+        self.lib.call("pymes_prof_reset", self.handle)
+
+    def prof_query(self):
+        n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+        self.lib.call("pymes_prof_query", self.handle, C.byref(n), C.byref(ms), C.byref(fl))
+        return {"launches": n.value, "ms": ms.value, "flops": fl.value}
+
+
+__all__ = ["Context", "DeviceArray", "PymesError", "BLOCK_NAMES", "pattern_of"]

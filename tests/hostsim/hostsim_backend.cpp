@@ -1,0 +1,139 @@
+// HOST SIMULATOR of pymes_amd/csrc/device_api.h — TEST INFRASTRUCTURE ONLY.
+//
+// Plain CPU loops standing in for the HIP kernels so that the HOST logic of the
+// engine (contraction planner, CC term sequencing, arena, C-ABI) can be checked
+// against the oracle under `pytest -m "not gpu"` (and under ASan/valgrind), where no
+// GPU exists.  It is built into tests/hostsim/_build/libpymes_hostsim.so by
+// tests/hostsim/Makefile, is never linked into pymes_amd/lib/libpymes_amd.so, and the
+// package loader (pymes_amd/_lib.py) rejects any library whose pymes_backend() is not
+// "hip-gfx950".  It says nothing about the kernels themselves: those are tested on the
+// GPU (tests/test_gpu_*.py).
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#include "../../pymes_amd/csrc/device_api.h"
+
+namespace dev {
+
+const char* backend_name() { return "hostsim"; }
+void set_device(int) {}
+void* dmalloc(size_t bytes) {
+    void* p = std::malloc(bytes ? bytes : 16);
+    if (!p) throw std::runtime_error("hostsim: out of memory");
+    std::memset(p, 0xA5, bytes ? bytes : 16);   // poison: uninitialised reads show up as garbage
+    return p;
+}
+void dfree(void* p) { std::free(p); }
+void memcpy_h2d(void* d, const void* h, size_t n, stream_t) { std::memcpy(d, h, n); }
+void memcpy_d2h(void* h, const void* d, size_t n, stream_t) { std::memcpy(h, d, n); }
+void memcpy_d2d(void* d, const void* s, size_t n, stream_t) { std::memmove(d, s, n); }
+void memset_zero(void* d, size_t n, stream_t) { std::memset(d, 0, n); }
+void stream_sync(stream_t) {}
+size_t mem_free_bytes() { return size_t(1) << 34; }
+
+static long g_launches = 0;
+static double g_flops = 0;
+static bool g_prof = false;
+void prof_enable(bool on) { g_prof = on; }
+void prof_reset() { g_launches = 0; g_flops = 0; }
+void prof_query(long* l, double* ms, double* f) { *l = g_launches; *ms = 0.0; *f = g_flops; }
+
+void gemm(const Gemm& g, stream_t) {
+    if (!((g.a_sm == 1 || g.a_sk == 1 || g.M == 1 || g.K == 1) && (g.b_sk == 1 || g.b_sn == 1 || g.N == 1 || g.K == 1)))
+        throw std::runtime_error("hostsim gemm: operand without unit stride");
+    for (int64_t z1 = 0; z1 < g.nb1; ++z1)
+        for (int64_t z2 = 0; z2 < g.nb2; ++z2) {
+            const double* A = g.A + z1 * g.a_b1 + z2 * g.a_b2;
+            const double* B = g.B + z1 * g.b_b1 + z2 * g.b_b2;
+            double* C = g.C + z1 * g.c_b1 + z2 * g.c_b2;
+            for (int64_t m = 0; m < g.M; ++m)
+                for (int64_t n = 0; n < g.N; ++n) {
+                    double s = 0.0;
+                    for (int64_t k = 0; k < g.K; ++k) s += A[m * g.a_sm + k * g.a_sk] * B[k * g.b_sk + n * g.b_sn];
+                    double* c = C + m * g.ldc + n;
+                    *c = g.beta != 0.0 ? g.alpha * s + g.beta * (*c) : g.alpha * s;
+                }
+        }
+    if (g_prof) { g_launches++; g_flops += 2.0 * g.M * g.N * g.K * g.nb1 * g.nb2; }
+}
+
+void permute(const Permute& p, stream_t) {
+    int64_t total = 1;
+    for (int i = 0; i < p.rank; ++i) total *= p.dim[i];
+    // out may alias in only for identical index maps (axpby on itself); buffer otherwise-unsafe cases
+    std::vector<double> tmp;
+    const double* in = p.in;
+    for (int64_t idx = 0; idx < total; ++idx) {
+        int64_t rem = idx, oi = 0, oo = 0;
+        for (int d = p.rank - 1; d >= 0; --d) {
+            const int64_t c = rem % p.dim[d];
+            rem /= p.dim[d];
+            oi += c * p.s_in[d];
+            oo += c * p.s_out[d];
+        }
+        double v = p.alpha * in[oi];
+        if (p.beta != 0.0) v += p.beta * p.out[oo];
+        p.out[oo] = v;
+    }
+}
+
+void mp2_amplitudes(double* t, const double* w, const double* eo, const double* ev, double shift, int no, int nv,
+                    stream_t) {
+    int64_t idx = 0;
+    for (int a = 0; a < nv; ++a)
+        for (int b = 0; b < nv; ++b)
+            for (int i = 0; i < no; ++i)
+                for (int j = 0; j < no; ++j, ++idx) t[idx] = w[idx] / ((eo[i] + eo[j] - ev[a] - ev[b]) + shift);
+}
+
+void cc_update(double* t, double* dt, const double* r, const double* eo, const double* ev, double shift, double delta,
+               int no, int nv, int rank, stream_t) {
+    int64_t idx = 0;
+    if (rank == 4) {
+        for (int a = 0; a < nv; ++a)
+            for (int b = 0; b < nv; ++b)
+                for (int i = 0; i < no; ++i)
+                    for (int j = 0; j < no; ++j, ++idx) {
+                        const double inv = 1.0 / ((eo[i] + eo[j] - ev[a] - ev[b]) + shift);
+                        dt[idx] = r[idx] * inv;
+                        t[idx] += delta * dt[idx];
+                    }
+    } else {
+        for (int a = 0; a < nv; ++a)
+            for (int i = 0; i < no; ++i, ++idx) {
+                const double inv = 1.0 / ((eo[i] - ev[a]) + shift);
+                dt[idx] = r[idx] * inv;
+                t[idx] += delta * dt[idx];
+            }
+    }
+}
+
+void dots(int npairs, const double* const* x, const double* const* y, int64_t n, double* out, stream_t) {
+    if (npairs > 16) throw std::runtime_error("dots: at most 16 pairs per call");
+    for (int p = 0; p < npairs; ++p) {
+        double s = 0.0;
+        for (int64_t i = 0; i < n; ++i) s += x[p][i] * y[p][i];
+        out[p] = s;
+    }
+}
+
+void lincomb(double* out, int nx, const double* const* x, const double* c, int64_t n, stream_t) {
+    if (nx < 0 || nx > 8) throw std::runtime_error("lincomb: at most 8 terms");
+    for (int64_t i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (int k = 0; k < nx; ++k) s += x[k][i] * c[k];
+        out[i] = s;
+    }
+}
+
+void tau_build(double* tau, const double* t2, const double* t1, int no, int nv, stream_t) {
+    int64_t idx = 0;
+    for (int a = 0; a < nv; ++a)
+        for (int b = 0; b < nv; ++b)
+            for (int i = 0; i < no; ++i)
+                for (int j = 0; j < no; ++j, ++idx) tau[idx] = t2[idx] + t1[a * no + i] * t1[b * no + j];
+}
+
+}  // namespace dev
