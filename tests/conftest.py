@@ -1,0 +1,29 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def hostsim_lib():
+    """Host engine linked against the CPU stand-in for the kernels (tests/hostsim): checks HOST logic only."""
+    from pymes_amd import _lib
+    d = os.path.join(ROOT, "tests", "hostsim")
+    subprocess.run(["make", "-s", "-C", d], check=True)
+    return _lib.Library(os.path.join(d, "_build", "libpymes_hostsim.so"), _testing_backend="hostsim")
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    """The product library (HIP, gfx950).  No fallback: a missing library is an error."""
+    from pymes_amd import _lib
+    return _lib.default_library()

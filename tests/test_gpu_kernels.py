@@ -1,0 +1,119 @@
+"""Kernel-level parity on the GPU: fp64 MFMA GEMM, permutation, element-wise and
+reduction kernels against numpy, through the C-ABI."""
+import numpy as np
+import pytest
+
+from pymes_amd.device import Context
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(gpu_lib):
+    c = Context(4, 12, lib=gpu_lib, workspace_bytes=1 << 30)
+    yield c
+    c.close()
+
+
+def _gemm_case(ctx, M, N, K, a_kc, b_kc, alpha, beta, rng, lda_pad=0, ldb_pad=0, ldc_pad=0):
+    a_rows, a_cols = (M, K) if a_kc else (K, M)
+    b_rows, b_cols = (N, K) if b_kc else (K, N)
+    A = rng.standard_normal((a_rows, a_cols + lda_pad))
+    B = rng.standard_normal((b_rows, b_cols + ldb_pad))
+    Cm = rng.standard_normal((M, N + ldc_pad))
+    Am = A[:, :a_cols] if a_kc else A[:, :a_cols].T          # logical [M,K]
+    Bm = B[:, :b_cols].T if b_kc else B[:, :b_cols]          # logical [K,N]
+    ref = Cm.copy()
+    ref[:, :N] = alpha * (Am @ Bm) + beta * Cm[:, :N]
+    dA, dB, dC = ctx.array(A), ctx.array(B), ctx.array(Cm)
+    a_sm, a_sk = (A.shape[1], 1) if a_kc else (1, A.shape[1])
+    b_sk, b_sn = (1, B.shape[1]) if b_kc else (B.shape[1], 1)
+    ctx.dgemm(M, N, K, alpha, dA, a_sm, a_sk, dB, b_sk, b_sn, beta, dC, Cm.shape[1])
+    got = dC.get()
+    scale = max(1.0, np.abs(ref).max())
+    err = np.abs(got - ref).max() / scale
+    assert err < 1e-13 * max(1, K) ** 0.5 + 1e-14, (M, N, K, a_kc, b_kc, alpha, beta, err)
+
+
+@pytest.mark.parametrize("a_kc", [True, False])
+@pytest.mark.parametrize("b_kc", [True, False])
+def test_dgemm_layouts_and_edges(ctx, a_kc, b_kc):
+    rng = np.random.default_rng(1)
+    shapes = [(128, 128, 64), (256, 384, 160), (130, 70, 50), (1, 1, 1), (3, 5, 7), (64, 64, 16), (200, 200, 33),
+              (17, 300, 129), (300, 17, 2), (129, 129, 129), (50, 2500, 50), (512, 64, 1000), (1, 200, 300),
+              (200, 1, 300), (96, 40, 4096)]
+    for (M, N, K) in shapes:
+        _gemm_case(ctx, M, N, K, a_kc, b_kc, 1.0, 0.0, rng)
+    _gemm_case(ctx, 150, 90, 77, a_kc, b_kc, -0.5, 1.0, rng)
+    _gemm_case(ctx, 150, 90, 78, a_kc, b_kc, 2.0, 0.25, rng, lda_pad=2, ldb_pad=4, ldc_pad=6)
+    _gemm_case(ctx, 151, 91, 78, a_kc, b_kc, 2.0, 0.25, rng, lda_pad=1, ldb_pad=3, ldc_pad=5)
+
+
+def test_dgemm_identity_asymmetric(ctx):
+    """A = I with an asymmetric B catches a transposed C fragment map (cdna guide §3)."""
+    n = 64
+    B = np.arange(n * n, dtype=np.float64).reshape(n, n)
+    dA, dB, dC = ctx.array(np.eye(n)), ctx.array(B), ctx.zeros((n, n))
+    ctx.dgemm(n, n, n, 1.0, dA, n, 1, dB, n, 1, 0.0, dC, n)
+    assert np.array_equal(dC.get(), B)
+
+
+def test_contract_splitk_and_batch(ctx):
+    rng = np.random.default_rng(2)
+    # small output, long K -> split-K path
+    A = rng.standard_normal((40, 30000)); B = rng.standard_normal((30000, 24))
+    got = ctx.contract("mk,kn->mn", ctx.array(A), ctx.array(B)).get()
+    assert np.abs(got - A @ B).max() < 1e-10
+    # batched small GEMMs with a stride-0 operand
+    X = rng.standard_normal((7, 9)); T = rng.standard_normal((11, 7, 13, 5))
+    E = rng.standard_normal((11, 9, 13, 5))
+    dE = ctx.array(E)
+    ctx.contract("ki,akbj->aibj", ctx.array(X), ctx.array(T), out=dE, alpha=-1.0, beta=1.0, batch="a")
+    assert np.abs(dE.get() - (E - np.einsum("ki,akbj->aibj", X, T))).max() < 1e-12
+    # operands that need transposition (TTGT path) and a transposed output
+    V = rng.standard_normal((6, 6, 10, 10)); T2 = rng.standard_normal((10, 10, 6, 6))
+    got = ctx.contract("klcd,adkj->alcj", ctx.array(V), ctx.array(T2)).get()
+    assert np.abs(got - np.einsum("klcd,adkj->alcj", V, T2)).max() < 1e-12
+    got = ctx.contract("klij,abkl->abij", ctx.array(rng.standard_normal((6, 6, 6, 6))), ctx.array(T2))
+    assert got.shape == (10, 10, 6, 6)
+
+
+@pytest.mark.parametrize("spec,shape", [("abij->aibj", (12, 12, 4, 4)), ("abij->ajbi", (33, 35, 9, 7)),
+                                         ("abij->baji", (40, 40, 10, 10)), ("abcd->dcba", (5, 6, 7, 8)),
+                                         ("ab->ba", (1000, 333)), ("abc->abc", (9, 8, 7)), ("klcd->ckdl", (50, 50, 64, 64))])
+def test_permute(ctx, spec, shape):
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal(shape)
+    li, lo = spec.split("->")
+    ref = np.einsum(spec, A)
+    assert np.array_equal(ctx.permute(spec, ctx.array(A)).get(), ref)
+    O = rng.standard_normal(ref.shape)
+    dO = ctx.array(O)
+    ctx.permute(spec, ctx.array(A), out=dO, alpha=2.0, beta=-1.0)
+    assert np.abs(dO.get() - (2.0 * ref - O)).max() < 1e-14
+
+
+def test_elementwise_and_reductions(ctx):
+    rng = np.random.default_rng(4)
+    no, nv = ctx.no, ctx.nv
+    eo, ev = np.sort(-1 - rng.random(no)), np.sort(1 + rng.random(nv))
+    ctx.set_orbital_energies(eo, ev)
+    D = eo[None, None, :, None] + eo[None, None, None, :] - ev[:, None, None, None] - ev[None, :, None, None]
+    R = rng.standard_normal((nv, nv, no, no)); T = rng.standard_normal((nv, nv, no, no))
+    dT, ddT = ctx.array(T), ctx.empty(T.shape)
+    ctx.cc_update(dT, ddT, ctx.array(R), level_shift=0.3, delta=1.0)
+    inv = 1.0 / (D + 0.3)
+    assert np.array_equal(ddT.get(), R * inv)
+    assert np.array_equal(dT.get(), T + R * inv)
+    r1 = rng.standard_normal((nv, no)); t1 = rng.standard_normal((nv, no))
+    d1, dd1 = ctx.array(t1), ctx.empty(t1.shape)
+    ctx.cc_update(d1, dd1, ctx.array(r1), level_shift=0.0)
+    assert np.array_equal(dd1.get(), r1 * (1.0 / (eo[None, :] - ev[:, None])))
+    xs = [ctx.array(rng.standard_normal(100003)) for _ in range(5)]
+    dots = ctx.dots(xs, xs[::-1])
+    ref = [float(np.dot(a.get(), b.get())) for a, b in zip(xs, xs[::-1])]
+    assert np.allclose(dots, ref, rtol=1e-13, atol=1e-10)
+    out = ctx.empty((100003,))
+    cs = rng.standard_normal(5)
+    ctx.lincomb(out, xs, cs)
+    assert np.abs(out.get() - sum(c * x.get() for c, x in zip(cs, xs))).max() < 1e-13
