@@ -82,11 +82,13 @@ class Context:
         self.lib.call("pymes_ctx_create", C.byref(h), self.device, self.no, self.nv, int(workspace_bytes))
         self.handle = h
         self._allocator = allocator      # optional callable(n_doubles) -> (ptr, keepalive), e.g. torch-backed
+        self._pool = {}
         if stream is not None:
             self.set_stream(stream)
 
     # ---- lifetime -----------------------------------------------------------------
     def close(self):
+        self._pool = {}
         if self.handle:
             self.lib.call("pymes_ctx_destroy", self.handle)
             self.handle = None
@@ -121,6 +123,21 @@ class Context:
 
     def zeros(self, shape):
         return self.empty(shape).zero_()
+
+    # amplitude-sized buffers are recycled instead of hipFree'd/hipMalloc'ed every iteration
+    def pool_get(self, shape):
+        shape = tuple(int(s) for s in shape)
+        free = self._pool.setdefault(int(np.prod(shape)), [])
+        if free:
+            arr = free.pop()
+            return DeviceArray(self, arr.ptr, shape, owned=False, keepalive=arr)
+        return self.empty(shape)
+
+    def pool_put(self, arr):
+        base = arr
+        while not base._owned and isinstance(base._keep, DeviceArray):
+            base = base._keep
+        self._pool.setdefault(base.size, []).append(base)
 
     def array(self, host):
         host = np.ascontiguousarray(host, dtype=np.float64)

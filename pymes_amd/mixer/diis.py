@@ -1,0 +1,78 @@
+"""DIIS mixer with the bookkeeping of pymes/mixer/diis.py:16-112, on device arrays.
+
+The stored error/amplitude vectors stay in HBM; per call the host sees only the
+overlaps <e_i, e_new> (one fused multi-dot) and the (<=7)x(<=7) system.  The reference's
+full-subspace quirk is reproduced on purpose: once ``dim_space`` vectors
+are stored, the shifted copy of the old L (diis.py:59-60) omits the row/column of the
+second-newest vector, which therefore become zeros — iteration histories depend on it.
+"""
+import numpy as np
+
+from pymes_amd.log import print_logging_info
+
+
+class DIIS:
+    def __init__(self, dim_space=5):
+        self.dim_space = dim_space
+        self.L = np.zeros((1, 1))
+        self.error_list = []
+        self.amplitude_list = []
+        self.last_coefficients = None
+
+    # -- host part: identical arithmetic to the reference ------------------------------
+    def _update_L(self, overlaps, was_full):
+        m = len(overlaps)
+        L = np.zeros((m + 1, m + 1))
+        L[-1, :-1] = -1.0
+        L[:-1, -1] = -1.0
+        if was_full:
+            L[:-3, :-3] = self.L[1:-2, 1:-2]
+        else:
+            L[:-2, :-2] = self.L[:-1, :-1]
+        L[:m, -2] += overlaps
+        L[-2, :] = L[:, -2]
+        self.L = L.copy()
+
+    def _solve(self):
+        unit = np.zeros(self.L.shape[0])
+        unit[-1] = -1.0
+        lam, vec = np.linalg.eigh(self.L)
+        if np.any(np.abs(lam) < 1e-12):
+            print_logging_info("Linear dependence found in DIIS subspace.", level=2)
+            ok = np.abs(lam) > 1e-12
+            return np.dot(vec[:, ok] * (1.0 / lam[ok]), np.dot(vec[:, ok].T.conj(), unit))
+        return np.linalg.inv(self.L).dot(unit)
+
+    def mix(self, error, amplitude, release=None):
+        """error / amplitude: lists of DeviceArray (one entry per amplitude type).
+        Returns freshly allocated DeviceArrays with the extrapolated amplitudes.  The
+        mixer keeps references to the arrays passed in (like the reference): the caller must
+        not modify them afterwards.  ``release(arr)`` is called for vectors that leave the
+        subspace so a caller-side pool can recycle their memory."""
+        was_full = len(self.error_list) == self.dim_space
+        if was_full:
+            old_e, old_a = self.error_list.pop(0), self.amplitude_list.pop(0)
+            if release is not None:
+                for arr in list(old_e) + list(old_a):
+                    release(arr)
+        self.error_list.append(list(error))
+        self.amplitude_list.append(list(amplitude))
+        ctx = error[0].ctx
+        m, ntypes = len(self.error_list), len(error)
+        overlaps = np.zeros(m)
+        for nt in range(ntypes):
+            overlaps += ctx.dots([self.error_list[i][nt] for i in range(m)], [error[nt]] * m)
+        self._update_L(overlaps, was_full)
+        c = self._solve()
+        self.last_coefficients = c
+        out = []
+        for nt in range(ntypes):
+            dst = ctx.pool_get(amplitude[nt].shape)
+            ctx.lincomb(dst, [self.amplitude_list[a][nt] for a in range(m)], c[:m])
+            out.append(dst)
+        print_logging_info("diis.mix", level=2)
+        print_logging_info("Coefficients for combining amplitudes=", level=3)
+        print_logging_info(c[:-1], level=3)
+        print_logging_info("Sum of coefficients = {:.8f}".format(np.sum(c[:-1])), level=3)
+        print_logging_info("Lagrangian multiplier = {:.8f}".format(c[-1]), level=3)
+        return out

@@ -1,0 +1,146 @@
+"""CCD / DCD driver and the T2 residual (pymes/solver/ccd.py) on the MI355X engine.
+
+Drop-in for ``pymes.solver.ccd.CCD``: same constructor, attributes, ``solve`` signature
+and return dictionary.  All tensors live in HBM between iterations; per iteration the
+host sees the energy, two norms and the DIIS overlaps."""
+import time
+
+import numpy as np
+
+from pymes_amd.device import Context, DeviceArray
+from pymes_amd.integral.device import DeviceIntegrals
+from pymes_amd.log import print_logging_info
+from pymes_amd.mixer import diis
+
+
+class CCD:
+    def __init__(self, no, delta_e=1.e-8, is_dcd=False, is_diis=True, is_dr_ccd=False, is_bruekner=False,
+                 device=0):
+        if is_dr_ccd or is_bruekner:
+            raise NotImplementedError("dr-CCD and Brueckner energies (ccd.py:95-121) are outside the HIP hot path")
+        self.is_dcd = is_dcd
+        self.is_diis = is_diis
+        self.is_dr_ccd = is_dr_ccd
+        self.is_bruekner = is_bruekner
+        self.no = no
+        self.delta_e = delta_e
+        self.max_iter = 50
+        self.device = device
+        if self.is_diis:
+            self.mixer = diis.DIIS(dim_space=6)
+
+    # ---- device plumbing shared with CCSD ------------------------------------------------
+    def _integrals(self, t_fock_pq, t_V_pqrs):
+        if isinstance(t_V_pqrs, DeviceIntegrals):
+            return t_V_pqrs, False
+        return DeviceIntegrals.from_V_pqrs(self.no, t_V_pqrs, device=self.device), True
+
+    def solve(self, t_fock_pq, t_V_pqrs, level_shift=0., sp=0, amps=None, **kwargs):
+        """ccd.py:24-162."""
+        algo_name = "ccd.solve"
+        time_ccd = time.time()
+        no = self.no
+        nv = t_fock_pq.shape[0] - no
+        t_epsilon_i = t_fock_pq.diagonal()[:no]
+        t_epsilon_a = t_fock_pq.diagonal()[no:]
+        max_iter = kwargs.get("max_iter", self.max_iter)
+        delta_e = kwargs.get("delta_e", self.delta_e)
+        delta = 1.0
+
+        ints, own = self._integrals(t_fock_pq, t_V_pqrs)
+        ctx = ints.ctx
+        try:
+            ctx.set_orbital_energies(t_epsilon_i, t_epsilon_a)
+            f_dev = ctx.array(np.asarray(t_fock_pq, dtype=np.float64))
+            print_logging_info(algo_name)
+            print_logging_info("Using DCD: ", self.is_dcd, level=1)
+            print_logging_info("Using dr-CCD: ", self.is_dr_ccd, level=1)
+            print_logging_info("Solving doubles amplitude equation", level=1)
+            print_logging_info("Using data type %s" % ints.dtype, level=1)
+            print_logging_info("Using DIIS mixer: ", self.is_diis, level=1)
+            print_logging_info("Using Bruekner quasi-particle energy: ", self.is_bruekner, level=1)
+            print_logging_info("Iteration = 0", level=1)
+            t2 = ctx.pool_get((nv, nv, no, no))
+            e_dir, e_exc = ctx.mp2(t2, level_shift)
+            e_mp2 = e_dir + e_exc
+            print("MP2 energy = ", e_mp2)
+            if amps is not None:
+                t2.set(np.asarray(amps))
+            dE = np.abs(e_mp2)
+            iteration = 0
+            e_last = e_mp2
+            e_ccd = e_dir_ccd = e_ex_ccd = 0.
+            first = True
+            while np.abs(dE) > delta_e and iteration <= max_iter:
+                iteration += 1
+                r2 = ctx.pool_get(t2.shape)
+                ctx.doubles_residual(f_dev, t2, r2, is_dcd=self.is_dcd)           # ccd.py:100-102
+                dt2 = ctx.pool_get(t2.shape)
+                ctx.cc_update(t2, dt2, r2, level_shift, delta)                    # :123-124
+                ctx.pool_put(r2)
+                if first and amps is not None:
+                    np.copyto(amps, t2.get())     # the reference updates the caller's array in place (:124)
+                first = False
+                if self.is_diis:
+                    t2 = self.mixer.mix([dt2], [t2], release=ctx.pool_put)[0]     # :126-127
+                e_dir_ccd, e_ex_ccd = ctx.ccd_energy(t2)                          # :132
+                e_ccd = e_dir_ccd + e_ex_ccd
+                dE = e_ccd - e_last
+                e_last = e_ccd
+                nt, nr = np.sqrt(ctx.dots([t2, dt2], [t2, dt2]))
+                if not self.is_diis:
+                    ctx.pool_put(dt2)
+                if iteration <= max_iter:
+                    print_logging_info("Iteration = ", iteration, level=1)
+                    print_logging_info("Correlation Energy = {:.12f}".format(e_ccd), level=2)
+                    print_logging_info("dE = {:.12e}".format(dE), level=2)
+                    print_logging_info("L1 Norm of T2 = {:.12f}".format(nt), level=2)
+                    print_logging_info("Norm Residual = {:.12f}".format(nr), level=2)
+                else:
+                    print_logging_info("A converged solution is not found!", level=1)
+            print_logging_info("Direct contribution = {:.12f}".format(e_dir_ccd), level=1)
+            print_logging_info("Exchange contribution = {:.12f}".format(e_ex_ccd), level=1)
+            print_logging_info("CCD correlation energy = {:.12f}".format(e_ccd), level=1)
+            print_logging_info("{:.3f} seconds spent on CCD".format((time.time() - time_ccd)), level=1)
+            result = {"ccd e": e_ccd, "t2 amp": t2.get(), "hole e": t_epsilon_i, "particle e": t_epsilon_a, "dE": dE}
+            self.iterations = iteration
+            return result
+        finally:
+            if self.is_diis:     # stored vectors belong to this context
+                self._drop_mixer_history_of(ctx)
+            if own:
+                ctx.close()
+
+    def _drop_mixer_history_of(self, ctx):
+        """The reference's mixer keeps growing across solve() calls on one instance
+        (diis history is never reset); device history cannot outlive its context, so it is
+        cleared when the context it lives in is closed."""
+        m = self.mixer
+        if any(arr.ctx is ctx for vec in m.error_list for arr in vec):
+            m.error_list, m.amplitude_list, m.L = [], [], np.zeros((1, 1))
+
+    def get_residual(self, t_fock_pq, t_T_abij, t_V_klij, t_V_ijab, t_V_abij, t_V_iajb, t_V_iabj, t_V_abcd):
+        """ccd.py:164-254 with host arrays in and a host array out (the reference's call form)."""
+        no = self.no
+        nv = t_fock_pq.shape[0] - no
+        ctx = Context(no, nv, device=self.device)
+        try:
+            for name, blk in (("klij", t_V_klij), ("ijab", t_V_ijab), ("abij", t_V_abij), ("iajb", t_V_iajb),
+                              ("iabj", t_V_iabj), ("abcd", t_V_abcd)):
+                ctx.set_V_block(name, np.ascontiguousarray(blk, dtype=np.float64))
+            r2 = ctx.empty((nv, nv, no, no))
+            ctx.doubles_residual(ctx.array(np.asarray(t_fock_pq, dtype=np.float64)),
+                                 ctx.array(np.asarray(t_T_abij, dtype=np.float64)), r2, is_dcd=self.is_dcd)
+            return r2.get()
+        finally:
+            ctx.close()
+
+    def get_energy(self, t_T_abij, t_V_ijab):
+        """ccd.py:256-262."""
+        no, nv = t_V_ijab.shape[0], t_V_ijab.shape[2]
+        ctx = Context(no, nv, device=self.device)
+        try:
+            ctx.set_V_block("ijab", np.ascontiguousarray(t_V_ijab, dtype=np.float64))
+            return ctx.ccd_energy(ctx.array(np.asarray(t_T_abij, dtype=np.float64)))
+        finally:
+            ctx.close()

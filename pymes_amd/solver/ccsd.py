@@ -1,0 +1,238 @@
+"""T1-similarity-transformed CCSD / DCSD (pymes/solver/ccsd.py) on the MI355X engine.
+
+Drop-in for ``pymes.solver.ccsd.CCSD``: same constructor, attributes, ``solve``
+signature, return dictionary and public helper methods.  Inside ``solve`` everything
+(T1, T2, dressed Fock/V blocks, residuals, DIIS history) stays in HBM; the host sees
+scalars only.  With ``torch.distributed`` initialised (one process per GPU) the
+particle-particle ladder is sharded over the ranks on the virtual index ``a``
+(pymes_amd/dist.py)."""
+import time
+
+import numpy as np
+
+from pymes_amd import dist as pdist
+from pymes_amd.device import Context, DeviceArray
+from pymes_amd.integral.device import DeviceIntegrals
+from pymes_amd.integral.partition import BLOCK_NAMES
+from pymes_amd.log import print_logging_info
+from pymes_amd.mixer import diis
+from pymes_amd.solver import ccd
+
+# blocks produced by get_T1_dressed_V (ccsd.py:322-419); the other five names stay None (:317)
+DRESSED_KEYS = ("abij", "klij", "ijab", "ijka", "ijak", "iajb", "iabj", "iabc", "abic", "iajk", "abcd")
+# what the T2 residual consumes (ccsd.py:449-454); ijab is a plain copy (:355-357) and is read undressed
+LOOP_KEYS = ("abij", "klij", "iajb", "iabj", "abcd")
+
+
+class CCSD(ccd.CCD):
+    def __init__(self, no, is_diis=True, delta_e=1.e-8, is_non_canonical=False, is_dcsd=False, device=0):
+        self.t_T_ai = None
+        self.t_T_abij = None
+        self.is_dcd = is_dcsd
+        self.is_diis = is_diis
+        self.is_bruekner = False
+        self.is_dr_ccd = False
+        self.no = no
+        self.max_iter = 50
+        self.delta = 1.0
+        self.delta_e = delta_e
+        self.debug_level = 1
+        self.device = device
+        if self.is_diis:
+            self.mixer = diis.DIIS(dim_space=6)
+
+    def write_logging_info(self):
+        return
+
+    # ------------------------------------------------------------------------------------
+    # iteration machinery (also driven directly by bench.py)
+    # ------------------------------------------------------------------------------------
+    def setup(self, t_fock_pq, ints, level_shift=0., amps=None):
+        """Everything before the while loop of ccsd.py:47-157.  Returns the state dict."""
+        ctx = ints.ctx
+        no, nv = self.no, ctx.nv
+        f = np.asarray(t_fock_pq, dtype=np.float64)
+        eps_i, eps_a = f.diagonal()[:no].copy(), f.diagonal()[no:].copy()
+        ctx.set_orbital_energies(eps_i, eps_a)
+        rank, wsize, _ = pdist.world()
+        st = {"ctx": ctx, "f": ctx.array(f), "fd": ctx.empty(f.shape), "level_shift": level_shift,
+              "eps_i": eps_i, "eps_a": eps_a, "rank": rank, "world": wsize, "first": True, "amps": amps}
+        t2 = ctx.pool_get((nv, nv, no, no))
+        e_dir, e_exc = ctx.mp2(t2, level_shift)                     # ccsd.py:128
+        st["e_mp2"] = e_dir + e_exc
+        t1 = ctx.pool_get((nv, no)).zero_()
+        if amps is not None:
+            t1.set(np.asarray(amps[0]))
+            t2.set(np.asarray(amps[1]))
+        st["t1"], st["t2"] = t1, t2
+        if wsize > 1:
+            import torch
+            dev = torch.device("cuda", ctx.device)
+            st["lad_t"] = torch.zeros((nv, nv * no * no), dtype=torch.float64, device=dev)
+            st["lad"] = DeviceArray(ctx, st["lad_t"].data_ptr(), (nv, nv, no, no), owned=False, keepalive=st["lad_t"])
+        return st
+
+    def iterate(self, st):
+        """One pass of the loop body ccsd.py:159-209.  Returns (e_1b, e_dir, e_ex, |T2|, |dT2|)."""
+        ctx, t1, t2 = st["ctx"], st["t1"], st["t2"]
+        shift = st["level_shift"]
+        ctx.dress_fock(st["f"], t1, st["fd"])                        # :163
+        ctx.dress_V(t1, LOOP_KEYS)                                  # :165 (only the blocks the residual reads)
+        r1 = ctx.pool_get(t1.shape)
+        ctx.singles_residual(st["fd"], t1, t2, r1)                  # :167
+        r2 = ctx.pool_get(t2.shape)
+        if st["world"] == 1:
+            ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True)       # :171
+        else:
+            # a-slab of the ladder on this rank; everything else replicated; one collective
+            lo, hi = pdist.slab_bounds(ctx.nv, st["rank"], st["world"])
+            if ctx.nv % st["world"] != 0:
+                st["lad"].zero_()
+            ctx.ladder(t2, st["lad"], lo, hi, dressed=True, beta=0.0)
+            ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True, skip_ladder=True)
+            self._sync_with_torch(ctx)
+            pdist.exchange_slabs(st["lad_t"], ctx.nv, st["rank"], st["world"])
+            self._sync_with_torch(ctx, after=True)
+            ctx.lincomb(r2, [r2, st["lad"]], [1.0, 1.0])
+        dt1, dt2 = ctx.pool_get(t1.shape), ctx.pool_get(t2.shape)
+        ctx.cc_update(t1, dt1, r1, shift, self.delta)               # :176-179
+        ctx.cc_update(t2, dt2, r2, shift, self.delta)
+        ctx.pool_put(r1)
+        ctx.pool_put(r2)
+        if st["first"] and st["amps"] is not None:
+            np.copyto(st["amps"][0], t1.get())      # the reference updates the caller's arrays in place
+            np.copyto(st["amps"][1], t2.get())
+        st["first"] = False
+        if self.is_diis:
+            t1, t2 = self.mixer.mix([dt1, dt2], [t1, t2], release=ctx.pool_put)           # :181-183
+        e = ctx.ccsd_energy(st["f"], t1, t2)                        # :189-192
+        nt, nr = np.sqrt(ctx.dots([t2, dt2], [t2, dt2]))            # :196-197
+        if not self.is_diis:
+            ctx.pool_put(dt1)
+            ctx.pool_put(dt2)
+        st["t1"], st["t2"] = t1, t2
+        return e[0], e[1], e[2], nt, nr
+
+    @staticmethod
+    def _sync_with_torch(ctx, after=False):
+        """The engine and torch.distributed must agree on stream order: the context runs on torch's
+        current stream when one is set (bench.py does); otherwise fall back to a full sync."""
+        import torch
+        if after:
+            torch.cuda.current_stream().synchronize()
+        else:
+            ctx.sync()
+
+    def solve(self, t_fock_pq, t_V_pqrs, level_shift=0., amps=None, sp=0, **kwargs):
+        """ccsd.py:47-224."""
+        algo_name = "ccsd.solve"
+        time_ccsd = time.time()
+        max_iter = kwargs.get("max_iter", self.max_iter)
+        delta_e = kwargs.get("delta_e", self.delta_e)
+        ints, own = self._integrals(t_fock_pq, t_V_pqrs)
+        ctx = ints.ctx
+        try:
+            print_logging_info(algo_name)
+            print_logging_info("Using dcsd: ", self.is_dcd, level=1)
+            print_logging_info("Solving doubles amplitude equation", level=1)
+            print_logging_info("Using data type %s" % ints.dtype, level=1)
+            print_logging_info("Using DIIS mixer: ", self.is_diis, level=1)
+            print_logging_info("Iteration = 0", level=1)
+            st = self.setup(t_fock_pq, ints, level_shift, amps)
+            e_mp2 = st["e_mp2"]
+            dE = np.abs(e_mp2)
+            iteration = 0
+            e_last = e_mp2
+            e_ccsd = e_1b = e_dir = e_ex = 0.
+            while np.abs(dE) > delta_e and iteration <= max_iter:
+                iteration += 1
+                e_1b, e_dir, e_ex, nt, nr = self.iterate(st)
+                e_ccsd = e_1b + e_dir + e_ex
+                dE = e_ccsd - e_last
+                e_last = e_ccsd
+                if iteration <= max_iter:
+                    print_logging_info("Iteration = ", iteration, level=1)
+                    print_logging_info("Correlation Energy = {:.14f}".format(e_ccsd), level=2)
+                    print_logging_info("dE = {:.12e}".format(dE), level=2)
+                    print_logging_info("L1 Norm of T2 = {:.14f}".format(nt), level=2)
+                    print_logging_info("Norm Residual = {:.14f}".format(nr), level=2)
+                else:
+                    print_logging_info("A converged solution is not found!", level=1)
+            print_logging_info("Fock contribution = {:.12f}".format(e_1b), level=1)
+            print_logging_info("Direct contribution = {:.12f}".format(e_dir), level=1)
+            print_logging_info("Exchange contribution = {:.12f}".format(e_ex), level=1)
+            print_logging_info("CCSD correlation energy = {:.12f}".format(e_ccsd), level=1)
+            print_logging_info("{:.3f} seconds spent on ccsd".format((time.time() - time_ccsd)), level=1)
+            self.t_T_ai = st["t1"].get()
+            self.t_T_abij = st["t2"].get()
+            self.iterations = iteration
+            return {"ccsd e": e_ccsd, "t1": self.t_T_ai, "t2": self.t_T_abij, "hole e": st["eps_i"],
+                    "particle e": st["eps_a"], "dE": dE}
+        finally:
+            if self.is_diis:
+                self._drop_mixer_history_of(ctx)
+            if own:
+                ctx.close()
+
+    # ------------------------------------------------------------------------------------
+    # public helpers with the reference's host-array call forms (used by the EOM drivers)
+    # ------------------------------------------------------------------------------------
+    def _ctx_from_blocks(self, dict_t_V, nv):
+        ctx = Context(self.no, nv, device=self.device)
+        for name, blk in dict_t_V.items():
+            if blk is not None:
+                ctx.set_V_block(name, np.ascontiguousarray(blk, dtype=np.float64))
+        return ctx
+
+    def get_T1_dressed_fock(self, t_fock_pq, t_T_ai, dict_t_V):
+        """ccsd.py:226-288."""
+        ctx = self._ctx_from_blocks(dict_t_V, t_T_ai.shape[0])
+        try:
+            fd = ctx.empty(t_fock_pq.shape)
+            ctx.dress_fock(ctx.array(np.asarray(t_fock_pq, dtype=np.float64)), ctx.array(t_T_ai), fd)
+            return fd.get()
+        finally:
+            ctx.close()
+
+    def get_T1_dressed_V(self, t_T_ai, dict_t_V, dict_t_V_dressed=None):
+        """ccsd.py:290-421; the optional third argument selects the blocks (:316-317)."""
+        if dict_t_V_dressed is None or len(dict_t_V_dressed) == 0:
+            dict_t_V_dressed = {}.fromkeys(dict_t_V, None)
+        ctx = self._ctx_from_blocks(dict_t_V, t_T_ai.shape[0])
+        try:
+            want = [k for k in dict_t_V_dressed if k in DRESSED_KEYS]
+            ctx.dress_V(ctx.array(t_T_ai), want)
+            for k in want:
+                dict_t_V_dressed[k] = ctx.V_block(k, dressed=True).get()
+            return dict_t_V_dressed
+        finally:
+            ctx.close()
+
+    def get_singles_residual(self, t_fock_pq, t_T_ai, t_T_abij, dict_t_V):
+        """ccsd.py:423-438 (t_fock_pq is the dressed Fock matrix)."""
+        ctx = self._ctx_from_blocks(dict_t_V, t_T_ai.shape[0])
+        try:
+            r1 = ctx.empty(t_T_ai.shape)
+            ctx.singles_residual(ctx.array(np.asarray(t_fock_pq, dtype=np.float64)), ctx.array(t_T_ai),
+                                 ctx.array(t_T_abij), r1)
+            return r1.get()
+        finally:
+            ctx.close()
+
+    def get_doubles_residual(self, t_fock_pq, t_T_abij, dict_t_V_dressed):
+        """ccsd.py:440-456."""
+        return self.get_residual(t_fock_pq, t_T_abij, dict_t_V_dressed["klij"], dict_t_V_dressed["ijab"],
+                                 dict_t_V_dressed["abij"], dict_t_V_dressed["iajb"], dict_t_V_dressed["iabj"],
+                                 dict_t_V_dressed["abcd"])
+
+    def get_energy(self, t_fock_ia, t_T_ai, t_T_abij, t_V_ijab):
+        """ccsd.py:458-466: [one-body, direct, exchange]."""
+        no, nv = t_fock_ia.shape
+        ctx = Context(no, nv, device=self.device)
+        try:
+            ctx.set_V_block("ijab", np.ascontiguousarray(t_V_ijab, dtype=np.float64))
+            f = np.zeros((no + nv, no + nv))
+            f[:no, no:] = t_fock_ia
+            return list(ctx.ccsd_energy(ctx.array(f), ctx.array(t_T_ai), ctx.array(t_T_abij)))
+        finally:
+            ctx.close()

@@ -1,0 +1,172 @@
+"""CPU: HOST logic of the engine (contraction planner, CC term sequences, C-ABI, Python
+drop-in classes) linked against the host simulator (tests/hostsim).  The kernels
+themselves are tested on the GPU (test_gpu_*.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cc_oracle as oc
+from oracle import io_oracle as oio
+from oracle.cases import random_case, synthetic_case
+from pymes_amd import _lib
+from pymes_amd.device import Context
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+SOLVES = json.load(open(os.path.join(GOLD, "solves.json")))
+
+
+@pytest.fixture()
+def sim(hostsim_lib, monkeypatch):
+    """Route the package's default library to the host simulator for this test only."""
+    monkeypatch.setattr(_lib, "_default", hostsim_lib)
+    return hostsim_lib
+
+
+def test_product_loader_rejects_non_hip_backend(hostsim_lib):
+    with pytest.raises(_lib.PymesError):
+        _lib.Library(hostsim_lib.path)          # the package itself never accepts the simulator
+
+
+@pytest.mark.parametrize("spec,shapes,batch", [
+    ("abcd,cdij->abij", ((5, 5, 5, 5), (5, 5, 3, 3)), ""),
+    ("klcd,adkj->alcj", ((3, 3, 5, 5), (5, 5, 3, 3)), ""),
+    ("klij,abkl->abij", ((3, 3, 3, 3), (5, 5, 3, 3)), ""),
+    ("ki,akbj->aibj", ((3, 3), (5, 3, 5, 3)), "a"),
+    ("bj,jabc->ac", ((5, 3), (3, 5, 5, 5)), ""),
+    ("pqxs,xr->pqrs", ((4, 3, 6, 2), (6, 5)), "pq"),
+    ("ai,bj->abij", ((5, 3), (4, 2)), ""),
+    ("Qpr,Qqs->pqrs", ((7, 3, 4), (7, 5, 2)), "pq"),
+    ("zab,zbc->zac", ((4, 3, 5), (4, 5, 2)), ""),
+])
+def test_contraction_planner(sim, spec, shapes, batch):
+    rng = np.random.default_rng(0)
+    A, B = rng.standard_normal(shapes[0]), rng.standard_normal(shapes[1])
+    ctx = Context(2, 2, workspace_bytes=1 << 22)
+    ref = np.einsum(spec, A, B)
+    assert np.abs(ctx.contract(spec, ctx.array(A), ctx.array(B), batch=batch).get() - ref).max() < 1e-13
+    C0 = rng.standard_normal(ref.shape)
+    dC = ctx.array(C0)
+    ctx.contract(spec, ctx.array(A), ctx.array(B), out=dC, alpha=-0.5, beta=2.0, batch=batch)
+    assert np.abs(dC.get() - (2.0 * C0 - 0.5 * ref)).max() < 1e-13
+    ctx.close()
+
+
+def test_planner_errors(sim):
+    ctx = Context(2, 2, workspace_bytes=1 << 20)
+    A, B = ctx.zeros((2, 3)), ctx.zeros((3, 4))
+    with pytest.raises(_lib.PymesError, match="only one tensor"):
+        ctx.lib.call("pymes_contract", ctx.handle, 1.0, A.ptr, b"ab", _lib.i64_array((2, 3)), None, B.ptr, b"bc",
+                     _lib.i64_array((3, 4)), None, 0.0, A.ptr, b"ad", _lib.i64_array((2, 5)), None, b"")
+    with pytest.raises(_lib.PymesError, match="extent mismatch"):
+        ctx.lib.call("pymes_contract", ctx.handle, 1.0, A.ptr, b"ab", _lib.i64_array((2, 3)), None, B.ptr, b"bc",
+                     _lib.i64_array((4, 4)), None, 0.0, A.ptr, b"ac", _lib.i64_array((2, 4)), None, b"")
+    with pytest.raises(_lib.PymesError, match="has not been set"):
+        ctx.V_block("abcd")
+    with pytest.raises(_lib.PymesError, match="workspace exhausted"):
+        big = Context(8, 8, workspace_bytes=4096)
+        big.set_V_pqrs(np.zeros((16,) * 4))
+        big.doubles_residual(big.zeros((16, 16)), big.zeros((8, 8, 8, 8)), big.zeros((8, 8, 8, 8)))
+    ctx.close()
+
+
+@pytest.mark.parametrize("no,nv,seed", [(1, 1, 3), (2, 3, 11), (3, 5, 12), (4, 7, 9)])
+def test_cc_terms_vs_oracle(sim, no, nv, seed):
+    f, V, t1, t2 = random_case(no, nv, seed, symmetric=False)
+    Vb = oc.split_blocks(no, V)
+    ctx = Context(no, nv)
+    ctx.set_V_pqrs(V)
+    dF, dT1, dT2 = ctx.array(f), ctx.array(t1), ctx.array(t2)
+    fd = ctx.empty(f.shape)
+    ctx.dress_fock(dF, dT1, fd)
+    fd_ref = oc.dressed_fock(no, f, t1, Vb)
+    assert np.abs(fd.get() - fd_ref).max() < 1e-13
+    ctx.dress_V(dT1, oc.DRESSED_KEYS)
+    Vd = oc.dressed_V(t1, Vb)
+    for k in oc.DRESSED_KEYS:
+        assert np.abs(ctx.V_block(k, dressed=True).get() - Vd[k]).max() < 1e-13, k
+    r1 = ctx.empty(t1.shape)
+    ctx.singles_residual(fd, dT1, dT2, r1)
+    assert np.abs(r1.get() - oc.singles_residual(no, fd_ref, t1, t2, Vb)).max() < 1e-13
+    for dcd in (False, True):
+        r2 = ctx.empty(t2.shape)
+        ctx.doubles_residual(fd, dT2, r2, is_dcd=dcd, dressed=True)
+        assert np.abs(r2.get() - oc.ccsd_doubles_residual(no, fd_ref, t2, Vd, is_dcsd=dcd)).max() < 1e-12
+        r2s = ctx.empty(t2.shape)
+        ctx.doubles_residual(fd, dT2, r2s, is_dcd=dcd, dressed=True, skip_ladder=True)
+        for lo, hi in ((0, nv // 2), (nv // 2, nv)):
+            ctx.ladder(dT2, r2s, lo, hi, dressed=True, beta=1.0)
+        assert np.abs(r2s.get() - r2.get()).max() < 1e-13
+    ctx.close()
+
+
+def _problem(tag):
+    if tag.startswith("syn_"):
+        no, nv = (int(x) for x in tag.split("_")[1:])
+        rec = SOLVES[tag]["recipe"]
+        f, V, _, _ = synthetic_case(no, nv, seed=rec["seed"], scale=rec["scale"], gap=rec["gap"])
+        return no, f, V
+    ne, n, ec, eps, h, V = oio.read_fcidump(os.path.join(GOLD, "fcidump", "FCIDUMP." + tag))
+    return ne // 2, oio.fock_matrix(ne // 2, h, V), V
+
+
+@pytest.mark.parametrize("tag,kind", [("LiH.sto6g", "ccsd"), ("H2.321g", "dcsd"), ("syn_4_12", "ccsd"),
+                                      ("LiH.bare", "ccd"), ("LiH.sto6g", "dcd")])
+def test_solver_classes_reproduce_reference_energies(sim, capsys, tag, kind):
+    """The drop-in classes (host logic + DIIS bookkeeping) against the reference's energies."""
+    from pymes_amd.solver import ccd, ccsd
+    ref = SOLVES[tag][kind]
+    no, f, V = _problem(tag)
+    if kind in ("ccd", "dcd"):
+        s = ccd.CCD(no, delta_e=ref["delta_e"], is_dcd=(kind == "dcd"))
+        res = s.solve(f, V)
+        e = res["ccd e"]
+        assert set(res) == {"ccd e", "t2 amp", "hole e", "particle e", "dE"}
+    else:
+        s = ccsd.CCSD(no, delta_e=ref["delta_e"], is_dcsd=(kind == "dcsd"))
+        res = s.solve(f, V)
+        e = res["ccsd e"]
+        assert set(res) == {"ccsd e", "t1", "t2", "hole e", "particle e", "dE"}
+        assert res["t1"].shape == (f.shape[0] - no, no)
+    assert s.iterations == ref["iterations"]
+    assert abs(e - ref["e"]) < 1e-9
+    assert abs(np.linalg.norm(res["t2"] if "t2" in res else res["t2 amp"]) - ref["t2_norm"]) < 1e-7
+    out = capsys.readouterr().out
+    assert "Correlation Energy" in out and out.count("Iteration = ") == min(ref["iterations"], 50) + 1
+
+
+def test_public_helper_methods_match_oracle(sim, capsys):
+    from pymes_amd.integral.partition import part_2_body_int
+    from pymes_amd.solver import ccsd
+    no, nv = 3, 5
+    f, V, t1, t2 = random_case(no, nv, 12, symmetric=False)
+    dV = part_2_body_int(no, V)
+    assert all(np.shares_memory(v, V) for v in dV.values()) and list(dV) == list(oc.BLOCK_NAMES)
+    cc = ccsd.CCSD(no)
+    fd = cc.get_T1_dressed_fock(f, t1, dV)
+    assert np.abs(fd - oc.dressed_fock(no, f, t1, dV)).max() < 1e-13
+    Vd = cc.get_T1_dressed_V(t1, dV)
+    ref = oc.dressed_V(t1, dV)
+    assert list(Vd) == list(ref)
+    for k in ref:
+        assert (Vd[k] is None) == (ref[k] is None)
+        if ref[k] is not None:
+            assert np.abs(Vd[k] - ref[k]).max() < 1e-13
+    sub = cc.get_T1_dressed_V(t1, dV, {"abcd": None, "klij": None})
+    assert set(sub) == {"abcd", "klij"} and np.abs(sub["abcd"] - ref["abcd"]).max() < 1e-13
+    assert np.abs(cc.get_singles_residual(fd, t1, t2, dV) - oc.singles_residual(no, fd, t1, t2, dV)).max() < 1e-13
+    assert np.abs(cc.get_doubles_residual(fd, t2, Vd) - oc.ccsd_doubles_residual(no, fd, t2, ref)).max() < 1e-12
+    assert np.abs(np.array(cc.get_energy(f[:no, no:], t1, t2, dV["ijab"])) -
+                  np.array(oc.ccsd_energy(f[:no, no:], t1, t2, dV["ijab"]))).max() < 1e-13
+
+
+def test_amps_warm_start_and_kwargs(sim, capsys):
+    from pymes_amd.solver import ccsd
+    no, f, V = _problem("syn_4_12")
+    first = ccsd.CCSD(no, delta_e=1e-6).solve(f, V, maxIter=3, epsilon_e=1)     # unknown kwargs are ignored
+    t1, t2 = first["t1"].copy(), first["t2"].copy()
+    t2_before = t2.copy()
+    res = ccsd.CCSD(no, delta_e=1e-10).solve(f, V, amps=[t1, t2], max_iter=30)
+    assert abs(res["ccsd e"] - SOLVES["syn_4_12"]["ccsd"]["e"]) < 5e-8     # a different (warm-started) path
+    assert not np.array_equal(t2, t2_before)      # caller's arrays are updated in place (ccsd.py:178-179)
