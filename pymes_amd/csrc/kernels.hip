@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -476,6 +477,7 @@ struct Prof {
     bool on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    std::vector<std::string> what;   // one description per recorded launch
     double flops = 0.0;
 } g_prof;
 
@@ -555,16 +557,23 @@ void prof_enable(bool on) { g_prof.on = on; }
 void prof_reset() {
     for (auto& e : g_prof.ev) g_prof.pool.push_back(e);
     g_prof.ev.clear();
+    g_prof.what.clear();
     g_prof.flops = 0.0;
 }
 void prof_query(long* launches, double* ms, double* flops) {
     double tot = 0.0;
-    for (auto& e : g_prof.ev) {
+    // PYMES_GEMM_LOG=<file>: one line per GEMM launch (shape, tile, time) for tuning
+    const char* logp = getenv("PYMES_GEMM_LOG");
+    FILE* lf = logp ? fopen(logp, "a") : nullptr;
+    for (size_t i = 0; i < g_prof.ev.size(); ++i) {
+        auto& e = g_prof.ev[i];
         HIP_CHECK(hipEventSynchronize(e.second));
         float t = 0.f;
         HIP_CHECK(hipEventElapsedTime(&t, e.first, e.second));
         tot += t;
+        if (lf) fprintf(lf, "%s ms=%.4f\n", g_prof.what[i].c_str(), t);
     }
+    if (lf) { fprintf(lf, "----\n"); fclose(lf); }
     *launches = (long)g_prof.ev.size();
     *ms = tot;
     *flops = g_prof.flops;
@@ -663,7 +672,12 @@ void gemm(const Gemm& g, stream_t s) {
     if (g_prof.on) {
         HIP_CHECK(hipEventRecord(ev.second, st));
         g_prof.ev.push_back(ev);
-        g_prof.flops += 2.0 * (double)g.M * (double)g.N * (double)g.K * (double)nbatch;
+        const double fl = 2.0 * (double)g.M * (double)g.N * (double)g.K * (double)nbatch;
+        g_prof.flops += fl;
+        char buf[256];
+        snprintf(buf, sizeof buf, "M=%ld N=%ld K=%ld batch=%ld tile=%dx%d akc=%d bkc=%d vec=%d split=%d flops=%.4e",
+                 (long)g.M, (long)g.N, (long)g.K, (long)nbatch, BM, BN, (int)a_kcontig, (int)b_kcontig, vec, nsplit, fl);
+        g_prof.what.push_back(buf);
     }
 }
 
