@@ -148,8 +148,8 @@ int pymes_dgemm(pymes_ctx* ctx, int64_t M, int64_t N, int64_t K, double alpha, c
         g.B = B; g.b_sk = b_sk; g.b_sn = b_sn;
         g.C = C; g.ldc = ldc;
         g.nb1 = g.nb2 = 1;
-        g.splitk_ws = nullptr;
-        g.splitk_ws_doubles = 0;
+        g.splitk_ws = e.splitk_ws();
+        g.splitk_ws_doubles = e.splitk_ws_doubles();
         dev::gemm(g, e.stream);
         e.stats.gemm_calls++;
         e.stats.gemm_flops += 2.0 * double(M) * double(N) * double(K);

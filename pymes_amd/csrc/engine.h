@@ -118,6 +118,8 @@ class Engine {
 
     double* eps_o = nullptr;
     double* eps_v = nullptr;
+    double* splitk_ws() const { return splitk_ws_; }
+    int64_t splitk_ws_doubles() const { return splitk_doubles_; }
 
   private:
     double* V_[16] = {nullptr};      // undressed blocks (owned)

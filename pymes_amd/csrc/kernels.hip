@@ -49,9 +49,11 @@ struct GemmK {
     double alpha, beta;
     int tiles_m, tiles_n;
     int nsplit, kchunk;
+    long tile_begin;   // first (batch-major) tile handled by this launch
+    int variant;       // scheduling experiment knob (PYMES_GEMM_VARIANT)
     long nb2;
     long a_b1, a_b2, b_b1, b_b2, c_b1, c_b2;
-    double* ws;   // split-K partials [z][ks][M][N]
+    double* ws;   // split-K partials, tile-local: [tile - tile_begin][ks][BM][BN]
 };
 
 // blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2): give each
@@ -91,11 +93,11 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_kernel(const GemmK g) {
     // ---- block -> (batch z, k-split ks, tile tm/tn) -------------------------------
     const long bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tiles = g.tiles_m * g.tiles_n;
-    const long per_batch = (long)tiles * g.nsplit;
-    const long z = bid / per_batch;
-    const int rem = (int)(bid - z * per_batch);
-    const int ks = rem / tiles;
-    const int t = rem - ks * tiles;
+    const long lt = bid / g.nsplit;                  // launch-local tile; its k-splits are adjacent blocks
+    const int ks = (int)(bid - lt * g.nsplit);
+    const long gt = g.tile_begin + lt;
+    const long z = gt / tiles;
+    const int t = (int)(gt - z * tiles);
     constexpr int GROUP = 8;
     const int group_sz = GROUP * g.tiles_n;
     const int grp = t / group_sz;
@@ -114,55 +116,88 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_kernel(const GemmK g) {
     const int nkt = (kend - kbeg + BK - 1) / BK;
 
     // ---- per-thread staging geometry (constant over the k loop) -------------------
+    // Rows/columns beyond M or N are CLAMPED to the last valid one instead of masked: they only
+    // feed rows/columns of C that the epilogue never stores.  Only the k-tail needs zero fill,
+    // and only in the last k-tile, so the steady-state loads are branch-free pointer bumps.
     const int a_r = tid / A_CH, a_c = (tid % A_CH) * VEC;
     const int b_r = tid / B_CH, b_c = (tid % B_CH) * VEC;
+    const double* pa[LA];
+    const double* pb[LB];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int r = a_r + i * A_RSTEP;
+        if (AKC) pa[i] = A + (long)min(m0 + r, g.M - 1) * g.a_ld + (kbeg + a_c);
+        else pa[i] = A + (long)(kbeg + r) * g.a_ld + min(m0 + a_c, g.M - VEC);
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const int r = b_r + i * B_RSTEP;
+        if (BKC) pb[i] = B + (long)min(n0 + r, g.N - 1) * g.b_ld + (kbeg + b_c);
+        else pb[i] = B + (long)(kbeg + r) * g.b_ld + min(n0 + b_c, g.N - VEC);
+    }
+    const long a_step = AKC ? (long)BK : (long)BK * g.a_ld;
+    const long b_step = BKC ? (long)BK : (long)BK * g.b_ld;
 
     double ra[LA * VEC], rb[LB * VEC];
 
-    auto load_tiles = [&](int kt) {
-        const int k0 = kbeg + kt * BK;
+    // steady state: whole k-tile in range
+    auto load_full = [&]() {
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
-            const int r = a_r + i * A_RSTEP;
-            long off;
-            bool ok;
-            if (AKC) {   // LDS row = m, chunk along k
-                ok = (m0 + r < g.M) && (k0 + a_c < kend);
-                off = (long)(m0 + r) * g.a_ld + (k0 + a_c);
-            } else {     // LDS row = k, chunk along m
-                ok = (k0 + r < kend) && (m0 + a_c < g.M);
-                off = (long)(k0 + r) * g.a_ld + (m0 + a_c);
-            }
             if constexpr (VEC == 2) {
-                v2d v = {0.0, 0.0};
-                if (ok) v = *reinterpret_cast<const v2d*>(A + off);
+                const v2d v = *reinterpret_cast<const v2d*>(pa[i]);
                 ra[2 * i] = v[0];
                 ra[2 * i + 1] = v[1];
             } else {
-                ra[i] = ok ? A[off] : 0.0;
+                ra[i] = *pa[i];
+            }
+            pa[i] += a_step;
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            if constexpr (VEC == 2) {
+                const v2d v = *reinterpret_cast<const v2d*>(pb[i]);
+                rb[2 * i] = v[0];
+                rb[2 * i + 1] = v[1];
+            } else {
+                rb[i] = *pb[i];
+            }
+            pb[i] += b_step;
+        }
+    };
+    // last, partial k-tile: k >= kend contributes zeros
+    auto load_tail = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int kk = k0 + (AKC ? a_c : a_r + i * A_RSTEP);
+            const bool ok = kk < kend;
+            if constexpr (VEC == 2) {
+                v2d v = {0.0, 0.0};
+                if (ok) v = *reinterpret_cast<const v2d*>(pa[i]);
+                ra[2 * i] = v[0];
+                ra[2 * i + 1] = v[1];
+            } else {
+                ra[i] = ok ? *pa[i] : 0.0;
             }
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
-            const int r = b_r + i * B_RSTEP;
-            long off;
-            bool ok;
-            if (BKC) {   // LDS row = n, chunk along k
-                ok = (n0 + r < g.N) && (k0 + b_c < kend);
-                off = (long)(n0 + r) * g.b_ld + (k0 + b_c);
-            } else {     // LDS row = k, chunk along n
-                ok = (k0 + r < kend) && (n0 + b_c < g.N);
-                off = (long)(k0 + r) * g.b_ld + (n0 + b_c);
-            }
+            const int kk = k0 + (BKC ? b_c : b_r + i * B_RSTEP);
+            const bool ok = kk < kend;
             if constexpr (VEC == 2) {
                 v2d v = {0.0, 0.0};
-                if (ok) v = *reinterpret_cast<const v2d*>(B + off);
+                if (ok) v = *reinterpret_cast<const v2d*>(pb[i]);
                 rb[2 * i] = v[0];
                 rb[2 * i + 1] = v[1];
             } else {
-                rb[i] = ok ? B[off] : 0.0;
+                rb[i] = ok ? *pb[i] : 0.0;
             }
         }
+    };
+    const int nfull = (kend - kbeg) / BK;          // k-tiles completely inside [kbeg, kend)
+    auto load_tiles = [&](int kt) {
+        if (kt < nfull) load_full();
+        else load_tail(kbeg + kt * BK);
     };
     auto store_tiles = [&](int buf) {
         double* as = As + buf * A_TILE;
@@ -203,6 +238,13 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_kernel(const GemmK g) {
     constexpr int A_KSTEP = AKC ? 4 : 4 * A_PITCH;       // next k-step of 4
     constexpr int B_KSTEP = BKC ? 4 : 4 * B_PITCH;
 
+    if (g.variant == 1) {            // static priority for every other co-resident block
+        if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(1);
+    } else if (g.variant == 3) {     // start stagger: every other block waits ~half a k-tile
+        if ((blockIdx.x >> 8) & 1) {
+            for (int w = 0; w < 16; ++w) __builtin_amdgcn_s_sleep(127);
+        }
+    }
     if (nkt > 0) {
         load_tiles(0);
         store_tiles(0);
@@ -213,37 +255,46 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_kernel(const GemmK g) {
         if (kt + 1 < nkt) load_tiles(kt + 1);   // global loads in flight under the MFMAs
         const double* as = As + cur * A_TILE + a_frag;
         const double* bs = Bs + cur * B_TILE + b_frag;
+        double a[2][FM], b[2][FN];               // fragments of k-step kk+1 are fetched under the MFMAs of kk
+#pragma unroll
+        for (int i = 0; i < FM; ++i) a[0][i] = as[i * A_FSTEP];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) b[0][j] = bs[j * B_FSTEP];
+        if (g.variant == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
-            double a[FM], b[FN];
+            if (kk + 1 < BK / 4) {
 #pragma unroll
-            for (int i = 0; i < FM; ++i) a[i] = as[kk * A_KSTEP + i * A_FSTEP];
+                for (int i = 0; i < FM; ++i) a[(kk + 1) & 1][i] = as[(kk + 1) * A_KSTEP + i * A_FSTEP];
 #pragma unroll
-            for (int j = 0; j < FN; ++j) b[j] = bs[kk * B_KSTEP + j * B_FSTEP];
+                for (int j = 0; j < FN; ++j) b[(kk + 1) & 1][j] = bs[(kk + 1) * B_KSTEP + j * B_FSTEP];
+            }
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
         }
+        if (g.variant == 2) __builtin_amdgcn_s_setprio(0);
         if (kt + 1 < nkt) store_tiles(cur ^ 1);
         __syncthreads();
     }
 
     // ---- epilogue -------------------------------------------------------------------
-    const bool partial = g.nsplit > 1;
-    double* __restrict__ C;
-    long ldc;
-    double alpha = g.alpha, beta = g.beta;
-    if (partial) {
-        C = g.ws + (z * g.nsplit + ks) * (long)g.M * g.N;
-        ldc = g.N;
-        alpha = 1.0;
-        beta = 0.0;
-    } else {
-        C = g.C + z1 * g.c_b1 + z2 * g.c_b2;
-        ldc = g.ldc;
+    if (g.nsplit > 1) {   // k-split partial: whole tile, tile-local layout, combined by splitk_reduce_kernel
+        double* __restrict__ W = g.ws + (lt * g.nsplit + ks) * (long)(BM * BN);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    W[(wm * WM + i * 16 + l4 + 4 * r) * BN + wn * WN + j * 16 + l15] = acc[i][j][r];
+        return;
     }
+    double* __restrict__ C = g.C + z1 * g.c_b1 + z2 * g.c_b2;
+    const long ldc = g.ldc;
+    const double alpha = g.alpha, beta = g.beta;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -263,22 +314,33 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_kernel(const GemmK g) {
     }
 }
 
-// C[z][m][n] = alpha * sum_ks ws[z][ks][m][n] + beta * C
-__global__ void splitk_reduce_kernel(const double* __restrict__ ws, double* __restrict__ C, long ldc, int M, int N,
-                                     int nsplit, long nb2, long c_b1, long c_b2, double alpha, double beta,
-                                     long total) {
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long)gridDim.x * blockDim.x) {
-        const long mn = (long)M * N;
-        const long z = idx / mn;
-        const long r = idx - z * mn;
-        const int m = (int)(r / N), n = (int)(r - (long)m * N);
-        double s = 0.0;
-        for (int k = 0; k < nsplit; ++k) s += ws[(z * nsplit + k) * mn + r];
-        const long z1 = z / nb2, z2 = z - z1 * nb2;
-        double* p = C + z1 * c_b1 + z2 * c_b2 + (long)m * ldc + n;
-        double v = alpha * s;
-        if (beta != 0.0) v += beta * (*p);
+// C tile = alpha * sum_ks ws[tile][ks] + beta * C tile, for the tiles [tile_begin, tile_begin + ntiles)
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmK g, int BM, int BN) {
+    const long lt = blockIdx.x;
+    const int tiles = g.tiles_m * g.tiles_n;
+    const long gt = g.tile_begin + lt;
+    const long z = gt / tiles;
+    const int t = (int)(gt - z * tiles);
+    constexpr int GROUP = 8;
+    const int group_sz = GROUP * g.tiles_n;
+    const int grp = t / group_sz;
+    const int first_m = grp * GROUP;
+    const int gm = min(g.tiles_m - first_m, GROUP);
+    const int tin = t - grp * group_sz;
+    const int tm = first_m + tin % gm;
+    const int tn = tin / gm;
+    const long z1 = z / g.nb2, z2 = z - z1 * g.nb2;
+    double* __restrict__ C = g.C + z1 * g.c_b1 + z2 * g.c_b2;
+    const double* __restrict__ W = g.ws + lt * g.nsplit * (long)(BM * BN);
+    for (int e = threadIdx.x; e < BM * BN; e += blockDim.x) {
+        const int r = e / BN, c = e - r * BN;
+        const int m = tm * BM + r, n = tn * BN + c;
+        if (m >= g.M || n >= g.N) continue;
+        double sum = 0.0;
+        for (int k = 0; k < g.nsplit; ++k) sum += W[(long)k * (BM * BN) + e];
+        double* p = C + (long)m * g.ldc + n;
+        double v = g.alpha * sum;
+        if (g.beta != 0.0) v += g.beta * (*p);
         *p = v;
     }
 }
@@ -602,6 +664,8 @@ void gemm(const Gemm& g, stream_t s) {
     k.nb2 = g.nb2;
     k.a_b1 = g.a_b1; k.a_b2 = g.a_b2; k.b_b1 = g.b_b1; k.b_b2 = g.b_b2; k.c_b1 = g.c_b1; k.c_b2 = g.c_b2;
     k.ws = nullptr;
+    static const int variant = getenv("PYMES_GEMM_VARIANT") ? atoi(getenv("PYMES_GEMM_VARIANT")) : 0;
+    k.variant = variant;
 
     // ---- tile shape: 128x128 unless a dimension is small -----------------------------
     int BM = 128, BN = 128;
@@ -613,27 +677,13 @@ void gemm(const Gemm& g, stream_t s) {
     if (BM == 128 && BN == 128 && ntiles(128, 128) < 256) { BM = 64; BN = 64; }
     else if (BM == 128 && BN == 64 && ntiles(128, 64) < 256) { BM = 64; }
     else if (BM == 64 && BN == 128 && ntiles(64, 128) < 256) { BN = 64; }
+    if (const char* ov = getenv("PYMES_GEMM_TILE")) {   // tuning experiments only
+        int bm = 0, bn = 0;
+        if (sscanf(ov, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) { BM = bm; BN = bn; }
+    }
     k.tiles_m = (int)((g.M + BM - 1) / BM);
     k.tiles_n = (int)((g.N + BN - 1) / BN);
     const long tiles = (long)k.tiles_m * k.tiles_n * nbatch;
-
-    // ---- split-K when the output has too few tiles to fill 256 CUs x 2 ----------------
-    int nsplit = 1;
-    const long ktiles = (g.K + BK - 1) / BK;
-    if (tiles < 256 && ktiles >= 16 && g.splitk_ws != nullptr) {
-        long want = (512 + tiles - 1) / tiles;
-        want = std::min<long>(want, ktiles / 8);          // >= 8 k-tiles (128 deep) per split
-        want = std::min<long>(want, 64);
-        const long fit = g.splitk_ws_doubles / std::max<long>(1, g.M * g.N * nbatch);
-        want = std::min<long>(want, fit);
-        if (want >= 2) nsplit = (int)want;
-    }
-    const long kt_per = (ktiles + nsplit - 1) / nsplit;
-    k.kchunk = (int)(kt_per * BK);
-    nsplit = (int)((ktiles + kt_per - 1) / kt_per);
-    if (nsplit < 1) nsplit = 1;
-    k.nsplit = nsplit;
-    if (nsplit > 1) k.ws = g.splitk_ws;
 
     // ---- 16-byte global loads need even strides/extents and aligned bases --------------
     int vec = 2;
@@ -645,8 +695,36 @@ void gemm(const Gemm& g, stream_t s) {
             !even(g.b_b2))
             vec = 1;
     }
-    const long nblocks = tiles * nsplit;
-    if (nblocks > 0x7fffffffL) throw std::runtime_error("gemm: grid too large");
+    if (tiles > 0x7fffffffL) throw std::runtime_error("gemm: grid too large");
+
+    // ---- k-splitting.  (1) whole problem when the output has too few tiles to fill the chip;
+    // (2) only the LAST, partially filled wave of tiles otherwise: tiles all cost the same, so a
+    // launch takes ceil(tiles/slots) tile-times; splitting the K range of the remainder tiles over
+    // the idle CUs turns that last wave into a fraction of a tile-time.
+    const long ktiles = (g.K + BK - 1) / BK;
+    const long slots = 256L * ((BM == 64 && BN == 64) ? 4 : 2);     // resident blocks on the chip
+    const long ws_tiles = g.splitk_ws ? g.splitk_ws_doubles / ((long)BM * BN) : 0;
+    long main_tiles = tiles, tail_tiles = 0;
+    int main_split = 1, tail_split = 1;
+    if (tiles < 256 && ktiles >= 16) {
+        long want = (512 + tiles - 1) / tiles;
+        want = std::min<long>(want, ktiles / 8);          // >= 8 k-tiles (128 deep) per split
+        want = std::min<long>(want, 64);
+        want = std::min<long>(want, ws_tiles / tiles);
+        if (want >= 2) main_split = (int)want;
+    } else if (tiles > slots && ktiles >= 64) {
+        const long rem = tiles % slots;
+        if (rem > 0 && rem <= slots / 2) {
+            long want = std::min<long>(slots / rem, 8);
+            want = std::min<long>(want, ktiles / 16);
+            want = std::min<long>(want, ws_tiles / rem);
+            if (want >= 2) {
+                tail_tiles = rem;
+                main_tiles = tiles - rem;
+                tail_split = (int)want;
+            }
+        }
+    }
 
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (g_prof.on) {
@@ -659,16 +737,25 @@ void gemm(const Gemm& g, stream_t s) {
         }
         HIP_CHECK(hipEventRecord(ev.first, st));
     }
-    if (BM == 128 && BN == 128) dispatch_layout<128, 128>(k, a_kcontig, b_kcontig, vec, nblocks, st);
-    else if (BM == 128 && BN == 64) dispatch_layout<128, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
-    else if (BM == 64 && BN == 128) dispatch_layout<64, 128>(k, a_kcontig, b_kcontig, vec, nblocks, st);
-    else dispatch_layout<64, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
-    if (nsplit > 1) {
-        const long total = g.M * g.N * nbatch;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, st, g.splitk_ws, g.C, g.ldc,
-                           (int)g.M, (int)g.N, nsplit, g.nb2, g.c_b1, g.c_b2, g.alpha, g.beta, total);
-        HIP_CHECK(hipGetLastError());
-    }
+    auto launch = [&](long tile_begin, long ntiles, int nsplit) {
+        const long kt_per = (ktiles + nsplit - 1) / nsplit;
+        k.kchunk = (int)std::max<long>(kt_per * BK, BK);
+        k.nsplit = (int)std::max<long>(1, (ktiles + kt_per - 1) / std::max<long>(kt_per, 1));
+        k.tile_begin = tile_begin;
+        k.ws = k.nsplit > 1 ? g.splitk_ws : nullptr;
+        const long nblocks = ntiles * k.nsplit;
+        if (BM == 128 && BN == 128) dispatch_layout<128, 128>(k, a_kcontig, b_kcontig, vec, nblocks, st);
+        else if (BM == 128 && BN == 64) dispatch_layout<128, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
+        else if (BM == 64 && BN == 128) dispatch_layout<64, 128>(k, a_kcontig, b_kcontig, vec, nblocks, st);
+        else dispatch_layout<64, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
+        if (k.nsplit > 1) {
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ntiles), dim3(256), 0, st, k, BM, BN);
+            HIP_CHECK(hipGetLastError());
+        }
+        return k.nsplit;
+    };
+    int nsplit = launch(0, main_tiles, main_split);
+    if (tail_tiles > 0) nsplit = -launch(main_tiles, tail_tiles, tail_split);   // logged as a negative split
     if (g_prof.on) {
         HIP_CHECK(hipEventRecord(ev.second, st));
         g_prof.ev.push_back(ev);

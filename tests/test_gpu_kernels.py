@@ -49,6 +49,18 @@ def test_dgemm_layouts_and_edges(ctx, a_kc, b_kc):
     _gemm_case(ctx, 151, 91, 78, a_kc, b_kc, 2.0, 0.25, rng, lda_pad=1, ldb_pad=3, ldc_pad=5)
 
 
+def test_dgemm_tail_wave_split(ctx):
+    """529 tiles of 128x128 = one full wave of 512 + 17: the remainder runs k-split (tile-local workspace)."""
+    rng = np.random.default_rng(7)
+    M = N = 2944
+    K = 1040
+    A, B = rng.standard_normal((M, K)), rng.standard_normal((K, N))
+    C0 = rng.standard_normal((M, N))
+    got = ctx.contract("mk,kn->mn", ctx.array(A), ctx.array(B), out=ctx.array(C0), alpha=0.5, beta=-1.0).get()
+    ref = 0.5 * (A @ B) - C0
+    assert np.abs(got - ref).max() < 1e-11
+
+
 def test_dgemm_identity_asymmetric(ctx):
     """A = I with an asymmetric B catches a transposed C fragment map (cdna guide §3)."""
     n = 64
