@@ -91,12 +91,22 @@ int pymes_ccsd_singles_residual(pymes_ctx* ctx, const double* fd_dev, const doub
  * PYMES_USE_DRESSED).  flags: */
 #define PYMES_DCD 1u          /* is_dcd / is_dcsd */
 #define PYMES_USE_DRESSED 2u  /* read the T1-dressed blocks instead of the undressed ones */
-#define PYMES_SKIP_LADDER 4u  /* leave out V_abcd.T (ccd.py:187) — it is added per a-slab by pymes_ladder */
+#define PYMES_SKIP_LADDER 4u  /* leave out V_abcd.T (ccd.py:187) — it is added per slab by pymes_ladder[_sym] */
+#define PYMES_SYM_LADDER 8u   /* evaluate V_abcd.T in pair-packed form (1/4 of the flops); requires
+                                 V_abcd = V_badc and T_cdij = T_dcji, true for every closed-shell solve that
+                                 starts from MP2 or from symmetric amplitudes */
 int pymes_doubles_residual(pymes_ctx* ctx, const double* f_dev, const double* t2_dev, double* r2_dev,
                            uint32_t flags);
 /* the particle-particle ladder on an a-slab (ccd.py:187): R[a0:a1] = beta*R[a0:a1] + V_abcd[a0:a1].T */
 int pymes_ladder(pymes_ctx* ctx, const double* t2_dev, double* r2_dev, int a_begin, int a_end, int dressed,
                  double beta);
+/* pair-packed form of the same term.  L is [v(v+1)/2][o*o] on the device; row r = P(a,b) = a(a+1)/2+b
+ * (a >= b) holds [ LS (o(o+1)/2 entries, P(i,j)) | LA (o(o-1)/2 entries, Q(i,j) = i(i-1)/2+j) ].
+ * pymes_ladder_sym fills rows [row_begin,row_end) (the shardable unit); pymes_ladder_sym_unpack adds
+ * R[a,b,i,j] = beta R + LS + sgn(a-b) sgn(i-j) LA from a complete L. */
+int pymes_ladder_sym(pymes_ctx* ctx, const double* t2_dev, double* L_dev, int64_t row_begin, int64_t row_end,
+                     int dressed);
+int pymes_ladder_sym_unpack(pymes_ctx* ctx, const double* L_dev, double* r2_dev, double beta);
 /* ccsd.py:176-179 / ccd.py:123-124: dt = r/(D+shift) (as r * (1/(D+shift))), t += delta*dt; rank 2 or 4 */
 int pymes_cc_update(pymes_ctx* ctx, double* t_dev, double* dt_dev, const double* r_dev, double level_shift,
                     double delta, int rank);

@@ -10,6 +10,7 @@
 //   Tx[(a,j),(b,i)] = T[a,b,i,j]   "crossed" pairing     (labels "ajbi")
 // so that every ring/exchange term of ccd.py:190-240 is a plain product of two such
 // matrices (possibly transposed), with no per-term transposition of the operands.
+#include <algorithm>
 #include <cstring>
 
 #include "engine.h"
@@ -66,7 +67,7 @@ void Engine::mp2(double shift, double* t2, double e_out[2]) {
 // ccd.py:164-254  (the doubles residual; also the CCSD one via dressed blocks, ccsd.py:440-456)
 // -----------------------------------------------------------------------------------
 void Engine::doubles_residual(const double* f, const double* t2, double* r2, unsigned flags) {
-    const bool dcd = flags & 1u, dressed = flags & 2u, skip_ladder = flags & 4u;
+    const bool dcd = flags & 1u, dressed = flags & 2u, skip_ladder = flags & 4u, sym_ladder = flags & 8u;
     const bool quad = !dcd;
     const int64_t o = no, v = nv, nn = n;
     const double w = quad ? 1.0 : 0.5;                                                      // :213-220
@@ -100,7 +101,16 @@ void Engine::doubles_residual(const double* f, const double* t2, double* r2, uns
         if (quad) contract(1.0, Vijab, "klcd", T, "cdij", 1.0, hole, "klij");                // :180
         contract(1.0, hole, "klij", T, "abkl", 1.0, R, "abij");                             // :186
     }
-    if (!skip_ladder) contract(1.0, block(P_abcd, dressed), "abcd", T, "cdij", 1.0, R, "abij");   // :187
+    if (!skip_ladder) {                                                                     // :187
+        if (sym_ladder) {
+            ArenaScope s2(arena);
+            double* L = arena.alloc(v * (v + 1) / 2 * o * o);
+            ladder_sym(t2, L, 0, v * (v + 1) / 2, dressed);
+            ladder_sym_unpack(L, r2, 1.0);
+        } else {
+            contract(1.0, block(P_abcd, dressed), "abcd", T, "cdij", 1.0, R, "abij");
+        }
+    }
 
     // ---- X_ac, X_ki (:206-221) ------------------------------------------------------------
     TView Xvv = make_view(arena.alloc(v * v), {v, v}), Xoo = make_view(arena.alloc(o * o), {o, o});
@@ -175,6 +185,55 @@ void Engine::ladder(const double* t2, double* r2, int a0, int a1, bool dressed, 
     TView R = slice(make_view(r2, {v, v, o, o}), 0, a0, a1);
     TView Vs = slice(block(P_abcd, dressed), 0, a0, a1);
     contract(1.0, Vs, "abcd", T, "cdij", beta, R, "abij");                                   // ccd.py:187
+}
+
+// Pair-packed ladder.  With V_abcd = V_badc (electron exchange) and T_cdij = T_dcji:
+//   L_abij = LS_(ab)(ij) + sgn(a-b) sgn(i-j) LA_(ab)(ij),
+//   LS = sum_{c>=d} (V_abcd + V_abdc) f_cd (T_cdij + T_dcij)/2,   LA = sum_{c>d} (V_abcd - V_abdc) (T_cdij - T_dcij)/2
+// for a >= b, i >= j only: two GEMMs of v(v+1)/2 x v(v+-1)/2 x o(o+-1)/2 = 1/4 of the flops of ccd.py:187.
+void Engine::ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1, bool dressed) {
+    const int64_t o = no, v = nv, npp = v * (v + 1) / 2, npm = v * (v - 1) / 2, opp = o * (o + 1) / 2,
+                  opm = o * (o - 1) / 2;
+    if (row0 < 0 || row1 > npp || row0 > row1) throw Error("ladder_sym: bad pair-row range");
+    if (row0 == row1) return;
+    const int64_t rows = row1 - row0;
+    if (!(lpack_.valid && lpack_.dressed == dressed && lpack_.row0 == row0 && lpack_.row1 == row1)) {
+        if (!lpack_.Vp || lpack_.row1 - lpack_.row0 != rows) {
+            dev::stream_sync(stream);
+            dev::dfree(lpack_.Vp);
+            dev::dfree(lpack_.Vm);
+            lpack_.Vp = lpack_.Vm = nullptr;
+            lpack_.Vp = static_cast<double*>(dev::dmalloc(sizeof(double) * rows * npp));
+            lpack_.Vm = static_cast<double*>(dev::dmalloc(sizeof(double) * rows * std::max<int64_t>(npm, 1)));
+        }
+        dev::ladder_pack_V(block(P_abcd, dressed).p, lpack_.Vp, lpack_.Vm, nv, row0, row1, stream);
+        stats.permute_calls++;
+        stats.permute_bytes += 8.0 * 2.0 * double(rows) * double(v * v);
+        lpack_.row0 = row0; lpack_.row1 = row1; lpack_.dressed = dressed; lpack_.valid = true;
+    }
+    ArenaScope scope(arena);
+    double* Sp = arena.alloc(npp * opp);
+    double* Am = arena.alloc(std::max<int64_t>(npm * opm, 1));
+    dev::ladder_pack_T(t2, Sp, Am, no, nv, stream);
+    stats.permute_calls++;
+    stats.permute_bytes += 8.0 * 2.0 * double(v * v * o * o);
+    // L rows [row0,row1): [ LS (opp) | LA (opm) ], row length o*o
+    TView Lrows = make_view(L + row0 * o * o, {rows, o * o});
+    contract(1.0, make_view(lpack_.Vp, {rows, npp}), "rk", make_view(Sp, {npp, opp}), "kn", 0.0,
+             slice(Lrows, 1, 0, opp), "rn");
+    if (opm > 0) {
+        if (npm > 0)
+            contract(1.0, make_view(lpack_.Vm, {rows, npm}), "rk", make_view(Am, {npm, opm}), "kn", 0.0,
+                     slice(Lrows, 1, opp, o * o), "rn");
+        else
+            zero(slice(Lrows, 1, opp, o * o));
+    }
+}
+
+void Engine::ladder_sym_unpack(const double* L, double* r2, double beta) {
+    dev::ladder_unpack(L, r2, beta, no, nv, stream);
+    stats.permute_calls++;
+    stats.permute_bytes += 8.0 * 2.5 * double(nv) * nv * no * no;
 }
 
 // -----------------------------------------------------------------------------------
@@ -278,6 +337,7 @@ void Engine::dress_V(const double* t1, uint32_t mask) {
         if (pat >> 3 & 1) pos.push_back(0);      // bra p virtual
         TView dst = block_view(ensure_dressed(pat), pat);
         dressed_into(pat, pos, static_cast<int>(pos.size()), t, dst);
+        if (pat == P_abcd && lpack_.dressed) lpack_.valid = false;
     }
 }
 

@@ -74,4 +74,17 @@ void dots(int npairs, const double* const* x, const double* const* y, int64_t n,
 void lincomb(double* out, int nx, const double* const* x, const double* c, int64_t n, stream_t s);
 // tau[a,b,i,j] = t2[a,b,i,j] + t1[a,i]*t1[b,j]                        (ccsd.py:462)
 void tau_build(double* tau, const double* t2, const double* t1, int no, int nv, stream_t s);
+
+// ---- symmetry-packed particle-particle ladder (ccd.py:187 with V_abcd = V_badc, T_cdij = T_dcji) --
+// pair indices: P(x,y) = x(x+1)/2 + y for x >= y ("plus"), Q(x,y) = x(x-1)/2 + y for x > y ("minus").
+// For the pair rows r = P(a,b) in [rp0, rp1):
+//   Vp[r - rp0][P(c,d)] = V[a,b,c,d] + V[a,b,d,c]
+//   Vm[r - rp0][Q(c,d)] = V[a,b,c,d] - V[a,b,d,c]   (zero row when a == b)
+void ladder_pack_V(const double* V, double* Vp, double* Vm, int nv, int64_t rp0, int64_t rp1, stream_t s);
+// Sp[P(c,d)][P(i,j)] = f_cd (T[c,d,i,j] + T[d,c,i,j]) / 2, f = 1/2 on c == d;  Am[Q(c,d)][Q(i,j)] = (T[c,d,i,j] - T[d,c,i,j]) / 2
+void ladder_pack_T(const double* T, double* Sp, double* Am, int no, int nv, stream_t s);
+// L[P(a,b)] = [ LS row (o(o+1)/2) | LA row (o(o-1)/2) ], row length o*o:
+// R[a,b,i,j] = beta R + LS[P(ab)][P(ij)] + sgn(a-b) sgn(i-j) LA[P(ab)][Q(ij)]
+void ladder_unpack(const double* L, double* R, double beta, int no, int nv, stream_t s);
+
 }  // namespace dev

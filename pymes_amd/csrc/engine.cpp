@@ -115,6 +115,8 @@ Engine::~Engine() {
         for (auto& p : Vd_) dev::dfree(p);
         for (auto& kv : static_) dev::dfree(kv.second);
         dev::dfree(splitk_ws_);
+        dev::dfree(lpack_.Vp);
+        dev::dfree(lpack_.Vm);
         dev::dfree(eps_o);
         dev::dfree(eps_v);
         arena.release();
@@ -125,6 +127,7 @@ Engine::~Engine() {
 void Engine::invalidate_static() {
     for (auto& kv : static_) dev::dfree(kv.second);
     static_.clear();
+    lpack_.valid = false;
 }
 
 int64_t Engine::block_size(int pattern) const {

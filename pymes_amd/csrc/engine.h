@@ -107,10 +107,15 @@ class Engine {
     void dress_fock(const double* f, const double* t1, double* fd);                           // ccsd.py:226-288
     void dress_V(const double* t1, uint32_t mask);                                            // ccsd.py:290-421
     void singles_residual(const double* fd, const double* t1, const double* t2, double* r1);  // ccsd.py:423-438
-    // ccd.py:164-254; flags: bit0 = DCD/DCSD, bit1 = use dressed blocks, bit2 = skip ladder
+    // ccd.py:164-254; flags: bit0 = DCD/DCSD, bit1 = use dressed blocks, bit2 = skip ladder,
+    // bit3 = pair-packed ladder (T and V exchange-symmetric)
     void doubles_residual(const double* f, const double* t2, double* r2, unsigned flags);
     // R[a0:a1,:,:,:] = beta*R + V_abcd[a0:a1] . T    (ccd.py:187; the sharded term)
     void ladder(const double* t2, double* r2, int a0, int a1, bool dressed, double beta);
+    // the same term at 1/4 of the flops, valid when V_abcd = V_badc and T_cdij = T_dcji:
+    // rows [row0,row1) of the pair-packed result L[v(v+1)/2][o*o] (device_api.h), then R = beta R + unpack(L)
+    void ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1, bool dressed);
+    void ladder_sym_unpack(const double* L, double* r2, double beta);
     void cc_update(double* t, double* dt, const double* r, double shift, double delta, int rank);  // ccsd.py:176-179
     void ccsd_energy(const double* f, const double* t1, const double* t2, double out[3]);     // ccsd.py:458-466
     void ccd_energy(const double* t2, double out[2]);                                         // ccd.py:256-262
@@ -125,6 +130,12 @@ class Engine {
     double* V_[16] = {nullptr};      // undressed blocks (owned)
     double* Vd_[16] = {nullptr};     // dressed blocks (owned, allocated on demand)
     std::map<std::string, double*> static_;   // cached permutations of static blocks (owned)
+    struct LadderPack {   // V^+ / V^- rows of the pair-packed ladder
+        double* Vp = nullptr;
+        double* Vm = nullptr;
+        int64_t row0 = 0, row1 = 0;
+        bool dressed = false, valid = false;
+    } lpack_;
     double* splitk_ws_ = nullptr;
     int64_t splitk_doubles_ = 0;
     double* get_static(const std::string& key);

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
@@ -529,6 +530,91 @@ __global__ void tau_kernel(double* __restrict__ tau, const double* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------
+// symmetry-packed ladder helpers
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void unrank_pair(long r, int& x, int& y) {   // r = x(x+1)/2 + y, x >= y
+    long xx = (long)((sqrt(8.0 * (double)r + 1.0) - 1.0) * 0.5);
+    while (xx * (xx + 1) / 2 > r) --xx;
+    while ((xx + 1) * (xx + 2) / 2 <= r) ++xx;
+    x = (int)xx;
+    y = (int)(r - xx * (xx + 1) / 2);
+}
+
+__global__ void __launch_bounds__(256) ladder_pack_V_kernel(const double* __restrict__ V, double* __restrict__ Vp,
+                                                            double* __restrict__ Vm, int nv, long rp0,
+                                                            int nt, long ntp) {
+    __shared__ double sA[32][33], sB[32][33];
+    const long bid = blockIdx.x;
+    const long row = bid / ntp;               // local pair row
+    const long tp = bid - row * ntp;          // tile pair (tc >= td)
+    int a, b, tc, td;
+    unrank_pair(rp0 + row, a, b);
+    unrank_pair(tp, tc, td);
+    const long npp = (long)nv * (nv + 1) / 2, npm = (long)nv * (nv - 1) / 2;
+    const double* __restrict__ Vab = V + ((long)a * nv + b) * nv * nv;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = tc * 32, d0 = td * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int y = ty + 8 * j;
+        if (c0 + y < nv && d0 + tx < nv) sA[y][tx] = Vab[(long)(c0 + y) * nv + d0 + tx];     // V[a,b,c,d]
+        if (d0 + y < nv && c0 + tx < nv) sB[y][tx] = Vab[(long)(d0 + y) * nv + c0 + tx];     // V[a,b,d,c]
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int y = ty + 8 * j;
+        const int c = c0 + y, d = d0 + tx;
+        if (c < nv && d < nv && c >= d) {
+            const double x1 = sA[y][tx], x2 = sB[tx][y];
+            Vp[row * npp + (long)c * (c + 1) / 2 + d] = x1 + x2;
+            if (c > d) Vm[row * npm + (long)c * (c - 1) / 2 + d] = (a > b) ? x1 - x2 : 0.0;   // zero rows for a == b
+        }
+    }
+}
+
+__global__ void ladder_pack_T_kernel(const double* __restrict__ T, double* __restrict__ Sp, double* __restrict__ Am,
+                                     int no, int nv) {
+    const long row = blockIdx.x;   // P(c,d)
+    int c, d;
+    unrank_pair(row, c, d);
+    const long o2 = (long)no * no, opp = (long)no * (no + 1) / 2, opm = (long)no * (no - 1) / 2;
+    const double* __restrict__ T1 = T + ((long)c * nv + d) * o2;
+    const double* __restrict__ T2 = T + ((long)d * nv + c) * o2;
+    const double f = (c == d) ? 0.25 : 0.5;
+    const long mrow = (long)c * (c - 1) / 2 + d;
+    for (int e = threadIdx.x; e < o2; e += blockDim.x) {
+        const int i = e / no, j = e - i * no;
+        if (i < j) continue;
+        const double x1 = T1[e], x2 = T2[e];
+        Sp[row * opp + (long)i * (i + 1) / 2 + j] = f * (x1 + x2);
+        if (c > d && i > j) Am[mrow * opm + (long)i * (i - 1) / 2 + j] = 0.5 * (x1 - x2);
+    }
+}
+
+// L[P(a,b)][0:opp] = LS, L[P(a,b)][opp:opp+opm] = LA (rows of diagonal pairs carry zeros there)
+__global__ void ladder_unpack_kernel(const double* __restrict__ L, double* __restrict__ R, double beta, int no,
+                                     int nv, long total) {
+    const long opp = (long)no * (no + 1) / 2, ld = (long)no * no;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        long r = idx;
+        const int j = (int)(r % no); r /= no;
+        const int i = (int)(r % no); r /= no;
+        const int b = (int)(r % nv);
+        const int a = (int)(r / nv);
+        const int ah = max(a, b), al = min(a, b), ih = max(i, j), il = min(i, j);
+        const double* __restrict__ row = L + ((long)ah * (ah + 1) / 2 + al) * ld;
+        double v = row[(long)ih * (ih + 1) / 2 + il];
+        if (a != b && i != j) {
+            const double x = row[opp + (long)ih * (ih - 1) / 2 + il];
+            v += ((a > b) == (i > j)) ? x : -x;
+        }
+        R[idx] = (beta != 0.0) ? beta * R[idx] + v : v;
+    }
+}
+
 inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
     long g = (total + block - 1) / block;
     return (int)std::max<long>(1, std::min<long>(g, cap));
@@ -875,6 +961,30 @@ void tau_build(double* tau, const double* t2, const double* t1, int no, int nv, 
     const long total = (long)nv * nv * no * no;
     if (!total) return;
     hipLaunchKernelGGL(tau_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, tau, t2, t1, no, nv, total);
+    HIP_CHECK(hipGetLastError());
+}
+
+void ladder_pack_V(const double* V, double* Vp, double* Vm, int nv, int64_t rp0, int64_t rp1, stream_t s) {
+    if (rp1 <= rp0) return;
+    const int nt = (nv + 31) / 32;
+    const long ntp = (long)nt * (nt + 1) / 2;
+    const long nblk = (rp1 - rp0) * ntp;
+    if (nblk > 0x7fffffffL) throw std::runtime_error("ladder_pack_V: grid too large");
+    hipLaunchKernelGGL(ladder_pack_V_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)s, V, Vp, Vm, nv,
+                       (long)rp0, nt, ntp);
+    HIP_CHECK(hipGetLastError());
+}
+
+void ladder_pack_T(const double* T, double* Sp, double* Am, int no, int nv, stream_t s) {
+    const long npp = (long)nv * (nv + 1) / 2;
+    hipLaunchKernelGGL(ladder_pack_T_kernel, dim3((unsigned)npp), dim3(256), 0, (hipStream_t)s, T, Sp, Am, no, nv);
+    HIP_CHECK(hipGetLastError());
+}
+
+void ladder_unpack(const double* L, double* R, double beta, int no, int nv, stream_t s) {
+    const long total = (long)nv * nv * no * no;
+    hipLaunchKernelGGL(ladder_unpack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, L, R, beta, no, nv,
+                       total);
     HIP_CHECK(hipGetLastError());
 }
 

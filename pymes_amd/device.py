@@ -241,9 +241,9 @@ class Context:
                       C.c_void_p(t2.ptr), C.c_void_p(out.ptr))
         return out
 
-    def doubles_residual(self, f, t2, out, is_dcd=False, dressed=False, skip_ladder=False):
+    def doubles_residual(self, f, t2, out, is_dcd=False, dressed=False, skip_ladder=False, sym_ladder=False):
         flags = (_lib.PYMES_DCD if is_dcd else 0) | (_lib.PYMES_USE_DRESSED if dressed else 0) | \
-                (_lib.PYMES_SKIP_LADDER if skip_ladder else 0)
+                (_lib.PYMES_SKIP_LADDER if skip_ladder else 0) | (_lib.PYMES_SYM_LADDER if sym_ladder else 0)
         self.lib.call("pymes_doubles_residual", self.handle, C.c_void_p(f.ptr), C.c_void_p(t2.ptr),
                       C.c_void_p(out.ptr), flags)
         return out
@@ -251,6 +251,16 @@ class Context:
     def ladder(self, t2, out, a_begin, a_end, dressed=False, beta=0.0):
         self.lib.call("pymes_ladder", self.handle, C.c_void_p(t2.ptr), C.c_void_p(out.ptr), int(a_begin), int(a_end),
                       int(dressed), float(beta))
+        return out
+
+    def ladder_sym(self, t2, L, row_begin, row_end, dressed=False):
+        """Rows [row_begin,row_end) of the pair-packed ladder L[v(v+1)/2, o*o] (include/pymes_amd.h)."""
+        self.lib.call("pymes_ladder_sym", self.handle, C.c_void_p(t2.ptr), C.c_void_p(L.ptr), int(row_begin),
+                      int(row_end), int(dressed))
+        return L
+
+    def ladder_sym_unpack(self, L, out, beta=1.0):
+        self.lib.call("pymes_ladder_sym_unpack", self.handle, C.c_void_p(L.ptr), C.c_void_p(out.ptr), float(beta))
         return out
 
     def cc_update(self, t, dt, r, level_shift=0.0, delta=1.0):

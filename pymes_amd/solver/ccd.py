@@ -64,8 +64,11 @@ class CCD:
             e_dir, e_exc = ctx.mp2(t2, level_shift)
             e_mp2 = e_dir + e_exc
             print("MP2 energy = ", e_mp2)
+            sym = True      # pair-packed ladder needs T_abij = T_baji: true for MP2, checked for user input
             if amps is not None:
-                t2.set(np.asarray(amps))
+                t2h = np.asarray(amps)
+                sym = bool(np.abs(t2h - t2h.transpose(1, 0, 3, 2)).max() <= 1e-13 * max(1.0, np.abs(t2h).max()))
+                t2.set(t2h)
             dE = np.abs(e_mp2)
             iteration = 0
             e_last = e_mp2
@@ -74,7 +77,7 @@ class CCD:
             while np.abs(dE) > delta_e and iteration <= max_iter:
                 iteration += 1
                 r2 = ctx.pool_get(t2.shape)
-                ctx.doubles_residual(f_dev, t2, r2, is_dcd=self.is_dcd)           # ccd.py:100-102
+                ctx.doubles_residual(f_dev, t2, r2, is_dcd=self.is_dcd, sym_ladder=sym)    # ccd.py:100-102
                 dt2 = ctx.pool_get(t2.shape)
                 ctx.cc_update(t2, dt2, r2, level_shift, delta)                    # :123-124
                 ctx.pool_put(r2)

@@ -18,6 +18,13 @@ from pymes_amd.log import print_logging_info
 from pymes_amd.mixer import diis
 from pymes_amd.solver import ccd
 
+
+def torch_sync():
+    """torch.distributed collectives are ordered on torch's current stream; the engine runs on the same
+    stream (bench.py passes it) but a host-side fence keeps the hand-off obviously correct."""
+    import torch
+    torch.cuda.current_stream().synchronize()
+
 # blocks produced by get_T1_dressed_V (ccsd.py:322-419); the other five names stay None (:317)
 DRESSED_KEYS = ("abij", "klij", "ijab", "ijka", "ijak", "iajb", "iabj", "iabc", "abic", "iajk", "abcd")
 # what the T2 residual consumes (ccsd.py:449-454); ijab is a plain copy (:355-357) and is read undressed
@@ -65,11 +72,20 @@ class CCSD(ccd.CCD):
             t1.set(np.asarray(amps[0]))
             t2.set(np.asarray(amps[1]))
         st["t1"], st["t2"] = t1, t2
+        # pair-packed ladder (1/4 of the flops) whenever T2 has the exchange symmetry T_abij = T_baji,
+        # i.e. always when starting from MP2; user amplitudes are checked
+        st["sym"] = True
+        if amps is not None:
+            t2h = np.asarray(amps[1])
+            st["sym"] = bool(np.abs(t2h - t2h.transpose(1, 0, 3, 2)).max() <= 1e-13 * max(1.0, np.abs(t2h).max()))
         if wsize > 1:
             import torch
             dev = torch.device("cuda", ctx.device)
-            st["lad_t"] = torch.zeros((nv, nv * no * no), dtype=torch.float64, device=dev)
-            st["lad"] = DeviceArray(ctx, st["lad_t"].data_ptr(), (nv, nv, no, no), owned=False, keepalive=st["lad_t"])
+            rows = nv * (nv + 1) // 2 if st["sym"] else nv * nv
+            st["lad_rows"] = rows
+            st["lad_t"] = torch.zeros((pdist.padded_rows(rows, wsize), no * no), dtype=torch.float64, device=dev)
+            st["lad"] = DeviceArray(ctx, st["lad_t"].data_ptr(), tuple(st["lad_t"].shape), owned=False,
+                                    keepalive=st["lad_t"])
         return st
 
     def iterate(self, st):
@@ -82,18 +98,24 @@ class CCSD(ccd.CCD):
         ctx.singles_residual(st["fd"], t1, t2, r1)                  # :167
         r2 = ctx.pool_get(t2.shape)
         if st["world"] == 1:
-            ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True)       # :171
+            ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True, sym_ladder=st["sym"])   # :171
         else:
-            # a-slab of the ladder on this rank; everything else replicated; one collective
-            lo, hi = pdist.slab_bounds(ctx.nv, st["rank"], st["world"])
-            if ctx.nv % st["world"] != 0:
-                st["lad"].zero_()
-            ctx.ladder(t2, st["lad"], lo, hi, dressed=True, beta=0.0)
+            # this rank's chunk of ladder rows; everything else replicated; ONE all-gather per iteration
+            lo, hi = pdist.slab_rows(st["lad_rows"], st["rank"], st["world"])
+            if st["sym"]:
+                ctx.ladder_sym(t2, st["lad"], lo, hi, dressed=True)
+            elif hi > lo:      # plain form: rows (a,b) of R = a-slabs when nv*nv rows are cut at multiples of nv
+                self._ladder_rows_plain(ctx, t2, st["lad"], lo, hi)
             ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True, skip_ladder=True)
-            self._sync_with_torch(ctx)
-            pdist.exchange_slabs(st["lad_t"], ctx.nv, st["rank"], st["world"])
-            self._sync_with_torch(ctx, after=True)
-            ctx.lincomb(r2, [r2, st["lad"]], [1.0, 1.0])
+            ctx.sync()
+            pdist.exchange_rows(st["lad_t"], st["rank"], st["world"])
+            torch_sync()
+            if st["sym"]:
+                ctx.ladder_sym_unpack(st["lad"], r2, beta=1.0)
+            else:
+                full = st["lad"].reshape(st["lad"].size)
+                r2f = r2.reshape(r2.size)
+                ctx.lincomb(r2f, [r2f, DeviceArray(ctx, full.ptr, (r2.size,), owned=False, keepalive=full)], [1.0, 1.0])
         dt1, dt2 = ctx.pool_get(t1.shape), ctx.pool_get(t2.shape)
         ctx.cc_update(t1, dt1, r1, shift, self.delta)               # :176-179
         ctx.cc_update(t2, dt2, r2, shift, self.delta)
@@ -114,14 +136,13 @@ class CCSD(ccd.CCD):
         return e[0], e[1], e[2], nt, nr
 
     @staticmethod
-    def _sync_with_torch(ctx, after=False):
-        """The engine and torch.distributed must agree on stream order: the context runs on torch's
-        current stream when one is set (bench.py does); otherwise fall back to a full sync."""
-        import torch
-        if after:
-            torch.cuda.current_stream().synchronize()
-        else:
-            ctx.sync()
+    def _ladder_rows_plain(ctx, t2, lad, lo, hi):
+        """Rows [lo,hi) of R[(a,b),(i,j)] = V[(a,b),(c,d)] T[(c,d),(i,j)] (unsymmetric amplitudes only)."""
+        nv, no = ctx.nv, ctx.no
+        Vab = ctx.V_block("abcd", dressed=True).reshape(nv * nv, nv * nv)
+        rows = DeviceArray(ctx, Vab.ptr + 8 * lo * nv * nv, (hi - lo, nv * nv), owned=False, keepalive=Vab)
+        out = DeviceArray(ctx, lad.ptr + 8 * lo * no * no, (hi - lo, no * no), owned=False, keepalive=lad)
+        ctx.contract("rk,kn->rn", rows, t2.reshape(nv * nv, no * no), out=out)
 
     def solve(self, t_fock_pq, t_V_pqrs, level_shift=0., amps=None, sp=0, **kwargs):
         """ccsd.py:47-224."""

@@ -136,4 +136,53 @@ void tau_build(double* tau, const double* t2, const double* t1, int no, int nv, 
                 for (int j = 0; j < no; ++j, ++idx) tau[idx] = t2[idx] + t1[a * no + i] * t1[b * no + j];
 }
 
+static inline int64_t P2(int64_t x, int64_t y) { return x * (x + 1) / 2 + y; }
+static inline int64_t Q2(int64_t x, int64_t y) { return x * (x - 1) / 2 + y; }
+
+void ladder_pack_V(const double* V, double* Vp, double* Vm, int nv, int64_t rp0, int64_t rp1, stream_t) {
+    const int64_t npp = (int64_t)nv * (nv + 1) / 2, npm = (int64_t)nv * (nv - 1) / 2;
+    for (int a = 0; a < nv; ++a)
+        for (int b = 0; b <= a; ++b) {
+            const int64_t r = P2(a, b);
+            if (r < rp0 || r >= rp1) continue;
+            const double* Vab = V + ((int64_t)a * nv + b) * nv * nv;
+            for (int c = 0; c < nv; ++c)
+                for (int d = 0; d <= c; ++d) {
+                    const double x1 = Vab[(int64_t)c * nv + d], x2 = Vab[(int64_t)d * nv + c];
+                    Vp[(r - rp0) * npp + P2(c, d)] = x1 + x2;
+                    if (c > d) Vm[(r - rp0) * npm + Q2(c, d)] = a > b ? x1 - x2 : 0.0;
+                }
+        }
+}
+
+void ladder_pack_T(const double* T, double* Sp, double* Am, int no, int nv, stream_t) {
+    const int64_t o2 = (int64_t)no * no, opp = (int64_t)no * (no + 1) / 2, opm = (int64_t)no * (no - 1) / 2;
+    for (int c = 0; c < nv; ++c)
+        for (int d = 0; d <= c; ++d)
+            for (int i = 0; i < no; ++i)
+                for (int j = 0; j <= i; ++j) {
+                    const double x1 = T[((int64_t)c * nv + d) * o2 + i * no + j], x2 = T[((int64_t)d * nv + c) * o2 + i * no + j];
+                    Sp[P2(c, d) * opp + P2(i, j)] = (c == d ? 0.25 : 0.5) * (x1 + x2);
+                    if (c > d && i > j) Am[Q2(c, d) * opm + Q2(i, j)] = 0.5 * (x1 - x2);
+                }
+}
+
+void ladder_unpack(const double* L, double* R, double beta, int no, int nv, stream_t) {
+    const int64_t opp = (int64_t)no * (no + 1) / 2, ld = (int64_t)no * no;
+    int64_t idx = 0;
+    for (int a = 0; a < nv; ++a)
+        for (int b = 0; b < nv; ++b)
+            for (int i = 0; i < no; ++i)
+                for (int j = 0; j < no; ++j, ++idx) {
+                    const int ah = a > b ? a : b, al = a > b ? b : a, ih = i > j ? i : j, il = i > j ? j : i;
+                    const double* row = L + P2(ah, al) * ld;
+                    double v = row[P2(ih, il)];
+                    if (a != b && i != j) {
+                        const double x = row[opp + Q2(ih, il)];
+                        v += ((a > b) == (i > j)) ? x : -x;
+                    }
+                    R[idx] = beta != 0.0 ? beta * R[idx] + v : v;
+                }
+}
+
 }  // namespace dev

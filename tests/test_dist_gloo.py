@@ -13,14 +13,18 @@ import torch.multiprocessing as mp
 from pymes_amd import dist as pdist
 
 
-def test_slab_bounds_cover_range():
-    for nv in (1, 7, 25, 200, 203):
+def test_slab_rows_cover_range():
+    for n in (1, 7, 25, 200, 203, 20100):
         for w in (1, 2, 3, 8):
-            b = [pdist.slab_bounds(nv, r, w) for r in range(w)]
-            assert b[0][0] == 0 and b[-1][1] == nv
+            b = [pdist.slab_rows(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
-            sizes = [hi - lo for lo, hi in b]
-            assert max(sizes) - min(sizes) <= 1
+            c = pdist.chunk_rows(n, w)
+            assert all(hi - lo <= c for lo, hi in b) and pdist.padded_rows(n, w) == c * w >= n
+
+
+def _pairs(n):
+    return [(x, y) for x in range(n) for y in range(x + 1)]
 
 
 def _worker(rank, world, port, nv, no, out):
@@ -30,14 +34,46 @@ def _worker(rank, world, port, nv, no, out):
     try:
         rng = np.random.default_rng(0)
         V = rng.standard_normal((nv, nv, nv, nv))
+        V = 0.5 * (V + V.transpose(1, 0, 3, 2))           # V_abcd = V_badc
         T = rng.standard_normal((nv, nv, no, no))
-        lo, hi = pdist.slab_bounds(nv, rank, world)
-        full = torch.zeros((nv, nv * no * no), dtype=torch.float64)
-        full[lo:hi] = torch.from_numpy(np.einsum("abcd,cdij->abij", V[lo:hi], T).reshape(hi - lo, -1))
+        T = 0.5 * (T + T.transpose(1, 0, 3, 2))           # T_cdij = T_dcji
+        ref = np.einsum("abcd,cdij->abij", V, T)
         assert pdist.world()[:2] == (rank, world)
-        pdist.exchange_slabs(full, nv, rank, world)
-        ref = np.einsum("abcd,cdij->abij", V, T).reshape(nv, -1)
-        out[rank] = float(np.abs(full.numpy() - ref).max())
+        # (1) plain rows (a,b) of R
+        rows = nv * nv
+        lo, hi = pdist.slab_rows(rows, rank, world)
+        full = torch.zeros((pdist.padded_rows(rows, world), no * no), dtype=torch.float64)
+        full[lo:hi] = torch.from_numpy(V.reshape(rows, -1)[lo:hi] @ T.reshape(nv * nv, -1))
+        pdist.exchange_rows(full, rank, world)
+        err1 = float(np.abs(full.numpy()[:rows] - ref.reshape(rows, -1)).max())
+        # (2) pair-packed rows P(a,b): the oracle's ladder restricted to a >= b, i >= j
+        pr = _pairs(nv)
+        lo, hi = pdist.slab_rows(len(pr), rank, world)
+        L = torch.zeros((pdist.padded_rows(len(pr), world), no * no), dtype=torch.float64)
+        for r in range(lo, hi):
+            a, b = pr[r]
+            k = 0
+            for i, j in _pairs(no):
+                L[r, k] = 0.5 * (ref[a, b, i, j] + ref[a, b, j, i]); k += 1          # LS
+            for i, j in _pairs(no):
+                if i > j:
+                    L[r, k] = 0.5 * (ref[a, b, i, j] - ref[a, b, j, i]); k += 1      # LA
+        pdist.exchange_rows(L, rank, world)
+        Ln = L.numpy()
+        opp = no * (no + 1) // 2
+        rec = np.zeros_like(ref)
+        for a in range(nv):
+            for b in range(nv):
+                row = Ln[max(a, b) * (max(a, b) + 1) // 2 + min(a, b)]
+                for i in range(no):
+                    for j in range(no):
+                        ih, il = max(i, j), min(i, j)
+                        v = row[ih * (ih + 1) // 2 + il]
+                        if a != b and i != j:
+                            x = row[opp + ih * (ih - 1) // 2 + il]
+                            v += x if (a > b) == (i > j) else -x
+                        rec[a, b, i, j] = v
+        out[rank] = max(err1, float(np.abs(rec - ref).max()))
     finally:
         dist.destroy_process_group()
 
@@ -47,5 +83,5 @@ def test_exchange_two_ranks(nv):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, port, nv, 2, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, nv, 3, out), nprocs=2, join=True)
     assert len(out) == 2 and max(out.values()) < 1e-12

@@ -107,3 +107,41 @@ def test_factor_built_integrals(gpu_lib):
             assert np.abs(ctx.V_block(nm).get() - blk).max() < 1e-13, nm
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("no,nv,seed", [(1, 1, 1), (2, 3, 2), (5, 9, 3), (8, 24, 4), (7, 33, 5)])
+def test_pair_packed_ladder(gpu_lib, no, nv, seed):
+    """ccd.py:187 in pair-packed form (exchange-symmetric V and T) against the oracle's plain einsum,
+    computed in two row slabs (the sharded form) and through the residual flag."""
+    f, V, t1, t2 = random_case(no, nv, seed, symmetric=True)
+    Vb = oc.split_blocks(no, V)
+    ctx = Context(no, nv, lib=gpu_lib)
+    try:
+        ctx.set_V_pqrs(V)
+        dT2, dF = ctx.array(t2), ctx.array(f)
+        ref = np.einsum("abcd,cdij->abij", Vb["abcd"], t2)
+        npp = nv * (nv + 1) // 2
+        L = ctx.zeros((npp, no * no))
+        cut = npp // 3
+        ctx.ladder_sym(dT2, L, 0, cut)
+        ctx.ladder_sym(dT2, L, cut, npp)
+        R0 = np.random.default_rng(seed).standard_normal(t2.shape)
+        R = ctx.array(R0)
+        ctx.ladder_sym_unpack(L, R, beta=0.5)
+        assert np.abs(R.get() - (ref + 0.5 * R0)).max() < TOL * max(1.0, np.abs(ref).max())
+        for dcd in (False, True):
+            r2 = ctx.empty(t2.shape)
+            ctx.doubles_residual(dF, dT2, r2, is_dcd=dcd, sym_ladder=True)
+            refr = oc.doubles_residual(no, f, t2, Vb["klij"], Vb["ijab"], Vb["abij"], Vb["iajb"], Vb["iabj"],
+                                       Vb["abcd"], is_dcd=dcd)
+            assert np.abs(r2.get() - refr).max() < 10 * TOL
+        # dressed blocks: the packed copy must follow a re-dressing
+        dT1 = ctx.array(t1)
+        for scale in (1.0, -0.5):
+            ctx.dress_V(ctx.array(scale * t1), ["abcd"])
+            Vd = oc.dressed_block("abcd", scale * t1, Vb)
+            ctx.ladder_sym(dT2, L, 0, npp, dressed=True)
+            ctx.ladder_sym_unpack(L, R, beta=0.0)
+            assert np.abs(R.get() - np.einsum("abcd,cdij->abij", Vd, t2)).max() < TOL * 10
+    finally:
+        ctx.close()

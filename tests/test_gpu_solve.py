@@ -105,6 +105,15 @@ def test_full_size_properties(gpu_lib):
         lb = ctx.empty(t2.shape); ctx.ladder(t2b, lb, 0, nv)
         ctx.lincomb(d, [lb, full], [1.0, 2.5])
         assert ctx.norm(d) < 1e-12 * ctx.norm(full)
+        # pair-packed ladder (1/4 of the flops) == plain ladder
+        npp = nv * (nv + 1) // 2
+        L = ctx.empty((npp, no * no))
+        ctx.ladder_sym(t2, L, 0, npp // 2)
+        ctx.ladder_sym(t2, L, npp // 2, npp)
+        ctx.ladder_sym_unpack(L, parts, beta=0.0)
+        ctx.lincomb(d, [full, parts], [1.0, -1.0])
+        assert ctx.norm(d) < 1e-12 * ctx.norm(full)
+        L.free()
         # residual symmetry R[a,b,i,j] = R[b,a,j,i] (8-fold symmetric V, symmetric MP2 amplitudes)
         f = ctx.array(np.diag(eps))
         r2 = ctx.empty(t2.shape); ctx.doubles_residual(f, t2, r2)
