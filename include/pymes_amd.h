@@ -95,6 +95,8 @@ int pymes_ccsd_singles_residual(pymes_ctx* ctx, const double* fd_dev, const doub
 #define PYMES_SYM_LADDER 8u   /* evaluate V_abcd.T in pair-packed form (1/4 of the flops); requires
                                  V_abcd = V_badc and T_cdij = T_dcji, true for every closed-shell solve that
                                  starts from MP2 or from symmetric amplitudes */
+#define PYMES_SYM_RINGS 16u   /* same precondition: merge the o^3v^3 ring/exchange products through the symmetry of
+                                 the pair matrices (6 products instead of 10; 4 instead of 5 for DCSD) */
 int pymes_doubles_residual(pymes_ctx* ctx, const double* f_dev, const double* t2_dev, double* r2_dev,
                            uint32_t flags);
 /* the particle-particle ladder on an a-slab (ccd.py:187): R[a0:a1] = beta*R[a0:a1] + V_abcd[a0:a1].T */

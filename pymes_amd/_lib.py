@@ -64,7 +64,7 @@ SIGNATURES = {
     "pymes_prof_query": (C.c_int, [C.c_void_p, c_i64_p, c_double_p, c_double_p]),
 }
 
-PYMES_DCD, PYMES_USE_DRESSED, PYMES_SKIP_LADDER, PYMES_SYM_LADDER = 1, 2, 4, 8
+PYMES_DCD, PYMES_USE_DRESSED, PYMES_SKIP_LADDER, PYMES_SYM_LADDER, PYMES_SYM_RINGS = 1, 2, 4, 8, 16
 
 
 class PymesError(RuntimeError):

@@ -241,9 +241,14 @@ class Context:
                       C.c_void_p(t2.ptr), C.c_void_p(out.ptr))
         return out
 
-    def doubles_residual(self, f, t2, out, is_dcd=False, dressed=False, skip_ladder=False, sym_ladder=False):
+    def doubles_residual(self, f, t2, out, is_dcd=False, dressed=False, skip_ladder=False, sym_ladder=False,
+                         sym_rings=None):
+        """``sym_ladder`` / ``sym_rings``: T_abij = T_baji and V_pqrs = V_qpsr hold, use the symmetry-reduced
+        forms (pair-packed ladder, merged ring products); ``sym_rings`` defaults to ``sym_ladder``."""
+        sym_rings = sym_ladder if sym_rings is None else sym_rings
         flags = (_lib.PYMES_DCD if is_dcd else 0) | (_lib.PYMES_USE_DRESSED if dressed else 0) | \
-                (_lib.PYMES_SKIP_LADDER if skip_ladder else 0) | (_lib.PYMES_SYM_LADDER if sym_ladder else 0)
+                (_lib.PYMES_SKIP_LADDER if skip_ladder else 0) | (_lib.PYMES_SYM_LADDER if sym_ladder else 0) | \
+                (_lib.PYMES_SYM_RINGS if sym_rings else 0)
         self.lib.call("pymes_doubles_residual", self.handle, C.c_void_p(f.ptr), C.c_void_p(t2.ptr),
                       C.c_void_p(out.ptr), flags)
         return out

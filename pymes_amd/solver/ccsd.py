@@ -106,7 +106,8 @@ class CCSD(ccd.CCD):
                 ctx.ladder_sym(t2, st["lad"], lo, hi, dressed=True)
             elif hi > lo:      # plain form: rows (a,b) of R = a-slabs when nv*nv rows are cut at multiples of nv
                 self._ladder_rows_plain(ctx, t2, st["lad"], lo, hi)
-            ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True, skip_ladder=True)
+            ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True, skip_ladder=True,
+                                 sym_rings=st["sym"])
             ctx.sync()
             pdist.exchange_rows(st["lad_t"], st["rank"], st["world"])
             torch_sync()

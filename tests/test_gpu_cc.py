@@ -114,6 +114,9 @@ def test_pair_packed_ladder(gpu_lib, no, nv, seed):
     """ccd.py:187 in pair-packed form (exchange-symmetric V and T) against the oracle's plain einsum,
     computed in two row slabs (the sharded form) and through the residual flag."""
     f, V, t1, t2 = random_case(no, nv, seed, symmetric=True)
+    if seed % 2:        # transcorrelated-like: non-hermitian, only V_pqrs = V_qpsr survives
+        V = V + 0.05 * np.random.default_rng(seed).standard_normal(V.shape)
+        V = 0.5 * (V + V.transpose(1, 0, 3, 2))
     Vb = oc.split_blocks(no, V)
     ctx = Context(no, nv, lib=gpu_lib)
     try:
@@ -130,11 +133,12 @@ def test_pair_packed_ladder(gpu_lib, no, nv, seed):
         ctx.ladder_sym_unpack(L, R, beta=0.5)
         assert np.abs(R.get() - (ref + 0.5 * R0)).max() < TOL * max(1.0, np.abs(ref).max())
         for dcd in (False, True):
-            r2 = ctx.empty(t2.shape)
-            ctx.doubles_residual(dF, dT2, r2, is_dcd=dcd, sym_ladder=True)
             refr = oc.doubles_residual(no, f, t2, Vb["klij"], Vb["ijab"], Vb["abij"], Vb["iajb"], Vb["iabj"],
                                        Vb["abcd"], is_dcd=dcd)
-            assert np.abs(r2.get() - refr).max() < 10 * TOL
+            for rings in (False, True):      # packed ladder alone, and with the symmetry-merged ring products
+                r2 = ctx.empty(t2.shape)
+                ctx.doubles_residual(dF, dT2, r2, is_dcd=dcd, sym_ladder=True, sym_rings=rings)
+                assert np.abs(r2.get() - refr).max() < 10 * TOL
         # dressed blocks: the packed copy must follow a re-dressing
         dT1 = ctx.array(t1)
         for scale in (1.0, -0.5):

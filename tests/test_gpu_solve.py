@@ -100,7 +100,7 @@ def test_full_size_properties(gpu_lib):
         for lo, hi in ((0, 25), (25, 130), (130, 200)):
             ctx.ladder(t2, parts, lo, hi, beta=0.0)
         d = ctx.empty(t2.shape); ctx.lincomb(d, [full, parts], [1.0, -1.0])
-        assert ctx.norm(d) == 0.0
+        assert ctx.norm(d) < 1e-13 * ctx.norm(full)      # k-splitting of tail tiles changes summation order only
         t2b = ctx.empty(t2.shape); ctx.lincomb(t2b, [t2], [-2.5])
         lb = ctx.empty(t2.shape); ctx.ladder(t2b, lb, 0, nv)
         ctx.lincomb(d, [lb, full], [1.0, 2.5])

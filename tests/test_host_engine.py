@@ -101,6 +101,28 @@ def test_cc_terms_vs_oracle(sim, no, nv, seed):
     ctx.close()
 
 
+@pytest.mark.parametrize("no,nv,seed", [(1, 1, 1), (2, 3, 2), (3, 5, 3), (4, 6, 4)])
+def test_symmetry_reduced_residual(sim, no, nv, seed):
+    """Pair-packed ladder + merged ring products on exchange-symmetric (also non-hermitian) input."""
+    f, V, t1, t2 = random_case(no, nv, seed, symmetric=True)
+    if seed % 2:
+        V = V + 0.05 * np.random.default_rng(seed).standard_normal(V.shape)
+        V = 0.5 * (V + V.transpose(1, 0, 3, 2))
+    Vb = oc.split_blocks(no, V)
+    ctx = Context(no, nv)
+    ctx.set_V_pqrs(V)
+    dF, dT2 = ctx.array(f), ctx.array(t2)
+    for dcd in (False, True):
+        ref = oc.doubles_residual(no, f, t2, Vb["klij"], Vb["ijab"], Vb["abij"], Vb["iajb"], Vb["iabj"], Vb["abcd"],
+                                  is_dcd=dcd)
+        for rings in (False, True):
+            r2 = ctx.empty(t2.shape)
+            ctx.doubles_residual(dF, dT2, r2, is_dcd=dcd, sym_ladder=True, sym_rings=rings)
+            assert np.abs(r2.get() - ref).max() < 1e-12
+        calls = ctx.stats(reset=True)
+    ctx.close()
+
+
 def _problem(tag):
     if tag.startswith("syn_"):
         no, nv = (int(x) for x in tag.split("_")[1:])
