@@ -1,0 +1,306 @@
+"""Closed-shell EOM-CCSD (pymes/solver/eom_ccsd.py) on the MI355X engine.
+
+Drop-in for ``pymes.solver.eom_ccsd.EOM_CCSD``: ``EOM_CCSD(no, n_excit).solve(f_dressed,
+dict_t_V_dressed, t_T_abij)`` returns the excitation energies; ``update_singles`` /
+``update_doubles`` keep the reference's host-array call forms.
+
+The sigma build H̄·u (eom_ccsd.py:268-385, 18 + 44 terms) runs on the device through the
+contraction engine (fp64 MFMA GEMM).  Every V·T product that does not depend on the trial
+vector is hoisted into per-solve intermediates (``_Sigma.__init__``), so one sigma costs the
+particle ladder ``V_abcd·u2`` plus eight (ov)^3 products instead of the reference's 34
+three-operand einsums.  The subspace algebra (QR, B = Uᵀσ, eig, collapse/expand) follows
+eom_ccsd.py:46-167 and stays on the host: the trial vectors live on the device, the host sees
+only overlaps and coefficients.
+"""
+import time
+
+import numpy as np
+
+from pymes_amd.device import Context, DeviceArray
+from pymes_amd.integral.partition import BLOCK_NAMES
+from pymes_amd.log import print_logging_info, print_title
+
+
+class _Sigma:
+    """Device-resident H̄·u with hoisted u-independent intermediates.
+
+    Pair layouts (ov x ov matrices): Xd[(a,i),(b,j)] = X[a,b,i,j], Xx[(a,j),(b,i)] = X[a,b,i,j]."""
+
+    def __init__(self, ctx, f, t2):
+        self.ctx, c = ctx, ctx
+        no, nv = ctx.no, ctx.nv
+        self.no, self.nv = no, nv
+        f = np.asarray(f, dtype=np.float64)
+        self.foo, self.fov, self.fvv = c.array(f[:no, :no]), c.array(f[:no, no:]), c.array(f[no:, no:])
+        V = {nm: c.V_block(nm) for nm in ("ijab", "iabj", "iajb", "ijka", "ijak", "iabc", "iajk", "abic", "klij",
+                                          "abcd")}
+        self.V = V
+        T = t2
+        self.T = T
+        self.Td = c.permute("abij->aibj", T)
+        self.Tx = c.permute("abij->ajbi", T)
+        Vd = c.permute("klcd->ckdl", V["ijab"])          # [(c,k),(d,l)]
+        Vx = c.permute("klcd->cldk", V["ijab"])          # [(c,l),(d,k)]
+        # ---- singles (eom_ccsd.py:288-308) ----------------------------------------------------
+        # W1[(c,k),(a,i)] = sum_jb (2V[j,k,b,c]-V[j,k,c,b]) (2T[b,a,j,i]-T[a,b,j,i]) + 2V_iabj[k,a,c,i] - V_iajb[k,a,i,c]
+        Vq = c.permute("jkbc->ckbj", V["ijab"], alpha=2.0)
+        c.permute("jkcb->ckbj", V["ijab"], out=Vq, alpha=-1.0, beta=1.0)
+        Tq = c.permute("baji->bjai", T, alpha=2.0)
+        c.permute("abji->bjai", T, out=Tq, alpha=-1.0, beta=1.0)
+        self.W1 = c.contract("ckbj,bjai->ckai", Vq, Tq)
+        c.permute("kaci->ckai", V["iabj"], out=self.W1, alpha=2.0, beta=1.0)
+        c.permute("kaic->ckai", V["iajb"], out=self.W1, alpha=-1.0, beta=1.0)
+        # Gvv_s[a,c] = fvv + sum V[j,k,b,c] (-2T[b,a,j,k] + T[a,b,j,k]);  Goo_s[k,i] = -foo + sum (-2V[j,k,b,c]+V[j,k,c,b]) T[b,c,j,i]
+        self.Gvv_s = c.array(f[no:, no:])
+        c.contract("jkbc,bajk->ac", V["ijab"], T, out=self.Gvv_s, alpha=-2.0, beta=1.0)
+        c.contract("jkbc,abjk->ac", V["ijab"], T, out=self.Gvv_s, alpha=1.0, beta=1.0)
+        self.Goo_s = c.array(-f[:no, :no])
+        c.contract("jkbc,bcji->ki", V["ijab"], T, out=self.Goo_s, alpha=-2.0, beta=1.0)
+        c.contract("jkcb,bcji->ki", V["ijab"], T, out=self.Goo_s, alpha=1.0, beta=1.0)
+        # ---- doubles: (V.T) pair matrices (eom_ccsd.py:352-372) ------------------------------------
+        M_A = c.contract("ckai,ckdl->aidl", self.Td, Vd)       # sum_kc V[k,l,c,d] T[c,a,k,i]
+        M_B = c.contract("aick,ckdl->aidl", self.Tx, Vd)       # sum_kc V[k,l,c,d] T[a,c,k,i]
+        self.M_C = c.contract("ckai,dlck->aidl", self.Td, Vx)  # sum_kc V[k,l,d,c] T[c,a,k,i]
+        self.M_D = c.contract("aick,dlck->aidl", self.Tx, Vx)  # sum_kc V[k,l,d,c] T[a,c,k,i]
+        self.M1 = c.permute("kaci->aick", V["iabj"])           # Wd'[(a,i),(c,k)] = V_iabj[k,a,c,i]
+        c.lincomb(self.M1, [self.M1, M_A, M_B], [1.0, 2.0, -1.0])
+        self.Ud = c.permute("kaic->aick", V["iajb"])           # Ud[(a,i),(c,k)] = V_iajb[k,a,i,c]
+        self.M2 = c.empty(self.M1.shape)
+        c.lincomb(self.M2, [self.M_D, self.M_C, self.Ud], [1.0, -2.0, -1.0])
+        del M_A, M_B, Vd, Vx, Vq, Tq
+        # small hoisted V.T blocks
+        self.A3 = c.contract("klci,cbkj->libj", V["ijak"], T, alpha=-2.0)                 # A_oovo
+        c.contract("klic,cbkj->libj", V["ijka"], T, out=self.A3, alpha=1.0, beta=1.0)
+        c.contract("kldi,bdkj->libj", V["ijak"], T, out=self.A3, alpha=1.0, beta=1.0)
+        self.A4 = c.contract("klid,adkj->liaj", V["ijka"], T)
+        self.A6 = c.contract("lacd,cdji->laji", V["iabc"], T)
+        self.Gvv = c.array(f[no:, no:])
+        c.contract("klcd,cakl->ad", V["ijab"], T, out=self.Gvv, alpha=-2.0, beta=1.0)
+        c.contract("klcd,ackl->ad", V["ijab"], T, out=self.Gvv, alpha=1.0, beta=1.0)
+        self.Goo = c.array(-f[:no, :no])
+        c.contract("klcd,cdki->li", V["ijab"], T, out=self.Goo, alpha=-2.0, beta=1.0)
+        c.contract("kldc,cdki->li", V["ijab"], T, out=self.Goo, alpha=1.0, beta=1.0)
+        self.B2 = c.permute("klij->klij", V["klij"])
+        c.contract("klcd,cdij->klij", V["ijab"], T, out=self.B2, alpha=1.0, beta=1.0)
+
+    # ------------------------------------------------------------------------------------------
+    def singles(self, u1, u2):
+        """eom_ccsd.py:268-310."""
+        c, V = self.ctx, self.V
+        ut = c.permute("abij->abij", u2, alpha=2.0)                   # 2 u2[a,b,i,j] - u2[b,a,i,j]
+        c.permute("baij->abij", u2, out=ut, alpha=-1.0, beta=1.0)
+        s = c.contract("ck,ckai->ai", u1, self.W1)
+        c.contract("ac,ci->ai", self.Gvv_s, u1, out=s, beta=1.0)
+        c.contract("ak,ki->ai", u1, self.Goo_s, out=s, beta=1.0)
+        c.contract("jb,baji->ai", self.fov, ut, out=s, beta=1.0)
+        c.contract("jkib,abjk->ai", V["ijka"], ut, out=s, alpha=-1.0, beta=1.0)
+        c.contract("jabc,bcji->ai", V["iabc"], ut, out=s, beta=1.0)
+        return s
+
+    def doubles(self, u1, u2):
+        """eom_ccsd.py:312-385."""
+        c, V, T = self.ctx, self.V, self.T
+        u2d = c.permute("abij->aibj", u2)
+        u2x = c.permute("abij->ajbi", u2)
+        utd = c.permute("abij->aibj", u2, alpha=2.0)                  # ut[d,b,l,j] = 2u2[d,b,l,j] - u2[b,d,l,j]
+        c.permute("baij->aibj", u2, out=utd, alpha=-1.0, beta=1.0)
+        # ---- (ov)^3 products -----------------------------------------------------------------------
+        Dd = c.contract("aidl,dlbj->aibj", self.M1, utd)
+        c.contract("aidl,dlbj->aibj", self.M2, u2d, out=Dd, beta=1.0)
+        c.contract("aidl,dlbj->aibj", self.M_C, u2x, out=Dd, beta=1.0)          # u2x[(d,l),(b,j)] = u2[d,b,j,l]
+        Dx = c.contract("ajdl,dlbi->ajbi", self.M_D, u2x)                         # :372  u2[d,b,i,l]
+        c.contract("ajck,bick->ajbi", u2x, self.Ud, out=Dx, alpha=-1.0, beta=1.0)  # :364
+        Cd = c.contract("kacd,di->aick", V["iabc"], u1)                           # sum_d V[k,a,c,d] u1[d,i]
+        Cp = c.contract("kadc,di->aick", V["iabc"], u1)                           # sum_d V[k,a,d,c] u1[d,i]
+        Cc = c.empty(Cd.shape)
+        c.lincomb(Cc, [Cd, Cp], [2.0, -1.0])
+        c.contract("aick,ckbj->aibj", Cc, self.Td, out=Dd, beta=1.0)              # :334, :345
+        c.contract("aick,bjck->aibj", Cd, self.Tx, out=Dd, alpha=-1.0, beta=1.0)  # :343
+        c.contract("ajck,bick->ajbi", Cp, self.Tx, out=Dx, alpha=-1.0, beta=1.0)  # :346
+        # ---- one-index dressings -----------------------------------------------------------------------
+        Xoo = c.contract("klid,dl->ki", V["ijka"], u1, alpha=-2.0)
+        c.contract("kldi,dl->ki", V["ijak"], u1, out=Xoo, beta=1.0)
+        c.contract("kd,di->ki", self.fov, u1, out=Xoo, alpha=-1.0, beta=1.0)
+        c.contract("kldc,dcil->ki", V["ijab"], u2, out=Xoo, alpha=-2.0, beta=1.0)
+        c.contract("kldc,dcli->ki", V["ijab"], u2, out=Xoo, beta=1.0)
+        c.contract("ki,akbj->aibj", Xoo, self.Td, out=Dd, beta=1.0, batch="a")
+        Xvv = c.contract("ladc,dl->ac", V["iabc"], u1, alpha=2.0)
+        c.contract("lacd,dl->ac", V["iabc"], u1, out=Xvv, alpha=-1.0, beta=1.0)
+        c.contract("al,lc->ac", u1, self.fov, out=Xvv, alpha=-1.0, beta=1.0)
+        c.contract("lkcd,adlk->ac", V["ijab"], u2, out=Xvv, alpha=-2.0, beta=1.0)
+        c.contract("lkcd,dalk->ac", V["ijab"], u2, out=Xvv, beta=1.0)
+        D = c.contract("ac,cbij->abij", Xvv, T)
+        c.contract("ad,dbij->abij", self.Gvv, u2, out=D, beta=1.0)
+        c.contract("li,ablj->abij", self.Goo, u2, out=D, beta=1.0, batch="ab")
+        c.contract("al,libj->abij", u1, self.A3, out=D, beta=1.0)
+        c.contract("bl,liaj->abij", u1, self.A4, out=D, beta=1.0)
+        c.contract("bl,laji->abij", u1, self.A6, out=D, alpha=-1.0, beta=1.0)
+        B5 = c.contract("klid,dj->klij", V["ijka"], u1)
+        c.contract("abkl,klij->abij", T, B5, out=D, beta=1.0)
+        c.contract("ak,kbij->abij", u1, V["iajk"], out=D, alpha=-1.0, beta=1.0)
+        c.contract("abic,cj->abij", V["abic"], u1, out=D, beta=1.0)
+        c.permute("aibj->abij", Dd, out=D, beta=1.0)
+        c.permute("ajbi->abij", Dx, out=D, beta=1.0)
+        # ---- P(ijab, jiba) (:377), then the unpermuted terms (:380-383) ----------------------------------
+        S = c.permute("baji->abij", D)
+        c.lincomb(D, [D, S], [1.0, 1.0])
+        c.contract("abkl,klij->abij", u2, self.B2, out=D, beta=1.0)               # :380, :382
+        Bn = c.contract("kldc,dcij->klij", V["ijab"], u2)
+        c.contract("abkl,klij->abij", T, Bn, out=D, beta=1.0)                     # :381
+        c.contract("abcd,cdij->abij", V["abcd"], u2, out=D, beta=1.0)             # :383
+        return D
+
+    def apply(self, u1, u2):
+        return self.singles(u1, u2), self.doubles(u1, u2)
+
+
+class EOM_CCSD:
+    def __init__(self, no, n_excit=3, device=0):
+        self.algo_name = "EOM-CCSD"
+        self.no = no
+        self.n_excit = n_excit
+        self.u_singles = []
+        self.u_doubles = []
+        self.e_excit = np.zeros(n_excit)
+        self.max_dim = n_excit * 4
+        self.e_epsilon = 1.e-8
+        self.max_iter = 500
+        self.device = device
+
+    def write_logging_info(self):
+        return
+
+    # ---- device plumbing ------------------------------------------------------------------
+    def _context(self, dict_t_V, nv):
+        ctx = Context(self.no, nv, device=self.device)
+        for name in BLOCK_NAMES:
+            blk = dict_t_V.get(name)
+            if blk is not None:
+                ctx.set_V_block(name, np.ascontiguousarray(blk, dtype=np.float64))
+        return ctx
+
+    def solve(self, t_fock_dressed_pq, dict_t_V_dressed, t_T_abij):
+        """eom_ccsd.py:46-167."""
+        print_title("EOM-CCSD Solver", )
+        time_init = time.time()
+        no = self.no
+        f = np.asarray(t_fock_dressed_pq, dtype=np.float64)
+        eps_i, eps_a = f.diagonal()[:no], f.diagonal()[no:]
+        nv = eps_a.shape[0]
+        D_ai = -(eps_i[None, :] - eps_a[:, None]).ravel()
+        lowest_ex_ind_init = np.argsort(D_ai)[:self.n_excit]
+        ctx = self._context(dict_t_V_dressed, nv)
+        try:
+            sig = _Sigma(ctx, f, ctx.array(t_T_abij))
+            print_logging_info("Initialising u tensors...", level=1)
+            n1, n2 = nv * no, nv * nv * no * no
+            us = []                                   # device vectors [u1 | u2], one flat buffer each
+            for i in range(self.n_excit):
+                vec = ctx.zeros((n1 + n2,))
+                one = np.zeros(n1)
+                one[lowest_ex_ind_init[i]] = 1.0
+                self._part(ctx, vec, 0, (nv, no)).set(one.reshape(nv, no))
+                us.append(vec)
+            e = self.e_excit
+            e_old = self.e_excit
+            e_imag = np.zeros(self.n_excit)
+            diff_e_norm = np.inf
+            for it in range(self.max_iter):
+                time_iter_init = time.time()
+                dim = len(us)
+                us = self._orthonormalise(ctx, us)                               # :91
+                ws = []
+                for l in range(dim):                                             # :95-101
+                    s1, s2 = sig.apply(self._part(ctx, us[l], 0, (nv, no)), self._part(ctx, us[l], n1, (nv, nv, no, no)))
+                    w = ctx.empty((n1 + n2,))
+                    self._part(ctx, w, 0, (nv, no)).copy_from(s1)
+                    self._part(ctx, w, n1, (nv, nv, no, no)).copy_from(s2)
+                    ws.append(w)
+                B = np.zeros((dim, dim))
+                for l in range(dim):                                             # :103-109
+                    B[:, l] = ctx.dots(us, [ws[l]] * dim)
+                lam, vec = np.linalg.eig(B)                                      # :112
+                pick = lam.argsort()[:self.n_excit]
+                e_imag = np.imag(lam[pick])
+                e = np.real(lam[pick])
+                v = np.real(vec[:, pick])
+                if dim >= self.max_dim:                                          # collapse :122-133
+                    new = []
+                    for n in range(self.n_excit):
+                        y = ctx.empty((n1 + n2,))
+                        ctx.lincomb(y, us, v[:, n])
+                        new.append(y)
+                    us = new
+                    self.e_excit = e_old
+                else:                                                            # expand :135-147
+                    basis = list(us)
+                    for n in range(self.n_excit):
+                        den = e[n] - D_ai[lowest_ex_ind_init[n]] + 1e-5
+                        y = ctx.empty((n1 + n2,))
+                        ctx.lincomb(y, ws + basis, list(v[:, n] / den) + list(-e[n] * v[:, n] / den))
+                        us.append(y)
+                    e_old = self.e_excit
+                    diff_e_norm = np.linalg.norm(self.e_excit - e)
+                    self.e_excit = e
+                if diff_e_norm < self.e_epsilon:
+                    print_logging_info("Iterative solver converged.", level=1)
+                    print_logging_info("Norm of energy difference = {:.12f}".format(diff_e_norm), level=2)
+                    for r in range(self.n_excit):
+                        print_logging_info("Excited state {:d} energy = {:.12f}".format(r, e[r]), level=2)
+                    print_logging_info("Excited states energies imaginary part = ", e_imag, level=2)
+                    break
+                print_logging_info("Iteration = ", it, level=1)
+                print_logging_info("Norm of energy difference = ", diff_e_norm, level=2)
+                for r in range(self.n_excit):
+                    print_logging_info("Excited state {:d} energy = {:.12f}".format(r, e[r]), level=2)
+                print_logging_info("Excited states energies imaginary part = ", e_imag, level=2)
+                print_logging_info("Took {:.3f} seconds ".format(time.time() - time_iter_init), level=2)
+            print_logging_info("EOM-CCSD finished in {:.3f} seconds".format(time.time() - time_init), level=1)
+            print_logging_info("Converged excited states energies:", level=1)
+            for r in range(self.n_excit):
+                print_logging_info("Excited state {:d} energy = {:.12f}".format(r, e[r]), level=2)
+            self.iterations = it + 1
+            self.u_singles = [self._part(ctx, u, 0, (nv, no)).get() for u in us[:self.n_excit]]
+            self.u_doubles = [self._part(ctx, u, n1, (nv, nv, no, no)).get() for u in us[:self.n_excit]]
+            return self.e_excit
+        finally:
+            ctx.close()
+
+    @staticmethod
+    def _part(ctx, vec, offset, shape):
+        return DeviceArray(ctx, vec.ptr + 8 * offset, shape, owned=False, keepalive=vec)
+
+    @staticmethod
+    def _orthonormalise(ctx, us):
+        """EOM_CCSD.QR (eom_ccsd.py:512-541): thin QR of the column block, done as Cholesky-free
+        modified Gram-Schmidt with re-orthogonalisation on the device (the host sees overlaps only).
+        The span and the orthonormality are those of numpy's Householder QR; individual columns can
+        differ from it by a sign, which the Rayleigh-Ritz step does not see."""
+        out = []
+        for u in us:
+            q = ctx.empty(u.shape).copy_from(u)
+            for _ in range(2):
+                if out:
+                    proj = ctx.dots(out, [q] * len(out))
+                    ctx.lincomb(q, [q] + out, [1.0] + list(-proj))
+            nrm = ctx.norm(q)
+            ctx.lincomb(q, [q], [1.0 / nrm])
+            out.append(q)
+        return out
+
+    # ---- the reference's host-array call forms (eom_ccsd.py:268-385) ---------------------------
+    def _host_sigma(self, t_fock_pq, dict_t_V, t_u_ai, t_u_abij, t_T_abij, which):
+        nv = t_u_ai.shape[0]
+        ctx = self._context(dict_t_V, nv)
+        try:
+            sig = _Sigma(ctx, t_fock_pq, ctx.array(t_T_abij))
+            u1, u2 = ctx.array(t_u_ai), ctx.array(t_u_abij)
+            return (sig.singles(u1, u2) if which == 1 else sig.doubles(u1, u2)).get()
+        finally:
+            ctx.close()
+
+    def update_singles(self, t_fock_pq, dict_t_V, t_u_ai, t_u_abij, t_T_abij):
+        return self._host_sigma(t_fock_pq, dict_t_V, t_u_ai, t_u_abij, t_T_abij, 1)
+
+    def update_doubles(self, t_fock_pq, dict_t_V, t_u_ai, t_u_abij, t_T_abij):
+        return self._host_sigma(t_fock_pq, dict_t_V, t_u_ai, t_u_abij, t_T_abij, 2)
