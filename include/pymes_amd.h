@@ -118,6 +118,15 @@ int pymes_ccsd_energy(pymes_ctx* ctx, const double* f_dev, const double* t1_dev,
 /* CCD.get_energy, ccd.py:256-262: e_out = {direct, exchange} */
 int pymes_ccd_energy(pymes_ctx* ctx, const double* t2_dev, double* e_out_host);
 
+/* ---- uniform electron gas integrals: UEG.eval_2b_integrals, pymes/model/ueg.py:265-516 ---------------- */
+/* V_dev[n_p^4] = <pq|rs> of the plane-wave basis k_int_host[n_p][3] (sorted by kinetic energy, as
+ * UEG.init_single_basis builds it) with lookup table index_map_host[(2 imax + 1)^3] (basis_indices_map).
+ * mode 0: Coulomb (correlator None); 1: transcorrelated is_only_2b; 2: is_effect_2b BEFORE its
+ * electron-exchange symmetrisation (ueg.py:509-513: use pymes_permute); 3: is_rpa_approx.  The correlator is
+ * UEG.trunc (ueg.py:772-800) with parameters k_cutoff, gamma; lattice_cutoff is sumNablaUSquare's (30). */
+int pymes_ueg_eval_2b(pymes_ctx* ctx, int n_p, int n_ele, int imax, int mode, double L, double k_cutoff, double gamma,
+                      int lattice_cutoff, const int32_t* k_int_host, const int32_t* index_map_host, double* V_dev);
+
 /* ---- vector helpers for DIIS (pymes/mixer/diis.py:65-103) and norms ----------------- */
 /* out_host[p] = sum_i x[p][i]*y[p][i], npairs <= 16, deterministic reduction (synchronises) */
 int pymes_dots(pymes_ctx* ctx, int npairs, const double* const* x_dev, const double* const* y_dev, int64_t n,

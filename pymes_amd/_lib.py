@@ -56,6 +56,8 @@ SIGNATURES = {
                                   C.c_int]),
     "pymes_ccsd_energy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_double_p]),
     "pymes_ccd_energy": (C.c_int, [C.c_void_p, C.c_void_p, c_double_p]),
+    "pymes_ueg_eval_2b": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pymes_dots": (C.c_int, [C.c_void_p, C.c_int, c_pp, c_pp, C.c_int64, c_double_p]),
     "pymes_lincomb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_pp, c_double_p, C.c_int64]),
     "pymes_stats": (C.c_int, [C.c_void_p, C.c_int, c_i64_p, c_double_p, c_i64_p, c_double_p]),

@@ -259,6 +259,28 @@ int pymes_ccd_energy(pymes_ctx* ctx, const double* t2, double* e_out) {
     });
 }
 
+int pymes_ueg_eval_2b(pymes_ctx* ctx, int n_p, int n_ele, int imax, int mode, double L, double k_cutoff, double gamma,
+                      int lattice_cutoff, const int32_t* k_int, const int32_t* index_map, double* V) {
+    return guarded([&] {
+        Engine& e = E(ctx);
+        need(k_int, "k_int"); need(index_map, "index_map"); need(V, "V");
+        if (n_p < 1 || imax < 0 || mode < 0 || mode > 3) throw pymes::Error("ueg: bad arguments");
+        const size_t m3 = size_t(2 * imax + 1) * (2 * imax + 1) * (2 * imax + 1);
+        int* kd = static_cast<int*>(dev::dmalloc(sizeof(int) * 3 * n_p));
+        int* md = static_cast<int*>(dev::dmalloc(sizeof(int) * m3));
+        try {
+            dev::memcpy_h2d(kd, k_int, sizeof(int) * 3 * n_p, e.stream);
+            dev::memcpy_h2d(md, index_map, sizeof(int) * m3, e.stream);
+            dev::UegParams p{n_p, n_ele, imax, mode, L, L * L * L, k_cutoff, gamma, lattice_cutoff};
+            dev::ueg_two_body(p, kd, md, V, e.stream);
+        } catch (...) {
+            dev::dfree(kd); dev::dfree(md);
+            throw;
+        }
+        dev::dfree(kd); dev::dfree(md);
+    });
+}
+
 int pymes_dots(pymes_ctx* ctx, int npairs, const double* const* x, const double* const* y, int64_t n,
                double* out) {
     return guarded([&] {

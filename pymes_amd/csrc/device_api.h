@@ -87,4 +87,16 @@ void ladder_pack_T(const double* T, double* Sp, double* Am, int no, int nv, stre
 // R[a,b,i,j] = beta R + LS[P(ab)][P(ij)] + sgn(a-b) sgn(i-j) LA[P(ab)][Q(ij)]
 void ladder_unpack(const double* L, double* R, double beta, int no, int nv, stream_t s);
 
+// ---- 3D uniform electron gas two-body integrals (pymes/model/ueg.py:265-516) ------------------
+// V[p,q,r,s] (dense [n_p]^4, zero where momentum is not conserved) for the plane-wave basis
+// k_int[n_p][3] (sorted by kinetic energy) and its lookup table index_map[(2 imax + 1)^3].
+struct UegParams {
+    int n_p, n_ele, imax;
+    int mode;               // 0 Coulomb, 1 TC "only_2b", 2 TC "effect_2b" (unsymmetrised), 3 RPA
+    double L, Omega;
+    double k_cutoff, gamma; // `trunc` correlator: u(k^2) = -4 pi gamma / k^4 for k > k_cutoff * 2 pi / L
+    int lattice_cutoff;     // k' lattice of sumNablaUSquare (ueg.py:581), 30 in the reference
+};
+void ueg_two_body(const UegParams& prm, const int* k_int_dev, const int* index_map_dev, double* V_dev, stream_t s);
+
 }  // namespace dev

@@ -615,6 +615,116 @@ __global__ void ladder_unpack_kernel(const double* __restrict__ L, double* __res
     }
 }
 
+// ------------------------------------------------------------------------------------
+// uniform electron gas integrals (ueg.py:265-596)
+// ------------------------------------------------------------------------------------
+struct UegK {
+    int n_p, n_occ, imax, m, mode, n_ele, lat;
+    double L, Omega, kc2g, gamma;
+};
+__device__ __forceinline__ double ueg_u(double x, const UegK& u) {      // trunc, ueg.py:772-800
+    if (x <= u.kc2g) x = 0.0;
+    return x > 1e-12 ? (-4.0 * M_PI / (x * x)) * u.gamma : 0.0;
+}
+__device__ __forceinline__ double ueg_kp(int k, double L) { return ((double)(k * 2) * M_PI) / L; }   // planewave.py:15
+
+// u_mat[d] = sum_k' (k'.(k-k')) u(k'^2) u((k-k')^2) / Omega, one block per momentum transfer d  (ueg.py:581-596)
+__global__ void __launch_bounds__(256) ueg_nabla_kernel(const UegK u, const double* __restrict__ dk, double* __restrict__ out) {
+    __shared__ double sh[4];
+    const double kx = dk[3 * blockIdx.x], ky = dk[3 * blockIdx.x + 1], kz = dk[3 * blockIdx.x + 2];
+    const int w = 2 * u.lat + 1;
+    const long total = (long)w * w * w;
+    double s = 0.0;
+    for (long idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const int c = (int)(idx % w), b = (int)((idx / w) % w), a = (int)(idx / ((long)w * w));
+        const double x1 = 2.0 * M_PI * (a - u.lat) / u.L, y1 = 2.0 * M_PI * (b - u.lat) / u.L,
+                     z1 = 2.0 * M_PI * (c - u.lat) / u.L;
+        const double x2 = kx - x1, y2 = ky - y1, z2 = kz - z1;
+        s += (x1 * x2 + y1 * y2 + z1 * z2) * ueg_u(x1 * x1 + y1 * y1 + z1 * z1, u) * ueg_u(x2 * x2 + y2 * y2 + z2 * z2, u);
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) out[blockIdx.x] = s / u.Omega;
+}
+
+// per (p,r): the q-independent singly-contracted 3-body value (ueg.py:461-474, 518-573)
+__global__ void ueg_effective_kernel(const UegK u, const int* __restrict__ kint, double* __restrict__ E) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= u.n_p * u.n_p) return;
+    const int p = idx / u.n_p, r = idx - p * u.n_p;
+    double kp[3], kr[3], dk[3];
+    for (int c = 0; c < 3; ++c) {
+        kp[c] = ueg_kp(kint[3 * p + c], u.L);
+        kr[c] = ueg_kp(kint[3 * r + c], u.L);
+        dk[c] = kr[c] - kp[c];
+    }
+    const double dk2 = dk[0] * dk[0] + dk[1] * dk[1] + dk[2] * dk[2];
+    const double udk = ueg_u(dk2, u);
+    double xr = 0.0, xp = 0.0, pk = 0.0;
+    for (int n = 0; n < u.n_occ; ++n) {
+        double o[3];
+        for (int c = 0; c < 3; ++c) o[c] = ueg_kp(kint[3 * n + c], u.L);
+        double a2 = 0, ad = 0, b2 = 0, bd = 0, v12 = 0, v11 = 0;
+        for (int c = 0; c < 3; ++c) {
+            const double a = kr[c] - o[c], b = kp[c] - o[c], v1 = kr[c] - dk[c] - o[c];
+            a2 += a * a; ad += a * dk[c];
+            b2 += b * b; bd += b * dk[c];
+            v12 += v1 * a; v11 += v1 * v1;
+        }
+        xr += ad * udk * ueg_u(a2, u);
+        xp += bd * udk * ueg_u(b2, u);
+        pk += v12 * ueg_u(v11, u) * ueg_u(a2, u);
+    }
+    xr /= u.Omega; xp /= u.Omega; pk /= u.Omega;
+    double val;
+    if (fabs(dk2) > 0.0) val = -(double)u.n_ele * dk2 * udk * udk / u.Omega + 2.0 * xr - 2.0 * xp + 2.0 * pk;
+    else val = 2.0 * pk;
+    E[idx] = val / u.Omega;
+}
+
+// one thread per (p,q,r): s by momentum conservation through the flattened lookup (ueg.py:384-507)
+__global__ void ueg_scatter_kernel(const UegK u, const int* __restrict__ kint, const int* __restrict__ map,
+                                   const double* __restrict__ umat, const int* __restrict__ umat_index,
+                                   const double* __restrict__ E, double* __restrict__ V) {
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long n = u.n_p;
+    if (idx >= n * n * n) return;
+    const int r = (int)(idx % n), q = (int)((idx / n) % n), p = (int)(idx / (n * n));
+    int d[3], ks[3];
+    for (int c = 0; c < 3; ++c) {
+        d[c] = kint[3 * r + c] - kint[3 * p + c];
+        ks[c] = kint[3 * q + c] - d[c];
+    }
+    const long loc = (long)u.m * u.m * (ks[0] + u.imax) + (long)u.m * (ks[1] + u.imax) + ks[2] + u.imax;
+    if (loc < 0 || loc >= (long)u.m * u.m * u.m) return;     // only the flattened index is range-checked (:397)
+    const int s = map[loc];
+    if (s < 0 || s >= u.n_p) return;
+    double dk[3], dk2 = 0.0;
+    for (int c = 0; c < 3; ++c) {
+        dk[c] = ueg_kp(kint[3 * r + c], u.L) - ueg_kp(kint[3 * p + c], u.L);
+        dk2 += dk[c] * dk[c];
+    }
+    double w = 0.0;
+    if (u.mode == 0) {
+        if (fabs(dk2) > 0.0) w = 4.0 * M_PI / dk2 / u.Omega;
+    } else if (u.mode == 3) {
+        if (fabs(dk2) > 0.0) { const double x = ueg_u(dk2, u); w = -(double)u.n_ele * dk2 * x * x / u.Omega / u.Omega; }
+    } else if (u.mode == 1) {
+        const int w4 = 4 * u.imax + 1;
+        const double um = umat[umat_index[((long)(d[0] + 2 * u.imax) * w4 + (d[1] + 2 * u.imax)) * w4 + d[2] + 2 * u.imax]];
+        if (fabs(dk2) > 0.0) {
+            double rsdk = 0.0;
+            for (int c = 0; c < 3; ++c) rsdk += (ueg_kp(kint[3 * r + c], u.L) - ueg_kp(kint[3 * s + c], u.L)) * dk[c];
+            const double x = ueg_u(dk2, u);
+            w = (4.0 * M_PI / dk2 + um + dk2 * x - rsdk * x) / u.Omega;
+        } else {
+            w = um / u.Omega;
+        }
+    } else {
+        w = E[(long)p * n + r];
+    }
+    V[((long)(p * n + q) * n + r) * n + s] = w;
+}
+
 inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
     long g = (total + block - 1) / block;
     return (int)std::max<long>(1, std::min<long>(g, cap));
@@ -986,6 +1096,65 @@ void ladder_unpack(const double* L, double* R, double beta, int no, int nv, stre
     hipLaunchKernelGGL(ladder_unpack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, L, R, beta, no, nv,
                        total);
     HIP_CHECK(hipGetLastError());
+}
+
+void ueg_two_body(const UegParams& prm, const int* k_int_dev, const int* index_map_dev, double* V_dev, stream_t s) {
+    hipStream_t st = (hipStream_t)s;
+    UegK u;
+    u.n_p = prm.n_p; u.n_occ = prm.n_ele / 2; u.imax = prm.imax; u.m = 2 * prm.imax + 1; u.mode = prm.mode;
+    u.n_ele = prm.n_ele; u.lat = prm.lattice_cutoff; u.L = prm.L; u.Omega = prm.Omega; u.gamma = prm.gamma;
+    const double kc = prm.k_cutoff * 2 * M_PI / prm.L;
+    u.kc2g = kc * kc * (1 + 0.00001);
+    const long n = prm.n_p;
+    HIP_CHECK(hipMemsetAsync(V_dev, 0, sizeof(double) * n * n * n * n, st));
+    std::vector<int> kint(3 * n);
+    HIP_CHECK(hipMemcpyAsync(kint.data(), k_int_dev, sizeof(int) * 3 * n, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    double *umat = nullptr, *E = nullptr, *dk_dev = nullptr;
+    int* uidx = nullptr;
+    try {
+        if (prm.mode == 1) {
+            // distinct momentum transfers d = k_r - k_p, with the float d_k of their first (p,r) pair
+            const int w4 = 4 * prm.imax + 1;
+            std::vector<int> index((size_t)w4 * w4 * w4, -1);
+            std::vector<double> dks;
+            for (long p = 0; p < n; ++p)
+                for (long r = 0; r < n; ++r) {
+                    int d[3];
+                    for (int c = 0; c < 3; ++c) {
+                        d[c] = kint[3 * r + c] - kint[3 * p + c];
+                        if (d[c] < -2 * prm.imax || d[c] > 2 * prm.imax) throw std::runtime_error("ueg: k outside the index map");
+                    }
+                    int& slot = index[((size_t)(d[0] + 2 * prm.imax) * w4 + (d[1] + 2 * prm.imax)) * w4 + d[2] + 2 * prm.imax];
+                    if (slot < 0) {
+                        slot = (int)(dks.size() / 3);
+                        for (int c = 0; c < 3; ++c)
+                            dks.push_back(((double)(kint[3 * r + c] * 2) * M_PI) / prm.L - ((double)(kint[3 * p + c] * 2) * M_PI) / prm.L);
+                    }
+                }
+            const int nd = (int)(dks.size() / 3);
+            umat = (double*)dmalloc(sizeof(double) * nd);
+            dk_dev = (double*)dmalloc(sizeof(double) * 3 * nd);
+            uidx = (int*)dmalloc(sizeof(int) * index.size());
+            HIP_CHECK(hipMemcpyAsync(dk_dev, dks.data(), sizeof(double) * 3 * nd, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(uidx, index.data(), sizeof(int) * index.size(), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(ueg_nabla_kernel, dim3(nd), dim3(256), 0, st, u, dk_dev, umat);
+            HIP_CHECK(hipGetLastError());
+        } else if (prm.mode == 2) {
+            E = (double*)dmalloc(sizeof(double) * n * n);
+            hipLaunchKernelGGL(ueg_effective_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, st, u, k_int_dev, E);
+            HIP_CHECK(hipGetLastError());
+        }
+        const long total = n * n * n;
+        hipLaunchKernelGGL(ueg_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, u, k_int_dev,
+                           index_map_dev, umat, uidx, E, V_dev);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(st));
+    } catch (...) {
+        hipFree(umat); hipFree(E); hipFree(dk_dev); hipFree(uidx);
+        throw;
+    }
+    hipFree(umat); hipFree(E); hipFree(dk_dev); hipFree(uidx);
 }
 
 }  // namespace dev

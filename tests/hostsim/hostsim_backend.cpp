@@ -8,6 +8,7 @@
 // package loader (pymes_amd/_lib.py) rejects any library whose pymes_backend() is not
 // "hip-gfx950".  It says nothing about the kernels themselves: those are tested on the
 // GPU (tests/test_gpu_*.py).
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -183,6 +184,82 @@ void ladder_unpack(const double* L, double* R, double beta, int no, int nv, stre
                     }
                     R[idx] = beta != 0.0 ? beta * R[idx] + v : v;
                 }
+}
+
+// ---- UEG integrals: plain loops with the same formulas as the HIP kernels ------------------------
+namespace {
+struct UegH { int n_p, n_occ, imax, m, mode, n_ele, lat; double L, Omega, kc2g, gamma; };
+inline double u_of(double x, const UegH& u) { if (x <= u.kc2g) x = 0.0; return x > 1e-12 ? (-4.0 * M_PI / (x * x)) * u.gamma : 0.0; }
+inline double kp_of(int k, double L) { return ((double)(k * 2) * M_PI) / L; }
+}  // namespace
+
+void ueg_two_body(const UegParams& prm, const int* kint, const int* map, double* V, stream_t) {
+    UegH u{prm.n_p, prm.n_ele / 2, prm.imax, 2 * prm.imax + 1, prm.mode, prm.n_ele, prm.lattice_cutoff, prm.L, prm.Omega, 0.0, prm.gamma};
+    const double kc = prm.k_cutoff * 2 * M_PI / prm.L;
+    u.kc2g = kc * kc * (1 + 0.00001);
+    const int64_t n = prm.n_p;
+    std::memset(V, 0, sizeof(double) * n * n * n * n);
+    std::vector<double> E(n * n, 0.0), umat(n * n, 0.0);
+    for (int64_t p = 0; p < n; ++p)
+        for (int64_t r = 0; r < n; ++r) {
+            double kpv[3], kr[3], dk[3], dk2 = 0;
+            for (int c = 0; c < 3; ++c) { kpv[c] = kp_of(kint[3 * p + c], u.L); kr[c] = kp_of(kint[3 * r + c], u.L); dk[c] = kr[c] - kpv[c]; dk2 += dk[c] * dk[c]; }
+            if (u.mode == 1) {
+                bool done = false;   // reuse the value of an earlier pair with the same integer transfer
+                for (int64_t p2 = 0; p2 <= p && !done; ++p2)
+                    for (int64_t r2 = 0; r2 < n && !done; ++r2) {
+                        if (p2 == p && r2 >= r) break;
+                        bool same = true;
+                        for (int c = 0; c < 3; ++c) same &= (kint[3 * r2 + c] - kint[3 * p2 + c]) == (kint[3 * r + c] - kint[3 * p + c]);
+                        if (same) { umat[p * n + r] = umat[p2 * n + r2]; done = true; }
+                    }
+                if (!done) {
+                    const int w = 2 * u.lat + 1;
+                    double s = 0.0;
+                    for (int a = 0; a < w; ++a) for (int b = 0; b < w; ++b) for (int c = 0; c < w; ++c) {
+                        const double x1 = 2.0 * M_PI * (a - u.lat) / u.L, y1 = 2.0 * M_PI * (b - u.lat) / u.L, z1 = 2.0 * M_PI * (c - u.lat) / u.L;
+                        const double x2 = dk[0] - x1, y2 = dk[1] - y1, z2 = dk[2] - z1;
+                        s += (x1 * x2 + y1 * y2 + z1 * z2) * u_of(x1 * x1 + y1 * y1 + z1 * z1, u) * u_of(x2 * x2 + y2 * y2 + z2 * z2, u);
+                    }
+                    umat[p * n + r] = s / u.Omega;
+                }
+            } else if (u.mode == 2) {
+                const double udk = u_of(dk2, u);
+                double xr = 0, xp = 0, pk = 0;
+                for (int o = 0; o < u.n_occ; ++o) {
+                    double a2 = 0, ad = 0, b2 = 0, bd = 0, v12 = 0, v11 = 0;
+                    for (int c = 0; c < 3; ++c) {
+                        const double oc = kp_of(kint[3 * o + c], u.L);
+                        const double a = kr[c] - oc, b = kpv[c] - oc, v1 = kr[c] - dk[c] - oc;
+                        a2 += a * a; ad += a * dk[c]; b2 += b * b; bd += b * dk[c]; v12 += v1 * a; v11 += v1 * v1;
+                    }
+                    xr += ad * udk * u_of(a2, u); xp += bd * udk * u_of(b2, u); pk += v12 * u_of(v11, u) * u_of(a2, u);
+                }
+                xr /= u.Omega; xp /= u.Omega; pk /= u.Omega;
+                const double val = std::fabs(dk2) > 0.0 ? -(double)u.n_ele * dk2 * udk * udk / u.Omega + 2.0 * xr - 2.0 * xp + 2.0 * pk : 2.0 * pk;
+                E[p * n + r] = val / u.Omega;
+            }
+            for (int64_t q = 0; q < n; ++q) {
+                int ks[3];
+                for (int c = 0; c < 3; ++c) ks[c] = kint[3 * q + c] - (kint[3 * r + c] - kint[3 * p + c]);
+                const int64_t loc = (int64_t)u.m * u.m * (ks[0] + u.imax) + (int64_t)u.m * (ks[1] + u.imax) + ks[2] + u.imax;
+                if (loc < 0 || loc >= (int64_t)u.m * u.m * u.m) continue;
+                const int s = map[loc];
+                if (s < 0 || s >= u.n_p) continue;
+                double w = 0.0;
+                if (u.mode == 0) { if (std::fabs(dk2) > 0.0) w = 4.0 * M_PI / dk2 / u.Omega; }
+                else if (u.mode == 3) { if (std::fabs(dk2) > 0.0) { const double x = u_of(dk2, u); w = -(double)u.n_ele * dk2 * x * x / u.Omega / u.Omega; } }
+                else if (u.mode == 1) {
+                    if (std::fabs(dk2) > 0.0) {
+                        double rsdk = 0.0;
+                        for (int c = 0; c < 3; ++c) rsdk += (kr[c] - kp_of(kint[3 * s + c], u.L)) * dk[c];
+                        const double x = u_of(dk2, u);
+                        w = (4.0 * M_PI / dk2 + umat[p * n + r] + dk2 * x - rsdk * x) / u.Omega;
+                    } else w = umat[p * n + r] / u.Omega;
+                } else w = E[p * n + r];
+                V[((p * n + q) * n + r) * n + s] = w;
+            }
+        }
 }
 
 }  // namespace dev
