@@ -109,6 +109,19 @@ int pymes_ladder(pymes_ctx* ctx, const double* t2_dev, double* r2_dev, int a_beg
 int pymes_ladder_sym(pymes_ctx* ctx, const double* t2_dev, double* L_dev, int64_t row_begin, int64_t row_end,
                      int dressed);
 int pymes_ladder_sym_unpack(pymes_ctx* ctx, const double* L_dev, double* r2_dev, double beta);
+/* The symmetry-reduced residual (PYMES_SYM_LADDER | PYMES_SYM_RINGS) in its shardable form, one process per
+ * GPU.  pymes_residual_slab computes what rank `rank` of `world` owns: the rows [c0,c1) of ETd and ETx (both
+ * [o*v][o*v] on the device; ET[(b,j),(a,i)] = Ex[(a,i),(b,j)], rows cut into `world` chunks of ceil(ov/world))
+ * and, if L_dev is not NULL, its chunk of rows of the pair-packed ladder L (pymes_ladder_sym).  No
+ * communication is needed to produce a slab.  After the slabs have been exchanged (one all-gather per buffer)
+ * pymes_residual_finish adds the replicated terms and assembles R.  world = 1 reproduces
+ * pymes_doubles_residual.  pymes_ccsd_dress_abcd_rows dresses only rows a in [a_begin,a_end) of V_abcd
+ * (ccsd.py:414-419) — the rows a rank's ladder chunk reads. */
+int pymes_residual_slab(pymes_ctx* ctx, const double* f_dev, const double* t2_dev, double* ETd_dev, double* ETx_dev,
+                        double* L_dev, int rank, int world, uint32_t flags);
+int pymes_residual_finish(pymes_ctx* ctx, const double* f_dev, const double* t2_dev, const double* ETd_dev,
+                          const double* ETx_dev, const double* L_dev, double* r2_dev, uint32_t flags);
+int pymes_ccsd_dress_abcd_rows(pymes_ctx* ctx, const double* t1_dev, int a_begin, int a_end);
 /* ccsd.py:176-179 / ccd.py:123-124: dt = r/(D+shift) (as r * (1/(D+shift))), t += delta*dt; rank 2 or 4 */
 int pymes_cc_update(pymes_ctx* ctx, double* t_dev, double* dt_dev, const double* r_dev, double level_shift,
                     double delta, int rank);

@@ -240,6 +240,26 @@ int pymes_ladder_sym_unpack(pymes_ctx* ctx, const double* L, double* r2, double 
         E(ctx).ladder_sym_unpack(L, r2, beta);
     });
 }
+int pymes_residual_slab(pymes_ctx* ctx, const double* f, const double* t2, double* ETd, double* ETx, double* L, int rank,
+                        int world, uint32_t flags) {
+    return guarded([&] {
+        need(f, "f"); need(t2, "t2"); need(ETd, "ETd"); need(ETx, "ETx");
+        E(ctx).residual_slab(f, t2, ETd, ETx, L, rank, world, flags);
+    });
+}
+int pymes_residual_finish(pymes_ctx* ctx, const double* f, const double* t2, const double* ETd, const double* ETx,
+                          const double* L, double* r2, uint32_t flags) {
+    return guarded([&] {
+        need(f, "f"); need(t2, "t2"); need(ETd, "ETd"); need(ETx, "ETx"); need(r2, "r2");
+        E(ctx).residual_finish(f, t2, ETd, ETx, L, r2, flags);
+    });
+}
+int pymes_ccsd_dress_abcd_rows(pymes_ctx* ctx, const double* t1, int a0, int a1) {
+    return guarded([&] {
+        need(t1, "t1");
+        E(ctx).dress_abcd_rows(t1, a0, a1);
+    });
+}
 int pymes_cc_update(pymes_ctx* ctx, double* t, double* dt, const double* r, double shift, double delta, int rank) {
     return guarded([&] {
         need(t, "t"); need(dt, "dt"); need(r, "r");

@@ -71,6 +71,15 @@ void Engine::doubles_residual(const double* f, const double* t2, double* r2, uns
                sym_rings = flags & 16u;
     const bool quad = !dcd;
     const int64_t o = no, v = nv, nn = n;
+    if (sym_rings) {      // symmetry-reduced evaluation = the one-rank case of the sharded form
+        ArenaScope sc(arena);
+        double* ETd = arena.alloc(o * v * o * v);
+        double* ETx = arena.alloc(o * v * o * v);
+        double* L = (sym_ladder && !skip_ladder) ? arena.alloc(v * (v + 1) / 2 * o * o) : nullptr;
+        residual_slab(f, t2, ETd, ETx, L, 0, 1, flags);
+        residual_finish(f, t2, ETd, ETx, L, r2, flags);
+        return;
+    }
     const double w = quad ? 1.0 : 0.5;                                                      // :213-220
     TView T = make_view(const_cast<double*>(t2), {v, v, o, o});
     TView R = make_view(r2, {v, v, o, o});
@@ -131,48 +140,6 @@ void Engine::doubles_residual(const double* f, const double* t2, double* r2, uns
     TView Exn = make_view(arena.alloc(o * o * v * v), {v, v, o, o});
     contract(1.0, Xvv, "ac", T, "cbij", 0.0, Exn, "abij");                                   // :231
     TView Exd = ov2(), Exx = ov2();
-    if (sym_rings) {
-        // Exchange-symmetric amplitudes (T_abij = T_baji) make Td, Tx, Tt_d, Vd, Vx symmetric ov x ov
-        // matrices.  Then (a) the products Tt_d Vd Tt_d (:202-204) and Tx Vx Tx (:190-191) are symmetric,
-        // so half of each can be carried inside Ex (which is symmetrised at :249), and (b) -Ud Td (:233)
-        // may be replaced by its transpose -Td Ud^T.  Every o^3v^3 term then has Td, Tt_d or Tx as LEFT
-        // factor and the right factors are summed first: 6 products instead of 10 (4 instead of 5 for DCSD).
-        //   Exd = Tt_d (Wd + Y/2) + Td (-UdT + U - U'),   Exx = Tx (U/2 - UdT)
-        //   Y = Vd Tt_d,  U = Vx Tx,  U' = Vx Td,  UdT[(c,k),(b,j)] = V_iajb[k,b,j,c]
-        ArenaScope s2(arena);
-        TView M = ov2(), UdT = ov2();
-        permute(1.0, Viajb, "kbjc", 0.0, UdT, "ckbj");
-        {
-            ArenaScope s3(arena);
-            TView Y = ov2();
-            contract(1.0, Vd, "ckdl", Ttd, "dlbj", 0.0, Y, "ckbj");                          // :202
-            permute(1.0, Viabj, "kbcj", 0.0, M, "ckbj");                                     // Wd
-            axpby(0.5, Y, 1.0, M);
-        }
-        contract(1.0, Ttd, "aick", M, "ckbj", 0.0, Exd, "aibj");                             // :204 (half) + :235
-        axpby(-1.0, UdT, 0.0, M);                                                            // M = -UdT
-        if (quad) {
-            TView Vx = make_view(get_static("Vx"), {v, o, v, o});
-            TView U = ov2();
-            contract(1.0, Vx, "cldk", Tx, "dkbj", 0.0, U, "clbj");                           // :190
-            axpby(1.0, U, 1.0, M);
-            axpby(0.5, U, -1.0, UdT);                                                        // UdT <- U/2 - UdT
-            contract(1.0, Vx, "cldk", Td, "dkbj", 0.0, U, "clbj");                           // U'   (:238)
-            axpby(-1.0, U, 1.0, M);
-        } else {
-            axpby(0.0, UdT, -1.0, UdT);                                                      // UdT <- -UdT
-        }
-        contract(1.0, Td, "aick", M, "ckbj", 1.0, Exd, "aibj");                              // :233, :238-240
-        contract(1.0, Tx, "ajck", UdT, "ckbi", 0.0, Exx, "ajbi");                            // :234, :191 (half)
-        contract(-1.0, Xoo, "ki", Td, "akbj", 1.0, Exd, "aibj", "a");                        // :232
-        permute(1.0, Exd, "aibj", 1.0, R, "abij");
-        permute(1.0, Exd, "bjai", 1.0, R, "abij");
-        permute(1.0, Exx, "ajbi", 1.0, R, "abij");
-        permute(1.0, Exx, "biaj", 1.0, R, "abij");
-        permute(1.0, Exn, "abij", 1.0, R, "abij");
-        permute(1.0, Exn, "baji", 1.0, R, "abij");
-        return;
-    }
     TView Rd = ov2();
     {
         // :202-204  R += Tt . (V . Tt)   in the direct layout
@@ -219,6 +186,171 @@ void Engine::doubles_residual(const double* f, const double* t2, double* r2, uns
     permute(1.0, Exx, "biaj", 1.0, R, "abij");
     permute(1.0, Exn, "abij", 1.0, R, "abij");
     permute(1.0, Exn, "baji", 1.0, R, "abij");
+}
+
+// -----------------------------------------------------------------------------------
+// Symmetry-reduced, shardable T2 residual (requires T_abij = T_baji and V_pqrs = V_qpsr).
+//
+// Exchange-symmetric amplitudes make Td, Tx, Tt_d, Vd, Vx symmetric ov x ov matrices.  Then
+// (a) Tt_d Vd Tt_d (ccd.py:202-204) and Tx Vx Tx (:190-191) are symmetric, so half of each can be
+// carried inside Ex, which is symmetrised at :249 anyway, and (b) -Ud Td (:233) may be replaced by
+// its transpose -Td Ud^T.  Every o^3v^3 term then has Td, Tt_d or Tx as LEFT factor and the right
+// factors are summed first: 6 products instead of 10 (4 instead of 5 for DCSD):
+//     Exd = Tt_d (Wd + Y/2) + Td (-UdT + U - U'),   Exx = Tx (U/2 - UdT)
+//     Y = Vd Tt_d,  U = Vx Tx,  U' = Vx Td,  UdT[(c,k),(b,j)] = V_iajb[k,b,j,c]
+// COLUMNS (b,j) of these products never mix, so a rank needs no communication to compute its column
+// slab; the slab is produced TRANSPOSED (ET[(b,j),(a,i)] = Ex[(a,i),(b,j)]) so that the slabs of all
+// ranks are contiguous row blocks of ETd / ETx = one all-gather each.  Since only Ex + Ex^T enters R
+// the transposition needs no undoing.  The pair-packed ladder rows of the same rank go to L.
+// -----------------------------------------------------------------------------------
+void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, double* ETx_p, double* L, int rank,
+                           int world, unsigned flags) {
+    const bool dcd = flags & 1u, dressed = flags & 2u, skip_ladder = flags & 4u;
+    const bool quad = !dcd;
+    const int64_t o = no, v = nv, nn = n, ov = o * v;
+    if (world < 1 || rank < 0 || rank >= world) throw Error("residual_slab: bad rank/world");
+    const double w = quad ? 1.0 : 0.5;
+    TView T = make_view(const_cast<double*>(t2), {v, v, o, o});
+    TView F = make_view(const_cast<double*>(f), {nn, nn});
+    TView Viajb = block(P_iajb, dressed), Viabj = block(P_iabj, dressed);
+    auto chunk = [&](int64_t rows, int64_t& lo, int64_t& hi) {
+        const int64_t c = (rows + world - 1) / world;
+        lo = std::min<int64_t>(rank * c, rows);
+        hi = std::min<int64_t>(lo + c, rows);
+    };
+    if (L && !skip_ladder) {
+        int64_t r0, r1;
+        chunk(v * (v + 1) / 2, r0, r1);
+        ladder_sym(t2, L, r0, r1, dressed);
+    }
+    int64_t c0, c1;
+    chunk(ov, c0, c1);
+    const int64_t nc = c1 - c0;
+    if (nc <= 0) return;
+
+    ArenaScope scope(arena);
+    auto pairm = [&](double* p) { return make_view(p, {ov, ov}); };
+    auto slab = [&]() { return make_view(arena.alloc(ov * nc), {ov, nc}); };
+    TView Vd = pairm(get_static("Vd"));
+    TView Td = pairm(arena.alloc(ov * ov)), Tx = pairm(arena.alloc(ov * ov)), Ttd = pairm(arena.alloc(ov * ov));
+    {
+        TView t4 = make_view(Td.p, {v, o, v, o});
+        permute(1.0, T, "abij", 0.0, t4, "aibj");
+        t4.p = Tx.p;
+        permute(1.0, T, "abij", 0.0, t4, "ajbi");
+        t4.p = Ttd.p;
+        permute(2.0, T, "abij", 0.0, t4, "aibj");
+        permute(-1.0, T, "baij", 1.0, t4, "aibj");
+    }
+    TView ETd = slice(pairm(ETd_p), 0, c0, c1), ETx = slice(pairm(ETx_p), 0, c0, c1);
+    auto cols = [&](const TView& m) { return slice(m, 1, c0, c1); };
+    // column slabs of the static / dressed right-hand factors, straight from the 4-index blocks
+    TView M = slab(), UdT = slab();
+    {
+        // Wd[(c,k),(b,j)] = V_iabj[k,b,c,j];  UdT[(c,k),(b,j)] = V_iajb[k,b,j,c];  columns (b,j) in [c0,c1)
+        ArenaScope s2(arena);
+        TView full = pairm(arena.alloc(ov * ov));
+        TView f4 = make_view(full.p, {v, o, v, o});
+        permute(1.0, Viabj, "kbcj", 0.0, f4, "ckbj");
+        copy(cols(full), M);
+        permute(1.0, Viajb, "kbjc", 0.0, f4, "ckbj");
+        copy(cols(full), UdT);
+    }
+    {
+        ArenaScope s2(arena);
+        TView Y = slab();
+        contract(1.0, Vd, "xy", cols(Ttd), "yn", 0.0, Y, "xn");                              // :202
+        axpby(0.5, Y, 1.0, M);                                                               // M = Wd + Y/2
+    }
+    contract(1.0, M, "kn", Ttd, "mk", 0.0, ETd, "nm");                                       // :204 (half) + :235
+    axpby(-1.0, UdT, 0.0, M);                                                                // M = -UdT
+    if (quad) {
+        TView Vx = pairm(get_static("Vx"));
+        TView U = slab();
+        contract(1.0, Vx, "xy", cols(Tx), "yn", 0.0, U, "xn");                               // :190
+        axpby(1.0, U, 1.0, M);
+        axpby(0.5, U, -1.0, UdT);                                                            // UdT <- U/2 - UdT
+        contract(1.0, Vx, "xy", cols(Td), "yn", 0.0, U, "xn");                               // U'   (:238)
+        axpby(-1.0, U, 1.0, M);
+    } else {
+        axpby(0.0, UdT, -1.0, UdT);                                                          // UdT <- -UdT
+    }
+    contract(1.0, M, "kn", Td, "mk", 1.0, ETd, "nm");                                        // :233, :238-240
+    contract(1.0, UdT, "kn", Tx, "mk", 0.0, ETx, "nm");                                      // :234, :191 (half)
+    {
+        // :232  Ex[a,b,i,j] -= X_ki T[a,b,k,j]  ->  ET[(b,j),(a,i)] -= sum_k Td[(b,j),(a,k)] X_ki   (Td symmetric)
+        ArenaScope s2(arena);
+        TView Foo = slice(slice(F, 0, 0, o), 1, 0, o);
+        TView Xoo = make_view(arena.alloc(o * o), {o, o});
+        copy(Foo, Xoo);
+        TView Tp = make_view(arena.alloc(o * o * v * v), {o, v, v, o});
+        permute(1.0, make_view(Ttd.p, {v, o, v, o}), "cidl", 0.0, Tp, "icdl");
+        contract(w, make_view(get_static("Vk2"), {o, v, v, o}), "kcdl", Tp, "icdl", 1.0, Xoo, "ki");   // :215-220
+        TView Trows = make_view(Td.p + c0 * ov, {nc, v, o});
+        TView Erows = make_view(ETd.p, {nc, v, o});
+        contract(-1.0, Trows, "nak", Xoo, "ki", 1.0, Erows, "nai");
+    }
+}
+
+void Engine::residual_finish(const double* f, const double* t2, const double* ETd_p, const double* ETx_p,
+                             const double* L, double* r2, unsigned flags) {
+    const bool dcd = flags & 1u, dressed = flags & 2u, skip_ladder = flags & 4u;
+    const bool quad = !dcd;
+    const int64_t o = no, v = nv, nn = n;
+    const double w = quad ? 1.0 : 0.5;
+    TView T = make_view(const_cast<double*>(t2), {v, v, o, o});
+    TView R = make_view(r2, {v, v, o, o});
+    TView F = make_view(const_cast<double*>(f), {nn, nn});
+    TView Fvv = slice(slice(F, 0, o, nn), 1, o, nn);
+    TView Vijab = block(P_ijab);
+    ArenaScope scope(arena);
+    copy(block(P_abij, dressed), R);                                                        // :185
+    {
+        ArenaScope s2(arena);
+        TView hole = make_view(arena.alloc(o * o * o * o), {o, o, o, o});
+        copy(block(P_klij, dressed), hole);                                                 // :178
+        if (quad) contract(1.0, Vijab, "klcd", T, "cdij", 1.0, hole, "klij");                // :180
+        contract(1.0, hole, "klij", T, "abkl", 1.0, R, "abij");                             // :186
+    }
+    if (!skip_ladder) {                                                                     // :187
+        if (L) ladder_sym_unpack(L, r2, 1.0);
+        else contract(1.0, block(P_abcd, dressed), "abcd", T, "cdij", 1.0, R, "abij");
+    }
+    {
+        // X_ac = f_ac - w sum Tt[a,d,k,l] V[l,k,d,c]  (:206-221);  Ex += X_ac T[c,b,i,j]  (:231)
+        ArenaScope s2(arena);
+        TView Ttd = make_view(arena.alloc(o * o * v * v), {v, o, v, o});
+        permute(2.0, T, "abij", 0.0, Ttd, "aibj");
+        permute(-1.0, T, "baij", 1.0, Ttd, "aibj");
+        TView Xvv = make_view(arena.alloc(v * v), {v, v});
+        copy(Fvv, Xvv);
+        contract(-w, Ttd, "akdl", make_view(get_static("Vk"), {o, v, o, v}), "kdlc", 1.0, Xvv, "ac");
+        TView Exn = make_view(Ttd.p, {v, v, o, o});      // Ttd is dead after X_ac: reuse its storage
+        contract(1.0, Xvv, "ac", T, "cbij", 0.0, Exn, "abij");
+        permute(1.0, Exn, "abij", 1.0, R, "abij");
+        permute(1.0, Exn, "baji", 1.0, R, "abij");
+    }
+    TView ETd = make_view(const_cast<double*>(ETd_p), {v, o, v, o}), ETx = make_view(const_cast<double*>(ETx_p), {v, o, v, o});
+    permute(1.0, ETd, "aibj", 1.0, R, "abij");                                              // Ex + Ex^T (:249-252)
+    permute(1.0, ETd, "bjai", 1.0, R, "abij");
+    permute(1.0, ETx, "ajbi", 1.0, R, "abij");
+    permute(1.0, ETx, "biaj", 1.0, R, "abij");
+}
+
+// rows a in [a0,a1) of the T1-dressed V_abcd (ccsd.py:414-419): what a rank needs for its ladder rows
+void Engine::dress_abcd_rows(const double* t1, int a0, int a1) {
+    if (a0 < 0 || a1 > nv || a0 > a1) throw Error("dress_abcd_rows: bad range");
+    if (a0 == a1) return;
+    TView t = make_view(const_cast<double*>(t1), {(int64_t)nv, (int64_t)no});
+    TView dst = slice(block_view(ensure_dressed(P_abcd), P_abcd), 0, a0, a1);
+    copy(slice(block(P_abcd), 0, a0, a1), dst);
+    contract(-1.0, t, "qx", slice(block(P_aibc), 0, a0, a1), "pxrs", 1.0, dst, "pqrs", "p");     // :416
+    ArenaScope scope(arena);
+    TView oth = block_view(arena.alloc(block_size(P_iabc)), P_iabc);
+    copy(block(P_iabc), oth);
+    contract(-1.0, t, "qy", block(P_ijab), "xyrs", 1.0, oth, "xqrs", "x");                       // dressed iabc (:385-388)
+    contract(-1.0, slice(t, 0, a0, a1), "px", oth, "xqrs", 1.0, dst, "pqrs");                    // :415, :417
+    if (lpack_.dressed) lpack_.valid = false;
 }
 
 void Engine::ladder(const double* t2, double* r2, int a0, int a1, bool dressed, double beta) {

@@ -116,6 +116,13 @@ class Engine {
     // rows [row0,row1) of the pair-packed result L[v(v+1)/2][o*o] (device_api.h), then R = beta R + unpack(L)
     void ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1, bool dressed);
     void ladder_sym_unpack(const double* L, double* r2, double beta);
+    // symmetry-reduced residual in shardable form (cc.cpp): this rank's column slab of the ring products
+    // (rows of ETd/ETx) and its rows of the packed ladder L; then the replicated remainder + assembly
+    void residual_slab(const double* f, const double* t2, double* ETd, double* ETx, double* L, int rank, int world,
+                       unsigned flags);
+    void residual_finish(const double* f, const double* t2, const double* ETd, const double* ETx, const double* L,
+                         double* r2, unsigned flags);
+    void dress_abcd_rows(const double* t1, int a0, int a1);
     void cc_update(double* t, double* dt, const double* r, double shift, double delta, int rank);  // ccsd.py:176-179
     void ccsd_energy(const double* f, const double* t1, const double* t2, double out[3]);     // ccsd.py:458-466
     void ccd_energy(const double* t2, double out[2]);                                         // ccd.py:256-262

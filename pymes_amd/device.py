@@ -258,6 +258,27 @@ class Context:
                       int(dressed), float(beta))
         return out
 
+    @staticmethod
+    def _flags(is_dcd, dressed, skip_ladder=False, sym_ladder=False, sym_rings=False):
+        return (_lib.PYMES_DCD if is_dcd else 0) | (_lib.PYMES_USE_DRESSED if dressed else 0) | \
+               (_lib.PYMES_SKIP_LADDER if skip_ladder else 0) | (_lib.PYMES_SYM_LADDER if sym_ladder else 0) | \
+               (_lib.PYMES_SYM_RINGS if sym_rings else 0)
+
+    def residual_slab(self, f, t2, ETd, ETx, L, rank, world, is_dcd=False, dressed=False):
+        """This rank's share of the symmetry-reduced residual (include/pymes_amd.h)."""
+        self.lib.call("pymes_residual_slab", self.handle, C.c_void_p(f.ptr), C.c_void_p(t2.ptr), C.c_void_p(ETd.ptr),
+                      C.c_void_p(ETx.ptr), C.c_void_p(L.ptr if L is not None else 0), int(rank), int(world),
+                      self._flags(is_dcd, dressed, False, True, True))
+
+    def residual_finish(self, f, t2, ETd, ETx, L, out, is_dcd=False, dressed=False):
+        self.lib.call("pymes_residual_finish", self.handle, C.c_void_p(f.ptr), C.c_void_p(t2.ptr), C.c_void_p(ETd.ptr),
+                      C.c_void_p(ETx.ptr), C.c_void_p(L.ptr if L is not None else 0), C.c_void_p(out.ptr),
+                      self._flags(is_dcd, dressed, False, True, True))
+        return out
+
+    def dress_abcd_rows(self, t1, a_begin, a_end):
+        self.lib.call("pymes_ccsd_dress_abcd_rows", self.handle, C.c_void_p(t1.ptr), int(a_begin), int(a_end))
+
     def ladder_sym(self, t2, L, row_begin, row_end, dressed=False):
         """Rows [row_begin,row_end) of the pair-packed ladder L[v(v+1)/2, o*o] (include/pymes_amd.h)."""
         self.lib.call("pymes_ladder_sym", self.handle, C.c_void_p(t2.ptr), C.c_void_p(L.ptr), int(row_begin),

@@ -44,6 +44,28 @@ def exchange_rows(full, rank, world_size):
     if world_size == 1:
         return full
     c = full.shape[0] // world_size
+    if full.is_cuda and dist.get_backend() == "gloo":
+        # test rigs only (several ranks on one GPU, no RCCL): stage the exchange through host memory
+        host = full.cpu()
+        mine = host[rank * c:(rank + 1) * c].clone()
+        dist.all_gather_into_tensor(host.view(-1), mine.view(-1))
+        full.copy_(host)
+        return full
     mine = full[rank * c:(rank + 1) * c].clone()      # all_gather_into_tensor must not alias its output
     dist.all_gather_into_tensor(full.view(-1), mine.view(-1))
     return full
+
+
+def a_range_of_pair_rows(lo, hi):
+    """Virtual indices a touched by the packed pair rows P(a,b) = a(a+1)/2 + b in [lo, hi)."""
+    if hi <= lo:
+        return 0, 0
+
+    def a_of(r):
+        a = int(((8.0 * r + 1.0) ** 0.5 - 1.0) / 2.0)
+        while a * (a + 1) // 2 > r:
+            a -= 1
+        while (a + 1) * (a + 2) // 2 <= r:
+            a += 1
+        return a
+    return a_of(lo), a_of(hi - 1) + 1

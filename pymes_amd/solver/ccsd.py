@@ -81,11 +81,18 @@ class CCSD(ccd.CCD):
         if wsize > 1:
             import torch
             dev = torch.device("cuda", ctx.device)
-            rows = nv * (nv + 1) // 2 if st["sym"] else nv * nv
-            st["lad_rows"] = rows
-            st["lad_t"] = torch.zeros((pdist.padded_rows(rows, wsize), no * no), dtype=torch.float64, device=dev)
-            st["lad"] = DeviceArray(ctx, st["lad_t"].data_ptr(), tuple(st["lad_t"].shape), owned=False,
-                                    keepalive=st["lad_t"])
+
+            def shared(rows, cols):      # exchange buffer: world equal row chunks, torch-owned for the collective
+                t = torch.zeros((pdist.padded_rows(rows, wsize), cols), dtype=torch.float64, device=dev)
+                return t, DeviceArray(ctx, t.data_ptr(), tuple(t.shape), owned=False, keepalive=t)
+            if st["sym"]:
+                st["npp"] = nv * (nv + 1) // 2
+                st["ETd_t"], st["ETd"] = shared(no * nv, no * nv)
+                st["ETx_t"], st["ETx"] = shared(no * nv, no * nv)
+                st["L_t"], st["L"] = shared(st["npp"], no * no)
+            else:
+                st["lad_rows"] = nv * nv
+                st["lad_t"], st["lad"] = shared(nv * nv, no * no)
         return st
 
     def iterate(self, st):
@@ -93,30 +100,40 @@ class CCSD(ccd.CCD):
         ctx, t1, t2 = st["ctx"], st["t1"], st["t2"]
         shift = st["level_shift"]
         ctx.dress_fock(st["f"], t1, st["fd"])                        # :163
-        ctx.dress_V(t1, LOOP_KEYS)                                  # :165 (only the blocks the residual reads)
         r1 = ctx.pool_get(t1.shape)
         ctx.singles_residual(st["fd"], t1, t2, r1)                  # :167
         r2 = ctx.pool_get(t2.shape)
-        if st["world"] == 1:
+        world, rank = st["world"], st["rank"]
+        if world == 1:
+            ctx.dress_V(t1, LOOP_KEYS)                              # :165 (only the blocks the residual reads)
             ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True, sym_ladder=st["sym"])   # :171
+        elif st["sym"]:
+            # sharded: this rank's column slab of the ring products + its rows of the packed ladder (for which it
+            # dresses only its own rows of V_abcd), three all-gathers, replicated remainder
+            ctx.dress_V(t1, ("abij", "klij", "iajb", "iabj"))
+            lo, hi = pdist.slab_rows(st["npp"], rank, world)
+            ctx.dress_abcd_rows(t1, *pdist.a_range_of_pair_rows(lo, hi))
+            ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], rank, world, is_dcd=self.is_dcd,
+                              dressed=True)
+            ctx.sync()
+            for key in ("ETd_t", "ETx_t", "L_t"):
+                pdist.exchange_rows(st[key], rank, world)
+            torch_sync()
+            ctx.residual_finish(st["fd"], t2, st["ETd"], st["ETx"], st["L"], r2, is_dcd=self.is_dcd, dressed=True)
         else:
-            # this rank's chunk of ladder rows; everything else replicated; ONE all-gather per iteration
-            lo, hi = pdist.slab_rows(st["lad_rows"], st["rank"], st["world"])
-            if st["sym"]:
-                ctx.ladder_sym(t2, st["lad"], lo, hi, dressed=True)
-            elif hi > lo:      # plain form: rows (a,b) of R = a-slabs when nv*nv rows are cut at multiples of nv
+            # unsymmetric user amplitudes: plain ladder rows on this rank, everything else replicated
+            ctx.dress_V(t1, LOOP_KEYS)
+            lo, hi = pdist.slab_rows(st["lad_rows"], rank, world)
+            if hi > lo:
                 self._ladder_rows_plain(ctx, t2, st["lad"], lo, hi)
             ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True, skip_ladder=True,
-                                 sym_rings=st["sym"])
+                                 sym_ladder=False, sym_rings=False)
             ctx.sync()
-            pdist.exchange_rows(st["lad_t"], st["rank"], st["world"])
+            pdist.exchange_rows(st["lad_t"], rank, world)
             torch_sync()
-            if st["sym"]:
-                ctx.ladder_sym_unpack(st["lad"], r2, beta=1.0)
-            else:
-                full = st["lad"].reshape(st["lad"].size)
-                r2f = r2.reshape(r2.size)
-                ctx.lincomb(r2f, [r2f, DeviceArray(ctx, full.ptr, (r2.size,), owned=False, keepalive=full)], [1.0, 1.0])
+            full = DeviceArray(ctx, st["lad"].ptr, (r2.size,), owned=False, keepalive=st["lad"])
+            r2f = r2.reshape(r2.size)
+            ctx.lincomb(r2f, [r2f, full], [1.0, 1.0])
         dt1, dt2 = ctx.pool_get(t1.shape), ctx.pool_get(t2.shape)
         ctx.cc_update(t1, dt1, r1, shift, self.delta)               # :176-179
         ctx.cc_update(t2, dt2, r2, shift, self.delta)

@@ -149,3 +149,8 @@ def test_pair_packed_ladder(gpu_lib, no, nv, seed):
             assert np.abs(R.get() - np.einsum("abcd,cdij->abij", Vd, t2)).max() < TOL * 10
     finally:
         ctx.close()
+
+
+def test_sharded_residual_simulated_ranks(gpu_lib):
+    from tests.test_host_engine import sharded_residual_check
+    sharded_residual_check(gpu_lib, [(3, 5, 2), (6, 17, 3), (8, 24, 4)], (1, 2, 8), 1e-11)

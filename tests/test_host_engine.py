@@ -123,6 +123,43 @@ def test_symmetry_reduced_residual(sim, no, nv, seed):
     ctx.close()
 
 
+def sharded_residual_check(lib, cases, worlds, tol):
+    """Every rank's slab computed one after the other into shared buffers (= a perfect exchange), then the
+    replicated finish: must equal the oracle for any world size, with abcd dressed row-block-wise."""
+    for no, nv, seed in cases:
+        f, V, t1, t2 = random_case(no, nv, seed, symmetric=True)
+        V = V + 0.05 * np.random.default_rng(seed).standard_normal(V.shape)
+        V = 0.5 * (V + V.transpose(1, 0, 3, 2))
+        Vb = oc.split_blocks(no, V)
+        fd_ref = oc.dressed_fock(no, f, t1, Vb)
+        Vd_ref = oc.dressed_V(t1, Vb)
+        ctx = Context(no, nv, lib=lib)
+        ctx.set_V_pqrs(V)
+        dT1, dT2, dF = ctx.array(t1), ctx.array(t2), ctx.array(fd_ref)
+        ov, npp = no * nv, nv * (nv + 1) // 2
+        for world in worlds:
+            ctx.dress_V(dT1, ["abij", "klij", "iajb", "iabj"])
+            for dcd in (False, True):
+                pad = lambda n: -(-n // world) * world
+                ETd, ETx, L = ctx.zeros((pad(ov), ov)), ctx.zeros((pad(ov), ov)), ctx.zeros((pad(npp), no * no))
+                for rank in range(world):
+                    lo = min(rank * (-(-npp // world)), npp)
+                    hi = min(lo + (-(-npp // world)), npp)
+                    if hi > lo:      # rows a of V_abcd that the packed rows [lo,hi) touch
+                        a_of = lambda r: int((np.sqrt(8.0 * r + 1.0) - 1.0) / 2.0 + 1e-9)
+                        ctx.dress_abcd_rows(dT1, a_of(lo), a_of(hi - 1) + 1)
+                    ctx.residual_slab(dF, dT2, ETd, ETx, L, rank, world, is_dcd=dcd, dressed=True)
+                r2 = ctx.empty(t2.shape)
+                ctx.residual_finish(dF, dT2, ETd, ETx, L, r2, is_dcd=dcd, dressed=True)
+                ref = oc.ccsd_doubles_residual(no, fd_ref, t2, Vd_ref, is_dcsd=dcd)
+                assert np.abs(r2.get() - ref).max() < tol, (no, nv, world, dcd)
+        ctx.close()
+
+
+def test_sharded_residual_host_logic(sim):
+    sharded_residual_check(sim, [(2, 3, 1), (3, 5, 2)], (1, 2, 3, 8), 1e-12)
+
+
 def _problem(tag):
     if tag.startswith("syn_"):
         no, nv = (int(x) for x in tag.split("_")[1:])
