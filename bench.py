@@ -36,17 +36,35 @@ def reference_flops(no, nv, is_dcsd=False):
     return 2.0 * (doubles + dressing + singles)
 
 
+def pmc_traffic_per_gemm_launch(no, nv, world):
+    """HBM bytes per fp64-GEMM launch from the committed rocprofv3 PMC passes of THIS command at the default
+    workload (profiles/r01/bench_c3_pmc_hbm_traffic.csv: FETCH_SIZE doubled per the gfx950 correction +
+    WRITE_SIZE, separate passes).  None for any other workload: counters cannot be read from inside the run."""
+    path = os.path.join(ROOT, "profiles", "r01", "bench_c3_pmc_hbm_traffic.csv")
+    if (no, nv, world) != (50, 200, 1) or not os.path.exists(path):
+        return None
+    launches, gbytes = 0, 0.0
+    for line in open(path):
+        if line.startswith('"void dgemm_kernel'):
+            name, n, fetch, write = line.rsplit(",", 3)
+            launches += int(n)
+            gbytes += int(n) * (float(fetch) + float(write))
+    return gbytes / launches * 1e9 if launches else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--no", type=int, default=50)
-    ap.add_argument("--nv", type=int, default=200)
+    ap.add_argument("--nocc", type=int, default=50)
+    ap.add_argument("--nvirt", type=int, default=200)
     ap.add_argument("--dcsd", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-diis", action="store_true")
+    ap.add_argument("--backend", default=os.environ.get("PYMES_DIST_BACKEND", "nccl"),
+                    help="torch.distributed backend; 'gloo' lets several ranks share one GPU in test rigs")
     args = ap.parse_args()
 
     import torch
@@ -56,16 +74,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from pymes_amd.integral.device import DeviceIntegrals
     from pymes_amd.model import synthetic
     from pymes_amd.solver.ccsd import CCSD
 
-    no, nv = args.no, args.nv
+    no, nv = args.nocc, args.nvirt
     B, eps = synthetic.factors(no, nv, seed=args.seed)
     stream = torch.cuda.current_stream().cuda_stream
     t0 = time.time()
@@ -128,9 +150,12 @@ def main():
             "config": {"workload": f"{'DCSD' if args.dcsd else 'CCSD'} iteration, synthetic density-fitted "
                                    f"integrals (nocc={no}, nvirt={nv}), seed {args.seed}",
                        "no": no, "nv": nv, "diis": not args.no_diis,
-                       "parallelism": "single GPU" if world == 1 else f"ladder a-slab x{world} + RCCL all-gather"},
+                       "parallelism": "single GPU" if world == 1 else
+                       f"ring-product column slabs + packed-ladder rows over {world} ranks, 3 all-gathers/iteration "
+                       f"({args.backend})"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                         "traffic": pmc_traffic_per_gemm_launch(no, nv, world),
                          "kernel": "dgemm_kernel (v_mfma_f64_16x16x4_f64)",
                          "launches_per_step": prof["launches"] / args.steps,
                          "avg_launch_ms": prof["ms"] / max(1, prof["launches"]),
@@ -149,6 +174,7 @@ def main():
             cpu = sample(no, nv)
             line["cpu_baseline"] = {
                 "value": cpu["faithful"]["seconds_per_doubles_residual"], "unit": "s", "cores": 1, "kind": "port",
+                "what": "one doubles residual (93 % of the reference's iteration flops), plain np.einsum",
                 "sample": "oracle contraction forms (plain np.einsum, as the reference's T2 residual): ladder on a "
                           "(1 x 25) (a,b)-slab and one o^3v^3 ring term on an a-slab of 1, extrapolated linearly to "
                           "one doubles residual with the SURVEY 8(d) flop table",
