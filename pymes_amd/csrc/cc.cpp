@@ -343,12 +343,12 @@ void Engine::dress_abcd_rows(const double* t1, int a0, int a1) {
     if (a0 == a1) return;
     TView t = make_view(const_cast<double*>(t1), {(int64_t)nv, (int64_t)no});
     TView dst = slice(block_view(ensure_dressed(P_abcd), P_abcd), 0, a0, a1);
-    copy(slice(block(P_abcd), 0, a0, a1), dst);
-    contract(-1.0, t, "qx", slice(block(P_aibc), 0, a0, a1), "pxrs", 1.0, dst, "pqrs", "p");     // :416
+    const TView raw = slice(block(P_abcd), 0, a0, a1);
+    contract(-1.0, t, "qx", slice(block(P_aibc), 0, a0, a1), "pxrs", 1.0, dst, "pqrs", "p", &raw);     // :416 (+ copy)
     ArenaScope scope(arena);
     TView oth = block_view(arena.alloc(block_size(P_iabc)), P_iabc);
-    copy(block(P_iabc), oth);
-    contract(-1.0, t, "qy", block(P_ijab), "xyrs", 1.0, oth, "xqrs", "x");                       // dressed iabc (:385-388)
+    const TView raw_iabc = block(P_iabc);
+    contract(-1.0, t, "qy", block(P_ijab), "xyrs", 1.0, oth, "xqrs", "x", &raw_iabc);                 // dressed iabc (:385-388)
     contract(-1.0, slice(t, 0, a0, a1), "px", oth, "xqrs", 1.0, dst, "pqrs");                    // :415, :417
     if (lpack_.dressed) lpack_.valid = false;
 }
@@ -482,7 +482,11 @@ void Engine::dressed_into(int pattern, const std::vector<int>& pos, int k, const
         copy(block(pattern), dst);
         return;
     }
-    dressed_into(pattern, pos, k - 1, t1v, dst);
+    // same-type part: when it is the raw block the copy is fused into the product below (C = Cin + ...)
+    const bool fuse_copy = (k - 1 == 0);
+    if (!fuse_copy) dressed_into(pattern, pos, k - 1, t1v, dst);
+    const TView raw = fuse_copy ? block(pattern) : TView();
+    const TView* cin = fuse_copy ? &raw : nullptr;
     const int x = pos[k - 1];
     const int other = pattern ^ (1 << (3 - x));
     ArenaScope scope(arena);
@@ -494,10 +498,10 @@ void Engine::dressed_into(int pattern, const std::vector<int>& pos, int k, const
         dressed_into(other, pos, k - 1, t1v, oth);
     }
     switch (x) {
-        case 3: contract(1.0, oth, "pqrx", t1v, "xs", 1.0, dst, "pqrs"); break;
-        case 2: contract(1.0, oth, "pqxs", t1v, "xr", 1.0, dst, "pqrs", "pq"); break;
-        case 1: contract(-1.0, t1v, "qx", oth, "pxrs", 1.0, dst, "pqrs", "p"); break;
-        case 0: contract(-1.0, t1v, "px", oth, "xqrs", 1.0, dst, "pqrs"); break;
+        case 3: contract(1.0, oth, "pqrx", t1v, "xs", 1.0, dst, "pqrs", "", cin); break;
+        case 2: contract(1.0, oth, "pqxs", t1v, "xr", 1.0, dst, "pqrs", "pq", cin); break;
+        case 1: contract(-1.0, t1v, "qx", oth, "pxrs", 1.0, dst, "pqrs", "p", cin); break;
+        case 0: contract(-1.0, t1v, "px", oth, "xqrs", 1.0, dst, "pqrs", "", cin); break;
         default: throw Error("bad index position");
     }
 }

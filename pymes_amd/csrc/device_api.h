@@ -42,6 +42,7 @@ struct Gemm {
     const double* A; int64_t a_sm, a_sk;
     const double* B; int64_t b_sk, b_sn;
     double* C; int64_t ldc;
+    const double* Cin = nullptr;      // optional: read the beta term from here (same layout/strides as C)
     int64_t nb1, nb2;                 // batch extents (>=1)
     int64_t a_b1, a_b2, b_b1, b_b2, c_b1, c_b2;
     double* splitk_ws;                // workspace for split-K partials (may be null)

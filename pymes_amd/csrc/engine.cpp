@@ -259,7 +259,14 @@ struct Operand {
 }  // namespace
 
 void Engine::contract(double alpha, const TView& A, const char* sa, const TView& B, const char* sb, double beta,
-                      const TView& C, const char* sc, const char* batch) {
+                      const TView& C, const char* sc, const char* batch, const TView* Cin) {
+    if (Cin) {
+        if (Cin->rank != C.rank) throw Error("contract: Cin must have the shape of C");
+        for (int i = 0; i < C.rank; ++i)
+            if (Cin->dim[i] != C.dim[i] || (C.dim[i] != 1 && Cin->st[i] != C.st[i]))
+                throw Error("contract: Cin must have the shape and strides of C");
+        if (beta == 0.0) Cin = nullptr;
+    }
     check_labels(sa, A.rank, "A");
     check_labels(sb, B.rank, "B");
     check_labels(sc, C.rank, "C");
@@ -344,6 +351,10 @@ void Engine::contract(double alpha, const TView& A, const char* sa, const TView&
     const auto& Ns = N_cand[best.in_];
     const auto& Ks = K_cand[best.ik];
 
+    if (Cin && best.copyC) {      // no fused path through a transposed temporary: do the copy explicitly
+        copy(*Cin, C);
+        Cin = nullptr;
+    }
     ArenaScope scope(arena);
     // ---- materialise copies where needed ----------------------------------------------
     // canonical copy layout: [batch labels present (C order)][group1][group2], contiguous
@@ -445,6 +456,7 @@ void Engine::contract(double alpha, const TView& A, const char* sa, const TView&
             g.b_b1 = bd[nouter].sa; g.b_b2 = bd[nouter + 1].sa;
         }
         g.c_b1 = bd[nouter].sc; g.c_b2 = bd[nouter + 1].sc;
+        g.Cin = Cin ? Cin->p + oc : nullptr;
         dev::gemm(g, stream);
         stats.gemm_calls++;
         stats.gemm_flops += 2.0 * double(Msz) * double(Nsz) * double(Ksz) * double(g.nb1) * double(g.nb2);

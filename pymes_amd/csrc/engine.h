@@ -85,8 +85,10 @@ class Engine {
     // ---- generic tensor ops ---------------------------------------------------------
     // C[sc] = alpha * sum A[sa] * B[sb] + beta * C[sc];  `batch` lists free labels that are
     // looped as GEMM batches instead of being merged into M/N.
+    // `Cin` (optional, same shape and strides as C) supplies the beta term: C = alpha*A*B + beta*Cin, which
+    // fuses a copy into the product.
     void contract(double alpha, const TView& A, const char* sa, const TView& B, const char* sb, double beta,
-                  const TView& C, const char* sc, const char* batch = "");
+                  const TView& C, const char* sc, const char* batch = "", const TView* Cin = nullptr);
     // out[so] = alpha * in[si] + beta * out[so]   (labels are a permutation of each other)
     void permute(double alpha, const TView& in, const char* si, double beta, const TView& out, const char* so);
     // out = alpha * in + beta * out, same index order (shapes must match)

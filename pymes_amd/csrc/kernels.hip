@@ -45,13 +45,13 @@ struct GemmK {
     const double* A;
     const double* B;
     double* C;
+    const double* Cin;   // beta term is read from here (== C unless the caller fuses a copy)
     long a_ld, b_ld, ldc;
     int M, N, K;
     double alpha, beta;
     int tiles_m, tiles_n;
     int nsplit, kchunk;
     long tile_begin;   // first (batch-major) tile handled by this launch
-    int variant;       // scheduling experiment knob (PYMES_GEMM_VARIANT)
     long nb2;
     long a_b1, a_b2, b_b1, b_b2, c_b1, c_b2;
     double* ws;   // split-K partials, tile-local: [tile - tile_begin][ks][BM][BN]
@@ -239,46 +239,47 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_kernel(const GemmK g) {
     constexpr int A_KSTEP = AKC ? 4 : 4 * A_PITCH;       // next k-step of 4
     constexpr int B_KSTEP = BKC ? 4 : 4 * B_PITCH;
 
-    if (g.variant == 1) {            // static priority for every other co-resident block
-        if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(1);
-    } else if (g.variant == 3) {     // start stagger: every other block waits ~half a k-tile
-        if ((blockIdx.x >> 8) & 1) {
-            for (int w = 0; w < 16; ++w) __builtin_amdgcn_s_sleep(127);
-        }
-    }
+    // Software pipeline across the per-tile barrier: the fragments of k-step 0 of tile t+1 are read right
+    // AFTER the barrier and the 16 MFMAs of the LAST k-step of tile t (operands already in registers) are
+    // issued behind those reads, so neither the LDS latency nor the LDS write-back of the staged tile is
+    // exposed; the staged tile is written to LDS between k-steps 1 and 2, under MFMAs.
+    double a[2][FM], b[2][FN];
+    auto read_frags = [&](const double* as, const double* bs, int kk, double (&ra_)[FM], double (&rb_)[FN]) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) ra_[i] = as[kk * A_KSTEP + i * A_FSTEP];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) rb_[j] = bs[kk * B_KSTEP + j * B_FSTEP];
+    };
+    auto mfma_step = [&](const double (&ra_)[FM], const double (&rb_)[FN]) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra_[i], rb_[j], acc[i][j], 0, 0, 0);
+    };
+    static_assert(BK == 16, "the k-step schedule below is written for 4 k-steps per tile");
     if (nkt > 0) {
         load_tiles(0);
         store_tiles(0);
     }
     __syncthreads();
+    if (nkt > 0) read_frags(As + a_frag, Bs + b_frag, 0, a[0], b[0]);
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nkt) load_tiles(kt + 1);   // global loads in flight under the MFMAs
+        const bool has_next = kt + 1 < nkt;
+        if (has_next) load_tiles(kt + 1);        // global loads in flight under the MFMAs
         const double* as = As + cur * A_TILE + a_frag;
         const double* bs = Bs + cur * B_TILE + b_frag;
-        double a[2][FM], b[2][FN];               // fragments of k-step kk+1 are fetched under the MFMAs of kk
-#pragma unroll
-        for (int i = 0; i < FM; ++i) a[0][i] = as[i * A_FSTEP];
-#pragma unroll
-        for (int j = 0; j < FN; ++j) b[0][j] = bs[j * B_FSTEP];
-        if (g.variant == 2) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            if (kk + 1 < BK / 4) {
-#pragma unroll
-                for (int i = 0; i < FM; ++i) a[(kk + 1) & 1][i] = as[(kk + 1) * A_KSTEP + i * A_FSTEP];
-#pragma unroll
-                for (int j = 0; j < FN; ++j) b[(kk + 1) & 1][j] = bs[(kk + 1) * B_KSTEP + j * B_FSTEP];
-            }
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
-        }
-        if (g.variant == 2) __builtin_amdgcn_s_setprio(0);
-        if (kt + 1 < nkt) store_tiles(cur ^ 1);
-        __syncthreads();
+        read_frags(as, bs, 1, a[1], b[1]);
+        mfma_step(a[0], b[0]);
+        read_frags(as, bs, 2, a[0], b[0]);
+        mfma_step(a[1], b[1]);
+        if (has_next) store_tiles(cur ^ 1);      // buffer cur^1 was last read before the previous barrier
+        read_frags(as, bs, 3, a[1], b[1]);
+        mfma_step(a[0], b[0]);
+        __syncthreads();                         // tile kt fully consumed into registers; tile kt+1 visible
+        if (has_next) read_frags(As + (cur ^ 1) * A_TILE + a_frag, Bs + (cur ^ 1) * B_TILE + b_frag, 0, a[0], b[0]);
+        mfma_step(a[1], b[1]);
     }
 
     // ---- epilogue -------------------------------------------------------------------
@@ -293,7 +294,8 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_kernel(const GemmK g) {
                     W[(wm * WM + i * 16 + l4 + 4 * r) * BN + wn * WN + j * 16 + l15] = acc[i][j][r];
         return;
     }
-    double* __restrict__ C = g.C + z1 * g.c_b1 + z2 * g.c_b2;
+    double* C = g.C + z1 * g.c_b1 + z2 * g.c_b2;
+    const double* Cin = g.Cin + z1 * g.c_b1 + z2 * g.c_b2;
     const long ldc = g.ldc;
     const double alpha = g.alpha, beta = g.beta;
 #pragma unroll
@@ -305,10 +307,10 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_kernel(const GemmK g) {
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm * WM + i * 16 + l4 + 4 * r;
                 if (m < g.M && n < g.N) {
-                    double* p = C + (long)m * ldc + n;
+                    const long off = (long)m * ldc + n;
                     double v = alpha * acc[i][j][r];
-                    if (beta != 0.0) v += beta * (*p);
-                    *p = v;
+                    if (beta != 0.0) v += beta * Cin[off];
+                    C[off] = v;
                 }
             }
         }
@@ -331,7 +333,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmK g, int B
     const int tm = first_m + tin % gm;
     const int tn = tin / gm;
     const long z1 = z / g.nb2, z2 = z - z1 * g.nb2;
-    double* __restrict__ C = g.C + z1 * g.c_b1 + z2 * g.c_b2;
+    double* C = g.C + z1 * g.c_b1 + z2 * g.c_b2;
+    const double* Cin = g.Cin + z1 * g.c_b1 + z2 * g.c_b2;
     const double* __restrict__ W = g.ws + lt * g.nsplit * (long)(BM * BN);
     for (int e = threadIdx.x; e < BM * BN; e += blockDim.x) {
         const int r = e / BN, c = e - r * BN;
@@ -339,10 +342,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmK g, int B
         if (m >= g.M || n >= g.N) continue;
         double sum = 0.0;
         for (int k = 0; k < g.nsplit; ++k) sum += W[(long)k * (BM * BN) + e];
-        double* p = C + (long)m * g.ldc + n;
+        const long off = (long)m * g.ldc + n;
         double v = g.alpha * sum;
-        if (g.beta != 0.0) v += g.beta * (*p);
-        *p = v;
+        if (g.beta != 0.0) v += g.beta * Cin[off];
+        C[off] = v;
     }
 }
 
@@ -852,6 +855,7 @@ void gemm(const Gemm& g, stream_t s) {
     const bool b_kcontig = (b_sk == 1);
     GemmK k;
     k.A = g.A; k.B = g.B; k.C = g.C;
+    k.Cin = g.Cin ? g.Cin : g.C;
     k.a_ld = a_kcontig ? a_sm : a_sk;
     k.b_ld = b_kcontig ? b_sn : b_sk;
     k.ldc = g.ldc;
@@ -860,8 +864,6 @@ void gemm(const Gemm& g, stream_t s) {
     k.nb2 = g.nb2;
     k.a_b1 = g.a_b1; k.a_b2 = g.a_b2; k.b_b1 = g.b_b1; k.b_b2 = g.b_b2; k.c_b1 = g.c_b1; k.c_b2 = g.c_b2;
     k.ws = nullptr;
-    static const int variant = getenv("PYMES_GEMM_VARIANT") ? atoi(getenv("PYMES_GEMM_VARIANT")) : 0;
-    k.variant = variant;
 
     // ---- tile shape: 128x128 unless a dimension is small -----------------------------
     int BM = 128, BN = 128;

@@ -49,12 +49,12 @@ void gemm(const Gemm& g, stream_t) {
             const double* A = g.A + z1 * g.a_b1 + z2 * g.a_b2;
             const double* B = g.B + z1 * g.b_b1 + z2 * g.b_b2;
             double* C = g.C + z1 * g.c_b1 + z2 * g.c_b2;
+            const double* Cin = (g.Cin ? g.Cin : g.C) + z1 * g.c_b1 + z2 * g.c_b2;
             for (int64_t m = 0; m < g.M; ++m)
                 for (int64_t n = 0; n < g.N; ++n) {
                     double s = 0.0;
                     for (int64_t k = 0; k < g.K; ++k) s += A[m * g.a_sm + k * g.a_sk] * B[k * g.b_sk + n * g.b_sn];
-                    double* c = C + m * g.ldc + n;
-                    *c = g.beta != 0.0 ? g.alpha * s + g.beta * (*c) : g.alpha * s;
+                    C[m * g.ldc + n] = g.beta != 0.0 ? g.alpha * s + g.beta * Cin[m * g.ldc + n] : g.alpha * s;
                 }
         }
     if (g_prof) { g_launches++; g_flops += 2.0 * g.M * g.N * g.K * g.nb1 * g.nb2; }
