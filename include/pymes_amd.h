@@ -116,12 +116,13 @@ int pymes_ladder_sym_unpack(pymes_ctx* ctx, const double* L_dev, double* r2_dev,
  * communication is needed to produce a slab.  After the slabs have been exchanged (one all-gather per buffer)
  * pymes_residual_finish adds the replicated terms and assembles R.  world = 1 reproduces
  * pymes_doubles_residual.  pymes_ccsd_dress_abcd_rows dresses only rows a in [a_begin,a_end) of V_abcd
- * (ccsd.py:414-419) — the rows a rank's ladder chunk reads. */
+ * (ccsd.py:414-419) — the rows a rank's ladder chunk reads; with lower_only != 0 only the entries b <= a
+ * (all the pair-packed ladder touches) are defined afterwards. */
 int pymes_residual_slab(pymes_ctx* ctx, const double* f_dev, const double* t2_dev, double* ETd_dev, double* ETx_dev,
                         double* L_dev, int rank, int world, uint32_t flags);
 int pymes_residual_finish(pymes_ctx* ctx, const double* f_dev, const double* t2_dev, const double* ETd_dev,
                           const double* ETx_dev, const double* L_dev, double* r2_dev, uint32_t flags);
-int pymes_ccsd_dress_abcd_rows(pymes_ctx* ctx, const double* t1_dev, int a_begin, int a_end);
+int pymes_ccsd_dress_abcd_rows(pymes_ctx* ctx, const double* t1_dev, int a_begin, int a_end, int lower_only);
 /* ccsd.py:176-179 / ccd.py:123-124: dt = r/(D+shift) (as r * (1/(D+shift))), t += delta*dt; rank 2 or 4 */
 int pymes_cc_update(pymes_ctx* ctx, double* t_dev, double* dt_dev, const double* r_dev, double level_shift,
                     double delta, int rank);

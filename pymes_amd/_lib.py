@@ -56,7 +56,7 @@ SIGNATURES = {
                                       C.c_int, C.c_uint32]),
     "pymes_residual_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_uint32]),
-    "pymes_ccsd_dress_abcd_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "pymes_ccsd_dress_abcd_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "pymes_cc_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
                                   C.c_int]),
     "pymes_ccsd_energy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_double_p]),

@@ -254,10 +254,10 @@ int pymes_residual_finish(pymes_ctx* ctx, const double* f, const double* t2, con
         E(ctx).residual_finish(f, t2, ETd, ETx, L, r2, flags);
     });
 }
-int pymes_ccsd_dress_abcd_rows(pymes_ctx* ctx, const double* t1, int a0, int a1) {
+int pymes_ccsd_dress_abcd_rows(pymes_ctx* ctx, const double* t1, int a0, int a1, int lower_only) {
     return guarded([&] {
         need(t1, "t1");
-        E(ctx).dress_abcd_rows(t1, a0, a1);
+        E(ctx).dress_abcd_rows(t1, a0, a1, lower_only != 0);
     });
 }
 int pymes_cc_update(pymes_ctx* ctx, double* t, double* dt, const double* r, double shift, double delta, int rank) {

@@ -337,19 +337,30 @@ void Engine::residual_finish(const double* f, const double* t2, const double* ET
     permute(1.0, ETx, "biaj", 1.0, R, "abij");
 }
 
-// rows a in [a0,a1) of the T1-dressed V_abcd (ccsd.py:414-419): what a rank needs for its ladder rows
-void Engine::dress_abcd_rows(const double* t1, int a0, int a1) {
+// rows a in [a0,a1) of the T1-dressed V_abcd (ccsd.py:414-419): what a rank needs for its ladder rows.
+// lower_only: only the entries with b <= a are produced (all the pair-packed ladder reads), in a-blocks of
+// 32 rows with b < block end — 56 % of the traffic of the full rows at nv = 200.
+void Engine::dress_abcd_rows(const double* t1, int a0, int a1, bool lower_only) {
     if (a0 < 0 || a1 > nv || a0 > a1) throw Error("dress_abcd_rows: bad range");
     if (a0 == a1) return;
     TView t = make_view(const_cast<double*>(t1), {(int64_t)nv, (int64_t)no});
-    TView dst = slice(block_view(ensure_dressed(P_abcd), P_abcd), 0, a0, a1);
-    const TView raw = slice(block(P_abcd), 0, a0, a1);
-    contract(-1.0, t, "qx", slice(block(P_aibc), 0, a0, a1), "pxrs", 1.0, dst, "pqrs", "p", &raw);     // :416 (+ copy)
+    TView full = block_view(ensure_dressed(P_abcd), P_abcd);
     ArenaScope scope(arena);
     TView oth = block_view(arena.alloc(block_size(P_iabc)), P_iabc);
     const TView raw_iabc = block(P_iabc);
     contract(-1.0, t, "qy", block(P_ijab), "xyrs", 1.0, oth, "xqrs", "x", &raw_iabc);                 // dressed iabc (:385-388)
-    contract(-1.0, slice(t, 0, a0, a1), "px", oth, "xqrs", 1.0, dst, "pqrs");                    // :415, :417
+    const int step = lower_only ? 32 : (a1 - a0);
+    for (int p0 = a0; p0 < a1; p0 += step) {
+        const int p1 = std::min(a1, p0 + step);
+        const int64_t qmax = lower_only ? p1 : nv;
+        auto cut = [&](const TView& x) { return slice(slice(x, 0, p0, p1), 1, 0, qmax); };
+        TView dst = cut(full);
+        const TView raw = cut(block(P_abcd));
+        // dst[p,q,r,s] = V[p,q,r,s] - sum_x t[q,x] V_aibc[p,x,r,s]                                   (:416, + copy)
+        contract(-1.0, slice(t, 0, 0, qmax), "qx", slice(block(P_aibc), 0, p0, p1), "pxrs", 1.0, dst, "pqrs", "p", &raw);
+        // dst[p,q,r,s] -= sum_x t[p,x] V~_iabc[x,q,r,s]                                              (:415, :417)
+        contract(-1.0, slice(t, 0, p0, p1), "px", slice(oth, 1, 0, qmax), "xqrs", 1.0, dst, "pqrs", "p");
+    }
     if (lpack_.dressed) lpack_.valid = false;
 }
 

@@ -124,7 +124,7 @@ class Engine {
                        unsigned flags);
     void residual_finish(const double* f, const double* t2, const double* ETd, const double* ETx, const double* L,
                          double* r2, unsigned flags);
-    void dress_abcd_rows(const double* t1, int a0, int a1);
+    void dress_abcd_rows(const double* t1, int a0, int a1, bool lower_only);
     void cc_update(double* t, double* dt, const double* r, double shift, double delta, int rank);  // ccsd.py:176-179
     void ccsd_energy(const double* f, const double* t1, const double* t2, double out[3]);     // ccsd.py:458-466
     void ccd_energy(const double* t2, double out[2]);                                         // ccd.py:256-262

@@ -276,8 +276,9 @@ class Context:
                       self._flags(is_dcd, dressed, False, True, True))
         return out
 
-    def dress_abcd_rows(self, t1, a_begin, a_end):
-        self.lib.call("pymes_ccsd_dress_abcd_rows", self.handle, C.c_void_p(t1.ptr), int(a_begin), int(a_end))
+    def dress_abcd_rows(self, t1, a_begin, a_end, lower_only=False):
+        self.lib.call("pymes_ccsd_dress_abcd_rows", self.handle, C.c_void_p(t1.ptr), int(a_begin), int(a_end),
+                      int(lower_only))
 
     def ladder_sym(self, t2, L, row_begin, row_end, dressed=False):
         """Rows [row_begin,row_end) of the pair-packed ladder L[v(v+1)/2, o*o] (include/pymes_amd.h)."""

@@ -105,14 +105,18 @@ class CCSD(ccd.CCD):
         r2 = ctx.pool_get(t2.shape)
         world, rank = st["world"], st["rank"]
         if world == 1:
-            ctx.dress_V(t1, LOOP_KEYS)                              # :165 (only the blocks the residual reads)
+            if st["sym"]:    # the pair-packed ladder reads V~_abcd for b <= a only
+                ctx.dress_V(t1, ("abij", "klij", "iajb", "iabj"))   # :165 (only the blocks the residual reads)
+                ctx.dress_abcd_rows(t1, 0, ctx.nv, lower_only=True)
+            else:
+                ctx.dress_V(t1, LOOP_KEYS)
             ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True, sym_ladder=st["sym"])   # :171
         elif st["sym"]:
             # sharded: this rank's column slab of the ring products + its rows of the packed ladder (for which it
             # dresses only its own rows of V_abcd), three all-gathers, replicated remainder
             ctx.dress_V(t1, ("abij", "klij", "iajb", "iabj"))
             lo, hi = pdist.slab_rows(st["npp"], rank, world)
-            ctx.dress_abcd_rows(t1, *pdist.a_range_of_pair_rows(lo, hi))
+            ctx.dress_abcd_rows(t1, *pdist.a_range_of_pair_rows(lo, hi), lower_only=True)
             ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], rank, world, is_dcd=self.is_dcd,
                               dressed=True)
             ctx.sync()

@@ -147,7 +147,7 @@ def sharded_residual_check(lib, cases, worlds, tol):
                     hi = min(lo + (-(-npp // world)), npp)
                     if hi > lo:      # rows a of V_abcd that the packed rows [lo,hi) touch
                         a_of = lambda r: int((np.sqrt(8.0 * r + 1.0) - 1.0) / 2.0 + 1e-9)
-                        ctx.dress_abcd_rows(dT1, a_of(lo), a_of(hi - 1) + 1)
+                        ctx.dress_abcd_rows(dT1, a_of(lo), a_of(hi - 1) + 1, lower_only=(world % 2 == 0))
                     ctx.residual_slab(dF, dT2, ETd, ETx, L, rank, world, is_dcd=dcd, dressed=True)
                 r2 = ctx.empty(t2.shape)
                 ctx.residual_finish(dF, dT2, ETd, ETx, L, r2, is_dcd=dcd, dressed=True)
