@@ -359,7 +359,7 @@ void Engine::dress_abcd_rows(const double* t1, int a0, int a1, bool lower_only) 
         // dst[p,q,r,s] = V[p,q,r,s] - sum_x t[q,x] V_aibc[p,x,r,s]                                   (:416, + copy)
         contract(-1.0, slice(t, 0, 0, qmax), "qx", slice(block(P_aibc), 0, p0, p1), "pxrs", 1.0, dst, "pqrs", "p", &raw);
         // dst[p,q,r,s] -= sum_x t[p,x] V~_iabc[x,q,r,s]                                              (:415, :417)
-        contract(-1.0, slice(t, 0, p0, p1), "px", slice(oth, 1, 0, qmax), "xqrs", 1.0, dst, "pqrs", "p");
+        contract(-1.0, slice(t, 0, p0, p1), "px", slice(oth, 1, 0, qmax), "xqrs", 1.0, dst, "pqrs");
     }
     if (lpack_.dressed) lpack_.valid = false;
 }
