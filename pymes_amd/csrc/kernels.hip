@@ -317,6 +317,232 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_kernel(const GemmK g) {
     }
 }
 
+// ------------------------------------------------------------------------------------
+// LDS-DMA variant of the 128x128 GEMM (16-byte aligned operands).  Same tiling, MFMA schedule and
+// epilogue as dgemm_kernel, but the operand tiles go global -> LDS directly
+// (`global_load_lds_dwordx4`: no staging VGPRs, no ds_write, no per-tile pointer arithmetic on the VALU):
+//   * an M/N-contiguous tile [16 k][128] is 16 wave-instructions of one 1-KiB k-row each, LDS pitch 144;
+//   * a K-contiguous tile [128 rows][16 k] is 16 wave-instructions of eight 128-B rows each.  The LDS
+//     destination of an LDS-DMA is lane-linear, so the bank-conflict fix cannot be padding: the 16-B
+//     chunk c of row r is stored at chunk slot c ^ ((r >> 1) & 7) by permuting the per-lane SOURCE address,
+//     and the fragment reads apply the same XOR (conflict-free ds_read_b64 for 16 consecutive rows).
+// The last, partial k-tile is staged through registers with zero fill.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const double* gsrc, double* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <bool AKC, bool BKC>
+__global__ void __launch_bounds__(kThreads, 2) dgemm_glds_kernel(const GemmK g) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int BM = 128, BN = 128, WM = 64, WN = 64, FM = 4, FN = 4;
+    constexpr int A_PITCH = AKC ? BK : (BM + 16);
+    constexpr int A_TILE = AKC ? BM * BK : BK * A_PITCH;
+    constexpr int B_PITCH = BKC ? BK : (BN + 16);
+    constexpr int B_TILE = BKC ? BN * BK : BK * B_PITCH;
+    double* As = smem;
+    double* Bs = smem + 2 * A_TILE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base = M0)
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    const long bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles = g.tiles_m * g.tiles_n;
+    const long lt = bid / g.nsplit;
+    const int ks = (int)(bid - lt * g.nsplit);
+    const long gt = g.tile_begin + lt;
+    const long z = gt / tiles;
+    const int t = (int)(gt - z * tiles);
+    constexpr int GROUP = 8;
+    const int group_sz = GROUP * g.tiles_n;
+    const int grp = t / group_sz;
+    const int first_m = grp * GROUP;
+    const int gm = min(g.tiles_m - first_m, GROUP);
+    const int tin = t - grp * group_sz;
+    const int tm = first_m + tin % gm;
+    const int tn = tin / gm;
+    const long z1 = z / g.nb2, z2 = z - z1 * g.nb2;
+    const double* __restrict__ A = g.A + z1 * g.a_b1 + z2 * g.a_b2;
+    const double* __restrict__ B = g.B + z1 * g.b_b1 + z2 * g.b_b2;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = ks * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+    const int nfull = (kend - kbeg) / BK;
+
+    // ---- LDS-DMA source pointers: 4 wave-instructions per operand per wave per tile ----------------
+    // K-contiguous: instruction j of wave w covers rows (4w+j)*8 .. +8; lane -> (row, chunk slot)
+    // M/N-contiguous: instruction j of wave w covers k-row 4w+j; lane -> columns 2*lane, 2*lane+1
+    // rows / columns beyond M or N are clamped (they only feed C entries that are never stored)
+    const double* pa_j[4];
+    const double* pb_j[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (AKC) {
+            const int row = wave * 32 + (lane >> 3) + 8 * j;
+            const int cg = (lane & 7) ^ ((row >> 1) & 7);
+            pa_j[j] = A + (long)min(m0 + row, g.M - 1) * g.a_ld + kbeg + cg * 2;
+        } else {
+            pa_j[j] = A + (long)(kbeg + wave * 4 + j) * g.a_ld + min(m0 + 2 * lane, g.M - 2);
+        }
+        if (BKC) {
+            const int row = wave * 32 + (lane >> 3) + 8 * j;
+            const int cg = (lane & 7) ^ ((row >> 1) & 7);
+            pb_j[j] = B + (long)min(n0 + row, g.N - 1) * g.b_ld + kbeg + cg * 2;
+        } else {
+            pb_j[j] = B + (long)(kbeg + wave * 4 + j) * g.b_ld + min(n0 + 2 * lane, g.N - 2);
+        }
+    }
+    const long a_kstep = AKC ? (long)BK : (long)BK * g.a_ld;
+    const long b_kstep = BKC ? (long)BK : (long)BK * g.b_ld;
+    // wave-uniform LDS destinations of the 4 instructions
+    const int a_dst = AKC ? wave * 32 * BK : wave * 4 * A_PITCH;       // + j * (8*BK | A_PITCH)
+    const int b_dst = BKC ? wave * 32 * BK : wave * 4 * B_PITCH;
+    constexpr int A_DSTEP = AKC ? 8 * BK : A_PITCH;
+    constexpr int B_DSTEP = BKC ? 8 * BK : B_PITCH;
+
+    auto stage_dma = [&](int buf) {      // one full k-tile, then advance the source pointers
+        double* as = As + buf * A_TILE + a_dst;
+        double* bs = Bs + buf * B_TILE + b_dst;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16(pa_j[j], as + j * A_DSTEP);
+            pa_j[j] += a_kstep;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16(pb_j[j], bs + j * B_DSTEP);
+            pb_j[j] += b_kstep;
+        }
+    };
+    auto stage_tail = [&](int buf, int k0) {   // partial k-tile through registers, zero beyond kend
+        double* as = As + buf * A_TILE;
+        double* bs = Bs + buf * B_TILE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v2d va = {0.0, 0.0}, vb = {0.0, 0.0};
+            if (AKC) {
+                const int row = wave * 32 + (lane >> 3) + 8 * j;
+                const int cg = (lane & 7) ^ ((row >> 1) & 7);
+                if (k0 + cg * 2 < kend) va = *reinterpret_cast<const v2d*>(pa_j[j]);
+                *reinterpret_cast<v2d*>(as + row * BK + (lane & 7) * 2) = va;
+            } else {
+                const int krow = wave * 4 + j;
+                if (k0 + krow < kend) va = *reinterpret_cast<const v2d*>(pa_j[j]);
+                *reinterpret_cast<v2d*>(as + krow * A_PITCH + 2 * lane) = va;
+            }
+            if (BKC) {
+                const int row = wave * 32 + (lane >> 3) + 8 * j;
+                const int cg = (lane & 7) ^ ((row >> 1) & 7);
+                if (k0 + cg * 2 < kend) vb = *reinterpret_cast<const v2d*>(pb_j[j]);
+                *reinterpret_cast<v2d*>(bs + row * BK + (lane & 7) * 2) = vb;
+            } else {
+                const int krow = wave * 4 + j;
+                if (k0 + krow < kend) vb = *reinterpret_cast<const v2d*>(pb_j[j]);
+                *reinterpret_cast<v2d*>(bs + krow * B_PITCH + 2 * lane) = vb;
+            }
+        }
+    };
+    auto stage = [&](int kt, int buf) {
+        if (kt < nfull) stage_dma(buf);
+        else stage_tail(buf, kbeg + kt * BK);
+    };
+
+    v4d acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+
+    // fragment offsets.  K-contiguous: row*16 + (((2kk + (l4>>1)) ^ f) * 2) + (l4&1), f = (row>>1)&7 = (l15>>1)&7
+    const int fsw = (l15 >> 1) & 7;
+    int a_koff[4], b_koff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int sw = (((2 * kk + (l4 >> 1)) ^ fsw) << 1) + (l4 & 1);
+        a_koff[kk] = AKC ? (wm * WM + l15) * BK + sw : (kk * 4 + l4) * A_PITCH + wm * WM + l15;
+        b_koff[kk] = BKC ? (wn * WN + l15) * BK + sw : (kk * 4 + l4) * B_PITCH + wn * WN + l15;
+    }
+    constexpr int A_FSTEP = AKC ? 16 * BK : 16;
+    constexpr int B_FSTEP = BKC ? 16 * BK : 16;
+
+    double a[2][FM], b[2][FN];
+    auto read_frags = [&](const double* as, const double* bs, int kk, double (&ra_)[FM], double (&rb_)[FN]) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) ra_[i] = as[a_koff[kk] + i * A_FSTEP];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) rb_[j] = bs[b_koff[kk] + j * B_FSTEP];
+    };
+    auto mfma_step = [&](const double (&ra_)[FM], const double (&rb_)[FN]) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra_[i], rb_[j], acc[i][j], 0, 0, 0);
+    };
+    auto landed = [&]() {     // this wave's DMA has landed and its LDS reads are done; then everyone's
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    if (nkt > 0) stage(0, 0);
+    landed();
+    if (nkt > 0) read_frags(As, Bs, 0, a[0], b[0]);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool has_next = kt + 1 < nkt;
+        if (has_next) stage(kt + 1, cur ^ 1);    // buffer cur^1 was last read before the previous barrier
+        const double* as = As + cur * A_TILE;
+        const double* bs = Bs + cur * B_TILE;
+        read_frags(as, bs, 1, a[1], b[1]);
+        mfma_step(a[0], b[0]);
+        read_frags(as, bs, 2, a[0], b[0]);
+        mfma_step(a[1], b[1]);
+        read_frags(as, bs, 3, a[1], b[1]);
+        mfma_step(a[0], b[0]);
+        landed();
+        if (has_next) read_frags(As + (cur ^ 1) * A_TILE, Bs + (cur ^ 1) * B_TILE, 0, a[0], b[0]);
+        mfma_step(a[1], b[1]);
+    }
+
+    // ---- epilogue (as dgemm_kernel) -----------------------------------------------------------------
+    if (g.nsplit > 1) {
+        double* __restrict__ W = g.ws + (lt * g.nsplit + ks) * (long)(BM * BN);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    W[(wm * WM + i * 16 + l4 + 4 * r) * BN + wn * WN + j * 16 + l15] = acc[i][j][r];
+        return;
+    }
+    double* C = g.C + z1 * g.c_b1 + z2 * g.c_b2;
+    const double* Cin = g.Cin + z1 * g.c_b1 + z2 * g.c_b2;
+    const long ldc = g.ldc;
+    const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * WN + j * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * WM + i * 16 + l4 + 4 * r;
+                if (m < g.M && n < g.N) {
+                    const long off = (long)m * ldc + n;
+                    double v = alpha * acc[i][j][r];
+                    if (beta != 0.0) v += beta * Cin[off];
+                    C[off] = v;
+                }
+            }
+        }
+    }
+}
+
 // C tile = alpha * sum_ks ws[tile][ks] + beta * C tile, for the tiles [tile_begin, tile_begin + ntiles)
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmK g, int BM, int BN) {
     const long lt = blockIdx.x;
@@ -761,8 +987,31 @@ void launch_gemm(const GemmK& k, long nblocks, hipStream_t st) {
     HIP_CHECK(hipGetLastError());
 }
 
+template <bool AKC, bool BKC>
+void launch_gemm_glds(const GemmK& k, long nblocks, hipStream_t st) {
+    constexpr int A_T = AKC ? 128 * BK : BK * (128 + 16);
+    constexpr int B_T = BKC ? 128 * BK : BK * (128 + 16);
+    constexpr size_t lds = (size_t)2 * (A_T + B_T) * sizeof(double);
+    static bool attr_set = false;
+    auto fn = dgemm_glds_kernel<AKC, BKC>;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)nblocks), dim3(kThreads), lds, st, k);
+    HIP_CHECK(hipGetLastError());
+}
+
 template <int BM, int BN>
 void dispatch_layout(const GemmK& k, bool akc, bool bkc, int vec, long nblocks, hipStream_t st) {
+    if (BM == 128 && BN == 128 && vec == 2 && !getenv("PYMES_GEMM_NO_LDSDMA")) {
+        if (akc && bkc) launch_gemm_glds<true, true>(k, nblocks, st);
+        else if (akc) launch_gemm_glds<true, false>(k, nblocks, st);
+        else if (bkc) launch_gemm_glds<false, true>(k, nblocks, st);
+        else launch_gemm_glds<false, false>(k, nblocks, st);
+        return;
+    }
     if (vec == 2) {
         if (akc && bkc) launch_gemm<BM, BN, true, true, 2>(k, nblocks, st);
         else if (akc) launch_gemm<BM, BN, true, false, 2>(k, nblocks, st);
