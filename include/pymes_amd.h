@@ -105,14 +105,17 @@ int pymes_ladder(pymes_ctx* ctx, const double* t2_dev, double* r2_dev, int a_beg
 /* pair-packed form of the same term.  L is [v(v+1)/2][o*o] on the device; row r = P(a,b) = a(a+1)/2+b
  * (a >= b) holds [ LS (o(o+1)/2 entries, P(i,j)) | LA (o(o-1)/2 entries, Q(i,j) = i(i-1)/2+j) ].
  * pymes_ladder_sym fills rows [row_begin,row_end) (the shardable unit); pymes_ladder_sym_unpack adds
- * R[a,b,i,j] = beta R + LS + sgn(a-b) sgn(i-j) LA from a complete L. */
+ * R[a,b,i,j] = beta R + LS + sgn(a-b) sgn(i-j) LA from a complete L.
+ * hole_ladder: 0 = ccd.py:187 only; 1 / 2 = also add the hole ladder sum_kl I_klij T_abkl (ccd.py:175-186) to the
+ * same rows, evaluated pair-packed as well (I_klij = I_lkji), with I = V_klij + V_klcd T_cdij (1, CCD/CCSD) or
+ * I = V_klij (2, DCD/DCSD). */
 int pymes_ladder_sym(pymes_ctx* ctx, const double* t2_dev, double* L_dev, int64_t row_begin, int64_t row_end,
-                     int dressed);
+                     int dressed, int hole_ladder);
 int pymes_ladder_sym_unpack(pymes_ctx* ctx, const double* L_dev, double* r2_dev, double beta);
 /* The symmetry-reduced residual (PYMES_SYM_LADDER | PYMES_SYM_RINGS) in its shardable form, one process per
  * GPU.  pymes_residual_slab computes what rank `rank` of `world` owns: the rows [c0,c1) of ETd and ETx (both
  * [o*v][o*v] on the device; ET[(b,j),(a,i)] = Ex[(a,i),(b,j)], rows cut into `world` chunks of ceil(ov/world))
- * and, if L_dev is not NULL, its chunk of rows of the pair-packed ladder L (pymes_ladder_sym).  No
+ * and, if L_dev is not NULL, its chunk of rows of the pair-packed ladders L (pymes_ladder_sym with the hole ladder included).  No
  * communication is needed to produce a slab.  After the slabs have been exchanged (one all-gather per buffer)
  * pymes_residual_finish adds the replicated terms and assembles R.  world = 1 reproduces
  * pymes_doubles_residual.  pymes_ccsd_dress_abcd_rows dresses only rows a in [a_begin,a_end) of V_abcd

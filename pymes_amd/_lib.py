@@ -50,7 +50,7 @@ SIGNATURES = {
     "pymes_ccsd_singles_residual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pymes_doubles_residual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "pymes_ladder": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]),
-    "pymes_ladder_sym": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int]),
+    "pymes_ladder_sym": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int]),
     "pymes_ladder_sym_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]),
     "pymes_residual_slab": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_int, C.c_uint32]),

@@ -228,10 +228,10 @@ int pymes_ladder(pymes_ctx* ctx, const double* t2, double* r2, int a0, int a1, i
         E(ctx).ladder(t2, r2, a0, a1, dressed != 0, beta);
     });
 }
-int pymes_ladder_sym(pymes_ctx* ctx, const double* t2, double* L, int64_t r0, int64_t r1, int dressed) {
+int pymes_ladder_sym(pymes_ctx* ctx, const double* t2, double* L, int64_t r0, int64_t r1, int dressed, int hole) {
     return guarded([&] {
         need(t2, "t2"); need(L, "L");
-        E(ctx).ladder_sym(t2, L, r0, r1, dressed != 0);
+        E(ctx).ladder_sym(t2, L, r0, r1, dressed != 0, hole);
     });
 }
 int pymes_ladder_sym_unpack(pymes_ctx* ctx, const double* L, double* r2, double beta) {

@@ -115,7 +115,7 @@ void Engine::doubles_residual(const double* f, const double* t2, double* r2, uns
         if (sym_ladder) {
             ArenaScope s2(arena);
             double* L = arena.alloc(v * (v + 1) / 2 * o * o);
-            ladder_sym(t2, L, 0, v * (v + 1) / 2, dressed);
+            ladder_sym(t2, L, 0, v * (v + 1) / 2, dressed, 0);
             ladder_sym_unpack(L, r2, 1.0);
         } else {
             contract(1.0, block(P_abcd, dressed), "abcd", T, "cdij", 1.0, R, "abij");
@@ -221,7 +221,7 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
     if (L && !skip_ladder) {
         int64_t r0, r1;
         chunk(v * (v + 1) / 2, r0, r1);
-        ladder_sym(t2, L, r0, r1, dressed);
+        ladder_sym(t2, L, r0, r1, dressed, quad ? 1 : 2);      // particle AND hole ladder rows of this rank
     }
     int64_t c0, c1;
     chunk(ov, c0, c1);
@@ -305,16 +305,15 @@ void Engine::residual_finish(const double* f, const double* t2, const double* ET
     TView Vijab = block(P_ijab);
     ArenaScope scope(arena);
     copy(block(P_abij, dressed), R);                                                        // :185
-    {
+    if (L && !skip_ladder) {
+        ladder_sym_unpack(L, r2, 1.0);                  // particle (:187) + hole (:175-186) ladders, pair-packed
+    } else {
         ArenaScope s2(arena);
         TView hole = make_view(arena.alloc(o * o * o * o), {o, o, o, o});
         copy(block(P_klij, dressed), hole);                                                 // :178
         if (quad) contract(1.0, Vijab, "klcd", T, "cdij", 1.0, hole, "klij");                // :180
         contract(1.0, hole, "klij", T, "abkl", 1.0, R, "abij");                             // :186
-    }
-    if (!skip_ladder) {                                                                     // :187
-        if (L) ladder_sym_unpack(L, r2, 1.0);
-        else contract(1.0, block(P_abcd, dressed), "abcd", T, "cdij", 1.0, R, "abij");
+        if (!skip_ladder) contract(1.0, block(P_abcd, dressed), "abcd", T, "cdij", 1.0, R, "abij");   // :187
     }
     {
         // X_ac = f_ac - w sum Tt[a,d,k,l] V[l,k,d,c]  (:206-221);  Ex += X_ac T[c,b,i,j]  (:231)
@@ -378,10 +377,11 @@ void Engine::ladder(const double* t2, double* r2, int a0, int a1, bool dressed, 
 //   L_abij = LS_(ab)(ij) + sgn(a-b) sgn(i-j) LA_(ab)(ij),
 //   LS = sum_{c>=d} (V_abcd + V_abdc) f_cd (T_cdij + T_dcij)/2,   LA = sum_{c>d} (V_abcd - V_abdc) (T_cdij - T_dcij)/2
 // for a >= b, i >= j only: two GEMMs of v(v+1)/2 x v(v+-1)/2 x o(o+-1)/2 = 1/4 of the flops of ccd.py:187.
-void Engine::ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1, bool dressed) {
+void Engine::ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1, bool dressed, int hole) {
     const int64_t o = no, v = nv, npp = v * (v + 1) / 2, npm = v * (v - 1) / 2, opp = o * (o + 1) / 2,
                   opm = o * (o - 1) / 2;
     if (row0 < 0 || row1 > npp || row0 > row1) throw Error("ladder_sym: bad pair-row range");
+    if (hole < 0 || hole > 2) throw Error("ladder_sym: hole must be 0, 1 (CCSD) or 2 (DCSD)");
     if (row0 == row1) return;
     const int64_t rows = row1 - row0;
     if (!(lpack_.valid && lpack_.dressed == dressed && lpack_.row0 == row0 && lpack_.row1 == row1)) {
@@ -393,7 +393,7 @@ void Engine::ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1,
             lpack_.Vp = static_cast<double*>(dev::dmalloc(sizeof(double) * rows * npp));
             lpack_.Vm = static_cast<double*>(dev::dmalloc(sizeof(double) * rows * std::max<int64_t>(npm, 1)));
         }
-        dev::ladder_pack_V(block(P_abcd, dressed).p, lpack_.Vp, lpack_.Vm, nv, row0, row1, stream);
+        dev::ladder_pack_V(block(P_abcd, dressed).p, lpack_.Vp, lpack_.Vm, nv, nv, row0, row1, stream);
         stats.permute_calls++;
         stats.permute_bytes += 8.0 * 2.0 * double(rows) * double(v * v);
         lpack_.row0 = row0; lpack_.row1 = row1; lpack_.dressed = dressed; lpack_.valid = true;
@@ -401,20 +401,49 @@ void Engine::ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1,
     ArenaScope scope(arena);
     double* Sp = arena.alloc(npp * opp);
     double* Am = arena.alloc(std::max<int64_t>(npm * opm, 1));
-    dev::ladder_pack_T(t2, Sp, Am, no, nv, stream);
+    dev::ladder_pack_T(t2, Sp, Am, no, nv, dev::PACK_ROW_HALF, stream);
     stats.permute_calls++;
     stats.permute_bytes += 8.0 * 2.0 * double(v * v * o * o);
     // L rows [row0,row1): [ LS (opp) | LA (opm) ], row length o*o
     TView Lrows = make_view(L + row0 * o * o, {rows, o * o});
-    contract(1.0, make_view(lpack_.Vp, {rows, npp}), "rk", make_view(Sp, {npp, opp}), "kn", 0.0,
-             slice(Lrows, 1, 0, opp), "rn");
+    TView LS = slice(Lrows, 1, 0, opp), LA = slice(Lrows, 1, opp, o * o);
+    TView SpT = make_view(Sp, {npp, opp}), AmT = make_view(Am, {npm, opm});
+    contract(1.0, make_view(lpack_.Vp, {rows, npp}), "rk", SpT, "kn", 0.0, LS, "rn");
     if (opm > 0) {
-        if (npm > 0)
-            contract(1.0, make_view(lpack_.Vm, {rows, npm}), "rk", make_view(Am, {npm, opm}), "kn", 0.0,
-                     slice(Lrows, 1, opp, o * o), "rn");
-        else
-            zero(slice(Lrows, 1, opp, o * o));
+        if (npm > 0) contract(1.0, make_view(lpack_.Vm, {rows, npm}), "rk", AmT, "kn", 0.0, LA, "rn");
+        else zero(LA);
     }
+    if (!hole) return;
+    // ---- hole ladder (ccd.py:175-186) in the same pair-packed rows:  HL_abij = sum_kl I_klij T_abkl,
+    // I = V~_klij (+ sum_cd V_klcd T_cdij for CCSD).  I_klij = I_lkji, so with S/A = (T_abkl +- T_bakl)/2:
+    //   HLS[(a>=b),(i>=j)] = sum_{k>=l} g_kl S_abkl (I_klij + I_lkij),  HLA[(a>b),(i>j)] = sum_{k>l} A_abkl (I_klij - I_lkij)
+    // and (I_klij +- I_lkij)/2 = pack(V~_klij) + sum_{c>=d} (V_klcd +- V_kldc) (f_cd S | A)_cdij.
+    double* Ip = arena.alloc(opp * opp);
+    double* Im = arena.alloc(std::max<int64_t>(opp * opm, 1));
+    dev::ladder_pack_T(block(P_klij, dressed).p, Ip, Im, no, no, dev::PACK_AM_PROWS, stream);
+    TView Ipv = make_view(Ip, {opp, opp}), Imv = make_view(Im, {opp, opm});
+    if (hole == 1) {
+        if (!static_.count("VpIjab")) {      // static per solve: dressed ijab == undressed ijab
+            double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * npp));
+            double* vm = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * std::max<int64_t>(npm, 1)));
+            static_["VpIjab"] = vp;
+            static_["VmIjab"] = vm;
+            dev::ladder_pack_V(block(P_ijab).p, vp, vm, no, nv, 0, opp, stream);
+        }
+        contract(2.0, make_view(static_["VpIjab"], {opp, npp}), "rk", SpT, "kn", 2.0, Ipv, "rn");
+        if (opm > 0 && npm > 0) contract(2.0, make_view(static_["VmIjab"], {opp, npm}), "rk", AmT, "kn", 2.0, Imv, "rn");
+        else if (opm > 0) axpby(2.0, Imv, 0.0, Imv);
+    } else {
+        axpby(2.0, Ipv, 0.0, Ipv);
+        if (opm > 0) axpby(2.0, Imv, 0.0, Imv);
+    }
+    double* SpR = arena.alloc(npp * opp);
+    double* AmR = arena.alloc(npp * opp);
+    dev::ladder_pack_T(t2, SpR, AmR, no, nv, dev::PACK_COL_HALF | dev::PACK_AM_PROWS | dev::PACK_AM_PCOLS, stream);
+    stats.permute_calls += 2;
+    stats.permute_bytes += 8.0 * 2.0 * double(v * v * o * o);
+    contract(1.0, slice(make_view(SpR, {npp, opp}), 0, row0, row1), "rk", Ipv, "kn", 1.0, LS, "rn");
+    if (opm > 0) contract(1.0, slice(make_view(AmR, {npp, opp}), 0, row0, row1), "rk", Imv, "kn", 1.0, LA, "rn");
 }
 
 void Engine::ladder_sym_unpack(const double* L, double* r2, double beta) {

@@ -76,14 +76,19 @@ void lincomb(double* out, int nx, const double* const* x, const double* c, int64
 // tau[a,b,i,j] = t2[a,b,i,j] + t1[a,i]*t1[b,j]                        (ccsd.py:462)
 void tau_build(double* tau, const double* t2, const double* t1, int no, int nv, stream_t s);
 
-// ---- symmetry-packed particle-particle ladder (ccd.py:187 with V_abcd = V_badc, T_cdij = T_dcji) --
+// ---- symmetry-packed ladders (ccd.py:186-187 with V_pqrs = V_qpsr, T_cdij = T_dcji) -----------------------
 // pair indices: P(x,y) = x(x+1)/2 + y for x >= y ("plus"), Q(x,y) = x(x-1)/2 + y for x > y ("minus").
-// For the pair rows r = P(a,b) in [rp0, rp1):
+// ladder_pack_V: V is [nr,nr,nc,nc].  For the pair rows r = P(a,b) in [rp0, rp1):
 //   Vp[r - rp0][P(c,d)] = V[a,b,c,d] + V[a,b,d,c]
 //   Vm[r - rp0][Q(c,d)] = V[a,b,c,d] - V[a,b,d,c]   (zero row when a == b)
-void ladder_pack_V(const double* V, double* Vp, double* Vm, int nv, int64_t rp0, int64_t rp1, stream_t s);
-// Sp[P(c,d)][P(i,j)] = f_cd (T[c,d,i,j] + T[d,c,i,j]) / 2, f = 1/2 on c == d;  Am[Q(c,d)][Q(i,j)] = (T[c,d,i,j] - T[d,c,i,j]) / 2
-void ladder_pack_T(const double* T, double* Sp, double* Am, int no, int nv, stream_t s);
+void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nc, int64_t rp0, int64_t rp1, stream_t s);
+// ladder_pack_T: X is [nr,nr,nc,nc]; pair (c,d) over nr, pair (i,j) over nc.
+//   Sp[P(c,d)][P(i,j)] = fr fc (X[c,d,i,j] + X[d,c,i,j]) / 2,  fr = 1/2 on c == d if PACK_ROW_HALF, fc = 1/2 on
+//   i == j if PACK_COL_HALF (a pair that is summed over carries the half on its diagonal);
+//   Am[row][col] = (X[c,d,i,j] - X[d,c,i,j]) / 2 with row = Q(c,d) (c > d) or P(c,d) if PACK_AM_PROWS and
+//   col = Q(i,j) (i > j) or P(i,j) if PACK_AM_PCOLS; entries on a diagonal pair are zero.
+enum { PACK_ROW_HALF = 1, PACK_AM_PROWS = 2, PACK_COL_HALF = 4, PACK_AM_PCOLS = 8 };
+void ladder_pack_T(const double* X, double* Sp, double* Am, int nc, int nr, int flags, stream_t s);
 // L[P(a,b)] = [ LS row (o(o+1)/2) | LA row (o(o-1)/2) ], row length o*o:
 // R[a,b,i,j] = beta R + LS[P(ab)][P(ij)] + sgn(a-b) sgn(i-j) LA[P(ab)][Q(ij)]
 void ladder_unpack(const double* L, double* R, double beta, int no, int nv, stream_t s);

@@ -116,7 +116,8 @@ class Engine {
     void ladder(const double* t2, double* r2, int a0, int a1, bool dressed, double beta);
     // the same term at 1/4 of the flops, valid when V_abcd = V_badc and T_cdij = T_dcji:
     // rows [row0,row1) of the pair-packed result L[v(v+1)/2][o*o] (device_api.h), then R = beta R + unpack(L)
-    void ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1, bool dressed);
+    // hole = 1 / 2 adds the hole ladder (ccd.py:175-186; CCSD / DCSD form of I_klij) to the same rows
+    void ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1, bool dressed, int hole = 0);
     void ladder_sym_unpack(const double* L, double* r2, double beta);
     // symmetry-reduced residual in shardable form (cc.cpp): this rank's column slab of the ring products
     // (rows of ETd/ETx) and its rows of the packed ladder L; then the replicated remainder + assembly

@@ -771,7 +771,7 @@ __device__ __forceinline__ void unrank_pair(long r, int& x, int& y) {   // r = x
 }
 
 __global__ void __launch_bounds__(256) ladder_pack_V_kernel(const double* __restrict__ V, double* __restrict__ Vp,
-                                                            double* __restrict__ Vm, int nv, long rp0,
+                                                            double* __restrict__ Vm, int nr, int nv, long rp0,
                                                             int nt, long ntp) {
     __shared__ double sA[32][33], sB[32][33];
     const long bid = blockIdx.x;
@@ -781,7 +781,7 @@ __global__ void __launch_bounds__(256) ladder_pack_V_kernel(const double* __rest
     unrank_pair(rp0 + row, a, b);
     unrank_pair(tp, tc, td);
     const long npp = (long)nv * (nv + 1) / 2, npm = (long)nv * (nv - 1) / 2;
-    const double* __restrict__ Vab = V + ((long)a * nv + b) * nv * nv;
+    const double* __restrict__ Vab = V + ((long)a * nr + b) * nv * nv;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c0 = tc * 32, d0 = td * 32;
 #pragma unroll
@@ -804,21 +804,28 @@ __global__ void __launch_bounds__(256) ladder_pack_V_kernel(const double* __rest
 }
 
 __global__ void ladder_pack_T_kernel(const double* __restrict__ T, double* __restrict__ Sp, double* __restrict__ Am,
-                                     int no, int nv) {
+                                     int no, int nv, int flags) {
     const long row = blockIdx.x;   // P(c,d)
     int c, d;
     unrank_pair(row, c, d);
+    const bool row_half = flags & dev::PACK_ROW_HALF, prow = flags & dev::PACK_AM_PROWS,
+               col_half = flags & dev::PACK_COL_HALF, pcol = flags & dev::PACK_AM_PCOLS;
     const long o2 = (long)no * no, opp = (long)no * (no + 1) / 2, opm = (long)no * (no - 1) / 2;
     const double* __restrict__ T1 = T + ((long)c * nv + d) * o2;
     const double* __restrict__ T2 = T + ((long)d * nv + c) * o2;
-    const double f = (c == d) ? 0.25 : 0.5;
-    const long mrow = (long)c * (c - 1) / 2 + d;
+    const double fr = (c == d && row_half) ? 0.25 : 0.5;
+    const long mrow = prow ? row : (long)c * (c - 1) / 2 + d;
+    const long mld = pcol ? opp : opm;
+    const bool has_m = prow || c > d;
     for (int e = threadIdx.x; e < o2; e += blockDim.x) {
         const int i = e / no, j = e - i * no;
         if (i < j) continue;
         const double x1 = T1[e], x2 = T2[e];
-        Sp[row * opp + (long)i * (i + 1) / 2 + j] = f * (x1 + x2);
-        if (c > d && i > j) Am[mrow * opm + (long)i * (i - 1) / 2 + j] = 0.5 * (x1 - x2);
+        Sp[row * opp + (long)i * (i + 1) / 2 + j] = ((i == j && col_half) ? 0.5 * fr : fr) * (x1 + x2);
+        if (has_m && (pcol || i > j)) {
+            const long mcol = pcol ? (long)i * (i + 1) / 2 + j : (long)i * (i - 1) / 2 + j;
+            Am[mrow * mld + mcol] = (c > d && i > j) ? 0.5 * (x1 - x2) : 0.0;
+        }
     }
 }
 
@@ -1325,20 +1332,21 @@ void tau_build(double* tau, const double* t2, const double* t1, int no, int nv, 
     HIP_CHECK(hipGetLastError());
 }
 
-void ladder_pack_V(const double* V, double* Vp, double* Vm, int nv, int64_t rp0, int64_t rp1, stream_t s) {
+void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nc, int64_t rp0, int64_t rp1, stream_t s) {
     if (rp1 <= rp0) return;
-    const int nt = (nv + 31) / 32;
+    const int nt = (nc + 31) / 32;
     const long ntp = (long)nt * (nt + 1) / 2;
     const long nblk = (rp1 - rp0) * ntp;
     if (nblk > 0x7fffffffL) throw std::runtime_error("ladder_pack_V: grid too large");
-    hipLaunchKernelGGL(ladder_pack_V_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)s, V, Vp, Vm, nv,
+    hipLaunchKernelGGL(ladder_pack_V_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)s, V, Vp, Vm, nr, nc,
                        (long)rp0, nt, ntp);
     HIP_CHECK(hipGetLastError());
 }
 
-void ladder_pack_T(const double* T, double* Sp, double* Am, int no, int nv, stream_t s) {
-    const long npp = (long)nv * (nv + 1) / 2;
-    hipLaunchKernelGGL(ladder_pack_T_kernel, dim3((unsigned)npp), dim3(256), 0, (hipStream_t)s, T, Sp, Am, no, nv);
+void ladder_pack_T(const double* X, double* Sp, double* Am, int nc, int nr, int flags, stream_t s) {
+    const long npp = (long)nr * (nr + 1) / 2;
+    hipLaunchKernelGGL(ladder_pack_T_kernel, dim3((unsigned)npp), dim3(256), 0, (hipStream_t)s, X, Sp, Am, nc, nr,
+                       flags);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1402,10 +1410,10 @@ void ueg_two_body(const UegParams& prm, const int* k_int_dev, const int* index_m
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(st));
     } catch (...) {
-        hipFree(umat); hipFree(E); hipFree(dk_dev); hipFree(uidx);
+        (void)hipFree(umat); (void)hipFree(E); (void)hipFree(dk_dev); (void)hipFree(uidx);
         throw;
     }
-    hipFree(umat); hipFree(E); hipFree(dk_dev); hipFree(uidx);
+    (void)hipFree(umat); (void)hipFree(E); (void)hipFree(dk_dev); (void)hipFree(uidx);
 }
 
 }  // namespace dev

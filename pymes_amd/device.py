@@ -280,10 +280,11 @@ class Context:
         self.lib.call("pymes_ccsd_dress_abcd_rows", self.handle, C.c_void_p(t1.ptr), int(a_begin), int(a_end),
                       int(lower_only))
 
-    def ladder_sym(self, t2, L, row_begin, row_end, dressed=False):
-        """Rows [row_begin,row_end) of the pair-packed ladder L[v(v+1)/2, o*o] (include/pymes_amd.h)."""
+    def ladder_sym(self, t2, L, row_begin, row_end, dressed=False, hole_ladder=0):
+        """Rows [row_begin,row_end) of the pair-packed ladder L[v(v+1)/2, o*o] (include/pymes_amd.h);
+        hole_ladder = 1 (CCSD) / 2 (DCSD) adds ccd.py:175-186 to the same rows."""
         self.lib.call("pymes_ladder_sym", self.handle, C.c_void_p(t2.ptr), C.c_void_p(L.ptr), int(row_begin),
-                      int(row_end), int(dressed))
+                      int(row_end), int(dressed), int(hole_ladder))
         return L
 
     def ladder_sym_unpack(self, L, out, beta=1.0):

@@ -140,13 +140,13 @@ void tau_build(double* tau, const double* t2, const double* t1, int no, int nv, 
 static inline int64_t P2(int64_t x, int64_t y) { return x * (x + 1) / 2 + y; }
 static inline int64_t Q2(int64_t x, int64_t y) { return x * (x - 1) / 2 + y; }
 
-void ladder_pack_V(const double* V, double* Vp, double* Vm, int nv, int64_t rp0, int64_t rp1, stream_t) {
+void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nv, int64_t rp0, int64_t rp1, stream_t) {
     const int64_t npp = (int64_t)nv * (nv + 1) / 2, npm = (int64_t)nv * (nv - 1) / 2;
-    for (int a = 0; a < nv; ++a)
+    for (int a = 0; a < nr; ++a)
         for (int b = 0; b <= a; ++b) {
             const int64_t r = P2(a, b);
             if (r < rp0 || r >= rp1) continue;
-            const double* Vab = V + ((int64_t)a * nv + b) * nv * nv;
+            const double* Vab = V + ((int64_t)a * nr + b) * nv * nv;
             for (int c = 0; c < nv; ++c)
                 for (int d = 0; d <= c; ++d) {
                     const double x1 = Vab[(int64_t)c * nv + d], x2 = Vab[(int64_t)d * nv + c];
@@ -156,15 +156,23 @@ void ladder_pack_V(const double* V, double* Vp, double* Vm, int nv, int64_t rp0,
         }
 }
 
-void ladder_pack_T(const double* T, double* Sp, double* Am, int no, int nv, stream_t) {
+void ladder_pack_T(const double* T, double* Sp, double* Am, int no, int nv, int flags, stream_t) {
+    const bool row_half = flags & PACK_ROW_HALF, prow = flags & PACK_AM_PROWS, col_half = flags & PACK_COL_HALF,
+               pcol = flags & PACK_AM_PCOLS;
     const int64_t o2 = (int64_t)no * no, opp = (int64_t)no * (no + 1) / 2, opm = (int64_t)no * (no - 1) / 2;
+    const int64_t mld = pcol ? opp : opm;
     for (int c = 0; c < nv; ++c)
         for (int d = 0; d <= c; ++d)
             for (int i = 0; i < no; ++i)
                 for (int j = 0; j <= i; ++j) {
                     const double x1 = T[((int64_t)c * nv + d) * o2 + i * no + j], x2 = T[((int64_t)d * nv + c) * o2 + i * no + j];
-                    Sp[P2(c, d) * opp + P2(i, j)] = (c == d ? 0.25 : 0.5) * (x1 + x2);
-                    if (c > d && i > j) Am[Q2(c, d) * opm + Q2(i, j)] = 0.5 * (x1 - x2);
+                    double f = 0.5;
+                    if (c == d && row_half) f *= 0.5;
+                    if (i == j && col_half) f *= 0.5;
+                    Sp[P2(c, d) * opp + P2(i, j)] = f * (x1 + x2);
+                    if ((prow || c > d) && (pcol || i > j))
+                        Am[(prow ? P2(c, d) : Q2(c, d)) * mld + (pcol ? P2(i, j) : Q2(i, j))] =
+                            (c > d && i > j) ? 0.5 * (x1 - x2) : 0.0;
                 }
 }
 

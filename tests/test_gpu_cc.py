@@ -139,6 +139,8 @@ def test_pair_packed_ladder(gpu_lib, no, nv, seed):
                 r2 = ctx.empty(t2.shape)
                 ctx.doubles_residual(dF, dT2, r2, is_dcd=dcd, sym_ladder=True, sym_rings=rings)
                 assert np.abs(r2.get() - refr).max() < 10 * TOL
+        from tests.test_host_engine import hole_ladder_check
+        hole_ladder_check(ctx, no, nv, Vb, t2, TOL)
         # dressed blocks: the packed copy must follow a re-dressing
         dT1 = ctx.array(t1)
         for scale in (1.0, -0.5):

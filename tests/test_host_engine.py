@@ -120,7 +120,26 @@ def test_symmetry_reduced_residual(sim, no, nv, seed):
             ctx.doubles_residual(dF, dT2, r2, is_dcd=dcd, sym_ladder=True, sym_rings=rings)
             assert np.abs(r2.get() - ref).max() < 1e-12
         calls = ctx.stats(reset=True)
+    hole_ladder_check(ctx, no, nv, Vb, t2, 1e-12)
     ctx.close()
+
+
+def hole_ladder_check(ctx, no, nv, Vb, t2, tol):
+    """pymes_ladder_sym with hole_ladder = 1 / 2: ccd.py:175-187 pair-packed, in two row chunks."""
+    npp = nv * (nv + 1) // 2
+    dT2 = ctx.array(t2)
+    for mode in (0, 1, 2):
+        ref = np.einsum("abcd,cdij->abij", Vb["abcd"], t2)
+        if mode:
+            I = Vb["klij"] + (np.einsum("klcd,cdij->klij", Vb["ijab"], t2) if mode == 1 else 0.0)
+            ref = ref + np.einsum("klij,abkl->abij", I, t2)
+        L = ctx.zeros((npp, no * no))
+        cut = npp // 2
+        ctx.ladder_sym(dT2, L, 0, cut, hole_ladder=mode)
+        ctx.ladder_sym(dT2, L, cut, npp, hole_ladder=mode)
+        R = ctx.empty(t2.shape)
+        ctx.ladder_sym_unpack(L, R, beta=0.0)
+        assert np.abs(R.get() - ref).max() < tol * max(1.0, np.abs(ref).max()), mode
 
 
 def sharded_residual_check(lib, cases, worlds, tol):
