@@ -82,7 +82,10 @@ int pymes_mp2(pymes_ctx* ctx, double level_shift, double* t2_dev, double* e_out_
 /* CCSD.get_T1_dressed_fock, ccsd.py:226-288 (f and fd are [n,n] on the device) */
 int pymes_ccsd_dress_fock(pymes_ctx* ctx, const double* f_dev, const double* t1_dev, double* fd_dev);
 /* CCSD.get_T1_dressed_V, ccsd.py:290-421; block_mask bit p = pattern id of the block
- * (bit 3-pos set when index `pos` is virtual: "abcd"=15, "klij"=0, "ijab"=3, "abij"=12 ...) */
+ * (bit 3-pos set when index `pos` is virtual: "abcd"=15, "klij"=0, "ijab"=3, "abij"=12 ...).
+ * PYMES_DRESS_ABIJ_REDUCED: V~_abij without its V_pqcd t_ci t_dj and t_ak t_bl V~_klrs terms — the form
+ * pymes_residual_slab/_finish expect when they are given t1 (those terms then travel with the ladders). */
+#define PYMES_DRESS_ABIJ_REDUCED (1u << 16)
 int pymes_ccsd_dress_V(pymes_ctx* ctx, const double* t1_dev, uint32_t block_mask);
 /* CCSD.get_singles_residual, ccsd.py:423-438 */
 int pymes_ccsd_singles_residual(pymes_ctx* ctx, const double* fd_dev, const double* t1_dev, const double* t2_dev,
@@ -120,11 +123,19 @@ int pymes_ladder_sym_unpack(pymes_ctx* ctx, const double* L_dev, double* r2_dev,
  * pymes_residual_finish adds the replicated terms and assembles R.  world = 1 reproduces
  * pymes_doubles_residual.  pymes_ccsd_dress_abcd_rows dresses only rows a in [a_begin,a_end) of V_abcd
  * (ccsd.py:414-419) — the rows a rank's ladder chunk reads; with lower_only != 0 only the entries b <= a
- * (all the pair-packed ladder touches) are defined afterwards. */
+ * (all the pair-packed ladder touches) are defined afterwards.
+ *
+ * t1_dev / QK_dev (both or neither; CCSD/DCSD with PYMES_USE_DRESSED): the T1 dressing of V_abcd (ccsd.py:414-419)
+ * is applied on the amplitude side instead — V~_abcd T = sum_pq X_a^p X_b^q V_pqcd T_cdij is evaluated from the
+ * undressed, once-packed V_abcd / V_kbcd / V_klcd with tau = T + t1 t1.  V_abcd is then never dressed (no
+ * pymes_ccsd_dress_abcd_rows, no second copy of V_abcd), V~_abij must be dressed with PYMES_DRESS_ABIJ_REDUCED
+ * and V~_klij in full.  QK is a fourth exchange buffer, [o*v][o*o] on the device cut into the same row chunks
+ * as ETd: QK[(k,b)] = [ QS | QA ] of sum_cd V_kbcd tau_cdij. */
 int pymes_residual_slab(pymes_ctx* ctx, const double* f_dev, const double* t2_dev, double* ETd_dev, double* ETx_dev,
-                        double* L_dev, int rank, int world, uint32_t flags);
+                        double* L_dev, int rank, int world, uint32_t flags, const double* t1_dev, double* QK_dev);
 int pymes_residual_finish(pymes_ctx* ctx, const double* f_dev, const double* t2_dev, const double* ETd_dev,
-                          const double* ETx_dev, const double* L_dev, double* r2_dev, uint32_t flags);
+                          const double* ETx_dev, const double* L_dev, double* r2_dev, uint32_t flags,
+                          const double* t1_dev, const double* QK_dev);
 int pymes_ccsd_dress_abcd_rows(pymes_ctx* ctx, const double* t1_dev, int a_begin, int a_end, int lower_only);
 /* ccsd.py:176-179 / ccd.py:123-124: dt = r/(D+shift) (as r * (1/(D+shift))), t += delta*dt; rank 2 or 4 */
 int pymes_cc_update(pymes_ctx* ctx, double* t_dev, double* dt_dev, const double* r_dev, double level_shift,

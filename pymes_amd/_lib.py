@@ -53,9 +53,9 @@ SIGNATURES = {
     "pymes_ladder_sym": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int]),
     "pymes_ladder_sym_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]),
     "pymes_residual_slab": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                      C.c_int, C.c_uint32]),
+                                      C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]),
     "pymes_residual_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                        C.c_void_p, C.c_uint32]),
+                                        C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "pymes_ccsd_dress_abcd_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "pymes_cc_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
                                   C.c_int]),
@@ -72,6 +72,7 @@ SIGNATURES = {
 }
 
 PYMES_DCD, PYMES_USE_DRESSED, PYMES_SKIP_LADDER, PYMES_SYM_LADDER, PYMES_SYM_RINGS = 1, 2, 4, 8, 16
+PYMES_DRESS_ABIJ_REDUCED = 1 << 16
 
 
 class PymesError(RuntimeError):

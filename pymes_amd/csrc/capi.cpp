@@ -241,17 +241,19 @@ int pymes_ladder_sym_unpack(pymes_ctx* ctx, const double* L, double* r2, double 
     });
 }
 int pymes_residual_slab(pymes_ctx* ctx, const double* f, const double* t2, double* ETd, double* ETx, double* L, int rank,
-                        int world, uint32_t flags) {
+                        int world, uint32_t flags, const double* t1, double* QK) {
     return guarded([&] {
         need(f, "f"); need(t2, "t2"); need(ETd, "ETd"); need(ETx, "ETx");
-        E(ctx).residual_slab(f, t2, ETd, ETx, L, rank, world, flags);
+        if ((t1 == nullptr) != (QK == nullptr)) throw pymes::Error("t1 and QK must be given together");
+        E(ctx).residual_slab(f, t2, ETd, ETx, L, rank, world, flags, t1, QK);
     });
 }
 int pymes_residual_finish(pymes_ctx* ctx, const double* f, const double* t2, const double* ETd, const double* ETx,
-                          const double* L, double* r2, uint32_t flags) {
+                          const double* L, double* r2, uint32_t flags, const double* t1, const double* QK) {
     return guarded([&] {
         need(f, "f"); need(t2, "t2"); need(ETd, "ETd"); need(ETx, "ETx"); need(r2, "r2");
-        E(ctx).residual_finish(f, t2, ETd, ETx, L, r2, flags);
+        if ((t1 == nullptr) != (QK == nullptr)) throw pymes::Error("t1 and QK must be given together");
+        E(ctx).residual_finish(f, t2, ETd, ETx, L, r2, flags, t1, QK);
     });
 }
 int pymes_ccsd_dress_abcd_rows(pymes_ctx* ctx, const double* t1, int a0, int a1, int lower_only) {

@@ -204,7 +204,7 @@ void Engine::doubles_residual(const double* f, const double* t2, double* r2, uns
 // the transposition needs no undoing.  The pair-packed ladder rows of the same rank go to L.
 // -----------------------------------------------------------------------------------
 void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, double* ETx_p, double* L, int rank,
-                           int world, unsigned flags) {
+                           int world, unsigned flags, const double* t1, double* QK) {
     const bool dcd = flags & 1u, dressed = flags & 2u, skip_ladder = flags & 4u;
     const bool quad = !dcd;
     const int64_t o = no, v = nv, nn = n, ov = o * v;
@@ -221,7 +221,14 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
     if (L && !skip_ladder) {
         int64_t r0, r1;
         chunk(v * (v + 1) / 2, r0, r1);
-        ladder_sym(t2, L, r0, r1, dressed, quad ? 1 : 2);      // particle AND hole ladder rows of this rank
+        if (t1) {
+            if (!QK) throw Error("residual_slab: QK buffer missing");
+            int64_t q0, q1;
+            chunk(o * v, q0, q1);
+            ladder_t1(t1, t2, L, r0, r1, QK, q0, q1, dcd);
+        } else {
+            ladder_sym(t2, L, r0, r1, dressed, quad ? 1 : 2);  // particle AND hole ladder rows of this rank
+        }
     }
     int64_t c0, c1;
     chunk(ov, c0, c1);
@@ -293,7 +300,7 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
 }
 
 void Engine::residual_finish(const double* f, const double* t2, const double* ETd_p, const double* ETx_p,
-                             const double* L, double* r2, unsigned flags) {
+                             const double* L, double* r2, unsigned flags, const double* t1, const double* QK) {
     const bool dcd = flags & 1u, dressed = flags & 2u, skip_ladder = flags & 4u;
     const bool quad = !dcd;
     const int64_t o = no, v = nv, nn = n;
@@ -326,6 +333,13 @@ void Engine::residual_finish(const double* f, const double* t2, const double* ET
         contract(-w, Ttd, "akdl", make_view(get_static("Vk"), {o, v, o, v}), "kdlc", 1.0, Xvv, "ac");
         TView Exn = make_view(Ttd.p, {v, v, o, o});      // Ttd is dead after X_ac: reuse its storage
         contract(1.0, Xvv, "ac", T, "cbij", 0.0, Exn, "abij");
+        if (t1 && L && !skip_ladder) {
+            // bras (k,b) and (a,l) of the amplitude-side dressing: -t_ak Q_kbij - t_bl Q_laji, Q = V_kbcd tau_cdij
+            if (!QK) throw Error("residual_finish: QK buffer missing");
+            TView Qf = make_view(arena.alloc(o * v * o * o), {o, v, o, o});
+            dev::rows_unpack(QK, Qf.p, o * v, no, stream);
+            contract(-1.0, make_view(const_cast<double*>(t1), {v, o}), "ak", Qf, "kbij", 1.0, Exn, "abij");
+        }
         permute(1.0, Exn, "abij", 1.0, R, "abij");
         permute(1.0, Exn, "baji", 1.0, R, "abij");
     }
@@ -401,7 +415,7 @@ void Engine::ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1,
     ArenaScope scope(arena);
     double* Sp = arena.alloc(npp * opp);
     double* Am = arena.alloc(std::max<int64_t>(npm * opm, 1));
-    dev::ladder_pack_T(t2, Sp, Am, no, nv, dev::PACK_ROW_HALF, stream);
+    dev::ladder_pack_T(t2, nullptr, Sp, Am, no, nv, dev::PACK_ROW_HALF, 0, 0, stream);
     stats.permute_calls++;
     stats.permute_bytes += 8.0 * 2.0 * double(v * v * o * o);
     // L rows [row0,row1): [ LS (opp) | LA (opm) ], row length o*o
@@ -420,7 +434,7 @@ void Engine::ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1,
     // and (I_klij +- I_lkij)/2 = pack(V~_klij) + sum_{c>=d} (V_klcd +- V_kldc) (f_cd S | A)_cdij.
     double* Ip = arena.alloc(opp * opp);
     double* Im = arena.alloc(std::max<int64_t>(opp * opm, 1));
-    dev::ladder_pack_T(block(P_klij, dressed).p, Ip, Im, no, no, dev::PACK_AM_PROWS, stream);
+    dev::ladder_pack_T(block(P_klij, dressed).p, nullptr, Ip, Im, no, no, dev::PACK_AM_PROWS, 0, 0, stream);
     TView Ipv = make_view(Ip, {opp, opp}), Imv = make_view(Im, {opp, opm});
     if (hole == 1) {
         if (!static_.count("VpIjab")) {      // static per solve: dressed ijab == undressed ijab
@@ -439,11 +453,123 @@ void Engine::ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1,
     }
     double* SpR = arena.alloc(npp * opp);
     double* AmR = arena.alloc(npp * opp);
-    dev::ladder_pack_T(t2, SpR, AmR, no, nv, dev::PACK_COL_HALF | dev::PACK_AM_PROWS | dev::PACK_AM_PCOLS, stream);
+    dev::ladder_pack_T(t2, nullptr, SpR, AmR, no, nv, dev::PACK_COL_HALF | dev::PACK_AM_PROWS | dev::PACK_AM_PCOLS, 0, 0, stream);
     stats.permute_calls += 2;
     stats.permute_bytes += 8.0 * 2.0 * double(v * v * o * o);
     contract(1.0, slice(make_view(SpR, {npp, opp}), 0, row0, row1), "rk", Ipv, "kn", 1.0, LS, "rn");
     if (opm > 0) contract(1.0, slice(make_view(AmR, {npp, opp}), 0, row0, row1), "rk", Imv, "kn", 1.0, LA, "rn");
+}
+
+// T1 dressing of the ladders on the amplitude side.  With X_a^p = delta_ap - t_ak delta_pk the dressed ladder and the
+// (c,d)-ket part of V~_abij are  sum_pq X_a^p X_b^q sum_cd V_pqcd tau_cdij,  tau = T + t1 t1 (exchange-symmetric like T):
+//   (p,q) = (a,b): the pair-packed ladder with the UNDRESSED V_abcd, packed once per solve          -> L rows
+//   (p,q) = (k,b), (a,l): -t_ak Q_kbij - t_bl Q_laji,  Q_kbij = sum_cd V_kbcd tau_cdij (cd pair-packed) -> QK rows
+//   (p,q) = (k,l): t_ak t_bl (V~_klij + V_klcd T_cdij), i.e. the hole ladder (ccd.py:175-186) taken with tau_abkl
+//                  instead of T_abkl also covers the (k,l)-bra part of V~_abij                      -> L rows
+// V~_abij must therefore be dressed in its reduced form (dress_V bit 16), V~_klij in full; V_abcd is never dressed:
+// no o v^4 work and no second copy of V_abcd per iteration.
+void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t row0, int64_t row1, double* QK,
+                       int64_t q0, int64_t q1, bool dcd) {
+    const int64_t o = no, v = nv, npp = v * (v + 1) / 2, npm = v * (v - 1) / 2, opp = o * (o + 1) / 2,
+                  opm = o * (o - 1) / 2, ov = o * v;
+    if (row0 < 0 || row1 > npp || row0 > row1) throw Error("ladder_t1: bad pair-row range");
+    if (q0 < 0 || q1 > ov || q0 > q1) throw Error("ladder_t1: bad (k,b) row range");
+    const int64_t rows = row1 - row0, qrows = q1 - q0;
+    const int64_t ldp = opp + (opp & 1), ldm = std::max<int64_t>(opm + (opm & 1), 2);   // even pitches: 16-byte loads
+    // ---- static packs (once per solve) ---------------------------------------------------------
+    if (rows > 0 && !(lpack_.valid && !lpack_.dressed && lpack_.row0 == row0 && lpack_.row1 == row1)) {
+        if (!lpack_.Vp || lpack_.row1 - lpack_.row0 != rows) {
+            dev::stream_sync(stream);
+            dev::dfree(lpack_.Vp);
+            dev::dfree(lpack_.Vm);
+            lpack_.Vp = lpack_.Vm = nullptr;
+            lpack_.Vp = static_cast<double*>(dev::dmalloc(sizeof(double) * rows * npp));
+            lpack_.Vm = static_cast<double*>(dev::dmalloc(sizeof(double) * rows * std::max<int64_t>(npm, 1)));
+        }
+        dev::ladder_pack_V(block(P_abcd).p, lpack_.Vp, lpack_.Vm, nv, nv, row0, row1, stream);
+        lpack_.row0 = row0; lpack_.row1 = row1; lpack_.dressed = false; lpack_.valid = true;
+    }
+    const std::string kkey = ":" + std::to_string(q0) + ":" + std::to_string(q1);
+    if (qrows > 0 && !static_.count("VpK" + kkey)) {
+        double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * qrows * npp));
+        double* vm = static_cast<double*>(dev::dmalloc(sizeof(double) * qrows * std::max<int64_t>(npm, 1)));
+        static_["VpK" + kkey] = vp;
+        static_["VmK" + kkey] = vm;
+        dev::ladder_pack_V(block(P_iabc).p, vp, vm, 0, nv, q0, q1, stream);          // rows (k,b) of V_kbcd as they are
+    }
+    if (!static_.count("VpIjab")) {
+        double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * npp));
+        double* vm = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * std::max<int64_t>(npm, 1)));
+        static_["VpIjab"] = vp;
+        static_["VmIjab"] = vm;
+        dev::ladder_pack_V(block(P_ijab).p, vp, vm, no, nv, 0, opp, stream);
+    }
+    ArenaScope scope(arena);
+    auto pitched = [&](double* p, int64_t r, int64_t c, int64_t ld) { return slice(make_view(p, {r, ld}), 1, 0, c); };
+    TView Lrows = make_view(L + row0 * o * o, {rows, o * o});
+    TView LS = slice(Lrows, 1, 0, opp), LA = slice(Lrows, 1, opp, o * o);
+    {
+        // ---- particle ladder and Q_kb from tau ----------------------------------------------
+        ArenaScope s2(arena);
+        double* Sp = arena.alloc(npp * ldp);
+        double* Am = arena.alloc(std::max<int64_t>(npm * ldm, 1));
+        dev::ladder_pack_T(t2, t1, Sp, Am, no, nv, dev::PACK_ROW_HALF, ldp, ldm, stream);
+        stats.permute_calls++;
+        stats.permute_bytes += 8.0 * 2.0 * double(v * v * o * o);
+        TView SpT = pitched(Sp, npp, opp, ldp), AmT = pitched(Am, npm, opm, ldm);
+        if (rows > 0) {
+            contract(1.0, make_view(lpack_.Vp, {rows, npp}), "rk", SpT, "kn", 0.0, LS, "rn");
+            if (opm > 0) {
+                if (npm > 0) contract(1.0, make_view(lpack_.Vm, {rows, npm}), "rk", AmT, "kn", 0.0, LA, "rn");
+                else zero(LA);
+            }
+        }
+        if (qrows > 0) {
+            TView Qrows = make_view(QK + q0 * o * o, {qrows, o * o});
+            TView QS = slice(Qrows, 1, 0, opp), QA = slice(Qrows, 1, opp, o * o);
+            contract(1.0, make_view(static_["VpK" + kkey], {qrows, npp}), "rk", SpT, "kn", 0.0, QS, "rn");
+            if (opm > 0) {
+                if (npm > 0) contract(1.0, make_view(static_["VmK" + kkey], {qrows, npm}), "rk", AmT, "kn", 0.0, QA, "rn");
+                else zero(QA);
+            }
+        }
+    }
+    if (rows == 0) return;
+    // ---- hole ladder rows.  Ifull = V~_klij + V_klcd T_cdij (pair-packed, doubled as in ladder_sym) ------
+    double* Ip = arena.alloc(opp * ldp);
+    double* Im = arena.alloc(std::max<int64_t>(opp * ldm, 1));
+    dev::ladder_pack_T(block(P_klij, true).p, nullptr, Ip, Im, no, no, dev::PACK_AM_PROWS, ldp, ldm, stream);
+    TView Ipv = pitched(Ip, opp, opp, ldp), Imv = pitched(Im, opp, opm, ldm);
+    double* SpR = arena.alloc(npp * opp);
+    double* AmR = arena.alloc(npp * opp);
+    const int rflags = dev::PACK_COL_HALF | dev::PACK_AM_PROWS | dev::PACK_AM_PCOLS;
+    auto rowsS = [&]() { return slice(make_view(SpR, {npp, opp}), 0, row0, row1); };
+    auto rowsA = [&]() { return slice(make_view(AmR, {npp, opp}), 0, row0, row1); };
+    if (dcd) {
+        // DCSD keeps only V~_klij in the hole ladder proper (ccd.py:178), but the (k,l)-bra part still sees Ifull
+        axpby(2.0, Ipv, 0.0, Ipv);
+        if (opm > 0) axpby(2.0, Imv, 0.0, Imv);
+        dev::ladder_pack_T(t2, nullptr, SpR, AmR, no, nv, rflags, 0, 0, stream);
+        contract(1.0, rowsS(), "rk", Ipv, "kn", 1.0, LS, "rn");
+        if (opm > 0) contract(1.0, rowsA(), "rk", Imv, "kn", 1.0, LA, "rn");
+    }
+    {
+        ArenaScope s2(arena);
+        double* Sp = arena.alloc(npp * ldp);
+        double* Am = arena.alloc(std::max<int64_t>(npm * ldm, 1));
+        dev::ladder_pack_T(t2, nullptr, Sp, Am, no, nv, dev::PACK_ROW_HALF, ldp, ldm, stream);
+        const double b = dcd ? 1.0 : 2.0;      // dcd: Ip already holds 2 pack(V~_klij)
+        contract(2.0, make_view(static_["VpIjab"], {opp, npp}), "rk", pitched(Sp, npp, opp, ldp), "kn", b, Ipv, "rn");
+        if (opm > 0 && npm > 0)
+            contract(2.0, make_view(static_["VmIjab"], {opp, npm}), "rk", pitched(Am, npm, opm, ldm), "kn", b, Imv, "rn");
+        else if (opm > 0 && !dcd) axpby(2.0, Imv, 0.0, Imv);
+    }
+    // CCSD: rows of tau against Ifull;  DCSD: rows of t1 t1 against Ifull (rows of T were taken above)
+    dev::ladder_pack_T(dcd ? nullptr : t2, t1, SpR, AmR, no, nv, rflags, 0, 0, stream);
+    stats.permute_calls += 3;
+    stats.permute_bytes += 8.0 * 4.0 * double(v * v * o * o);
+    contract(1.0, rowsS(), "rk", Ipv, "kn", 1.0, LS, "rn");
+    if (opm > 0) contract(1.0, rowsA(), "rk", Imv, "kn", 1.0, LA, "rn");
 }
 
 void Engine::ladder_sym_unpack(const double* L, double* r2, double beta) {
@@ -517,25 +643,31 @@ void Engine::dress_fock(const double* f, const double* t1, double* fd) {
 // Implemented as a recursion of one-index transforms: ket indices first (they shrink
 // v -> o), bra indices last.
 // -----------------------------------------------------------------------------------
-void Engine::dressed_into(int pattern, const std::vector<int>& pos, int k, const TView& t1v, const TView& dst) {
+// reduced (V_abij only, pos = {3,2,1,0}): leave out the terms with both kets virtual (V_pqcd t_ci t_dj) and the
+// terms with both bras occupied (t_ak t_bl V~_klrs); ladder_t1 carries them through tau and the hole ladder.
+void Engine::dressed_into(int pattern, const std::vector<int>& pos, int k, const TView& t1v, const TView& dst,
+                          bool reduced) {
     if (k == 0) {
         copy(block(pattern), dst);
         return;
     }
     // same-type part: when it is the raw block the copy is fused into the product below (C = Cin + ...)
     const bool fuse_copy = (k - 1 == 0);
-    if (!fuse_copy) dressed_into(pattern, pos, k - 1, t1v, dst);
+    if (!fuse_copy) dressed_into(pattern, pos, k - 1, t1v, dst, reduced);
     const TView raw = fuse_copy ? block(pattern) : TView();
     const TView* cin = fuse_copy ? &raw : nullptr;
     const int x = pos[k - 1];
     const int other = pattern ^ (1 << (3 - x));
+    int depth = k - 1;                       // dressing depth of the other-type part
+    if (reduced && k == 4) depth = 2;        // p -> k: no q -> l on top of it
+    if (reduced && k == 2) depth = 0;        // r -> c: no s -> d on top of it
     ArenaScope scope(arena);
     TView oth;
-    if (k - 1 == 0) {
+    if (depth == 0) {
         oth = block(other);
     } else {
         oth = block_view(arena.alloc(block_size(other)), other);
-        dressed_into(other, pos, k - 1, t1v, oth);
+        dressed_into(other, pos, depth, t1v, oth, reduced);
     }
     switch (x) {
         case 3: contract(1.0, oth, "pqrx", t1v, "xs", 1.0, dst, "pqrs", "", cin); break;
@@ -556,7 +688,7 @@ void Engine::dress_V(const double* t1, uint32_t mask) {
         if (pat >> 2 & 1) pos.push_back(1);      // bra q virtual
         if (pat >> 3 & 1) pos.push_back(0);      // bra p virtual
         TView dst = block_view(ensure_dressed(pat), pat);
-        dressed_into(pat, pos, static_cast<int>(pos.size()), t, dst);
+        dressed_into(pat, pos, static_cast<int>(pos.size()), t, dst, pat == P_abij && (mask >> 16 & 1u));
         if (pat == P_abcd && lpack_.dressed) lpack_.valid = false;
     }
 }

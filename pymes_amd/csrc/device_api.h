@@ -81,17 +81,23 @@ void tau_build(double* tau, const double* t2, const double* t1, int no, int nv, 
 // ladder_pack_V: V is [nr,nr,nc,nc].  For the pair rows r = P(a,b) in [rp0, rp1):
 //   Vp[r - rp0][P(c,d)] = V[a,b,c,d] + V[a,b,d,c]
 //   Vm[r - rp0][Q(c,d)] = V[a,b,c,d] - V[a,b,d,c]   (zero row when a == b)
+// nr == 0: V is [rows,nc,nc] and the rows [rp0, rp1) are taken as they are (no zero rows in Vm).
 void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nc, int64_t rp0, int64_t rp1, stream_t s);
 // ladder_pack_T: X is [nr,nr,nc,nc]; pair (c,d) over nr, pair (i,j) over nc.
 //   Sp[P(c,d)][P(i,j)] = fr fc (X[c,d,i,j] + X[d,c,i,j]) / 2,  fr = 1/2 on c == d if PACK_ROW_HALF, fc = 1/2 on
 //   i == j if PACK_COL_HALF (a pair that is summed over carries the half on its diagonal);
 //   Am[row][col] = (X[c,d,i,j] - X[d,c,i,j]) / 2 with row = Q(c,d) (c > d) or P(c,d) if PACK_AM_PROWS and
 //   col = Q(i,j) (i > j) or P(i,j) if PACK_AM_PCOLS; entries on a diagonal pair are zero.
+// If t1 ([nr,nc]) is given, t1[c,i] t1[d,j] is added to X[c,d,i,j] on the fly (tau of ccsd.py:462); X may then be
+// null.  ldp / ldm are the row pitches of Sp / Am (0 = dense).
 enum { PACK_ROW_HALF = 1, PACK_AM_PROWS = 2, PACK_COL_HALF = 4, PACK_AM_PCOLS = 8 };
-void ladder_pack_T(const double* X, double* Sp, double* Am, int nc, int nr, int flags, stream_t s);
+void ladder_pack_T(const double* X, const double* t1, double* Sp, double* Am, int nc, int nr, int flags, int64_t ldp,
+                   int64_t ldm, stream_t s);
 // L[P(a,b)] = [ LS row (o(o+1)/2) | LA row (o(o-1)/2) ], row length o*o:
 // R[a,b,i,j] = beta R + LS[P(ab)][P(ij)] + sgn(a-b) sgn(i-j) LA[P(ab)][Q(ij)]
 void ladder_unpack(const double* L, double* R, double beta, int no, int nv, stream_t s);
+// plain rows of the same [ S | A ] layout: out[r][i][j] = Q[r][P(i,j)] + sgn(i-j) Q[r][o(o+1)/2 + Q(i,j)]
+void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t s);
 
 // ---- 3D uniform electron gas two-body integrals (pymes/model/ueg.py:265-516) ------------------
 // V[p,q,r,s] (dense [n_p]^4, zero where momentum is not conserved) for the plane-wave basis

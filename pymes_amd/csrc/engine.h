@@ -121,10 +121,15 @@ class Engine {
     void ladder_sym_unpack(const double* L, double* r2, double beta);
     // symmetry-reduced residual in shardable form (cc.cpp): this rank's column slab of the ring products
     // (rows of ETd/ETx) and its rows of the packed ladder L; then the replicated remainder + assembly
+    // t1 + QK given: V_abcd is never dressed; its T1 dressing is applied on the amplitude side (ladder_t1)
     void residual_slab(const double* f, const double* t2, double* ETd, double* ETx, double* L, int rank, int world,
-                       unsigned flags);
+                       unsigned flags, const double* t1 = nullptr, double* QK = nullptr);
     void residual_finish(const double* f, const double* t2, const double* ETd, const double* ETx, const double* L,
-                         double* r2, unsigned flags);
+                         double* r2, unsigned flags, const double* t1 = nullptr, const double* QK = nullptr);
+    // rows [row0,row1) of the pair-packed ladders and rows [q0,q1) of QK[(k,b)] = sum_cd V_kbcd tau_cdij, all
+    // from UNDRESSED, statically packed integrals; tau = T + t1 t1
+    void ladder_t1(const double* t1, const double* t2, double* L, int64_t row0, int64_t row1, double* QK, int64_t q0,
+                   int64_t q1, bool dcd);
     void dress_abcd_rows(const double* t1, int a0, int a1, bool lower_only);
     void cc_update(double* t, double* dt, const double* r, double shift, double delta, int rank);  // ccsd.py:176-179
     void ccsd_energy(const double* f, const double* t1, const double* t2, double out[3]);     // ccsd.py:458-466
@@ -149,7 +154,8 @@ class Engine {
     double* splitk_ws_ = nullptr;
     int64_t splitk_doubles_ = 0;
     double* get_static(const std::string& key);
-    void dressed_into(int pattern, const std::vector<int>& pos, int k, const TView& t1v, const TView& dst);
+    void dressed_into(int pattern, const std::vector<int>& pos, int k, const TView& t1v, const TView& dst,
+                      bool reduced = false);
     int64_t block_size(int pattern) const;
     TView block_view(double* p, int pattern) const;
     double* ensure_dressed(int pattern);

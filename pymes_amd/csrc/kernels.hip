@@ -48,6 +48,7 @@ struct GemmK {
     const double* Cin;   // beta term is read from here (== C unless the caller fuses a copy)
     long a_ld, b_ld, ldc;
     int M, N, K;
+    int Mc, Nc;          // extents the unit-stride M / N loads are clamped to: M, N rounded up to even when the pitch has room
     double alpha, beta;
     int tiles_m, tiles_n;
     int nsplit, kchunk;
@@ -128,13 +129,13 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_kernel(const GemmK g) {
     for (int i = 0; i < LA; ++i) {
         const int r = a_r + i * A_RSTEP;
         if (AKC) pa[i] = A + (long)min(m0 + r, g.M - 1) * g.a_ld + (kbeg + a_c);
-        else pa[i] = A + (long)(kbeg + r) * g.a_ld + min(m0 + a_c, g.M - VEC);
+        else pa[i] = A + (long)(kbeg + r) * g.a_ld + min(m0 + a_c, g.Mc - VEC);
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
         const int r = b_r + i * B_RSTEP;
         if (BKC) pb[i] = B + (long)min(n0 + r, g.N - 1) * g.b_ld + (kbeg + b_c);
-        else pb[i] = B + (long)(kbeg + r) * g.b_ld + min(n0 + b_c, g.N - VEC);
+        else pb[i] = B + (long)(kbeg + r) * g.b_ld + min(n0 + b_c, g.Nc - VEC);
     }
     const long a_step = AKC ? (long)BK : (long)BK * g.a_ld;
     const long b_step = BKC ? (long)BK : (long)BK * g.b_ld;
@@ -386,14 +387,14 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_glds_kernel(const GemmK g) 
             const int cg = (lane & 7) ^ ((row >> 1) & 7);
             pa_j[j] = A + (long)min(m0 + row, g.M - 1) * g.a_ld + kbeg + cg * 2;
         } else {
-            pa_j[j] = A + (long)(kbeg + wave * 4 + j) * g.a_ld + min(m0 + 2 * lane, g.M - 2);
+            pa_j[j] = A + (long)(kbeg + wave * 4 + j) * g.a_ld + min(m0 + 2 * lane, g.Mc - 2);
         }
         if (BKC) {
             const int row = wave * 32 + (lane >> 3) + 8 * j;
             const int cg = (lane & 7) ^ ((row >> 1) & 7);
             pb_j[j] = B + (long)min(n0 + row, g.N - 1) * g.b_ld + kbeg + cg * 2;
         } else {
-            pb_j[j] = B + (long)(kbeg + wave * 4 + j) * g.b_ld + min(n0 + 2 * lane, g.N - 2);
+            pb_j[j] = B + (long)(kbeg + wave * 4 + j) * g.b_ld + min(n0 + 2 * lane, g.Nc - 2);
         }
     }
     const long a_kstep = AKC ? (long)BK : (long)BK * g.a_ld;
@@ -777,11 +778,11 @@ __global__ void __launch_bounds__(256) ladder_pack_V_kernel(const double* __rest
     const long bid = blockIdx.x;
     const long row = bid / ntp;               // local pair row
     const long tp = bid - row * ntp;          // tile pair (tc >= td)
-    int a, b, tc, td;
-    unrank_pair(rp0 + row, a, b);
+    int a = 1, b = 0, tc, td;
+    if (nr > 0) unrank_pair(rp0 + row, a, b);
     unrank_pair(tp, tc, td);
     const long npp = (long)nv * (nv + 1) / 2, npm = (long)nv * (nv - 1) / 2;
-    const double* __restrict__ Vab = V + ((long)a * nr + b) * nv * nv;
+    const double* __restrict__ Vab = V + (nr > 0 ? (long)a * nr + b : rp0 + row) * nv * nv;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c0 = tc * 32, d0 = td * 32;
 #pragma unroll
@@ -803,28 +804,33 @@ __global__ void __launch_bounds__(256) ladder_pack_V_kernel(const double* __rest
     }
 }
 
-__global__ void ladder_pack_T_kernel(const double* __restrict__ T, double* __restrict__ Sp, double* __restrict__ Am,
-                                     int no, int nv, int flags) {
+__global__ void ladder_pack_T_kernel(const double* __restrict__ T, const double* __restrict__ t1,
+                                     double* __restrict__ Sp, double* __restrict__ Am, int no, int nv, int flags,
+                                     long ldp, long ldm) {
     const long row = blockIdx.x;   // P(c,d)
     int c, d;
     unrank_pair(row, c, d);
     const bool row_half = flags & dev::PACK_ROW_HALF, prow = flags & dev::PACK_AM_PROWS,
                col_half = flags & dev::PACK_COL_HALF, pcol = flags & dev::PACK_AM_PCOLS;
-    const long o2 = (long)no * no, opp = (long)no * (no + 1) / 2, opm = (long)no * (no - 1) / 2;
-    const double* __restrict__ T1 = T + ((long)c * nv + d) * o2;
-    const double* __restrict__ T2 = T + ((long)d * nv + c) * o2;
+    const long o2 = (long)no * no;
+    const double* __restrict__ T1 = T ? T + ((long)c * nv + d) * o2 : nullptr;
+    const double* __restrict__ T2 = T ? T + ((long)d * nv + c) * o2 : nullptr;
     const double fr = (c == d && row_half) ? 0.25 : 0.5;
     const long mrow = prow ? row : (long)c * (c - 1) / 2 + d;
-    const long mld = pcol ? opp : opm;
     const bool has_m = prow || c > d;
     for (int e = threadIdx.x; e < o2; e += blockDim.x) {
         const int i = e / no, j = e - i * no;
         if (i < j) continue;
-        const double x1 = T1[e], x2 = T2[e];
-        Sp[row * opp + (long)i * (i + 1) / 2 + j] = ((i == j && col_half) ? 0.5 * fr : fr) * (x1 + x2);
+        double x1 = 0.0, x2 = 0.0;
+        if (T) { x1 = T1[e]; x2 = T2[e]; }
+        if (t1) {
+            x1 += t1[(long)c * no + i] * t1[(long)d * no + j];
+            x2 += t1[(long)d * no + i] * t1[(long)c * no + j];
+        }
+        Sp[row * ldp + (long)i * (i + 1) / 2 + j] = ((i == j && col_half) ? 0.5 * fr : fr) * (x1 + x2);
         if (has_m && (pcol || i > j)) {
             const long mcol = pcol ? (long)i * (i + 1) / 2 + j : (long)i * (i - 1) / 2 + j;
-            Am[mrow * mld + mcol] = (c > d && i > j) ? 0.5 * (x1 - x2) : 0.0;
+            Am[mrow * ldm + mcol] = (c > d && i > j) ? 0.5 * (x1 - x2) : 0.0;
         }
     }
 }
@@ -848,6 +854,25 @@ __global__ void ladder_unpack_kernel(const double* __restrict__ L, double* __res
             v += ((a > b) == (i > j)) ? x : -x;
         }
         R[idx] = (beta != 0.0) ? beta * R[idx] + v : v;
+    }
+}
+
+// out[r][i][j] = Q[r][P(i,j)] + sgn(i-j) Q[r][opp + Q(i,j)]   (rows are plain, not pair-packed)
+__global__ void rows_unpack_kernel(const double* __restrict__ Q, double* __restrict__ out, int no, long total) {
+    const long opp = (long)no * (no + 1) / 2, ld = (long)no * no;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / ld;
+        const int e = (int)(idx - r * ld);
+        const int i = e / no, j = e - i * no;
+        const int ih = max(i, j), il = min(i, j);
+        const double* __restrict__ row = Q + r * ld;
+        double v = row[(long)ih * (ih + 1) / 2 + il];
+        if (i != j) {
+            const double x = row[opp + (long)ih * (ih - 1) / 2 + il];
+            v += (i > j) ? x : -x;
+        }
+        out[idx] = v;
     }
 }
 
@@ -1140,10 +1165,15 @@ void gemm(const Gemm& g, stream_t s) {
     const long tiles = (long)k.tiles_m * k.tiles_n * nbatch;
 
     // ---- 16-byte global loads need even strides/extents and aligned bases --------------
+    // An odd M (N) of an M- (N-)contiguous operand is fine when the pitch has room for one more element: the
+    // pair load at the edge then reads a pad element that only feeds a row (column) of C which is never stored.
     int vec = 2;
+    k.Mc = k.M; k.Nc = k.N;
+    if (!a_kcontig && (g.M & 1) && k.a_ld > g.M) k.Mc = k.M + 1;
+    if (!b_kcontig && (g.N & 1) && k.b_ld > g.N) k.Nc = k.N + 1;
     {
-        const long a_contig_extent = a_kcontig ? g.K : g.M;
-        const long b_contig_extent = b_kcontig ? g.K : g.N;
+        const long a_contig_extent = a_kcontig ? g.K : k.Mc;
+        const long b_contig_extent = b_kcontig ? g.K : k.Nc;
         if (!even(k.a_ld) || !even(k.b_ld) || !even(a_contig_extent) || !even(b_contig_extent) ||
             !aligned16(g.A) || !aligned16(g.B) || !even(g.a_b1) || !even(g.a_b2) || !even(g.b_b1) ||
             !even(g.b_b2))
@@ -1163,7 +1193,7 @@ void gemm(const Gemm& g, stream_t s) {
     if (tiles < 256 && ktiles >= 16) {
         long want = (512 + tiles - 1) / tiles;
         want = std::min<long>(want, ktiles / 8);          // >= 8 k-tiles (128 deep) per split
-        want = std::min<long>(want, 64);
+        want = std::min<long>(want, 512);
         want = std::min<long>(want, ws_tiles / tiles);
         if (want >= 2) main_split = (int)want;
     } else if (tiles > slots && ktiles >= 64) {
@@ -1343,10 +1373,14 @@ void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nc, int6
     HIP_CHECK(hipGetLastError());
 }
 
-void ladder_pack_T(const double* X, double* Sp, double* Am, int nc, int nr, int flags, stream_t s) {
-    const long npp = (long)nr * (nr + 1) / 2;
-    hipLaunchKernelGGL(ladder_pack_T_kernel, dim3((unsigned)npp), dim3(256), 0, (hipStream_t)s, X, Sp, Am, nc, nr,
-                       flags);
+void ladder_pack_T(const double* X, const double* t1, double* Sp, double* Am, int nc, int nr, int flags, int64_t ldp,
+                   int64_t ldm, stream_t s) {
+    const long npp = (long)nr * (nr + 1) / 2, opp = (long)nc * (nc + 1) / 2, opm = (long)nc * (nc - 1) / 2;
+    if (!ldp) ldp = opp;
+    if (!ldm) ldm = (flags & PACK_AM_PCOLS) ? opp : opm;
+    if (!X && !t1) throw std::runtime_error("ladder_pack_T: nothing to pack");
+    hipLaunchKernelGGL(ladder_pack_T_kernel, dim3((unsigned)npp), dim3(256), 0, (hipStream_t)s, X, t1, Sp, Am, nc, nr,
+                       flags, (long)ldp, (long)ldm);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1354,6 +1388,13 @@ void ladder_unpack(const double* L, double* R, double beta, int no, int nv, stre
     const long total = (long)nv * nv * no * no;
     hipLaunchKernelGGL(ladder_unpack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, L, R, beta, no, nv,
                        total);
+    HIP_CHECK(hipGetLastError());
+}
+
+void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t s) {
+    const long total = (long)rows * no * no;
+    if (!total) return;
+    hipLaunchKernelGGL(rows_unpack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, Q, out, no, total);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -230,8 +230,10 @@ class Context:
         self.lib.call("pymes_ccsd_dress_fock", self.handle, C.c_void_p(f.ptr), C.c_void_p(t1.ptr), C.c_void_p(out.ptr))
         return out
 
-    def dress_V(self, t1, names):
-        mask = 0
+    def dress_V(self, t1, names, reduced_abij=False):
+        """ccsd.py:290-421 for the named blocks; ``reduced_abij``: the form of V~_abij that goes with
+        ``residual_slab(..., t1=, QK=)`` (include/pymes_amd.h)."""
+        mask = _lib.PYMES_DRESS_ABIJ_REDUCED if reduced_abij else 0
         for nm in names:
             mask |= 1 << pattern_of(nm)
         self.lib.call("pymes_ccsd_dress_V", self.handle, C.c_void_p(t1.ptr), mask)
@@ -264,16 +266,19 @@ class Context:
                (_lib.PYMES_SKIP_LADDER if skip_ladder else 0) | (_lib.PYMES_SYM_LADDER if sym_ladder else 0) | \
                (_lib.PYMES_SYM_RINGS if sym_rings else 0)
 
-    def residual_slab(self, f, t2, ETd, ETx, L, rank, world, is_dcd=False, dressed=False):
-        """This rank's share of the symmetry-reduced residual (include/pymes_amd.h)."""
+    def residual_slab(self, f, t2, ETd, ETx, L, rank, world, is_dcd=False, dressed=False, t1=None, QK=None):
+        """This rank's share of the symmetry-reduced residual (include/pymes_amd.h).  ``t1`` + ``QK``: T1 dressing
+        of V_abcd on the amplitude side."""
         self.lib.call("pymes_residual_slab", self.handle, C.c_void_p(f.ptr), C.c_void_p(t2.ptr), C.c_void_p(ETd.ptr),
                       C.c_void_p(ETx.ptr), C.c_void_p(L.ptr if L is not None else 0), int(rank), int(world),
-                      self._flags(is_dcd, dressed, False, True, True))
+                      self._flags(is_dcd, dressed, False, True, True), C.c_void_p(t1.ptr if t1 is not None else 0),
+                      C.c_void_p(QK.ptr if QK is not None else 0))
 
-    def residual_finish(self, f, t2, ETd, ETx, L, out, is_dcd=False, dressed=False):
+    def residual_finish(self, f, t2, ETd, ETx, L, out, is_dcd=False, dressed=False, t1=None, QK=None):
         self.lib.call("pymes_residual_finish", self.handle, C.c_void_p(f.ptr), C.c_void_p(t2.ptr), C.c_void_p(ETd.ptr),
                       C.c_void_p(ETx.ptr), C.c_void_p(L.ptr if L is not None else 0), C.c_void_p(out.ptr),
-                      self._flags(is_dcd, dressed, False, True, True))
+                      self._flags(is_dcd, dressed, False, True, True), C.c_void_p(t1.ptr if t1 is not None else 0),
+                      C.c_void_p(QK.ptr if QK is not None else 0))
         return out
 
     def dress_abcd_rows(self, t1, a_begin, a_end, lower_only=False):

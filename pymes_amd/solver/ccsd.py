@@ -78,6 +78,7 @@ class CCSD(ccd.CCD):
         if amps is not None:
             t2h = np.asarray(amps[1])
             st["sym"] = bool(np.abs(t2h - t2h.transpose(1, 0, 3, 2)).max() <= 1e-13 * max(1.0, np.abs(t2h).max()))
+        st["npp"] = nv * (nv + 1) // 2
         if wsize > 1:
             import torch
             dev = torch.device("cuda", ctx.device)
@@ -86,13 +87,16 @@ class CCSD(ccd.CCD):
                 t = torch.zeros((pdist.padded_rows(rows, wsize), cols), dtype=torch.float64, device=dev)
                 return t, DeviceArray(ctx, t.data_ptr(), tuple(t.shape), owned=False, keepalive=t)
             if st["sym"]:
-                st["npp"] = nv * (nv + 1) // 2
                 st["ETd_t"], st["ETd"] = shared(no * nv, no * nv)
                 st["ETx_t"], st["ETx"] = shared(no * nv, no * nv)
                 st["L_t"], st["L"] = shared(st["npp"], no * no)
+                st["QK_t"], st["QK"] = shared(no * nv, no * no)
             else:
                 st["lad_rows"] = nv * nv
                 st["lad_t"], st["lad"] = shared(nv * nv, no * no)
+        elif st["sym"]:
+            st["ETd"], st["ETx"] = ctx.empty((no * nv, no * nv)), ctx.empty((no * nv, no * nv))
+            st["L"], st["QK"] = ctx.empty((st["npp"], no * no)), ctx.empty((no * nv, no * no))
         return st
 
     def iterate(self, st):
@@ -104,26 +108,24 @@ class CCSD(ccd.CCD):
         ctx.singles_residual(st["fd"], t1, t2, r1)                  # :167
         r2 = ctx.pool_get(t2.shape)
         world, rank = st["world"], st["rank"]
-        if world == 1:
-            if st["sym"]:    # the pair-packed ladder reads V~_abcd for b <= a only
-                ctx.dress_V(t1, ("abij", "klij", "iajb", "iabj"))   # :165 (only the blocks the residual reads)
-                ctx.dress_abcd_rows(t1, 0, ctx.nv, lower_only=True)
-            else:
-                ctx.dress_V(t1, LOOP_KEYS)
-            ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True, sym_ladder=st["sym"])   # :171
-        elif st["sym"]:
-            # sharded: this rank's column slab of the ring products + its rows of the packed ladder (for which it
-            # dresses only its own rows of V_abcd), three all-gathers, replicated remainder
-            ctx.dress_V(t1, ("abij", "klij", "iajb", "iabj"))
-            lo, hi = pdist.slab_rows(st["npp"], rank, world)
-            ctx.dress_abcd_rows(t1, *pdist.a_range_of_pair_rows(lo, hi), lower_only=True)
+        if st["sym"]:
+            # Symmetry-reduced, sharded form (world = 1 included): this rank's column slab of the ring products,
+            # its rows of the pair-packed particle + hole ladders and of Q_kb; four all-gathers; replicated
+            # remainder.  V_abcd is never dressed: its T1 dressing (:165, ccsd.py:414-419) is carried by
+            # tau = T2 + T1 T1 inside the ladders (include/pymes_amd.h, pymes_residual_slab).
+            ctx.dress_V(t1, ("abij", "klij", "iajb", "iabj"), reduced_abij=True)      # :165
             ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], rank, world, is_dcd=self.is_dcd,
-                              dressed=True)
-            ctx.sync()
-            for key in ("ETd_t", "ETx_t", "L_t"):
-                pdist.exchange_rows(st[key], rank, world)
-            torch_sync()
-            ctx.residual_finish(st["fd"], t2, st["ETd"], st["ETx"], st["L"], r2, is_dcd=self.is_dcd, dressed=True)
+                              dressed=True, t1=t1, QK=st["QK"])                        # :171
+            if world > 1:
+                ctx.sync()
+                for key in ("ETd_t", "ETx_t", "L_t", "QK_t"):
+                    pdist.exchange_rows(st[key], rank, world)
+                torch_sync()
+            ctx.residual_finish(st["fd"], t2, st["ETd"], st["ETx"], st["L"], r2, is_dcd=self.is_dcd, dressed=True,
+                                t1=t1, QK=st["QK"])
+        elif world == 1:
+            ctx.dress_V(t1, LOOP_KEYS)                                                # :165
+            ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True, sym_ladder=False)   # :171
         else:
             # unsymmetric user amplitudes: plain ladder rows on this rank, everything else replicated
             ctx.dress_V(t1, LOOP_KEYS)

@@ -142,38 +142,66 @@ static inline int64_t Q2(int64_t x, int64_t y) { return x * (x - 1) / 2 + y; }
 
 void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nv, int64_t rp0, int64_t rp1, stream_t) {
     const int64_t npp = (int64_t)nv * (nv + 1) / 2, npm = (int64_t)nv * (nv - 1) / 2;
+    auto pack_row = [&](const double* Vab, int64_t r, bool diag) {
+        for (int c = 0; c < nv; ++c)
+            for (int d = 0; d <= c; ++d) {
+                const double x1 = Vab[(int64_t)c * nv + d], x2 = Vab[(int64_t)d * nv + c];
+                Vp[r * npp + P2(c, d)] = x1 + x2;
+                if (c > d) Vm[r * npm + Q2(c, d)] = diag ? 0.0 : x1 - x2;
+            }
+    };
+    if (nr == 0) {
+        for (int64_t r = rp0; r < rp1; ++r) pack_row(V + r * nv * nv, r - rp0, false);
+        return;
+    }
     for (int a = 0; a < nr; ++a)
         for (int b = 0; b <= a; ++b) {
             const int64_t r = P2(a, b);
             if (r < rp0 || r >= rp1) continue;
-            const double* Vab = V + ((int64_t)a * nr + b) * nv * nv;
-            for (int c = 0; c < nv; ++c)
-                for (int d = 0; d <= c; ++d) {
-                    const double x1 = Vab[(int64_t)c * nv + d], x2 = Vab[(int64_t)d * nv + c];
-                    Vp[(r - rp0) * npp + P2(c, d)] = x1 + x2;
-                    if (c > d) Vm[(r - rp0) * npm + Q2(c, d)] = a > b ? x1 - x2 : 0.0;
-                }
+            pack_row(V + ((int64_t)a * nr + b) * nv * nv, r - rp0, a == b);
         }
 }
 
-void ladder_pack_T(const double* T, double* Sp, double* Am, int no, int nv, int flags, stream_t) {
+void ladder_pack_T(const double* T, const double* t1, double* Sp, double* Am, int no, int nv, int flags, int64_t ldp,
+                   int64_t ldm, stream_t) {
     const bool row_half = flags & PACK_ROW_HALF, prow = flags & PACK_AM_PROWS, col_half = flags & PACK_COL_HALF,
                pcol = flags & PACK_AM_PCOLS;
     const int64_t o2 = (int64_t)no * no, opp = (int64_t)no * (no + 1) / 2, opm = (int64_t)no * (no - 1) / 2;
-    const int64_t mld = pcol ? opp : opm;
+    if (!ldp) ldp = opp;
+    if (!ldm) ldm = pcol ? opp : opm;
     for (int c = 0; c < nv; ++c)
         for (int d = 0; d <= c; ++d)
             for (int i = 0; i < no; ++i)
                 for (int j = 0; j <= i; ++j) {
-                    const double x1 = T[((int64_t)c * nv + d) * o2 + i * no + j], x2 = T[((int64_t)d * nv + c) * o2 + i * no + j];
+                    double x1 = 0.0, x2 = 0.0;
+                    if (T) {
+                        x1 = T[((int64_t)c * nv + d) * o2 + i * no + j];
+                        x2 = T[((int64_t)d * nv + c) * o2 + i * no + j];
+                    }
+                    if (t1) {
+                        x1 += t1[c * no + i] * t1[d * no + j];
+                        x2 += t1[d * no + i] * t1[c * no + j];
+                    }
                     double f = 0.5;
                     if (c == d && row_half) f *= 0.5;
                     if (i == j && col_half) f *= 0.5;
-                    Sp[P2(c, d) * opp + P2(i, j)] = f * (x1 + x2);
+                    Sp[P2(c, d) * ldp + P2(i, j)] = f * (x1 + x2);
                     if ((prow || c > d) && (pcol || i > j))
-                        Am[(prow ? P2(c, d) : Q2(c, d)) * mld + (pcol ? P2(i, j) : Q2(i, j))] =
+                        Am[(prow ? P2(c, d) : Q2(c, d)) * ldm + (pcol ? P2(i, j) : Q2(i, j))] =
                             (c > d && i > j) ? 0.5 * (x1 - x2) : 0.0;
                 }
+}
+
+void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t) {
+    const int64_t opp = (int64_t)no * (no + 1) / 2, ld = (int64_t)no * no;
+    for (int64_t r = 0; r < rows; ++r)
+        for (int i = 0; i < no; ++i)
+            for (int j = 0; j < no; ++j) {
+                const int ih = i > j ? i : j, il = i > j ? j : i;
+                double v = Q[r * ld + P2(ih, il)];
+                if (i != j) v += (i > j ? 1.0 : -1.0) * Q[r * ld + opp + Q2(ih, il)];
+                out[r * ld + i * no + j] = v;
+            }
 }
 
 void ladder_unpack(const double* L, double* R, double beta, int no, int nv, stream_t) {

@@ -172,6 +172,17 @@ def sharded_residual_check(lib, cases, worlds, tol):
                 ctx.residual_finish(dF, dT2, ETd, ETx, L, r2, is_dcd=dcd, dressed=True)
                 ref = oc.ccsd_doubles_residual(no, fd_ref, t2, Vd_ref, is_dcsd=dcd)
                 assert np.abs(r2.get() - ref).max() < tol, (no, nv, world, dcd)
+            # the same with the T1 dressing of V_abcd carried by the amplitudes (never dresses abcd)
+            ctx.dress_V(dT1, ["abij", "klij", "iajb", "iabj"], reduced_abij=True)
+            for dcd in (False, True):
+                ETd, ETx, L = ctx.zeros((pad(ov), ov)), ctx.zeros((pad(ov), ov)), ctx.zeros((pad(npp), no * no))
+                QK = ctx.zeros((pad(ov), no * no))
+                for rank in range(world):
+                    ctx.residual_slab(dF, dT2, ETd, ETx, L, rank, world, is_dcd=dcd, dressed=True, t1=dT1, QK=QK)
+                r2 = ctx.empty(t2.shape)
+                ctx.residual_finish(dF, dT2, ETd, ETx, L, r2, is_dcd=dcd, dressed=True, t1=dT1, QK=QK)
+                ref = oc.ccsd_doubles_residual(no, fd_ref, t2, Vd_ref, is_dcsd=dcd)
+                assert np.abs(r2.get() - ref).max() < tol, ("t1-side", no, nv, world, dcd)
         ctx.close()
 
 
