@@ -102,7 +102,7 @@ Engine::Engine(int device, int no_, int nv_, size_t workspace_bytes) : no(no_), 
         workspace_bytes = static_cast<size_t>(bytes);
     }
     arena.init(workspace_bytes);
-    splitk_doubles_ = 16 << 20;   // 128 MiB of split-K partials (1024 tile-splits of 128x128)
+    splitk_doubles_ = 32 << 20;   // 256 MiB of split-K partials (2048 tile-splits of 128x128)
     splitk_ws_ = static_cast<double*>(dev::dmalloc(sizeof(double) * splitk_doubles_));
     eps_o = static_cast<double*>(dev::dmalloc(sizeof(double) * no));
     eps_v = static_cast<double*>(dev::dmalloc(sizeof(double) * nv));

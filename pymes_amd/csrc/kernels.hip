@@ -14,6 +14,7 @@
 // A[i=l&15][k=l>>4], B lane l holds B[k=l>>4][j=l&15], D register r of lane l is
 // D[i=(l>>4)+4r][j=l&15].
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <algorithm>
 #include <cmath>
@@ -334,6 +335,29 @@ __device__ __forceinline__ void glds16(const double* gsrc, double* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// wave-uniform values that the compiler computes on the VALU (64-bit divisions of the block id) are moved to
+// SGPRs explicitly, so that loop control and the LDS-DMA base addresses stay on the scalar unit
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ const char* uni_ptr(const void* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+
+// LDS-DMA with the address split the way the hardware wants it: wave-uniform 64-bit base in SGPRs + 32-bit byte
+// offset per lane + wave-uniform LDS destination in M0 (written here because the compiler turns the builtin's
+// address back into a 64-bit VALU add per load inside the k loop).
+__device__ __forceinline__ void glds16_su(const char* base_uniform, unsigned voff, unsigned lds_addr_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(voff), "s"(base_uniform), "s"(lds_addr_uniform)
+                 : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const double* p) {
+    return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
+}
+
 template <bool AKC, bool BKC>
 __global__ void __launch_bounds__(kThreads, 2) dgemm_glds_kernel(const GemmK g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -353,7 +377,7 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_glds_kernel(const GemmK g) 
     const long bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tiles = g.tiles_m * g.tiles_n;
     const long lt = bid / g.nsplit;
-    const int ks = (int)(bid - lt * g.nsplit);
+    const int ks = uni((int)(bid - lt * g.nsplit));
     const long gt = g.tile_begin + lt;
     const long z = gt / tiles;
     const int t = (int)(gt - z * tiles);
@@ -363,61 +387,58 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_glds_kernel(const GemmK g) 
     const int first_m = grp * GROUP;
     const int gm = min(g.tiles_m - first_m, GROUP);
     const int tin = t - grp * group_sz;
-    const int tm = first_m + tin % gm;
-    const int tn = tin / gm;
+    const int tm = uni(first_m + tin % gm);
+    const int tn = uni(tin / gm);
     const long z1 = z / g.nb2, z2 = z - z1 * g.nb2;
-    const double* __restrict__ A = g.A + z1 * g.a_b1 + z2 * g.a_b2;
-    const double* __restrict__ B = g.B + z1 * g.b_b1 + z2 * g.b_b2;
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = ks * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     const int nkt = (kend - kbeg + BK - 1) / BK;
     const int nfull = (kend - kbeg) / BK;
 
-    // ---- LDS-DMA source pointers: 4 wave-instructions per operand per wave per tile ----------------
+    // ---- LDS-DMA sources: 4 wave-instructions per operand per wave per tile -------------------------
     // K-contiguous: instruction j of wave w covers rows (4w+j)*8 .. +8; lane -> (row, chunk slot)
     // M/N-contiguous: instruction j of wave w covers k-row 4w+j; lane -> columns 2*lane, 2*lane+1
-    // rows / columns beyond M or N are clamped (they only feed C entries that are never stored)
-    const double* pa_j[4];
-    const double* pb_j[4];
+    // rows / columns beyond M or N are clamped (they only feed C entries that are never stored).
+    // Address = wave-uniform 64-bit base (SGPRs, advanced per k-tile on the scalar unit) + loop-invariant
+    // 32-bit byte offset per lane (the host guarantees 128 * ld * 8 < 2^32): no VALU work per k-tile.
+    const char* ua = uni_ptr(g.A + z1 * g.a_b1 + z2 * g.a_b2 + (AKC ? (long)m0 * g.a_ld + kbeg : (long)kbeg * g.a_ld + m0));
+    const char* ub = uni_ptr(g.B + z1 * g.b_b1 + z2 * g.b_b2 + (BKC ? (long)n0 * g.b_ld + kbeg : (long)kbeg * g.b_ld + n0));
+    unsigned ao[4], bo[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (AKC) {
             const int row = wave * 32 + (lane >> 3) + 8 * j;
             const int cg = (lane & 7) ^ ((row >> 1) & 7);
-            pa_j[j] = A + (long)min(m0 + row, g.M - 1) * g.a_ld + kbeg + cg * 2;
+            ao[j] = ((unsigned)(min(m0 + row, g.M - 1) - m0) * (unsigned)g.a_ld + cg * 2) * 8u;
         } else {
-            pa_j[j] = A + (long)(kbeg + wave * 4 + j) * g.a_ld + min(m0 + 2 * lane, g.Mc - 2);
+            ao[j] = ((unsigned)(wave * 4 + j) * (unsigned)g.a_ld + (unsigned)(min(m0 + 2 * lane, g.Mc - 2) - m0)) * 8u;
         }
         if (BKC) {
             const int row = wave * 32 + (lane >> 3) + 8 * j;
             const int cg = (lane & 7) ^ ((row >> 1) & 7);
-            pb_j[j] = B + (long)min(n0 + row, g.N - 1) * g.b_ld + kbeg + cg * 2;
+            bo[j] = ((unsigned)(min(n0 + row, g.N - 1) - n0) * (unsigned)g.b_ld + cg * 2) * 8u;
         } else {
-            pb_j[j] = B + (long)(kbeg + wave * 4 + j) * g.b_ld + min(n0 + 2 * lane, g.Nc - 2);
+            bo[j] = ((unsigned)(wave * 4 + j) * (unsigned)g.b_ld + (unsigned)(min(n0 + 2 * lane, g.Nc - 2) - n0)) * 8u;
         }
     }
-    const long a_kstep = AKC ? (long)BK : (long)BK * g.a_ld;
-    const long b_kstep = BKC ? (long)BK : (long)BK * g.b_ld;
+    const long a_kstep = 8 * (AKC ? (long)BK : (long)BK * g.a_ld);      // bytes
+    const long b_kstep = 8 * (BKC ? (long)BK : (long)BK * g.b_ld);
     // wave-uniform LDS destinations of the 4 instructions
     const int a_dst = AKC ? wave * 32 * BK : wave * 4 * A_PITCH;       // + j * (8*BK | A_PITCH)
     const int b_dst = BKC ? wave * 32 * BK : wave * 4 * B_PITCH;
     constexpr int A_DSTEP = AKC ? 8 * BK : A_PITCH;
     constexpr int B_DSTEP = BKC ? 8 * BK : B_PITCH;
 
-    auto stage_dma = [&](int buf) {      // one full k-tile, then advance the source pointers
-        double* as = As + buf * A_TILE + a_dst;
-        double* bs = Bs + buf * B_TILE + b_dst;
+    const unsigned a_lds = uni((int)lds_addr_of(As + a_dst)), b_lds = uni((int)lds_addr_of(Bs + b_dst));
+    auto stage_dma = [&](int buf) {      // one full k-tile, then advance the source bases
+        const unsigned as = a_lds + buf * (A_TILE * 8), bs = b_lds + buf * (B_TILE * 8);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            glds16(pa_j[j], as + j * A_DSTEP);
-            pa_j[j] += a_kstep;
-        }
+        for (int j = 0; j < 4; ++j) glds16_su(ua, ao[j], as + j * (A_DSTEP * 8));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            glds16(pb_j[j], bs + j * B_DSTEP);
-            pb_j[j] += b_kstep;
-        }
+        for (int j = 0; j < 4; ++j) glds16_su(ub, bo[j], bs + j * (B_DSTEP * 8));
+        ua += a_kstep;
+        ub += b_kstep;
     };
     auto stage_tail = [&](int buf, int k0) {   // partial k-tile through registers, zero beyond kend
         double* as = As + buf * A_TILE;
@@ -428,28 +449,24 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_glds_kernel(const GemmK g) 
             if (AKC) {
                 const int row = wave * 32 + (lane >> 3) + 8 * j;
                 const int cg = (lane & 7) ^ ((row >> 1) & 7);
-                if (k0 + cg * 2 < kend) va = *reinterpret_cast<const v2d*>(pa_j[j]);
+                if (k0 + cg * 2 < kend) va = *reinterpret_cast<const v2d*>(ua + ao[j]);
                 *reinterpret_cast<v2d*>(as + row * BK + (lane & 7) * 2) = va;
             } else {
                 const int krow = wave * 4 + j;
-                if (k0 + krow < kend) va = *reinterpret_cast<const v2d*>(pa_j[j]);
+                if (k0 + krow < kend) va = *reinterpret_cast<const v2d*>(ua + ao[j]);
                 *reinterpret_cast<v2d*>(as + krow * A_PITCH + 2 * lane) = va;
             }
             if (BKC) {
                 const int row = wave * 32 + (lane >> 3) + 8 * j;
                 const int cg = (lane & 7) ^ ((row >> 1) & 7);
-                if (k0 + cg * 2 < kend) vb = *reinterpret_cast<const v2d*>(pb_j[j]);
+                if (k0 + cg * 2 < kend) vb = *reinterpret_cast<const v2d*>(ub + bo[j]);
                 *reinterpret_cast<v2d*>(bs + row * BK + (lane & 7) * 2) = vb;
             } else {
                 const int krow = wave * 4 + j;
-                if (k0 + krow < kend) vb = *reinterpret_cast<const v2d*>(pb_j[j]);
+                if (k0 + krow < kend) vb = *reinterpret_cast<const v2d*>(ub + bo[j]);
                 *reinterpret_cast<v2d*>(bs + krow * B_PITCH + 2 * lane) = vb;
             }
         }
-    };
-    auto stage = [&](int kt, int buf) {
-        if (kt < nfull) stage_dma(buf);
-        else stage_tail(buf, kbeg + kt * BK);
     };
 
     v4d acc[FM][FN];
@@ -488,14 +505,12 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_glds_kernel(const GemmK g) 
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
-
-    if (nkt > 0) stage(0, 0);
-    landed();
-    if (nkt > 0) read_frags(As, Bs, 0, a[0], b[0]);
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const bool has_next = kt + 1 < nkt;
-        if (has_next) stage(kt + 1, cur ^ 1);    // buffer cur^1 was last read before the previous barrier
+    // one k-tile out of buffer CUR (a compile-time constant: the fragment addresses are then loop-invariant
+    // registers + immediate offsets); `next`: 0 = nothing follows, 1 = a full tile (DMA), 2 = the partial tile
+    auto ktile = [&](auto curc, int next, int k_next) {
+        constexpr int cur = decltype(curc)::value;
+        if (next == 1) stage_dma(cur ^ 1);           // buffer cur^1 was last read before the previous barrier
+        else if (next == 2) stage_tail(cur ^ 1, k_next);
         const double* as = As + cur * A_TILE;
         const double* bs = Bs + cur * B_TILE;
         read_frags(as, bs, 1, a[1], b[1]);
@@ -505,8 +520,30 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_glds_kernel(const GemmK g) 
         read_frags(as, bs, 3, a[1], b[1]);
         mfma_step(a[0], b[0]);
         landed();
-        if (has_next) read_frags(As + (cur ^ 1) * A_TILE, Bs + (cur ^ 1) * B_TILE, 0, a[0], b[0]);
+        if (next) read_frags(As + (cur ^ 1) * A_TILE, Bs + (cur ^ 1) * B_TILE, 0, a[0], b[0]);
         mfma_step(a[1], b[1]);
+    };
+    const std::integral_constant<int, 0> buf0;
+    const std::integral_constant<int, 1> buf1;
+
+    if (nkt > 0) {
+        if (nfull > 0) stage_dma(0);
+        else stage_tail(0, kbeg);
+        landed();
+        read_frags(As, Bs, 0, a[0], b[0]);
+        int kt = 0;
+        // steady state: the tile after the current one and the one after that are both full
+        for (; kt + 2 < nfull; kt += 2) {
+            ktile(buf0, 1, 0);
+            ktile(buf1, 1, 0);
+        }
+        for (; kt < nkt; ++kt) {
+            const int next = kt + 1 < nfull ? 1 : (kt + 1 < nkt ? 2 : 0);
+            if (kt & 1) ktile(buf1, next, kbeg + (kt + 1) * BK);
+            else ktile(buf0, next, kbeg + (kt + 1) * BK);
+        }
+    } else {
+        landed();
     }
 
     // ---- epilogue (as dgemm_kernel) -----------------------------------------------------------------
@@ -1037,7 +1074,9 @@ void launch_gemm_glds(const GemmK& k, long nblocks, hipStream_t st) {
 
 template <int BM, int BN>
 void dispatch_layout(const GemmK& k, bool akc, bool bkc, int vec, long nblocks, hipStream_t st) {
-    if (BM == 128 && BN == 128 && vec == 2 && !getenv("PYMES_GEMM_NO_LDSDMA")) {
+    // the LDS-DMA kernel addresses a tile as uniform base + 32-bit byte offset per lane
+    const bool off32 = (akc ? 128 : 16) * k.a_ld * 8 + 4096 < (1L << 32) && (bkc ? 128 : 16) * k.b_ld * 8 + 4096 < (1L << 32);
+    if (BM == 128 && BN == 128 && vec == 2 && off32 && !getenv("PYMES_GEMM_NO_LDSDMA")) {
         if (akc && bkc) launch_gemm_glds<true, true>(k, nblocks, st);
         else if (akc) launch_gemm_glds<true, false>(k, nblocks, st);
         else if (bkc) launch_gemm_glds<false, true>(k, nblocks, st);
@@ -1186,7 +1225,9 @@ void gemm(const Gemm& g, stream_t s) {
     // launch takes ceil(tiles/slots) tile-times; splitting the K range of the remainder tiles over
     // the idle CUs turns that last wave into a fraction of a tile-time.
     const long ktiles = (g.K + BK - 1) / BK;
-    const long slots = 256L * ((BM == 64 && BN == 64) ? 4 : 2);     // resident blocks on the chip
+    // Blocks that share a CU time-share its MFMA pipes, so what has to balance is the number of tiles per CU:
+    // a launch costs about ceil(tiles / 256) tile-times (64x64 tiles need 4 co-resident blocks to fill a CU).
+    const long slots = (BM == 64 && BN == 64) ? 1024 : 256;
     const long ws_tiles = g.splitk_ws ? g.splitk_ws_doubles / ((long)BM * BN) : 0;
     long main_tiles = tiles, tail_tiles = 0;
     int main_split = 1, tail_split = 1;
@@ -1196,16 +1237,21 @@ void gemm(const Gemm& g, stream_t s) {
         want = std::min<long>(want, 512);
         want = std::min<long>(want, ws_tiles / tiles);
         if (want >= 2) main_split = (int)want;
-    } else if (tiles > slots && ktiles >= 64) {
+    } else if (ktiles >= 32) {
         const long rem = tiles % slots;
-        if (rem > 0 && rem <= slots / 2) {
-            long want = std::min<long>(slots / rem, 8);
-            want = std::min<long>(want, ktiles / 16);
-            want = std::min<long>(want, ws_tiles / rem);
-            if (want >= 2) {
+        if (rem > 0) {
+            // split the K range of the remainder tiles s ways: ceil(rem s / slots) rounds of 1/s tile-time each
+            long best = 1;
+            double best_cost = 1.0;
+            const long smax = std::min<long>(std::min<long>(8, ktiles / 16), ws_tiles / rem);
+            for (long sp = 2; sp <= smax; ++sp) {
+                const double cost = (double)((rem * sp + slots - 1) / slots) / (double)sp + 0.01 * sp;
+                if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
+            }
+            if (best >= 2 && best_cost < 0.8) {
                 tail_tiles = rem;
                 main_tiles = tiles - rem;
-                tail_split = (int)want;
+                tail_split = (int)best;
             }
         }
     }
@@ -1238,7 +1284,7 @@ void gemm(const Gemm& g, stream_t s) {
         }
         return k.nsplit;
     };
-    int nsplit = launch(0, main_tiles, main_split);
+    int nsplit = main_tiles > 0 ? launch(0, main_tiles, main_split) : 1;
     if (tail_tiles > 0) nsplit = -launch(main_tiles, tail_tiles, tail_split);   // logged as a negative split
     if (g_prof.on) {
         HIP_CHECK(hipEventRecord(ev.second, st));
