@@ -240,7 +240,11 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
     auto slab = [&]() { return make_view(arena.alloc(ov * nc), {ov, nc}); };
     TView Vd = pairm(get_static("Vd"));
     TView Td = pairm(arena.alloc(ov * ov)), Tx = pairm(arena.alloc(ov * ov)), Ttd = pairm(arena.alloc(ov * ov));
-    {
+    if (dev::fused_pair_kernels_ok(no)) {
+        dev::t2_layouts(t2, Td.p, Tx.p, Ttd.p, no, nv, stream);
+        stats.permute_calls++;
+        stats.permute_bytes += 8.0 * 5.0 * double(ov * ov);
+    } else {
         TView t4 = make_view(Td.p, {v, o, v, o});
         permute(1.0, T, "abij", 0.0, t4, "aibj");
         t4.p = Tx.p;
@@ -251,39 +255,38 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
     }
     TView ETd = slice(pairm(ETd_p), 0, c0, c1), ETx = slice(pairm(ETx_p), 0, c0, c1);
     auto cols = [&](const TView& m) { return slice(m, 1, c0, c1); };
-    // column slabs of the static / dressed right-hand factors, straight from the 4-index blocks
-    TView M = slab(), UdT = slab();
-    {
-        // Wd[(c,k),(b,j)] = V_iabj[k,b,c,j];  UdT[(c,k),(b,j)] = V_iajb[k,b,j,c];  columns (b,j) in [c0,c1)
-        ArenaScope s2(arena);
-        TView full = pairm(arena.alloc(ov * ov));
-        TView f4 = make_view(full.p, {v, o, v, o});
-        permute(1.0, Viabj, "kbcj", 0.0, f4, "ckbj");
-        copy(cols(full), M);
-        permute(1.0, Viajb, "kbjc", 0.0, f4, "ckbj");
-        copy(cols(full), UdT);
-    }
-    {
-        ArenaScope s2(arena);
-        TView Y = slab();
-        contract(1.0, Vd, "xy", cols(Ttd), "yn", 0.0, Y, "xn");                              // :202
-        axpby(0.5, Y, 1.0, M);                                                               // M = Wd + Y/2
-    }
+    // column slabs (b,j) in [c0,c1) of the static / dressed right-hand factors, straight from the 4-index blocks:
+    //   Wd[(c,k),(b,j)] = V_iabj[k,b,c,j],   UdT[(c,k),(b,j)] = V_iajb[k,b,j,c]
+    const int64_t b0 = c0 / o, b1 = (c1 + o - 1) / o;
+    auto load_cols = [&](double alpha, const TView& blk, const char* spec, const TView& dst) {
+        TView src = slice(blk, 1, b0, b1);                       // only the b values the slab touches
+        if (b0 * o == c0 && b1 * o == c1) {
+            permute(alpha, src, spec, 0.0, make_view(dst.p, {v, o, b1 - b0, o}), "ckbj");
+        } else {
+            ArenaScope s2(arena);
+            TView tmp = make_view(arena.alloc(ov * (b1 - b0) * o), {ov, (b1 - b0) * o});
+            permute(alpha, src, spec, 0.0, make_view(tmp.p, {v, o, b1 - b0, o}), "ckbj");
+            copy(slice(tmp, 1, c0 - b0 * o, c1 - b0 * o), dst);
+        }
+    };
+    TView M = slab(), N1 = slab();
+    load_cols(1.0, Viabj, "kbcj", M);                                                         // M = Wd
+    load_cols(-1.0, Viajb, "kbjc", N1);                                                       // N1 = -UdT
+    contract(0.5, Vd, "xy", cols(Ttd), "yn", 1.0, M, "xn");                                  // M = Wd + Y/2   (:202)
     contract(1.0, M, "kn", Ttd, "mk", 0.0, ETd, "nm");                                       // :204 (half) + :235
-    axpby(-1.0, UdT, 0.0, M);                                                                // M = -UdT
     if (quad) {
+        // U = Vx Tx (:190), U' = Vx Td (:238):  X3 = U/2 - UdT,  M2 = -UdT + U - U' = 2 X3 + UdT - U'
         TView Vx = pairm(get_static("Vx"));
-        TView U = slab();
-        contract(1.0, Vx, "xy", cols(Tx), "yn", 0.0, U, "xn");                               // :190
-        axpby(1.0, U, 1.0, M);
-        axpby(0.5, U, -1.0, UdT);                                                            // UdT <- U/2 - UdT
-        contract(1.0, Vx, "xy", cols(Td), "yn", 0.0, U, "xn");                               // U'   (:238)
-        axpby(-1.0, U, 1.0, M);
+        TView X3 = M;                                                                        // M is free again
+        contract(0.5, Vx, "xy", cols(Tx), "yn", 1.0, X3, "xn", "", &N1);                     // X3 = N1 + U/2
+        axpby(2.0, X3, -1.0, N1);                                                            // N1 = 2 X3 + UdT
+        contract(-1.0, Vx, "xy", cols(Td), "yn", 1.0, N1, "xn");                             // N1 = M2
+        contract(1.0, N1, "kn", Td, "mk", 1.0, ETd, "nm");                                   // :233, :238-240
+        contract(1.0, X3, "kn", Tx, "mk", 0.0, ETx, "nm");                                   // :234, :191 (half)
     } else {
-        axpby(0.0, UdT, -1.0, UdT);                                                          // UdT <- -UdT
+        contract(1.0, N1, "kn", Td, "mk", 1.0, ETd, "nm");                                   // :233
+        contract(1.0, N1, "kn", Tx, "mk", 0.0, ETx, "nm");                                   // :234
     }
-    contract(1.0, M, "kn", Td, "mk", 1.0, ETd, "nm");                                        // :233, :238-240
-    contract(1.0, UdT, "kn", Tx, "mk", 0.0, ETx, "nm");                                      // :234, :191 (half)
     {
         // :232  Ex[a,b,i,j] -= X_ki T[a,b,k,j]  ->  ET[(b,j),(a,i)] -= sum_k Td[(b,j),(a,k)] X_ki   (Td symmetric)
         ArenaScope s2(arena);
@@ -311,38 +314,46 @@ void Engine::residual_finish(const double* f, const double* t2, const double* ET
     TView Fvv = slice(slice(F, 0, o, nn), 1, o, nn);
     TView Vijab = block(P_ijab);
     ArenaScope scope(arena);
-    copy(block(P_abij, dressed), R);                                                        // :185
-    if (L && !skip_ladder) {
-        ladder_sym_unpack(L, r2, 1.0);                  // particle (:187) + hole (:175-186) ladders, pair-packed
-    } else {
+    const bool packed = L && !skip_ladder;
+    const bool fused = dev::fused_pair_kernels_ok(no);
+    if (!fused) copy(block(P_abij, dressed), R);                                            // :185
+    if (!packed) {
         ArenaScope s2(arena);
+        if (fused) copy(block(P_abij, dressed), R);
         TView hole = make_view(arena.alloc(o * o * o * o), {o, o, o, o});
         copy(block(P_klij, dressed), hole);                                                 // :178
         if (quad) contract(1.0, Vijab, "klcd", T, "cdij", 1.0, hole, "klij");                // :180
         contract(1.0, hole, "klij", T, "abkl", 1.0, R, "abij");                             // :186
         if (!skip_ladder) contract(1.0, block(P_abcd, dressed), "abcd", T, "cdij", 1.0, R, "abij");   // :187
+    } else if (!fused) {
+        ladder_sym_unpack(L, r2, 1.0);                  // particle (:187) + hole (:175-186) ladders, pair-packed
     }
-    {
-        // X_ac = f_ac - w sum Tt[a,d,k,l] V[l,k,d,c]  (:206-221);  Ex += X_ac T[c,b,i,j]  (:231)
-        ArenaScope s2(arena);
-        TView Ttd = make_view(arena.alloc(o * o * v * v), {v, o, v, o});
-        permute(2.0, T, "abij", 0.0, Ttd, "aibj");
-        permute(-1.0, T, "baij", 1.0, Ttd, "aibj");
-        TView Xvv = make_view(arena.alloc(v * v), {v, v});
-        copy(Fvv, Xvv);
-        contract(-w, Ttd, "akdl", make_view(get_static("Vk"), {o, v, o, v}), "kdlc", 1.0, Xvv, "ac");
-        TView Exn = make_view(Ttd.p, {v, v, o, o});      // Ttd is dead after X_ac: reuse its storage
-        contract(1.0, Xvv, "ac", T, "cbij", 0.0, Exn, "abij");
-        if (t1 && L && !skip_ladder) {
-            // bras (k,b) and (a,l) of the amplitude-side dressing: -t_ak Q_kbij - t_bl Q_laji, Q = V_kbcd tau_cdij
-            if (!QK) throw Error("residual_finish: QK buffer missing");
-            TView Qf = make_view(arena.alloc(o * v * o * o), {o, v, o, o});
-            dev::rows_unpack(QK, Qf.p, o * v, no, stream);
-            contract(-1.0, make_view(const_cast<double*>(t1), {v, o}), "ak", Qf, "kbij", 1.0, Exn, "abij");
-        }
-        permute(1.0, Exn, "abij", 1.0, R, "abij");
-        permute(1.0, Exn, "baji", 1.0, R, "abij");
+    // X_ac = f_ac - w sum Tt[a,d,k,l] V[l,k,d,c]  (:206-221);  Ex += X_ac T[c,b,i,j]  (:231)
+    TView Ttd = make_view(arena.alloc(o * o * v * v), {v, o, v, o});
+    permute(2.0, T, "abij", 0.0, Ttd, "aibj");
+    permute(-1.0, T, "baij", 1.0, Ttd, "aibj");
+    TView Xvv = make_view(arena.alloc(v * v), {v, v});
+    copy(Fvv, Xvv);
+    contract(-w, Ttd, "akdl", make_view(get_static("Vk"), {o, v, o, v}), "kdlc", 1.0, Xvv, "ac");
+    TView Exn = make_view(Ttd.p, {v, v, o, o});      // Ttd is dead after X_ac: reuse its storage
+    contract(1.0, Xvv, "ac", T, "cbij", 0.0, Exn, "abij");
+    if (t1 && packed) {
+        // bras (k,b) and (a,l) of the amplitude-side dressing: -t_ak Q_kbij - t_bl Q_laji, Q = V_kbcd tau_cdij
+        if (!QK) throw Error("residual_finish: QK buffer missing");
+        TView Qf = make_view(arena.alloc(o * v * o * o), {o, v, o, o});
+        dev::rows_unpack(QK, Qf.p, o * v, no, stream);
+        contract(-1.0, make_view(const_cast<double*>(t1), {v, o}), "ak", Qf, "kbij", 1.0, Exn, "abij");
     }
+    if (fused) {
+        // R = V~_abij (or what R holds already) + ladders + Ex + Ex^T in one pass              (:185-187, :249-252)
+        dev::residual_assemble(packed ? block(P_abij, dressed).p : r2, packed ? L : nullptr, Exn.p, ETd_p, ETx_p, r2, no,
+                               nv, stream);
+        stats.permute_calls++;
+        stats.permute_bytes += 8.0 * 5.5 * double(o * o * v * v);
+        return;
+    }
+    permute(1.0, Exn, "abij", 1.0, R, "abij");
+    permute(1.0, Exn, "baji", 1.0, R, "abij");
     TView ETd = make_view(const_cast<double*>(ETd_p), {v, o, v, o}), ETx = make_view(const_cast<double*>(ETx_p), {v, o, v, o});
     permute(1.0, ETd, "aibj", 1.0, R, "abij");                                              // Ex + Ex^T (:249-252)
     permute(1.0, ETd, "bjai", 1.0, R, "abij");
@@ -536,22 +547,29 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
     }
     if (rows == 0) return;
     // ---- hole ladder rows.  Ifull = V~_klij + V_klcd T_cdij (pair-packed, doubled as in ladder_sym) ------
-    double* Ip = arena.alloc(opp * ldp);
-    double* Im = arena.alloc(std::max<int64_t>(opp * ldm, 1));
+    // The (k,l) pair is the GEMM K index here: it runs over the padded pitch ldp (zero pad column in the rows of
+    // T / tau, zero pad row in I) so that both operands qualify for 16-byte loads.
+    double* Ip = arena.alloc(ldp * ldp);
+    double* Im = arena.alloc(ldp * ldm);
+    if (ldp > opp) {
+        dev::memset_zero(Ip + opp * ldp, sizeof(double) * ldp, stream);
+        dev::memset_zero(Im + opp * ldm, sizeof(double) * ldm, stream);
+    }
     dev::ladder_pack_T(block(P_klij, true).p, nullptr, Ip, Im, no, no, dev::PACK_AM_PROWS, ldp, ldm, stream);
-    TView Ipv = pitched(Ip, opp, opp, ldp), Imv = pitched(Im, opp, opm, ldm);
-    double* SpR = arena.alloc(npp * opp);
-    double* AmR = arena.alloc(npp * opp);
+    TView Ipv = pitched(Ip, opp, opp, ldp), Imv = pitched(Im, opp, opm, ldm);        // the defined part
+    TView IpK = pitched(Ip, ldp, opp, ldp), ImK = pitched(Im, ldp, opm, ldm);        // with the zero pad row
+    double* SpR = arena.alloc(npp * ldp);
+    double* AmR = arena.alloc(npp * ldp);
     const int rflags = dev::PACK_COL_HALF | dev::PACK_AM_PROWS | dev::PACK_AM_PCOLS;
-    auto rowsS = [&]() { return slice(make_view(SpR, {npp, opp}), 0, row0, row1); };
-    auto rowsA = [&]() { return slice(make_view(AmR, {npp, opp}), 0, row0, row1); };
+    auto rowsS = [&]() { return slice(make_view(SpR, {npp, ldp}), 0, row0, row1); };
+    auto rowsA = [&]() { return slice(make_view(AmR, {npp, ldp}), 0, row0, row1); };
     if (dcd) {
         // DCSD keeps only V~_klij in the hole ladder proper (ccd.py:178), but the (k,l)-bra part still sees Ifull
         axpby(2.0, Ipv, 0.0, Ipv);
         if (opm > 0) axpby(2.0, Imv, 0.0, Imv);
-        dev::ladder_pack_T(t2, nullptr, SpR, AmR, no, nv, rflags, 0, 0, stream);
-        contract(1.0, rowsS(), "rk", Ipv, "kn", 1.0, LS, "rn");
-        if (opm > 0) contract(1.0, rowsA(), "rk", Imv, "kn", 1.0, LA, "rn");
+        dev::ladder_pack_T(t2, nullptr, SpR, AmR, no, nv, rflags, ldp, ldp, stream);
+        contract(1.0, rowsS(), "rk", IpK, "kn", 1.0, LS, "rn");
+        if (opm > 0) contract(1.0, rowsA(), "rk", ImK, "kn", 1.0, LA, "rn");
     }
     {
         ArenaScope s2(arena);
@@ -565,11 +583,11 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
         else if (opm > 0 && !dcd) axpby(2.0, Imv, 0.0, Imv);
     }
     // CCSD: rows of tau against Ifull;  DCSD: rows of t1 t1 against Ifull (rows of T were taken above)
-    dev::ladder_pack_T(dcd ? nullptr : t2, t1, SpR, AmR, no, nv, rflags, 0, 0, stream);
+    dev::ladder_pack_T(dcd ? nullptr : t2, t1, SpR, AmR, no, nv, rflags, ldp, ldp, stream);
     stats.permute_calls += 3;
     stats.permute_bytes += 8.0 * 4.0 * double(v * v * o * o);
-    contract(1.0, rowsS(), "rk", Ipv, "kn", 1.0, LS, "rn");
-    if (opm > 0) contract(1.0, rowsA(), "rk", Imv, "kn", 1.0, LA, "rn");
+    contract(1.0, rowsS(), "rk", IpK, "kn", 1.0, LS, "rn");
+    if (opm > 0) contract(1.0, rowsA(), "rk", ImK, "kn", 1.0, LA, "rn");
 }
 
 void Engine::ladder_sym_unpack(const double* L, double* r2, double beta) {

@@ -855,6 +855,11 @@ __global__ void ladder_pack_T_kernel(const double* __restrict__ T, const double*
     const double fr = (c == d && row_half) ? 0.25 : 0.5;
     const long mrow = prow ? row : (long)c * (c - 1) / 2 + d;
     const bool has_m = prow || c > d;
+    if (threadIdx.x == 0) {      // pad columns of an even pitch are part of the GEMM K range when this is an A operand
+        const long opp = (long)no * (no + 1) / 2, mcols = pcol ? opp : opp - no;
+        if (ldp > opp) Sp[row * ldp + opp] = 0.0;
+        if (has_m && ldm > mcols) Am[mrow * ldm + mcols] = 0.0;
+    }
     for (int e = threadIdx.x; e < o2; e += blockDim.x) {
         const int i = e / no, j = e - i * no;
         if (i < j) continue;
@@ -891,6 +896,71 @@ __global__ void ladder_unpack_kernel(const double* __restrict__ L, double* __res
             v += ((a > b) == (i > j)) ? x : -x;
         }
         R[idx] = (beta != 0.0) ? beta * R[idx] + v : v;
+    }
+}
+
+// Pair layouts of exchange-symmetric-or-not amplitudes in one pass over T[a,b,i,j]; one block per (a,b):
+//   Td[(a,i),(b,j)] = T_abij,  Tx[(a,j),(b,i)] = T_abij,  Ttd[(a,i),(b,j)] = 2 T_abij - T_baij
+__global__ void __launch_bounds__(256) t2_layouts_kernel(const double* __restrict__ T, double* __restrict__ Td,
+                                                         double* __restrict__ Tx, double* __restrict__ Ttd, int no,
+                                                         int nv) {
+    extern __shared__ double tile[];          // [no][no + 1]
+    const int a = blockIdx.x / nv, b = blockIdx.x - a * nv;
+    const long o2 = (long)no * no, ov = (long)no * nv;
+    const double* __restrict__ Tab = T + ((long)a * nv + b) * o2;
+    const double* __restrict__ Tba = T + ((long)b * nv + a) * o2;
+    const long base = (long)a * no * ov + (long)b * no;       // element [(a,0),(b,0)] of a pair matrix
+    for (int e = threadIdx.x; e < o2; e += blockDim.x) {
+        const int i = e / no, j = e - i * no;
+        const double x = Tab[e];
+        tile[i * (no + 1) + j] = x;
+        const long off = base + (long)i * ov + j;
+        Td[off] = x;
+        Ttd[off] = 2.0 * x - Tba[e];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < o2; e += blockDim.x) {
+        const int j = e / no, i = e - j * no;                   // Tx tile row j, column i
+        Tx[base + (long)j * ov + i] = tile[i * (no + 1) + j];
+    }
+}
+
+// R[a,b,:,:] and R[b,a,:,:] of the symmetry-reduced residual in one pass (one block per pair a >= b):
+//   S[i][j] = N_ab[i][j] + N_ba[j][i] + D[(a,i),(b,j)] + D[(b,j),(a,i)] + X[(a,j),(b,i)] + X[(b,i),(a,j)]
+//   R_ab = V_ab + unpack(L)_ab + S,   R_ba = V_ba + unpack(L)_ba + S^T
+__global__ void __launch_bounds__(256) residual_assemble_kernel(const double* V, const double* __restrict__ L,
+                                                                const double* __restrict__ N, const double* __restrict__ D,
+                                                                const double* __restrict__ X, double* R,   // V may be R
+                                                                int no, int nv) {
+    extern __shared__ double S[];             // [no][no + 1]
+    int a, b;
+    unrank_pair(blockIdx.x, a, b);
+    const int p = no + 1;
+    const long o2 = (long)no * no, ov = (long)no * nv, opp = (long)no * (no + 1) / 2;
+    const long ab = ((long)a * nv + b) * o2, ba = ((long)b * nv + a) * o2;
+    const long tab = (long)a * no * ov + (long)b * no, tba = (long)b * no * ov + (long)a * no;
+    for (int e = threadIdx.x; e < o2; e += blockDim.x) {      // sources read in (i,j) order
+        const int i = e / no, j = e - i * no;
+        S[i * p + j] = N[ab + e] + D[tab + (long)i * ov + j] + X[tba + (long)i * ov + j];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < o2; e += blockDim.x) {      // sources read in (j,i) order
+        const int j = e / no, i = e - j * no;
+        S[i * p + j] += N[ba + e] + D[tba + (long)j * ov + i] + X[tab + (long)j * ov + i];
+    }
+    __syncthreads();
+    const double* __restrict__ row = L ? L + ((long)a * (a + 1) / 2 + b) * o2 : nullptr;
+    for (int e = threadIdx.x; e < o2; e += blockDim.x) {
+        const int i = e / no, j = e - i * no;
+        const int ih = max(i, j), il = min(i, j);
+        double ls = 0.0, la = 0.0;
+        if (row) {
+            ls = row[(long)ih * (ih + 1) / 2 + il];
+            if (a != b && i != j) la = row[opp + (long)ih * (ih - 1) / 2 + il];
+        }
+        const double sgn = i > j ? 1.0 : -1.0;
+        R[ab + e] = V[ab + e] + ls + sgn * la + S[i * p + j];
+        if (a != b) R[ba + e] = V[ba + e] + ls - sgn * la + S[j * p + i];
     }
 }
 
@@ -1076,7 +1146,8 @@ template <int BM, int BN>
 void dispatch_layout(const GemmK& k, bool akc, bool bkc, int vec, long nblocks, hipStream_t st) {
     // the LDS-DMA kernel addresses a tile as uniform base + 32-bit byte offset per lane
     const bool off32 = (akc ? 128 : 16) * k.a_ld * 8 + 4096 < (1L << 32) && (bkc ? 128 : 16) * k.b_ld * 8 + 4096 < (1L << 32);
-    if (BM == 128 && BN == 128 && vec == 2 && off32 && !getenv("PYMES_GEMM_NO_LDSDMA")) {
+    // ... and pays off from about 64 k-tiles per block on (measured: below that the register-staged kernel wins)
+    if (BM == 128 && BN == 128 && vec == 2 && off32 && k.kchunk >= 1024 && !getenv("PYMES_GEMM_NO_LDSDMA")) {
         if (akc && bkc) launch_gemm_glds<true, true>(k, nblocks, st);
         else if (akc) launch_gemm_glds<true, false>(k, nblocks, st);
         else if (bkc) launch_gemm_glds<false, true>(k, nblocks, st);
@@ -1434,6 +1505,24 @@ void ladder_unpack(const double* L, double* R, double beta, int no, int nv, stre
     const long total = (long)nv * nv * no * no;
     hipLaunchKernelGGL(ladder_unpack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, L, R, beta, no, nv,
                        total);
+    HIP_CHECK(hipGetLastError());
+}
+
+bool fused_pair_kernels_ok(int no) { return (size_t)no * (no + 1) * sizeof(double) <= 64 * 1024; }
+
+void t2_layouts(const double* T, double* Td, double* Tx, double* Ttd, int no, int nv, stream_t s) {
+    if (!fused_pair_kernels_ok(no)) throw std::runtime_error("t2_layouts: nocc too large for the LDS tile");
+    const size_t lds = sizeof(double) * no * (no + 1);
+    hipLaunchKernelGGL(t2_layouts_kernel, dim3((unsigned)(nv * nv)), dim3(256), lds, (hipStream_t)s, T, Td, Tx, Ttd, no, nv);
+    HIP_CHECK(hipGetLastError());
+}
+
+void residual_assemble(const double* V, const double* L, const double* N, const double* D, const double* X, double* R,
+                       int no, int nv, stream_t s) {
+    if (!fused_pair_kernels_ok(no)) throw std::runtime_error("residual_assemble: nocc too large for the LDS tile");
+    const size_t lds = sizeof(double) * no * (no + 1);
+    hipLaunchKernelGGL(residual_assemble_kernel, dim3((unsigned)((long)nv * (nv + 1) / 2)), dim3(256), lds, (hipStream_t)s,
+                       V, L, N, D, X, R, no, nv);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -170,6 +170,11 @@ void ladder_pack_T(const double* T, const double* t1, double* Sp, double* Am, in
     if (!ldp) ldp = opp;
     if (!ldm) ldm = pcol ? opp : opm;
     for (int c = 0; c < nv; ++c)
+        for (int d = 0; d <= c; ++d) {
+            if (ldp > opp) Sp[P2(c, d) * ldp + opp] = 0.0;
+            if ((prow || c > d) && ldm > (pcol ? opp : opm)) Am[(prow ? P2(c, d) : Q2(c, d)) * ldm + (pcol ? opp : opm)] = 0.0;
+        }
+    for (int c = 0; c < nv; ++c)
         for (int d = 0; d <= c; ++d)
             for (int i = 0; i < no; ++i)
                 for (int j = 0; j <= i; ++j) {
@@ -189,6 +194,43 @@ void ladder_pack_T(const double* T, const double* t1, double* Sp, double* Am, in
                     if ((prow || c > d) && (pcol || i > j))
                         Am[(prow ? P2(c, d) : Q2(c, d)) * ldm + (pcol ? P2(i, j) : Q2(i, j))] =
                             (c > d && i > j) ? 0.5 * (x1 - x2) : 0.0;
+                }
+}
+
+bool fused_pair_kernels_ok(int no) { return no <= 3; }   // small, so that the tests reach both code paths
+
+void t2_layouts(const double* T, double* Td, double* Tx, double* Ttd, int no, int nv, stream_t) {
+    const int64_t o2 = (int64_t)no * no, ov = (int64_t)no * nv;
+    for (int a = 0; a < nv; ++a)
+        for (int b = 0; b < nv; ++b)
+            for (int i = 0; i < no; ++i)
+                for (int j = 0; j < no; ++j) {
+                    const double x = T[((int64_t)a * nv + b) * o2 + i * no + j];
+                    const double y = T[((int64_t)b * nv + a) * o2 + i * no + j];
+                    Td[((int64_t)a * no + i) * ov + b * no + j] = x;
+                    Tx[((int64_t)a * no + j) * ov + b * no + i] = x;
+                    Ttd[((int64_t)a * no + i) * ov + b * no + j] = 2.0 * x - y;
+                }
+}
+
+void residual_assemble(const double* V, const double* L, const double* N, const double* D, const double* X, double* R,
+                       int no, int nv, stream_t) {
+    const int64_t o2 = (int64_t)no * no, ov = (int64_t)no * nv, opp = (int64_t)no * (no + 1) / 2;
+    auto pm = [&](const double* M, int a, int i, int b, int j) { return M[((int64_t)a * no + i) * ov + b * no + j]; };
+    for (int a = 0; a < nv; ++a)
+        for (int b = 0; b < nv; ++b)
+            for (int i = 0; i < no; ++i)
+                for (int j = 0; j < no; ++j) {
+                    const int64_t e = ((int64_t)a * nv + b) * o2 + i * no + j;
+                    double v = V[e] + N[e] + N[((int64_t)b * nv + a) * o2 + j * no + i] + pm(D, a, i, b, j) +
+                               pm(D, b, j, a, i) + pm(X, a, j, b, i) + pm(X, b, i, a, j);
+                    if (L) {
+                        const int ah = a > b ? a : b, al = a > b ? b : a, ih = i > j ? i : j, il = i > j ? j : i;
+                        const double* row = L + P2(ah, al) * o2;
+                        v += row[P2(ih, il)];
+                        if (a != b && i != j) v += (((a > b) == (i > j)) ? 1.0 : -1.0) * row[opp + Q2(ih, il)];
+                    }
+                    R[e] = v;
                 }
 }
 
