@@ -39,6 +39,10 @@ double* Engine::get_static(const std::string& key) {
     else if (key == "Vx") permute(1.0, Vijab, "klcd", 0.0, make_view(p, {v, o, v, o}), "cldk");   // [(c,l),(d,k)]
     else if (key == "Vk") permute(1.0, Vijab, "lkdc", 0.0, make_view(p, {o, v, o, v}), "kdlc");   // [(k,d,l),c]
     else if (key == "Vk2") permute(1.0, Vijab, "lkdc", 0.0, make_view(p, {o, v, v, o}), "kcdl");  // [k,(c,d,l)]
+    // K-major copies for the o x o results contracted over o v^2 (K = 2e6 at the benchmark size): with the long index
+    // slowest both GEMM operands stream contiguously instead of gathering 128-byte pieces of 50 distant rows
+    else if (key == "Vk3") permute(1.0, Vijab, "lkdc", 0.0, make_view(p, {v, v, o, o}), "cdlk");  // [(c,d,l),k]
+    else if (key == "Vjbck") permute(1.0, Vijab, "kjbc", 0.0, make_view(p, {o, v, v, o}), "jbck"); // [(j,b,c),k]
     else if (key == "Edir") permute(1.0, Vijab, "ijab", 0.0, make_view(p, {v, v, o, o}), "abij"); // V[i,j,a,b]
     else if (key == "Eex") permute(1.0, Vijab, "ijba", 0.0, make_view(p, {v, v, o, o}), "abij");  // V[i,j,b,a]
     else throw Error("unknown static tensor " + key);
@@ -293,9 +297,9 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
         TView Foo = slice(slice(F, 0, 0, o), 1, 0, o);
         TView Xoo = make_view(arena.alloc(o * o), {o, o});
         copy(Foo, Xoo);
-        TView Tp = make_view(arena.alloc(o * o * v * v), {o, v, v, o});
-        permute(1.0, make_view(Ttd.p, {v, o, v, o}), "cidl", 0.0, Tp, "icdl");
-        contract(w, make_view(get_static("Vk2"), {o, v, v, o}), "kcdl", Tp, "icdl", 1.0, Xoo, "ki");   // :215-220
+        TView Tp = make_view(arena.alloc(o * o * v * v), {v, v, o, o});
+        permute(1.0, make_view(Ttd.p, {v, o, v, o}), "cidl", 0.0, Tp, "cdli");
+        contract(w, make_view(get_static("Vk3"), {v, v, o, o}), "cdlk", Tp, "cdli", 1.0, Xoo, "ki");   // :215-220
         TView Trows = make_view(Td.p + c0 * ov, {nc, v, o});
         TView Erows = make_view(ETd.p, {nc, v, o});
         contract(-1.0, Trows, "nak", Xoo, "ki", 1.0, Erows, "nai");
@@ -733,7 +737,7 @@ void Engine::singles_residual(const double* fd, const double* t1, const double* 
     contract(1.0, Tq, "aibj", Dov, "jb", 1.0, R, "ai");                                      // :432
     contract(1.0, block(P_aibc), "ajbc", P1, "jbci", 1.0, R, "ai");                          // :433
     TView S2 = make_view(arena.alloc(o * o), {o, o});
-    contract(1.0, block(P_ijab), "kjbc", P1, "jbci", 0.0, S2, "ki");
+    contract(1.0, make_view(get_static("Vjbck"), {o, v, v, o}), "jbck", P1, "jbci", 0.0, S2, "ki");
     contract(-1.0, t, "ak", S2, "ki", 1.0, R, "ai");                                         // :434
     contract(-1.0, Tq, "ajbk", block(P_ijka), "jkib", 1.0, R, "ai");                         // :435
     TView S4 = make_view(arena.alloc(v * v), {v, v});

@@ -600,17 +600,26 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmK g, int B
     double* C = g.C + z1 * g.c_b1 + z2 * g.c_b2;
     const double* Cin = g.Cin + z1 * g.c_b1 + z2 * g.c_b2;
     const double* __restrict__ W = g.ws + lt * g.nsplit * (long)(BM * BN);
-    for (int e = threadIdx.x; e < BM * BN; e += blockDim.x) {
-        const int r = e / BN, c = e - r * BN;
-        const int m = tm * BM + r, n = tn * BN + c;
-        if (m >= g.M || n >= g.N) continue;
-        double sum = 0.0;
-        for (int k = 0; k < g.nsplit; ++k) sum += W[(long)k * (BM * BN) + e];
-        const long off = (long)m * g.ldc + n;
-        double v = g.alpha * sum;
-        if (g.beta != 0.0) v += g.beta * Cin[off];
-        C[off] = v;
+    // blockIdx.y cuts the tile into 256-element pieces: a launch with few tiles and many splits (huge K, tiny
+    // output) still spreads over the chip
+    const int e = blockIdx.y * 256 + threadIdx.x;
+    const int r = e / BN, c = e - r * BN;
+    const int m = tm * BM + r, n = tn * BN + c;
+    if (m >= g.M || n >= g.N) return;
+    const long st = (long)BM * BN;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = 0;
+    for (; k + 4 <= g.nsplit; k += 4) {
+        s0 += W[(long)k * st + e];
+        s1 += W[(long)(k + 1) * st + e];
+        s2 += W[(long)(k + 2) * st + e];
+        s3 += W[(long)(k + 3) * st + e];
     }
+    for (; k < g.nsplit; ++k) s0 += W[(long)k * st + e];
+    const long off = (long)m * g.ldc + n;
+    double v = g.alpha * ((s0 + s1) + (s2 + s3));
+    if (g.beta != 0.0) v += g.beta * Cin[off];
+    C[off] = v;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1350,7 +1359,7 @@ void gemm(const Gemm& g, stream_t s) {
         else if (BM == 64 && BN == 128) dispatch_layout<64, 128>(k, a_kcontig, b_kcontig, vec, nblocks, st);
         else dispatch_layout<64, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
         if (k.nsplit > 1) {
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ntiles), dim3(256), 0, st, k, BM, BN);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ntiles, (unsigned)(BM * BN / 256)), dim3(256), 0, st, k, BM, BN);
             HIP_CHECK(hipGetLastError());
         }
         return k.nsplit;
