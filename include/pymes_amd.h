@@ -168,10 +168,13 @@ int pymes_lincomb(pymes_ctx* ctx, double* out_dev, int nx, const double* const* 
  * (2*M*N*K*batch), permutation launches, bytes moved by explicit permutations */
 int pymes_stats(pymes_ctx* ctx, int reset, int64_t* gemm_calls, double* gemm_flops, int64_t* permute_calls,
                 double* permute_bytes);
-/* HIP-event timing of every fp64 GEMM launch on the context's stream (off by default) */
+/* HIP-event timing of every fp64 GEMM call on the context's stream (off by default).  kernel_class 0 = all
+ * calls, 1 = the calls that ran on the LDS-DMA 128x128 MFMA kernel (the o^3v^3 / ladder products);
+ * kernel_launches counts GEMM kernel launches (a call whose last tiles are k-split launches twice). */
 int pymes_prof_enable(pymes_ctx* ctx, int on);
 int pymes_prof_reset(pymes_ctx* ctx);
-int pymes_prof_query(pymes_ctx* ctx, int64_t* launches, double* total_ms, double* flops);
+int pymes_prof_query(pymes_ctx* ctx, int kernel_class, int64_t* calls, int64_t* kernel_launches, double* total_ms,
+                     double* flops);
 
 #ifdef __cplusplus
 }

@@ -68,7 +68,7 @@ SIGNATURES = {
     "pymes_stats": (C.c_int, [C.c_void_p, C.c_int, c_i64_p, c_double_p, c_i64_p, c_double_p]),
     "pymes_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "pymes_prof_reset": (C.c_int, [C.c_void_p]),
-    "pymes_prof_query": (C.c_int, [C.c_void_p, c_i64_p, c_double_p, c_double_p]),
+    "pymes_prof_query": (C.c_int, [C.c_void_p, C.c_int, c_i64_p, c_i64_p, c_double_p, c_double_p]),
 }
 
 PYMES_DCD, PYMES_USE_DRESSED, PYMES_SKIP_LADDER, PYMES_SYM_LADDER, PYMES_SYM_RINGS = 1, 2, 4, 8, 16

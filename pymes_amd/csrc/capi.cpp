@@ -340,13 +340,16 @@ int pymes_prof_reset(pymes_ctx* ctx) {
         dev::prof_reset();
     });
 }
-int pymes_prof_query(pymes_ctx* ctx, int64_t* launches, double* ms, double* flops) {
+int pymes_prof_query(pymes_ctx* ctx, int kernel_class, int64_t* calls, int64_t* kernel_launches, double* ms,
+                     double* flops) {
     return guarded([&] {
         E(ctx);
-        long l = 0;
+        if (kernel_class != 0 && kernel_class != 1) throw pymes::Error("prof_query: kernel_class must be 0 or 1");
+        long c = 0, l = 0;
         double m = 0, f = 0;
-        dev::prof_query(&l, &m, &f);
-        if (launches) *launches = l;
+        dev::prof_query(kernel_class, &c, &l, &m, &f);
+        if (calls) *calls = c;
+        if (kernel_launches) *kernel_launches = l;
         if (ms) *ms = m;
         if (flops) *flops = f;
     });

@@ -29,7 +29,8 @@ size_t mem_free_bytes();
 void   prof_enable(bool on);
 void   prof_reset();
 // number of GEMM launches recorded, summed milliseconds, summed executed flops
-void   prof_query(long* launches, double* ms, double* flops);
+// kernel_class 0: every fp64 GEMM call; 1: only the calls that ran on the LDS-DMA 128x128 kernel
+void   prof_query(int kernel_class, long* calls, long* kernel_launches, double* ms, double* flops);
 
 // ---- fp64 GEMM  C = alpha * A * B + beta * C ---------------------------------
 // A(m,k) = A[z] + m*a_sm + k*a_sk   with exactly one of a_sm / a_sk equal to 1

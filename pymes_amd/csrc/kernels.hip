@@ -1112,7 +1112,10 @@ struct Prof {
     bool on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
-    std::vector<std::string> what;   // one description per recorded launch
+    std::vector<std::string> what;   // one description per recorded GEMM call
+    std::vector<double> fl;          // its flops
+    std::vector<int> klass;          // 1: ran on the LDS-DMA 128x128 kernel
+    std::vector<int> nk;             // GEMM kernel launches of the call (2 with a k-split tail)
     double flops = 0.0;
 } g_prof;
 
@@ -1152,7 +1155,7 @@ void launch_gemm_glds(const GemmK& k, long nblocks, hipStream_t st) {
 }
 
 template <int BM, int BN>
-void dispatch_layout(const GemmK& k, bool akc, bool bkc, int vec, long nblocks, hipStream_t st) {
+bool dispatch_layout(const GemmK& k, bool akc, bool bkc, int vec, long nblocks, hipStream_t st) {   // true: LDS-DMA kernel
     // the LDS-DMA kernel addresses a tile as uniform base + 32-bit byte offset per lane
     const bool off32 = (akc ? 128 : 16) * k.a_ld * 8 + 4096 < (1L << 32) && (bkc ? 128 : 16) * k.b_ld * 8 + 4096 < (1L << 32);
     // ... and pays off from about 64 k-tiles per block on (measured: below that the register-staged kernel wins)
@@ -1161,7 +1164,7 @@ void dispatch_layout(const GemmK& k, bool akc, bool bkc, int vec, long nblocks, 
         else if (akc) launch_gemm_glds<true, false>(k, nblocks, st);
         else if (bkc) launch_gemm_glds<false, true>(k, nblocks, st);
         else launch_gemm_glds<false, false>(k, nblocks, st);
-        return;
+        return true;
     }
     if (vec == 2) {
         if (akc && bkc) launch_gemm<BM, BN, true, true, 2>(k, nblocks, st);
@@ -1174,6 +1177,7 @@ void dispatch_layout(const GemmK& k, bool akc, bool bkc, int vec, long nblocks, 
         else if (bkc) launch_gemm<BM, BN, false, true, 1>(k, nblocks, st);
         else launch_gemm<BM, BN, false, false, 1>(k, nblocks, st);
     }
+    return false;
 }
 
 inline bool even(long x) { return (x & 1) == 0; }
@@ -1219,25 +1223,34 @@ void prof_reset() {
     for (auto& e : g_prof.ev) g_prof.pool.push_back(e);
     g_prof.ev.clear();
     g_prof.what.clear();
+    g_prof.fl.clear();
+    g_prof.klass.clear();
+    g_prof.nk.clear();
     g_prof.flops = 0.0;
 }
-void prof_query(long* launches, double* ms, double* flops) {
-    double tot = 0.0;
-    // PYMES_GEMM_LOG=<file>: one line per GEMM launch (shape, tile, time) for tuning
+void prof_query(int kernel_class, long* calls, long* kernel_launches, double* ms, double* flops) {
+    double tot = 0.0, fl = 0.0;
+    long nc = 0, nk = 0;
+    // PYMES_GEMM_LOG=<file>: one line per GEMM call (shape, tile, time) for tuning
     const char* logp = getenv("PYMES_GEMM_LOG");
-    FILE* lf = logp ? fopen(logp, "a") : nullptr;
+    FILE* lf = (logp && kernel_class == 0) ? fopen(logp, "a") : nullptr;
     for (size_t i = 0; i < g_prof.ev.size(); ++i) {
         auto& e = g_prof.ev[i];
         HIP_CHECK(hipEventSynchronize(e.second));
         float t = 0.f;
         HIP_CHECK(hipEventElapsedTime(&t, e.first, e.second));
-        tot += t;
         if (lf) fprintf(lf, "%s ms=%.4f\n", g_prof.what[i].c_str(), t);
+        if (kernel_class == 1 && g_prof.klass[i] != 1) continue;
+        tot += t;
+        fl += g_prof.fl[i];
+        nc += 1;
+        nk += g_prof.nk[i];
     }
     if (lf) { fprintf(lf, "----\n"); fclose(lf); }
-    *launches = (long)g_prof.ev.size();
+    *calls = nc;
+    *kernel_launches = nk;
     *ms = tot;
-    *flops = g_prof.flops;
+    *flops = fl;
 }
 
 void gemm(const Gemm& g, stream_t s) {
@@ -1347,6 +1360,8 @@ void gemm(const Gemm& g, stream_t s) {
         }
         HIP_CHECK(hipEventRecord(ev.first, st));
     }
+    bool used_dma = false;
+    int n_kernels = 0;
     auto launch = [&](long tile_begin, long ntiles, int nsplit) {
         const long kt_per = (ktiles + nsplit - 1) / nsplit;
         k.kchunk = (int)std::max<long>(kt_per * BK, BK);
@@ -1354,10 +1369,17 @@ void gemm(const Gemm& g, stream_t s) {
         k.tile_begin = tile_begin;
         k.ws = k.nsplit > 1 ? g.splitk_ws : nullptr;
         const long nblocks = ntiles * k.nsplit;
-        if (BM == 128 && BN == 128) dispatch_layout<128, 128>(k, a_kcontig, b_kcontig, vec, nblocks, st);
-        else if (BM == 128 && BN == 64) dispatch_layout<128, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
-        else if (BM == 64 && BN == 128) dispatch_layout<64, 128>(k, a_kcontig, b_kcontig, vec, nblocks, st);
-        else dispatch_layout<64, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
+        if (BM == 128 && BN == 128) {
+            const bool dma = dispatch_layout<128, 128>(k, a_kcontig, b_kcontig, vec, nblocks, st);
+            used_dma |= dma;
+            n_kernels += used_dma ? (dma ? 1 : 0) : 1;      // a DMA call reports its DMA launches only
+        }
+        else {
+            ++n_kernels;
+            if (BM == 128 && BN == 64) dispatch_layout<128, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
+            else if (BM == 64 && BN == 128) dispatch_layout<64, 128>(k, a_kcontig, b_kcontig, vec, nblocks, st);
+            else dispatch_layout<64, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
+        }
         if (k.nsplit > 1) {
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ntiles, (unsigned)(BM * BN / 256)), dim3(256), 0, st, k, BM, BN);
             HIP_CHECK(hipGetLastError());
@@ -1371,9 +1393,13 @@ void gemm(const Gemm& g, stream_t s) {
         g_prof.ev.push_back(ev);
         const double fl = 2.0 * (double)g.M * (double)g.N * (double)g.K * (double)nbatch;
         g_prof.flops += fl;
+        g_prof.fl.push_back(fl);
+        g_prof.klass.push_back(used_dma ? 1 : 0);
+        g_prof.nk.push_back(n_kernels);
         char buf[256];
-        snprintf(buf, sizeof buf, "M=%ld N=%ld K=%ld batch=%ld tile=%dx%d akc=%d bkc=%d vec=%d split=%d flops=%.4e",
-                 (long)g.M, (long)g.N, (long)g.K, (long)nbatch, BM, BN, (int)a_kcontig, (int)b_kcontig, vec, nsplit, fl);
+        snprintf(buf, sizeof buf, "M=%ld N=%ld K=%ld batch=%ld tile=%dx%d akc=%d bkc=%d vec=%d dma=%d split=%d flops=%.4e",
+                 (long)g.M, (long)g.N, (long)g.K, (long)nbatch, BM, BN, (int)a_kcontig, (int)b_kcontig, vec, (int)used_dma,
+                 nsplit, fl);
         g_prof.what.push_back(buf);
     }
 }

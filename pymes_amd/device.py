@@ -352,10 +352,12 @@ class Context:
     def prof_reset(self):
         self.lib.call("pymes_prof_reset", self.handle)
 
-    def prof_query(self):
-        n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
-        self.lib.call("pymes_prof_query", self.handle, C.byref(n), C.byref(ms), C.byref(fl))
-        return {"launches": n.value, "ms": ms.value, "flops": fl.value}
+    def prof_query(self, kernel_class=0):
+        """HIP-event totals of the fp64 GEMM calls since prof_reset (kernel_class 1: LDS-DMA kernel only)."""
+        n, nk, ms, fl = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
+        self.lib.call("pymes_prof_query", self.handle, int(kernel_class), C.byref(n), C.byref(nk), C.byref(ms),
+                      C.byref(fl))
+        return {"launches": n.value, "kernel_launches": nk.value, "ms": ms.value, "flops": fl.value}
 
 
 __all__ = ["Context", "DeviceArray", "PymesError", "BLOCK_NAMES", "pattern_of"]

@@ -39,7 +39,7 @@ static double g_flops = 0;
 static bool g_prof = false;
 void prof_enable(bool on) { g_prof = on; }
 void prof_reset() { g_launches = 0; g_flops = 0; }
-void prof_query(long* l, double* ms, double* f) { *l = g_launches; *ms = 0.0; *f = g_flops; }
+void prof_query(int, long* l, long* nk, double* ms, double* f) { *l = g_launches; *nk = g_launches; *ms = 0.0; *f = g_flops; }
 
 void gemm(const Gemm& g, stream_t) {
     if (!((g.a_sm == 1 || g.a_sk == 1 || g.M == 1 || g.K == 1) && (g.b_sk == 1 || g.b_sn == 1 || g.N == 1 || g.K == 1)))
