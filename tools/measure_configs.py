@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""The other measurement rows of SURVEY.md 8(d), each next to a CPU time of the oracle (test infrastructure) on a
+bounded sample: C2 CCSD iteration at (20,80), C4 UEG N=14 / 57 plane waves (TC integrals on the device + one DCSD
+iteration), C5 one EOM-CCSD sigma build at (30,120).  One JSON object per line on stdout.
+
+    python3 tools/measure_configs.py [--skip-cpu]     (needs the GPU; bench.py stays the headline measurement)
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def timed(fn, sync, reps):
+    fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / reps
+
+
+def c2(args):
+    from pymes_amd.integral.device import DeviceIntegrals
+    from pymes_amd.model import synthetic
+    from pymes_amd.solver.ccsd import CCSD
+    from oracle.baseline import algorithmic_fma
+    no, nv = 20, 80
+    B, eps = synthetic.factors(no, nv, seed=0, scale=0.15)
+    ints = DeviceIntegrals.from_factors(no, B)
+    solver = CCSD(no)
+    st = quiet(solver.setup, np.diag(eps), ints)
+    dt = timed(lambda: quiet(solver.iterate, st), ints.ctx.sync, 20)
+    o, v = float(no), float(nv)
+    flops = 2.0 * (algorithmic_fma(no, nv, False) + 5 * o * v**4 + 28 * o**2 * v**3 + 2 * o**2 * v**3 + 2 * o**3 * v**2)
+    out = {"config": "C2 CCSD iteration, synthetic (nocc=20, nvirt=80, scale 0.15)", "gpu_s": dt,
+           "reference_algorithmic_flops": flops, "algorithmic_tflops": flops / dt / 1e12}
+    if not args.skip_cpu:
+        from oracle import cc_oracle as oc
+        from oracle.cases import synthetic_case
+        so, sv = 10, 40                                     # bounded sample: flops scale as the closed form above
+        f, V, _, _ = synthetic_case(so, sv, seed=0, scale=0.15)
+        rs_ = np.random.default_rng(1)
+        t1, t2 = 0.05 * rs_.standard_normal((sv, so)), 0.05 * rs_.standard_normal((sv, sv, so, so))
+        Vb = oc.split_blocks(so, V)
+        t0 = time.perf_counter()
+        fd = oc.dressed_fock(so, f, t1, Vb)
+        Vd = oc.dressed_V(t1, Vb)
+        oc.singles_residual(so, fd, t1, t2, Vb)
+        oc.ccsd_doubles_residual(so, fd, t2, Vd)
+        cpu = time.perf_counter() - t0
+        so_, sv_ = float(so), float(sv)
+        sfl = 2.0 * (algorithmic_fma(so, sv, False) + 5 * so_ * sv_**4 + 28 * so_**2 * sv_**3 + 2 * so_**2 * sv_**3 +
+                     2 * so_**3 * sv_**2)
+        out["cpu_baseline"] = {"value": cpu * flops / sfl, "unit": "s", "cores": 1, "kind": "port",
+                               "sample": f"oracle residuals + dressing at ({so},{sv}) in {cpu:.2f} s, scaled by the "
+                                         "algorithmic-flop ratio"}
+    ints.ctx.close()
+    return out
+
+
+def c4(args):
+    from pymes_amd.model.ueg import UEG
+    from pymes_amd.solver.ccsd import CCSD
+    from pymes_amd.integral.device import DeviceIntegrals
+    from tests.test_ueg import tc_problem
+    nel, rs, cutoff = 14, 1.0, 5
+    m = UEG(nel, nel // 2, nel // 2, rs)
+    m.init_single_basis(cutoff)
+    n_pw = len(m.basis_fns) // 2
+    kc = m.L / (2 * np.pi) * 2.3225029893472993 / rs       # test_ccd_dcd.py:99
+    t0 = time.perf_counter()
+    no, V, f, e_hf, d2, e3, eps_i, eps_a = tc_problem(UEG, nel, rs, cutoff, kc)
+    t_int = time.perf_counter() - t0
+    ints = DeviceIntegrals.from_V_pqrs(no, V)
+    solver = CCSD(no, is_dcsd=True)
+    st = quiet(solver.setup, f, ints)
+    dt = timed(lambda: quiet(solver.iterate, st), ints.ctx.sync, 20)
+    out = {"config": f"C4 UEG N=14 rs=1.0 cutoff=5 ({n_pw} plane waves): TC integrals + DCSD iteration",
+           "gpu_integrals_s": t_int, "gpu_iteration_s": dt,
+           "note": "integrals = eval_2b_integrals(only_2b) + eval_2b_integrals(effect_2b) + HF + 3-body contractions, "
+                   "device kernels + host glue, download included"}
+    if not args.skip_cpu:
+        from oracle.ueg_oracle import Ueg
+        from oracle import cc_oracle as oc
+        u = Ueg(nel, rs)
+        u.init_basis(cutoff)
+        u.k_cutoff = kc
+        t0 = time.perf_counter()
+        u.two_body("only_2b")
+        t_2b = time.perf_counter() - t0
+        Vb = oc.split_blocks(no, V)
+        t2 = oc.mp2(f.diagonal()[:no], f.diagonal()[no:], Vb["ijab"], Vb["abij"])[1]
+        t0 = time.perf_counter()
+        oc.ccsd_doubles_residual(no, f, t2, Vb, is_dcsd=True)
+        cpu_it = time.perf_counter() - t0
+        out["cpu_baseline"] = {"integrals_only_2b_s": t_2b, "dcsd_doubles_residual_s": cpu_it, "cores": 1,
+                               "kind": "port", "sample": "oracle two_body('only_2b') (vectorised numpy; the reference's "
+                               "Python loops took 53.6 s for this call in the survey container) and one oracle DCSD "
+                               "doubles residual at full size"}
+    ints.ctx.close()
+    return out
+
+
+def c5(args):
+    from pymes_amd.integral.device import DeviceIntegrals
+    from pymes_amd.model import synthetic
+    from pymes_amd.solver.eom_ccsd import _Sigma
+    no, nv = 30, 120
+    B, eps = synthetic.factors(no, nv, seed=0)
+    ints = DeviceIntegrals.from_factors(no, B)
+    ctx = ints.ctx
+    t2 = ctx.empty((nv, nv, no, no))
+    ctx.mp2(t2, 0.0)
+    f = np.diag(eps)
+    t0 = time.perf_counter()
+    sig = _Sigma(ctx, f, t2)
+    ctx.sync()
+    t_hoist = time.perf_counter() - t0
+    rng = np.random.default_rng(0)
+    u1 = ctx.array(rng.standard_normal((nv, no)))
+    u2 = ctx.array(rng.standard_normal((nv, nv, no, no)))
+    dt = timed(lambda: sig.apply(u1, u2), ctx.sync, 5)
+    flops = 2.0 * (6.4e9 + 1.502e12)
+    out = {"config": "C5 one EOM-CCSD sigma build (singles + doubles), synthetic (nocc=30, nvirt=120)", "gpu_s": dt,
+           "hoisted_intermediates_once_per_solve_s": t_hoist, "reference_algorithmic_flops": flops,
+           "algorithmic_tflops": flops / dt / 1e12}
+    if not args.skip_cpu:
+        from oracle import eom_oracle as eo, cc_oracle as oc
+        from oracle.cases import synthetic_case
+        so, sv = 12, 48
+        fs, V, _, _ = synthetic_case(so, sv, seed=0)
+        t2s = 0.05 * rng.standard_normal((sv, sv, so, so))
+        Vb = oc.split_blocks(so, V)
+        u1s, u2s = rng.standard_normal((sv, so)), rng.standard_normal((sv, sv, so, so))
+        t0 = time.perf_counter()
+        eo.sigma_singles(so, fs, Vb, u1s, u2s, t2s)
+        eo.sigma_doubles(so, fs, Vb, u1s, u2s, t2s)
+        cpu = time.perf_counter() - t0
+        # leading terms o^2 v^4 (ladder) + o^3 v^3 (40 three-operand terms contracted pairwise)
+        scale = (30.0**2 * 120.0**4 + 20 * 30.0**3 * 120.0**3) / (so**2 * sv**4 + 20 * so**3 * sv**3)
+        out["cpu_baseline"] = {"value": cpu * scale, "unit": "s", "cores": 1, "kind": "port",
+                               "sample": f"oracle sigma (np.einsum optimize=True per term) at ({so},{sv}) in {cpu:.2f} s, "
+                                         "scaled by o^2v^4 + 20 o^3v^3"}
+    ctx.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--only", default="c2,c4,c5")
+    args = ap.parse_args()
+    for name in args.only.split(","):
+        print(json.dumps({"c2": c2, "c4": c4, "c5": c5}[name](args)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
