@@ -163,6 +163,18 @@ int pymes_dots(pymes_ctx* ctx, int npairs, const double* const* x_dev, const dou
 int pymes_lincomb(pymes_ctx* ctx, double* out_dev, int nx, const double* const* x_dev, const double* c_host,
                   int64_t n);
 
+/* ---- explicit 3-body (transcorrelated) operator ---------------------------------------
+ * pymes/util/tcdump.py:52-56: dense fill of L[nb]^6 from (flat index, value) pairs — the host parser hands over
+ * unique targets (the last of duplicate entries, as the reference's sequential assignment keeps). */
+int pymes_scatter(pymes_ctx* ctx, double* dst_dev, uint64_t dst_elements, const int64_t* index_host,
+                  const double* value_host, int64_t n);
+/* pymes/integral/contraction.py:17-39 get_single_contraction -> D[p,r,q,s] ([nb]^4 on the device),
+ * :41-65 get_double_contraction -> S[p,q], :67-95 get_triple_contraction -> scalar.
+ * L_dev is [nb]^6 in the chemists' order (or|ps|qt) that tcdump.read returns. */
+int pymes_tc_single_contraction(pymes_ctx* ctx, const double* L_dev, int nb, int no, double* D_dev);
+int pymes_tc_double_contraction(pymes_ctx* ctx, const double* L_dev, int nb, int no, double* S_dev);
+int pymes_tc_triple_contraction(pymes_ctx* ctx, const double* L_dev, int nb, int no, double* t0_host);
+
 /* ---- measurement --------------------------------------------------------------------- */
 /* executed-work counters since the last reset: GEMM launches, executed GEMM flops
  * (2*M*N*K*batch), permutation launches, bytes moved by explicit permutations */

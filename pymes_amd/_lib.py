@@ -63,6 +63,10 @@ SIGNATURES = {
     "pymes_ccd_energy": (C.c_int, [C.c_void_p, C.c_void_p, c_double_p]),
     "pymes_ueg_eval_2b": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                     C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pymes_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, c_i64_p, c_double_p, C.c_int64]),
+    "pymes_tc_single_contraction": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "pymes_tc_double_contraction": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "pymes_tc_triple_contraction": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, c_double_p]),
     "pymes_dots": (C.c_int, [C.c_void_p, C.c_int, c_pp, c_pp, C.c_int64, c_double_p]),
     "pymes_lincomb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_pp, c_double_p, C.c_int64]),
     "pymes_stats": (C.c_int, [C.c_void_p, C.c_int, c_i64_p, c_double_p, c_i64_p, c_double_p]),

@@ -328,6 +328,38 @@ int pymes_stats(pymes_ctx* ctx, int reset, int64_t* gemm_calls, double* gemm_flo
         if (reset) e.stats = pymes::ContractStats{};
     });
 }
+int pymes_scatter(pymes_ctx* ctx, double* dst, uint64_t dst_elements, const int64_t* index_host,
+                  const double* value_host, int64_t n) {
+    return guarded([&] {
+        need(dst, "dst");
+        if (n > 0) { need(index_host, "index"); need(value_host, "value"); }
+        for (int64_t t = 0; t < n; ++t)
+            if (index_host[t] < 0 || (uint64_t)index_host[t] >= dst_elements) throw pymes::Error("scatter: index out of range");
+        dev::scatter(dst, index_host, value_host, n, E(ctx).stream);
+    });
+}
+int pymes_tc_single_contraction(pymes_ctx* ctx, const double* L, int nb, int no, double* D) {
+    return guarded([&] {
+        need(L, "L"); need(D, "D");
+        if (nb <= 0 || no < 0 || no > nb) throw pymes::Error("tc contraction: bad nb/no");
+        dev::tc_single_contraction(L, D, nb, no, E(ctx).stream);
+    });
+}
+int pymes_tc_double_contraction(pymes_ctx* ctx, const double* L, int nb, int no, double* S) {
+    return guarded([&] {
+        need(L, "L"); need(S, "S");
+        if (nb <= 0 || no < 0 || no > nb) throw pymes::Error("tc contraction: bad nb/no");
+        dev::tc_double_contraction(L, S, nb, no, E(ctx).stream);
+    });
+}
+int pymes_tc_triple_contraction(pymes_ctx* ctx, const double* L, int nb, int no, double* t0_host) {
+    return guarded([&] {
+        need(L, "L"); need(t0_host, "t0");
+        if (nb <= 0 || no < 0 || no > nb) throw pymes::Error("tc contraction: bad nb/no");
+        *t0_host = dev::tc_triple_contraction(L, nb, no, E(ctx).stream);
+    });
+}
+
 int pymes_prof_enable(pymes_ctx* ctx, int on) {
     return guarded([&] {
         E(ctx);

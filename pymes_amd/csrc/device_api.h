@@ -109,6 +109,13 @@ void residual_assemble(const double* V, const double* L, const double* N, const 
 // plain rows of the same [ S | A ] layout: out[r][i][j] = Q[r][P(i,j)] + sgn(i-j) Q[r][o(o+1)/2 + Q(i,j)]
 void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t s);
 
+// ---- explicit 3-body (transcorrelated) operator: pymes/util/tcdump.py:52-56, pymes/integral/contraction.py:17-95 ----
+// dst[idx[t]] = val[t] for t < n (host index/value lists, unique targets); L below is dense [nb]^6, (or|ps|qt) order
+void scatter(double* dst, const int64_t* idx_host, const double* val_host, int64_t n, stream_t s);
+void tc_single_contraction(const double* L, double* D, int nb, int no, stream_t s);   // D[p,r,q,s]
+void tc_double_contraction(const double* L, double* S, int nb, int no, stream_t s);   // S[p,q]
+double tc_triple_contraction(const double* L, int nb, int no, stream_t s);
+
 // ---- 3D uniform electron gas two-body integrals (pymes/model/ueg.py:265-516) ------------------
 // V[p,q,r,s] (dense [n_p]^4, zero where momentum is not conserved) for the plane-wave basis
 // k_int[n_p][3] (sorted by kinetic energy) and its lookup table index_map[(2 imax + 1)^3].

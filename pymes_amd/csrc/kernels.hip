@@ -993,6 +993,66 @@ __global__ void rows_unpack_kernel(const double* __restrict__ Q, double* __restr
 }
 
 // ------------------------------------------------------------------------------------
+// explicit 3-body operator: TCDUMP scatter (tcdump.py:52-56) and its mean-field foldings (contraction.py:17-95)
+// L is dense [nb]^6 in chemists' order (or|ps|qt)
+// ------------------------------------------------------------------------------------
+__global__ void scatter_kernel(double* __restrict__ dst, const long* __restrict__ idx, const double* __restrict__ val,
+                               long n) {
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
+        dst[idx[t]] = val[t];                        // targets are unique (the host keeps the last of duplicates)
+}
+
+__device__ __forceinline__ double L6(const double* __restrict__ L, int nb, int a, int b, int c, int d, int e, int f) {
+    return L[((((long)a * nb + b) * nb + c) * nb + d) * nb * nb + (long)e * nb + f];
+}
+
+// D[p,r,q,s] = -1/3 { -3 sum_i (L[p,q,r,i,i,s] + L[r,s,p,i,i,q]) + 6 sum_i L[p,q,r,s,i,i] }     (contraction.py:17-39)
+__global__ void tc_single_kernel(const double* __restrict__ L, double* __restrict__ D, int nb, int no, long total) {
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        long x = t;
+        const int s = (int)(x % nb); x /= nb;
+        const int q = (int)(x % nb); x /= nb;
+        const int r = (int)(x % nb);
+        const int p = (int)(x / nb);
+        double acc = 0.0;
+        for (int i = 0; i < no; ++i)
+            acc += -3.0 * (L6(L, nb, p, q, r, i, i, s) + L6(L, nb, r, s, p, i, i, q)) + 6.0 * L6(L, nb, p, q, r, s, i, i);
+        D[t] = -acc / 3.0;
+    }
+}
+
+// S[p,q] = -1/6 sum_ij { 12 L[i,i,j,j,p,q] - 12 L[i,i,p,j,j,q] + 6 L[p,i,j,q,i,j] - 6 L[i,j,j,i,p,q] }   (contraction.py:41-65)
+__global__ void tc_double_kernel(const double* __restrict__ L, double* __restrict__ S, int nb, int no) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nb * nb) return;
+    const int p = t / nb, q = t - p * nb;
+    double acc = 0.0;
+    for (int i = 0; i < no; ++i)
+        for (int j = 0; j < no; ++j)
+            acc += 12.0 * L6(L, nb, i, i, j, j, p, q) - 12.0 * L6(L, nb, i, i, p, j, j, q) +
+                   6.0 * L6(L, nb, p, i, j, q, i, j) - 6.0 * L6(L, nb, i, j, j, i, p, q);
+    S[t] = -acc / 6.0;
+}
+
+// T0 = -1/6 sum_ijk { 8 L[i,i,j,j,k,k] - 12 L[i,j,j,i,k,k] + 4 L[i,j,j,k,k,i] }       (contraction.py:67-95)
+__global__ void __launch_bounds__(256) tc_triple_kernel(const double* __restrict__ L, double* __restrict__ out, int nb, int no) {
+    __shared__ double sh[256];
+    double acc = 0.0;
+    const long n3 = (long)no * no * no;
+    for (long t = threadIdx.x; t < n3; t += blockDim.x) {
+        const int k = (int)(t % no), j = (int)((t / no) % no), i = (int)(t / ((long)no * no));
+        acc += 8.0 * L6(L, nb, i, i, j, j, k, k) - 12.0 * L6(L, nb, i, j, j, i, k, k) + 4.0 * L6(L, nb, i, j, j, k, k, i);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = -sh[0] / 6.0;
+}
+
+// ------------------------------------------------------------------------------------
 // uniform electron gas integrals (ueg.py:265-596)
 // ------------------------------------------------------------------------------------
 struct UegK {
@@ -1559,6 +1619,46 @@ void residual_assemble(const double* V, const double* L, const double* N, const 
     hipLaunchKernelGGL(residual_assemble_kernel, dim3((unsigned)((long)nv * (nv + 1) / 2)), dim3(256), lds, (hipStream_t)s,
                        V, L, N, D, X, R, no, nv);
     HIP_CHECK(hipGetLastError());
+}
+
+void scatter(double* dst, const int64_t* idx_host, const double* val_host, int64_t n, stream_t s) {
+    if (n <= 0) return;
+    long* idx = nullptr;
+    double* val = nullptr;
+    HIP_CHECK(hipMalloc(&idx, sizeof(long) * n));
+    if (hipMalloc(&val, sizeof(double) * n) != hipSuccess) { (void)hipFree(idx); throw std::runtime_error("scatter: out of device memory"); }
+    hipStream_t st = (hipStream_t)s;
+    HIP_CHECK(hipMemcpyAsync(idx, idx_host, sizeof(long) * n, hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipMemcpyAsync(val, val_host, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(scatter_kernel, dim3(grid_for(n)), dim3(256), 0, st, dst, idx, val, (long)n);
+    const hipError_t e = hipGetLastError();
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(idx);
+    (void)hipFree(val);
+    HIP_CHECK(e);
+}
+
+void tc_single_contraction(const double* L, double* D, int nb, int no, stream_t s) {
+    const long total = (long)nb * nb * nb * nb;
+    hipLaunchKernelGGL(tc_single_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, L, D, nb, no, total);
+    HIP_CHECK(hipGetLastError());
+}
+void tc_double_contraction(const double* L, double* S, int nb, int no, stream_t s) {
+    hipLaunchKernelGGL(tc_double_kernel, dim3((nb * nb + 255) / 256), dim3(256), 0, (hipStream_t)s, L, S, nb, no);
+    HIP_CHECK(hipGetLastError());
+}
+double tc_triple_contraction(const double* L, int nb, int no, stream_t s) {
+    double* out = nullptr;
+    HIP_CHECK(hipMalloc(&out, sizeof(double)));
+    hipLaunchKernelGGL(tc_triple_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, L, out, nb, no);
+    double h = 0.0;
+    const hipError_t e1 = hipGetLastError();
+    const hipError_t e2 = hipMemcpyAsync(&h, out, sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)s);
+    (void)hipStreamSynchronize((hipStream_t)s);
+    (void)hipFree(out);
+    HIP_CHECK(e1);
+    HIP_CHECK(e2);
+    return h;
 }
 
 void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t s) {

@@ -234,6 +234,45 @@ void residual_assemble(const double* V, const double* L, const double* N, const 
                 }
 }
 
+void scatter(double* dst, const int64_t* idx, const double* val, int64_t n, stream_t) {
+    for (int64_t t = 0; t < n; ++t) dst[idx[t]] = val[t];
+}
+namespace {
+inline double L6(const double* L, int nb, int a, int b, int c, int d, int e, int f) {
+    return L[((((int64_t)a * nb + b) * nb + c) * nb + d) * nb * nb + (int64_t)e * nb + f];
+}
+}  // namespace
+void tc_single_contraction(const double* L, double* D, int nb, int no, stream_t) {
+    for (int p = 0; p < nb; ++p)
+        for (int r = 0; r < nb; ++r)
+            for (int q = 0; q < nb; ++q)
+                for (int s = 0; s < nb; ++s) {
+                    double acc = 0.0;
+                    for (int i = 0; i < no; ++i)
+                        acc += -3.0 * (L6(L, nb, p, q, r, i, i, s) + L6(L, nb, r, s, p, i, i, q)) + 6.0 * L6(L, nb, p, q, r, s, i, i);
+                    D[(((int64_t)p * nb + r) * nb + q) * nb + s] = -acc / 3.0;
+                }
+}
+void tc_double_contraction(const double* L, double* S, int nb, int no, stream_t) {
+    for (int p = 0; p < nb; ++p)
+        for (int q = 0; q < nb; ++q) {
+            double acc = 0.0;
+            for (int i = 0; i < no; ++i)
+                for (int j = 0; j < no; ++j)
+                    acc += 12.0 * L6(L, nb, i, i, j, j, p, q) - 12.0 * L6(L, nb, i, i, p, j, j, q) +
+                           6.0 * L6(L, nb, p, i, j, q, i, j) - 6.0 * L6(L, nb, i, j, j, i, p, q);
+            S[p * nb + q] = -acc / 6.0;
+        }
+}
+double tc_triple_contraction(const double* L, int nb, int no, stream_t) {
+    double acc = 0.0;
+    for (int i = 0; i < no; ++i)
+        for (int j = 0; j < no; ++j)
+            for (int k = 0; k < no; ++k)
+                acc += 8.0 * L6(L, nb, i, i, j, j, k, k) - 12.0 * L6(L, nb, i, j, j, i, k, k) + 4.0 * L6(L, nb, i, j, j, k, k, i);
+    return -acc / 6.0;
+}
+
 void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t) {
     const int64_t opp = (int64_t)no * (no + 1) / 2, ld = (int64_t)no * no;
     for (int64_t r = 0; r < rows; ++r)
