@@ -82,6 +82,86 @@ DOUBLES_TERMS_N = (
 )
 
 
+# eom_ccsd.py:169-198: (coefficient, subscripts, operands); results are broadcast onto [a,i]
+DIAG_SINGLES_TERMS = (
+    (+2.0, "iaai->ai", ("iabj",)),
+    (-1.0, "iaia->ai", ("iajb",)),
+    (+4.0, "jiba,baji->ai", ("ijab", "t")),
+    (-2.0, "jkba,abjk->a", ("ijab", "t")),
+    (-2.0, "jicb,bcji->i", ("ijab", "t")),
+    (-2.0, "jiba,abji->ai", ("ijab", "t")),
+    (-2.0, "jiab,baji->ai", ("ijab", "t")),
+    (+1.0, "jkab,abjk->a", ("ijab", "t")),
+    (+1.0, "jicb,bcji->i", ("ijab", "t")),
+    (+1.0, "jiab,abji->ai", ("ijab", "t")),
+)
+# eom_ccsd.py:200-252: the terms under P(ijab, jiba); results are broadcast onto [a,b,i,j].  The reference places
+# "ibib->bi" on the axes (0, 2) like "iaia->ai" (:232), which makes the two terms identical: kept as written.
+DIAG_DOUBLES_TERMS_P = (
+    (+4.0, "kica,caki->ai", ("ijab", "t")),
+    (-2.0, "klca,cakl->a", ("ijab", "t")),
+    (-2.0, "kicd,cdki->i", ("ijab", "t")),
+    (-2.0, "kica,caki->ai", ("ijab", "t")),
+    (+2.0, "iaai->ai", ("iabj",)),
+    (-2.0, "kica,acki->ai", ("ijab", "t")),
+    (-2.0, "kiac,caki->ai", ("ijab", "t")),
+    (-2.0, "kjab,abkj->abj", ("ijab", "t")),
+    (-2.0, "ijcb,cbij->ij", ("ijab", "t")),
+    (-1.0, "iaia->ai", ("iajb",)),
+    (-1.0, "iaia->ai", ("iajb",)),
+    (+1.0, "klca,ackl->a", ("ijab", "t")),
+    (+1.0, "kidc,cdki->i", ("ijab", "t")),
+    (+1.0, "kicb,acki->ai", ("ijab", "t")),
+    (-1.0, "iaai->ai", ("iabj",)),
+    (+1.0, "kiac,acki->ai", ("ijab", "t")),
+    (+1.0, "kiab,abkj->abij", ("ijab", "t")),
+    (+1.0, "kjac,caki->aij", ("ijab", "t")),
+    (+1.0, "kjac,ackj->aj", ("ijab", "t")),
+    (+1.0, "ijca,cbij->abij", ("ijab", "t")),
+)
+# eom_ccsd.py:255-265: not permuted
+DIAG_DOUBLES_TERMS_N = (
+    (+1.0, "ijij->ij", ("klij",)),
+    (+1.0, "klab,abkl->ab", ("ijab", "t")),
+    (+1.0, "ijcd,cdij->ij", ("ijab", "t")),
+    (+1.0, "abab->ab", ("abcd",)),
+)
+
+
+def _broadcast(x, labels, target):
+    """Place the result of an einsum with output ``labels`` on the axes of ``target`` (e.g. "abij")."""
+    idx = tuple(slice(None) if c in labels else None for c in target)
+    order = [labels.index(c) for c in target if c in labels]
+    return np.transpose(x, order)[idx]
+
+
+def _diag_sum(terms, env, target, shape):
+    out = np.zeros(shape)
+    for c, spec, names in terms:
+        spec = spec.replace(" ", "")
+        out = out + c * _broadcast(np.einsum(spec, *[env[n] for n in names]), spec.split("->")[1], target)
+    return out
+
+
+def diag_singles(no, f, Vd, t2):
+    """EOM_CCSD.get_diag_singles, eom_ccsd.py:169-198."""
+    nv = f.shape[0] - no
+    env = dict(Vd, t=t2)
+    out = -f.diagonal()[:no][None, :] + f.diagonal()[no:][:, None]
+    return out + _diag_sum(DIAG_SINGLES_TERMS, env, "ai", (nv, no))
+
+
+def diag_doubles(no, f, Vd, t2):
+    """EOM_CCSD.get_diag_doubles, eom_ccsd.py:200-266."""
+    nv = f.shape[0] - no
+    env = dict(Vd, t=t2)
+    shape = (nv, nv, no, no)
+    out = _diag_sum(DIAG_DOUBLES_TERMS_P, env, "abij", shape)
+    out = out - f.diagonal()[:no][None, None, :, None] + f.diagonal()[no:][:, None, None, None]      # :228
+    out = out + out.transpose(1, 0, 3, 2)                                                               # :253
+    return out + _diag_sum(DIAG_DOUBLES_TERMS_N, env, "abij", shape)
+
+
 def _env(no, f, Vd, t2, u1, u2):
     env = dict(Vd)
     env.update(foo=f[:no, :no], fov=f[:no, no:], fvv=f[no:, no:], t=t2, u1=u1, u2=u2)
@@ -91,7 +171,7 @@ def _env(no, f, Vd, t2, u1, u2):
 def sigma_singles(no, f, Vd, u1, u2, t2):
     """EOM_CCSD.update_singles, eom_ccsd.py:268-310."""
     env = _env(no, f, Vd, t2, u1, u2)
-    out = np.zeros_like(u1)
+    out = np.zeros_like(u1)                      # complex u (FEAST / real-time callers) flows through
     for c, spec, names in SINGLES_TERMS:
         out += c * np.einsum(spec, *[env[n] for n in names], optimize=True)
     return out

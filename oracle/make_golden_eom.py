@@ -44,7 +44,20 @@ def sigma_case(no, nv, seed):
     o1 = eo.sigma_singles(no, f, Vb, u1, u2, t2)
     o2 = eo.sigma_doubles(no, f, Vb, u1, u2, t2)
     assert np.abs(o1 - s1).max() < 1e-12 and np.abs(o2 - s2).max() < 1e-12
-    np.savez_compressed(os.path.join(GOLD, f"eom_sigma_{no}_{nv}.npz"), seed=seed, s1=s1, s2=s2)
+    # diagonals used as preconditioner by the FEAST / real-time callers (eom_ccsd.py:169-266)
+    d1 = e.get_diag_singles(f, Vb, t2)
+    d2 = e.get_diag_doubles(f, Vb, t2)
+    assert np.abs(eo.diag_singles(no, f, Vb, t2) - d1).max() < 1e-12
+    assert np.abs(eo.diag_doubles(no, f, Vb, t2) - d2).max() < 1e-12
+    # complex trial vectors (feast_eom_ccsd.py:309-350 calls update_* with complex u)
+    w1 = rng.standard_normal((nv, no))
+    w2 = rng.standard_normal((nv, nv, no, no))
+    c1 = e.update_singles(f, Vb, u1 + 1j * w1, u2 + 1j * w2, t2)
+    c2 = e.update_doubles(f, Vb, u1 + 1j * w1, u2 + 1j * w2, t2)
+    assert np.abs(eo.sigma_singles(no, f, Vb, u1 + 1j * w1, u2 + 1j * w2, t2) - c1).max() < 1e-12
+    assert np.abs(eo.sigma_doubles(no, f, Vb, u1 + 1j * w1, u2 + 1j * w2, t2) - c2).max() < 1e-12
+    np.savez_compressed(os.path.join(GOLD, f"eom_sigma_{no}_{nv}.npz"), seed=seed, s1=s1, s2=s2, d1=d1, d2=d2,
+                        c1=c1, c2=c2)
     print(f"sigma ({no},{nv}): oracle == reference")
 
 

@@ -290,14 +290,60 @@ class EOM_CCSD:
 
     # ---- the reference's host-array call forms (eom_ccsd.py:268-385) ---------------------------
     def _host_sigma(self, t_fock_pq, dict_t_V, t_u_ai, t_u_abij, t_T_abij, which):
+        """Complex trial vectors (the FEAST / real-time callers, feast_eom_ccsd.py:309-350) are propagated as two
+        real ones: the operator is real and linear, sigma(u + i w) = sigma(u) + i sigma(w)."""
+        if np.iscomplexobj(t_fock_pq) or np.iscomplexobj(t_T_abij):
+            raise TypeError("complex Fock matrix / amplitudes are not supported")
         nv = t_u_ai.shape[0]
         ctx = self._context(dict_t_V, nv)
         try:
             sig = _Sigma(ctx, t_fock_pq, ctx.array(t_T_abij))
-            u1, u2 = ctx.array(t_u_ai), ctx.array(t_u_abij)
-            return (sig.singles(u1, u2) if which == 1 else sig.doubles(u1, u2)).get()
+            apply = sig.singles if which == 1 else sig.doubles
+            cplx = np.iscomplexobj(t_u_ai) or np.iscomplexobj(t_u_abij)
+            out = apply(ctx.array(np.real(t_u_ai)), ctx.array(np.real(t_u_abij))).get()
+            if cplx:
+                out = out + 1j * apply(ctx.array(np.imag(t_u_ai)), ctx.array(np.imag(t_u_abij))).get()
+            return out
         finally:
             ctx.close()
+
+    def get_diag_singles(self, t_fock_pq, dict_t_V, t_T_abij):
+        """eom_ccsd.py:169-198, terms grouped: with V~ = 2V - V^(ab), T~ = 2T - T^(ab) the four (a,i)-resolved
+        V.T terms are one Hadamard sum.  O(o^2 v^2) work on the caller's host arrays (preconditioner data)."""
+        no = self.no
+        V, T = np.asarray(dict_t_V["ijab"]), np.asarray(t_T_abij)
+        f = np.asarray(t_fock_pq)
+        Vt = 2.0 * V - V.transpose(0, 1, 3, 2)
+        Tt = 2.0 * T - T.transpose(1, 0, 2, 3)
+        d = f.diagonal()[no:][:, None] - f.diagonal()[:no][None, :]
+        d = d + 2.0 * np.einsum("iaai->ai", dict_t_V["iabj"]) - np.einsum("iaia->ai", dict_t_V["iajb"])
+        d = d + np.einsum("jiba,baji->ai", Vt, Tt)
+        d = d - np.einsum("jkba,abjk->a", Vt, T)[:, None]
+        d = d - np.einsum("jicb,bcji->i", V, T)[None, :]
+        return d
+
+    def get_diag_doubles(self, t_fock_pq, dict_t_V, t_T_abij):
+        """eom_ccsd.py:200-266 (same grouping; the reference's placement of the `ibib` term on the (a,i) axes is kept)."""
+        no = self.no
+        V, T = np.asarray(dict_t_V["ijab"]), np.asarray(t_T_abij)
+        f = np.asarray(t_fock_pq)
+        Vx = V.transpose(0, 1, 3, 2)                         # V[k,i,a,c] read as [k,i,c,a]
+        Tx = T.transpose(1, 0, 2, 3)                         # T[a,c,k,i] read as [c,a,k,i]
+        ai = f.diagonal()[no:][:, None] - f.diagonal()[:no][None, :]
+        ai = ai + np.einsum("iaai->ai", dict_t_V["iabj"]) - 2.0 * np.einsum("iaia->ai", dict_t_V["iajb"])
+        ai = ai + np.einsum("kica,caki->ai", 2.0 * V - 2.0 * Vx, T) + np.einsum("kica,caki->ai", Vx - 2.0 * V, Tx)
+        ai = ai + np.einsum("kicb,acki->ai", V, T)
+        a_ = np.einsum("klca,cakl->a", V, Tx - 2.0 * T)
+        i_ = np.einsum("kicd,cdki->i", Vx - 2.0 * V, T)
+        d = ai[:, None, :, None] + a_[:, None, None, None] + i_[None, None, :, None]
+        d = d - 2.0 * np.einsum("kjab,abkj->abj", V, T)[:, :, None, :]
+        d = d - 2.0 * np.einsum("ijcb,cbij->ij", V, T)[None, None, :, :]
+        d = d + np.einsum("kiab,abkj->abij", V, T) + np.einsum("ijca,cbij->abij", V, T)
+        d = d + np.einsum("kjac,caki->aij", V, T)[:, None, :, :] + np.einsum("kjac,ackj->aj", V, T)[:, None, None, :]
+        d = d + d.transpose(1, 0, 3, 2)                                                           # P(ijab, jiba), :253
+        d = d + (np.einsum("ijij->ij", dict_t_V["klij"]) + np.einsum("ijcd,cdij->ij", V, T))[None, None, :, :]
+        d = d + (np.einsum("klab,abkl->ab", V, T) + np.einsum("abab->ab", dict_t_V["abcd"]))[:, :, None, None]
+        return d
 
     def update_singles(self, t_fock_pq, dict_t_V, t_u_ai, t_u_abij, t_T_abij):
         return self._host_sigma(t_fock_pq, dict_t_V, t_u_ai, t_u_abij, t_T_abij, 1)

@@ -16,10 +16,13 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 SOLVES = json.load(open(os.path.join(GOLD, "eom_solves.json")))
 
 
-def sigma_inputs(no, nv, seed):
+def sigma_inputs(no, nv, seed, with_imag=False):
     f, V, t1, t2 = random_case(no, nv, seed, symmetric=False)
     rng = np.random.default_rng(seed + 100)
-    return f, oc.split_blocks(no, V), rng.standard_normal((nv, no)), rng.standard_normal((nv, nv, no, no)), t2
+    out = (f, oc.split_blocks(no, V), rng.standard_normal((nv, no)), rng.standard_normal((nv, nv, no, no)), t2)
+    if with_imag:       # imaginary parts of the complex trial vector of the golden file (make_golden_eom.py)
+        out += (rng.standard_normal((nv, no)), rng.standard_normal((nv, nv, no, no)))
+    return out
 
 
 def ground_state(tag):
@@ -39,6 +42,16 @@ def test_oracle_sigma_matches_reference(no, nv, seed):
     assert np.abs(eo.sigma_doubles(no, f, Vb, u1, u2, t2) - g["s2"]).max() < 1e-12
 
 
+@pytest.mark.parametrize("no,nv,seed", [(2, 3, 31), (3, 5, 32)])
+def test_oracle_diag_and_complex_sigma_match_reference(no, nv, seed):
+    g = np.load(os.path.join(GOLD, f"eom_sigma_{no}_{nv}.npz"))
+    f, Vb, u1, u2, t2, w1, w2 = sigma_inputs(no, nv, seed, with_imag=True)
+    assert np.abs(eo.diag_singles(no, f, Vb, t2) - g["d1"]).max() < 1e-12
+    assert np.abs(eo.diag_doubles(no, f, Vb, t2) - g["d2"]).max() < 1e-12
+    assert np.abs(eo.sigma_singles(no, f, Vb, u1 + 1j * w1, u2 + 1j * w2, t2) - g["c1"]).max() < 1e-12
+    assert np.abs(eo.sigma_doubles(no, f, Vb, u1 + 1j * w1, u2 + 1j * w2, t2) - g["c2"]).max() < 1e-12
+
+
 def test_oracle_solve_matches_reference():
     no, fd, Vd, t2 = ground_state("LiH.sto6g")
     r = eo.eom_solve(no, fd, Vd, t2, n_excit=2, max_iter=1000)
@@ -55,6 +68,14 @@ def run_product(lib, monkeypatch):
         e = EOM_CCSD(no, 2)
         assert np.abs(e.update_singles(f, Vb, u1, u2, t2) - g["s1"]).max() < 1e-12
         assert np.abs(e.update_doubles(f, Vb, u1, u2, t2) - g["s2"]).max() < 1e-12
+        # complex trial vectors and the diagonals (FEAST / real-time callers, eom_ccsd.py:169-266)
+        _, _, _, _, _, w1, w2 = sigma_inputs(no, nv, seed, with_imag=True)
+        assert np.abs(e.update_singles(f, Vb, u1 + 1j * w1, u2 + 1j * w2, t2) - g["c1"]).max() < 1e-12
+        assert np.abs(e.update_doubles(f, Vb, u1 + 1j * w1, u2 + 1j * w2, t2) - g["c2"]).max() < 1e-12
+        assert np.abs(e.get_diag_singles(f, Vb, t2) - g["d1"]).max() < 1e-12
+        assert np.abs(e.get_diag_doubles(f, Vb, t2) - g["d2"]).max() < 1e-12
+        with pytest.raises(TypeError):
+            e.update_singles(f.astype(complex), Vb, u1, u2, t2)
     for tag in ("LiH.sto6g", "H2.ccpvdz"):
         no, fd, Vd, t2 = ground_state(tag)
         e = EOM_CCSD(no, n_excit=2)
