@@ -2,6 +2,8 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <tuple>
 
@@ -171,6 +173,15 @@ static void check_labels(const char* s, int rank, const char* what) {
             if (s[i] == s[j]) throw Error(std::string("repeated label in '") + s + "'");
 }
 
+static bool is_contiguous(const TView& t) {
+    int64_t expect = 1;
+    for (int i = t.rank - 1; i >= 0; --i) {
+        if (t.dim[i] != 1 && t.st[i] != expect) return false;
+        expect *= t.dim[i];
+    }
+    return true;
+}
+
 void Engine::permute(double alpha, const TView& in, const char* si, double beta, const TView& out,
                      const char* so) {
     check_labels(si, in.rank, "input");
@@ -198,6 +209,14 @@ void Engine::permute(double alpha, const TView& in, const char* si, double beta,
     dev::permute(p, stream);
     stats.permute_calls++;
     stats.permute_bytes += 8.0 * static_cast<double>(out.size()) * (beta != 0.0 ? 3.0 : 2.0);
+    if (const char* logp = getenv("PYMES_PERMUTE_LOG")) {       // tuning aid: one line per explicit permutation
+        if (FILE* lf = fopen(logp, "a")) {
+            fprintf(lf, "%s->%s alpha=%g beta=%g MB=%.1f dims", si, so, alpha, beta, 8e-6 * static_cast<double>(out.size()));
+            for (int i = 0; i < out.rank; ++i) fprintf(lf, " %ld", static_cast<long>(out.dim[i]));
+            fprintf(lf, "\n");
+            fclose(lf);
+        }
+    }
 }
 
 void Engine::axpby(double alpha, const TView& in, double beta, const TView& out) {
@@ -369,6 +388,24 @@ void Engine::contract(double alpha, const TView& A, const char* sa, const TView&
         for (auto* l : g2) lay.push_back(l->c);
         int64_t d[6];
         for (size_t i = 0; i < lay.size(); ++i) d[i] = find(lay[i])->n;
+        // A transposed copy of a whole UNDRESSED integral block is the same in every iteration: keep it
+        // (dressed Fock / singles terms contract o v^3-sized blocks with T1 over non-adjacent indices).
+        if (fill) {
+            for (int pat = 0; pat < 16; ++pat) {
+                if (X.p != V_[pat] || !V_[pat] || X.size() != block_size(pat) || !is_contiguous(X)) continue;
+                std::string key = "perm:" + std::to_string(pat) + ":";
+                for (char ch : lay) key.push_back(static_cast<char>('0' + (std::strchr(sx, ch) - sx)));
+                auto it = static_.find(key);
+                if (it == static_.end()) {
+                    const size_t bytes = sizeof(double) * static_cast<size_t>(X.size());
+                    if (dev::mem_free_bytes() < 2 * bytes + (size_t(8) << 30)) break;     // not worth the memory
+                    double* p = static_cast<double*>(dev::dmalloc(bytes));
+                    it = static_.emplace(key, p).first;
+                    permute(1.0, X, sx, 0.0, make_view(p, static_cast<int>(lay.size()), d, nullptr), lay.c_str());
+                }
+                return std::make_pair(make_view(it->second, static_cast<int>(lay.size()), d, nullptr), lay);
+            }
+        }
         TView t = make_view(arena.alloc(X.size()), static_cast<int>(lay.size()), d, nullptr);
         if (fill) permute(1.0, X, sx, 0.0, t, lay.c_str());
         return std::make_pair(t, lay);
