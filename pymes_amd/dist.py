@@ -56,6 +56,38 @@ def exchange_rows(full, rank, world_size):
     return full
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
+class _Pending:
+    """An all-gather in flight; keeps its send buffer alive until waited for."""
+
+    def __init__(self, work, send):
+        self.work, self.send = work, send
+
+    def wait(self):
+        self.work.wait()
+        self.send = None
+        return True
+
+
+def exchange_rows_start(full, rank, world_size):
+    """Asynchronous form of ``exchange_rows``: returns a handle whose ``wait()`` makes the current stream wait for
+    the all-gather (RCCL runs it on its own stream, so kernels enqueued in between overlap with the transfer).
+    The gloo test rig and PYMES_SYNC_EXCHANGE=1 fall back to the blocking exchange."""
+    import torch.distributed as dist
+    if world_size == 1:
+        return _Done()
+    if (full.is_cuda and dist.get_backend() == "gloo") or os.environ.get("PYMES_SYNC_EXCHANGE"):
+        exchange_rows(full, rank, world_size)
+        return _Done()
+    c = full.shape[0] // world_size
+    mine = full[rank * c:(rank + 1) * c].clone()
+    return _Pending(dist.all_gather_into_tensor(full.view(-1), mine.view(-1), async_op=True), mine)
+
+
 def a_range_of_pair_rows(lo, hi):
     """Virtual indices a touched by the packed pair rows P(a,b) = a(a+1)/2 + b in [lo, hi)."""
     if hi <= lo:

@@ -105,7 +105,6 @@ class CCSD(ccd.CCD):
         shift = st["level_shift"]
         ctx.dress_fock(st["f"], t1, st["fd"])                        # :163
         r1 = ctx.pool_get(t1.shape)
-        ctx.singles_residual(st["fd"], t1, t2, r1)                  # :167
         r2 = ctx.pool_get(t2.shape)
         world, rank = st["world"], st["rank"]
         if st["sym"]:
@@ -113,20 +112,30 @@ class CCSD(ccd.CCD):
             # its rows of the pair-packed particle + hole ladders and of Q_kb; four all-gathers; replicated
             # remainder.  V_abcd is never dressed: its T1 dressing (:165, ccsd.py:414-419) is carried by
             # tau = T2 + T1 T1 inside the ladders (include/pymes_amd.h, pymes_residual_slab).
-            ctx.dress_V(t1, ("abij", "klij", "iajb", "iabj"), reduced_abij=True)      # :165
+            # The replicated work that the slab does not need (R1, V~_abij) is enqueued after the all-gathers
+            # have been started, so that it overlaps with the transfers.
+            ctx.dress_V(t1, ("klij", "iajb", "iabj"))                                 # :165
             ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], rank, world, is_dcd=self.is_dcd,
                               dressed=True, t1=t1, QK=st["QK"])                        # :171
+            pending = []
             if world > 1:
                 ctx.sync()
-                for key in ("ETd_t", "ETx_t", "L_t", "QK_t"):
-                    pdist.exchange_rows(st[key], rank, world)
+                pending = [pdist.exchange_rows_start(st[key], rank, world) for key in ("ETd_t", "ETx_t", "L_t", "QK_t")]
+            ctx.singles_residual(st["fd"], t1, t2, r1)                                # :167
+            ctx.dress_V(t1, ("abij",), reduced_abij=True)                             # :165
+            for work in pending:
+                work.wait()
+            if world > 1:
                 torch_sync()
             ctx.residual_finish(st["fd"], t2, st["ETd"], st["ETx"], st["L"], r2, is_dcd=self.is_dcd, dressed=True,
                                 t1=t1, QK=st["QK"])
+            world = 0           # handled
         elif world == 1:
+            ctx.singles_residual(st["fd"], t1, t2, r1)                                # :167
             ctx.dress_V(t1, LOOP_KEYS)                                                # :165
             ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True, sym_ladder=False)   # :171
         else:
+            ctx.singles_residual(st["fd"], t1, t2, r1)                                # :167
             # unsymmetric user amplitudes: plain ladder rows on this rank, everything else replicated
             ctx.dress_V(t1, LOOP_KEYS)
             lo, hi = pdist.slab_rows(st["lad_rows"], rank, world)

@@ -58,7 +58,17 @@ def _worker(rank, world, port, nv, no, out):
             for i, j in _pairs(no):
                 if i > j:
                     L[r, k] = 0.5 * (ref[a, b, i, j] - ref[a, b, j, i]); k += 1      # LA
-        pdist.exchange_rows(L, rank, world)
+        # the overlapped form: two exchanges in flight, local work in between, then wait (as CCSD.iterate does)
+        full2 = torch.zeros_like(full)
+        full2[slice(*pdist.slab_rows(rows, rank, world))] = float(rank + 1)
+        pending = [pdist.exchange_rows_start(L, rank, world), pdist.exchange_rows_start(full2, rank, world)]
+        _ = float((full * 2.0).sum())
+        for w in pending:
+            assert w.wait()
+        c = pdist.chunk_rows(rows, world)
+        for r in range(world):
+            blk = full2[r * c:min((r + 1) * c, rows)]
+            assert blk.numel() == 0 or bool((blk == float(r + 1)).all())
         Ln = L.numpy()
         opp = no * (no + 1) // 2
         rec = np.zeros_like(ref)
