@@ -133,6 +133,14 @@ class Context:
             return DeviceArray(self, arr.ptr, shape, owned=False, keepalive=arr)
         return self.empty(shape)
 
+    def pool_reserve(self, shape, count):
+        """Make sure ``count`` buffers of this size exist (in use or free): device allocations (page-table set-up and
+        clearing of fresh HBM pages) then happen at set-up time, not inside the first iterations of a solve."""
+        n = int(np.prod(tuple(int(s) for s in shape)))
+        free = self._pool.setdefault(n, [])
+        while len(free) < count:
+            free.append(self.empty((n,)))
+
     def pool_put(self, arr):
         base = arr
         while not base._owned and isinstance(base._keep, DeviceArray):

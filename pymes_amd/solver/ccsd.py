@@ -78,6 +78,9 @@ class CCSD(ccd.CCD):
         if amps is not None:
             t2h = np.asarray(amps[1])
             st["sym"] = bool(np.abs(t2h - t2h.transpose(1, 0, 3, 2)).max() <= 1e-13 * max(1.0, np.abs(t2h).max()))
+        if self.is_diis:     # DIIS keeps dim_space (dT, T) pairs + the mixed result + residual/update scratch
+            ctx.pool_reserve(t2.shape, 2 * self.mixer.dim_space + 4)
+            ctx.pool_reserve(t1.shape, 2 * self.mixer.dim_space + 4)
         st["npp"] = nv * (nv + 1) // 2
         if wsize > 1:
             import torch
