@@ -49,6 +49,25 @@ def test_dgemm_layouts_and_edges(ctx, a_kc, b_kc):
     _gemm_case(ctx, 151, 91, 78, a_kc, b_kc, 2.0, 0.25, rng, lda_pad=1, ldb_pad=3, ldc_pad=5)
 
 
+@pytest.mark.parametrize("a_kc", [True, False])
+@pytest.mark.parametrize("b_kc", [True, False])
+def test_dgemm_lds_dma_kernel(ctx, a_kc, b_kc):
+    """Shapes that reach the LDS-DMA 128x128 kernel (>= 256 tiles, K >= 1024, 16-byte aligned operands): ragged M/N
+    edges, a partial last k-tile, k-split remainder tiles, alpha/beta, padded pitches, and odd M / N with an even
+    pitch (pair loads one element past the extent)."""
+    rng = np.random.default_rng(5)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    _gemm_case(ctx, 2100, 2180, 1100, a_kc, b_kc, 1.0, 0.0, rng)                     # 17 x 18 tiles, k-tail of 12
+    dma = ctx.prof_query(kernel_class=1)
+    ctx.prof_enable(False)
+    assert dma["launches"] == 1 and dma["kernel_launches"] >= 1, "the LDS-DMA kernel was not selected"
+    _gemm_case(ctx, 2100, 2180, 1104, a_kc, b_kc, -0.5, 0.75, rng, lda_pad=2, ldb_pad=6, ldc_pad=3)
+    _gemm_case(ctx, 2049, 2051, 1030, a_kc, b_kc, 2.0, 1.0, rng, lda_pad=2 if a_kc else 1,
+               ldb_pad=2 if b_kc else 1)                                                          # odd M, N; even pitch
+    _gemm_case(ctx, 4000, 1275, 2052, a_kc, b_kc, 1.0, 0.0, rng, ldb_pad=0 if b_kc else 1)        # ladder-like N
+
+
 def test_dgemm_tail_wave_split(ctx):
     """529 tiles of 128x128 = one full wave of 512 + 17: the remainder runs k-split (tile-local workspace)."""
     rng = np.random.default_rng(7)
