@@ -182,15 +182,20 @@ def main():
                           "last_energy": energies[-1]},
         }
         if world == 1 and not args.no_cpu_baseline:
-            from oracle.baseline import sample
+            from oracle.baseline import sample, algorithmic_fma
             cpu = sample(no, nv)
+            # the sample times the doubles residual (93 % of the reference's flops); dressing + singles + Fock are
+            # priced at the same rate through the SURVEY 8(d) flop table so that the value is the bench metric
+            to_iter = ref_fl / (2.0 * algorithmic_fma(no, nv, args.dcsd))
             line["cpu_baseline"] = {
-                "value": cpu["faithful"]["seconds_per_doubles_residual"], "unit": "s", "cores": 1, "kind": "port",
-                "what": "one doubles residual (93 % of the reference's iteration flops), plain np.einsum",
+                "value": cpu["faithful"]["seconds_per_doubles_residual"] * to_iter, "unit": "s", "cores": 1,
+                "kind": "port",
                 "sample": "oracle contraction forms (plain np.einsum, as the reference's T2 residual): ladder on a "
                           "(1 x 25) (a,b)-slab and one o^3v^3 ring term on an a-slab of 1, extrapolated linearly to "
-                          "one doubles residual with the SURVEY 8(d) flop table",
-                "blas_all_cores": {"value": cpu["blas"]["seconds_per_doubles_residual"], "unit": "s",
+                          f"one doubles residual with the SURVEY 8(d) flop table, x {to_iter:.3f} (flop ratio "
+                          "iteration / doubles residual) for one CCSD iteration",
+                "doubles_residual_s": cpu["faithful"]["seconds_per_doubles_residual"],
+                "blas_all_cores": {"value": cpu["blas"]["seconds_per_doubles_residual"] * to_iter, "unit": "s",
                                    "cores": cpu["cores"]["blas"]}}
         print(json.dumps(line), flush=True)
     if world > 1:
