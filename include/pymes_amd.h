@@ -137,6 +137,23 @@ int pymes_residual_finish(pymes_ctx* ctx, const double* f_dev, const double* t2_
                           const double* ETx_dev, const double* L_dev, double* r2_dev, uint32_t flags,
                           const double* t1_dev, const double* QK_dev);
 int pymes_ccsd_dress_abcd_rows(pymes_ctx* ctx, const double* t1_dev, int a_begin, int a_end, int lower_only);
+/* Pair-sharded tail of the iteration (world > 1).  Rank r owns the virtual pairs P(a,b) = a(a+1)/2+b, a >= b, of chunk
+ * r of v(v+1)/2 (ceil(npp/world) pairs per chunk, the rows of L it produced in pymes_residual_slab) and keeps every
+ * amplitude-sized quantity only for them, in the compact layout Xc[P - r0][2][o*o]: tile 0 = X[a,b,:,:], tile 1 =
+ * X[b,a,:,:] (zeros for a == b, so that dots over Xc summed over the ranks equal dots over the full array).
+ *   pymes_residual_finish_pairs: pymes_residual_finish restricted to the rank's pairs -> Rc (L is read locally and is
+ *                                NOT exchanged; ETd, ETx, QK must have been all-gathered); needs t1/QK
+ *   pymes_cc_update_pairs:       ccsd.py:176-179 on compact tiles (dt = r/(D+shift), t += delta dt)
+ *   pymes_pairs_pack:            compact tiles of this rank from a full [v,v,o,o] array
+ *   pymes_pairs_unpack:          full [v,v,o,o] array from the all-gathered compact buffer [world * chunk][2][o*o] */
+int pymes_residual_finish_pairs(pymes_ctx* ctx, const double* f_dev, const double* t2_dev, const double* ETd_dev,
+                                const double* ETx_dev, const double* L_dev, double* Rc_dev, uint32_t flags,
+                                const double* t1_dev, const double* QK_dev, int rank, int world);
+int pymes_cc_update_pairs(pymes_ctx* ctx, double* tc_dev, double* dtc_dev, const double* rc_dev, double level_shift,
+                          double delta, int rank, int world);
+int pymes_pairs_supported(pymes_ctx* ctx, int* yes);   /* the o x o tile of the fused pair kernels fits the LDS */
+int pymes_pairs_pack(pymes_ctx* ctx, const double* full_dev, double* xc_dev, int rank, int world);
+int pymes_pairs_unpack(pymes_ctx* ctx, const double* xc_all_dev, double* full_dev, int world);
 /* ccsd.py:176-179 / ccd.py:123-124: dt = r/(D+shift) (as r * (1/(D+shift))), t += delta*dt; rank 2 or 4 */
 int pymes_cc_update(pymes_ctx* ctx, double* t_dev, double* dt_dev, const double* r_dev, double level_shift,
                     double delta, int rank);

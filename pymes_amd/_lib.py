@@ -56,6 +56,13 @@ SIGNATURES = {
                                       C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]),
     "pymes_residual_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "pymes_residual_finish_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "pymes_cc_update_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
+                                        C.c_int]),
+    "pymes_pairs_supported": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "pymes_pairs_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "pymes_pairs_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "pymes_ccsd_dress_abcd_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "pymes_cc_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
                                   C.c_int]),

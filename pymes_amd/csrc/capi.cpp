@@ -256,6 +256,52 @@ int pymes_residual_finish(pymes_ctx* ctx, const double* f, const double* t2, con
         E(ctx).residual_finish(f, t2, ETd, ETx, L, r2, flags, t1, QK);
     });
 }
+int pymes_residual_finish_pairs(pymes_ctx* ctx, const double* f, const double* t2, const double* ETd, const double* ETx,
+                                const double* L, double* Rc, uint32_t flags, const double* t1, const double* QK, int rank,
+                                int world) {
+    return guarded([&] {
+        need(f, "f"); need(t2, "t2"); need(ETd, "ETd"); need(ETx, "ETx"); need(L, "L"); need(Rc, "Rc");
+        need(t1, "t1"); need(QK, "QK");
+        E(ctx).residual_finish_pairs(f, t2, ETd, ETx, L, Rc, flags, t1, QK, rank, world);
+    });
+}
+int pymes_pairs_supported(pymes_ctx* ctx, int* yes) {
+    return guarded([&] {
+        if (!yes) throw pymes::Error("null output");
+        *yes = dev::fused_pair_kernels_ok(E(ctx).no) ? 1 : 0;
+    });
+}
+int pymes_pairs_pack(pymes_ctx* ctx, const double* full, double* xc, int rank, int world) {
+    return guarded([&] {
+        need(full, "full"); need(xc, "xc");
+        int64_t r0, r1;
+        E(ctx).pair_chunk(rank, world, r0, r1);
+        dev::pairs_pack(full, xc, E(ctx).no, E(ctx).nv, r0, r1, E(ctx).stream);
+    });
+}
+int pymes_pairs_unpack(pymes_ctx* ctx, const double* xc_all, double* full, int world) {
+    return guarded([&] {
+        need(xc_all, "xc_all"); need(full, "full");
+        pymes::Engine& e = E(ctx);
+        const int64_t o2 = static_cast<int64_t>(e.no) * e.no;
+        for (int r = 0; r < world; ++r) {       // chunk r of the exchanged buffer starts at r * chunk_rows
+            int64_t r0, r1, c0, c1;
+            e.pair_chunk(r, world, r0, r1);
+            e.pair_chunk(0, world, c0, c1);
+            dev::pairs_unpack(xc_all + static_cast<int64_t>(r) * (c1 - c0) * 2 * o2, full, e.no, e.nv, r0, r1, e.stream);
+        }
+    });
+}
+int pymes_cc_update_pairs(pymes_ctx* ctx, double* tc, double* dtc, const double* rc, double shift, double delta, int rank,
+                          int world) {
+    return guarded([&] {
+        need(tc, "tc"); need(dtc, "dtc"); need(rc, "rc");
+        pymes::Engine& e = E(ctx);
+        int64_t r0, r1;
+        e.pair_chunk(rank, world, r0, r1);
+        dev::cc_update_pairs(tc, dtc, rc, e.eps_o, e.eps_v, shift, delta, e.no, e.nv, r0, r1, e.stream);
+    });
+}
 int pymes_ccsd_dress_abcd_rows(pymes_ctx* ctx, const double* t1, int a0, int a1, int lower_only) {
     return guarded([&] {
         need(t1, "t1");

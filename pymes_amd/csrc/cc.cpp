@@ -15,6 +15,8 @@
 
 #include "engine.h"
 
+#include <cmath>
+
 namespace pymes {
 
 namespace {
@@ -363,6 +365,64 @@ void Engine::residual_finish(const double* f, const double* t2, const double* ET
     permute(1.0, ETd, "bjai", 1.0, R, "abij");
     permute(1.0, ETx, "ajbi", 1.0, R, "abij");
     permute(1.0, ETx, "biaj", 1.0, R, "abij");
+}
+
+void Engine::pair_chunk(int rank, int world, int64_t& r0, int64_t& r1) const {
+    if (world < 1 || rank < 0 || rank >= world) throw Error("pair_chunk: bad rank/world");
+    const int64_t npp = static_cast<int64_t>(nv) * (nv + 1) / 2, c = (npp + world - 1) / world;
+    r0 = std::min<int64_t>(rank * c, npp);
+    r1 = std::min<int64_t>(r0 + c, npp);
+}
+
+static int a_of_pair_row(int64_t r) {
+    int64_t a = static_cast<int64_t>((std::sqrt(8.0 * static_cast<double>(r) + 1.0) - 1.0) * 0.5);
+    while (a * (a + 1) / 2 > r) --a;
+    while ((a + 1) * (a + 2) / 2 <= r) ++a;
+    return static_cast<int>(a);
+}
+
+// The replicated remainder of residual_finish reduced to what the pairs of one rank need: X_ac (v x v, cheap) is
+// still formed by everyone; the X_ac.T / t.Q_kb combination N'_ab = N_ab + N_ba^T only for the rows a of the rank's
+// pairs; the assembly only for its pairs.  Needs the fused assembly kernel (o x o tile in LDS).
+void Engine::residual_finish_pairs(const double* f, const double* t2, const double* ETd_p, const double* ETx_p,
+                                   const double* L, double* Rc, unsigned flags, const double* t1, const double* QK,
+                                   int rank, int world) {
+    const bool dcd = flags & 1u, dressed = flags & 2u;
+    const int64_t o = no, v = nv, nn = n;
+    const double w = dcd ? 0.5 : 1.0;
+    if (!L || !t1 || !QK) throw Error("residual_finish_pairs: L, t1 and QK are required");
+    if (!dev::fused_pair_kernels_ok(no)) throw Error("residual_finish_pairs: nocc too large for the fused assembly");
+    int64_t r0, r1;
+    pair_chunk(rank, world, r0, r1);
+    if (r1 <= r0) return;
+    const int a0 = a_of_pair_row(r0), a1 = a_of_pair_row(r1 - 1) + 1;
+    const int64_t na = a1 - a0;
+    TView T = make_view(const_cast<double*>(t2), {v, v, o, o});
+    TView F = make_view(const_cast<double*>(f), {nn, nn});
+    TView Fvv = slice(slice(F, 0, o, nn), 1, o, nn);
+    TView t = make_view(const_cast<double*>(t1), {v, o});
+    ArenaScope scope(arena);
+    // X_ac = f_ac - w sum Tt[a,d,k,l] V[l,k,d,c]  (ccd.py:206-221)
+    TView Xvv = make_view(arena.alloc(v * v), {v, v});
+    {
+        ArenaScope s2(arena);
+        TView Ttd = make_view(arena.alloc(o * o * v * v), {v, o, v, o});
+        permute(2.0, T, "abij", 0.0, Ttd, "aibj");
+        permute(-1.0, T, "baij", 1.0, Ttd, "aibj");
+        copy(Fvv, Xvv);
+        contract(-w, Ttd, "akdl", make_view(get_static("Vk"), {o, v, o, v}), "kdlc", 1.0, Xvv, "ac");
+    }
+    // N'[a,b,i,j] = X_ac T[c,b,i,j] + X_bc T[c,a,j,i] - t_ak Q[k,b,i,j] - t_bk Q[k,a,j,i]   for a in [a0,a1)   (:231)
+    TView Np = make_view(arena.alloc(na * v * o * o), {na, v, o, o});
+    TView Qf = make_view(arena.alloc(o * v * o * o), {o, v, o, o});
+    dev::rows_unpack(QK, Qf.p, o * v, no, stream);
+    contract(1.0, slice(Xvv, 0, a0, a1), "ac", T, "cbij", 0.0, Np, "abij");
+    contract(1.0, Xvv, "bc", slice(T, 1, a0, a1), "caji", 1.0, Np, "abij");
+    contract(-1.0, slice(t, 0, a0, a1), "ak", Qf, "kbij", 1.0, Np, "abij");
+    contract(-1.0, t, "bk", slice(Qf, 1, a0, a1), "kaji", 1.0, Np, "abij");
+    dev::residual_assemble_pairs(block(P_abij, dressed).p, L, Np.p, ETd_p, ETx_p, Rc, no, nv, r0, r1, a0, stream);
+    stats.permute_calls++;
+    stats.permute_bytes += 8.0 * 5.5 * double(r1 - r0) * 2.0 * double(o * o);
 }
 
 // rows a in [a0,a1) of the T1-dressed V_abcd (ccsd.py:414-419): what a rank needs for its ladder rows.

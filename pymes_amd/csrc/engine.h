@@ -126,6 +126,12 @@ class Engine {
                        unsigned flags, const double* t1 = nullptr, double* QK = nullptr);
     void residual_finish(const double* f, const double* t2, const double* ETd, const double* ETx, const double* L,
                          double* r2, unsigned flags, const double* t1 = nullptr, const double* QK = nullptr);
+    // Pair-sharded tail (one process per GPU): rank owns the virtual pairs P(a,b), a >= b, of its chunk of
+    // v(v+1)/2 (the rows of L it computed itself) and produces R for exactly those pairs in the compact layout
+    // Rc[P - r0][2][o*o] (tiles R[a,b,:,:], R[b,a,:,:]); L is read locally, ETd/ETx/QK must have been exchanged
+    void residual_finish_pairs(const double* f, const double* t2, const double* ETd, const double* ETx, const double* L,
+                               double* Rc, unsigned flags, const double* t1, const double* QK, int rank, int world);
+    void pair_chunk(int rank, int world, int64_t& r0, int64_t& r1) const;
     // rows [row0,row1) of the pair-packed ladders and rows [q0,q1) of QK[(k,b)] = sum_cd V_kbcd tau_cdij, all
     // from UNDRESSED, statically packed integrals; tau = T + t1 t1
     void ladder_t1(const double* t1, const double* t2, double* L, int64_t row0, int64_t row1, double* QK, int64_t q0,

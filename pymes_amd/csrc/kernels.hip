@@ -973,6 +973,92 @@ __global__ void __launch_bounds__(256) residual_assemble_kernel(const double* V,
     }
 }
 
+// ---- pair-sharded tail of the iteration (one process per GPU): a rank owns the virtual pairs P(a,b) in [r0,r1), a >= b,
+// and keeps the tiles X[a,b,:,:] and X[b,a,:,:] of every amplitude-sized quantity in the compact layout
+// Xc[P - r0][2][o*o] (tile 1 is zero for a == b, so that dot products over Xc equal those over the full array) -----
+__global__ void __launch_bounds__(256) pairs_pack_kernel(const double* __restrict__ full, double* __restrict__ Xc,
+                                                         int no, int nv, long r0) {
+    int a, b;
+    unrank_pair(r0 + blockIdx.x, a, b);
+    const long o2 = (long)no * no;
+    const double* __restrict__ ab = full + ((long)a * nv + b) * o2;
+    const double* __restrict__ ba = full + ((long)b * nv + a) * o2;
+    double* __restrict__ out = Xc + (long)blockIdx.x * 2 * o2;
+    for (int e = threadIdx.x; e < o2; e += blockDim.x) {
+        out[e] = ab[e];
+        out[o2 + e] = (a != b) ? ba[e] : 0.0;
+    }
+}
+__global__ void __launch_bounds__(256) pairs_unpack_kernel(const double* __restrict__ Xc, double* __restrict__ full,
+                                                           int no, int nv, long r0) {
+    int a, b;
+    unrank_pair(r0 + blockIdx.x, a, b);
+    const long o2 = (long)no * no;
+    const double* __restrict__ in = Xc + (long)blockIdx.x * 2 * o2;
+    double* __restrict__ ab = full + ((long)a * nv + b) * o2;
+    double* __restrict__ ba = full + ((long)b * nv + a) * o2;
+    for (int e = threadIdx.x; e < o2; e += blockDim.x) {
+        ab[e] = in[e];
+        if (a != b) ba[e] = in[o2 + e];
+    }
+}
+// ccsd.py:176-179 on the compact tiles: the denominator of T[b,a,i,j] is that of T[a,b,i,j]
+__global__ void __launch_bounds__(256) cc_update_pairs_kernel(double* __restrict__ tc, double* __restrict__ dtc,
+                                                              const double* __restrict__ rc, const double* __restrict__ eo,
+                                                              const double* __restrict__ ev, double shift, double delta,
+                                                              int no, long r0) {
+    int a, b;
+    unrank_pair(r0 + blockIdx.x, a, b);
+    const long o2 = (long)no * no, base = (long)blockIdx.x * 2 * o2;
+    const double eab = ev[a] + ev[b];
+    for (int e = threadIdx.x; e < 2 * o2; e += blockDim.x) {
+        const int t = e >= o2 ? e - (int)o2 : e;
+        const int i = t / no, j = t - i * no;
+        const double x = rc[base + e] * (1.0 / (eo[i] + eo[j] - eab + shift));
+        dtc[base + e] = x;
+        tc[base + e] += delta * x;
+    }
+}
+// residual_assemble for the pairs [r0,r1) with compact output; Np[a - a0][b][o*o] already holds the complete
+// X_ac / Q_kb combination N_ab + N_ba^T of the pair (its rows a are what the owner of the pair computes)
+__global__ void __launch_bounds__(256) residual_assemble_pairs_kernel(const double* __restrict__ V, const double* __restrict__ L,
+                                                                      const double* __restrict__ Np, const double* __restrict__ D,
+                                                                      const double* __restrict__ X, double* __restrict__ Rc,
+                                                                      int no, int nv, long r0, int a0) {
+    extern __shared__ double S[];             // [no][no + 1]
+    int a, b;
+    unrank_pair(r0 + blockIdx.x, a, b);
+    const int p = no + 1;
+    const long o2 = (long)no * no, ov = (long)no * nv, opp = (long)no * (no + 1) / 2;
+    const long ab = ((long)a * nv + b) * o2, ba = ((long)b * nv + a) * o2;
+    const long tab = (long)a * no * ov + (long)b * no, tba = (long)b * no * ov + (long)a * no;
+    const double* __restrict__ n = Np + ((long)(a - a0) * nv + b) * o2;
+    for (int e = threadIdx.x; e < o2; e += blockDim.x) {
+        const int i = e / no, j = e - i * no;
+        S[i * p + j] = n[e] + D[tab + (long)i * ov + j] + X[tba + (long)i * ov + j];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < o2; e += blockDim.x) {
+        const int j = e / no, i = e - j * no;
+        S[i * p + j] += D[tba + (long)j * ov + i] + X[tab + (long)j * ov + i];
+    }
+    __syncthreads();
+    const double* __restrict__ row = L ? L + ((long)a * (a + 1) / 2 + b) * o2 : nullptr;
+    double* __restrict__ out = Rc + (long)blockIdx.x * 2 * o2;
+    for (int e = threadIdx.x; e < o2; e += blockDim.x) {
+        const int i = e / no, j = e - i * no;
+        const int ih = max(i, j), il = min(i, j);
+        double ls = 0.0, la = 0.0;
+        if (row) {
+            ls = row[(long)ih * (ih + 1) / 2 + il];
+            if (a != b && i != j) la = row[opp + (long)ih * (ih - 1) / 2 + il];
+        }
+        const double sgn = i > j ? 1.0 : -1.0;
+        out[e] = V[ab + e] + ls + sgn * la + S[i * p + j];
+        out[o2 + e] = (a != b) ? V[ba + e] + ls - sgn * la + S[j * p + i] : 0.0;
+    }
+}
+
 // out[r][i][j] = Q[r][P(i,j)] + sgn(i-j) Q[r][opp + Q(i,j)]   (rows are plain, not pair-packed)
 __global__ void rows_unpack_kernel(const double* __restrict__ Q, double* __restrict__ out, int no, long total) {
     const long opp = (long)no * (no + 1) / 2, ld = (long)no * no;
@@ -1659,6 +1745,33 @@ double tc_triple_contraction(const double* L, int nb, int no, stream_t s) {
     HIP_CHECK(e1);
     HIP_CHECK(e2);
     return h;
+}
+
+void pairs_pack(const double* full, double* Xc, int no, int nv, int64_t r0, int64_t r1, stream_t s) {
+    if (r1 <= r0) return;
+    hipLaunchKernelGGL(pairs_pack_kernel, dim3((unsigned)(r1 - r0)), dim3(256), 0, (hipStream_t)s, full, Xc, no, nv, (long)r0);
+    HIP_CHECK(hipGetLastError());
+}
+void pairs_unpack(const double* Xc, double* full, int no, int nv, int64_t r0, int64_t r1, stream_t s) {
+    if (r1 <= r0) return;
+    hipLaunchKernelGGL(pairs_unpack_kernel, dim3((unsigned)(r1 - r0)), dim3(256), 0, (hipStream_t)s, Xc, full, no, nv, (long)r0);
+    HIP_CHECK(hipGetLastError());
+}
+void cc_update_pairs(double* tc, double* dtc, const double* rc, const double* eo, const double* ev, double shift,
+                     double delta, int no, int nv, int64_t r0, int64_t r1, stream_t s) {
+    if (r1 <= r0) return;
+    hipLaunchKernelGGL(cc_update_pairs_kernel, dim3((unsigned)(r1 - r0)), dim3(256), 0, (hipStream_t)s, tc, dtc, rc, eo, ev,
+                       shift, delta, no, (long)r0);
+    HIP_CHECK(hipGetLastError());
+}
+void residual_assemble_pairs(const double* V, const double* L, const double* Np, const double* D, const double* X,
+                             double* Rc, int no, int nv, int64_t r0, int64_t r1, int a0, stream_t s) {
+    if (r1 <= r0) return;
+    if (!fused_pair_kernels_ok(no)) throw std::runtime_error("residual_assemble_pairs: nocc too large for the LDS tile");
+    const size_t lds = sizeof(double) * no * (no + 1);
+    hipLaunchKernelGGL(residual_assemble_pairs_kernel, dim3((unsigned)(r1 - r0)), dim3(256), lds, (hipStream_t)s, V, L, Np,
+                       D, X, Rc, no, nv, (long)r0, a0);
+    HIP_CHECK(hipGetLastError());
 }
 
 void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t s) {

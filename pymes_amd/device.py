@@ -289,6 +289,31 @@ class Context:
                       C.c_void_p(QK.ptr if QK is not None else 0))
         return out
 
+    # ---- pair-sharded tail (include/pymes_amd.h) ----------------------------------------------------------------
+    def residual_finish_pairs(self, f, t2, ETd, ETx, L, Rc, rank, world, t1, QK, is_dcd=False, dressed=False):
+        self.lib.call("pymes_residual_finish_pairs", self.handle, C.c_void_p(f.ptr), C.c_void_p(t2.ptr),
+                      C.c_void_p(ETd.ptr), C.c_void_p(ETx.ptr), C.c_void_p(L.ptr), C.c_void_p(Rc.ptr),
+                      self._flags(is_dcd, dressed, False, True, True), C.c_void_p(t1.ptr), C.c_void_p(QK.ptr),
+                      int(rank), int(world))
+        return Rc
+
+    def cc_update_pairs(self, tc, dtc, rc, shift, delta, rank, world):
+        self.lib.call("pymes_cc_update_pairs", self.handle, C.c_void_p(tc.ptr), C.c_void_p(dtc.ptr), C.c_void_p(rc.ptr),
+                      float(shift), float(delta), int(rank), int(world))
+
+    def pairs_supported(self):
+        yes = C.c_int()
+        self.lib.call("pymes_pairs_supported", self.handle, C.byref(yes))
+        return bool(yes.value)
+
+    def pairs_pack(self, full, xc, rank, world):
+        self.lib.call("pymes_pairs_pack", self.handle, C.c_void_p(full.ptr), C.c_void_p(xc.ptr), int(rank), int(world))
+        return xc
+
+    def pairs_unpack(self, xc_all, full, world):
+        self.lib.call("pymes_pairs_unpack", self.handle, C.c_void_p(xc_all.ptr), C.c_void_p(full.ptr), int(world))
+        return full
+
     def dress_abcd_rows(self, t1, a_begin, a_end, lower_only=False):
         self.lib.call("pymes_ccsd_dress_abcd_rows", self.handle, C.c_void_p(t1.ptr), int(a_begin), int(a_end),
                       int(lower_only))

@@ -56,6 +56,20 @@ def exchange_rows(full, rank, world_size):
     return full
 
 
+def allreduce_sum(vec):
+    """Sum of a small float64 numpy vector over the ranks (identical result on every rank)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return np.asarray(vec, dtype=np.float64)
+    t = torch.from_numpy(np.array(vec, dtype=np.float64, copy=True))
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
 class _Done:
     def wait(self):
         return True

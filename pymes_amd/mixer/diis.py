@@ -43,12 +43,14 @@ class DIIS:
             return np.dot(vec[:, ok] * (1.0 / lam[ok]), np.dot(vec[:, ok].T.conj(), unit))
         return np.linalg.inv(self.L).dot(unit)
 
-    def mix(self, error, amplitude, release=None):
+    def mix(self, error, amplitude, release=None, sharded=(), allreduce=None):
         """error / amplitude: lists of DeviceArray (one entry per amplitude type).
         Returns freshly allocated DeviceArrays with the extrapolated amplitudes.  The
         mixer keeps references to the arrays passed in (like the reference): the caller must
         not modify them afterwards.  ``release(arr)`` is called for vectors that leave the
-        subspace so a caller-side pool can recycle their memory."""
+        subspace so a caller-side pool can recycle their memory.  ``sharded``: indices of the amplitude types of which
+        this process holds only its share (one process per GPU); their overlaps are summed over the ranks with
+        ``allreduce`` (a callable on a small numpy vector), the extrapolation itself is local."""
         was_full = len(self.error_list) == self.dim_space
         if was_full:
             old_e, old_a = self.error_list.pop(0), self.amplitude_list.pop(0)
@@ -61,7 +63,8 @@ class DIIS:
         m, ntypes = len(self.error_list), len(error)
         overlaps = np.zeros(m)
         for nt in range(ntypes):
-            overlaps += ctx.dots([self.error_list[i][nt] for i in range(m)], [error[nt]] * m)
+            part = ctx.dots([self.error_list[i][nt] for i in range(m)], [error[nt]] * m)
+            overlaps += allreduce(part) if nt in sharded else part
         self._update_L(overlaps, was_full)
         c = self._solve()
         self.last_coefficients = c

@@ -23,7 +23,8 @@ def torch_sync():
     """torch.distributed collectives are ordered on torch's current stream; the engine runs on the same
     stream (bench.py passes it) but a host-side fence keeps the hand-off obviously correct."""
     import torch
-    torch.cuda.current_stream().synchronize()
+    if torch.cuda.is_available():
+        torch.cuda.current_stream().synchronize()
 
 # blocks produced by get_T1_dressed_V (ccsd.py:322-419); the other five names stay None (:317)
 DRESSED_KEYS = ("abij", "klij", "ijab", "ijka", "ijak", "iajb", "iabj", "iabc", "abic", "iajk", "abcd")
@@ -78,13 +79,18 @@ class CCSD(ccd.CCD):
         if amps is not None:
             t2h = np.asarray(amps[1])
             st["sym"] = bool(np.abs(t2h - t2h.transpose(1, 0, 3, 2)).max() <= 1e-13 * max(1.0, np.abs(t2h).max()))
-        if self.is_diis:     # DIIS keeps dim_space (dT, T) pairs + the mixed result + residual/update scratch
-            ctx.pool_reserve(t2.shape, 2 * self.mixer.dim_space + 4)
-            ctx.pool_reserve(t1.shape, 2 * self.mixer.dim_space + 4)
         st["npp"] = nv * (nv + 1) // 2
+        # world > 1: every rank keeps T2-sized quantities (residual, update, DIIS history) only for the virtual pairs it
+        # owns ("pair-sharded tail", include/pymes_amd.h); user amplitudes keep the replicated tail (in-place contract)
+        st["pairs"] = bool(wsize > 1 and st["sym"] and amps is None and ctx.pairs_supported())
+        lo, hi = pdist.slab_rows(st["npp"], rank, wsize)
+        st["cshape"] = (max(hi - lo, 1), 2, no * no)
+        if self.is_diis:     # DIIS keeps dim_space (dT, T) pairs + the mixed result + residual/update scratch
+            ctx.pool_reserve(st["cshape"] if st["pairs"] else t2.shape, 2 * self.mixer.dim_space + 4)
+            ctx.pool_reserve(t1.shape, 2 * self.mixer.dim_space + 4)
         if wsize > 1:
             import torch
-            dev = torch.device("cuda", ctx.device)
+            dev = torch.device("cuda", ctx.device) if ctx.lib.backend.startswith("hip") else torch.device("cpu")
 
             def shared(rows, cols):      # exchange buffer: world equal row chunks, torch-owned for the collective
                 t = torch.zeros((pdist.padded_rows(rows, wsize), cols), dtype=torch.float64, device=dev)
@@ -94,6 +100,10 @@ class CCSD(ccd.CCD):
                 st["ETx_t"], st["ETx"] = shared(no * nv, no * nv)
                 st["L_t"], st["L"] = shared(st["npp"], no * no)
                 st["QK_t"], st["QK"] = shared(no * nv, no * no)
+                if st["pairs"]:
+                    st["Tall_t"], st["Tall"] = shared(st["npp"], 2 * no * no)       # exchange buffer of the compact T2
+                    st["Tc"] = self._compact(ctx, st)
+                    ctx.pairs_pack(t2, st["Tc"], rank, wsize)
             else:
                 st["lad_rows"] = nv * nv
                 st["lad_t"], st["lad"] = shared(nv * nv, no * no)
@@ -123,13 +133,17 @@ class CCSD(ccd.CCD):
             pending = []
             if world > 1:
                 ctx.sync()
-                pending = [pdist.exchange_rows_start(st[key], rank, world) for key in ("ETd_t", "ETx_t", "L_t", "QK_t")]
+                keys = ("ETd_t", "ETx_t", "QK_t") if st["pairs"] else ("ETd_t", "ETx_t", "L_t", "QK_t")
+                pending = [pdist.exchange_rows_start(st[key], rank, world) for key in keys]
             ctx.singles_residual(st["fd"], t1, t2, r1)                                # :167
             ctx.dress_V(t1, ("abij",), reduced_abij=True)                             # :165
             for work in pending:
                 work.wait()
             if world > 1:
                 torch_sync()
+            if st["pairs"]:
+                ctx.pool_put(r2)
+                return self._pair_sharded_tail(st, r1)
             ctx.residual_finish(st["fd"], t2, st["ETd"], st["ETx"], st["L"], r2, is_dcd=self.is_dcd, dressed=True,
                                 t1=t1, QK=st["QK"])
             world = 0           # handled
@@ -172,6 +186,48 @@ class CCSD(ccd.CCD):
         return e[0], e[1], e[2], nt, nr
 
     @staticmethod
+    def _compact(ctx, st):
+        """A buffer for the compact tiles of this rank's pairs; zeroed when the rank owns no pair at all."""
+        lo, hi = pdist.slab_rows(st["npp"], st["rank"], st["world"])
+        arr = ctx.pool_get(st["cshape"])
+        return arr.zero_() if hi <= lo else arr
+
+    def _pair_sharded_tail(self, st, r1):
+        """Rest of the loop body (ccsd.py:171-197) when every rank owns a chunk of the virtual pairs: R2, the update,
+        the DIIS history and extrapolation exist only for the rank's pairs (compact tiles); the new T2 is all-gathered
+        (0.8 GB at (50,200)) and unpacked into the replicated full array that the next residual reads."""
+        ctx, t1, t2 = st["ctx"], st["t1"], st["t2"]
+        rank, world, shift = st["rank"], st["world"], st["level_shift"]
+        rc = self._compact(ctx, st)
+        ctx.residual_finish_pairs(st["fd"], t2, st["ETd"], st["ETx"], st["L"], rc, rank, world, t1, st["QK"],
+                                  is_dcd=self.is_dcd, dressed=True)                  # :171
+        dt1, dtc, tc = ctx.pool_get(t1.shape), self._compact(ctx, st), st["Tc"]
+        ctx.cc_update(t1, dt1, r1, shift, self.delta)                                 # :176-179
+        ctx.cc_update_pairs(tc, dtc, rc, shift, self.delta, rank, world)
+        ctx.pool_put(r1)
+        ctx.pool_put(rc)
+        st["first"] = False
+        if self.is_diis:
+            t1, tc = self.mixer.mix([dt1, dtc], [t1, tc], release=ctx.pool_put, sharded=(1,),
+                                    allreduce=pdist.allreduce_sum)                    # :181-183
+        lo, hi = pdist.slab_rows(st["npp"], rank, world)
+        if hi > lo:
+            mine = DeviceArray(ctx, st["Tall"].ptr + 8 * lo * 2 * ctx.no * ctx.no, (hi - lo, 2, ctx.no * ctx.no),
+                               owned=False, keepalive=st["Tall"])
+            mine.copy_from(DeviceArray(ctx, tc.ptr, mine.shape, owned=False, keepalive=tc))
+        ctx.sync()
+        pdist.exchange_rows(st["Tall_t"], rank, world)
+        torch_sync()
+        ctx.pairs_unpack(st["Tall"], t2, world)
+        e = ctx.ccsd_energy(st["f"], t1, t2)                                          # :189-192
+        nt, nr = np.sqrt(pdist.allreduce_sum(ctx.dots([tc, dtc], [tc, dtc])))        # :196-197
+        if not self.is_diis:
+            ctx.pool_put(dt1)
+            ctx.pool_put(dtc)
+        st["t1"], st["Tc"] = t1, tc
+        return e[0], e[1], e[2], nt, nr
+
+    @staticmethod
     def _ladder_rows_plain(ctx, t2, lad, lo, hi):
         """Rows [lo,hi) of R[(a,b),(i,j)] = V[(a,b),(c,d)] T[(c,d),(i,j)] (unsymmetric amplitudes only)."""
         nv, no = ctx.nv, ctx.no
@@ -196,6 +252,7 @@ class CCSD(ccd.CCD):
             print_logging_info("Using DIIS mixer: ", self.is_diis, level=1)
             print_logging_info("Iteration = 0", level=1)
             st = self.setup(t_fock_pq, ints, level_shift, amps)
+            self.pair_sharded = st["pairs"]          # which tail the iterations use (world > 1 only)
             e_mp2 = st["e_mp2"]
             dE = np.abs(e_mp2)
             iteration = 0

@@ -273,6 +273,80 @@ double tc_triple_contraction(const double* L, int nb, int no, stream_t) {
     return -acc / 6.0;
 }
 
+namespace {
+inline void unrank_pair_h(int64_t r, int& a, int& b) {
+    a = 0;
+    while ((int64_t)(a + 1) * (a + 2) / 2 <= r) ++a;
+    b = (int)(r - (int64_t)a * (a + 1) / 2);
+}
+}  // namespace
+void pairs_pack(const double* full, double* Xc, int no, int nv, int64_t r0, int64_t r1, stream_t) {
+    const int64_t o2 = (int64_t)no * no;
+    for (int64_t r = r0; r < r1; ++r) {
+        int a, b;
+        unrank_pair_h(r, a, b);
+        for (int64_t e = 0; e < o2; ++e) {
+            Xc[(r - r0) * 2 * o2 + e] = full[((int64_t)a * nv + b) * o2 + e];
+            Xc[(r - r0) * 2 * o2 + o2 + e] = a != b ? full[((int64_t)b * nv + a) * o2 + e] : 0.0;
+        }
+    }
+}
+void pairs_unpack(const double* Xc, double* full, int no, int nv, int64_t r0, int64_t r1, stream_t) {
+    const int64_t o2 = (int64_t)no * no;
+    for (int64_t r = r0; r < r1; ++r) {
+        int a, b;
+        unrank_pair_h(r, a, b);
+        for (int64_t e = 0; e < o2; ++e) {
+            full[((int64_t)a * nv + b) * o2 + e] = Xc[(r - r0) * 2 * o2 + e];
+            if (a != b) full[((int64_t)b * nv + a) * o2 + e] = Xc[(r - r0) * 2 * o2 + o2 + e];
+        }
+    }
+}
+void cc_update_pairs(double* tc, double* dtc, const double* rc, const double* eo, const double* ev, double shift,
+                     double delta, int no, int nv, int64_t r0, int64_t r1, stream_t) {
+    (void)nv;
+    const int64_t o2 = (int64_t)no * no;
+    for (int64_t r = r0; r < r1; ++r) {
+        int a, b;
+        unrank_pair_h(r, a, b);
+        for (int64_t e = 0; e < 2 * o2; ++e) {
+            const int64_t t = e % o2;
+            const int i = (int)(t / no), j = (int)(t % no);
+            const int64_t k = (r - r0) * 2 * o2 + e;
+            const double x = rc[k] * (1.0 / (eo[i] + eo[j] - (ev[a] + ev[b]) + shift));
+            dtc[k] = x;
+            tc[k] += delta * x;
+        }
+    }
+}
+void residual_assemble_pairs(const double* V, const double* L, const double* Np, const double* D, const double* X,
+                             double* Rc, int no, int nv, int64_t r0, int64_t r1, int a0, stream_t) {
+    const int64_t o2 = (int64_t)no * no, ov = (int64_t)no * nv, opp = (int64_t)no * (no + 1) / 2;
+    auto pm = [&](const double* M, int a, int i, int b, int j) { return M[((int64_t)a * no + i) * ov + b * no + j]; };
+    for (int64_t r = r0; r < r1; ++r) {
+        int a, b;
+        unrank_pair_h(r, a, b);
+        const double* row = L ? L + r * o2 : nullptr;
+        for (int i = 0; i < no; ++i)
+            for (int j = 0; j < no; ++j) {
+                auto S = [&](int x, int y) {
+                    return Np[((int64_t)(a - a0) * nv + b) * o2 + x * no + y] + pm(D, a, x, b, y) + pm(D, b, y, a, x) +
+                           pm(X, a, y, b, x) + pm(X, b, x, a, y);
+                };
+                const int ih = i > j ? i : j, il = i > j ? j : i;
+                double ls = 0.0, la = 0.0;
+                if (row) {
+                    ls = row[P2(ih, il)];
+                    if (a != b && i != j) la = row[opp + Q2(ih, il)];
+                }
+                const double sgn = i > j ? 1.0 : -1.0;
+                const int64_t e = (int64_t)i * no + j;
+                Rc[(r - r0) * 2 * o2 + e] = V[((int64_t)a * nv + b) * o2 + e] + ls + sgn * la + S(i, j);
+                Rc[(r - r0) * 2 * o2 + o2 + e] = a != b ? V[((int64_t)b * nv + a) * o2 + e] + ls - sgn * la + S(j, i) : 0.0;
+            }
+    }
+}
+
 void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t) {
     const int64_t opp = (int64_t)no * (no + 1) / 2, ld = (int64_t)no * no;
     for (int64_t r = 0; r < rows; ++r)

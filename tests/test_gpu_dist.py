@@ -1,6 +1,7 @@
 """GPU: the distributed CCSD iteration end to end with TWO ranks sharing the one GPU of the test box
-(gloo staging instead of RCCL, see pymes_amd/dist.py): slab/finish residual, row-restricted dressing,
-three all-gathers per iteration — must reproduce the single-rank energies."""
+(gloo staging instead of RCCL, see pymes_amd/dist.py): slab residual, overlapped all-gathers, pair-sharded tail
+(compact R2 / update / DIIS with all-reduced overlaps, all-gather of the new T2) — must reproduce the single-rank
+energies and iteration counts."""
 import contextlib
 import io
 import json
@@ -31,6 +32,7 @@ def _worker(rank, world, port, out):
             s = CCSD(no, delta_e=1e-10, is_dcsd=dcsd, device=0)
             with contextlib.redirect_stdout(io.StringIO()):
                 r = s.solve(f, ints)
+            assert s.pair_sharded
             ints.ctx.close()
             res[f"syn_{no}_{nv}_{'dcsd' if dcsd else 'ccsd'}"] = (float(r["ccsd e"]), int(s.iterations))
         # unsymmetric user amplitudes take the plain-ladder sharded path
