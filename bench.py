@@ -157,7 +157,8 @@ def main():
                                    f"integrals (nocc={no}, nvirt={nv}), seed {args.seed}",
                        "no": no, "nv": nv, "diis": not args.no_diis,
                        "parallelism": "single GPU" if world == 1 else
-                       f"ring-product column slabs + packed-ladder rows over {world} ranks, 4 all-gathers/iteration "
+                       f"ring-product column slabs + packed-ladder / Q_kb rows + pair-sharded update and DIIS over {world} ranks; "
+                       f"all-gathers of ETd, ETx, Q_kb (overlapped) and T2 per iteration "
                        f"({args.backend})"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
