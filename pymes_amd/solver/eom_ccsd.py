@@ -67,6 +67,12 @@ class _Sigma:
         self.Ud = c.permute("kaic->aick", V["iajb"])           # Ud[(a,i),(c,k)] = V_iajb[k,a,i,c]
         self.M2 = c.empty(self.M1.shape)
         c.lincomb(self.M2, [self.M_D, self.M_C, self.Ud], [1.0, -2.0, -1.0])
+        # for exchange-symmetric trial doubles ut = 2 u2 - u2^(ab) is 2 u2d - u2x in the pair layout, so
+        # M1.utd + M2.u2d + M_C.u2x = (2 M1 + M2).u2d + (M_C - M1).u2x: two products instead of three
+        self.M12 = c.empty(self.M1.shape)
+        c.lincomb(self.M12, [self.M1, self.M2], [2.0, 1.0])
+        self.MC1 = c.empty(self.M1.shape)
+        c.lincomb(self.MC1, [self.M_C, self.M1], [1.0, -1.0])
         del M_A, M_B, Vd, Vx, Vq, Tq
         # small hoisted V.T blocks
         self.A3 = c.contract("klci,cbkj->libj", V["ijak"], T, alpha=-2.0)                 # A_oovo
@@ -82,6 +88,19 @@ class _Sigma:
         c.contract("kldc,cdki->li", V["ijab"], T, out=self.Goo, alpha=1.0, beta=1.0)
         self.B2 = c.permute("klij->klij", V["klij"])
         c.contract("klcd,cdij->klij", V["ijab"], T, out=self.B2, alpha=1.0, beta=1.0)
+        # particle ladder (:383): pair-packed form (1/4 of the flops) whenever V_abcd = V_badc and the trial doubles
+        # are exchange-symmetric, u2_abij = u2_baji — true for every vector the Davidson driver generates
+        tmp = c.permute("badc->abcd", V["abcd"])
+        c.lincomb(tmp, [tmp, V["abcd"]], [1.0, -1.0])
+        self.v_sym = bool(c.dots([tmp], [tmp])[0] <= 1e-26 * max(1.0, c.dots([V["abcd"]], [V["abcd"]])[0]))
+        del tmp
+        self.L = c.empty((nv * (nv + 1) // 2, no * no)) if self.v_sym else None
+
+    def _exchange_symmetric(self, u2):
+        c = self.ctx
+        d = c.permute("baji->abij", u2)
+        c.lincomb(d, [d, u2], [1.0, -1.0])
+        return bool(c.dots([d], [d])[0] <= 1e-26 * max(1.0, c.dots([u2], [u2])[0]))
 
     # ------------------------------------------------------------------------------------------
     def singles(self, u1, u2):
@@ -102,12 +121,17 @@ class _Sigma:
         c, V, T = self.ctx, self.V, self.T
         u2d = c.permute("abij->aibj", u2)
         u2x = c.permute("abij->ajbi", u2)
-        utd = c.permute("abij->aibj", u2, alpha=2.0)                  # ut[d,b,l,j] = 2u2[d,b,l,j] - u2[b,d,l,j]
-        c.permute("baij->aibj", u2, out=utd, alpha=-1.0, beta=1.0)
+        u2_sym = self._exchange_symmetric(u2)
         # ---- (ov)^3 products -----------------------------------------------------------------------
-        Dd = c.contract("aidl,dlbj->aibj", self.M1, utd)
-        c.contract("aidl,dlbj->aibj", self.M2, u2d, out=Dd, beta=1.0)
-        c.contract("aidl,dlbj->aibj", self.M_C, u2x, out=Dd, beta=1.0)          # u2x[(d,l),(b,j)] = u2[d,b,j,l]
+        if u2_sym:
+            Dd = c.contract("aidl,dlbj->aibj", self.M12, u2d)
+            c.contract("aidl,dlbj->aibj", self.MC1, u2x, out=Dd, beta=1.0)
+        else:
+            utd = c.permute("abij->aibj", u2, alpha=2.0)              # ut[d,b,l,j] = 2u2[d,b,l,j] - u2[b,d,l,j]
+            c.permute("baij->aibj", u2, out=utd, alpha=-1.0, beta=1.0)
+            Dd = c.contract("aidl,dlbj->aibj", self.M1, utd)
+            c.contract("aidl,dlbj->aibj", self.M2, u2d, out=Dd, beta=1.0)
+            c.contract("aidl,dlbj->aibj", self.M_C, u2x, out=Dd, beta=1.0)      # u2x[(d,l),(b,j)] = u2[d,b,j,l]
         Dx = c.contract("ajdl,dlbi->ajbi", self.M_D, u2x)                         # :372  u2[d,b,i,l]
         c.contract("ajck,bick->ajbi", u2x, self.Ud, out=Dx, alpha=-1.0, beta=1.0)  # :364
         Cd = c.contract("kacd,di->aick", V["iabc"], u1)                           # sum_d V[k,a,c,d] u1[d,i]
@@ -147,7 +171,11 @@ class _Sigma:
         c.contract("abkl,klij->abij", u2, self.B2, out=D, beta=1.0)               # :380, :382
         Bn = c.contract("kldc,dcij->klij", V["ijab"], u2)
         c.contract("abkl,klij->abij", T, Bn, out=D, beta=1.0)                     # :381
-        c.contract("abcd,cdij->abij", V["abcd"], u2, out=D, beta=1.0)             # :383
+        if self.v_sym and u2_sym:                                                 # :383
+            c.ladder_sym(u2, self.L, 0, self.L.shape[0])
+            c.ladder_sym_unpack(self.L, D, beta=1.0)
+        else:
+            c.contract("abcd,cdij->abij", V["abcd"], u2, out=D, beta=1.0)
         return D
 
     def apply(self, u1, u2):

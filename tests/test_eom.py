@@ -76,6 +76,17 @@ def run_product(lib, monkeypatch):
         assert np.abs(e.get_diag_doubles(f, Vb, t2) - g["d2"]).max() < 1e-12
         with pytest.raises(TypeError):
             e.update_singles(f.astype(complex), Vb, u1, u2, t2)
+    # exchange-symmetric integrals and trial doubles: the pair-packed particle ladder must give the same sigma
+    no, nv = 3, 5
+    f, V, t1, t2 = random_case(no, nv, 77, symmetric=True)
+    rng = np.random.default_rng(78)
+    u1, u2 = rng.standard_normal((nv, no)), rng.standard_normal((nv, nv, no, no))
+    u2 = u2 + u2.transpose(1, 0, 3, 2)
+    Vb = oc.split_blocks(no, V)
+    e = EOM_CCSD(no, 2)
+    assert np.abs(e.update_doubles(f, Vb, u1, u2, t2) - eo.sigma_doubles(no, f, Vb, u1, u2, t2)).max() < 1e-11
+    u2[0, 1, 0, 1] += 0.5                 # not symmetric any more: falls back to the plain ladder
+    assert np.abs(e.update_doubles(f, Vb, u1, u2, t2) - eo.sigma_doubles(no, f, Vb, u1, u2, t2)).max() < 1e-11
     for tag in ("LiH.sto6g", "H2.ccpvdz"):
         no, fd, Vd, t2 = ground_state(tag)
         e = EOM_CCSD(no, n_excit=2)

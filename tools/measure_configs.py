@@ -131,7 +131,8 @@ def c5(args):
     t_hoist = time.perf_counter() - t0
     rng = np.random.default_rng(0)
     u1 = ctx.array(rng.standard_normal((nv, no)))
-    u2 = ctx.array(rng.standard_normal((nv, nv, no, no)))
+    u2h = rng.standard_normal((nv, nv, no, no))
+    u2 = ctx.array(u2h + u2h.transpose(1, 0, 3, 2))          # exchange-symmetric, like every Davidson vector
     dt = timed(lambda: sig.apply(u1, u2), ctx.sync, 5)
     flops = 2.0 * (6.4e9 + 1.502e12)
     out = {"config": "C5 one EOM-CCSD sigma build (singles + doubles), synthetic (nocc=30, nvirt=120)", "gpu_s": dt,
