@@ -96,7 +96,7 @@ class _Sigma:
         del tmp
         self.L = c.empty((nv * (nv + 1) // 2, no * no)) if self.v_sym else None
 
-    def _exchange_symmetric(self, u2):
+    def exchange_symmetric(self, u2):
         c = self.ctx
         d = c.permute("baji->abij", u2)
         c.lincomb(d, [d, u2], [1.0, -1.0])
@@ -116,12 +116,14 @@ class _Sigma:
         c.contract("jabc,bcji->ai", V["iabc"], ut, out=s, beta=1.0)
         return s
 
-    def doubles(self, u1, u2):
-        """eom_ccsd.py:312-385."""
+    def doubles(self, u1, u2, u2_sym=None):
+        """eom_ccsd.py:312-385.  ``u2_sym``: the caller's knowledge that u2_abij = u2_baji (checked here, with a
+        device-to-host synchronisation, when None)."""
         c, V, T = self.ctx, self.V, self.T
         u2d = c.permute("abij->aibj", u2)
         u2x = c.permute("abij->ajbi", u2)
-        u2_sym = self._exchange_symmetric(u2)
+        if u2_sym is None:
+            u2_sym = self.exchange_symmetric(u2)
         # ---- (ov)^3 products -----------------------------------------------------------------------
         if u2_sym:
             Dd = c.contract("aidl,dlbj->aibj", self.M12, u2d)
@@ -178,8 +180,8 @@ class _Sigma:
             c.contract("abcd,cdij->abij", V["abcd"], u2, out=D, beta=1.0)
         return D
 
-    def apply(self, u1, u2):
-        return self.singles(u1, u2), self.doubles(u1, u2)
+    def apply(self, u1, u2, u2_sym=None):
+        return self.singles(u1, u2), self.doubles(u1, u2, u2_sym)
 
 
 class EOM_CCSD:
@@ -238,8 +240,12 @@ class EOM_CCSD:
                 dim = len(us)
                 us = self._orthonormalise(ctx, us)                               # :91
                 ws = []
+                # exchange symmetry of the trial doubles, decided here (between the sigma builds) so that the builds
+                # themselves run without host synchronisation
+                sym = [sig.exchange_symmetric(self._part(ctx, u, n1, (nv, nv, no, no))) for u in us]
                 for l in range(dim):                                             # :95-101
-                    s1, s2 = sig.apply(self._part(ctx, us[l], 0, (nv, no)), self._part(ctx, us[l], n1, (nv, nv, no, no)))
+                    s1, s2 = sig.apply(self._part(ctx, us[l], 0, (nv, no)), self._part(ctx, us[l], n1, (nv, nv, no, no)),
+                                       u2_sym=sym[l])
                     w = ctx.empty((n1 + n2,))
                     self._part(ctx, w, 0, (nv, no)).copy_from(s1)
                     self._part(ctx, w, n1, (nv, nv, no, no)).copy_from(s2)
