@@ -118,15 +118,13 @@ class CCSD(ccd.CCD):
         shift = st["level_shift"]
         ctx.dress_fock(st["f"], t1, st["fd"])                        # :163
         r1 = ctx.pool_get(t1.shape)
-        r2 = ctx.pool_get(t2.shape)
         world, rank = st["world"], st["rank"]
         if st["sym"]:
             # Symmetry-reduced, sharded form (world = 1 included): this rank's column slab of the ring products,
-            # its rows of the pair-packed particle + hole ladders and of Q_kb; four all-gathers; replicated
-            # remainder.  V_abcd is never dressed: its T1 dressing (:165, ccsd.py:414-419) is carried by
-            # tau = T2 + T1 T1 inside the ladders (include/pymes_amd.h, pymes_residual_slab).
-            # The replicated work that the slab does not need (R1, V~_abij) is enqueued after the all-gathers
-            # have been started, so that it overlaps with the transfers.
+            # its rows of the pair-packed particle + hole ladders and of Q_kb; all-gathers; remainder.
+            # V_abcd is never dressed: its T1 dressing (:165, ccsd.py:414-419) is carried by tau = T2 + T1 T1
+            # inside the ladders (include/pymes_amd.h, pymes_residual_slab).  The replicated work that the slab
+            # does not need (R1, V~_abij) is enqueued after the all-gathers have been started: overlap.
             ctx.dress_V(t1, ("klij", "iajb", "iabj"))                                 # :165
             ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], rank, world, is_dcd=self.is_dcd,
                               dressed=True, t1=t1, QK=st["QK"])                        # :171
@@ -142,30 +140,29 @@ class CCSD(ccd.CCD):
             if world > 1:
                 torch_sync()
             if st["pairs"]:
-                ctx.pool_put(r2)
                 return self._pair_sharded_tail(st, r1)
+            r2 = ctx.pool_get(t2.shape)
             ctx.residual_finish(st["fd"], t2, st["ETd"], st["ETx"], st["L"], r2, is_dcd=self.is_dcd, dressed=True,
                                 t1=t1, QK=st["QK"])
-            world = 0           # handled
-        elif world == 1:
+        else:
+            # general path (user amplitudes without the exchange symmetry): explicitly dressed blocks
+            r2 = ctx.pool_get(t2.shape)
             ctx.singles_residual(st["fd"], t1, t2, r1)                                # :167
             ctx.dress_V(t1, LOOP_KEYS)                                                # :165
-            ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True, sym_ladder=False)   # :171
-        else:
-            ctx.singles_residual(st["fd"], t1, t2, r1)                                # :167
-            # unsymmetric user amplitudes: plain ladder rows on this rank, everything else replicated
-            ctx.dress_V(t1, LOOP_KEYS)
-            lo, hi = pdist.slab_rows(st["lad_rows"], rank, world)
-            if hi > lo:
-                self._ladder_rows_plain(ctx, t2, st["lad"], lo, hi)
-            ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True, skip_ladder=True,
-                                 sym_ladder=False, sym_rings=False)
-            ctx.sync()
-            pdist.exchange_rows(st["lad_t"], rank, world)
-            torch_sync()
-            full = DeviceArray(ctx, st["lad"].ptr, (r2.size,), owned=False, keepalive=st["lad"])
-            r2f = r2.reshape(r2.size)
-            ctx.lincomb(r2f, [r2f, full], [1.0, 1.0])
+            if world == 1:
+                ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True, sym_ladder=False)   # :171
+            else:       # plain ladder rows on this rank (one all-gather), everything else replicated
+                lo, hi = pdist.slab_rows(st["lad_rows"], rank, world)
+                if hi > lo:
+                    self._ladder_rows_plain(ctx, t2, st["lad"], lo, hi)
+                ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True, skip_ladder=True,
+                                     sym_ladder=False, sym_rings=False)
+                ctx.sync()
+                pdist.exchange_rows(st["lad_t"], rank, world)
+                torch_sync()
+                full = DeviceArray(ctx, st["lad"].ptr, (r2.size,), owned=False, keepalive=st["lad"])
+                r2f = r2.reshape(r2.size)
+                ctx.lincomb(r2f, [r2f, full], [1.0, 1.0])
         dt1, dt2 = ctx.pool_get(t1.shape), ctx.pool_get(t2.shape)
         ctx.cc_update(t1, dt1, r1, shift, self.delta)               # :176-179
         ctx.cc_update(t2, dt2, r2, shift, self.delta)
