@@ -87,6 +87,9 @@ int pymes_ccsd_dress_fock(pymes_ctx* ctx, const double* f_dev, const double* t1_
  * pymes_residual_slab/_finish expect when they are given t1 (those terms then travel with the ladders). */
 #define PYMES_DRESS_ABIJ_REDUCED (1u << 16)
 int pymes_ccsd_dress_V(pymes_ctx* ctx, const double* t1_dev, uint32_t block_mask);
+/* the same for the range [q_begin, q_end) of the SECOND index only (blocks whose second index is virtual, e.g.
+ * "iajb", "iabj"): what one rank's column slab of pymes_residual_slab reads — 1/world of the work, no exchange */
+int pymes_ccsd_dress_V_slab(pymes_ctx* ctx, const double* t1_dev, uint32_t block_mask, int q_begin, int q_end);
 /* CCSD.get_singles_residual, ccsd.py:423-438 */
 int pymes_ccsd_singles_residual(pymes_ctx* ctx, const double* fd_dev, const double* t1_dev, const double* t2_dev,
                                 double* r1_dev);

@@ -125,7 +125,13 @@ class CCSD(ccd.CCD):
             # V_abcd is never dressed: its T1 dressing (:165, ccsd.py:414-419) is carried by tau = T2 + T1 T1
             # inside the ladders (include/pymes_amd.h, pymes_residual_slab).  The replicated work that the slab
             # does not need (R1, V~_abij) is enqueued after the all-gathers have been started: overlap.
-            ctx.dress_V(t1, ("klij", "iajb", "iabj"))                                 # :165
+            if world > 1:      # V~_iajb / V~_iabj only for the second-index range that this rank's column slab reads
+                c0, c1 = pdist.slab_rows(ctx.no * ctx.nv, rank, world)
+                ctx.dress_V(t1, ("klij",))                                            # :165
+                if c1 > c0:
+                    ctx.dress_V(t1, ("iajb", "iabj"), q_range=(c0 // ctx.no, -(-c1 // ctx.no)))
+            else:
+                ctx.dress_V(t1, ("klij", "iajb", "iabj"))                             # :165
             ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], rank, world, is_dcd=self.is_dcd,
                               dressed=True, t1=t1, QK=st["QK"])                        # :171
             pending = []

@@ -178,7 +178,14 @@ def sharded_residual_check(lib, cases, worlds, tol):
             for dcd in (False, True):
                 ETd, ETx, L = ctx.zeros((pad(ov), ov)), ctx.zeros((pad(ov), ov)), ctx.zeros((pad(npp), no * no))
                 QK = ctx.zeros((pad(ov), no * no))
+                # every rank dresses only the range of the second index of V_iajb / V_iabj that its column slab reads
+                ctx.V_block("iajb", dressed=True).zero_()
+                ctx.V_block("iabj", dressed=True).zero_()
                 for rank in range(world):
+                    c0 = min(rank * (-(-ov // world)), ov)
+                    c1 = min(c0 + (-(-ov // world)), ov)
+                    if c1 > c0:
+                        ctx.dress_V(dT1, ["iajb", "iabj"], q_range=(c0 // no, -(-c1 // no)))
                     ctx.residual_slab(dF, dT2, ETd, ETx, L, rank, world, is_dcd=dcd, dressed=True, t1=dT1, QK=QK)
                 r2 = ctx.empty(t2.shape)
                 ctx.residual_finish(dF, dT2, ETd, ETx, L, r2, is_dcd=dcd, dressed=True, t1=dT1, QK=QK)
