@@ -183,6 +183,22 @@ int pymes_dots(pymes_ctx* ctx, int npairs, const double* const* x_dev, const dou
 int pymes_lincomb(pymes_ctx* ctx, double* out_dev, int nx, const double* const* x_dev, const double* c_host,
                   int64_t n);
 
+/* ---- FCIDUMP ingestion: pymes/util/fcidump.py:59-163 with a native text parser -------------------
+ * Same semantics as the reference's reader (header by substring match, "value i j k l" -> p r q s, |value| < 1e-19
+ * skipped, the three index-swap images restored but not the electron-exchange one, is_tc: only [q,p,s,r]; a body line
+ * without exactly five fields is an error).
+ *   pymes_fcidump_header:    NELEC, NORB (to size the context)
+ *   pymes_fcidump_read_host: everything on the host, V[n,n,n,n] caller-allocated (the drop-in fcidump.read)
+ *   pymes_fcidump_load:      e_core / eps[n] / h[n,n] on the host, V packed into the context's 16 device blocks like
+ *                            pymes_set_V_pqrs; for NORB > 64 the lines are uploaded in chunks and V_pqrs is filled on
+ *                            the device (it never exists on the host; files whose symmetry-related lines disagree are
+ *                            refused there because the result would depend on the order of the lines). */
+int pymes_fcidump_header(const char* path, int* n_elec, int* n_orb);
+int pymes_fcidump_read_host(const char* path, int is_tc, double* e_core, double* eps_host, double* h_host,
+                            double* V_host);
+int pymes_fcidump_load(pymes_ctx* ctx, const char* path, int is_tc, double* e_core, double* eps_host, double* h_host,
+                       int64_t* n_two_electron_lines);
+
 /* ---- explicit 3-body (transcorrelated) operator ---------------------------------------
  * pymes/util/tcdump.py:52-56: dense fill of L[nb]^6 from (flat index, value) pairs — the host parser hands over
  * unique targets (the last of duplicate entries, as the reference's sequential assignment keeps). */

@@ -5,6 +5,7 @@
 
 #include "../../include/pymes_amd.h"
 #include "engine.h"
+#include "fcidump.h"
 
 using pymes::Engine;
 using pymes::TView;
@@ -379,6 +380,65 @@ int pymes_stats(pymes_ctx* ctx, int reset, int64_t* gemm_calls, double* gemm_flo
         if (permute_calls) *permute_calls = e.stats.permute_calls;
         if (permute_bytes) *permute_bytes = e.stats.permute_bytes;
         if (reset) e.stats = pymes::ContractStats{};
+    });
+}
+int pymes_fcidump_header(const char* path, int* n_elec, int* n_orb) {
+    return guarded([&] {
+        if (!path || !n_elec || !n_orb) throw pymes::Error("null argument");
+        pymes::FcidumpFile f;
+        pymes::parse_fcidump(path, f, true);
+        *n_elec = f.n_elec;
+        *n_orb = f.n_orb;
+    });
+}
+int pymes_fcidump_read_host(const char* path, int is_tc, double* e_core, double* eps, double* h, double* V) {
+    return guarded([&] {
+        if (!path || !e_core || !eps || !h || !V) throw pymes::Error("null argument");
+        pymes::FcidumpFile f;
+        pymes::parse_fcidump(path, f);
+        const size_t n = static_cast<size_t>(f.n_orb);
+        *e_core = f.e_core;
+        std::copy(f.eps.begin(), f.eps.end(), eps);
+        std::copy(f.h.begin(), f.h.end(), h);
+        std::fill(V, V + n * n * n * n, 0.0);
+        pymes::fill_V_host(f, is_tc != 0, V);
+    });
+}
+int pymes_fcidump_load(pymes_ctx* ctx, const char* path, int is_tc, double* e_core, double* eps, double* h,
+                       int64_t* n_lines) {
+    return guarded([&] {
+        if (!path || !e_core || !eps || !h) throw pymes::Error("null argument");
+        pymes::Engine& e = E(ctx);
+        pymes::FcidumpFile f;
+        pymes::parse_fcidump(path, f);
+        if (f.n_orb != e.n) throw pymes::Error("FCIDUMP NORB does not match the context (no + nv)");
+        *e_core = f.e_core;
+        std::copy(f.eps.begin(), f.eps.end(), eps);
+        std::copy(f.h.begin(), f.h.end(), h);
+        if (n_lines) *n_lines = static_cast<int64_t>(f.val.size());
+        const int64_t nn = e.n, n4 = nn * nn * nn * nn;
+        if (nn <= 64) {       // small: the reference's sequential fill, exact for any (even inconsistent) file
+            std::vector<double> V(static_cast<size_t>(n4), 0.0);
+            pymes::fill_V_host(f, is_tc != 0, V.data());
+            e.set_V_full(V.data(), false, nullptr);
+            return;
+        }
+        // large: V_pqrs never exists on the host
+        double* Vd = static_cast<double*>(dev::dmalloc(sizeof(double) * n4));
+        try {
+            dev::memset_zero(Vd, sizeof(double) * n4, e.stream);
+            const int64_t bad = dev::fcidump_fill(Vd, f.val.data(), f.pqrs.data(), static_cast<int64_t>(f.val.size()),
+                                                  e.n, is_tc != 0, e.stream);
+            if (bad)
+                throw pymes::Error(std::to_string(bad) + " FCIDUMP lines disagree with their symmetry images: the result "
+                                   "would depend on the order of the lines (not supported for NORB > 64)");
+            e.set_V_full(Vd, true, nullptr);
+            dev::stream_sync(e.stream);
+        } catch (...) {
+            dev::dfree(Vd);
+            throw;
+        }
+        dev::dfree(Vd);
     });
 }
 int pymes_scatter(pymes_ctx* ctx, double* dst, uint64_t dst_elements, const int64_t* index_host,

@@ -118,6 +118,12 @@ void residual_assemble_pairs(const double* V, const double* L, const double* Np,
 // plain rows of the same [ S | A ] layout: out[r][i][j] = Q[r][P(i,j)] + sgn(i-j) Q[r][o(o+1)/2 + Q(i,j)]
 void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t s);
 
+// ---- FCIDUMP ingestion (pymes/util/fcidump.py:140-149): the two-electron lines (0-based p,q,r,s after the reference's
+// renaming, file order) are written with their symmetry images into the zero-initialised dense V[n]^4 on the device.
+// Returns the number of lines whose images do not all hold the line's value afterwards (0 for consistent files).
+int64_t fcidump_fill(double* V, const double* val_host, const int32_t* pqrs_host, int64_t count, int n, bool is_tc,
+                     stream_t s);
+
 // ---- explicit 3-body (transcorrelated) operator: pymes/util/tcdump.py:52-56, pymes/integral/contraction.py:17-95 ----
 // dst[idx[t]] = val[t] for t < n (host index/value lists, unique targets); L below is dense [nb]^6, (or|ps|qt) order
 void scatter(double* dst, const int64_t* idx_host, const double* val_host, int64_t n, stream_t s);

@@ -1138,6 +1138,31 @@ __global__ void __launch_bounds__(256) tc_triple_kernel(const double* __restrict
     if (threadIdx.x == 0) out[0] = -sh[0] / 6.0;
 }
 
+// FCIDUMP lines -> dense V[n]^4 (fcidump.py:140-149): one thread per line writes the symmetry images in the
+// reference's order.  A second kernel counts lines whose images do not all hold the line's value afterwards, i.e.
+// files whose symmetry-related entries disagree (only there does the order of the lines matter).
+__global__ void fcidump_fill_kernel(double* __restrict__ V, const double* __restrict__ val, const int* __restrict__ pqrs,
+                                    long count, long n, int is_tc, int verify, unsigned long long* __restrict__ bad) {
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < count; t += (long)gridDim.x * blockDim.x) {
+        const long p = pqrs[4 * t], q = pqrs[4 * t + 1], r = pqrs[4 * t + 2], s = pqrs[4 * t + 3];
+        const double x = val[t];
+        long tg[4];
+        int m;
+        if (is_tc) { tg[0] = ((q * n + p) * n + s) * n + r; tg[1] = ((p * n + q) * n + r) * n + s; m = 2; }
+        else {
+            tg[0] = ((p * n + q) * n + r) * n + s; tg[1] = ((r * n + q) * n + p) * n + s;
+            tg[2] = ((r * n + s) * n + p) * n + q; tg[3] = ((p * n + s) * n + r) * n + q; m = 4;
+        }
+        if (!verify) {
+            for (int i = 0; i < m; ++i) V[tg[i]] = x;
+        } else {
+            bool ok = true;
+            for (int i = 0; i < m; ++i) ok = ok && (V[tg[i]] == x);
+            if (!ok) atomicAdd(bad, 1ULL);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // uniform electron gas integrals (ueg.py:265-596)
 // ------------------------------------------------------------------------------------
@@ -1722,6 +1747,38 @@ void scatter(double* dst, const int64_t* idx_host, const double* val_host, int64
     (void)hipFree(idx);
     (void)hipFree(val);
     HIP_CHECK(e);
+}
+
+int64_t fcidump_fill(double* V, const double* val_host, const int32_t* pqrs_host, int64_t count, int n, bool is_tc,
+                     stream_t s) {
+    if (count <= 0) return 0;
+    hipStream_t st = (hipStream_t)s;
+    const int64_t chunk = 1 << 22;                      // lines per upload
+    double* dval = nullptr;
+    int* didx = nullptr;
+    unsigned long long* dbad = nullptr;
+    unsigned long long bad = 0;
+    HIP_CHECK(hipMalloc(&dval, sizeof(double) * std::min(count, chunk)));
+    if (hipMalloc(&didx, sizeof(int) * 4 * std::min(count, chunk)) != hipSuccess || hipMalloc(&dbad, sizeof(bad)) != hipSuccess) {
+        (void)hipFree(dval); (void)hipFree(didx);
+        throw std::runtime_error("fcidump_fill: out of device memory");
+    }
+    hipError_t err = hipMemsetAsync(dbad, 0, sizeof(bad), st);
+    for (int pass = 0; pass < 2 && err == hipSuccess; ++pass)          // fill everything, then verify everything
+        for (int64_t b0 = 0; b0 < count && err == hipSuccess; b0 += chunk) {
+            const int64_t nb = std::min(chunk, count - b0);
+            err = hipMemcpyAsync(dval, val_host + b0, sizeof(double) * nb, hipMemcpyHostToDevice, st);
+            if (err == hipSuccess) err = hipMemcpyAsync(didx, pqrs_host + 4 * b0, sizeof(int) * 4 * nb, hipMemcpyHostToDevice, st);
+            if (err != hipSuccess) break;
+            hipLaunchKernelGGL(fcidump_fill_kernel, dim3(grid_for(nb)), dim3(256), 0, st, V, dval, didx, (long)nb, (long)n,
+                               is_tc ? 1 : 0, pass, dbad);
+            err = hipGetLastError();
+            if (err == hipSuccess) err = hipStreamSynchronize(st);      // the staging buffers are reused
+        }
+    if (err == hipSuccess) err = hipMemcpy(&bad, dbad, sizeof(bad), hipMemcpyDeviceToHost);
+    (void)hipFree(dval); (void)hipFree(didx); (void)hipFree(dbad);
+    HIP_CHECK(err);
+    return (int64_t)bad;
 }
 
 void tc_single_contraction(const double* L, double* D, int nb, int no, stream_t s) {

@@ -234,6 +234,29 @@ void residual_assemble(const double* V, const double* L, const double* N, const 
                 }
 }
 
+int64_t fcidump_fill(double* V, const double* val, const int32_t* pqrs, int64_t count, int n_, bool is_tc, stream_t) {
+    const int64_t n = n_;
+    int64_t bad = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int64_t t = 0; t < count; ++t) {
+            const int64_t p = pqrs[4 * t], q = pqrs[4 * t + 1], r = pqrs[4 * t + 2], s = pqrs[4 * t + 3];
+            int64_t tg[4];
+            int m;
+            if (is_tc) { tg[0] = ((q * n + p) * n + s) * n + r; tg[1] = ((p * n + q) * n + r) * n + s; m = 2; }
+            else {
+                tg[0] = ((p * n + q) * n + r) * n + s; tg[1] = ((r * n + q) * n + p) * n + s;
+                tg[2] = ((r * n + s) * n + p) * n + q; tg[3] = ((p * n + s) * n + r) * n + q; m = 4;
+            }
+            bool ok = true;
+            for (int i = 0; i < m; ++i) {
+                if (pass == 0) V[tg[i]] = val[t];
+                else ok = ok && V[tg[i]] == val[t];
+            }
+            if (!ok) ++bad;
+        }
+    return bad;
+}
+
 void scatter(double* dst, const int64_t* idx, const double* val, int64_t n, stream_t) {
     for (int64_t t = 0; t < n; ++t) dst[idx[t]] = val[t];
 }

@@ -33,3 +33,82 @@ def test_write_read_round_trip(tmp_path, capsys):
     fcidump.write(V, h, ne // 2, e_nuc=ec, file=out)
     ne2, n2, ec2, _, h2, V2 = fcidump.read(out)
     assert (ne2, n2, ec2) == (ne, n, ec) and np.array_equal(V2, V) and np.array_equal(h2, h)
+
+
+def test_native_reader_errors_and_header(tmp_path):
+    """Failure modes of fcidump.py:100-161 in the native parser: blank body line, short line, non-numeric field,
+    unterminated header, index beyond NORB; header fields found by substring match in any order / case."""
+    import pytest
+    p = tmp_path / "F"
+    head = "&FCI NELEC= 2, norb =3 ,MS2=0,\n ORBSYM=1,1,1,\n ISYM=1,\n&END\n"
+    p.write_text(head + " 0.5 1 1 1 1\n 0.25 2 1 2 1\n 1e-20 3 3 3 3\n -1.5 1 0 0 0\n 0.75 2 1 0 0\n 3.0 0 0 0 0\n 4.0 0 0 0 0\n")
+    ne, n, ec, eps, h, V = fcidump.read(str(p))
+    o = oio.read_fcidump(str(p))
+    assert (ne, n, ec) == (2, 3, 4.0) == (o[0], o[1], o[2])
+    assert np.array_equal(eps, o[3]) and np.array_equal(h, o[4]) and np.array_equal(V, o[5]) and V[2, 2, 2, 2] == 0.0
+    for body, exc in ((" 0.5 1 1 1 1\n\n 0.25 2 1 2 1\n", ValueError), (" 0.5 1 1 1\n", ValueError),
+                      (" 0.5 1 1 1 1 1\n", ValueError), (" 0.5D+00 1 1 1 1\n", ValueError),
+                      (" 0.5 1 1 x 1\n", ValueError), (" 0.5 4 1 1 1\n", ValueError)):
+        p.write_text(head + body)
+        with pytest.raises(exc):
+            fcidump.read(str(p))
+    p.write_text("&FCI NORB=2,NELEC=2,\n 0.5 1 1 1 1\n")
+    with pytest.raises(ValueError):
+        fcidump.read(str(p))
+    with pytest.raises(FileNotFoundError):
+        fcidump.read(str(tmp_path / "missing"))
+    # lines whose symmetry images disagree: the later assignment wins, exactly as in the reference's loop
+    p.write_text(head + " 1.0 1 2 1 3\n 2.0 2 1 1 3\n")                 # (12|13) and (21|13) share their images
+    Vc = fcidump.read(str(p))[5]
+    assert np.array_equal(Vc, oio.read_fcidump(str(p))[5]) and Vc[0, 0, 1, 2] == 2.0 and Vc[1, 0, 0, 2] == 2.0
+
+
+def sparse_fcidump(path, n, nelec, lines, seed):
+    """A consistent FCIDUMP with `lines` random two-electron entries (each unordered index set once), some one-electron
+    entries and a core energy."""
+    rng = np.random.default_rng(seed)
+    seen, out = set(), []
+    while len(out) < lines:
+        i, j, k, l = (int(x) for x in rng.integers(1, n + 1, 4))
+        key = frozenset((frozenset(((i, j), (j, i))), frozenset(((k, l), (l, k)))))       # (ij|kl) ~ (ji|kl) ~ (kl|ij) ...
+        if key in seen:
+            continue
+        seen.add(key)
+        out.append(" %.17g %d %d %d %d" % (rng.standard_normal(), i, j, k, l))
+    for i in range(1, n + 1):
+        out.append(" %.17g %d %d 0 0" % (rng.standard_normal(), i, max(1, i - 1)))
+    out.append(" 1.25 0 0 0 0")
+    with open(path, "w") as fh:
+        fh.write("&FCI NORB=%d,NELEC=%d,MS2=0,\n ORBSYM=%s\n ISYM=1,\n&END\n" % (n, nelec, "1," * n))
+        fh.write("\n".join(out) + "\n")
+
+
+def check_read_to_device(lib, monkeypatch, tmp_path, n, nelec, lines):
+    from pymes_amd import _lib
+    from oracle import cc_oracle as oc
+    monkeypatch.setattr(_lib, "_default", lib)
+    path = str(tmp_path / ("FCIDUMP.%d" % n))
+    sparse_fcidump(path, n, nelec, lines, seed=n)
+    ref = oio.read_fcidump(path)
+    ne, norb, ec, eps, h, ints = fcidump.read_to_device(path)
+    try:
+        assert (ne, norb, ec) == (ref[0], ref[1], ref[2]) and np.array_equal(eps, ref[3]) and np.array_equal(h, ref[4])
+        blocks = oc.split_blocks(ne // 2, ref[5])
+        for name in ("abcd", "ijab", "iajb", "klij", "abij", "iabc"):
+            assert np.array_equal(ints.ctx.V_block(name).get(), blocks[name]), name
+    finally:
+        ints.ctx.close()
+
+
+def test_read_to_device_host_logic(hostsim_lib, monkeypatch, tmp_path):
+    check_read_to_device(hostsim_lib, monkeypatch, tmp_path, 12, 6, 3000)      # NORB <= 64: sequential host fill
+    check_read_to_device(hostsim_lib, monkeypatch, tmp_path, 66, 8, 20000)     # NORB > 64: chunked device fill
+    # inconsistent symmetry images are refused on the large-file path (order-dependent result)
+    from pymes_amd import _lib
+    import pytest
+    p = str(tmp_path / "bad")
+    sparse_fcidump(p, 66, 8, 10, seed=1)
+    with open(p, "a") as fh:
+        fh.write(" 1.0 60 61 62 63\n 2.0 61 60 62 63\n")
+    with pytest.raises(_lib.PymesError):
+        fcidump.read_to_device(p)
