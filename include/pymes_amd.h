@@ -183,6 +183,9 @@ int pymes_dots(pymes_ctx* ctx, int npairs, const double* const* x_dev, const dou
 int pymes_lincomb(pymes_ctx* ctx, double* out_dev, int nx, const double* const* x_dev, const double* c_host,
                   int64_t n);
 
+/* pymes/mean_field/hf.py:14-18 from the context's device blocks: f = h + 2 V_piqi - V_piiq (i occupied); h, f [n,n] host */
+int pymes_hf_fock_matrix(pymes_ctx* ctx, const double* h_host, double* f_host);
+
 /* ---- FCIDUMP ingestion: pymes/util/fcidump.py:59-163 with a native text parser -------------------
  * Same semantics as the reference's reader (header by substring match, "value i j k l" -> p r q s, |value| < 1e-19
  * skipped, the three index-swap images restored but not the electron-exchange one, is_tc: only [q,p,s,r]; a body line

@@ -71,6 +71,7 @@ SIGNATURES = {
     "pymes_ccd_energy": (C.c_int, [C.c_void_p, C.c_void_p, c_double_p]),
     "pymes_ueg_eval_2b": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                     C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pymes_hf_fock_matrix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pymes_fcidump_header": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pymes_fcidump_read_host": (C.c_int, [C.c_char_p, C.c_int, c_double_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pymes_fcidump_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, c_double_p, C.c_void_p, C.c_void_p, c_i64_p]),

@@ -382,6 +382,12 @@ int pymes_stats(pymes_ctx* ctx, int reset, int64_t* gemm_calls, double* gemm_flo
         if (reset) e.stats = pymes::ContractStats{};
     });
 }
+int pymes_hf_fock_matrix(pymes_ctx* ctx, const double* h_host, double* f_host) {
+    return guarded([&] {
+        need(h_host, "h"); need(f_host, "f");
+        E(ctx).hf_fock_matrix(h_host, f_host);
+    });
+}
 int pymes_fcidump_header(const char* path, int* n_elec, int* n_orb) {
     return guarded([&] {
         if (!path || !n_elec || !n_orb) throw pymes::Error("null argument");

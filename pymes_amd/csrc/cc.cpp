@@ -367,6 +367,24 @@ void Engine::residual_finish(const double* f, const double* t2, const double* ET
     permute(1.0, ETx, "biaj", 1.0, R, "abij");
 }
 
+// hf.py:14-18 from the packed blocks: f = h + 2 V_piqi - V_piiq (i occupied)
+void Engine::hf_fock_matrix(const double* h_host, double* f_host) {
+    const double* dir[4];
+    const double* exc[4];
+    for (int tp = 0; tp < 2; ++tp)
+        for (int tq = 0; tq < 2; ++tq) {
+            dir[tp * 2 + tq] = block((tp << 3) | (tq << 1)).p;          // (tp, occ, tq, occ)
+            exc[tp * 2 + tq] = block((tp << 3) | tq).p;                 // (tp, occ, occ, tq)
+        }
+    ArenaScope scope(arena);
+    const int64_t nn = n;
+    double* h = arena.alloc(nn * nn);
+    double* f = arena.alloc(nn * nn);
+    dev::memcpy_h2d(h, h_host, sizeof(double) * nn * nn, stream);
+    dev::hf_fock(dir, exc, h, f, no, nv, stream);
+    dev::memcpy_d2h(f_host, f, sizeof(double) * nn * nn, stream);
+}
+
 void Engine::pair_chunk(int rank, int world, int64_t& r0, int64_t& r1) const {
     if (world < 1 || rank < 0 || rank >= world) throw Error("pair_chunk: bad rank/world");
     const int64_t npp = static_cast<int64_t>(nv) * (nv + 1) / 2, c = (npp + world - 1) / world;

@@ -118,6 +118,11 @@ void residual_assemble_pairs(const double* V, const double* L, const double* Np,
 // plain rows of the same [ S | A ] layout: out[r][i][j] = Q[r][P(i,j)] + sgn(i-j) Q[r][o(o+1)/2 + Q(i,j)]
 void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t s);
 
+// ---- Hartree-Fock matrix from the packed blocks (pymes/mean_field/hf.py:14-18); dir[tp*2+tq] = block (tp,o,tq,o),
+// exc[tp*2+tq] = block (tp,o,o,tq), tp/tq = 1 for a virtual index; h and f are [n,n] on the device
+void hf_fock(const double* const dir[4], const double* const exc[4], const double* h_dev, double* f_dev, int no, int nv,
+             stream_t s);
+
 // ---- FCIDUMP ingestion (pymes/util/fcidump.py:140-149): the two-electron lines (0-based p,q,r,s after the reference's
 // renaming, file order) are written with their symmetry images into the zero-initialised dense V[n]^4 on the device.
 // Returns the number of lines whose images do not all hold the line's value afterwards (0 for consistent files).

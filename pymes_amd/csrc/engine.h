@@ -106,6 +106,7 @@ class Engine {
 
     // ---- CC path (cc.cpp) -----------------------------------------------------------
     void mp2(double shift, double* t2, double e_out[2]);                                      // mp2.py:9-22
+    void hf_fock_matrix(const double* h_host, double* f_host);                                // hf.py:14-18
     void dress_fock(const double* f, const double* t1, double* fd);                           // ccsd.py:226-288
     // ccsd.py:290-421; [q0,q1) (optional): only that range of the second (virtual) index of the blocks is produced
     void dress_V(const double* t1, uint32_t mask, int64_t q0 = 0, int64_t q1 = 0);

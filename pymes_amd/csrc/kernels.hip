@@ -1138,6 +1138,24 @@ __global__ void __launch_bounds__(256) tc_triple_kernel(const double* __restrict
     if (threadIdx.x == 0) out[0] = -sh[0] / 6.0;
 }
 
+// Hartree-Fock matrix from the packed blocks (hf.py:14-18): f[p,q] = h[p,q] + sum_i (2 V[p,i,q,i] - V[p,i,i,q]), i occupied.
+// dir[tp*2+tq] = block (tp, occ, tq, occ), exc[tp*2+tq] = block (tp, occ, occ, tq); tp/tq = 1 for a virtual index.
+struct HfBlocks { const double* dir[4]; const double* exc[4]; };
+__global__ void hf_fock_kernel(const HfBlocks B, const double* __restrict__ h, double* __restrict__ f, int no, int nv) {
+    const int n = no + nv;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * n) return;
+    const int p = t / n, q = t - p * n;
+    const int tp = p >= no, tq = q >= no;
+    const long pl = tp ? p - no : p, ql = tq ? q - no : q, nq = tq ? nv : no;
+    const double* __restrict__ D = B.dir[tp * 2 + tq];
+    const double* __restrict__ X = B.exc[tp * 2 + tq];
+    double acc = 0.0;
+    for (long i = 0; i < no; ++i)
+        acc += 2.0 * D[((pl * no + i) * nq + ql) * no + i] - X[((pl * no + i) * no + i) * nq + ql];
+    f[t] = h[t] + acc;
+}
+
 // FCIDUMP lines -> dense V[n]^4 (fcidump.py:140-149): one thread per line writes the symmetry images in the
 // reference's order.  A second kernel counts lines whose images do not all hold the line's value afterwards, i.e.
 // files whose symmetry-related entries disagree (only there does the order of the lines matter).
@@ -1747,6 +1765,15 @@ void scatter(double* dst, const int64_t* idx_host, const double* val_host, int64
     (void)hipFree(idx);
     (void)hipFree(val);
     HIP_CHECK(e);
+}
+
+void hf_fock(const double* const dir[4], const double* const exc[4], const double* h_dev, double* f_dev, int no, int nv,
+             stream_t s) {
+    HfBlocks B;
+    for (int i = 0; i < 4; ++i) { B.dir[i] = dir[i]; B.exc[i] = exc[i]; }
+    const int n = no + nv;
+    hipLaunchKernelGGL(hf_fock_kernel, dim3((n * n + 255) / 256), dim3(256), 0, (hipStream_t)s, B, h_dev, f_dev, no, nv);
+    HIP_CHECK(hipGetLastError());
 }
 
 int64_t fcidump_fill(double* V, const double* val_host, const int32_t* pqrs_host, int64_t count, int n, bool is_tc,

@@ -9,7 +9,18 @@ def calc_hf_e(no, e_core, t_h_pq, t_V_pqrs):
 
 
 def construct_hf_matrix(no, t_h_pq, t_V_pqrs):
-    """pymes/mean_field/hf.py:14-18: f = h + 2 V_piqi - V_piiq."""
+    """pymes/mean_field/hf.py:14-18: f = h + 2 V_piqi - V_piiq.  ``t_V_pqrs`` may be a
+    ``pymes_amd.integral.device.DeviceIntegrals`` (e.g. from ``fcidump.read_to_device``): the traces then run on the
+    device blocks (``pymes_hf_fock_matrix``) and V_pqrs is never needed on the host."""
+    if hasattr(t_V_pqrs, "ctx"):
+        import ctypes as C
+        ctx = t_V_pqrs.ctx
+        if ctx.no != no:
+            raise ValueError("number of occupied orbitals does not match the device integrals")
+        h = np.ascontiguousarray(t_h_pq, dtype=np.float64)
+        f = np.empty_like(h)
+        ctx.lib.call("pymes_hf_fock_matrix", ctx.handle, h.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p))
+        return f
     f = np.array(t_h_pq, dtype=np.float64, copy=True)
     f += 2.0 * np.einsum("piqi->pq", t_V_pqrs[:, :no, :, :no])
     f -= np.einsum("piiq->pq", t_V_pqrs[:, :no, :no, :])

@@ -234,6 +234,21 @@ void residual_assemble(const double* V, const double* L, const double* N, const 
                 }
 }
 
+void hf_fock(const double* const dir[4], const double* const exc[4], const double* h, double* f, int no, int nv, stream_t) {
+    const int n = no + nv;
+    for (int p = 0; p < n; ++p)
+        for (int q = 0; q < n; ++q) {
+            const int tp = p >= no, tq = q >= no;
+            const int64_t pl = tp ? p - no : p, ql = tq ? q - no : q, nq = tq ? nv : no;
+            const double* D = dir[tp * 2 + tq];
+            const double* X = exc[tp * 2 + tq];
+            double acc = 0.0;
+            for (int64_t i = 0; i < no; ++i)
+                acc += 2.0 * D[((pl * no + i) * nq + ql) * no + i] - X[((pl * no + i) * no + i) * nq + ql];
+            f[p * n + q] = h[p * n + q] + acc;
+        }
+}
+
 int64_t fcidump_fill(double* V, const double* val, const int32_t* pqrs, int64_t count, int n_, bool is_tc, stream_t) {
     const int64_t n = n_;
     int64_t bad = 0;

@@ -93,6 +93,7 @@ def check_read_to_device(lib, monkeypatch, tmp_path, n, nelec, lines):
     ne, norb, ec, eps, h, ints = fcidump.read_to_device(path)
     try:
         assert (ne, norb, ec) == (ref[0], ref[1], ref[2]) and np.array_equal(eps, ref[3]) and np.array_equal(h, ref[4])
+        assert np.abs(hf.construct_hf_matrix(ne // 2, h, ints) - oio.fock_matrix(ne // 2, ref[4], ref[5])).max() < 1e-12
         blocks = oc.split_blocks(ne // 2, ref[5])
         for name in ("abcd", "ijab", "iajb", "klij", "abij", "iabc"):
             assert np.array_equal(ints.ctx.V_block(name).get(), blocks[name]), name
