@@ -87,9 +87,12 @@ int pymes_ccsd_dress_fock(pymes_ctx* ctx, const double* f_dev, const double* t1_
  * pymes_residual_slab/_finish expect when they are given t1 (those terms then travel with the ladders). */
 #define PYMES_DRESS_ABIJ_REDUCED (1u << 16)
 int pymes_ccsd_dress_V(pymes_ctx* ctx, const double* t1_dev, uint32_t block_mask);
-/* the same for the range [q_begin, q_end) of the SECOND index only (blocks whose second index is virtual, e.g.
- * "iajb", "iabj"): what one rank's column slab of pymes_residual_slab reads — 1/world of the work, no exchange */
-int pymes_ccsd_dress_V_slab(pymes_ctx* ctx, const double* t1_dev, uint32_t block_mask, int q_begin, int q_end);
+/* the same for the range [p_begin,p_end) of the FIRST and [q_begin,q_end) of the SECOND index only (an empty range =
+ * the whole index; a restricted index must be virtual in every selected block): "iajb" / "iabj" with a q-range is what
+ * one rank's column slab of pymes_residual_slab reads, "abij" with (p,q) = (rows a of the rank's pairs, b below their
+ * end) and the transposed pair of ranges is what the pair-sharded tail reads — no exchange */
+int pymes_ccsd_dress_V_slab(pymes_ctx* ctx, const double* t1_dev, uint32_t block_mask, int p_begin, int p_end,
+                            int q_begin, int q_end);
 /* CCSD.get_singles_residual, ccsd.py:423-438 */
 int pymes_ccsd_singles_residual(pymes_ctx* ctx, const double* fd_dev, const double* t1_dev, const double* t2_dev,
                                 double* r1_dev);

@@ -47,7 +47,7 @@ SIGNATURES = {
     "pymes_mp2": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, c_double_p]),
     "pymes_ccsd_dress_fock": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pymes_ccsd_dress_V": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
-    "pymes_ccsd_dress_V_slab": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int]),
+    "pymes_ccsd_dress_V_slab": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int]),
     "pymes_ccsd_singles_residual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pymes_doubles_residual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "pymes_ladder": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]),

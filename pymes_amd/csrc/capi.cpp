@@ -211,11 +211,12 @@ int pymes_ccsd_dress_V(pymes_ctx* ctx, const double* t1, uint32_t mask) {
         E(ctx).dress_V(t1, mask);
     });
 }
-int pymes_ccsd_dress_V_slab(pymes_ctx* ctx, const double* t1, uint32_t mask, int q_begin, int q_end) {
+int pymes_ccsd_dress_V_slab(pymes_ctx* ctx, const double* t1, uint32_t mask, int p_begin, int p_end, int q_begin,
+                            int q_end) {
     return guarded([&] {
         need(t1, "t1");
-        if (q_end <= q_begin) return;
-        E(ctx).dress_V(t1, mask, q_begin, q_end);
+        const int64_t cut[4] = {p_begin, p_end, q_begin, q_end};
+        E(ctx).dress_V(t1, mask, cut);
     });
 }
 int pymes_ccsd_singles_residual(pymes_ctx* ctx, const double* fd, const double* t1, const double* t2, double* r1) {

@@ -746,21 +746,34 @@ void Engine::dress_fock(const double* f, const double* t1, double* fd) {
 // reduced (V_abij only, pos = {3,2,1,0}): leave out the terms with both kets virtual (V_pqcd t_ci t_dj) and the
 // terms with both bras occupied (t_ak t_bl V~_klrs); ladder_t1 carries them through tau and the hole ladder.
 void Engine::dressed_into(int pattern, const std::vector<int>& pos, int k, const TView& t1v, const TView& dst,
-                          bool reduced, int64_t q0, int64_t q1) {
-    // [q0,q1): only this range of the SECOND index (a virtual one) is produced; dst is already cut.  Every block
-    // whose second index is still that virtual index is read through the same cut; the transform of the second
-    // index itself (x == 1) restricts the rows of t1 instead.
-    const bool cut = q1 > q0;
-    auto cutq = [&](const TView& v, int pat) { return (cut && (pat >> 2 & 1)) ? slice(v, 1, q0, q1) : v; };
+                          bool reduced, const int64_t* cut) {
+    // cut = {p0, p1, q0, q1} (or null): only the range [p0,p1) of the first and [q0,q1) of the second index are
+    // produced (an empty range = the whole index; a cut index must be virtual in the requested block); dst is already
+    // cut.  Every block in which such an index is still that virtual index is read through the same cut; the
+    // transform of the index itself (x == 0 / 1) restricts the rows of t1 instead.
+    auto has = [&](int axis) { return cut && cut[2 * axis + 1] > cut[2 * axis]; };
+    auto cutq = [&](TView v, int pat) {
+        for (int axis = 0; axis < 2; ++axis)
+            if (has(axis) && (pat >> (3 - axis) & 1)) v = slice(v, axis, cut[2 * axis], cut[2 * axis + 1]);
+        return v;
+    };
     if (k == 0) {
         copy(cutq(block(pattern), pattern), dst);
         return;
     }
     // same-type part: when it is the raw block the copy is fused into the product below (C = Cin + ...)
     const bool fuse_copy = (k - 1 == 0);
-    if (!fuse_copy) dressed_into(pattern, pos, k - 1, t1v, dst, reduced, q0, q1);
+    if (!fuse_copy) dressed_into(pattern, pos, k - 1, t1v, dst, reduced, cut);
     const TView raw = fuse_copy ? cutq(block(pattern), pattern) : TView();
     const TView* cin = fuse_copy ? &raw : nullptr;
+    if (cin) {      // the fused copy needs Cin laid out like C: a cut of the full block vs a compact temporary is not
+        bool same = true;
+        for (int i = 0; i < 4; ++i) same = same && (raw.dim[i] == 1 || raw.st[i] == dst.st[i]);
+        if (!same) {
+            copy(raw, dst);
+            cin = nullptr;
+        }
+    }
     const int x = pos[k - 1];
     const int other = pattern ^ (1 << (3 - x));
     int depth = k - 1;                       // dressing depth of the other-type part
@@ -773,34 +786,39 @@ void Engine::dressed_into(int pattern, const std::vector<int>& pos, int k, const
     } else {
         int64_t d[4];
         for (int i = 0; i < 4; ++i) d[i] = (other >> (3 - i) & 1) ? nv : no;
-        if (cut && (other >> 2 & 1)) d[1] = q1 - q0;
+        for (int axis = 0; axis < 2; ++axis)
+            if (has(axis) && (other >> (3 - axis) & 1)) d[axis] = cut[2 * axis + 1] - cut[2 * axis];
         oth = make_view(arena.alloc(d[0] * d[1] * d[2] * d[3]), 4, d, nullptr);
-        dressed_into(other, pos, depth, t1v, oth, reduced, q0, q1);
+        dressed_into(other, pos, depth, t1v, oth, reduced, cut);
     }
+    const TView tcut = (x < 2 && has(x)) ? slice(t1v, 0, cut[2 * x], cut[2 * x + 1]) : t1v;
     switch (x) {
         case 3: contract(1.0, oth, "pqrx", t1v, "xs", 1.0, dst, "pqrs", "", cin); break;
         case 2: contract(1.0, oth, "pqxs", t1v, "xr", 1.0, dst, "pqrs", "pq", cin); break;
-        case 1: contract(-1.0, cut ? slice(t1v, 0, q0, q1) : t1v, "qx", oth, "pxrs", 1.0, dst, "pqrs", "p", cin); break;
-        case 0: contract(-1.0, t1v, "px", oth, "xqrs", 1.0, dst, "pqrs", "", cin); break;
+        case 1: contract(-1.0, tcut, "qx", oth, "pxrs", 1.0, dst, "pqrs", "p", cin); break;
+        case 0: contract(-1.0, tcut, "px", oth, "xqrs", 1.0, dst, "pqrs", "", cin); break;
         default: throw Error("bad index position");
     }
 }
 
-void Engine::dress_V(const double* t1, uint32_t mask, int64_t q0, int64_t q1) {
+void Engine::dress_V(const double* t1, uint32_t mask, const int64_t* cut) {
     TView t = make_view(const_cast<double*>(t1), {(int64_t)nv, (int64_t)no});
-    const bool cut = q1 > q0;
-    if (q0 < 0 || q1 > nv || q0 > q1) throw Error("dress_V: bad range of the second index");
+    for (int axis = 0; axis < 2 && cut; ++axis)
+        if (cut[2 * axis] < 0 || cut[2 * axis + 1] > nv || cut[2 * axis] > cut[2 * axis + 1]) throw Error("dress_V: bad index range");
     for (int pat = 0; pat < 16; ++pat) {
         if (!(mask >> pat & 1u)) continue;
-        if (cut && !(pat >> 2 & 1)) throw Error("dress_V: a range of the second index needs that index to be virtual");
+        TView dst = block_view(ensure_dressed(pat), pat);
+        for (int axis = 0; axis < 2 && cut; ++axis) {
+            if (cut[2 * axis + 1] <= cut[2 * axis]) continue;
+            if (!(pat >> (3 - axis) & 1)) throw Error("dress_V: an index range needs that index to be virtual");
+            dst = slice(dst, axis, cut[2 * axis], cut[2 * axis + 1]);
+        }
         std::vector<int> pos;
         if (!(pat >> 0 & 1)) pos.push_back(3);   // ket s occupied
         if (!(pat >> 1 & 1)) pos.push_back(2);   // ket r occupied
         if (pat >> 2 & 1) pos.push_back(1);      // bra q virtual
         if (pat >> 3 & 1) pos.push_back(0);      // bra p virtual
-        TView dst = block_view(ensure_dressed(pat), pat);
-        if (cut) dst = slice(dst, 1, q0, q1);
-        dressed_into(pat, pos, static_cast<int>(pos.size()), t, dst, pat == P_abij && (mask >> 16 & 1u), q0, cut ? q1 : q0);
+        dressed_into(pat, pos, static_cast<int>(pos.size()), t, dst, pat == P_abij && (mask >> 16 & 1u), cut);
         if (pat == P_abcd && lpack_.dressed) lpack_.valid = false;
     }
 }

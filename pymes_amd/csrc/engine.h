@@ -108,8 +108,8 @@ class Engine {
     void mp2(double shift, double* t2, double e_out[2]);                                      // mp2.py:9-22
     void hf_fock_matrix(const double* h_host, double* f_host);                                // hf.py:14-18
     void dress_fock(const double* f, const double* t1, double* fd);                           // ccsd.py:226-288
-    // ccsd.py:290-421; [q0,q1) (optional): only that range of the second (virtual) index of the blocks is produced
-    void dress_V(const double* t1, uint32_t mask, int64_t q0 = 0, int64_t q1 = 0);
+    // ccsd.py:290-421; cut = {p0,p1,q0,q1} (optional): only these ranges of the first / second (virtual) index
+    void dress_V(const double* t1, uint32_t mask, const int64_t* cut = nullptr);
     void singles_residual(const double* fd, const double* t1, const double* t2, double* r1);  // ccsd.py:423-438
     // ccd.py:164-254; flags: bit0 = DCD/DCSD, bit1 = use dressed blocks, bit2 = skip ladder,
     // bit3 = pair-packed ladder (T and V exchange-symmetric)
@@ -163,7 +163,7 @@ class Engine {
     int64_t splitk_doubles_ = 0;
     double* get_static(const std::string& key);
     void dressed_into(int pattern, const std::vector<int>& pos, int k, const TView& t1v, const TView& dst,
-                      bool reduced = false, int64_t q0 = 0, int64_t q1 = 0);
+                      bool reduced = false, const int64_t* cut = nullptr);
     int64_t block_size(int pattern) const;
     TView block_view(double* p, int pattern) const;
     double* ensure_dressed(int pattern);

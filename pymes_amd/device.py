@@ -238,15 +238,17 @@ class Context:
         self.lib.call("pymes_ccsd_dress_fock", self.handle, C.c_void_p(f.ptr), C.c_void_p(t1.ptr), C.c_void_p(out.ptr))
         return out
 
-    def dress_V(self, t1, names, reduced_abij=False, q_range=None):
+    def dress_V(self, t1, names, reduced_abij=False, q_range=None, p_range=None):
         """ccsd.py:290-421 for the named blocks; ``reduced_abij``: the form of V~_abij that goes with
-        ``residual_slab(..., t1=, QK=)``; ``q_range``: only this range of the second (virtual) index of the blocks
+        ``residual_slab(..., t1=, QK=)``; ``p_range`` / ``q_range``: only these ranges of the first / second (virtual) index of the blocks
         (include/pymes_amd.h)."""
         mask = _lib.PYMES_DRESS_ABIJ_REDUCED if reduced_abij else 0
         for nm in names:
             mask |= 1 << pattern_of(nm)
-        if q_range is not None:
-            self.lib.call("pymes_ccsd_dress_V_slab", self.handle, C.c_void_p(t1.ptr), mask, int(q_range[0]), int(q_range[1]))
+        if q_range is not None or p_range is not None:
+            p0, p1 = p_range if p_range is not None else (0, 0)
+            q0, q1 = q_range if q_range is not None else (0, 0)
+            self.lib.call("pymes_ccsd_dress_V_slab", self.handle, C.c_void_p(t1.ptr), mask, int(p0), int(p1), int(q0), int(q1))
         else:
             self.lib.call("pymes_ccsd_dress_V", self.handle, C.c_void_p(t1.ptr), mask)
 

@@ -140,7 +140,16 @@ class CCSD(ccd.CCD):
                 keys = ("ETd_t", "ETx_t", "QK_t") if st["pairs"] else ("ETd_t", "ETx_t", "L_t", "QK_t")
                 pending = [pdist.exchange_rows_start(st[key], rank, world) for key in keys]
             ctx.singles_residual(st["fd"], t1, t2, r1)                                # :167
-            ctx.dress_V(t1, ("abij",), reduced_abij=True)                             # :165
+            if st["pairs"]:    # V~_abij only where the tiles (a,b) and (b,a) of this rank's pairs live
+                lo, hi = pdist.slab_rows(st["npp"], rank, world)
+                a0, a1 = pdist.a_range_of_pair_rows(lo, hi)
+                if 2 * (a1 - a0) * a1 >= 0.8 * ctx.nv * ctx.nv:          # the two cuts would cost as much as the whole block
+                    ctx.dress_V(t1, ("abij",), reduced_abij=True)
+                elif a1 > a0:
+                    ctx.dress_V(t1, ("abij",), reduced_abij=True, p_range=(a0, a1), q_range=(0, a1))
+                    ctx.dress_V(t1, ("abij",), reduced_abij=True, p_range=(0, a1), q_range=(a0, a1))
+            else:
+                ctx.dress_V(t1, ("abij",), reduced_abij=True)                         # :165
             for work in pending:
                 work.wait()
             if world > 1:
