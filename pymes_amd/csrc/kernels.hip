@@ -322,7 +322,8 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_kernel(const GemmK g) {
 // ------------------------------------------------------------------------------------
 // LDS-DMA variant of the 128x128 GEMM (16-byte aligned operands).  Same tiling, MFMA schedule and
 // epilogue as dgemm_kernel, but the operand tiles go global -> LDS directly
-// (`global_load_lds_dwordx4`: no staging VGPRs, no ds_write, no per-tile pointer arithmetic on the VALU):
+// (`global_load_lds_dwordx4`, issued through glds16_su below: no staging VGPRs, no ds_write, no per-tile pointer
+// arithmetic on the VALU; M0 is written by hand — the kernel has no other M0 user):
 //   * an M/N-contiguous tile [16 k][128] is 16 wave-instructions of one 1-KiB k-row each, LDS pitch 144;
 //   * a K-contiguous tile [128 rows][16 k] is 16 wave-instructions of eight 128-B rows each.  The LDS
 //     destination of an LDS-DMA is lane-linear, so the bank-conflict fix cannot be padding: the 16-B
@@ -330,11 +331,6 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_kernel(const GemmK g) {
 //     and the fragment reads apply the same XOR (conflict-free ds_read_b64 for 16 consecutive rows).
 // The last, partial k-tile is staged through registers with zero fill.
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ void glds16(const double* gsrc, double* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
-
 // wave-uniform values that the compiler computes on the VALU (64-bit divisions of the block id) are moved to
 // SGPRs explicitly, so that loop control and the LDS-DMA base addresses stay on the scalar unit
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
@@ -1473,8 +1469,13 @@ void gemm(const Gemm& g, stream_t s) {
     if (g.M <= 64) BM = 64;
     const long nbatch = g.nb1 * g.nb2;
     auto ntiles = [&](int bm, int bn) { return ((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * nbatch; };
-    // under-filled chip (<1 block per CU at 128x128): use 64x64 tiles for 4x the blocks
-    if (BM == 128 && BN == 128 && ntiles(128, 128) < 256) { BM = 64; BN = 64; }
+    // under-filled chip (<1 block per CU at 128x128): 64x64 tiles give 4x the blocks — unless K is deep enough to fill
+    // the chip by k-splitting with >= 1024 per split, which keeps the (faster) 128x128 LDS-DMA kernel
+    if (BM == 128 && BN == 128 && ntiles(128, 128) < 256) {
+        const long nt = ntiles(128, 128), want = (512 + nt - 1) / nt;
+        const bool deep = g.splitk_ws && g.K / want >= 1024 && nt * want * 128L * 128L <= g.splitk_ws_doubles;
+        if (!deep) { BM = 64; BN = 64; }
+    }
     else if (BM == 128 && BN == 64 && ntiles(128, 64) < 256) { BM = 64; }
     else if (BM == 64 && BN == 128 && ntiles(64, 128) < 256) { BN = 64; }
     if (const char* ov = getenv("PYMES_GEMM_TILE")) {   // tuning experiments only
@@ -1513,21 +1514,18 @@ void gemm(const Gemm& g, stream_t s) {
     const long ws_tiles = g.splitk_ws ? g.splitk_ws_doubles / ((long)BM * BN) : 0;
     long main_tiles = tiles, tail_tiles = 0;
     int main_split = 1, tail_split = 1;
-    if (tiles < 256 && ktiles >= 16) {
-        long want = (512 + tiles - 1) / tiles;
-        want = std::min<long>(want, ktiles / 8);          // >= 8 k-tiles (128 deep) per split
-        want = std::min<long>(want, 512);
-        want = std::min<long>(want, ws_tiles / tiles);
-        if (want >= 2) main_split = (int)want;
-    } else if (ktiles >= 32) {
+    if (ktiles >= 16) {
+        // The last, partially filled round of tiles (all of them for a small output) is split s ways along K:
+        // ceil(rem s / slots) rounds of 1/s tile-time each.  Few remainder tiles may be split finer (huge K, tiny output).
         const long rem = tiles % slots;
         if (rem > 0) {
-            // split the K range of the remainder tiles s ways: ceil(rem s / slots) rounds of 1/s tile-time each
             long best = 1;
             double best_cost = 1.0;
-            const long smax = std::min<long>(std::min<long>(8, ktiles / 16), ws_tiles / rem);
+            long smax = std::min<long>(512, std::max<long>(8, 2048 / rem));
+            smax = std::min<long>(smax, ktiles / ((BM == 128 && BN == 128) ? 16 : 8));   // >= 256 / 128 deep per split
+            smax = std::min<long>(smax, ws_tiles / rem);
             for (long sp = 2; sp <= smax; ++sp) {
-                const double cost = (double)((rem * sp + slots - 1) / slots) / (double)sp + 0.01 * sp;
+                const double cost = (double)((rem * sp + slots - 1) / slots) / (double)sp + 1e-5 * sp;
                 if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
             }
             if (best >= 2 && best_cost < 0.8) {

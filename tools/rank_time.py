@@ -73,6 +73,14 @@ def main():
             solver.iterate(st)
         ctx.sync()
     total = (time.perf_counter() - t0) / reps
+    if os.environ.get("PYMES_GEMM_LOG"):              # one more iteration with per-GEMM events, written to that file
+        for name, fn in calls.items():
+            setattr(ctx, name, fn)
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        with contextlib.redirect_stdout(io.StringIO()):
+            solver.iterate(st)
+        ctx.prof_query()
     out = {"world": args.world, "rank": args.rank, "no": no, "nv": nv, "iteration_compute_ms": 1e3 * total,
            "phases_ms": {k: 1e3 * v / reps for k, v in sorted(phases.items(), key=lambda kv: -kv[1])}}
     print(json.dumps(out))
