@@ -122,5 +122,33 @@ def test_full_size_properties(gpu_lib):
         assert ctx.norm(d) < 1e-11 * ctx.norm(r2)
         # energy functional consistency: E_mp2 = 2 T:V - T:V^x through the CCD energy entry point
         assert abs(sum(ctx.ccd_energy(t2)) - e_mp2) < 1e-10 * abs(e_mp2)
+        # CCSD residual with T1 != 0: explicitly dressed blocks through the general path (ccsd.py:165,171 as written)
+        # == amplitude-side dressing of V_abcd in the symmetry-reduced slab/finish path == its pair-sharded tail
+        from pymes_amd.solver.ccsd import LOOP_KEYS
+        from pymes_amd.device import DeviceArray
+        t1 = ctx.array(0.02 * np.random.default_rng(3).standard_normal((nv, no)))
+        ov = no * nv
+        world = 3
+        pad = lambda n: -(-n // world) * world
+        ETd, ETx = ctx.zeros((pad(ov), ov)), ctx.zeros((pad(ov), ov))
+        Lb, QK = ctx.zeros((pad(npp), no * no)), ctx.zeros((pad(ov), no * no))
+        chunk = pad(npp) // world
+        Rall = ctx.zeros((world * chunk, 2, no * no))
+        for dcd in (False, True):
+            ctx.dress_V(t1, LOOP_KEYS)
+            ctx.doubles_residual(f, t2, r2, is_dcd=dcd, dressed=True, sym_ladder=False, sym_rings=False)
+            ctx.dress_V(t1, ("klij", "iajb", "iabj", "abij"), reduced_abij=True)
+            for rank in range(world):
+                ctx.residual_slab(f, t2, ETd, ETx, Lb, rank, world, is_dcd=dcd, dressed=True, t1=t1, QK=QK)
+            ctx.residual_finish(f, t2, ETd, ETx, Lb, parts, is_dcd=dcd, dressed=True, t1=t1, QK=QK)
+            ctx.lincomb(d, [r2, parts], [1.0, -1.0])
+            assert ctx.norm(d) < 1e-11 * ctx.norm(r2), dcd
+            for rank in range(world):
+                piece = DeviceArray(ctx, Rall.ptr + 8 * rank * chunk * 2 * no * no, (chunk, 2, no * no), owned=False,
+                                    keepalive=Rall)
+                ctx.residual_finish_pairs(f, t2, ETd, ETx, Lb, piece, rank, world, t1, QK, is_dcd=dcd, dressed=True)
+            ctx.pairs_unpack(Rall, parts, world)
+            ctx.lincomb(d, [r2, parts], [1.0, -1.0])
+            assert ctx.norm(d) < 1e-11 * ctx.norm(r2), dcd
     finally:
         ctx.close()
