@@ -1522,7 +1522,10 @@ void gemm(const Gemm& g, stream_t s) {
             long best = 1;
             double best_cost = 1.0;
             long smax = std::min<long>(512, std::max<long>(8, 2048 / rem));
-            smax = std::min<long>(smax, ktiles / ((BM == 128 && BN == 128) ? 16 : 8));   // >= 256 / 128 deep per split
+            // per split: >= 1024 deep when the launch is deep enough for the LDS-DMA kernel (the split blocks then run on
+            // it too), else >= 256 (128x128) / 128 (smaller tiles)
+            const long min_kt = (BM == 128 && BN == 128) ? (ktiles >= 128 ? 64 : 16) : 8;
+            smax = std::min<long>(smax, ktiles / min_kt);
             smax = std::min<long>(smax, ws_tiles / rem);
             for (long sp = 2; sp <= smax; ++sp) {
                 const double cost = (double)((rem * sp + slots - 1) / slots) / (double)sp + 1e-5 * sp;
