@@ -73,6 +73,11 @@ class _Sigma:
         c.lincomb(self.M12, [self.M1, self.M2], [2.0, 1.0])
         self.MC1 = c.empty(self.M1.shape)
         c.lincomb(self.MC1, [self.M_C, self.M1], [1.0, -1.0])
+        # crossed layout: the result is symmetrised by P(ijab, jiba) (:377), i.e. only Dx + Dx^T counts, and u2x is a
+        # symmetric matrix for exchange-symmetric u2, so -u2x.Ud^T (:364) may be replaced by its transpose -Ud.u2x:
+        # M_D.u2x - Ud.u2x = (M_D - Ud).u2x, one product instead of two
+        self.MDU = c.empty(self.M1.shape)
+        c.lincomb(self.MDU, [self.M_D, self.Ud], [1.0, -1.0])
         del M_A, M_B, Vd, Vx, Vq, Tq
         # small hoisted V.T blocks
         self.A3 = c.contract("klci,cbkj->libj", V["ijak"], T, alpha=-2.0)                 # A_oovo
@@ -134,8 +139,11 @@ class _Sigma:
             Dd = c.contract("aidl,dlbj->aibj", self.M1, utd)
             c.contract("aidl,dlbj->aibj", self.M2, u2d, out=Dd, beta=1.0)
             c.contract("aidl,dlbj->aibj", self.M_C, u2x, out=Dd, beta=1.0)      # u2x[(d,l),(b,j)] = u2[d,b,j,l]
-        Dx = c.contract("ajdl,dlbi->ajbi", self.M_D, u2x)                         # :372  u2[d,b,i,l]
-        c.contract("ajck,bick->ajbi", u2x, self.Ud, out=Dx, alpha=-1.0, beta=1.0)  # :364
+        if u2_sym:
+            Dx = c.contract("ajdl,dlbi->ajbi", self.MDU, u2x)                     # :372 and :364 (transposed)
+        else:
+            Dx = c.contract("ajdl,dlbi->ajbi", self.M_D, u2x)                     # :372  u2[d,b,i,l]
+            c.contract("ajck,bick->ajbi", u2x, self.Ud, out=Dx, alpha=-1.0, beta=1.0)  # :364
         Cd = c.contract("kacd,di->aick", V["iabc"], u1)                           # sum_d V[k,a,c,d] u1[d,i]
         Cp = c.contract("kadc,di->aick", V["iabc"], u1)                           # sum_d V[k,a,d,c] u1[d,i]
         Cc = c.empty(Cd.shape)
