@@ -21,7 +21,7 @@ namespace pymes {
 
 namespace {
 constexpr int P_klij = 0, P_ijka = 1, P_ijak = 2, P_ijab = 3, P_iajk = 4, P_iajb = 5, P_iabj = 6, P_iabc = 7,
-              P_aibc = 11, P_abij = 12, P_abcd = 15;
+              P_aibc = 11, P_abij = 12, P_abic = 13, P_abci = 14, P_abcd = 15;
 }
 
 // -----------------------------------------------------------------------------------
@@ -322,7 +322,10 @@ void Engine::residual_finish(const double* f, const double* t2, const double* ET
     ArenaScope scope(arena);
     const bool packed = L && !skip_ladder;
     const bool fused = dev::fused_pair_kernels_ok(no);
-    if (!fused) copy(block(P_abij, dressed), R);                                            // :185
+    // amplitude-side mode: V_abij is read UNDRESSED; its (reduced) T1 dressing Z + Z^T(baji) rides in Exn, see below
+    const bool amp_side = t1 && packed;
+    const TView Vabij_src = block(P_abij, amp_side ? false : dressed);
+    if (!fused) copy(Vabij_src, R);                                                         // :185
     if (!packed) {
         ArenaScope s2(arena);
         if (fused) copy(block(P_abij, dressed), R);
@@ -343,16 +346,13 @@ void Engine::residual_finish(const double* f, const double* t2, const double* ET
     contract(-w, Ttd, "akdl", make_view(get_static("Vk"), {o, v, o, v}), "kdlc", 1.0, Xvv, "ac");
     TView Exn = make_view(Ttd.p, {v, v, o, o});      // Ttd is dead after X_ac: reuse its storage
     contract(1.0, Xvv, "ac", T, "cbij", 0.0, Exn, "abij");
-    if (t1 && packed) {
-        // bras (k,b) and (a,l) of the amplitude-side dressing: -t_ak Q_kbij - t_bl Q_laji, Q = V_kbcd tau_cdij
+    if (amp_side) {
         if (!QK) throw Error("residual_finish: QK buffer missing");
-        TView Qf = make_view(arena.alloc(o * v * o * o), {o, v, o, o});
-        dev::rows_unpack(QK, Qf.p, o * v, no, stream);
-        contract(-1.0, make_view(const_cast<double*>(t1), {v, o}), "ak", Qf, "kbij", 1.0, Exn, "abij");
+        amplitude_side_abij(t1, QK, Exn, 0, nv, nv, false);
     }
     if (fused) {
         // R = V~_abij (or what R holds already) + ladders + Ex + Ex^T in one pass              (:185-187, :249-252)
-        dev::residual_assemble(packed ? block(P_abij, dressed).p : r2, packed ? L : nullptr, Exn.p, ETd_p, ETx_p, r2, no,
+        dev::residual_assemble(packed ? Vabij_src.p : r2, packed ? L : nullptr, Exn.p, ETd_p, ETx_p, r2, no,
                                nv, stream);
         stats.permute_calls++;
         stats.permute_bytes += 8.0 * 5.5 * double(o * o * v * v);
@@ -383,6 +383,32 @@ void Engine::hf_fock_matrix(const double* h_host, double* f_host) {
     dev::memcpy_h2d(h, h_host, sizeof(double) * nn * nn, stream);
     dev::hf_fock(dir, exc, h, f, no, nv, stream);
     dev::memcpy_d2h(f_host, f, sizeof(double) * nn * nn, stream);
+}
+
+// The part of the T1 dressing of the residual that is linear in the rows a of R and enters through Ex + Ex^T(baji)
+// (amplitude-side mode; exchange symmetry V_pqrs = V_qpsr).  With W_kbij = V_kbij + V_kbcj t_ci + V_kbid t_dj:
+//     N[a,b,i,j] += V_abcj t_ci - t_ak (Q_kbij + W_kbij)          for a in [a0,a1)   (+ the (b,a,j,i) halves if asked)
+// Q_kb (from QK) carries the (c,d)-ket part of the bras (k,b)/(a,l); W the rest of those bras; V_abcj t_ci and its
+// partner V_abid t_dj = (V_abcj t_ci)_baji are the (c,j)/(i,d) kets of the bra (a,b).  Together with the undressed
+// V_abij in the assembly and the (k,l) bra inside the hole ladder this is all of V~_abij (ccsd.py:322-343).
+void Engine::amplitude_side_abij(const double* t1, const double* QK, const TView& N, int64_t a0, int64_t a1,
+                                 int64_t b1, bool with_partner) {
+    // N is [a1 - a0][b1][o][o]: rows a in [a0,a1), columns b in [0,b1)
+    const int64_t o = no, v = nv;
+    TView t = make_view(const_cast<double*>(t1), {v, o});
+    ArenaScope scope(arena);
+    TView Qf = make_view(arena.alloc(o * v * o * o), {o, v, o, o});
+    dev::rows_unpack(QK, Qf.p, o * v, no, stream);
+    axpby(1.0, block(P_iajk), 1.0, Qf);
+    contract(1.0, block(P_iabj), "kbcj", t, "ci", 1.0, Qf, "kbij");
+    contract(1.0, block(P_iajb), "kbid", t, "dj", 1.0, Qf, "kbij");
+    contract(-1.0, slice(t, 0, a0, a1), "ak", slice(Qf, 1, 0, b1), "kbij", 1.0, N, "abij");
+    contract(1.0, slice(slice(block(P_abci), 0, a0, a1), 1, 0, b1), "abcj", t, "ci", 1.0, N, "abij");
+    if (!with_partner) return;
+    // the (b,a,j,i) halves for the same rows a (pair-sharded tail): -t_bk (Q+W)[k,a,j,i] and
+    // (V_bacᵢ t_cj =) V_abic t_cj, the latter straight from the block with the roles of the kets exchanged
+    contract(-1.0, slice(t, 0, 0, b1), "bk", slice(Qf, 1, a0, a1), "kaji", 1.0, N, "abij");
+    contract(1.0, slice(slice(block(P_abic), 0, a0, a1), 1, 0, b1), "abic", t, "cj", 1.0, N, "abij");
 }
 
 void Engine::pair_chunk(int rank, int world, int64_t& r0, int64_t& r1) const {
@@ -431,14 +457,16 @@ void Engine::residual_finish_pairs(const double* f, const double* t2, const doub
         contract(-w, Ttd, "akdl", make_view(get_static("Vk"), {o, v, o, v}), "kdlc", 1.0, Xvv, "ac");
     }
     // N'[a,b,i,j] = X_ac T[c,b,i,j] + X_bc T[c,a,j,i] - t_ak Q[k,b,i,j] - t_bk Q[k,a,j,i]   for a in [a0,a1)   (:231)
-    TView Np = make_view(arena.alloc(na * v * o * o), {na, v, o, o});
-    TView Qf = make_view(arena.alloc(o * v * o * o), {o, v, o, o});
-    dev::rows_unpack(QK, Qf.p, o * v, no, stream);
-    contract(1.0, slice(Xvv, 0, a0, a1), "ac", T, "cbij", 0.0, Np, "abij");
-    contract(1.0, Xvv, "bc", slice(T, 1, a0, a1), "caji", 1.0, Np, "abij");
-    contract(-1.0, slice(t, 0, a0, a1), "ak", Qf, "kbij", 1.0, Np, "abij");
-    contract(-1.0, t, "bk", slice(Qf, 1, a0, a1), "kaji", 1.0, Np, "abij");
-    dev::residual_assemble_pairs(block(P_abij, dressed).p, L, Np.p, ETd_p, ETx_p, Rc, no, nv, r0, r1, a0, stream);
+    // N'[a,b,i,j] = N[a,b,i,j] + N[b,a,j,i] for a in [a0,a1), N = X_ac T[c,b,i,j] + amplitude_side_abij:
+    // the (b,a,j,i) halves are written out term by term (they need row b of X / t and row a of the big operands)
+    // only the columns b < a1 are needed (b <= a for every pair of the rank): [na][a1] tiles instead of [na][v]
+    const int64_t nb = a1;
+    TView Np = make_view(arena.alloc(na * nb * o * o), {na, nb, o, o});
+    contract(1.0, slice(Xvv, 0, a0, a1), "ac", slice(T, 1, 0, nb), "cbij", 0.0, Np, "abij");
+    contract(1.0, slice(Xvv, 0, 0, nb), "bc", slice(T, 1, a0, a1), "caji", 1.0, Np, "abij");
+    amplitude_side_abij(t1, QK, Np, a0, a1, nb, true);
+    (void)dressed;      // V_abij is read undressed in the amplitude-side mode
+    dev::residual_assemble_pairs(block(P_abij).p, L, Np.p, ETd_p, ETx_p, Rc, no, nv, r0, r1, a0, static_cast<int>(nb), stream);
     stats.permute_calls++;
     stats.permute_bytes += 8.0 * 5.5 * double(r1 - r0) * 2.0 * double(o * o);
 }

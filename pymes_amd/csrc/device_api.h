@@ -112,9 +112,9 @@ void pairs_pack(const double* full, double* Xc, int no, int nv, int64_t r0, int6
 void pairs_unpack(const double* Xc, double* full, int no, int nv, int64_t r0, int64_t r1, stream_t s);   // Xc of these pairs
 void cc_update_pairs(double* tc, double* dtc, const double* rc, const double* eo, const double* ev, double shift,
                      double delta, int no, int nv, int64_t r0, int64_t r1, stream_t s);
-// residual_assemble for the pairs [r0,r1), compact output; Np[a - a0][b][o*o] = N_ab + N_ba^T already combined
+// residual_assemble for the pairs [r0,r1), compact output; Np[a - a0][b][o*o] (b < nbp) = N_ab + N_ba^T already combined
 void residual_assemble_pairs(const double* V, const double* L, const double* Np, const double* D, const double* X,
-                             double* Rc, int no, int nv, int64_t r0, int64_t r1, int a0, stream_t s);
+                             double* Rc, int no, int nv, int64_t r0, int64_t r1, int a0, int nbp, stream_t s);
 // plain rows of the same [ S | A ] layout: out[r][i][j] = Q[r][P(i,j)] + sgn(i-j) Q[r][o(o+1)/2 + Q(i,j)]
 void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t s);
 

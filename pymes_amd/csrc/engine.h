@@ -134,6 +134,8 @@ class Engine {
     void residual_finish_pairs(const double* f, const double* t2, const double* ETd, const double* ETx, const double* L,
                                double* Rc, unsigned flags, const double* t1, const double* QK, int rank, int world);
     void pair_chunk(int rank, int world, int64_t& r0, int64_t& r1) const;
+    void amplitude_side_abij(const double* t1, const double* QK, const TView& N, int64_t a0, int64_t a1, int64_t b1,
+                             bool with_partner);
     // rows [row0,row1) of the pair-packed ladders and rows [q0,q1) of QK[(k,b)] = sum_cd V_kbcd tau_cdij, all
     // from UNDRESSED, statically packed integrals; tau = T + t1 t1
     void ladder_t1(const double* t1, const double* t2, double* L, int64_t row0, int64_t row1, double* QK, int64_t q0,

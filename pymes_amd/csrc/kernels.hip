@@ -1020,7 +1020,7 @@ __global__ void __launch_bounds__(256) cc_update_pairs_kernel(double* __restrict
 __global__ void __launch_bounds__(256) residual_assemble_pairs_kernel(const double* __restrict__ V, const double* __restrict__ L,
                                                                       const double* __restrict__ Np, const double* __restrict__ D,
                                                                       const double* __restrict__ X, double* __restrict__ Rc,
-                                                                      int no, int nv, long r0, int a0) {
+                                                                      int no, int nv, long r0, int a0, int nbp) {
     extern __shared__ double S[];             // [no][no + 1]
     int a, b;
     unrank_pair(r0 + blockIdx.x, a, b);
@@ -1028,7 +1028,7 @@ __global__ void __launch_bounds__(256) residual_assemble_pairs_kernel(const doub
     const long o2 = (long)no * no, ov = (long)no * nv, opp = (long)no * (no + 1) / 2;
     const long ab = ((long)a * nv + b) * o2, ba = ((long)b * nv + a) * o2;
     const long tab = (long)a * no * ov + (long)b * no, tba = (long)b * no * ov + (long)a * no;
-    const double* __restrict__ n = Np + ((long)(a - a0) * nv + b) * o2;
+    const double* __restrict__ n = Np + ((long)(a - a0) * nbp + b) * o2;       // Np is [a1 - a0][nbp][o*o], nbp > b
     for (int e = threadIdx.x; e < o2; e += blockDim.x) {
         const int i = e / no, j = e - i * no;
         S[i * p + j] = n[e] + D[tab + (long)i * ov + j] + X[tba + (long)i * ov + j];
@@ -1850,12 +1850,12 @@ void cc_update_pairs(double* tc, double* dtc, const double* rc, const double* eo
     HIP_CHECK(hipGetLastError());
 }
 void residual_assemble_pairs(const double* V, const double* L, const double* Np, const double* D, const double* X,
-                             double* Rc, int no, int nv, int64_t r0, int64_t r1, int a0, stream_t s) {
+                             double* Rc, int no, int nv, int64_t r0, int64_t r1, int a0, int nbp, stream_t s) {
     if (r1 <= r0) return;
     if (!fused_pair_kernels_ok(no)) throw std::runtime_error("residual_assemble_pairs: nocc too large for the LDS tile");
     const size_t lds = sizeof(double) * no * (no + 1);
     hipLaunchKernelGGL(residual_assemble_pairs_kernel, dim3((unsigned)(r1 - r0)), dim3(256), lds, (hipStream_t)s, V, L, Np,
-                       D, X, Rc, no, nv, (long)r0, a0);
+                       D, X, Rc, no, nv, (long)r0, a0, nbp);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -123,8 +123,8 @@ class CCSD(ccd.CCD):
             # Symmetry-reduced, sharded form (world = 1 included): this rank's column slab of the ring products,
             # its rows of the pair-packed particle + hole ladders and of Q_kb; all-gathers; remainder.
             # V_abcd is never dressed: its T1 dressing (:165, ccsd.py:414-419) is carried by tau = T2 + T1 T1
-            # inside the ladders (include/pymes_amd.h, pymes_residual_slab).  The replicated work that the slab
-            # does not need (R1, V~_abij) is enqueued after the all-gathers have been started: overlap.
+            # inside the ladders, that of V_abij by Q_kb and two small products inside the finish (include/pymes_amd.h,
+            # pymes_residual_slab).  The singles residual is enqueued after the all-gathers have been started: overlap.
             if world > 1:      # V~_iajb / V~_iabj only for the second-index range that this rank's column slab reads
                 c0, c1 = pdist.slab_rows(ctx.no * ctx.nv, rank, world)
                 ctx.dress_V(t1, ("klij",))                                            # :165
@@ -140,16 +140,6 @@ class CCSD(ccd.CCD):
                 keys = ("ETd_t", "ETx_t", "QK_t") if st["pairs"] else ("ETd_t", "ETx_t", "L_t", "QK_t")
                 pending = [pdist.exchange_rows_start(st[key], rank, world) for key in keys]
             ctx.singles_residual(st["fd"], t1, t2, r1)                                # :167
-            if st["pairs"]:    # V~_abij only where the tiles (a,b) and (b,a) of this rank's pairs live
-                lo, hi = pdist.slab_rows(st["npp"], rank, world)
-                a0, a1 = pdist.a_range_of_pair_rows(lo, hi)
-                if 2 * (a1 - a0) * a1 >= 0.8 * ctx.nv * ctx.nv:          # the two cuts would cost as much as the whole block
-                    ctx.dress_V(t1, ("abij",), reduced_abij=True)
-                elif a1 > a0:
-                    ctx.dress_V(t1, ("abij",), reduced_abij=True, p_range=(a0, a1), q_range=(0, a1))
-                    ctx.dress_V(t1, ("abij",), reduced_abij=True, p_range=(0, a1), q_range=(a0, a1))
-            else:
-                ctx.dress_V(t1, ("abij",), reduced_abij=True)                         # :165
             for work in pending:
                 work.wait()
             if world > 1:

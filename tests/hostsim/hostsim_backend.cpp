@@ -358,7 +358,7 @@ void cc_update_pairs(double* tc, double* dtc, const double* rc, const double* eo
     }
 }
 void residual_assemble_pairs(const double* V, const double* L, const double* Np, const double* D, const double* X,
-                             double* Rc, int no, int nv, int64_t r0, int64_t r1, int a0, stream_t) {
+                             double* Rc, int no, int nv, int64_t r0, int64_t r1, int a0, int nbp, stream_t) {
     const int64_t o2 = (int64_t)no * no, ov = (int64_t)no * nv, opp = (int64_t)no * (no + 1) / 2;
     auto pm = [&](const double* M, int a, int i, int b, int j) { return M[((int64_t)a * no + i) * ov + b * no + j]; };
     for (int64_t r = r0; r < r1; ++r) {
@@ -368,7 +368,7 @@ void residual_assemble_pairs(const double* V, const double* L, const double* Np,
         for (int i = 0; i < no; ++i)
             for (int j = 0; j < no; ++j) {
                 auto S = [&](int x, int y) {
-                    return Np[((int64_t)(a - a0) * nv + b) * o2 + x * no + y] + pm(D, a, x, b, y) + pm(D, b, y, a, x) +
+                    return Np[((int64_t)(a - a0) * nbp + b) * o2 + x * no + y] + pm(D, a, x, b, y) + pm(D, b, y, a, x) +
                            pm(X, a, y, b, x) + pm(X, b, x, a, y);
                 };
                 const int ih = i > j ? i : j, il = i > j ? j : i;

@@ -137,7 +137,8 @@ def test_full_size_properties(gpu_lib):
         for dcd in (False, True):
             ctx.dress_V(t1, LOOP_KEYS)
             ctx.doubles_residual(f, t2, r2, is_dcd=dcd, dressed=True, sym_ladder=False, sym_rings=False)
-            ctx.dress_V(t1, ("klij", "iajb", "iabj", "abij"), reduced_abij=True)
+            ctx.dress_V(t1, ("klij", "iajb", "iabj"))
+            ctx.V_block("abij", dressed=True).zero_()          # amplitude-side mode: V_abij and V_abcd stay undressed
             for rank in range(world):
                 ctx.residual_slab(f, t2, ETd, ETx, Lb, rank, world, is_dcd=dcd, dressed=True, t1=t1, QK=QK)
             ctx.residual_finish(f, t2, ETd, ETx, Lb, parts, is_dcd=dcd, dressed=True, t1=t1, QK=QK)

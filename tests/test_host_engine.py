@@ -175,7 +175,8 @@ def sharded_residual_check(lib, cases, worlds, tol):
                 assert np.abs(r2.get() - ref).max() < tol, (no, nv, world, dcd)
             # the same with the T1 dressing of V_abcd carried by the amplitudes (never dresses abcd)
             for dcd in (False, True):
-                ctx.dress_V(dT1, ["abij", "klij", "iajb", "iabj"], reduced_abij=True)
+                ctx.dress_V(dT1, ["klij", "iajb", "iabj"])      # V_abij and V_abcd are never dressed in this mode
+                ctx.V_block("abij", dressed=True).zero_()
                 ETd, ETx, L = ctx.zeros((pad(ov), ov)), ctx.zeros((pad(ov), ov)), ctx.zeros((pad(npp), no * no))
                 QK = ctx.zeros((pad(ov), no * no))
                 # every rank dresses only the range of the second index of V_iajb / V_iabj that its column slab reads
@@ -199,14 +200,7 @@ def sharded_residual_check(lib, cases, worlds, tol):
                 Tall, dTall = ctx.zeros(Rall.shape), ctx.zeros(Rall.shape)
                 piece = lambda arr, rank: DeviceArray(ctx, arr.ptr + 8 * rank * chunk * 2 * no * no,
                                                       (chunk, 2, no * no), owned=False, keepalive=arr)
-                ctx.V_block("abij", dressed=True).zero_()     # each rank dresses V~_abij only where its pairs' tiles live
                 for rank in range(world):
-                    lo = min(rank * chunk, npp)
-                    hi = min(lo + chunk, npp)
-                    if hi > lo:
-                        a0, a1 = a_of(lo), a_of(hi - 1) + 1
-                        ctx.dress_V(dT1, ["abij"], reduced_abij=True, p_range=(a0, a1), q_range=(0, a1))
-                        ctx.dress_V(dT1, ["abij"], reduced_abij=True, p_range=(0, a1), q_range=(a0, a1))
                     ctx.residual_finish_pairs(dF, dT2, ETd, ETx, L, piece(Rall, rank), rank, world, dT1, QK, is_dcd=dcd,
                                               dressed=True)
                     ctx.pairs_pack(dT2, piece(Tall, rank), rank, world)
