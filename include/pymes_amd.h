@@ -83,8 +83,9 @@ int pymes_mp2(pymes_ctx* ctx, double level_shift, double* t2_dev, double* e_out_
 int pymes_ccsd_dress_fock(pymes_ctx* ctx, const double* f_dev, const double* t1_dev, double* fd_dev);
 /* CCSD.get_T1_dressed_V, ccsd.py:290-421; block_mask bit p = pattern id of the block
  * (bit 3-pos set when index `pos` is virtual: "abcd"=15, "klij"=0, "ijab"=3, "abij"=12 ...).
- * PYMES_DRESS_ABIJ_REDUCED: V~_abij without its V_pqcd t_ci t_dj and t_ak t_bl V~_klrs terms — the form
- * pymes_residual_slab/_finish expect when they are given t1 (those terms then travel with the ladders). */
+ * PYMES_DRESS_ABIJ_REDUCED: V~_abij without its V_pqcd t_ci t_dj and t_ak t_bl V~_klrs terms, i.e. what is left of
+ * it once those terms travel with the ladders (the amplitude-side mode of pymes_residual_finish forms the same
+ * quantity implicitly; the explicit block is kept for inspection and tests). */
 #define PYMES_DRESS_ABIJ_REDUCED (1u << 16)
 int pymes_ccsd_dress_V(pymes_ctx* ctx, const double* t1_dev, uint32_t block_mask);
 /* the same for the range [p_begin,p_end) of the FIRST and [q_begin,q_end) of the SECOND index only (an empty range =
@@ -134,8 +135,10 @@ int pymes_ladder_sym_unpack(pymes_ctx* ctx, const double* L_dev, double* r2_dev,
  * t1_dev / QK_dev (both or neither; CCSD/DCSD with PYMES_USE_DRESSED): the T1 dressing of V_abcd (ccsd.py:414-419)
  * is applied on the amplitude side instead — V~_abcd T = sum_pq X_a^p X_b^q V_pqcd T_cdij is evaluated from the
  * undressed, once-packed V_abcd / V_kbcd / V_klcd with tau = T + t1 t1.  V_abcd is then never dressed (no
- * pymes_ccsd_dress_abcd_rows, no second copy of V_abcd), V~_abij must be dressed with PYMES_DRESS_ABIJ_REDUCED
- * and V~_klij in full.  QK is a fourth exchange buffer, [o*v][o*o] on the device cut into the same row chunks
+ * pymes_ccsd_dress_abcd_rows, no second copy of V_abcd) and neither is V_abij: pymes_residual_finish reads it
+ * undressed and adds its T1 dressing through Ex + Ex^T as V_abcj t_ci - t_ak (V_kbij + V_kbcj t_ci + V_kbid t_dj + Q_kbij)
+ * (the (k,l)-bra part rides in the hole ladder taken with tau).  Only V~_klij, V~_iajb, V~_iabj have to be dressed.
+ * QK is a fourth exchange buffer, [o*v][o*o] on the device cut into the same row chunks
  * as ETd: QK[(k,b)] = [ QS | QA ] of sum_cd V_kbcd tau_cdij. */
 int pymes_residual_slab(pymes_ctx* ctx, const double* f_dev, const double* t2_dev, double* ETd_dev, double* ETx_dev,
                         double* L_dev, int rank, int world, uint32_t flags, const double* t1_dev, double* QK_dev);
