@@ -151,7 +151,7 @@ int pymes_ccsd_dress_abcd_rows(pymes_ctx* ctx, const double* t1_dev, int a_begin
  * amplitude-sized quantity only for them, in the compact layout Xc[P - r0][2][o*o]: tile 0 = X[a,b,:,:], tile 1 =
  * X[b,a,:,:] (zeros for a == b, so that dots over Xc summed over the ranks equal dots over the full array).
  *   pymes_residual_finish_pairs: pymes_residual_finish restricted to the rank's pairs -> Rc (L is read locally and is
- *                                NOT exchanged; ETd, ETx, QK must have been all-gathered); needs t1/QK
+ *                                NOT exchanged; ETd, ETx (and QK) must have been all-gathered); t1/QK NULL for CCD/DCD
  *   pymes_cc_update_pairs:       ccsd.py:176-179 on compact tiles (dt = r/(D+shift), t += delta dt)
  *   pymes_pairs_pack:            compact tiles of this rank from a full [v,v,o,o] array
  *   pymes_pairs_unpack:          full [v,v,o,o] array from the all-gathered compact buffer [world * chunk][2][o*o] */

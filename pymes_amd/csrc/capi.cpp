@@ -270,7 +270,6 @@ int pymes_residual_finish_pairs(pymes_ctx* ctx, const double* f, const double* t
                                 int world) {
     return guarded([&] {
         need(f, "f"); need(t2, "t2"); need(ETd, "ETd"); need(ETx, "ETx"); need(L, "L"); need(Rc, "Rc");
-        need(t1, "t1"); need(QK, "QK");
         E(ctx).residual_finish_pairs(f, t2, ETd, ETx, L, Rc, flags, t1, QK, rank, world);
     });
 }

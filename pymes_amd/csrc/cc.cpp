@@ -434,7 +434,8 @@ void Engine::residual_finish_pairs(const double* f, const double* t2, const doub
     const bool dcd = flags & 1u, dressed = flags & 2u;
     const int64_t o = no, v = nv, nn = n;
     const double w = dcd ? 0.5 : 1.0;
-    if (!L || !t1 || !QK) throw Error("residual_finish_pairs: L, t1 and QK are required");
+    if (!L) throw Error("residual_finish_pairs: L is required");
+    if ((t1 == nullptr) != (QK == nullptr)) throw Error("residual_finish_pairs: t1 and QK must be given together");
     if (!dev::fused_pair_kernels_ok(no)) throw Error("residual_finish_pairs: nocc too large for the fused assembly");
     int64_t r0, r1;
     pair_chunk(rank, world, r0, r1);
@@ -444,7 +445,6 @@ void Engine::residual_finish_pairs(const double* f, const double* t2, const doub
     TView T = make_view(const_cast<double*>(t2), {v, v, o, o});
     TView F = make_view(const_cast<double*>(f), {nn, nn});
     TView Fvv = slice(slice(F, 0, o, nn), 1, o, nn);
-    TView t = make_view(const_cast<double*>(t1), {v, o});
     ArenaScope scope(arena);
     // X_ac = f_ac - w sum Tt[a,d,k,l] V[l,k,d,c]  (ccd.py:206-221)
     TView Xvv = make_view(arena.alloc(v * v), {v, v});
@@ -464,9 +464,10 @@ void Engine::residual_finish_pairs(const double* f, const double* t2, const doub
     TView Np = make_view(arena.alloc(na * nb * o * o), {na, nb, o, o});
     contract(1.0, slice(Xvv, 0, a0, a1), "ac", slice(T, 1, 0, nb), "cbij", 0.0, Np, "abij");
     contract(1.0, slice(Xvv, 0, 0, nb), "bc", slice(T, 1, a0, a1), "caji", 1.0, Np, "abij");
-    amplitude_side_abij(t1, QK, Np, a0, a1, nb, true);
-    (void)dressed;      // V_abij is read undressed in the amplitude-side mode
-    dev::residual_assemble_pairs(block(P_abij).p, L, Np.p, ETd_p, ETx_p, Rc, no, nv, r0, r1, a0, static_cast<int>(nb), stream);
+    if (t1) amplitude_side_abij(t1, QK, Np, a0, a1, nb, true);
+    // V_abij is read undressed in the amplitude-side mode (CCSD); CCD/DCD have nothing to dress
+    const TView Vabij = block(P_abij, t1 ? false : dressed);
+    dev::residual_assemble_pairs(Vabij.p, L, Np.p, ETd_p, ETx_p, Rc, no, nv, r0, r1, a0, static_cast<int>(nb), stream);
     stats.permute_calls++;
     stats.permute_bytes += 8.0 * 5.5 * double(r1 - r0) * 2.0 * double(o * o);
 }

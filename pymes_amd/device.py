@@ -296,11 +296,11 @@ class Context:
         return out
 
     # ---- pair-sharded tail (include/pymes_amd.h) ----------------------------------------------------------------
-    def residual_finish_pairs(self, f, t2, ETd, ETx, L, Rc, rank, world, t1, QK, is_dcd=False, dressed=False):
+    def residual_finish_pairs(self, f, t2, ETd, ETx, L, Rc, rank, world, t1=None, QK=None, is_dcd=False, dressed=False):
         self.lib.call("pymes_residual_finish_pairs", self.handle, C.c_void_p(f.ptr), C.c_void_p(t2.ptr),
                       C.c_void_p(ETd.ptr), C.c_void_p(ETx.ptr), C.c_void_p(L.ptr), C.c_void_p(Rc.ptr),
-                      self._flags(is_dcd, dressed, False, True, True), C.c_void_p(t1.ptr), C.c_void_p(QK.ptr),
-                      int(rank), int(world))
+                      self._flags(is_dcd, dressed, False, True, True), C.c_void_p(t1.ptr if t1 is not None else 0),
+                      C.c_void_p(QK.ptr if QK is not None else 0), int(rank), int(world))
         return Rc
 
     def cc_update_pairs(self, tc, dtc, rc, shift, delta, rank, world):

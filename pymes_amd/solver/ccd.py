@@ -74,25 +74,30 @@ class CCD:
             e_last = e_mp2
             e_ccd = e_dir_ccd = e_ex_ccd = 0.
             first = True
+            shard = self._shard_setup(ctx, t2, sym and amps is None)     # one process per GPU (None for a single rank)
+            self.pair_sharded = shard is not None
             while np.abs(dE) > delta_e and iteration <= max_iter:
                 iteration += 1
-                r2 = ctx.pool_get(t2.shape)
-                ctx.doubles_residual(f_dev, t2, r2, is_dcd=self.is_dcd, sym_ladder=sym)    # ccd.py:100-102
-                dt2 = ctx.pool_get(t2.shape)
-                ctx.cc_update(t2, dt2, r2, level_shift, delta)                    # :123-124
-                ctx.pool_put(r2)
-                if first and amps is not None:
-                    np.copyto(amps, t2.get())     # the reference updates the caller's array in place (:124)
-                first = False
-                if self.is_diis:
-                    t2 = self.mixer.mix([dt2], [t2], release=ctx.pool_put)[0]     # :126-127
+                if shard is not None:
+                    nt, nr = self._sharded_iteration(ctx, shard, f_dev, t2, level_shift, delta)
+                else:
+                    r2 = ctx.pool_get(t2.shape)
+                    ctx.doubles_residual(f_dev, t2, r2, is_dcd=self.is_dcd, sym_ladder=sym)    # ccd.py:100-102
+                    dt2 = ctx.pool_get(t2.shape)
+                    ctx.cc_update(t2, dt2, r2, level_shift, delta)                    # :123-124
+                    ctx.pool_put(r2)
+                    if first and amps is not None:
+                        np.copyto(amps, t2.get())     # the reference updates the caller's array in place (:124)
+                    first = False
+                    if self.is_diis:
+                        t2 = self.mixer.mix([dt2], [t2], release=ctx.pool_put)[0]     # :126-127
+                    nt, nr = np.sqrt(ctx.dots([t2, dt2], [t2, dt2]))
+                    if not self.is_diis:
+                        ctx.pool_put(dt2)
                 e_dir_ccd, e_ex_ccd = ctx.ccd_energy(t2)                          # :132
                 e_ccd = e_dir_ccd + e_ex_ccd
                 dE = e_ccd - e_last
                 e_last = e_ccd
-                nt, nr = np.sqrt(ctx.dots([t2, dt2], [t2, dt2]))
-                if not self.is_diis:
-                    ctx.pool_put(dt2)
                 if iteration <= max_iter:
                     print_logging_info("Iteration = ", iteration, level=1)
                     print_logging_info("Correlation Energy = {:.12f}".format(e_ccd), level=2)
@@ -113,6 +118,69 @@ class CCD:
                 self._drop_mixer_history_of(ctx)
             if own:
                 ctx.close()
+
+    # ---- one process per GPU (torch.distributed): the same sharding as CCSD.iterate, without T1 ----------------
+    def _shard_setup(self, ctx, t2, allowed):
+        from pymes_amd import dist as pdist
+        from pymes_amd.device import DeviceArray
+        rank, world, _ = pdist.world()
+        if world == 1 or not allowed or not ctx.pairs_supported():
+            return None
+        import torch
+        no, nv = ctx.no, ctx.nv
+        dev = torch.device("cuda", ctx.device) if ctx.lib.backend.startswith("hip") else torch.device("cpu")
+
+        def shared(rows, cols):
+            t = torch.zeros((pdist.padded_rows(rows, world), cols), dtype=torch.float64, device=dev)
+            return t, DeviceArray(ctx, t.data_ptr(), tuple(t.shape), owned=False, keepalive=t)
+        npp = nv * (nv + 1) // 2
+        lo, hi = pdist.slab_rows(npp, rank, world)
+        sh = {"rank": rank, "world": world, "npp": npp, "lo": lo, "hi": hi, "cshape": (max(hi - lo, 1), 2, no * no)}
+        sh["ETd_t"], sh["ETd"] = shared(no * nv, no * nv)
+        sh["ETx_t"], sh["ETx"] = shared(no * nv, no * nv)
+        sh["L"] = ctx.zeros((pdist.padded_rows(npp, world), no * no))
+        sh["Tall_t"], sh["Tall"] = shared(npp, 2 * no * no)
+        sh["Tc"] = self._compact(ctx, sh)
+        ctx.pairs_pack(t2, sh["Tc"], rank, world)
+        return sh
+
+    @staticmethod
+    def _compact(ctx, sh):
+        arr = ctx.pool_get(sh["cshape"])
+        return arr.zero_() if sh["hi"] <= sh["lo"] else arr
+
+    def _sharded_iteration(self, ctx, sh, f_dev, t2, level_shift, delta):
+        """ccd.py:100-127 with the residual slab / pair-sharded tail of include/pymes_amd.h; t2 (full, replicated) is
+        refreshed in place from the all-gathered compact amplitudes."""
+        from pymes_amd import dist as pdist
+        from pymes_amd.device import DeviceArray
+        from pymes_amd.solver.ccsd import torch_sync
+        rank, world = sh["rank"], sh["world"]
+        ctx.residual_slab(f_dev, t2, sh["ETd"], sh["ETx"], sh["L"], rank, world, is_dcd=self.is_dcd)
+        ctx.sync()
+        for work in [pdist.exchange_rows_start(sh[k], rank, world) for k in ("ETd_t", "ETx_t")]:
+            work.wait()
+        torch_sync()
+        rc, dtc, tc = self._compact(ctx, sh), self._compact(ctx, sh), sh["Tc"]
+        ctx.residual_finish_pairs(f_dev, t2, sh["ETd"], sh["ETx"], sh["L"], rc, rank, world, is_dcd=self.is_dcd)
+        ctx.cc_update_pairs(tc, dtc, rc, level_shift, delta, rank, world)             # :123-124
+        ctx.pool_put(rc)
+        if self.is_diis:
+            tc = self.mixer.mix([dtc], [tc], release=ctx.pool_put, sharded=(0,), allreduce=pdist.allreduce_sum)[0]
+        if sh["hi"] > sh["lo"]:
+            n = sh["hi"] - sh["lo"]
+            mine = DeviceArray(ctx, sh["Tall"].ptr + 8 * sh["lo"] * 2 * ctx.no * ctx.no, (n, 2, ctx.no * ctx.no),
+                               owned=False, keepalive=sh["Tall"])
+            mine.copy_from(DeviceArray(ctx, tc.ptr, mine.shape, owned=False, keepalive=tc))
+        ctx.sync()
+        pdist.exchange_rows(sh["Tall_t"], rank, world)
+        torch_sync()
+        ctx.pairs_unpack(sh["Tall"], t2, world)
+        nt, nr = np.sqrt(pdist.allreduce_sum(ctx.dots([tc, dtc], [tc, dtc])))
+        if not self.is_diis:
+            ctx.pool_put(dtc)
+        sh["Tc"] = tc
+        return nt, nr
 
     def _drop_mixer_history_of(self, ctx):
         """The reference's mixer keeps growing across solve() calls on one instance

@@ -128,6 +128,14 @@ def _solver_worker(rank, world, port, libpath, out):
             assert s.pair_sharded
             res[(no, nv, dcsd, diis)] = (float(r["ccsd e"]), int(s.iterations), float(np.abs(r["t2"]).sum()),
                                          float(np.abs(r["t2"] - r["t2"].transpose(1, 0, 3, 2)).max()))
+        from pymes_amd.solver.ccd import CCD
+        for no, nv, dcd, diis in ((3, 7, False, True), (2, 6, True, True), (3, 5, True, False)):
+            f, V, B, eps = synthetic_case(no, nv, seed=4, scale=0.3)
+            s = CCD(no, delta_e=1e-10, is_dcd=dcd, is_diis=diis)
+            with contextlib.redirect_stdout(io.StringIO()):
+                r = s.solve(f, V)
+            assert s.pair_sharded
+            res[("ccd", no, nv, dcd, diis)] = (float(r["ccd e"]), int(s.iterations), float(np.abs(r["t2 amp"]).sum()), 0.0)
         out[rank] = res
     finally:
         dist.destroy_process_group()
@@ -141,7 +149,15 @@ def test_distributed_solver_host_logic(hostsim_lib, world):
     out = mgr.dict()
     mp.spawn(_solver_worker, args=(world, _free_port(), hostsim_lib.path, out), nprocs=world, join=True)
     assert len(out) == world and all(out[r] == out[0] for r in range(world))          # ranks agree bit for bit
-    for (no, nv, dcsd, diis), (e, it, t2sum, asym) in out[0].items():
+    for key, (e, it, t2sum, asym) in out[0].items():
+        if key[0] == "ccd":
+            _, no, nv, dcd, diis = key
+            f, V, B, eps = synthetic_case(no, nv, seed=4, scale=0.3)
+            ref = oc.ccd_solve(no, f, V, is_dcd=dcd, is_diis=diis, delta_e=1e-10)
+            assert abs(e - ref["e"]) < 1e-10 and it == ref["iterations"], (key, e, ref["e"], it, ref["iterations"])
+            assert abs(t2sum - np.abs(ref["t2"]).sum()) < 1e-8
+            continue
+        no, nv, dcsd, diis = key
         f, V, B, eps = synthetic_case(no, nv, seed=3, scale=0.3)
         ref = oc.ccsd_solve(no, f, V, is_dcsd=dcsd, is_diis=diis, delta_e=1e-10)
         assert abs(e - ref["e"]) < 1e-10 and it == ref["iterations"], (no, nv, dcsd, diis, e, ref["e"], it)

@@ -35,6 +35,13 @@ def _worker(rank, world, port, out):
             assert s.pair_sharded
             ints.ctx.close()
             res[f"syn_{no}_{nv}_{'dcsd' if dcsd else 'ccsd'}"] = (float(r["ccsd e"]), int(s.iterations))
+        from pymes_amd.solver.ccd import CCD
+        f, V, B, eps = synthetic_case(4, 12, seed=0, scale=0.3)
+        c = CCD(4, delta_e=1e-10, device=0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = c.solve(f, V)
+        assert c.pair_sharded
+        res["syn_4_12_ccd"] = (float(r["ccd e"]), int(c.iterations))
         # unsymmetric user amplitudes take the plain-ladder sharded path
         no, nv = 4, 12
         f, V, B, eps = synthetic_case(no, nv, seed=0, scale=0.3)
@@ -60,6 +67,8 @@ def test_two_ranks_one_gpu(gpu_lib):
     assert abs(e - gold["syn_6_20"]["ccsd"]["e"]) < 1e-9 and it == gold["syn_6_20"]["ccsd"]["iterations"]
     e, it = out[0]["syn_4_12_dcsd"]
     assert abs(e - gold["syn_4_12"]["dcsd"]["e"]) < 1e-9 and it == gold["syn_4_12"]["dcsd"]["iterations"]
+    e, it = out[0]["syn_4_12_ccd"]
+    assert abs(e - gold["syn_4_12"]["ccd"]["e"]) < 1e-9 and it == gold["syn_4_12"]["ccd"]["iterations"]
     # unsymmetric start: the reference's own fixed-point run (= oracle) is the expectation, not the converged CCSD
     from oracle import cc_oracle as oc
     from oracle.cases import synthetic_case
