@@ -68,6 +68,25 @@ def test_dgemm_lds_dma_kernel(ctx, a_kc, b_kc):
     _gemm_case(ctx, 4000, 1275, 2052, a_kc, b_kc, 1.0, 0.0, rng, ldb_pad=0 if b_kc else 1)        # ladder-like N
 
 
+def test_lds_dma_kernel_batched(ctx):
+    """Batched products big enough for the LDS-DMA kernel: per-batch base pointers (moved to SGPRs in the kernel), a
+    stride-0 operand shared by all batches, and k-split remainder tiles across batch boundaries."""
+    rng = np.random.default_rng(9)
+    nb, M, N, K = 3, 1500, 1530, 1100
+    A, B = rng.standard_normal((nb, M, K)), rng.standard_normal((nb, K, N))
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    got = ctx.contract("zmk,zkn->zmn", ctx.array(A), ctx.array(B), batch="z").get()
+    dma = ctx.prof_query(kernel_class=1)
+    ctx.prof_enable(False)
+    assert dma["launches"] == 1, "the LDS-DMA kernel was not selected"
+    assert np.abs(got - np.einsum("zmk,zkn->zmn", A, B)).max() < 1e-10
+    S = rng.standard_normal((K, N))                          # one B for all batches
+    C0 = rng.standard_normal((nb, M, N))
+    got = ctx.contract("zmk,kn->zmn", ctx.array(A), ctx.array(S), out=ctx.array(C0), alpha=0.5, beta=-1.0, batch="z").get()
+    assert np.abs(got - (0.5 * np.einsum("zmk,kn->zmn", A, S) - C0)).max() < 1e-10
+
+
 def test_dgemm_tail_wave_split(ctx):
     """529 tiles of 128x128 = one full wave of 512 + 17: the remainder runs k-split (tile-local workspace)."""
     rng = np.random.default_rng(7)
