@@ -157,7 +157,20 @@ int pymes_ccsd_dress_abcd_rows(pymes_ctx* ctx, const double* t1_dev, int a_begin
  *   pymes_pairs_unpack:          full [v,v,o,o] array from the all-gathered compact buffer [world * chunk][2][o*o] */
 int pymes_residual_finish_pairs(pymes_ctx* ctx, const double* f_dev, const double* t2_dev, const double* ETd_dev,
                                 const double* ETx_dev, const double* L_dev, double* Rc_dev, uint32_t flags,
-                                const double* t1_dev, const double* QK_dev, int rank, int world);
+                                const double* t1_dev, const double* QK_dev, int rank, int world, const double* Xvv_dev);
+/* Small replicated intermediates as K-sharded partial sums (world > 1): every rank sums over its chunk of one occupied
+ * index and the v x v / o x v results are all-reduced by the caller.
+ *   pymes_xvv_partial:              X_ac = f_ac - w Tt_adkl V_lkdc (ccd.py:206-221), k in the rank's chunk, f on rank 0;
+ *                                   the all-reduced matrix is handed to pymes_residual_finish_pairs (Xvv_dev, else NULL)
+ *   pymes_ccsd_dress_fock_partial:  the six T1.V intermediates of ccsd.py:226-288 (j in the rank's chunk) into W_dev
+ *                                   (pymes_ccsd_dress_fock_ws doubles); pymes_ccsd_dress_fock_finish completes f~ from the
+ *                                   all-reduced W.  pymes_ccsd_dress_fock = partial(0, 1) + finish. */
+int pymes_xvv_partial(pymes_ctx* ctx, const double* f_dev, const double* t2_dev, double* Xvv_dev, int rank, int world,
+                      uint32_t flags);
+int pymes_ccsd_dress_fock_ws(pymes_ctx* ctx, int64_t* n_doubles);
+int pymes_ccsd_dress_fock_partial(pymes_ctx* ctx, const double* t1_dev, double* W_dev, int rank, int world);
+int pymes_ccsd_dress_fock_finish(pymes_ctx* ctx, const double* f_dev, const double* t1_dev, const double* W_dev,
+                                 double* fd_dev);
 int pymes_cc_update_pairs(pymes_ctx* ctx, double* tc_dev, double* dtc_dev, const double* rc_dev, double level_shift,
                           double delta, int rank, int world);
 int pymes_pairs_supported(pymes_ctx* ctx, int* yes);   /* the o x o tile of the fused pair kernels fits the LDS */

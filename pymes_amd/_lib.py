@@ -58,7 +58,12 @@ SIGNATURES = {
     "pymes_residual_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "pymes_residual_finish_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                              C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+                                              C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                              C.c_void_p]),
+    "pymes_xvv_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32]),
+    "pymes_ccsd_dress_fock_ws": (C.c_int, [C.c_void_p, c_i64_p]),
+    "pymes_ccsd_dress_fock_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "pymes_ccsd_dress_fock_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pymes_cc_update_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
                                         C.c_int]),
     "pymes_pairs_supported": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),

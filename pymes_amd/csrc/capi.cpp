@@ -267,10 +267,34 @@ int pymes_residual_finish(pymes_ctx* ctx, const double* f, const double* t2, con
 }
 int pymes_residual_finish_pairs(pymes_ctx* ctx, const double* f, const double* t2, const double* ETd, const double* ETx,
                                 const double* L, double* Rc, uint32_t flags, const double* t1, const double* QK, int rank,
-                                int world) {
+                                int world, const double* Xvv) {
     return guarded([&] {
         need(f, "f"); need(t2, "t2"); need(ETd, "ETd"); need(ETx, "ETx"); need(L, "L"); need(Rc, "Rc");
-        E(ctx).residual_finish_pairs(f, t2, ETd, ETx, L, Rc, flags, t1, QK, rank, world);
+        E(ctx).residual_finish_pairs(f, t2, ETd, ETx, L, Rc, flags, t1, QK, rank, world, Xvv);
+    });
+}
+int pymes_xvv_partial(pymes_ctx* ctx, const double* f, const double* t2, double* Xvv, int rank, int world, uint32_t flags) {
+    return guarded([&] {
+        need(f, "f"); need(t2, "t2"); need(Xvv, "Xvv");
+        E(ctx).xvv_partial(f, t2, Xvv, rank, world, flags);
+    });
+}
+int pymes_ccsd_dress_fock_ws(pymes_ctx* ctx, int64_t* n_doubles) {
+    return guarded([&] {
+        if (!n_doubles) throw pymes::Error("null output");
+        *n_doubles = E(ctx).dress_fock_ws_doubles();
+    });
+}
+int pymes_ccsd_dress_fock_partial(pymes_ctx* ctx, const double* t1, double* W, int rank, int world) {
+    return guarded([&] {
+        need(t1, "t1"); need(W, "W");
+        E(ctx).dress_fock_partial(t1, W, rank, world);
+    });
+}
+int pymes_ccsd_dress_fock_finish(pymes_ctx* ctx, const double* f, const double* t1, const double* W, double* fd) {
+    return guarded([&] {
+        need(f, "f"); need(t1, "t1"); need(W, "W"); need(fd, "fd");
+        E(ctx).dress_fock_finish(f, t1, W, fd);
     });
 }
 int pymes_pairs_supported(pymes_ctx* ctx, int* yes) {

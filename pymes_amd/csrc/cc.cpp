@@ -430,7 +430,7 @@ static int a_of_pair_row(int64_t r) {
 // pairs; the assembly only for its pairs.  Needs the fused assembly kernel (o x o tile in LDS).
 void Engine::residual_finish_pairs(const double* f, const double* t2, const double* ETd_p, const double* ETx_p,
                                    const double* L, double* Rc, unsigned flags, const double* t1, const double* QK,
-                                   int rank, int world) {
+                                   int rank, int world, const double* Xvv_in) {
     const bool dcd = flags & 1u, dressed = flags & 2u;
     const int64_t o = no, v = nv, nn = n;
     const double w = dcd ? 0.5 : 1.0;
@@ -446,9 +446,9 @@ void Engine::residual_finish_pairs(const double* f, const double* t2, const doub
     TView F = make_view(const_cast<double*>(f), {nn, nn});
     TView Fvv = slice(slice(F, 0, o, nn), 1, o, nn);
     ArenaScope scope(arena);
-    // X_ac = f_ac - w sum Tt[a,d,k,l] V[l,k,d,c]  (ccd.py:206-221)
-    TView Xvv = make_view(arena.alloc(v * v), {v, v});
-    {
+    // X_ac = f_ac - w sum Tt[a,d,k,l] V[l,k,d,c]  (ccd.py:206-221): given (all-reduced xvv_partial) or formed here
+    TView Xvv = Xvv_in ? make_view(const_cast<double*>(Xvv_in), {v, v}) : make_view(arena.alloc(v * v), {v, v});
+    if (!Xvv_in) {
         ArenaScope s2(arena);
         TView Ttd = make_view(arena.alloc(o * o * v * v), {v, o, v, o});
         permute(2.0, T, "abij", 0.0, Ttd, "aibj");
@@ -718,7 +718,40 @@ void Engine::ladder_sym_unpack(const double* L, double* r2, double beta) {
 //   f~_vv = f_vv + G - t f_ov - t Mm                                  (:282-286)
 //   f~_vo = f_vo - t f_oo + f_vv t - t (f_ov t) + 2 K1^T - K2 - t L + G t - t Mm t   (:260-272)
 // -----------------------------------------------------------------------------------
-void Engine::dress_fock(const double* f, const double* t1, double* fd) {
+// The dressed Fock matrix is built in two stages.  Stage 1: the six intermediates that contract T1 with a V block over
+// (b,j) — linear in V, so a rank may sum over its chunk of the occupied index j only (one process per GPU: the partial
+// buffers are all-reduced, 0.6 MB at (50,200)); W = [ G (v,v) | J2 (o,v) | Mm (o,v) | K1 (o,v) | K2 (v,o) | L (o,o) ].
+// Stage 2: the products of those with T1 and f (tiny, replicated).
+int64_t Engine::dress_fock_ws_doubles() const {
+    const int64_t o = no, v = nv;
+    return v * v + 4 * o * v + o * o;
+}
+
+void Engine::dress_fock_partial(const double* t1, double* W, int rank, int world) {
+    const int64_t o = no, v = nv;
+    if (world < 1 || rank < 0 || rank >= world) throw Error("dress_fock_partial: bad rank/world");
+    const int64_t c = (o + world - 1) / world, j0 = std::min<int64_t>(rank * c, o), j1 = std::min<int64_t>(j0 + c, o);
+    TView G = make_view(W, {v, v}), J2 = make_view(G.p + v * v, {o, v}), Mm = make_view(J2.p + o * v, {o, v}),
+          K1 = make_view(Mm.p + o * v, {o, v}), K2 = make_view(K1.p + o * v, {v, o}), L = make_view(K2.p + o * v, {o, o});
+    if (j1 <= j0) {
+        dev::memset_zero(W, sizeof(double) * dress_fock_ws_doubles(), stream);
+        return;
+    }
+    TView t = slice(make_view(const_cast<double*>(t1), {v, o}), 1, j0, j1);
+    const bool all = (j0 == 0 && j1 == o);       // whole blocks: the planner may reuse its cached transposed copies
+    auto js = [&](int pat) { return all ? block(pat) : slice(block(pat), 0, j0, j1); };
+    contract(2.0, t, "bj", js(P_iabc), "jabc", 0.0, G, "ac");
+    contract(-1.0, t, "bj", js(P_iabc), "jacb", 1.0, G, "ac");
+    contract(1.0, t, "bj", js(P_ijab), "jkcb", 0.0, J2, "kc");
+    contract(2.0, t, "bj", js(P_ijab), "jkbc", 0.0, Mm, "kc");
+    axpby(-1.0, J2, 1.0, Mm);
+    contract(2.0, t, "bj", js(P_ijak), "jkbi", 0.0, L, "ki");
+    contract(-1.0, t, "bj", js(P_ijka), "jkib", 1.0, L, "ki");
+    contract(1.0, t, "bj", js(P_iabj), "jabi", 0.0, K1, "ia");
+    contract(1.0, t, "bj", js(P_iajb), "jaib", 0.0, K2, "ai");
+}
+
+void Engine::dress_fock_finish(const double* f, const double* t1, const double* W, double* fd) {
     const int64_t o = no, v = nv, nn = n;
     TView F = make_view(const_cast<double*>(f), {nn, nn}), D = make_view(fd, {nn, nn});
     TView t = make_view(const_cast<double*>(t1), {v, o});
@@ -728,18 +761,10 @@ void Engine::dress_fock(const double* f, const double* t1, double* fd) {
     TView Foo = blk(F, 0, 0), Fov = blk(F, 0, 1), Fvv = blk(F, 1, 1);
     TView Doo = blk(D, 0, 0), Dov = blk(D, 0, 1), Dvo = blk(D, 1, 0), Dvv = blk(D, 1, 1);
     copy(F, D);
+    double* w = const_cast<double*>(W);
+    TView G = make_view(w, {v, v}), J2 = make_view(G.p + v * v, {o, v}), Mm = make_view(J2.p + o * v, {o, v}),
+          K1 = make_view(Mm.p + o * v, {o, v}), K2 = make_view(K1.p + o * v, {v, o}), L = make_view(K2.p + o * v, {o, o});
     ArenaScope scope(arena);
-    auto mat = [&](int64_t r, int64_t c) { return make_view(arena.alloc(r * c), {r, c}); };
-    TView G = mat(v, v), Mm = mat(o, v), L = mat(o, o), K1 = mat(o, v), K2 = mat(v, o), J2 = mat(o, v);
-    contract(2.0, t, "bj", block(P_iabc), "jabc", 0.0, G, "ac");
-    contract(-1.0, t, "bj", block(P_iabc), "jacb", 1.0, G, "ac");
-    contract(1.0, t, "bj", block(P_ijab), "jkcb", 0.0, J2, "kc");
-    contract(2.0, t, "bj", block(P_ijab), "jkbc", 0.0, Mm, "kc");
-    axpby(-1.0, J2, 1.0, Mm);
-    contract(2.0, t, "bj", block(P_ijak), "jkbi", 0.0, L, "ki");
-    contract(-1.0, t, "bj", block(P_ijka), "jkib", 1.0, L, "ki");
-    contract(1.0, t, "bj", block(P_iabj), "jabi", 0.0, K1, "ia");
-    contract(1.0, t, "bj", block(P_iajb), "jaib", 0.0, K2, "ai");
     // ov
     axpby(2.0, K1, 1.0, Dov);
     axpby(-1.0, J2, 1.0, Dov);
@@ -754,7 +779,7 @@ void Engine::dress_fock(const double* f, const double* t1, double* fd) {
     // vo
     contract(-1.0, t, "aj", Foo, "ji", 1.0, Dvo, "ai");
     contract(1.0, Fvv, "ab", t, "bi", 1.0, Dvo, "ai");
-    TView ft = mat(o, o);   // (f_ov + Mm) t   -> shared by -t (f_ov t) and -t Mm t
+    TView ft = make_view(arena.alloc(o * o), {o, o});   // (f_ov + Mm) t   -> shared by -t (f_ov t) and -t Mm t
     contract(1.0, Fov, "jb", t, "bi", 0.0, ft, "ji");
     contract(1.0, Mm, "jb", t, "bi", 1.0, ft, "ji");
     axpby(1.0, L, 1.0, ft);            // ft = f_ov t + Mm t + L
@@ -762,6 +787,35 @@ void Engine::dress_fock(const double* f, const double* t1, double* fd) {
     permute(2.0, K1, "ia", 1.0, Dvo, "ai");
     axpby(-1.0, K2, 1.0, Dvo);
     contract(1.0, G, "ac", t, "ci", 1.0, Dvo, "ai");
+}
+
+void Engine::dress_fock(const double* f, const double* t1, double* fd) {
+    ArenaScope scope(arena);
+    double* W = arena.alloc(dress_fock_ws_doubles());
+    dress_fock_partial(t1, W, 0, 1);
+    dress_fock_finish(f, t1, W, fd);
+}
+
+// X_ac = f_ac - w sum_{kdl} Tt[a,d,k,l] V[l,k,d,c] (ccd.py:206-221), the sum restricted to this rank's chunk of k (one
+// process per GPU; f_ac enters on rank 0 only): v x v partial results to be all-reduced
+void Engine::xvv_partial(const double* f, const double* t2, double* Xvv_p, int rank, int world, unsigned flags) {
+    const bool dcd = flags & 1u;
+    const int64_t o = no, v = nv, nn = n;
+    if (world < 1 || rank < 0 || rank >= world) throw Error("xvv_partial: bad rank/world");
+    const int64_t c = (o + world - 1) / world, k0 = std::min<int64_t>(rank * c, o), k1 = std::min<int64_t>(k0 + c, o);
+    TView Xvv = make_view(Xvv_p, {v, v});
+    TView F = make_view(const_cast<double*>(f), {nn, nn});
+    if (rank == 0) copy(slice(slice(F, 0, o, nn), 1, o, nn), Xvv);
+    else zero(Xvv);
+    if (k1 <= k0) return;
+    ArenaScope scope(arena);
+    TView T = make_view(const_cast<double*>(t2), {v, v, o, o});
+    TView Tk = slice(T, 2, k0, k1);                                      // T[a,d,k,l], k in the chunk
+    TView Ttd = make_view(arena.alloc(v * (k1 - k0) * v * o), {v, k1 - k0, v, o});
+    permute(2.0, Tk, "adkl", 0.0, Ttd, "akdl");
+    permute(-1.0, Tk, "dakl", 1.0, Ttd, "akdl");
+    TView Vk = slice(make_view(get_static("Vk"), {o, v, o, v}), 0, k0, k1);
+    contract(dcd ? -0.5 : -1.0, Ttd, "akdl", Vk, "kdlc", 1.0, Xvv, "ac");
 }
 
 // -----------------------------------------------------------------------------------

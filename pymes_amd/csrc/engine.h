@@ -108,6 +108,11 @@ class Engine {
     void mp2(double shift, double* t2, double e_out[2]);                                      // mp2.py:9-22
     void hf_fock_matrix(const double* h_host, double* f_host);                                // hf.py:14-18
     void dress_fock(const double* f, const double* t1, double* fd);                           // ccsd.py:226-288
+    // the same in two stages with a K-sharded first stage (one process per GPU), see cc.cpp
+    int64_t dress_fock_ws_doubles() const;
+    void dress_fock_partial(const double* t1, double* W, int rank, int world);
+    void dress_fock_finish(const double* f, const double* t1, const double* W, double* fd);
+    void xvv_partial(const double* f, const double* t2, double* Xvv, int rank, int world, unsigned flags);
     // ccsd.py:290-421; cut = {p0,p1,q0,q1} (optional): only these ranges of the first / second (virtual) index
     void dress_V(const double* t1, uint32_t mask, const int64_t* cut = nullptr);
     void singles_residual(const double* fd, const double* t1, const double* t2, double* r1);  // ccsd.py:423-438
@@ -132,7 +137,8 @@ class Engine {
     // v(v+1)/2 (the rows of L it computed itself) and produces R for exactly those pairs in the compact layout
     // Rc[P - r0][2][o*o] (tiles R[a,b,:,:], R[b,a,:,:]); L is read locally, ETd/ETx/QK must have been exchanged
     void residual_finish_pairs(const double* f, const double* t2, const double* ETd, const double* ETx, const double* L,
-                               double* Rc, unsigned flags, const double* t1, const double* QK, int rank, int world);
+                               double* Rc, unsigned flags, const double* t1, const double* QK, int rank, int world,
+                               const double* Xvv_in = nullptr);
     void pair_chunk(int rank, int world, int64_t& r0, int64_t& r1) const;
     void amplitude_side_abij(const double* t1, const double* QK, const TView& N, int64_t a0, int64_t a1, int64_t b1,
                              bool with_partner);

@@ -296,12 +296,33 @@ class Context:
         return out
 
     # ---- pair-sharded tail (include/pymes_amd.h) ----------------------------------------------------------------
-    def residual_finish_pairs(self, f, t2, ETd, ETx, L, Rc, rank, world, t1=None, QK=None, is_dcd=False, dressed=False):
+    def residual_finish_pairs(self, f, t2, ETd, ETx, L, Rc, rank, world, t1=None, QK=None, is_dcd=False, dressed=False,
+                              Xvv=None):
         self.lib.call("pymes_residual_finish_pairs", self.handle, C.c_void_p(f.ptr), C.c_void_p(t2.ptr),
                       C.c_void_p(ETd.ptr), C.c_void_p(ETx.ptr), C.c_void_p(L.ptr), C.c_void_p(Rc.ptr),
                       self._flags(is_dcd, dressed, False, True, True), C.c_void_p(t1.ptr if t1 is not None else 0),
-                      C.c_void_p(QK.ptr if QK is not None else 0), int(rank), int(world))
+                      C.c_void_p(QK.ptr if QK is not None else 0), int(rank), int(world),
+                      C.c_void_p(Xvv.ptr if Xvv is not None else 0))
         return Rc
+
+    def xvv_partial(self, f, t2, Xvv, rank, world, is_dcd=False):
+        self.lib.call("pymes_xvv_partial", self.handle, C.c_void_p(f.ptr), C.c_void_p(t2.ptr), C.c_void_p(Xvv.ptr),
+                      int(rank), int(world), _lib.PYMES_DCD if is_dcd else 0)
+        return Xvv
+
+    def dress_fock_ws(self):
+        n = C.c_int64()
+        self.lib.call("pymes_ccsd_dress_fock_ws", self.handle, C.byref(n))
+        return n.value
+
+    def dress_fock_partial(self, t1, W, rank, world):
+        self.lib.call("pymes_ccsd_dress_fock_partial", self.handle, C.c_void_p(t1.ptr), C.c_void_p(W.ptr), int(rank), int(world))
+        return W
+
+    def dress_fock_finish(self, f, t1, W, fd):
+        self.lib.call("pymes_ccsd_dress_fock_finish", self.handle, C.c_void_p(f.ptr), C.c_void_p(t1.ptr), C.c_void_p(W.ptr),
+                      C.c_void_p(fd.ptr))
+        return fd
 
     def cc_update_pairs(self, tc, dtc, rc, shift, delta, rank, world):
         self.lib.call("pymes_cc_update_pairs", self.handle, C.c_void_p(tc.ptr), C.c_void_p(dtc.ptr), C.c_void_p(rc.ptr),

@@ -70,6 +70,22 @@ def allreduce_sum(vec):
     return t.cpu().numpy()
 
 
+def allreduce_tensor_start(t):
+    """In-place sum of a torch tensor over the ranks; returns a handle with ``wait()`` (async under RCCL)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return _Done()
+    if os.environ.get("PYMES_SYNC_EXCHANGE") or not t.is_cuda or dist.get_backend() == "gloo":
+        if t.is_cuda:                               # test rig: several ranks on one GPU, gloo cannot reduce device memory
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return _Done()
+    return _Pending(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True), t)
+
+
 class _Done:
     def wait(self):
         return True

@@ -104,6 +104,12 @@ class CCSD(ccd.CCD):
                     st["Tall_t"], st["Tall"] = shared(st["npp"], 2 * no * no)       # exchange buffer of the compact T2
                     st["Tc"] = self._compact(ctx, st)
                     ctx.pairs_pack(t2, st["Tc"], rank, wsize)
+
+                def reduced(n):          # small buffer that is summed over the ranks
+                    t = torch.zeros((n,), dtype=torch.float64, device=dev)
+                    return t, DeviceArray(ctx, t.data_ptr(), (n,), owned=False, keepalive=t)
+                st["W_t"], st["W"] = reduced(ctx.dress_fock_ws())
+                st["Xvv_t"], st["Xvv"] = reduced(nv * nv)
             else:
                 st["lad_rows"] = nv * nv
                 st["lad_t"], st["lad"] = shared(nv * nv, no * no)
@@ -116,9 +122,16 @@ class CCSD(ccd.CCD):
         """One pass of the loop body ccsd.py:159-209.  Returns (e_1b, e_dir, e_ex, |T2|, |dT2|)."""
         ctx, t1, t2 = st["ctx"], st["t1"], st["t2"]
         shift = st["level_shift"]
-        ctx.dress_fock(st["f"], t1, st["fd"])                        # :163
-        r1 = ctx.pool_get(t1.shape)
         world, rank = st["world"], st["rank"]
+        if world > 1 and st["sym"]:      # :163 with the T1.V intermediates summed over this rank's chunk of j only
+            ctx.dress_fock_partial(t1, st["W"], rank, world)
+            ctx.sync()
+            pdist.allreduce_tensor_start(st["W_t"]).wait()
+            torch_sync()
+            ctx.dress_fock_finish(st["f"], t1, st["W"], st["fd"])
+        else:
+            ctx.dress_fock(st["f"], t1, st["fd"])                    # :163
+        r1 = ctx.pool_get(t1.shape)
         if st["sym"]:
             # Symmetry-reduced, sharded form (world = 1 included): this rank's column slab of the ring products,
             # its rows of the pair-packed particle + hole ladders and of Q_kb; all-gathers; remainder.
@@ -136,9 +149,13 @@ class CCSD(ccd.CCD):
                               dressed=True, t1=t1, QK=st["QK"])                        # :171
             pending = []
             if world > 1:
+                if st["pairs"]:      # X_ac (:206-221) as a partial sum over this rank's chunk of k, all-reduced below
+                    ctx.xvv_partial(st["fd"], t2, st["Xvv"], rank, world, is_dcd=self.is_dcd)
                 ctx.sync()
                 keys = ("ETd_t", "ETx_t", "QK_t") if st["pairs"] else ("ETd_t", "ETx_t", "L_t", "QK_t")
                 pending = [pdist.exchange_rows_start(st[key], rank, world) for key in keys]
+                if st["pairs"]:
+                    pending.append(pdist.allreduce_tensor_start(st["Xvv_t"]))
             ctx.singles_residual(st["fd"], t1, t2, r1)                                # :167
             for work in pending:
                 work.wait()
@@ -202,7 +219,7 @@ class CCSD(ccd.CCD):
         rank, world, shift = st["rank"], st["world"], st["level_shift"]
         rc = self._compact(ctx, st)
         ctx.residual_finish_pairs(st["fd"], t2, st["ETd"], st["ETx"], st["L"], rc, rank, world, t1, st["QK"],
-                                  is_dcd=self.is_dcd, dressed=True)                  # :171
+                                  is_dcd=self.is_dcd, dressed=True, Xvv=st["Xvv"])   # :171
         dt1, dtc, tc = ctx.pool_get(t1.shape), self._compact(ctx, st), st["Tc"]
         ctx.cc_update(t1, dt1, r1, shift, self.delta)                                 # :176-179
         ctx.cc_update_pairs(tc, dtc, rc, shift, self.delta, rank, world)

@@ -192,6 +192,18 @@ def sharded_residual_check(lib, cases, worlds, tol):
                 ctx.residual_finish(dF, dT2, ETd, ETx, L, r2, is_dcd=dcd, dressed=True, t1=dT1, QK=QK)
                 ref = oc.ccsd_doubles_residual(no, fd_ref, t2, Vd_ref, is_dcsd=dcd)
                 assert np.abs(r2.get() - ref).max() < tol, ("t1-side", no, nv, world, dcd)
+                # K-sharded small intermediates: the partial sums of all ranks add up to the replicated result
+                Wsum = np.zeros(ctx.dress_fock_ws())
+                Xsum = np.zeros((nv, nv))
+                for rank in range(world):
+                    Wsum += ctx.dress_fock_partial(dT1, ctx.empty((ctx.dress_fock_ws(),)), rank, world).get()
+                    Xsum += ctx.xvv_partial(dF, dT2, ctx.empty((nv, nv)), rank, world, is_dcd=dcd).get()
+                fd2 = ctx.dress_fock_finish(ctx.array(f), dT1, ctx.array(Wsum), ctx.empty(f.shape)).get()
+                assert np.abs(fd2 - fd_ref).max() < 1e-12
+                Tt = 2.0 * t2 - t2.transpose(1, 0, 2, 3)
+                Xref = fd_ref[no:, no:] - (0.5 if dcd else 1.0) * np.einsum("adkl,lkdc->ac", Tt, Vb["ijab"])
+                assert np.abs(Xsum - Xref).max() < 1e-12
+                dXvv = ctx.array(Xsum)
                 if not lib.dll.pymes_backend().decode().startswith("hip") and no > 3:
                     continue            # the host simulator declares the fused pair kernels available for no <= 3 only
                 # pair-sharded tail: every rank assembles R for its own pairs (compact), then update + unpack
@@ -202,7 +214,7 @@ def sharded_residual_check(lib, cases, worlds, tol):
                                                       (chunk, 2, no * no), owned=False, keepalive=arr)
                 for rank in range(world):
                     ctx.residual_finish_pairs(dF, dT2, ETd, ETx, L, piece(Rall, rank), rank, world, dT1, QK, is_dcd=dcd,
-                                              dressed=True)
+                                              dressed=True, Xvv=dXvv if rank % 2 else None)
                     ctx.pairs_pack(dT2, piece(Tall, rank), rank, world)
                     ctx.cc_update_pairs(piece(Tall, rank), piece(dTall, rank), piece(Rall, rank), 0.25, 0.5, rank, world)
                 full = ctx.zeros(t2.shape)

@@ -46,7 +46,8 @@ def main():
         st = solver.setup(np.diag(eps), ints)
     assert st["pairs"], "pair-sharded tail not active"
     phases = {}
-    calls = {name: getattr(ctx, name) for name in ("dress_fock", "dress_V", "residual_slab", "singles_residual",
+    calls = {name: getattr(ctx, name) for name in ("dress_fock", "dress_fock_partial", "dress_fock_finish", "xvv_partial",
+                                                   "dress_V", "residual_slab", "singles_residual",
                                                    "residual_finish_pairs", "cc_update", "cc_update_pairs", "pairs_unpack",
                                                    "ccsd_energy", "dots", "lincomb")}
 
