@@ -128,6 +128,17 @@ def _solver_worker(rank, world, port, libpath, out):
             assert s.pair_sharded
             res[(no, nv, dcsd, diis)] = (float(r["ccsd e"]), int(s.iterations), float(np.abs(r["t2"]).sum()),
                                          float(np.abs(r["t2"] - r["t2"].transpose(1, 0, 3, 2)).max()))
+        # symmetric user amplitudes: sharded residual with the replicated tail (the caller's arrays are updated in place)
+        no, nv = 3, 6
+        f, V, B, eps = synthetic_case(no, nv, seed=5, scale=0.3)
+        rng = np.random.default_rng(6)
+        x = rng.standard_normal((nv, nv, no, no)) * 1e-2
+        amps = [rng.standard_normal((nv, no)) * 1e-2, x + x.transpose(1, 0, 3, 2)]
+        s = CCSD(no, delta_e=1e-10)
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = s.solve(f, V, amps=[a.copy() for a in amps])
+        assert not s.pair_sharded
+        res[("amps", no, nv)] = (float(r["ccsd e"]), int(s.iterations), float(np.abs(r["t2"]).sum()), 0.0)
         from pymes_amd.solver.ccd import CCD
         for no, nv, dcd, diis in ((3, 7, False, True), (2, 6, True, True), (3, 5, True, False)):
             f, V, B, eps = synthetic_case(no, nv, seed=4, scale=0.3)
@@ -150,6 +161,15 @@ def test_distributed_solver_host_logic(hostsim_lib, world):
     mp.spawn(_solver_worker, args=(world, _free_port(), hostsim_lib.path, out), nprocs=world, join=True)
     assert len(out) == world and all(out[r] == out[0] for r in range(world))          # ranks agree bit for bit
     for key, (e, it, t2sum, asym) in out[0].items():
+        if key[0] == "amps":
+            _, no, nv = key
+            f, V, B, eps = synthetic_case(no, nv, seed=5, scale=0.3)
+            rng = np.random.default_rng(6)
+            x = rng.standard_normal((nv, nv, no, no)) * 1e-2
+            amps = [rng.standard_normal((nv, no)) * 1e-2, x + x.transpose(1, 0, 3, 2)]
+            ref = oc.ccsd_solve(no, f, V, delta_e=1e-10, amps=amps)
+            assert abs(e - ref["e"]) < 1e-10 and it == ref["iterations"], (key, e, ref["e"], it, ref["iterations"])
+            continue
         if key[0] == "ccd":
             _, no, nv, dcd, diis = key
             f, V, B, eps = synthetic_case(no, nv, seed=4, scale=0.3)
