@@ -141,7 +141,14 @@ int pymes_ladder_sym_unpack(pymes_ctx* ctx, const double* L_dev, double* r2_dev,
  * QK is a fourth exchange buffer, [o*v][o*o] on the device cut into the same row chunks
  * as ETd: QK[(k,b)] = [ QS | QA ] of sum_cd V_kbcd tau_cdij. */
 int pymes_residual_slab(pymes_ctx* ctx, const double* f_dev, const double* t2_dev, double* ETd_dev, double* ETx_dev,
-                        double* L_dev, int rank, int world, uint32_t flags, const double* t1_dev, double* QK_dev);
+                        double* L_dev, int rank, int world, uint32_t flags, const double* t1_dev, double* QK_dev,
+                        const double* P_dev);
+/* P_dev (optional, amplitude-side mode only): the slab's small replicated intermediates — w Tt_cdil V_lkdc (the V.T part
+ * of X_ki, ccd.py:215-220) and the pair-packed 2 V_klcd T_cdij of the hole ladder (:180) — as produced by
+ * pymes_slab_prepare (every rank sums over its chunk of c / of the pairs (c,d)) and all-reduced by the caller;
+ * pymes_slab_prepare_ws doubles.  NULL: the slab forms them itself. */
+int pymes_slab_prepare_ws(pymes_ctx* ctx, int64_t* n_doubles);
+int pymes_slab_prepare(pymes_ctx* ctx, const double* t2_dev, double* P_dev, int rank, int world, uint32_t flags);
 int pymes_residual_finish(pymes_ctx* ctx, const double* f_dev, const double* t2_dev, const double* ETd_dev,
                           const double* ETx_dev, const double* L_dev, double* r2_dev, uint32_t flags,
                           const double* t1_dev, const double* QK_dev);

@@ -54,7 +54,9 @@ SIGNATURES = {
     "pymes_ladder_sym": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int]),
     "pymes_ladder_sym_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]),
     "pymes_residual_slab": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                      C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]),
+                                      C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pymes_slab_prepare_ws": (C.c_int, [C.c_void_p, c_i64_p]),
+    "pymes_slab_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32]),
     "pymes_residual_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "pymes_residual_finish_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -249,12 +249,25 @@ int pymes_ladder_sym_unpack(pymes_ctx* ctx, const double* L, double* r2, double 
         E(ctx).ladder_sym_unpack(L, r2, beta);
     });
 }
+int pymes_slab_prepare_ws(pymes_ctx* ctx, int64_t* n_doubles) {
+    return guarded([&] {
+        if (!n_doubles) throw pymes::Error("null output");
+        *n_doubles = E(ctx).slab_prepare_ws_doubles();
+    });
+}
+int pymes_slab_prepare(pymes_ctx* ctx, const double* t2, double* P, int rank, int world, uint32_t flags) {
+    return guarded([&] {
+        need(t2, "t2"); need(P, "P");
+        E(ctx).slab_prepare(t2, P, rank, world, flags);
+    });
+}
 int pymes_residual_slab(pymes_ctx* ctx, const double* f, const double* t2, double* ETd, double* ETx, double* L, int rank,
-                        int world, uint32_t flags, const double* t1, double* QK) {
+                        int world, uint32_t flags, const double* t1, double* QK, const double* P) {
     return guarded([&] {
         need(f, "f"); need(t2, "t2"); need(ETd, "ETd"); need(ETx, "ETx");
         if ((t1 == nullptr) != (QK == nullptr)) throw pymes::Error("t1 and QK must be given together");
-        E(ctx).residual_slab(f, t2, ETd, ETx, L, rank, world, flags, t1, QK);
+        if (P && !t1) throw pymes::Error("prepared partial sums go with the amplitude-side mode (t1, QK)");
+        E(ctx).residual_slab(f, t2, ETd, ETx, L, rank, world, flags, t1, QK, P);
     });
 }
 int pymes_residual_finish(pymes_ctx* ctx, const double* f, const double* t2, const double* ETd, const double* ETx,

@@ -210,7 +210,7 @@ void Engine::doubles_residual(const double* f, const double* t2, double* r2, uns
 // the transposition needs no undoing.  The pair-packed ladder rows of the same rank go to L.
 // -----------------------------------------------------------------------------------
 void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, double* ETx_p, double* L, int rank,
-                           int world, unsigned flags, const double* t1, double* QK) {
+                           int world, unsigned flags, const double* t1, double* QK, const double* P) {
     const bool dcd = flags & 1u, dressed = flags & 2u, skip_ladder = flags & 4u;
     const bool quad = !dcd;
     const int64_t o = no, v = nv, nn = n, ov = o * v;
@@ -231,7 +231,7 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
             if (!QK) throw Error("residual_slab: QK buffer missing");
             int64_t q0, q1;
             chunk(o * v, q0, q1);
-            ladder_t1(t1, t2, L, r0, r1, QK, q0, q1, dcd);
+            ladder_t1(t1, t2, L, r0, r1, QK, q0, q1, dcd, P ? P + o * o : nullptr);
         } else {
             ladder_sym(t2, L, r0, r1, dressed, quad ? 1 : 2);  // particle AND hole ladder rows of this rank
         }
@@ -299,12 +299,76 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
         TView Foo = slice(slice(F, 0, 0, o), 1, 0, o);
         TView Xoo = make_view(arena.alloc(o * o), {o, o});
         copy(Foo, Xoo);
-        TView Tp = make_view(arena.alloc(o * o * v * v), {v, v, o, o});
-        permute(1.0, make_view(Ttd.p, {v, o, v, o}), "cidl", 0.0, Tp, "cdli");
-        contract(w, make_view(get_static("Vk3"), {v, v, o, o}), "cdlk", Tp, "cdli", 1.0, Xoo, "ki");   // :215-220
+        if (P) {                 // the V.T part was summed over the ranks (slab_prepare)
+            axpby(1.0, make_view(const_cast<double*>(P), {o, o}), 1.0, Xoo);
+        } else {
+            TView Tp = make_view(arena.alloc(o * o * v * v), {v, v, o, o});
+            permute(1.0, make_view(Ttd.p, {v, o, v, o}), "cidl", 0.0, Tp, "cdli");
+            contract(w, make_view(get_static("Vk3"), {v, v, o, o}), "cdlk", Tp, "cdli", 1.0, Xoo, "ki");   // :215-220
+        }
         TView Trows = make_view(Td.p + c0 * ov, {nc, v, o});
         TView Erows = make_view(ETd.p, {nc, v, o});
         contract(-1.0, Trows, "nak", Xoo, "ki", 1.0, Erows, "nai");
+    }
+}
+
+// Small replicated intermediates of residual_slab as K-sharded partial sums (one process per GPU; the caller all-reduces):
+//   P = [ X'_ki = w sum_{cdl} Tt[c,d,i,l] V[l,k,d,c]  (o x o;  c in the rank's chunk)
+//       | Jp, Jm = 2 V_klcd T_cdij pair-packed       (opp x ldp, opp x ldm;  pairs (c,d) in the rank's chunk) ]
+int64_t Engine::slab_prepare_ws_doubles() const {
+    const int64_t o = no, opp = o * (o + 1) / 2, opm = o * (o - 1) / 2;
+    const int64_t ldp = opp + (opp & 1), ldm = std::max<int64_t>(opm + (opm & 1), 2);
+    return o * o + opp * ldp + opp * ldm;
+}
+
+void Engine::slab_prepare(const double* t2, double* P, int rank, int world, unsigned flags) {
+    const bool dcd = flags & 1u;
+    const int64_t o = no, v = nv, npp = v * (v + 1) / 2, npm = v * (v - 1) / 2, opp = o * (o + 1) / 2, opm = o * (o - 1) / 2;
+    const int64_t ldp = opp + (opp & 1), ldm = std::max<int64_t>(opm + (opm & 1), 2);
+    if (world < 1 || rank < 0 || rank >= world) throw Error("slab_prepare: bad rank/world");
+    dev::memset_zero(P, sizeof(double) * slab_prepare_ws_doubles(), stream);
+    TView T = make_view(const_cast<double*>(t2), {v, v, o, o});
+    ArenaScope scope(arena);
+    {
+        // X'_ki over c in [c0,c1)
+        const int64_t cc = (v + world - 1) / world, c0 = std::min<int64_t>(rank * cc, v), c1 = std::min<int64_t>(c0 + cc, v);
+        if (c1 > c0) {
+            ArenaScope s2(arena);
+            TView Tc = slice(T, 0, c0, c1);                                       // T[c,d,i,l]
+            TView Tp = make_view(arena.alloc((c1 - c0) * v * o * o), {c1 - c0, v, o, o});
+            permute(2.0, Tc, "cdil", 0.0, Tp, "cdli");                            // Tt[c,d,i,l] = 2 T[c,d,i,l] - T[d,c,i,l]
+            permute(-1.0, slice(T, 1, c0, c1), "dcil", 1.0, Tp, "cdli");
+            TView Vk3 = slice(make_view(get_static("Vk3"), {v, v, o, o}), 0, c0, c1);
+            contract(dcd ? 0.5 : 1.0, Vk3, "cdlk", Tp, "cdli", 0.0, make_view(P, {o, o}), "ki");   // :215-220
+        }
+    }
+    if (!static_.count("VpIjab")) {
+        double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * npp));
+        double* vm = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * std::max<int64_t>(npm, 1)));
+        static_["VpIjab"] = vp;
+        static_["VmIjab"] = vm;
+        dev::ladder_pack_V(block(P_ijab).p, vp, vm, no, nv, 0, opp, stream);
+    }
+    {
+        // J over the packed pairs P(c,d) in the rank's chunk (Q(c,d) for the antisymmetric part)
+        double* Sp = arena.alloc(npp * ldp);
+        double* Am = arena.alloc(std::max<int64_t>(npm * ldm, 1));
+        dev::ladder_pack_T(t2, nullptr, Sp, Am, no, nv, dev::PACK_ROW_HALF, ldp, ldm, stream);
+        auto pitched = [&](double* p, int64_t r, int64_t c, int64_t ld) { return slice(make_view(p, {r, ld}), 1, 0, c); };
+        auto cut = [&](int64_t n, int64_t& k0, int64_t& k1) {
+            const int64_t c = (n + world - 1) / world;
+            k0 = std::min<int64_t>(rank * c, n);
+            k1 = std::min<int64_t>(k0 + c, n);
+        };
+        int64_t k0, k1;
+        cut(npp, k0, k1);
+        if (k1 > k0)
+            contract(2.0, slice(make_view(static_["VpIjab"], {opp, npp}), 1, k0, k1), "rk",
+                     slice(pitched(Sp, npp, opp, ldp), 0, k0, k1), "kn", 0.0, pitched(P + o * o, opp, opp, ldp), "rn");
+        cut(npm, k0, k1);
+        if (opm > 0 && k1 > k0)
+            contract(2.0, slice(make_view(static_["VmIjab"], {opp, npm}), 1, k0, k1), "rk",
+                     slice(pitched(Am, npm, opm, ldm), 0, k0, k1), "kn", 0.0, pitched(P + o * o + opp * ldp, opp, opm, ldm), "rn");
     }
 }
 
@@ -591,7 +655,7 @@ void Engine::ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1,
 // V~_abij must therefore be dressed in its reduced form (dress_V bit 16), V~_klij in full; V_abcd is never dressed:
 // no o v^4 work and no second copy of V_abcd per iteration.
 void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t row0, int64_t row1, double* QK,
-                       int64_t q0, int64_t q1, bool dcd) {
+                       int64_t q0, int64_t q1, bool dcd, const double* J) {
     const int64_t o = no, v = nv, npp = v * (v + 1) / 2, npm = v * (v - 1) / 2, opp = o * (o + 1) / 2,
                   opm = o * (o - 1) / 2, ov = o * v;
     if (row0 < 0 || row1 > npp || row0 > row1) throw Error("ladder_t1: bad pair-row range");
@@ -682,15 +746,19 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
         contract(1.0, rowsS(), "rk", IpK, "kn", 1.0, LS, "rn");
         if (opm > 0) contract(1.0, rowsA(), "rk", ImK, "kn", 1.0, LA, "rn");
     }
-    {
+    const double bI = dcd ? 1.0 : 2.0;         // dcd: Ip already holds 2 pack(V~_klij)
+    if (J) {       // 2 V_klcd T_cdij (pair-packed) was summed over the ranks (slab_prepare): [ Jp (opp x ldp) | Jm (opp x ldm) ]
+        double* j = const_cast<double*>(J);
+        axpby(1.0, pitched(j, opp, opp, ldp), bI, Ipv);
+        if (opm > 0) axpby(1.0, pitched(j + opp * ldp, opp, opm, ldm), bI, Imv);
+    } else {
         ArenaScope s2(arena);
         double* Sp = arena.alloc(npp * ldp);
         double* Am = arena.alloc(std::max<int64_t>(npm * ldm, 1));
         dev::ladder_pack_T(t2, nullptr, Sp, Am, no, nv, dev::PACK_ROW_HALF, ldp, ldm, stream);
-        const double b = dcd ? 1.0 : 2.0;      // dcd: Ip already holds 2 pack(V~_klij)
-        contract(2.0, make_view(static_["VpIjab"], {opp, npp}), "rk", pitched(Sp, npp, opp, ldp), "kn", b, Ipv, "rn");
+        contract(2.0, make_view(static_["VpIjab"], {opp, npp}), "rk", pitched(Sp, npp, opp, ldp), "kn", bI, Ipv, "rn");
         if (opm > 0 && npm > 0)
-            contract(2.0, make_view(static_["VmIjab"], {opp, npm}), "rk", pitched(Am, npm, opm, ldm), "kn", b, Imv, "rn");
+            contract(2.0, make_view(static_["VmIjab"], {opp, npm}), "rk", pitched(Am, npm, opm, ldm), "kn", bI, Imv, "rn");
         else if (opm > 0 && !dcd) axpby(2.0, Imv, 0.0, Imv);
     }
     // CCSD: rows of tau against Ifull;  DCSD: rows of t1 t1 against Ifull (rows of T were taken above)

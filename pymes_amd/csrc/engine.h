@@ -130,7 +130,10 @@ class Engine {
     // (rows of ETd/ETx) and its rows of the packed ladder L; then the replicated remainder + assembly
     // t1 + QK given: V_abcd is never dressed; its T1 dressing is applied on the amplitude side (ladder_t1)
     void residual_slab(const double* f, const double* t2, double* ETd, double* ETx, double* L, int rank, int world,
-                       unsigned flags, const double* t1 = nullptr, double* QK = nullptr);
+                       unsigned flags, const double* t1 = nullptr, double* QK = nullptr, const double* P = nullptr);
+    // K-sharded partial sums of the slab's small replicated intermediates (X'_ki, pair-packed V_klcd T_cdij), see cc.cpp
+    int64_t slab_prepare_ws_doubles() const;
+    void slab_prepare(const double* t2, double* P, int rank, int world, unsigned flags);
     void residual_finish(const double* f, const double* t2, const double* ETd, const double* ETx, const double* L,
                          double* r2, unsigned flags, const double* t1 = nullptr, const double* QK = nullptr);
     // Pair-sharded tail (one process per GPU): rank owns the virtual pairs P(a,b), a >= b, of its chunk of
@@ -145,7 +148,7 @@ class Engine {
     // rows [row0,row1) of the pair-packed ladders and rows [q0,q1) of QK[(k,b)] = sum_cd V_kbcd tau_cdij, all
     // from UNDRESSED, statically packed integrals; tau = T + t1 t1
     void ladder_t1(const double* t1, const double* t2, double* L, int64_t row0, int64_t row1, double* QK, int64_t q0,
-                   int64_t q1, bool dcd);
+                   int64_t q1, bool dcd, const double* J = nullptr);
     void dress_abcd_rows(const double* t1, int a0, int a1, bool lower_only);
     void cc_update(double* t, double* dt, const double* r, double shift, double delta, int rank);  // ccsd.py:176-179
     void ccsd_energy(const double* f, const double* t1, const double* t2, double out[3]);     // ccsd.py:458-466

@@ -280,13 +280,23 @@ class Context:
                (_lib.PYMES_SKIP_LADDER if skip_ladder else 0) | (_lib.PYMES_SYM_LADDER if sym_ladder else 0) | \
                (_lib.PYMES_SYM_RINGS if sym_rings else 0)
 
-    def residual_slab(self, f, t2, ETd, ETx, L, rank, world, is_dcd=False, dressed=False, t1=None, QK=None):
+    def residual_slab(self, f, t2, ETd, ETx, L, rank, world, is_dcd=False, dressed=False, t1=None, QK=None, P=None):
         """This rank's share of the symmetry-reduced residual (include/pymes_amd.h).  ``t1`` + ``QK``: T1 dressing
-        of V_abcd on the amplitude side."""
+        of V_abcd on the amplitude side; ``P``: all-reduced output of ``slab_prepare``."""
         self.lib.call("pymes_residual_slab", self.handle, C.c_void_p(f.ptr), C.c_void_p(t2.ptr), C.c_void_p(ETd.ptr),
                       C.c_void_p(ETx.ptr), C.c_void_p(L.ptr if L is not None else 0), int(rank), int(world),
                       self._flags(is_dcd, dressed, False, True, True), C.c_void_p(t1.ptr if t1 is not None else 0),
-                      C.c_void_p(QK.ptr if QK is not None else 0))
+                      C.c_void_p(QK.ptr if QK is not None else 0), C.c_void_p(P.ptr if P is not None else 0))
+
+    def slab_prepare_ws(self):
+        n = C.c_int64()
+        self.lib.call("pymes_slab_prepare_ws", self.handle, C.byref(n))
+        return n.value
+
+    def slab_prepare(self, t2, P, rank, world, is_dcd=False):
+        self.lib.call("pymes_slab_prepare", self.handle, C.c_void_p(t2.ptr), C.c_void_p(P.ptr), int(rank), int(world),
+                      _lib.PYMES_DCD if is_dcd else 0)
+        return P
 
     def residual_finish(self, f, t2, ETd, ETx, L, out, is_dcd=False, dressed=False, t1=None, QK=None):
         self.lib.call("pymes_residual_finish", self.handle, C.c_void_p(f.ptr), C.c_void_p(t2.ptr), C.c_void_p(ETd.ptr),

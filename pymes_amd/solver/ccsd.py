@@ -110,6 +110,7 @@ class CCSD(ccd.CCD):
                     return t, DeviceArray(ctx, t.data_ptr(), (n,), owned=False, keepalive=t)
                 st["W_t"], st["W"] = reduced(ctx.dress_fock_ws())
                 st["Xvv_t"], st["Xvv"] = reduced(nv * nv)
+                st["P_t"], st["P"] = reduced(ctx.slab_prepare_ws())
             else:
                 st["lad_rows"] = nv * nv
                 st["lad_t"], st["lad"] = shared(nv * nv, no * no)
@@ -123,10 +124,15 @@ class CCSD(ccd.CCD):
         ctx, t1, t2 = st["ctx"], st["t1"], st["t2"]
         shift = st["level_shift"]
         world, rank = st["world"], st["rank"]
-        if world > 1 and st["sym"]:      # :163 with the T1.V intermediates summed over this rank's chunk of j only
+        if world > 1 and st["sym"]:
+            # K-sharded partial sums, all-reduced: the T1.V intermediates of the dressed Fock (:163, this rank's chunk of
+            # j) and the slab's small V.T intermediates (X_ki, hole-ladder V_klcd T_cdij; this rank's chunk of c / (c,d))
             ctx.dress_fock_partial(t1, st["W"], rank, world)
+            ctx.slab_prepare(t2, st["P"], rank, world, is_dcd=self.is_dcd)
             ctx.sync()
-            pdist.allreduce_tensor_start(st["W_t"]).wait()
+            red = [pdist.allreduce_tensor_start(st["W_t"]), pdist.allreduce_tensor_start(st["P_t"])]
+            for work in red:
+                work.wait()
             torch_sync()
             ctx.dress_fock_finish(st["f"], t1, st["W"], st["fd"])
         else:
@@ -146,7 +152,7 @@ class CCSD(ccd.CCD):
             else:
                 ctx.dress_V(t1, ("klij", "iajb", "iabj"))                             # :165
             ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], rank, world, is_dcd=self.is_dcd,
-                              dressed=True, t1=t1, QK=st["QK"])                        # :171
+                              dressed=True, t1=t1, QK=st["QK"], P=st["P"] if world > 1 else None)   # :171
             pending = []
             if world > 1:
                 if st["pairs"]:      # X_ac (:206-221) as a partial sum over this rank's chunk of k, all-reduced below

@@ -182,12 +182,17 @@ def sharded_residual_check(lib, cases, worlds, tol):
                 # every rank dresses only the range of the second index of V_iajb / V_iabj that its column slab reads
                 ctx.V_block("iajb", dressed=True).zero_()
                 ctx.V_block("iabj", dressed=True).zero_()
+                Psum = np.zeros(ctx.slab_prepare_ws())       # K-sharded partial sums of the slab's small intermediates
+                for rank in range(world):
+                    Psum += ctx.slab_prepare(dT2, ctx.empty((ctx.slab_prepare_ws(),)), rank, world, is_dcd=dcd).get()
+                dP = ctx.array(Psum)
                 for rank in range(world):
                     c0 = min(rank * (-(-ov // world)), ov)
                     c1 = min(c0 + (-(-ov // world)), ov)
                     if c1 > c0:
                         ctx.dress_V(dT1, ["iajb", "iabj"], q_range=(c0 // no, -(-c1 // no)))
-                    ctx.residual_slab(dF, dT2, ETd, ETx, L, rank, world, is_dcd=dcd, dressed=True, t1=dT1, QK=QK)
+                    ctx.residual_slab(dF, dT2, ETd, ETx, L, rank, world, is_dcd=dcd, dressed=True, t1=dT1, QK=QK,
+                                      P=dP if rank % 2 == 0 else None)
                 r2 = ctx.empty(t2.shape)
                 ctx.residual_finish(dF, dT2, ETd, ETx, L, r2, is_dcd=dcd, dressed=True, t1=dT1, QK=QK)
                 ref = oc.ccsd_doubles_residual(no, fd_ref, t2, Vd_ref, is_dcsd=dcd)
