@@ -218,7 +218,6 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
     const double w = quad ? 1.0 : 0.5;
     TView T = make_view(const_cast<double*>(t2), {v, v, o, o});
     TView F = make_view(const_cast<double*>(f), {nn, nn});
-    TView Viajb = block(P_iajb, dressed), Viabj = block(P_iabj, dressed);
     auto chunk = [&](int64_t rows, int64_t& lo, int64_t& hi) {
         const int64_t c = (rows + world - 1) / world;
         lo = std::min<int64_t>(rank * c, rows);
@@ -239,7 +238,8 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
     int64_t c0, c1;
     chunk(ov, c0, c1);
     const int64_t nc = c1 - c0;
-    if (nc <= 0) return;
+    if (nc <= 0) return;           // a rank without columns never touches (or needs) the dressed ov blocks
+    TView Viajb = block(P_iajb, dressed), Viabj = block(P_iabj, dressed);
 
     ArenaScope scope(arena);
     auto pairm = [&](double* p) { return make_view(p, {ov, ov}); };

@@ -152,7 +152,7 @@ def _solver_worker(rank, world, port, libpath, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])        # 8: more ranks than some index ranges have chunks (empty shares)
 def test_distributed_solver_host_logic(hostsim_lib, world):
     from oracle import cc_oracle as oc
     from oracle.cases import synthetic_case
