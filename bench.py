@@ -2,9 +2,9 @@
 """Headline benchmark: wall time of one CCSD iteration at (nocc=50, nvirt=200) on N MI355X,
 plus the fp64-MFMA roofline fraction of the dominant kernel and a CPU baseline.
 
-    python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          (N > 1: spawns its own N rank processes, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W          (ranks started by the launcher)
 
 A "step" is one full pass of the loop body of pymes/solver/ccsd.py:159-209 (dressed Fock,
 T1-dressed V blocks, singles + doubles residuals, amplitude update, DIIS, energy, norms) on
@@ -53,6 +53,49 @@ def pmc_traffic_per_launch(no, nv, world, kernel_prefix):
     return gbytes / launches * 1e9 if launches else None
 
 
+def launch_ranks(n, argv, script=None):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this script (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1) and relay rank 0's JSON line.  The parent never
+    touches the GPU (no HIP call, no exec of an initialised process); a failing rank takes the others down."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    # rank 0 prints the one JSON line (read by a thread so that a dead sibling cannot leave us blocked on the pipe);
+    # stderr of every rank is inherited
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        if any(c not in (None, 0) for c in codes):          # a rank failed: the others would wait for it forever
+            time.sleep(5.0)
+            for r, p in enumerate(procs):
+                if codes[r] is None and p.poll() is None:
+                    p.kill()                                  # exactly the PIDs started above
+                if codes[r] is None:
+                    codes[r] = p.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10.0)
+    for ln in b"".join(chunks).decode().splitlines():      # only the JSON line goes to stdout (gloo logs there too)
+        (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln + "\n")
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit(f"rank exit codes {codes}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,17 +111,22 @@ def main():
                     help="torch.distributed backend; 'gloo' lets several ranks share one GPU in test rigs")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        return launch_ranks(args.gpus, sys.argv[1:])      # no launcher around us: be the launcher
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
-    if world > 1:
+    # PYMES_FORCE_SHARDED=1 with one rank: rehearse the one-process-per-GPU path (RCCL communicator of one rank)
+    if world > 1 or os.environ.get("PYMES_FORCE_SHARDED"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
@@ -114,7 +162,7 @@ def main():
     def fence():
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -131,8 +179,8 @@ def main():
     prof_dma = ctx.prof_query(kernel_class=1)
     stats = ctx.stats()
     ctx.prof_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if dist.is_initialized():
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if not all(np.isfinite(energies)):
@@ -199,7 +247,7 @@ def main():
                 "blas_all_cores": {"value": cpu["blas"]["seconds_per_doubles_residual"] * to_iter, "unit": "s",
                                    "cores": cpu["cores"]["blas"]}}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

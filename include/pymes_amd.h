@@ -33,13 +33,29 @@ const char* pymes_last_error(void);
 const char* pymes_backend(void);                 /* "hip-gfx950" for the product library */
 int pymes_ctx_create(pymes_ctx** out, int device, int no, int nv, uint64_t workspace_bytes /* 0 = auto */);
 int pymes_ctx_destroy(pymes_ctx* ctx);
+/* A context runs on a HIP stream of its own; pymes_ctx_set_stream binds another one (after completing what was
+ * enqueued on the old one) — e.g. torch's current stream, so that RCCL collectives and engine kernels are ordered on
+ * the device without host fences (pymes_amd/dist.py). */
 int pymes_ctx_set_stream(pymes_ctx* ctx, void* hip_stream);
 int pymes_ctx_sync(pymes_ctx* ctx);
 int pymes_ctx_workspace(pymes_ctx* ctx, uint64_t* capacity_bytes, uint64_t* high_water_bytes);
 
 /* ---- device memory ------------------------------------------------------------ */
+/* buffers belong to the context: pymes_ctx_destroy releases whatever has not been passed to pymes_free */
 int pymes_malloc(pymes_ctx* ctx, uint64_t bytes, void** dev_ptr);
 int pymes_free(pymes_ctx* ctx, void* dev_ptr);
+int pymes_live_allocations(int64_t* n);          /* device allocations of this library not yet released (leak tests) */
+
+/* ---- launch graphs (hipGraph): the loop body of a small, launch-bound solve is recorded once and replayed.
+ * Between begin and end the context's entry points only RECORD their kernels (nothing executes, nothing may
+ * synchronise: no pymes_dots / pymes_download / pymes_free); every pointer passed in is baked into the graph, so the
+ * replayed segment must work on fixed buffers (pymes_amd/solver/ccsd.py keeps T1/T2 and the residuals in place).
+ * The reference has no counterpart: its loop body (ccsd.py:159-209) is re-interpreted by Python every iteration. */
+int pymes_graph_begin(pymes_ctx* ctx);
+int pymes_graph_end(pymes_ctx* ctx, void** graph);
+int pymes_graph_abort(pymes_ctx* ctx);
+int pymes_graph_launch(pymes_ctx* ctx, void* graph);
+int pymes_graph_destroy(pymes_ctx* ctx, void* graph);
 int pymes_upload(pymes_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);   /* synchronous */
 int pymes_download(pymes_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes); /* synchronous */
 int pymes_copy(pymes_ctx* ctx, void* dst_dev, const void* src_dev, uint64_t bytes);      /* stream-ordered */
@@ -66,9 +82,17 @@ int pymes_dgemm(pymes_ctx* ctx, int64_t M, int64_t N, int64_t K, double alpha, c
 /* ---- integrals: pymes/integral/partition.py:4-39 -------------------------------- */
 /* V[n,n,n,n] (host: C-contiguous, strides ignored; device: element strides or NULL) -> 16 blocks */
 int pymes_set_V_pqrs(pymes_ctx* ctx, const double* V, int on_device, const int64_t* strides);
-/* a single block by its partition.py name ("abcd", "ijab", ...) */
-int pymes_set_V_block(pymes_ctx* ctx, const char* name, const double* data, int on_device,
+/* a single block by its partition.py name ("abcd", "ijab", ...); n_elements must be the block's size for this
+ * context (a mis-shaped block is refused instead of being read out of bounds) */
+int pymes_set_V_block(pymes_ctx* ctx, const char* name, const double* data, int64_t n_elements, int on_device,
                       const int64_t* strides);
+/* Electron-exchange symmetry V_pqrs = V_qpsr, which the symmetry-reduced residual (PYMES_SYM_LADDER / PYMES_SYM_RINGS)
+ * presumes and the reference's own Ex += Ex^T (ccd.py:245-249) relies on: out = { max |V_pqrs - V_qpsr| over the blocks
+ * that are set (infinity when a block's partner is absent), max |V| }.  pymes_exchange_asymmetry is the same test for
+ * any pair A [d0,d1,d2,d3], B [d1,d0,d3,d2] on the device (T2 against itself: T_abij = T_baji). */
+int pymes_V_exchange_asymmetry(pymes_ctx* ctx, double* out_host);
+int pymes_exchange_asymmetry(pymes_ctx* ctx, const double* A_dev, const double* B_dev, const int64_t* dims,
+                             double* out_host);
 /* V[p,q,r,s] = sum_Q B[Q,p,r] B[Q,q,s]  (density-fitted / synthetic input), B_host is [naux,n,n] */
 int pymes_set_V_from_factors(pymes_ctx* ctx, const double* B_host, int naux);
 /* device address of a block ("dressed" = output of pymes_ccsd_dress_V); NULL+error if absent */
@@ -186,6 +210,14 @@ int pymes_pairs_unpack(pymes_ctx* ctx, const double* xc_all_dev, double* full_de
 /* ccsd.py:176-179 / ccd.py:123-124: dt = r/(D+shift) (as r * (1/(D+shift))), t += delta*dt; rank 2 or 4 */
 int pymes_cc_update(pymes_ctx* ctx, double* t_dev, double* dt_dev, const double* r_dev, double level_shift,
                     double delta, int rank);
+/* out-of-place form of the same update: dt = r/(D+shift), t_out = t_in + delta*dt (t_out may alias t_in).  Lets the
+ * residuals read T from a fixed buffer (launch graphs) while the DIIS history keeps the updated copy. */
+int pymes_cc_update_to(pymes_ctx* ctx, double* t_out_dev, double* dt_dev, const double* t_in_dev, const double* r_dev,
+                       double level_shift, double delta, int rank);
+/* ccsd.py:458-466 (ccd.py:256-262 when f_dev and t1_dev are NULL) and the norms of ccsd.py:196-197 in ONE pass over
+ * T2: out = {one-body, direct, exchange, |t2|^2, |dt2|^2} (dt2_dev may be NULL); one host synchronisation */
+int pymes_energy_norms(pymes_ctx* ctx, const double* f_dev, const double* t1_dev, const double* t2_dev,
+                       const double* dt2_dev, double* out_host);
 /* CCSD.get_energy, ccsd.py:458-466: e_out = {one-body, direct, exchange}; f is the UNDRESSED Fock */
 int pymes_ccsd_energy(pymes_ctx* ctx, const double* f_dev, const double* t1_dev, const double* t2_dev,
                       double* e_out_host);
@@ -205,6 +237,9 @@ int pymes_ueg_eval_2b(pymes_ctx* ctx, int n_p, int n_ele, int imax, int mode, do
 /* out_host[p] = sum_i x[p][i]*y[p][i], npairs <= 16, deterministic reduction (synchronises) */
 int pymes_dots(pymes_ctx* ctx, int npairs, const double* const* x_dev, const double* const* y_dev, int64_t n,
                double* out_host);
+/* the same with one length per pair (the DIIS overlaps of T1 and T2 in one launch / one synchronisation) */
+int pymes_dots_var(pymes_ctx* ctx, int npairs, const double* const* x_dev, const double* const* y_dev,
+                   const int64_t* n, double* out_host);
 /* out = sum_k c[k]*x[k], nx <= 8 */
 int pymes_lincomb(pymes_ctx* ctx, double* out_dev, int nx, const double* const* x_dev, const double* c_host,
                   int64_t n);

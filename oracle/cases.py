@@ -30,3 +30,20 @@ def synthetic_case(no, nv, seed=0, scale=0.3, gap=3.0):
     """SURVEY §8(d) synthetic closed-shell problem: f = diag(eps), 8-fold symmetric PSD V."""
     B, eps = synthetic_factors(no, nv, seed, scale, gap)
     return np.diag(eps), eri_from_factors(B), B, eps
+
+
+def eom_sigma_case(no, nv, seed, scale):
+    """Inputs of one EOM-CCSD sigma build at a benchmark size (config 5): synthetic 8-fold symmetric V standing in for
+    the dressed integrals, a dressed-like (non-diagonal) Fock matrix, exchange-symmetric T2 and trial vector (u1, u2) —
+    what ``EOM_CCSD.solve`` hands to ``update_singles`` / ``update_doubles`` (eom_ccsd.py:95-101).
+    Returns (f~, V_pqrs, T2, u1, u2)."""
+    rng = np.random.default_rng(seed)
+    f, V, _, _ = synthetic_case(no, nv, seed=0, scale=scale)
+    n = no + nv
+    fd = f + 0.02 * rng.standard_normal((n, n))
+    t2 = rng.standard_normal((nv, nv, no, no)) * 0.02
+    t2 = 0.5 * (t2 + t2.transpose(1, 0, 3, 2))
+    u1 = rng.standard_normal((nv, no)) * 0.3
+    u2 = rng.standard_normal((nv, nv, no, no)) * 0.05
+    u2 = 0.5 * (u2 + u2.transpose(1, 0, 3, 2))
+    return fd, V, t2, u1, u2

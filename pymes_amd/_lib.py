@@ -27,6 +27,12 @@ SIGNATURES = {
     "pymes_ctx_workspace": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "pymes_malloc": (C.c_int, [C.c_void_p, C.c_uint64, c_pp]),
     "pymes_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pymes_live_allocations": (C.c_int, [c_i64_p]),
+    "pymes_graph_begin": (C.c_int, [C.c_void_p]),
+    "pymes_graph_end": (C.c_int, [C.c_void_p, c_pp]),
+    "pymes_graph_abort": (C.c_int, [C.c_void_p]),
+    "pymes_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pymes_graph_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pymes_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "pymes_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "pymes_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
@@ -40,7 +46,9 @@ SIGNATURES = {
     "pymes_dgemm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_void_p, C.c_int64,
                               C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_double, C.c_void_p, C.c_int64]),
     "pymes_set_V_pqrs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_i64_p]),
-    "pymes_set_V_block": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, c_i64_p]),
+    "pymes_set_V_block": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int, c_i64_p]),
+    "pymes_V_exchange_asymmetry": (C.c_int, [C.c_void_p, c_double_p]),
+    "pymes_exchange_asymmetry": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i64_p, c_double_p]),
     "pymes_set_V_from_factors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "pymes_V_block_ptr": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, c_pp, c_i64_p]),
     "pymes_set_orbital_energies": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -74,6 +82,9 @@ SIGNATURES = {
     "pymes_ccsd_dress_abcd_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "pymes_cc_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
                                   C.c_int]),
+    "pymes_cc_update_to": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                     C.c_int]),
+    "pymes_energy_norms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_double_p]),
     "pymes_ccsd_energy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_double_p]),
     "pymes_ccd_energy": (C.c_int, [C.c_void_p, C.c_void_p, c_double_p]),
     "pymes_ueg_eval_2b": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
@@ -87,6 +98,7 @@ SIGNATURES = {
     "pymes_tc_double_contraction": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pymes_tc_triple_contraction": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, c_double_p]),
     "pymes_dots": (C.c_int, [C.c_void_p, C.c_int, c_pp, c_pp, C.c_int64, c_double_p]),
+    "pymes_dots_var": (C.c_int, [C.c_void_p, C.c_int, c_pp, c_pp, c_i64_p, c_double_p]),
     "pymes_lincomb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_pp, c_double_p, C.c_int64]),
     "pymes_stats": (C.c_int, [C.c_void_p, C.c_int, c_i64_p, c_double_p, c_i64_p, c_double_p]),
     "pymes_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -31,6 +31,7 @@ int guarded(F&& f) {
 }
 Engine& E(pymes_ctx* c) {
     if (!c || !c->e) throw pymes::Error("null context");
+    dev::set_device(c->e->device);      // a process may hold contexts on several GPUs: every entry runs on its own
     return *c->e;
 }
 void need(const void* p, const char* what) {
@@ -65,7 +66,12 @@ int pymes_ctx_destroy(pymes_ctx* ctx) {
     });
 }
 int pymes_ctx_set_stream(pymes_ctx* ctx, void* s) {
-    return guarded([&] { E(ctx).stream = s; });
+    return guarded([&] {
+        Engine& e = E(ctx);
+        if (e.capturing()) throw pymes::Error("set_stream while a launch graph is being recorded");
+        dev::stream_sync(e.stream);       // work already enqueued on the old stream is complete before the switch
+        e.set_stream(s);
+    });
 }
 int pymes_ctx_sync(pymes_ctx* ctx) {
     return guarded([&] { dev::stream_sync(E(ctx).stream); });
@@ -79,16 +85,37 @@ int pymes_ctx_workspace(pymes_ctx* ctx, uint64_t* cap, uint64_t* high) {
 
 int pymes_malloc(pymes_ctx* ctx, uint64_t bytes, void** p) {
     return guarded([&] {
-        E(ctx);
         need(p, "dev_ptr");
-        *p = dev::dmalloc(bytes);
+        *p = E(ctx).user_malloc(bytes);
     });
 }
 int pymes_free(pymes_ctx* ctx, void* p) {
+    return guarded([&] { E(ctx).user_free(p); });
+}
+int pymes_live_allocations(int64_t* n) {
     return guarded([&] {
-        dev::stream_sync(E(ctx).stream);
-        dev::dfree(p);
+        if (!n) throw pymes::Error("null output");
+        *n = dev::live_allocations();
     });
+}
+int pymes_graph_begin(pymes_ctx* ctx) {
+    return guarded([&] { E(ctx).graph_begin(); });
+}
+int pymes_graph_end(pymes_ctx* ctx, void** graph) {
+    return guarded([&] {
+        need(graph, "graph");
+        *graph = nullptr;
+        *graph = E(ctx).graph_end();
+    });
+}
+int pymes_graph_abort(pymes_ctx* ctx) {
+    return guarded([&] { E(ctx).graph_abort(); });
+}
+int pymes_graph_launch(pymes_ctx* ctx, void* graph) {
+    return guarded([&] { E(ctx).graph_launch(graph); });
+}
+int pymes_graph_destroy(pymes_ctx* ctx, void* graph) {
+    return guarded([&] { E(ctx).graph_destroy(graph); });
 }
 int pymes_upload(pymes_ctx* ctx, void* d, const void* h, uint64_t bytes) {
     return guarded([&] {
@@ -163,10 +190,31 @@ int pymes_set_V_pqrs(pymes_ctx* ctx, const double* V, int on_device, const int64
         E(ctx).set_V_full(V, on_device != 0, strides);
     });
 }
-int pymes_set_V_block(pymes_ctx* ctx, const char* name, const double* data, int on_device, const int64_t* strides) {
+int pymes_set_V_block(pymes_ctx* ctx, const char* name, const double* data, int64_t n_elements, int on_device,
+                      const int64_t* strides) {
     return guarded([&] {
         need(data, "data");
-        E(ctx).set_V_block(name, data, on_device != 0, strides);
+        Engine& e = E(ctx);
+        int64_t want = 1;
+        const int pat = pymes::pattern_of_name(name);
+        for (int i = 0; i < 4; ++i) want *= (pat >> (3 - i) & 1) ? e.nv : e.no;
+        if (n_elements != want)
+            throw pymes::Error(std::string("block '") + name + "' has " + std::to_string(want) + " elements for this context, got " +
+                               std::to_string(n_elements));
+        e.set_V_block(name, data, on_device != 0, strides);
+    });
+}
+int pymes_V_exchange_asymmetry(pymes_ctx* ctx, double* out_host) {
+    return guarded([&] {
+        need(out_host, "out");
+        E(ctx).exchange_asymmetry_V(out_host);
+    });
+}
+int pymes_exchange_asymmetry(pymes_ctx* ctx, const double* A, const double* B, const int64_t* dims, double* out_host) {
+    return guarded([&] {
+        need(A, "A"); need(B, "B"); need(dims, "dims"); need(out_host, "out");
+        Engine& e = E(ctx);
+        dev::exchange_asymmetry(A, B, dims, out_host, e.stream);
     });
 }
 int pymes_set_V_from_factors(pymes_ctx* ctx, const double* B, int naux) {
@@ -359,6 +407,21 @@ int pymes_cc_update(pymes_ctx* ctx, double* t, double* dt, const double* r, doub
         E(ctx).cc_update(t, dt, r, shift, delta, rank);
     });
 }
+int pymes_cc_update_to(pymes_ctx* ctx, double* t_out, double* dt, const double* t_in, const double* r, double shift,
+                       double delta, int rank) {
+    return guarded([&] {
+        need(t_out, "t_out"); need(dt, "dt"); need(t_in, "t_in"); need(r, "r");
+        E(ctx).cc_update_to(t_out, dt, t_in, r, shift, delta, rank);
+    });
+}
+int pymes_energy_norms(pymes_ctx* ctx, const double* f, const double* t1, const double* t2, const double* dt2,
+                       double* out) {
+    return guarded([&] {
+        need(t2, "t2"); need(out, "out");
+        if ((f == nullptr) != (t1 == nullptr)) throw pymes::Error("f and t1 must be given together");
+        E(ctx).energy_norms(f, t1, t2, dt2, out);
+    });
+}
 int pymes_ccsd_energy(pymes_ctx* ctx, const double* f, const double* t1, const double* t2, double* e_out) {
     return guarded([&] {
         need(f, "f"); need(t1, "t1"); need(t2, "t2"); need(e_out, "e_out");
@@ -398,6 +461,16 @@ int pymes_dots(pymes_ctx* ctx, int npairs, const double* const* x, const double*
                double* out) {
     return guarded([&] {
         need(x, "x"); need(y, "y"); need(out, "out");
+        if (npairs < 0 || npairs > 16) throw pymes::Error("dots: 0..16 pairs");
+        int64_t len[16];
+        for (int i = 0; i < npairs; ++i) len[i] = n;
+        dev::dots(npairs, x, y, len, out, E(ctx).stream);
+    });
+}
+int pymes_dots_var(pymes_ctx* ctx, int npairs, const double* const* x, const double* const* y, const int64_t* n,
+                   double* out) {
+    return guarded([&] {
+        need(x, "x"); need(y, "y"); need(n, "n"); need(out, "out");
         dev::dots(npairs, x, y, n, out, E(ctx).stream);
     });
 }

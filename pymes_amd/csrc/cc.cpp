@@ -63,8 +63,9 @@ void Engine::mp2(double shift, double* t2, double e_out[2]) {
     permute(1.0, block(P_ijab), "jiab", 0.0, make_view(e2, {v, v, o, o}), "abij");          // 'abij,jiab' :20
     const double* x[2] = {t2, t2};
     const double* y[2] = {get_static("Edir"), e2};
+    const int64_t len[2] = {n4, n4};
     double d[2];
-    dev::dots(2, x, y, n4, d, stream);
+    dev::dots(2, x, y, len, d, stream);
     e_out[0] = 2.0 * d[0];                                                                  // :19
     e_out[1] = -1.0 * d[1];                                                                 // :20
 }
@@ -1015,34 +1016,35 @@ void Engine::cc_update(double* t, double* dt, const double* r, double shift, dou
 // -----------------------------------------------------------------------------------
 // ccsd.py:458-466 and ccd.py:256-262
 // -----------------------------------------------------------------------------------
+void Engine::cc_update_to(double* t_out, double* dt, const double* t_in, const double* r, double shift, double delta,
+                          int rank) {
+    if (rank != 2 && rank != 4) throw Error("cc_update: rank must be 2 (T1) or 4 (T2)");
+    dev::cc_update_to(t_out, dt, t_in, r, eps_o, eps_v, shift, delta, no, nv, rank, stream);
+}
+
+void Engine::energy_norms(const double* f, const double* t1, const double* t2, const double* dt2, double out[5]) {
+    double r[5];
+    dev::energy_norms(f, t1, t2, get_static("Edir"), get_static("Eex"), dt2, no, nv, r, stream);
+    out[0] = 2.0 * r[0];      // ccsd.py:465
+    out[1] = 2.0 * r[1];      // :463 / ccd.py:260
+    out[2] = -1.0 * r[2];     // :464 / ccd.py:261
+    out[3] = r[3];
+    out[4] = r[4];
+}
+
 void Engine::ccsd_energy(const double* f, const double* t1, const double* t2, double out[3]) {
-    const int64_t o = no, v = nv, nn = n, n4 = v * v * o * o;
-    ArenaScope scope(arena);
-    double* tau = arena.alloc(n4);
-    dev::tau_build(tau, t2, t1, no, nv, stream);                                              // :462
-    TView F = make_view(const_cast<double*>(f), {nn, nn});
-    TView g = make_view(arena.alloc(o * v), {v, o});
-    permute(1.0, slice(slice(F, 0, 0, o), 1, o, nn), "ia", 0.0, g, "ai");
-    const double* x[2] = {tau, tau};
-    const double* y[2] = {get_static("Edir"), get_static("Eex")};
-    double d[2], e1;
-    dev::dots(2, x, y, n4, d, stream);
-    const double* x1[1] = {g.p};
-    const double* y1[1] = {t1};
-    dev::dots(1, x1, y1, o * v, &e1, stream);
-    out[0] = 2.0 * e1;        // :465
-    out[1] = 2.0 * d[0];      // :463
-    out[2] = -1.0 * d[1];     // :464
+    double r[5];
+    energy_norms(f, t1, t2, nullptr, r);
+    out[0] = r[0];
+    out[1] = r[1];
+    out[2] = r[2];
 }
 
 void Engine::ccd_energy(const double* t2, double out[2]) {
-    const int64_t o = no, v = nv, n4 = v * v * o * o;
-    const double* x[2] = {t2, t2};
-    const double* y[2] = {get_static("Edir"), get_static("Eex")};
-    double d[2];
-    dev::dots(2, x, y, n4, d, stream);
-    out[0] = 2.0 * d[0];      // ccd.py:260
-    out[1] = -1.0 * d[1];     // ccd.py:261
+    double r[5];
+    energy_norms(nullptr, nullptr, t2, nullptr, r);
+    out[0] = r[1];
+    out[1] = r[2];
 }
 
 }  // namespace pymes

@@ -24,6 +24,22 @@ void  memcpy_d2d(void* d, const void* s_, size_t bytes, stream_t s);
 void  memset_zero(void* d, size_t bytes, stream_t s);
 void  stream_sync(stream_t s);
 size_t mem_free_bytes();
+// a stream of the engine's own (non-blocking with respect to the legacy default stream); null for the host simulator
+stream_t stream_create();
+void  stream_destroy(stream_t s);
+// device allocations made through dmalloc and not yet released (leak accounting in the tests)
+int64_t live_allocations();
+
+// ---- launch graphs: the launch-bound inner loop of a small problem is captured once and replayed -------------------
+// graph_begin puts the stream into capture mode (work enqueued until graph_end is recorded, not executed);
+// graph_end returns an executable graph.  Nothing that synchronises or frees may run while capturing.
+typedef void* graph_t;
+bool  graphs_supported();
+void  graph_begin(stream_t s);
+graph_t graph_end(stream_t s);          // throws (after leaving capture mode) if the capture was invalidated
+void  graph_abort(stream_t s);          // leave capture mode, discard what was recorded
+void  graph_launch(graph_t g, stream_t s);
+void  graph_destroy(graph_t g);
 
 // ---- timing of the dominant kernel (fp64 MFMA GEMM) with device events --------
 void   prof_enable(bool on);
@@ -69,9 +85,23 @@ void mp2_amplitudes(double* t, const double* w, const double* eo, const double* 
 // dt = r * (1/(D+shift)) ; t += delta*dt   rank 4 (abij) or rank 2 (ai)   (ccsd.py:176-179)
 void cc_update(double* t, double* dt, const double* r, const double* eo, const double* ev, double shift,
                double delta, int no, int nv, int rank, stream_t s);
-// out[p] = sum_i x_p[i]*y_p[i], p < npairs (<= 16); deterministic two-stage reduction; result on host
-void dots(int npairs, const double* const* x, const double* const* y, int64_t n, double* out_host,
+// out[p] = sum_{i < n[p]} x_p[i]*y_p[i], p < npairs (<= 16); deterministic two-stage reduction; result on host
+// (synchronises the stream)
+void dots(int npairs, const double* const* x, const double* const* y, const int64_t* n, double* out_host,
           stream_t s);
+// ccsd.py:458-466 and the norms of ccsd.py:196-197 in one pass over T2 (tau = t2 + t1 t1 formed on the fly):
+//   out[0] = sum f_ov[i,a] t1[a,i]   (f is the [n,n] Fock matrix on the device)
+//   out[1] = sum tau Edir,  out[2] = sum tau Eex   (Edir = V_ijab as [a,b,i,j], Eex = V_ijba as [a,b,i,j])
+//   out[3] = sum t2^2,  out[4] = sum dt2^2  (dt2 may be null: 0)
+// t1 / f may be null (CCD: out[0] = 0, tau = t2).  Result on host (synchronises the stream).
+void energy_norms(const double* f, const double* t1, const double* t2, const double* Edir, const double* Eex,
+                  const double* dt2, int no, int nv, double out_host[5], stream_t s);
+// max |A[p,q,r,s] - B[q,p,s,r]| and max |A| for A [d0,d1,d2,d3], B [d1,d0,d3,d2] (electron-exchange partner; B may be
+// A itself when d0 == d1 and d2 == d3).  Result on host (synchronises the stream).
+void exchange_asymmetry(const double* A, const double* B, const int64_t d[4], double out_host[2], stream_t s);
+// out-of-place form: dt = r * (1/(D+shift)); t_out = t_in + delta*dt  (t_out may alias t_in)
+void cc_update_to(double* t_out, double* dt, const double* t_in, const double* r, const double* eo, const double* ev,
+                  double shift, double delta, int no, int nv, int rank, stream_t s);
 // out = sum_k c[k] * x_k   (k < nx <= 8)
 void lincomb(double* out, int nx, const double* const* x, const double* c, int64_t n, stream_t s);
 // tau[a,b,i,j] = t2[a,b,i,j] + t1[a,i]*t1[b,j]                        (ccsd.py:462)

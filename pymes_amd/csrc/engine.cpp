@@ -93,9 +93,11 @@ std::string canonical_name(int pattern) {
 // ---------------------------------------------------------------------------------
 // engine basics
 // ---------------------------------------------------------------------------------
-Engine::Engine(int device, int no_, int nv_, size_t workspace_bytes) : no(no_), nv(nv_), n(no_ + nv_) {
+Engine::Engine(int device_, int no_, int nv_, size_t workspace_bytes) : device(device_), no(no_), nv(nv_), n(no_ + nv_) {
     if (no < 1 || nv < 1) throw Error("need at least one occupied and one virtual orbital");
     dev::set_device(device);
+    own_stream_ = dev::stream_create();
+    stream = own_stream_;
     if (workspace_bytes == 0) {
         // ~24 amplitude-sized temporaries + the largest dressing temporary (o v^3) + slack
         const double o = no, v = nv;
@@ -112,7 +114,11 @@ Engine::Engine(int device, int no_, int nv_, size_t workspace_bytes) : no(no_), 
 
 Engine::~Engine() {
     try {
+        dev::set_device(device);
+        if (capturing_) dev::graph_abort(stream);
         dev::stream_sync(stream);
+        for (auto g : graphs_) dev::graph_destroy(g);
+        for (void* p : user_allocs_) dev::dfree(p);
         for (auto& p : V_) dev::dfree(p);
         for (auto& p : Vd_) dev::dfree(p);
         for (auto& kv : static_) dev::dfree(kv.second);
@@ -122,7 +128,79 @@ Engine::~Engine() {
         dev::dfree(eps_o);
         dev::dfree(eps_v);
         arena.release();
+        dev::stream_destroy(own_stream_);
     } catch (...) {
+    }
+}
+
+void* Engine::user_malloc(size_t bytes) {
+    void* p = dev::dmalloc(bytes);
+    user_allocs_.insert(p);
+    return p;
+}
+void Engine::user_free(void* p) {
+    if (!p) return;
+    auto it = user_allocs_.find(p);
+    if (it == user_allocs_.end()) throw Error("pymes_free: not a live allocation of this context");
+    if (capturing_) throw Error("pymes_free while a launch graph is being recorded");
+    dev::stream_sync(stream);
+    dev::dfree(p);
+    user_allocs_.erase(it);
+}
+
+void Engine::graph_begin() {
+    if (capturing_) throw Error("graph_begin: already recording");
+    if (!dev::graphs_supported()) throw Error("launch graphs are not supported by this backend");
+    dev::graph_begin(stream);
+    capturing_ = true;
+}
+dev::graph_t Engine::graph_end() {
+    if (!capturing_) throw Error("graph_end: not recording");
+    capturing_ = false;
+    dev::graph_t g = nullptr;
+    try {
+        g = dev::graph_end(stream);
+    } catch (...) {
+        dev::graph_abort(stream);
+        throw;
+    }
+    graphs_.insert(g);
+    return g;
+}
+void Engine::graph_abort() {
+    if (!capturing_) return;
+    capturing_ = false;
+    dev::graph_abort(stream);
+}
+void Engine::graph_launch(dev::graph_t g) {
+    if (!graphs_.count(g)) throw Error("graph_launch: unknown graph");
+    dev::graph_launch(g, stream);
+}
+void Engine::graph_destroy(dev::graph_t g) {
+    auto it = graphs_.find(g);
+    if (it == graphs_.end()) return;
+    dev::stream_sync(stream);
+    dev::graph_destroy(g);
+    graphs_.erase(it);
+}
+
+void Engine::exchange_asymmetry_V(double out[2]) {
+    out[0] = out[1] = 0.0;
+    for (int pat = 0; pat < 16; ++pat) {
+        if (!V_[pat]) continue;
+        // partner block under (p,q,r,s) -> (q,p,s,r): swap the type bits of the two bras and of the two kets
+        const int partner = ((pat & 8) >> 1) | ((pat & 4) << 1) | ((pat & 2) >> 1) | ((pat & 1) << 1);
+        if (!V_[partner]) {
+            out[0] = 1.0 / 0.0;
+            continue;
+        }
+        if (partner < pat) continue;          // each pair once
+        int64_t d[4];
+        for (int i = 0; i < 4; ++i) d[i] = (pat >> (3 - i) & 1) ? nv : no;
+        double r[2];
+        dev::exchange_asymmetry(V_[pat], V_[partner], d, r, stream);
+        out[0] = std::max(out[0], r[0]);
+        out[1] = std::max(out[1], r[1]);
     }
 }
 

@@ -8,6 +8,7 @@
 #pragma once
 #include <cstdint>
 #include <map>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -77,10 +78,28 @@ class Engine {
     Engine(int device, int no, int nv, size_t workspace_bytes);
     ~Engine();
 
+    int device;
     int no, nv, n;
+    // all work of the engine is ordered on this stream: a stream of the engine's own unless the caller binds another
+    // one (pymes_ctx_set_stream, e.g. torch's current stream so that RCCL collectives are ordered with the kernels)
     dev::stream_t stream = nullptr;
     Arena arena;
     ContractStats stats;
+
+    void set_stream(dev::stream_t s) { stream = s; }
+    // caller-visible device buffers (pymes_malloc): tracked so that closing the context releases whatever the host
+    // side still holds
+    void* user_malloc(size_t bytes);
+    void user_free(void* p);
+    // launch graphs recorded on this engine's stream (see device_api.h)
+    void graph_begin();
+    dev::graph_t graph_end();
+    void graph_abort();
+    void graph_launch(dev::graph_t g);
+    void graph_destroy(dev::graph_t g);
+    bool capturing() const { return capturing_; }
+    // max |V_pqrs - V_qpsr| over all blocks that are set (infinity if a block's exchange partner is missing) and max |V|
+    void exchange_asymmetry_V(double out[2]);
 
     // ---- generic tensor ops ---------------------------------------------------------
     // C[sc] = alpha * sum A[sa] * B[sb] + beta * C[sc];  `batch` lists free labels that are
@@ -151,8 +170,12 @@ class Engine {
                    int64_t q1, bool dcd, const double* J = nullptr);
     void dress_abcd_rows(const double* t1, int a0, int a1, bool lower_only);
     void cc_update(double* t, double* dt, const double* r, double shift, double delta, int rank);  // ccsd.py:176-179
+    void cc_update_to(double* t_out, double* dt, const double* t_in, const double* r, double shift, double delta, int rank);
     void ccsd_energy(const double* f, const double* t1, const double* t2, double out[3]);     // ccsd.py:458-466
     void ccd_energy(const double* t2, double out[2]);                                         // ccd.py:256-262
+    // energies (ccsd.py:458-466 / ccd.py:256-262 when f, t1 are null) and the squared norms of t2 and dt2
+    // (ccsd.py:196-197) in one pass: out = {one-body, direct, exchange, |t2|^2, |dt2|^2}
+    void energy_norms(const double* f, const double* t1, const double* t2, const double* dt2, double out[5]);
     void invalidate_static();
 
     double* eps_o = nullptr;
@@ -161,6 +184,10 @@ class Engine {
     int64_t splitk_ws_doubles() const { return splitk_doubles_; }
 
   private:
+    dev::stream_t own_stream_ = nullptr;
+    std::set<void*> user_allocs_;
+    std::set<dev::graph_t> graphs_;
+    bool capturing_ = false;
     double* V_[16] = {nullptr};      // undressed blocks (owned)
     double* Vd_[16] = {nullptr};     // dressed blocks (owned, allocated on demand)
     std::map<std::string, double*> static_;   // cached permutations of static blocks (owned)

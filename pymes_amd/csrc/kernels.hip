@@ -710,7 +710,8 @@ __global__ void mp2_amplitudes_kernel(double* __restrict__ t, const double* __re
     }
 }
 
-__global__ void cc_update_kernel(double* __restrict__ t, double* __restrict__ dt, const double* __restrict__ r_,
+// t_out may alias t_in (in-place update), hence no __restrict__ on those two
+__global__ void cc_update_kernel(double* t, double* __restrict__ dt, const double* t_in, const double* __restrict__ r_,
                                  const double* __restrict__ eo, const double* __restrict__ ev, double shift,
                                  double delta, int no, int nv, int rank, long total) {
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
@@ -731,7 +732,7 @@ __global__ void cc_update_kernel(double* __restrict__ t, double* __restrict__ dt
         const double inv = 1.0 / (d + shift);
         const double x = r_[idx] * inv;
         dt[idx] = x;
-        t[idx] += delta * x;
+        t[idx] = t_in[idx] + delta * x;
     }
 }
 
@@ -739,6 +740,7 @@ constexpr int kDotBlocks = 1024;
 struct DotPtrs {
     const double* x[16];
     const double* y[16];
+    long n[16];
 };
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -756,11 +758,12 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
     __syncthreads();
     return r;   // valid on thread 0
 }
-__global__ void __launch_bounds__(256) dots_stage1_kernel(const DotPtrs p, long n, double* __restrict__ partial) {
+__global__ void __launch_bounds__(256) dots_stage1_kernel(const DotPtrs p, double* __restrict__ partial) {
     __shared__ double sh[4];
     const int pair = blockIdx.y;
     const double* __restrict__ x = p.x[pair];
     const double* __restrict__ y = p.y[pair];
+    const long n = p.n[pair];
     double s = 0.0;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         s += x[i] * y[i];
@@ -775,6 +778,81 @@ __global__ void __launch_bounds__(256) dots_stage2_kernel(const double* __restri
     for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += partial[pair * kDotBlocks + i];
     s = block_sum(s, sh);
     if (threadIdx.x == 0) out[pair] = s;
+}
+
+// five reductions in one pass over the amplitudes (device_api.h energy_norms); partial[q * kDotBlocks + block]
+__global__ void __launch_bounds__(256) energy_norms_kernel(const double* __restrict__ f, const double* __restrict__ t1,
+                                                           const double* __restrict__ t2, const double* __restrict__ Edir,
+                                                           const double* __restrict__ Eex, const double* __restrict__ dt2,
+                                                           int no, int nv, long total, double* __restrict__ partial) {
+    __shared__ double sh[4];
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s0 = 0.0;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const double x = t2[idx];
+        double tau = x;
+        if (t1) {
+            long r = idx;
+            const int j = (int)(r % no); r /= no;
+            const int i = (int)(r % no); r /= no;
+            const int b = (int)(r % nv);
+            const int a = (int)(r / nv);
+            tau += t1[a * no + i] * t1[b * no + j];
+        }
+        s1 += tau * Edir[idx];
+        s2 += tau * Eex[idx];
+        s3 += x * x;
+        if (dt2) { const double d = dt2[idx]; s4 += d * d; }
+    }
+    if (t1 && f) {
+        const long n = no + nv, ov = (long)no * nv;
+        for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < ov; e += (long)gridDim.x * blockDim.x) {
+            const long a = e / no, i = e - a * no;
+            s0 += f[i * n + no + a] * t1[e];
+        }
+    }
+    const double r0 = block_sum(s0, sh), r1 = block_sum(s1, sh), r2 = block_sum(s2, sh), r3 = block_sum(s3, sh),
+                 r4 = block_sum(s4, sh);
+    if (threadIdx.x == 0) {
+        partial[0 * kDotBlocks + blockIdx.x] = r0;
+        partial[1 * kDotBlocks + blockIdx.x] = r1;
+        partial[2 * kDotBlocks + blockIdx.x] = r2;
+        partial[3 * kDotBlocks + blockIdx.x] = r3;
+        partial[4 * kDotBlocks + blockIdx.x] = r4;
+    }
+}
+
+// out[0] = max |A[p,q,r,s] - B[q,p,s,r]|, out[1] = max |A| as bit patterns (non-negative doubles order like integers)
+__global__ void __launch_bounds__(256) exchange_asym_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                            long d0, long d1, long d2, long d3, long total,
+                                                            unsigned long long* __restrict__ out) {
+    __shared__ double sh[8];
+    double m1 = 0.0, m2 = 0.0;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        long r = idx;
+        const long s_ = r % d3; r /= d3;
+        const long r_ = r % d2; r /= d2;
+        const long q = r % d1;
+        const long p = r / d1;
+        const double a = A[idx], b = B[((q * d0 + p) * d3 + s_) * d2 + r_];
+        const double d = fabs(a - b);
+        m1 = d > m1 || d != d ? d : m1;           // a NaN difference must not pass as symmetric
+        m2 = fmax(m2, fabs(a));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o1 = __shfl_down(m1, off, 64), o2 = __shfl_down(m2, off, 64);
+        m1 = (o1 > m1 || o1 != o1) ? o1 : m1;
+        m2 = fmax(m2, o2);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sh[w] = m1; sh[4 + w] = m2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) { m1 = (sh[k] > m1 || sh[k] != sh[k]) ? sh[k] : m1; m2 = fmax(m2, sh[4 + k]); }
+        if (m1 != m1) m1 = INFINITY;
+        atomicMax(out, (unsigned long long)__double_as_longlong(m1));
+        atomicMax(out + 1, (unsigned long long)__double_as_longlong(m2));
+    }
 }
 
 struct LinPtrs {
@@ -1304,20 +1382,37 @@ struct Prof {
     double flops = 0.0;
 } g_prof;
 
-double* g_dot_ws = nullptr;     // [16*kDotBlocks + 16]
-double* g_dot_host = nullptr;   // pinned [16]
+// per device ordinal (a process may hold contexts on several GPUs): reduction workspace [16*kDotBlocks + 16] on the
+// device, pinned result buffer [16] on the host, and "attribute set" flags of the kernels with > 64 KB of dynamic LDS
+constexpr int kMaxDevices = 16;
+double* g_dot_ws[kMaxDevices] = {nullptr};
+double* g_dot_host[kMaxDevices] = {nullptr};
+long g_live_allocs = 0;
+
+int current_device() {
+    int d = 0;
+    HIP_CHECK(hipGetDevice(&d));
+    if (d < 0 || d >= kMaxDevices) throw std::runtime_error("device ordinal out of range");
+    return d;
+}
+void ensure_dot_ws(int d) {
+    if (g_dot_ws[d]) return;
+    HIP_CHECK(hipMalloc((void**)&g_dot_ws[d], sizeof(double) * (16 * kDotBlocks + 16)));
+    HIP_CHECK(hipHostMalloc((void**)&g_dot_host[d], sizeof(double) * 16));
+}
 
 template <int BM, int BN, bool AKC, bool BKC, int VEC>
 void launch_gemm(const GemmK& k, long nblocks, hipStream_t st) {
     constexpr int A_T = (AKC ? (BK + 2) * BM : (BM + 16) * BK);
     constexpr int B_T = (BKC ? (BK + 2) * BN : (BN + 16) * BK);
     constexpr size_t lds = (size_t)2 * (A_T + B_T) * sizeof(double);
-    static bool attr_set = false;
+    static bool attr_set[kMaxDevices] = {false};
     auto fn = dgemm_kernel<BM, BN, AKC, BKC, VEC>;
-    if (!attr_set) {
+    const int dv = current_device();
+    if (!attr_set[dv]) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[dv] = true;
     }
     hipLaunchKernelGGL(fn, dim3((unsigned)nblocks), dim3(kThreads), lds, st, k);
     HIP_CHECK(hipGetLastError());
@@ -1328,12 +1423,13 @@ void launch_gemm_glds(const GemmK& k, long nblocks, hipStream_t st) {
     constexpr int A_T = AKC ? 128 * BK : BK * (128 + 16);
     constexpr int B_T = BKC ? 128 * BK : BK * (128 + 16);
     constexpr size_t lds = (size_t)2 * (A_T + B_T) * sizeof(double);
-    static bool attr_set = false;
+    static bool attr_set[kMaxDevices] = {false};
     auto fn = dgemm_glds_kernel<AKC, BKC>;
-    if (!attr_set) {
+    const int dv = current_device();
+    if (!attr_set[dv]) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
-        attr_set = true;
+        attr_set[dv] = true;
     }
     hipLaunchKernelGGL(fn, dim3((unsigned)nblocks), dim3(kThreads), lds, st, k);
     HIP_CHECK(hipGetLastError());
@@ -1379,10 +1475,48 @@ void set_device(int ordinal) { HIP_CHECK(hipSetDevice(ordinal)); }
 void* dmalloc(size_t bytes) {
     void* p = nullptr;
     HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
+    ++g_live_allocs;
     return p;
 }
 void dfree(void* p) {
-    if (p) HIP_CHECK(hipFree(p));
+    if (!p) return;
+    HIP_CHECK(hipFree(p));
+    --g_live_allocs;
+}
+int64_t live_allocations() { return g_live_allocs; }
+stream_t stream_create() {
+    hipStream_t s = nullptr;
+    HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return (stream_t)s;
+}
+void stream_destroy(stream_t s) {
+    if (s) HIP_CHECK(hipStreamDestroy((hipStream_t)s));
+}
+
+bool graphs_supported() { return true; }
+void graph_begin(stream_t s) {
+    if (!s) throw std::runtime_error("graph capture needs a stream of its own (not the default stream)");
+    HIP_CHECK(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeRelaxed));
+}
+graph_t graph_end(stream_t s) {
+    hipGraph_t g = nullptr;
+    HIP_CHECK(hipStreamEndCapture((hipStream_t)s, &g));
+    if (!g) throw std::runtime_error("graph capture produced no graph");
+    hipGraphExec_t ex = nullptr;
+    const hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    HIP_CHECK(e);
+    return (graph_t)ex;
+}
+void graph_abort(stream_t s) {
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture((hipStream_t)s, &g);
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+}
+void graph_launch(graph_t g, stream_t s) { HIP_CHECK(hipGraphLaunch((hipGraphExec_t)g, (hipStream_t)s)); }
+void graph_destroy(graph_t g) {
+    if (g) HIP_CHECK(hipGraphExecDestroy((hipGraphExec_t)g));
 }
 void memcpy_h2d(void* d, const void* h, size_t bytes, stream_t s) {
     HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, (hipStream_t)s));
@@ -1657,35 +1791,74 @@ void mp2_amplitudes(double* t, const double* w, const double* eo, const double* 
     HIP_CHECK(hipGetLastError());
 }
 
-void cc_update(double* t, double* dt, const double* r, const double* eo, const double* ev, double shift,
-               double delta, int no, int nv, int rank, stream_t s) {
+void cc_update_to(double* t_out, double* dt, const double* t_in, const double* r, const double* eo, const double* ev,
+                  double shift, double delta, int no, int nv, int rank, stream_t s) {
     const long total = rank == 4 ? (long)nv * nv * no * no : (long)nv * no;
     if (!total) return;
-    hipLaunchKernelGGL(cc_update_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, t, dt, r, eo, ev,
+    hipLaunchKernelGGL(cc_update_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, t_out, dt, t_in, r, eo, ev,
                        shift, delta, no, nv, rank, total);
     HIP_CHECK(hipGetLastError());
 }
+void cc_update(double* t, double* dt, const double* r, const double* eo, const double* ev, double shift,
+               double delta, int no, int nv, int rank, stream_t s) {
+    cc_update_to(t, dt, t, r, eo, ev, shift, delta, no, nv, rank, s);
+}
 
-void dots(int npairs, const double* const* x, const double* const* y, int64_t n, double* out_host, stream_t s) {
+void dots(int npairs, const double* const* x, const double* const* y, const int64_t* n, double* out_host, stream_t s) {
     if (npairs <= 0) return;
     if (npairs > 16) throw std::runtime_error("dots: at most 16 pairs per call");
     hipStream_t st = (hipStream_t)s;
-    if (!g_dot_ws) {
-        g_dot_ws = (double*)dmalloc(sizeof(double) * (16 * kDotBlocks + 16));
-        HIP_CHECK(hipHostMalloc((void**)&g_dot_host, sizeof(double) * 16));
-    }
+    const int dv = current_device();
+    ensure_dot_ws(dv);
     DotPtrs p;
-    for (int i = 0; i < npairs; ++i) { p.x[i] = x[i]; p.y[i] = y[i]; }
-    for (int i = npairs; i < 16; ++i) { p.x[i] = nullptr; p.y[i] = nullptr; }
-    const int nb = (int)std::max<long>(1, std::min<long>(kDotBlocks, (n + 255) / 256));
-    hipLaunchKernelGGL(dots_stage1_kernel, dim3(nb, npairs), dim3(256), 0, st, p, (long)n, g_dot_ws);
+    long nmax = 0;
+    for (int i = 0; i < npairs; ++i) { p.x[i] = x[i]; p.y[i] = y[i]; p.n[i] = (long)n[i]; nmax = std::max(nmax, p.n[i]); }
+    for (int i = npairs; i < 16; ++i) { p.x[i] = nullptr; p.y[i] = nullptr; p.n[i] = 0; }
+    const int nb = (int)std::max<long>(1, std::min<long>(kDotBlocks, (nmax + 255) / 256));
+    hipLaunchKernelGGL(dots_stage1_kernel, dim3(nb, npairs), dim3(256), 0, st, p, g_dot_ws[dv]);
     HIP_CHECK(hipGetLastError());
-    double* out_dev = g_dot_ws + 16 * kDotBlocks;
-    hipLaunchKernelGGL(dots_stage2_kernel, dim3(npairs), dim3(256), 0, st, g_dot_ws, nb, out_dev);
+    double* out_dev = g_dot_ws[dv] + 16 * kDotBlocks;
+    hipLaunchKernelGGL(dots_stage2_kernel, dim3(npairs), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipMemcpyAsync(g_dot_host, out_dev, sizeof(double) * npairs, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(g_dot_host[dv], out_dev, sizeof(double) * npairs, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    for (int i = 0; i < npairs; ++i) out_host[i] = g_dot_host[i];
+    for (int i = 0; i < npairs; ++i) out_host[i] = g_dot_host[dv][i];
+}
+
+void energy_norms(const double* f, const double* t1, const double* t2, const double* Edir, const double* Eex,
+                  const double* dt2, int no, int nv, double out_host[5], stream_t s) {
+    hipStream_t st = (hipStream_t)s;
+    const int dv = current_device();
+    ensure_dot_ws(dv);
+    const long total = (long)nv * nv * no * no;
+    const int nb = (int)std::max<long>(1, std::min<long>(kDotBlocks, (total + 255) / 256));
+    hipLaunchKernelGGL(energy_norms_kernel, dim3(nb), dim3(256), 0, st, f, t1, t2, Edir, Eex, dt2, no, nv, total,
+                       g_dot_ws[dv]);
+    HIP_CHECK(hipGetLastError());
+    double* out_dev = g_dot_ws[dv] + 16 * kDotBlocks;
+    hipLaunchKernelGGL(dots_stage2_kernel, dim3(5), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(g_dot_host[dv], out_dev, sizeof(double) * 5, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    for (int i = 0; i < 5; ++i) out_host[i] = g_dot_host[dv][i];
+}
+
+void exchange_asymmetry(const double* A, const double* B, const int64_t d[4], double out_host[2], stream_t s) {
+    hipStream_t st = (hipStream_t)s;
+    const int dv = current_device();
+    ensure_dot_ws(dv);
+    const long total = (long)d[0] * d[1] * d[2] * d[3];
+    out_host[0] = out_host[1] = 0.0;
+    if (!total) return;
+    unsigned long long* out_dev = reinterpret_cast<unsigned long long*>(g_dot_ws[dv] + 16 * kDotBlocks);
+    HIP_CHECK(hipMemsetAsync(out_dev, 0, 2 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(exchange_asym_kernel, dim3(grid_for(total, 256, 256 * 8)), dim3(256), 0, st, A, B, (long)d[0],
+                       (long)d[1], (long)d[2], (long)d[3], total, out_dev);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(g_dot_host[dv], out_dev, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    out_host[0] = g_dot_host[dv][0];
+    out_host[1] = g_dot_host[dv][1];
 }
 
 void lincomb(double* out, int nx, const double* const* x, const double* c, int64_t n, stream_t s) {

@@ -61,6 +61,7 @@ class DeviceArray:
         return DeviceArray(self.ctx, self.ptr, shape, owned=False, keepalive=self)
 
     def free(self):
+        # a closed context has released every buffer it handed out (pymes_ctx_destroy)
         if self._owned and self.ptr and self.ctx.handle:
             self.ctx.lib.call("pymes_free", self.ctx.handle, C.c_void_p(self.ptr))
         self.ptr, self._owned = 0, False
@@ -83,11 +84,14 @@ class Context:
         self.handle = h
         self._allocator = allocator      # optional callable(n_doubles) -> (ptr, keepalive), e.g. torch-backed
         self._pool = {}
+        self.profiling = False           # per-GEMM event timing is on (launch graphs are bypassed then)
         if stream is not None:
             self.set_stream(stream)
 
     # ---- lifetime -----------------------------------------------------------------
     def close(self):
+        """Destroys the context; every buffer it handed out (pool, arrays still referenced by the caller) is released
+        with it, DeviceArrays of a closed context are dead."""
         self._pool = {}
         if self.handle:
             self.lib.call("pymes_ctx_destroy", self.handle)
@@ -202,11 +206,36 @@ class Context:
             self.lib.call("pymes_set_V_pqrs", self.handle, _lib.host_ptr(V), 0, None)
 
     def set_V_block(self, name, data):
+        want = self.block_shape(name)
+        if tuple(data.shape) != want:      # the reference would raise a numpy/einsum shape error at first use
+            raise ValueError(f"integral block '{name}' must have shape {want} for (no, nv) = ({self.no}, {self.nv}), "
+                             f"got {tuple(data.shape)}")
         if isinstance(data, DeviceArray):
-            self.lib.call("pymes_set_V_block", self.handle, name.encode(), C.c_void_p(data.ptr), 1, None)
+            self.lib.call("pymes_set_V_block", self.handle, name.encode(), C.c_void_p(data.ptr), data.size, 1, None)
         else:
             data = np.ascontiguousarray(data, dtype=np.float64)
-            self.lib.call("pymes_set_V_block", self.handle, name.encode(), _lib.host_ptr(data), 0, None)
+            self.lib.call("pymes_set_V_block", self.handle, name.encode(), _lib.host_ptr(data), data.size, 0, None)
+
+    def V_exchange_asymmetry(self):
+        """(max |V_pqrs - V_qpsr| over the blocks that are set — inf if a partner block is missing —, max |V|)."""
+        out = (C.c_double * 2)()
+        self.lib.call("pymes_V_exchange_asymmetry", self.handle, out)
+        return out[0], out[1]
+
+    def V_exchange_symmetric(self, rtol=1e-12):
+        """V_pqrs = V_qpsr to rounding: the precondition of the symmetry-reduced residual (pair-packed ladders, merged
+        ring products, amplitude-side dressing).  The reference makes no such assumption, so inputs that violate it
+        (a user-built TC Hamiltonian, an FCIDUMP that lists only one of (ij|kl) / (kl|ij)) take the general path."""
+        asym, vmax = self.V_exchange_asymmetry()
+        return bool(asym <= rtol * max(1.0, vmax))
+
+    def exchange_symmetric(self, x, rtol=1e-13):
+        """X[p,q,r,s] = X[q,p,s,r] (amplitudes: T_abij = T_baji) for a DeviceArray with shape (d0,d0,d2,d2)."""
+        if len(x.shape) != 4 or x.shape[0] != x.shape[1] or x.shape[2] != x.shape[3]:
+            raise ValueError("exchange_symmetric: need a [p,p,r,r] array")
+        out = (C.c_double * 2)()
+        self.lib.call("pymes_exchange_asymmetry", self.handle, C.c_void_p(x.ptr), C.c_void_p(x.ptr), i64_array(x.shape), out)
+        return bool(out[0] <= rtol * max(1.0, out[1]))
 
     def set_V_from_factors(self, B):
         B = np.ascontiguousarray(B, dtype=np.float64)
@@ -371,6 +400,40 @@ class Context:
         self.lib.call("pymes_cc_update", self.handle, C.c_void_p(t.ptr), C.c_void_p(dt.ptr), C.c_void_p(r.ptr),
                       float(level_shift), float(delta), rank)
 
+    def cc_update_to(self, t_out, dt, t_in, r, level_shift=0.0, delta=1.0):
+        """dt = r/(D+shift), t_out = t_in + delta*dt (t_out may be t_in)."""
+        self.lib.call("pymes_cc_update_to", self.handle, C.c_void_p(t_out.ptr), C.c_void_p(dt.ptr), C.c_void_p(t_in.ptr),
+                      C.c_void_p(r.ptr), float(level_shift), float(delta), len(t_in.shape))
+
+    def energy_norms(self, f, t1, t2, dt2=None):
+        """(one-body, direct, exchange, |t2|^2, |dt2|^2) in one pass and one synchronisation; f/t1 None for CCD."""
+        out = (C.c_double * 5)()
+        self.lib.call("pymes_energy_norms", self.handle, C.c_void_p(f.ptr if f is not None else 0),
+                      C.c_void_p(t1.ptr if t1 is not None else 0), C.c_void_p(t2.ptr),
+                      C.c_void_p(dt2.ptr if dt2 is not None else 0), out)
+        return tuple(out[:])
+
+    # ---- launch graphs ----------------------------------------------------------------
+    def graph_begin(self):
+        self.lib.call("pymes_graph_begin", self.handle)
+
+    def graph_end(self):
+        g = C.c_void_p()
+        self.lib.call("pymes_graph_end", self.handle, C.byref(g))
+        return g
+
+    def graph_abort(self):
+        self.lib.call("pymes_graph_abort", self.handle)
+
+    def graph_launch(self, g):
+        self.lib.call("pymes_graph_launch", self.handle, g)
+
+    def graph_destroy(self, g):
+        self.lib.call("pymes_graph_destroy", self.handle, g)
+
+    def graphs_supported(self):
+        return self.lib.backend.startswith("hip")
+
     def ccsd_energy(self, f, t1, t2):
         e = (C.c_double * 3)()
         self.lib.call("pymes_ccsd_energy", self.handle, C.c_void_p(f.ptr), C.c_void_p(t1.ptr), C.c_void_p(t2.ptr), e)
@@ -383,14 +446,14 @@ class Context:
 
     # ---- vector helpers ---------------------------------------------------------------
     def dots(self, xs, ys):
-        n = xs[0].size
-        assert all(x.size == n for x in xs) and all(y.size == n for y in ys) and len(xs) == len(ys)
+        """out[p] = <xs[p], ys[p]>; the pairs may differ in length (T1 and T2 overlaps in one launch)."""
+        assert len(xs) == len(ys) and all(x.size == y.size for x, y in zip(xs, ys))
         out = np.empty(len(xs))
         for lo in range(0, len(xs), 16):
             hi = min(len(xs), lo + 16)
             buf = (C.c_double * (hi - lo))()
-            self.lib.call("pymes_dots", self.handle, hi - lo, ptr_array([x.ptr for x in xs[lo:hi]]),
-                          ptr_array([y.ptr for y in ys[lo:hi]]), n, buf)
+            self.lib.call("pymes_dots_var", self.handle, hi - lo, ptr_array([x.ptr for x in xs[lo:hi]]),
+                          ptr_array([y.ptr for y in ys[lo:hi]]), i64_array([x.size for x in xs[lo:hi]]), buf)
             out[lo:hi] = buf[:]
         return out
 
@@ -418,6 +481,7 @@ class Context:
 
     def prof_enable(self, on=True):
         self.lib.call("pymes_prof_enable", self.handle, int(on))
+        self.profiling = bool(on)
 
     def prof_reset(self):
         self.lib.call("pymes_prof_reset", self.handle)

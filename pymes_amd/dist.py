@@ -37,21 +37,69 @@ def padded_rows(n_rows, world_size):
     return chunk_rows(n_rows, world_size) * world_size
 
 
-def exchange_rows(full, rank, world_size):
-    """``full`` is a torch tensor [padded_rows, ...] whose chunk ``rank`` was computed locally.
-    On return every rank holds every chunk."""
+def forced():
+    """PYMES_FORCE_SHARDED=1: take the one-process-per-GPU code path (exchange buffers, collectives, pair-sharded tail)
+    even in a world of one rank.  This is how the RCCL calls are exercised on a box with a single GPU (a communicator
+    of one rank still goes through ``init_process_group("nccl")`` and every collective entry point)."""
+    return bool(os.environ.get("PYMES_FORCE_SHARDED"))
+
+
+def sharded():
+    """True when the solvers should run their sharded form."""
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return False
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or forced()
+
+
+def _staged(t):
+    """The exchange goes through host memory (test rigs: gloo cannot touch device memory; CPU tensors of the host
+    simulator).  Only then are host fences needed: under RCCL the
+    engine runs on torch's current stream (``bind_stream``), the collective is ordered behind the kernels already
+    enqueued there and ``wait()`` orders the stream behind the collective — no host synchronisation at all."""
     import torch.distributed as dist
-    if world_size == 1:
+    return (not t.is_cuda) or dist.get_backend() != "nccl"
+
+
+def bind_stream(ctx):
+    """One process per GPU under RCCL: run the engine on torch's current stream, so that engine kernels and
+    collectives are ordered on the device without host fences.  No-op for the host simulator / CPU tensors."""
+    import torch
+    if ctx.lib.backend.startswith("hip") and torch.cuda.is_available():
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+
+def _fence_before(t, ctx):
+    if ctx is not None:
+        ctx.sync()
+
+
+def _fence_after(t):
+    if t.is_cuda:
+        import torch
+        torch.cuda.current_stream().synchronize()
+
+
+def exchange_rows(full, rank, world_size, ctx=None):
+    """``full`` is a torch tensor [padded_rows, ...] whose chunk ``rank`` was computed locally (by ``ctx``'s engine).
+    On return every rank holds every chunk (stream-ordered under RCCL, complete on the host otherwise)."""
+    import torch.distributed as dist
+    if not sharded():
         return full
     c = full.shape[0] // world_size
-    if full.is_cuda and dist.get_backend() == "gloo":
-        # test rigs only (several ranks on one GPU, no RCCL): stage the exchange through host memory
-        host = full.cpu()
-        mine = host[rank * c:(rank + 1) * c].clone()
+    if _staged(full):
+        _fence_before(full, ctx)
+        host = full.cpu() if full.is_cuda else full
+        mine = host[rank * c:(rank + 1) * c].clone()      # all_gather_into_tensor must not alias its output
         dist.all_gather_into_tensor(host.view(-1), mine.view(-1))
-        full.copy_(host)
+        if full.is_cuda:
+            full.copy_(host)
+            _fence_after(full)
         return full
-    mine = full[rank * c:(rank + 1) * c].clone()      # all_gather_into_tensor must not alias its output
+    mine = full[rank * c:(rank + 1) * c].clone()
     dist.all_gather_into_tensor(full.view(-1), mine.view(-1))
     return full
 
@@ -61,7 +109,7 @@ def allreduce_sum(vec):
     import numpy as np
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not sharded():
         return np.asarray(vec, dtype=np.float64)
     t = torch.from_numpy(np.array(vec, dtype=np.float64, copy=True))
     if dist.get_backend() == "nccl":
@@ -70,18 +118,24 @@ def allreduce_sum(vec):
     return t.cpu().numpy()
 
 
-def allreduce_tensor_start(t):
+def allreduce_tensor_start(t, ctx=None):
     """In-place sum of a torch tensor over the ranks; returns a handle with ``wait()`` (async under RCCL)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not sharded():
         return _Done()
-    if os.environ.get("PYMES_SYNC_EXCHANGE") or not t.is_cuda or dist.get_backend() == "gloo":
+    if _staged(t):
+        _fence_before(t, ctx)
         if t.is_cuda:                               # test rig: several ranks on one GPU, gloo cannot reduce device memory
             h = t.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM)
             t.copy_(h)
+            _fence_after(t)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return _Done()
+    if os.environ.get("PYMES_SYNC_EXCHANGE"):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        _fence_after(t)
         return _Done()
     return _Pending(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True), t)
 
@@ -92,7 +146,8 @@ class _Done:
 
 
 class _Pending:
-    """An all-gather in flight; keeps its send buffer alive until waited for."""
+    """A collective in flight; keeps its send buffer alive until waited for.  ``wait()`` makes torch's current stream
+    (= the engine's stream) wait for the collective; the host does not block."""
 
     def __init__(self, work, send):
         self.work, self.send = work, send
@@ -103,15 +158,16 @@ class _Pending:
         return True
 
 
-def exchange_rows_start(full, rank, world_size):
+def exchange_rows_start(full, rank, world_size, ctx=None):
     """Asynchronous form of ``exchange_rows``: returns a handle whose ``wait()`` makes the current stream wait for
     the all-gather (RCCL runs it on its own stream, so kernels enqueued in between overlap with the transfer).
-    The gloo test rig and PYMES_SYNC_EXCHANGE=1 fall back to the blocking exchange."""
+    The staged test rigs and PYMES_SYNC_EXCHANGE=1 fall back to the blocking exchange."""
     import torch.distributed as dist
-    if world_size == 1:
+    if not sharded():
         return _Done()
-    if (full.is_cuda and dist.get_backend() == "gloo") or os.environ.get("PYMES_SYNC_EXCHANGE"):
-        exchange_rows(full, rank, world_size)
+    if _staged(full) or os.environ.get("PYMES_SYNC_EXCHANGE"):
+        exchange_rows(full, rank, world_size, ctx)
+        _fence_after(full)
         return _Done()
     c = full.shape[0] // world_size
     mine = full[rank * c:(rank + 1) * c].clone()

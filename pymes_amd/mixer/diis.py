@@ -43,14 +43,16 @@ class DIIS:
             return np.dot(vec[:, ok] * (1.0 / lam[ok]), np.dot(vec[:, ok].T.conj(), unit))
         return np.linalg.inv(self.L).dot(unit)
 
-    def mix(self, error, amplitude, release=None, sharded=(), allreduce=None):
+    def mix(self, error, amplitude, release=None, sharded=(), allreduce=None, out=None):
         """error / amplitude: lists of DeviceArray (one entry per amplitude type).
         Returns freshly allocated DeviceArrays with the extrapolated amplitudes.  The
         mixer keeps references to the arrays passed in (like the reference): the caller must
         not modify them afterwards.  ``release(arr)`` is called for vectors that leave the
         subspace so a caller-side pool can recycle their memory.  ``sharded``: indices of the amplitude types of which
         this process holds only its share (one process per GPU); their overlaps are summed over the ranks with
-        ``allreduce`` (a callable on a small numpy vector), the extrapolation itself is local."""
+        ``allreduce`` (a callable on a small numpy vector), the extrapolation itself is local.  ``out``: arrays to
+        write the extrapolated amplitudes into instead of fresh ones (the solvers keep T1/T2 in fixed buffers so that
+        their loop body can be replayed as a launch graph); they must not be among the stored vectors."""
         was_full = len(self.error_list) == self.dim_space
         if was_full:
             old_e, old_a = self.error_list.pop(0), self.amplitude_list.pop(0)
@@ -62,17 +64,22 @@ class DIIS:
         ctx = error[0].ctx
         m, ntypes = len(self.error_list), len(error)
         overlaps = np.zeros(m)
+        # all <e_i, e_new> of all amplitude types in one launch and one synchronisation; summed per type on the host
+        # in the order of the reference's loop (diis.py:65-78)
+        parts = ctx.dots([self.error_list[i][nt] for nt in range(ntypes) for i in range(m)],
+                         [error[nt] for nt in range(ntypes) for _ in range(m)])
         for nt in range(ntypes):
-            part = ctx.dots([self.error_list[i][nt] for i in range(m)], [error[nt]] * m)
+            part = parts[nt * m:(nt + 1) * m]
             overlaps += allreduce(part) if nt in sharded else part
         self._update_L(overlaps, was_full)
         c = self._solve()
         self.last_coefficients = c
-        out = []
+        res = []
         for nt in range(ntypes):
-            dst = ctx.pool_get(amplitude[nt].shape)
+            dst = out[nt] if out is not None else ctx.pool_get(amplitude[nt].shape)
             ctx.lincomb(dst, [self.amplitude_list[a][nt] for a in range(m)], c[:m])
-            out.append(dst)
+            res.append(dst)
+        out = res
         print_logging_info("diis.mix", level=2)
         print_logging_info("Coefficients for combining amplitudes=", level=3)
         print_logging_info(c[:-1], level=3)

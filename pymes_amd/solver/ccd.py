@@ -3,14 +3,38 @@
 Drop-in for ``pymes.solver.ccd.CCD``: same constructor, attributes, ``solve`` signature
 and return dictionary.  All tensors live in HBM between iterations; per iteration the
 host sees the energy, two norms and the DIIS overlaps."""
+import os
 import time
 
 import numpy as np
 
-from pymes_amd.device import Context, DeviceArray
+from pymes_amd.device import Context, DeviceArray, PymesError
 from pymes_amd.integral.device import DeviceIntegrals
 from pymes_amd.log import print_logging_info
 from pymes_amd.mixer import diis
+
+
+def run_replayable(ctx, st, body):
+    """Run ``body`` (a callable that only ENQUEUES kernels on fixed buffers: the residual part of a solver's loop body)
+    — eagerly the first time (lazy set-up work: cached permutations, packed integrals), then recorded once as a launch
+    graph and replayed.  Small problems are launch-bound (about 130 kernels per CCSD iteration); at benchmark sizes the
+    graph changes nothing.  Timing of individual GEMMs with events (``prof_enable``) needs the eager form."""
+    if st.get("graph") is not None and not ctx.profiling:
+        ctx.graph_launch(st["graph"])
+        return
+    if st.get("graph_ok") and st["eager_passes"] >= 1 and st.get("graph") is None and not ctx.profiling:
+        try:
+            ctx.graph_begin()
+            body()
+            st["graph"] = ctx.graph_end()
+        except PymesError:
+            ctx.graph_abort()
+            st["graph_ok"] = False       # something in the body cannot be recorded: stay eager
+        else:
+            ctx.graph_launch(st["graph"])
+            return
+    body()
+    st["eager_passes"] += 1
 
 
 class CCD:
@@ -64,11 +88,11 @@ class CCD:
             e_dir, e_exc = ctx.mp2(t2, level_shift)
             e_mp2 = e_dir + e_exc
             print("MP2 energy = ", e_mp2)
-            sym = True      # pair-packed ladder needs T_abij = T_baji: true for MP2, checked for user input
             if amps is not None:
-                t2h = np.asarray(amps)
-                sym = bool(np.abs(t2h - t2h.transpose(1, 0, 3, 2)).max() <= 1e-13 * max(1.0, np.abs(t2h).max()))
-                t2.set(t2h)
+                t2.set(np.asarray(amps))
+            # the symmetry-reduced residual needs T_abij = T_baji (true for MP2, checked for user input) and
+            # V_pqrs = V_qpsr (checked once; the reference assumes neither)
+            sym = ctx.V_exchange_symmetric() and (amps is None or ctx.exchange_symmetric(t2))
             dE = np.abs(e_mp2)
             iteration = 0
             e_last = e_mp2
@@ -76,25 +100,32 @@ class CCD:
             first = True
             shard = self._shard_setup(ctx, t2, sym and amps is None)     # one process per GPU (None for a single rank)
             self.pair_sharded = shard is not None
+            if shard is None:       # fixed buffers: the residual is replayed as a launch graph (run_replayable)
+                r2 = ctx.pool_get(t2.shape)
+                st = {"graph": None, "eager_passes": 0,
+                      "graph_ok": ctx.graphs_supported() and not os.environ.get("PYMES_NO_GRAPH")}
+                dt_fixed = None if self.is_diis else ctx.pool_get(t2.shape)
             while np.abs(dE) > delta_e and iteration <= max_iter:
                 iteration += 1
                 if shard is not None:
                     nt, nr = self._sharded_iteration(ctx, shard, f_dev, t2, level_shift, delta)
+                    e_dir_ccd, e_ex_ccd = ctx.ccd_energy(t2)                      # :132
                 else:
-                    r2 = ctx.pool_get(t2.shape)
-                    ctx.doubles_residual(f_dev, t2, r2, is_dcd=self.is_dcd, sym_ladder=sym)    # ccd.py:100-102
-                    dt2 = ctx.pool_get(t2.shape)
-                    ctx.cc_update(t2, dt2, r2, level_shift, delta)                    # :123-124
-                    ctx.pool_put(r2)
+                    run_replayable(ctx, st, lambda: ctx.doubles_residual(f_dev, t2, r2, is_dcd=self.is_dcd,
+                                                                         sym_ladder=sym))     # ccd.py:100-102
+                    if self.is_diis:
+                        t2n, dt2 = ctx.pool_get(t2.shape), ctx.pool_get(t2.shape)
+                        ctx.cc_update_to(t2n, dt2, t2, r2, level_shift, delta)        # :123-124
+                    else:
+                        t2n, dt2 = t2, dt_fixed
+                        ctx.cc_update(t2, dt2, r2, level_shift, delta)
                     if first and amps is not None:
-                        np.copyto(amps, t2.get())     # the reference updates the caller's array in place (:124)
+                        np.copyto(amps, t2n.get())    # the reference updates the caller's array in place (:124)
                     first = False
                     if self.is_diis:
-                        t2 = self.mixer.mix([dt2], [t2], release=ctx.pool_put)[0]     # :126-127
-                    nt, nr = np.sqrt(ctx.dots([t2, dt2], [t2, dt2]))
-                    if not self.is_diis:
-                        ctx.pool_put(dt2)
-                e_dir_ccd, e_ex_ccd = ctx.ccd_energy(t2)                          # :132
+                        self.mixer.mix([dt2], [t2n], release=ctx.pool_put, out=[t2])   # :126-127
+                    _, e_dir_ccd, e_ex_ccd, nt2, nr2 = ctx.energy_norms(None, None, t2, dt2)   # :132 + norms, one pass
+                    nt, nr = np.sqrt(nt2), np.sqrt(nr2)
                 e_ccd = e_dir_ccd + e_ex_ccd
                 dE = e_ccd - e_last
                 e_last = e_ccd
@@ -110,6 +141,8 @@ class CCD:
             print_logging_info("Exchange contribution = {:.12f}".format(e_ex_ccd), level=1)
             print_logging_info("CCD correlation energy = {:.12f}".format(e_ccd), level=1)
             print_logging_info("{:.3f} seconds spent on CCD".format((time.time() - time_ccd)), level=1)
+            if amps is not None and not self.is_diis and iteration > 0 and shard is None:
+                np.copyto(amps, t2.get())         # without DIIS the reference updates the caller's array every iteration
             result = {"ccd e": e_ccd, "t2 amp": t2.get(), "hole e": t_epsilon_i, "particle e": t_epsilon_a, "dE": dE}
             self.iterations = iteration
             return result
@@ -124,9 +157,10 @@ class CCD:
         from pymes_amd import dist as pdist
         from pymes_amd.device import DeviceArray
         rank, world, _ = pdist.world()
-        if world == 1 or not allowed or not ctx.pairs_supported():
+        if not pdist.sharded() or not allowed or not ctx.pairs_supported():
             return None
         import torch
+        pdist.bind_stream(ctx)          # engine kernels and RCCL collectives ordered on one stream: no host fences
         no, nv = ctx.no, ctx.nv
         dev = torch.device("cuda", ctx.device) if ctx.lib.backend.startswith("hip") else torch.device("cpu")
 
@@ -154,13 +188,10 @@ class CCD:
         refreshed in place from the all-gathered compact amplitudes."""
         from pymes_amd import dist as pdist
         from pymes_amd.device import DeviceArray
-        from pymes_amd.solver.ccsd import torch_sync
         rank, world = sh["rank"], sh["world"]
         ctx.residual_slab(f_dev, t2, sh["ETd"], sh["ETx"], sh["L"], rank, world, is_dcd=self.is_dcd)
-        ctx.sync()
-        for work in [pdist.exchange_rows_start(sh[k], rank, world) for k in ("ETd_t", "ETx_t")]:
+        for work in [pdist.exchange_rows_start(sh[k], rank, world, ctx) for k in ("ETd_t", "ETx_t")]:
             work.wait()
-        torch_sync()
         rc, dtc, tc = self._compact(ctx, sh), self._compact(ctx, sh), sh["Tc"]
         ctx.residual_finish_pairs(f_dev, t2, sh["ETd"], sh["ETx"], sh["L"], rc, rank, world, is_dcd=self.is_dcd)
         ctx.cc_update_pairs(tc, dtc, rc, level_shift, delta, rank, world)             # :123-124
@@ -172,9 +203,7 @@ class CCD:
             mine = DeviceArray(ctx, sh["Tall"].ptr + 8 * sh["lo"] * 2 * ctx.no * ctx.no, (n, 2, ctx.no * ctx.no),
                                owned=False, keepalive=sh["Tall"])
             mine.copy_from(DeviceArray(ctx, tc.ptr, mine.shape, owned=False, keepalive=tc))
-        ctx.sync()
-        pdist.exchange_rows(sh["Tall_t"], rank, world)
-        torch_sync()
+        pdist.exchange_rows(sh["Tall_t"], rank, world, ctx)
         ctx.pairs_unpack(sh["Tall"], t2, world)
         nt, nr = np.sqrt(pdist.allreduce_sum(ctx.dots([tc, dtc], [tc, dtc])))
         if not self.is_diis:

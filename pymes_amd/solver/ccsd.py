@@ -6,6 +6,7 @@ signature, return dictionary and public helper methods.  Inside ``solve`` everyt
 scalars only.  With ``torch.distributed`` initialised (one process per GPU) the
 particle-particle ladder is sharded over the ranks on the virtual index ``a``
 (pymes_amd/dist.py)."""
+import os
 import time
 
 import numpy as np
@@ -18,13 +19,6 @@ from pymes_amd.log import print_logging_info
 from pymes_amd.mixer import diis
 from pymes_amd.solver import ccd
 
-
-def torch_sync():
-    """torch.distributed collectives are ordered on torch's current stream; the engine runs on the same
-    stream (bench.py passes it) but a host-side fence keeps the hand-off obviously correct."""
-    import torch
-    if torch.cuda.is_available():
-        torch.cuda.current_stream().synchronize()
 
 # blocks produced by get_T1_dressed_V (ccsd.py:322-419); the other five names stay None (:317)
 DRESSED_KEYS = ("abij", "klij", "ijab", "ijka", "ijak", "iajb", "iabj", "iabc", "abic", "iajk", "abcd")
@@ -63,7 +57,10 @@ class CCSD(ccd.CCD):
         eps_i, eps_a = f.diagonal()[:no].copy(), f.diagonal()[no:].copy()
         ctx.set_orbital_energies(eps_i, eps_a)
         rank, wsize, _ = pdist.world()
-        st = {"ctx": ctx, "f": ctx.array(f), "fd": ctx.empty(f.shape), "level_shift": level_shift,
+        dist_on = pdist.sharded()       # one process per GPU (or the forced one-rank rehearsal of that path)
+        if dist_on:
+            pdist.bind_stream(ctx)      # engine kernels and RCCL collectives ordered on one stream: no host fences
+        st = {"ctx": ctx, "dist": dist_on, "f": ctx.array(f), "fd": ctx.empty(f.shape), "level_shift": level_shift,
               "eps_i": eps_i, "eps_a": eps_a, "rank": rank, "world": wsize, "first": True, "amps": amps}
         t2 = ctx.pool_get((nv, nv, no, no))
         e_dir, e_exc = ctx.mp2(t2, level_shift)                     # ccsd.py:128
@@ -75,20 +72,19 @@ class CCSD(ccd.CCD):
         st["t1"], st["t2"] = t1, t2
         # pair-packed ladder (1/4 of the flops) whenever T2 has the exchange symmetry T_abij = T_baji,
         # i.e. always when starting from MP2; user amplitudes are checked
-        st["sym"] = True
-        if amps is not None:
-            t2h = np.asarray(amps[1])
-            st["sym"] = bool(np.abs(t2h - t2h.transpose(1, 0, 3, 2)).max() <= 1e-13 * max(1.0, np.abs(t2h).max()))
+        # ... and the integrals must have the electron-exchange symmetry V_pqrs = V_qpsr (every FCIDUMP-derived or
+        # transcorrelated Hamiltonian has it; the reference does not assume it, so anything else takes the general path)
+        st["sym"] = ctx.V_exchange_symmetric() and (amps is None or ctx.exchange_symmetric(t2))
         st["npp"] = nv * (nv + 1) // 2
         # world > 1: every rank keeps T2-sized quantities (residual, update, DIIS history) only for the virtual pairs it
         # owns ("pair-sharded tail", include/pymes_amd.h); user amplitudes keep the replicated tail (in-place contract)
-        st["pairs"] = bool(wsize > 1 and st["sym"] and amps is None and ctx.pairs_supported())
+        st["pairs"] = bool(dist_on and st["sym"] and amps is None and ctx.pairs_supported())
         lo, hi = pdist.slab_rows(st["npp"], rank, wsize)
         st["cshape"] = (max(hi - lo, 1), 2, no * no)
         if self.is_diis:     # DIIS keeps dim_space (dT, T) pairs + the mixed result + residual/update scratch
             ctx.pool_reserve(st["cshape"] if st["pairs"] else t2.shape, 2 * self.mixer.dim_space + 4)
             ctx.pool_reserve(t1.shape, 2 * self.mixer.dim_space + 4)
-        if wsize > 1:
+        if dist_on:
             import torch
             dev = torch.device("cuda", ctx.device) if ctx.lib.backend.startswith("hip") else torch.device("cpu")
 
@@ -117,23 +113,78 @@ class CCSD(ccd.CCD):
         elif st["sym"]:
             st["ETd"], st["ETx"] = ctx.empty((no * nv, no * nv)), ctx.empty((no * nv, no * nv))
             st["L"], st["QK"] = ctx.empty((st["npp"], no * no)), ctx.empty((no * nv, no * no))
+        if not dist_on:
+            # single rank: T1, T2 and the residuals live in fixed buffers, so the residual part of the loop body (about
+            # 130 kernel launches) can be recorded once as a launch graph and replayed (small problems are launch-bound)
+            st["r1"], st["r2"] = ctx.pool_get(t1.shape), ctx.pool_get(t2.shape)
+            if not self.is_diis:
+                st["dt1"], st["dt2"] = ctx.pool_get(t1.shape), ctx.pool_get(t2.shape)
+            st["graph"], st["eager_passes"] = None, 0
+            st["graph_ok"] = ctx.graphs_supported() and not os.environ.get("PYMES_NO_GRAPH")
         return st
 
     def iterate(self, st):
         """One pass of the loop body ccsd.py:159-209.  Returns (e_1b, e_dir, e_ex, |T2|, |dT2|)."""
+        return self._iterate_sharded(st) if st["dist"] else self._iterate_single(st)
+
+    # ---- single rank ------------------------------------------------------------------------------------------------
+    def _residuals(self, st):
+        """ccsd.py:161-171: dressed Fock, dressed V blocks, R1, R2 from the fixed T1/T2 buffers into the fixed residual
+        buffers.  Only enqueues kernels (no host read-back), hence replayable as a launch graph."""
+        ctx, t1, t2, r1, r2 = st["ctx"], st["t1"], st["t2"], st["r1"], st["r2"]
+        ctx.dress_fock(st["f"], t1, st["fd"])                                         # :163
+        if st["sym"]:
+            # Symmetry-reduced form = the one-rank case of the sharded form: V_abcd is never dressed, its T1 dressing
+            # (:165, ccsd.py:414-419) is carried by tau = T2 + T1 T1 inside the ladders, that of V_abij by Q_kb and two
+            # small products inside the finish (include/pymes_amd.h, pymes_residual_slab)
+            ctx.dress_V(t1, ("klij", "iajb", "iabj"))                                 # :165
+            ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], 0, 1, is_dcd=self.is_dcd, dressed=True, t1=t1,
+                              QK=st["QK"])                                            # :171
+            ctx.singles_residual(st["fd"], t1, t2, r1)                                # :167
+            ctx.residual_finish(st["fd"], t2, st["ETd"], st["ETx"], st["L"], r2, is_dcd=self.is_dcd, dressed=True,
+                                t1=t1, QK=st["QK"])
+        else:
+            # general path (amplitudes or integrals without the exchange symmetry): explicitly dressed blocks
+            ctx.singles_residual(st["fd"], t1, t2, r1)                                # :167
+            ctx.dress_V(t1, LOOP_KEYS)                                                # :165
+            ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True, sym_ladder=False)   # :171
+
+    def _iterate_single(self, st):
+        ctx, t1, t2, r1, r2 = st["ctx"], st["t1"], st["t2"], st["r1"], st["r2"]
+        shift = st["level_shift"]
+        ccd.run_replayable(ctx, st, lambda: self._residuals(st))
+        if self.is_diis:
+            # the DIIS history keeps the updated amplitudes (:176-183); the extrapolation goes back into the fixed buffers
+            t1n, t2n, dt1, dt2 = (ctx.pool_get(t1.shape), ctx.pool_get(t2.shape), ctx.pool_get(t1.shape),
+                                  ctx.pool_get(t2.shape))
+            ctx.cc_update_to(t1n, dt1, t1, r1, shift, self.delta)                     # :176-179
+            ctx.cc_update_to(t2n, dt2, t2, r2, shift, self.delta)
+        else:
+            t1n, t2n, dt1, dt2 = t1, t2, st["dt1"], st["dt2"]
+            ctx.cc_update(t1, dt1, r1, shift, self.delta)
+            ctx.cc_update(t2, dt2, r2, shift, self.delta)
+        if st["first"] and st["amps"] is not None:
+            np.copyto(st["amps"][0], t1n.get())     # the reference updates the caller's arrays in place
+            np.copyto(st["amps"][1], t2n.get())
+        st["first"] = False
+        if self.is_diis:
+            self.mixer.mix([dt1, dt2], [t1n, t2n], release=ctx.pool_put, out=[t1, t2])    # :181-183
+        e1, ed, ex, nt2, nr2 = ctx.energy_norms(st["f"], t1, t2, dt2)                 # :189-197, one pass
+        return e1, ed, ex, np.sqrt(nt2), np.sqrt(nr2)
+
+    # ---- one process per GPU ----------------------------------------------------------------------------------------
+    def _iterate_sharded(self, st):
         ctx, t1, t2 = st["ctx"], st["t1"], st["t2"]
         shift = st["level_shift"]
-        world, rank = st["world"], st["rank"]
-        if world > 1 and st["sym"]:
+        world, rank, dist_on = st["world"], st["rank"], st["dist"]
+        if dist_on and st["sym"]:
             # K-sharded partial sums, all-reduced: the T1.V intermediates of the dressed Fock (:163, this rank's chunk of
             # j) and the slab's small V.T intermediates (X_ki, hole-ladder V_klcd T_cdij; this rank's chunk of c / (c,d))
             ctx.dress_fock_partial(t1, st["W"], rank, world)
             ctx.slab_prepare(t2, st["P"], rank, world, is_dcd=self.is_dcd)
-            ctx.sync()
-            red = [pdist.allreduce_tensor_start(st["W_t"]), pdist.allreduce_tensor_start(st["P_t"])]
+            red = [pdist.allreduce_tensor_start(st["W_t"], ctx), pdist.allreduce_tensor_start(st["P_t"], ctx)]
             for work in red:
                 work.wait()
-            torch_sync()
             ctx.dress_fock_finish(st["f"], t1, st["W"], st["fd"])
         else:
             ctx.dress_fock(st["f"], t1, st["fd"])                    # :163
@@ -144,7 +195,7 @@ class CCSD(ccd.CCD):
             # V_abcd is never dressed: its T1 dressing (:165, ccsd.py:414-419) is carried by tau = T2 + T1 T1
             # inside the ladders, that of V_abij by Q_kb and two small products inside the finish (include/pymes_amd.h,
             # pymes_residual_slab).  The singles residual is enqueued after the all-gathers have been started: overlap.
-            if world > 1:      # V~_iajb / V~_iabj only for the second-index range that this rank's column slab reads
+            if dist_on:      # V~_iajb / V~_iabj only for the second-index range that this rank's column slab reads
                 c0, c1 = pdist.slab_rows(ctx.no * ctx.nv, rank, world)
                 ctx.dress_V(t1, ("klij",))                                            # :165
                 if c1 > c0:
@@ -152,21 +203,18 @@ class CCSD(ccd.CCD):
             else:
                 ctx.dress_V(t1, ("klij", "iajb", "iabj"))                             # :165
             ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], rank, world, is_dcd=self.is_dcd,
-                              dressed=True, t1=t1, QK=st["QK"], P=st["P"] if world > 1 else None)   # :171
+                              dressed=True, t1=t1, QK=st["QK"], P=st["P"] if dist_on else None)   # :171
             pending = []
-            if world > 1:
+            if dist_on:
                 if st["pairs"]:      # X_ac (:206-221) as a partial sum over this rank's chunk of k, all-reduced below
                     ctx.xvv_partial(st["fd"], t2, st["Xvv"], rank, world, is_dcd=self.is_dcd)
-                ctx.sync()
                 keys = ("ETd_t", "ETx_t", "QK_t") if st["pairs"] else ("ETd_t", "ETx_t", "L_t", "QK_t")
-                pending = [pdist.exchange_rows_start(st[key], rank, world) for key in keys]
+                pending = [pdist.exchange_rows_start(st[key], rank, world, ctx) for key in keys]
                 if st["pairs"]:
-                    pending.append(pdist.allreduce_tensor_start(st["Xvv_t"]))
+                    pending.append(pdist.allreduce_tensor_start(st["Xvv_t"], ctx))
             ctx.singles_residual(st["fd"], t1, t2, r1)                                # :167
             for work in pending:
                 work.wait()
-            if world > 1:
-                torch_sync()
             if st["pairs"]:
                 return self._pair_sharded_tail(st, r1)
             r2 = ctx.pool_get(t2.shape)
@@ -177,7 +225,7 @@ class CCSD(ccd.CCD):
             r2 = ctx.pool_get(t2.shape)
             ctx.singles_residual(st["fd"], t1, t2, r1)                                # :167
             ctx.dress_V(t1, LOOP_KEYS)                                                # :165
-            if world == 1:
+            if not dist_on:
                 ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True, sym_ladder=False)   # :171
             else:       # plain ladder rows on this rank (one all-gather), everything else replicated
                 lo, hi = pdist.slab_rows(st["lad_rows"], rank, world)
@@ -185,9 +233,7 @@ class CCSD(ccd.CCD):
                     self._ladder_rows_plain(ctx, t2, st["lad"], lo, hi)
                 ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True, skip_ladder=True,
                                      sym_ladder=False, sym_rings=False)
-                ctx.sync()
-                pdist.exchange_rows(st["lad_t"], rank, world)
-                torch_sync()
+                pdist.exchange_rows(st["lad_t"], rank, world, ctx)
                 full = DeviceArray(ctx, st["lad"].ptr, (r2.size,), owned=False, keepalive=st["lad"])
                 r2f = r2.reshape(r2.size)
                 ctx.lincomb(r2f, [r2f, full], [1.0, 1.0])
@@ -240,9 +286,7 @@ class CCSD(ccd.CCD):
             mine = DeviceArray(ctx, st["Tall"].ptr + 8 * lo * 2 * ctx.no * ctx.no, (hi - lo, 2, ctx.no * ctx.no),
                                owned=False, keepalive=st["Tall"])
             mine.copy_from(DeviceArray(ctx, tc.ptr, mine.shape, owned=False, keepalive=tc))
-        ctx.sync()
-        pdist.exchange_rows(st["Tall_t"], rank, world)
-        torch_sync()
+        pdist.exchange_rows(st["Tall_t"], rank, world, ctx)
         ctx.pairs_unpack(st["Tall"], t2, world)
         e = ctx.ccsd_energy(st["f"], t1, t2)                                          # :189-192
         nt, nr = np.sqrt(pdist.allreduce_sum(ctx.dots([tc, dtc], [tc, dtc])))        # :196-197
@@ -304,6 +348,10 @@ class CCSD(ccd.CCD):
             print_logging_info("{:.3f} seconds spent on ccsd".format((time.time() - time_ccsd)), level=1)
             self.t_T_ai = st["t1"].get()
             self.t_T_abij = st["t2"].get()
+            if amps is not None and not self.is_diis and iteration > 0:
+                # without DIIS the reference keeps updating the caller's arrays in place (ccsd.py:178-179)
+                np.copyto(amps[0], self.t_T_ai)
+                np.copyto(amps[1], self.t_T_abij)
             self.iterations = iteration
             return {"ccsd e": e_ccsd, "t1": self.t_T_ai, "t2": self.t_T_abij, "hole e": st["eps_i"],
                     "particle e": st["eps_a"], "dE": dE}

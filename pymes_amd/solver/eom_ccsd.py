@@ -95,17 +95,11 @@ class _Sigma:
         c.contract("klcd,cdij->klij", V["ijab"], T, out=self.B2, alpha=1.0, beta=1.0)
         # particle ladder (:383): pair-packed form (1/4 of the flops) whenever V_abcd = V_badc and the trial doubles
         # are exchange-symmetric, u2_abij = u2_baji — true for every vector the Davidson driver generates
-        tmp = c.permute("badc->abcd", V["abcd"])
-        c.lincomb(tmp, [tmp, V["abcd"]], [1.0, -1.0])
-        self.v_sym = bool(c.dots([tmp], [tmp])[0] <= 1e-26 * max(1.0, c.dots([V["abcd"]], [V["abcd"]])[0]))
-        del tmp
+        self.v_sym = c.exchange_symmetric(V["abcd"])
         self.L = c.empty((nv * (nv + 1) // 2, no * no)) if self.v_sym else None
 
     def exchange_symmetric(self, u2):
-        c = self.ctx
-        d = c.permute("baji->abij", u2)
-        c.lincomb(d, [d, u2], [1.0, -1.0])
-        return bool(c.dots([d], [d])[0] <= 1e-26 * max(1.0, c.dots([u2], [u2])[0]))
+        return self.ctx.exchange_symmetric(u2)      # one reduction kernel, no temporary
 
     # ------------------------------------------------------------------------------------------
     def singles(self, u1, u2):

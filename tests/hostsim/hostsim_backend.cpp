@@ -20,13 +20,29 @@ namespace dev {
 
 const char* backend_name() { return "hostsim"; }
 void set_device(int) {}
+static long g_live = 0;
 void* dmalloc(size_t bytes) {
     void* p = std::malloc(bytes ? bytes : 16);
     if (!p) throw std::runtime_error("hostsim: out of memory");
     std::memset(p, 0xA5, bytes ? bytes : 16);   // poison: uninitialised reads show up as garbage
+    ++g_live;
     return p;
 }
-void dfree(void* p) { std::free(p); }
+void dfree(void* p) {
+    if (!p) return;
+    std::free(p);
+    --g_live;
+}
+int64_t live_allocations() { return g_live; }
+stream_t stream_create() { return nullptr; }
+void stream_destroy(stream_t) {}
+// no launch graphs on the host: the solvers run their loop body eagerly
+bool graphs_supported() { return false; }
+void graph_begin(stream_t) { throw std::runtime_error("hostsim: no launch graphs"); }
+graph_t graph_end(stream_t) { throw std::runtime_error("hostsim: no launch graphs"); }
+void graph_abort(stream_t) {}
+void graph_launch(graph_t, stream_t) { throw std::runtime_error("hostsim: no launch graphs"); }
+void graph_destroy(graph_t) {}
 void memcpy_h2d(void* d, const void* h, size_t n, stream_t) { std::memcpy(d, h, n); }
 void memcpy_d2h(void* h, const void* d, size_t n, stream_t) { std::memcpy(h, d, n); }
 void memcpy_d2d(void* d, const void* s, size_t n, stream_t) { std::memmove(d, s, n); }
@@ -89,8 +105,8 @@ void mp2_amplitudes(double* t, const double* w, const double* eo, const double* 
                 for (int j = 0; j < no; ++j, ++idx) t[idx] = w[idx] / ((eo[i] + eo[j] - ev[a] - ev[b]) + shift);
 }
 
-void cc_update(double* t, double* dt, const double* r, const double* eo, const double* ev, double shift, double delta,
-               int no, int nv, int rank, stream_t) {
+void cc_update_to(double* t, double* dt, const double* tin, const double* r, const double* eo, const double* ev, double shift,
+                  double delta, int no, int nv, int rank, stream_t) {
     int64_t idx = 0;
     if (rank == 4) {
         for (int a = 0; a < nv; ++a)
@@ -99,25 +115,61 @@ void cc_update(double* t, double* dt, const double* r, const double* eo, const d
                     for (int j = 0; j < no; ++j, ++idx) {
                         const double inv = 1.0 / ((eo[i] + eo[j] - ev[a] - ev[b]) + shift);
                         dt[idx] = r[idx] * inv;
-                        t[idx] += delta * dt[idx];
+                        t[idx] = tin[idx] + delta * dt[idx];
                     }
     } else {
         for (int a = 0; a < nv; ++a)
             for (int i = 0; i < no; ++i, ++idx) {
                 const double inv = 1.0 / ((eo[i] - ev[a]) + shift);
                 dt[idx] = r[idx] * inv;
-                t[idx] += delta * dt[idx];
+                t[idx] = tin[idx] + delta * dt[idx];
             }
     }
 }
+void cc_update(double* t, double* dt, const double* r, const double* eo, const double* ev, double shift, double delta,
+               int no, int nv, int rank, stream_t s) {
+    cc_update_to(t, dt, t, r, eo, ev, shift, delta, no, nv, rank, s);
+}
 
-void dots(int npairs, const double* const* x, const double* const* y, int64_t n, double* out, stream_t) {
+void dots(int npairs, const double* const* x, const double* const* y, const int64_t* n, double* out, stream_t) {
     if (npairs > 16) throw std::runtime_error("dots: at most 16 pairs per call");
     for (int p = 0; p < npairs; ++p) {
         double s = 0.0;
-        for (int64_t i = 0; i < n; ++i) s += x[p][i] * y[p][i];
+        for (int64_t i = 0; i < n[p]; ++i) s += x[p][i] * y[p][i];
         out[p] = s;
     }
+}
+
+void energy_norms(const double* f, const double* t1, const double* t2, const double* Edir, const double* Eex,
+                  const double* dt2, int no, int nv, double out[5], stream_t) {
+    for (int q = 0; q < 5; ++q) out[q] = 0.0;
+    int64_t idx = 0;
+    for (int a = 0; a < nv; ++a)
+        for (int b = 0; b < nv; ++b)
+            for (int i = 0; i < no; ++i)
+                for (int j = 0; j < no; ++j, ++idx) {
+                    const double tau = t2[idx] + (t1 ? t1[a * no + i] * t1[b * no + j] : 0.0);
+                    out[1] += tau * Edir[idx];
+                    out[2] += tau * Eex[idx];
+                    out[3] += t2[idx] * t2[idx];
+                    if (dt2) out[4] += dt2[idx] * dt2[idx];
+                }
+    if (t1 && f)
+        for (int a = 0; a < nv; ++a)
+            for (int i = 0; i < no; ++i) out[0] += f[(int64_t)i * (no + nv) + no + a] * t1[a * no + i];
+}
+
+void exchange_asymmetry(const double* A, const double* B, const int64_t d[4], double out[2], stream_t) {
+    out[0] = out[1] = 0.0;
+    for (int64_t p = 0; p < d[0]; ++p)
+        for (int64_t q = 0; q < d[1]; ++q)
+            for (int64_t r = 0; r < d[2]; ++r)
+                for (int64_t s = 0; s < d[3]; ++s) {
+                    const double a = A[((p * d[1] + q) * d[2] + r) * d[3] + s], b = B[((q * d[0] + p) * d[3] + s) * d[2] + r];
+                    const double df = std::fabs(a - b);
+                    if (df > out[0] || df != df) out[0] = (df != df) ? INFINITY : df;
+                    out[1] = std::fmax(out[1], std::fabs(a));
+                }
 }
 
 void lincomb(double* out, int nx, const double* const* x, const double* c, int64_t n, stream_t) {

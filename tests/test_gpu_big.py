@@ -1,0 +1,199 @@
+"""GPU: parity at BASELINE.json's configuration sizes.
+
+  C2 (20,80)   the reference's own CCSD.solve history (tests/golden/solves.json["syn_20_80"], oracle/make_golden_big.py)
+               and every function of the iteration against the oracle;
+  C3 (50,200)  dressed Fock, singles residual and an a-slab of the CCSD / DCSD doubles residual against the slab oracle
+               (oracle/slab_oracle.py: cost linear in the slab, blocks rebuilt on the host from the factors), for the
+               symmetry-reduced path on one rank and on three simulated ranks;
+  C5 (30,120)  one EOM-CCSD sigma build against the reference's output (tests/golden/eom_sigma_30_120.npz).
+"""
+import contextlib
+import io
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import cc_oracle as oc
+from oracle import slab_oracle as so
+from oracle.cases import eom_sigma_case, random_case, synthetic_case
+from pymes_amd import _lib
+from pymes_amd.device import Context, DeviceArray
+from pymes_amd.integral.device import DeviceIntegrals
+from pymes_amd.solver import ccsd
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+SOLVES = json.load(open(os.path.join(GOLD, "solves.json")))
+
+
+def opt(*a):
+    return np.einsum(*a, optimize=True)
+
+
+def test_c2_solve_history_matches_reference(gpu_lib):
+    """Config 2: every logged iteration energy of the reference's CCSD.solve at (20,80), the converged amplitudes'
+    norms and sampled entries, and the iteration count."""
+    ref = SOLVES["syn_20_80"]["ccsd"]
+    rec = SOLVES["syn_20_80"]["recipe"]
+    no, nv = 20, 80
+    f, V, B, eps = synthetic_case(no, nv, seed=rec["seed"], scale=rec["scale"], gap=rec["gap"])
+    s = ccsd.CCSD(no, delta_e=ref["delta_e"])
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        res = s.solve(f, V)
+    hist = [float(x) for x in re.findall(r"Correlation Energy = (-?[0-9.eE+-]+)", buf.getvalue())]
+    assert s.iterations == ref["iterations"] == len(hist)
+    assert np.abs(np.array(hist) - np.array(ref["history"])).max() < 1e-9
+    assert abs(res["ccsd e"] - ref["e"]) < 1e-9
+    assert abs(np.linalg.norm(res["t2"]) - ref["t2_norm"]) < 1e-8
+    assert abs(np.linalg.norm(res["t1"]) - ref["t1_norm"]) < 1e-8
+    for a, b, i, j, val in ref["t2_samples"]:
+        assert abs(res["t2"][a, b, i, j] - val) < 1e-9
+    # the same solve with the integrals formed on the device from the factors, and without launch-graph replay
+    ints = DeviceIntegrals.from_factors(no, B)
+    try:
+        os.environ["PYMES_NO_GRAPH"] = "1"
+        with contextlib.redirect_stdout(io.StringIO()):
+            res2 = ccsd.CCSD(no, delta_e=ref["delta_e"]).solve(f, ints)
+    finally:
+        del os.environ["PYMES_NO_GRAPH"]
+        ints.ctx.close()
+    assert abs(res2["ccsd e"] - ref["e"]) < 1e-9 and np.abs(res2["t2"] - res["t2"]).max() < 1e-9
+
+
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_c2_functions_vs_oracle(gpu_lib, symmetric):
+    """Config 2 size, function by function: dressed Fock, the dressed blocks the loop reads, R1, R2 (CCSD and DCSD).
+    symmetric=False: V without any permutational symmetry (general path, explicitly dressed blocks);
+    symmetric=True: 8-fold symmetric V, exchange-symmetric T2 (symmetry-reduced path as the solver runs it)."""
+    no, nv = 20, 80
+    f, V, t1, t2 = random_case(no, nv, 41, symmetric=symmetric, amp=0.05)
+    Vb = oc.split_blocks(no, V)
+    ctx = Context(no, nv, lib=gpu_lib)
+    try:
+        ctx.set_V_pqrs(V)
+        assert ctx.V_exchange_symmetric() == symmetric
+        dF, dT1, dT2 = ctx.array(f), ctx.array(t1), ctx.array(t2)
+        fd = ctx.empty(f.shape)
+        ctx.dress_fock(dF, dT1, fd)
+        fd_ref = oc.dressed_fock(no, f, t1, Vb)
+        assert np.abs(fd.get() - fd_ref).max() < 1e-11
+        keys = ("abij", "klij", "iajb", "iabj", "abcd")
+        ctx.dress_V(dT1, keys)
+        Vd = {k: oc.dressed_block(k, t1, Vb) for k in keys}
+        Vd["ijab"] = Vb["ijab"]
+        for k in keys:
+            assert np.abs(ctx.V_block(k, dressed=True).get() - Vd[k]).max() < 1e-11, k
+        r1 = ctx.empty(t1.shape)
+        ctx.singles_residual(fd, dT1, dT2, r1)
+        assert np.abs(r1.get() - oc.singles_residual(no, fd_ref, t1, t2, Vb)).max() < 1e-10
+        npp, ov = nv * (nv + 1) // 2, no * nv
+        for dcd in (False, True):
+            ref = oc.ccsd_doubles_residual(no, fd_ref, t2, Vd, is_dcsd=dcd, ein=opt)
+            scale = np.abs(ref).max()
+            r2 = ctx.empty(t2.shape)
+            ctx.doubles_residual(fd, dT2, r2, is_dcd=dcd, dressed=True, sym_ladder=False, sym_rings=False)
+            assert np.abs(r2.get() - ref).max() < 1e-11 * max(1.0, scale)
+            if symmetric:       # what CCSD.iterate runs: amplitude-side dressing, pair-packed ladders, merged rings
+                ETd, ETx = ctx.empty((ov, ov)), ctx.empty((ov, ov))
+                L, QK = ctx.empty((npp, no * no)), ctx.empty((ov, no * no))
+                ctx.dress_V(dT1, ("klij", "iajb", "iabj"))
+                ctx.residual_slab(fd, dT2, ETd, ETx, L, 0, 1, is_dcd=dcd, dressed=True, t1=dT1, QK=QK)
+                ctx.residual_finish(fd, dT2, ETd, ETx, L, r2, is_dcd=dcd, dressed=True, t1=dT1, QK=QK)
+                assert np.abs(r2.get() - ref).max() < 1e-11 * max(1.0, scale)
+    finally:
+        ctx.close()
+
+
+def test_c3_slab_vs_oracle(gpu_lib):
+    """Config 3 (50,200): after two real CCSD iterations (T1, T2 of realistic size) the dressed Fock, R1 and the rows
+    a in [37,39) and [199,200) of R2 (CCSD and DCSD) of the path bench.py times, against the slab oracle; R2 again from
+    three simulated ranks (slab + finish, and the pair-sharded tail)."""
+    from pymes_amd.model import synthetic
+    no, nv = 50, 200
+    B, eps = synthetic.factors(no, nv, seed=0)
+    f = np.diag(eps)
+    ints = DeviceIntegrals.from_factors(no, B)
+    ctx = ints.ctx
+    try:
+        solver = ccsd.CCSD(no, is_diis=False)
+        with contextlib.redirect_stdout(io.StringIO()):
+            st = solver.setup(f, ints)
+            for _ in range(2):
+                solver.iterate(st)
+        assert st["sym"] and st["graph"] is not None        # second pass was recorded and replayed
+        dT1, dT2, dF = st["t1"], st["t2"], st["f"]
+        t1, t2 = dT1.get(), dT2.get()
+        assert 1e-3 < np.abs(t1).max() < 1.0
+        # dressed Fock and singles residual in full
+        fd = ctx.empty(f.shape)
+        ctx.dress_fock(dF, dT1, fd)
+        fd_ref = oc.dressed_fock(no, f, t1, so.fock_blocks(no, B))
+        assert np.abs(fd.get() - fd_ref).max() < 1e-11
+        r1 = ctx.empty(t1.shape)
+        ctx.singles_residual(fd, dT1, dT2, r1)
+        r1_ref = oc.singles_residual(no, fd_ref, t1, t2, so.singles_blocks(no, B))
+        assert np.abs(r1.get() - r1_ref).max() < 1e-10
+        # doubles residual on slabs
+        npp, ov, o2 = nv * (nv + 1) // 2, no * nv, no * no
+        world = 3
+        pad = lambda n: -(-n // world) * world
+        ETd, ETx = ctx.zeros((pad(ov), ov)), ctx.zeros((pad(ov), ov))
+        L, QK = ctx.zeros((pad(npp), o2)), ctx.zeros((pad(ov), o2))
+        r2, r2b = ctx.empty(t2.shape), ctx.empty(t2.shape)
+        chunk = pad(npp) // world
+        Rall = ctx.zeros((world * chunk, 2, o2))
+
+        def rows(arr, a0, a1):
+            return DeviceArray(ctx, arr.ptr + 8 * a0 * nv * o2, (a1 - a0, nv, no, no), owned=False, keepalive=arr).get()
+        for dcd in (False, True):
+            ctx.dress_V(dT1, ("klij", "iajb", "iabj"))
+            ctx.residual_slab(fd, dT2, ETd, ETx, L, 0, 1, is_dcd=dcd, dressed=True, t1=dT1, QK=QK)
+            ctx.residual_finish(fd, dT2, ETd, ETx, L, r2, is_dcd=dcd, dressed=True, t1=dT1, QK=QK)
+            for rank in range(world):
+                ctx.residual_slab(fd, dT2, ETd, ETx, L, rank, world, is_dcd=dcd, dressed=True, t1=dT1, QK=QK)
+            ctx.residual_finish(fd, dT2, ETd, ETx, L, r2b, is_dcd=dcd, dressed=True, t1=dT1, QK=QK)
+            for rank in range(world):
+                piece = DeviceArray(ctx, Rall.ptr + 8 * rank * chunk * 2 * o2, (chunk, 2, o2), owned=False, keepalive=Rall)
+                ctx.residual_finish_pairs(fd, dT2, ETd, ETx, L, piece, rank, world, dT1, QK, is_dcd=dcd, dressed=True)
+            r2c = ctx.empty(t2.shape)
+            ctx.pairs_unpack(Rall, r2c, world)
+            for a0, a1 in ((37, 39), (199, 200)):
+                ref = so.residual_slab(no, fd_ref, t1, t2, B, a0, a1, is_dcsd=dcd)
+                tol = 1e-11 * max(1.0, np.abs(ref).max())
+                assert np.abs(rows(r2, a0, a1) - ref).max() < tol, (dcd, a0)
+                assert np.abs(rows(r2b, a0, a1) - ref).max() < tol, (dcd, a0, "3 simulated ranks")
+                assert np.abs(rows(r2c, a0, a1) - ref).max() < tol, (dcd, a0, "pair-sharded tail")
+            r2c.free()
+    finally:
+        ctx.close()
+
+
+def test_c5_sigma_matches_reference(gpu_lib, monkeypatch):
+    """Config 5 (30,120): sigma1 in full, an a-slab, 4096 sampled entries and three checksums of sigma2 of the
+    reference's update_singles / update_doubles (eom_ccsd.py:268-385) on the same seeded inputs."""
+    from pymes_amd.solver.eom_ccsd import EOM_CCSD
+    monkeypatch.setattr(_lib, "_default", gpu_lib)
+    g = np.load(os.path.join(GOLD, "eom_sigma_30_120.npz"))
+    no, nv = 30, 120
+    fd, V, t2, u1, u2 = eom_sigma_case(no, nv, int(g["seed"]), scale=float(g["scale"]))
+    Vb = oc.split_blocks(no, V)
+    e = EOM_CCSD(no, 2)
+    s1 = e.update_singles(fd, Vb, u1, u2, t2)
+    s2 = e.update_doubles(fd, Vb, u1, u2, t2)
+    sc1, sc2 = np.abs(g["sigma1"]).max(), np.abs(g["sigma2_val"]).max()
+    assert np.abs(s1 - g["sigma1"]).max() < 1e-10 * sc1                       # rel. 1e-10
+    assert np.abs(s2[7:8] - g["sigma2_slab"]).max() < 1e-10 * sc2
+    assert np.abs(s2.reshape(-1)[g["sigma2_idx"]] - g["sigma2_val"]).max() < 1e-10 * sc2
+    sums = np.array([s2.sum(), np.abs(s2).sum(), np.linalg.norm(s2)])
+    assert np.abs(sums - g["sigma2_sums"]).max() < 1e-9 * g["sigma2_sums"][1]
+    # a trial vector without the exchange symmetry takes the general sigma (plain particle ladder)
+    u2n = u2.copy()
+    u2n[3, 5, 1, 2] += 0.25
+    from oracle import eom_oracle as eo
+    if os.environ.get("PYMES_TEST_C5_GENERAL"):       # 45 s of host einsum: opt-in
+        ref = eo.sigma_doubles(no, fd, Vb, u1, u2n, t2)
+        assert np.abs(e.update_doubles(fd, Vb, u1, u2n, t2) - ref).max() < 1e-10 * sc2

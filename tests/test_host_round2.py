@@ -1,0 +1,158 @@
+"""CPU (host simulator standing in for the kernels): host logic added in round 2 — exchange-symmetry guard of the
+symmetry-reduced path, buffers released with their context, block-shape validation, fused reductions, fixed-buffer
+iteration with and without DIIS, in-place contract of ``amps``."""
+import contextlib
+import ctypes as C
+import io
+
+import numpy as np
+import pytest
+
+from oracle import cc_oracle as oc
+from oracle.cases import random_case, synthetic_case
+from pymes_amd import _lib
+from pymes_amd.device import Context
+from pymes_amd.solver.ccd import CCD
+from pymes_amd.solver.ccsd import CCSD
+
+
+@pytest.fixture()
+def sim(hostsim_lib, monkeypatch):
+    monkeypatch.setattr(_lib, "_default", hostsim_lib)
+    return hostsim_lib
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def live(lib):
+    n = C.c_int64()
+    lib.call("pymes_live_allocations", C.byref(n))
+    return n.value
+
+
+def test_exchange_asymmetry(sim):
+    no, nv = 3, 4
+    f, V, t1, t2 = random_case(no, nv, 5, symmetric=True)
+    ctx = Context(no, nv)
+    ctx.set_V_pqrs(V)
+    asym, vmax = ctx.V_exchange_asymmetry()
+    assert asym < 1e-14 and abs(vmax - np.abs(V).max()) < 1e-15 and ctx.V_exchange_symmetric()
+    V2 = V.copy()
+    V2[no + 1, 0, no + 2, 1] += 1e-6            # one element of V_aibj: its partner sits in V_iajb
+    ctx.set_V_pqrs(V2)
+    asym, _ = ctx.V_exchange_asymmetry()
+    assert abs(asym - 1e-6) < 1e-12 and not ctx.V_exchange_symmetric()
+    assert ctx.exchange_symmetric(ctx.array(t2))
+    t2[1, 0, 2, 1] += 1e-9
+    assert not ctx.exchange_symmetric(ctx.array(t2))
+    ctx.close()
+    # a context with only some blocks: a missing partner block means "unknown" -> not symmetric
+    ctx = Context(no, nv)
+    ctx.set_V_block("iajb", oc.split_blocks(no, V)["iajb"])
+    assert ctx.V_exchange_asymmetry()[0] == np.inf
+    ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["ccsd", "dcsd", "ccd"])
+def test_non_symmetric_V_takes_the_general_path(sim, kind):
+    """V without V_pqrs = V_qpsr must not be fed to the symmetry-reduced residual.  The oracle (= the
+    reference's algebra) makes no symmetry assumption; three iterations without DIIS must agree with it."""
+    no, nv = 3, 5
+    f, V, _, _ = synthetic_case(no, nv, seed=1, scale=0.3)
+    V = V + 0.01 * np.random.default_rng(3).standard_normal(V.shape)
+    if kind == "ccd":
+        ref = oc.ccd_solve(no, f, V, is_diis=False, delta_e=1e-30, max_iter=2)
+        s = CCD(no, is_diis=False, delta_e=1e-30)
+        s.max_iter = 2
+        res = quiet(s.solve, f, V)
+        e, t2 = res["ccd e"], res["t2 amp"]
+    else:
+        ref = oc.ccsd_solve(no, f, V, is_dcsd=(kind == "dcsd"), is_diis=False, delta_e=1e-30, max_iter=2)
+        s = CCSD(no, is_diis=False, is_dcsd=(kind == "dcsd"), delta_e=1e-30)
+        s.max_iter = 2
+        res = quiet(s.solve, f, V)
+        e, t2 = res["ccsd e"], res["t2"]
+    assert abs(e - ref["e"]) < 1e-12
+    assert np.abs(t2 - ref["t2"]).max() < 1e-12
+
+
+def test_context_releases_every_buffer(sim):
+    """buffers handed out by a context (DIIS history, state arrays, pool) die with it."""
+    no, nv = 4, 12
+    f, V, _, _ = synthetic_case(no, nv, seed=0, scale=0.3)
+    base = live(sim)
+    for _ in range(2):
+        quiet(CCSD(no, delta_e=1e-9).solve, f, V)
+        quiet(CCD(no, delta_e=1e-9).solve, f, V)
+        assert live(sim) == base
+    ctx = Context(no, nv)
+    keep = [ctx.empty((100,)) for _ in range(5)]      # still referenced by the caller when the context closes
+    assert live(sim) > base
+    ctx.close()
+    assert live(sim) == base
+    del keep                                          # dead handles: freeing them is a no-op, not a double free
+    assert live(sim) == base
+
+
+def test_block_shape_is_validated(sim):
+    no, nv = 2, 3
+    ctx = Context(no, nv)
+    with pytest.raises(ValueError, match="must have shape"):
+        ctx.set_V_block("abij", np.zeros((nv, nv, no, no + 1)))
+    with pytest.raises(ValueError, match="must have shape"):
+        ctx.set_V_block("iajb", np.zeros((nv, no, nv, no)))         # transposed block
+    bad = np.zeros(7)
+    with pytest.raises(_lib.PymesError, match="elements for this context"):
+        ctx.lib.call("pymes_set_V_block", ctx.handle, b"abij", _lib.host_ptr(bad), 7, 0, None)
+    ctx.close()
+
+
+def test_fused_reductions(sim):
+    no, nv = 3, 4
+    f, V, t1, t2 = random_case(no, nv, 8, symmetric=False)
+    rng = np.random.default_rng(0)
+    dt2 = rng.standard_normal(t2.shape)
+    ctx = Context(no, nv)
+    ctx.set_V_pqrs(V)
+    Vb = oc.split_blocks(no, V)
+    e1, ed, ex, nt, nr = ctx.energy_norms(ctx.array(f), ctx.array(t1), ctx.array(t2), ctx.array(dt2))
+    ref = oc.ccsd_energy(f[:no, no:], t1, t2, Vb["ijab"])
+    assert np.allclose([e1, ed, ex], ref, rtol=0, atol=1e-13)
+    assert abs(nt - (t2 ** 2).sum()) < 1e-12 and abs(nr - (dt2 ** 2).sum()) < 1e-12
+    _, ed, ex, _, nr0 = ctx.energy_norms(None, None, ctx.array(t2))
+    assert np.allclose([ed, ex], oc.ccd_energy(t2, Vb["ijab"]), rtol=0, atol=1e-13) and nr0 == 0.0
+    # pairs of different lengths in one call
+    a, b = rng.standard_normal(7), rng.standard_normal(1000)
+    out = ctx.dots([ctx.array(a), ctx.array(b)], [ctx.array(a), ctx.array(b)])
+    assert np.allclose(out, [a @ a, b @ b], rtol=1e-14)
+    # out-of-place update
+    eps = f.diagonal()
+    ctx.set_orbital_energies(eps[:no], eps[no:])
+    r = rng.standard_normal(t2.shape)
+    tn, dt = ctx.empty(t2.shape), ctx.empty(t2.shape)
+    ctx.cc_update_to(tn, dt, ctx.array(t2), ctx.array(r), 0.3, 0.7)
+    D = oc.denominators(eps[:no], eps[no:], 0.3)[1]
+    assert np.abs(dt.get() - r * D).max() < 1e-14 and np.abs(tn.get() - (t2 + 0.7 * r * D)).max() < 1e-14
+    ctx.close()
+
+
+@pytest.mark.parametrize("diis", [True, False])
+def test_amps_are_updated_in_place(sim, diis):
+    """ccsd.py:132,178-179: the caller's arrays are the iteration's arrays — after the first update with DIIS (the
+    mixer then hands back fresh arrays, diis.py:97-103), after every update without it."""
+    no, nv = 3, 5
+    f, V, _, _ = synthetic_case(no, nv, seed=2, scale=0.3)
+    r0 = oc.ccsd_solve(no, f, V, is_diis=diis, delta_e=1e-30, max_iter=0)      # one pass from MP2
+    t1, t2 = r0["t1"].copy(), r0["t2"].copy()
+    ref = oc.ccsd_solve(no, f, V, is_diis=diis, delta_e=1e-30, max_iter=2, amps=[t1.copy(), t2.copy()])
+    a1, a2 = t1.copy(), t2.copy()
+    s = CCSD(no, is_diis=diis, delta_e=1e-30)
+    s.max_iter = 2
+    res = quiet(s.solve, f, V, amps=[a1, a2])
+    assert not np.array_equal(a2, t2)               # updated in place
+    if not diis:
+        assert np.array_equal(a2, res["t2"]) and np.array_equal(a1, res["t1"])
+    assert abs(res["ccsd e"] - ref["e"]) < 1e-12

@@ -98,3 +98,29 @@ def test_solves(tag, kind):
     assert abs(r["e"] - ref["e"]) < 1e-9
     hist = [h[0] for h in r["history"]][:len(ref["history"])]
     assert np.abs(np.array(hist[:6]) - np.array(ref["history"][:6])).max() < 1e-11
+
+
+@pytest.mark.parametrize("no,nv,a0,a1,dcsd", [(3, 7, 2, 4, False), (3, 7, 0, 7, True), (4, 9, 8, 9, False), (2, 5, 1, 3, True)])
+def test_slab_oracle_equals_full_oracle(no, nv, a0, a1, dcsd):
+    """oracle/slab_oracle.py (factor-built dressed blocks, slab-linear contraction order) == rows of the full oracle
+    residual, which make_golden.py pins to the reference.  The GPU tests use it at (50,200)."""
+    from oracle import slab_oracle as so
+    from oracle.cases import synthetic_case
+    rng = np.random.default_rng(no * 100 + nv)
+    f, V, B, eps = synthetic_case(no, nv, seed=3, scale=0.4)
+    t1 = 0.1 * rng.standard_normal((nv, no))
+    t2 = 0.1 * rng.standard_normal((nv, nv, no, no))
+    t2 = 0.5 * (t2 + t2.transpose(1, 0, 3, 2))
+    Vb = oc.split_blocks(no, V)
+    Vd = oc.dressed_V(t1, Vb)
+    fb = so.FactorBlocks(no, so.dressed_factors(no, B, t1))
+    for k in oc.DRESSED_KEYS:
+        assert np.abs(fb(k) - Vd[k]).max() < 1e-13, k
+    assert np.abs(fb("abcd", {0: (a0, a1)}) - Vd["abcd"][a0:a1]).max() < 1e-13
+    for k, blk in so.fock_blocks(no, B).items():
+        assert np.abs(blk - Vb[k]).max() < 1e-14, k
+    fd = oc.dressed_fock(no, f, t1, Vb)
+    full = oc.ccsd_doubles_residual(no, fd, t2, Vd, is_dcsd=dcsd)
+    slab = so.residual_slab(no, fd, t1, t2, B, a0, a1, is_dcsd=dcsd)
+    assert slab.shape == (a1 - a0, nv, no, no)
+    assert np.abs(slab - full[a0:a1]).max() < 1e-13
