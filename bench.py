@@ -36,21 +36,39 @@ def reference_flops(no, nv, is_dcsd=False):
     return 2.0 * (doubles + dressing + singles)
 
 
+TRAFFIC_CSV = os.path.join("profiles", "r02", "bench_c3_pmc_hbm_traffic.csv")
+
+
+def kernels_hash():
+    import hashlib
+    return hashlib.sha256(open(os.path.join(ROOT, "pymes_amd", "csrc", "kernels.hip"), "rb").read()).hexdigest()
+
+
 def pmc_traffic_per_launch(no, nv, world, kernel_prefix):
-    """HBM bytes per launch of the kernels whose name starts with `kernel_prefix`, from the committed rocprofv3
-    PMC passes of THIS command at the default workload (profiles/r01/bench_c3_pmc_hbm_traffic.csv: FETCH_SIZE
-    doubled per the gfx950 correction + WRITE_SIZE, separate passes; tools/pmc_summary.py).  None for any other
-    workload: counters cannot be read from inside the run."""
-    path = os.path.join(ROOT, "profiles", "r01", "bench_c3_pmc_hbm_traffic.csv")
-    if (no, nv, world) != (50, 200, 1) or not os.path.exists(path):
-        return None
-    launches, gbytes = 0, 0.0
+    """(HBM bytes per launch of the kernels whose name starts with `kernel_prefix`, provenance string).
+
+    Hardware counters cannot be read from inside the run, so the figure comes from the committed rocprofv3 PMC passes of
+    THIS command at the default workload (tools/profile_bench.sh -> TRAFFIC_CSV: FETCH_SIZE doubled per the gfx950
+    correction + WRITE_SIZE, separate passes).  The CSV records the sha256 of kernels.hip it was collected with; when
+    the kernels have changed since, or for any other workload, the value is null rather than stale."""
+    path = os.path.join(ROOT, TRAFFIC_CSV)
+    if (no, nv, world) != (50, 200, 1):
+        return None, "not collected for this workload"
+    if not os.path.exists(path):
+        return None, f"{TRAFFIC_CSV} missing"
+    launches, gbytes, recorded = 0, 0.0, None
     for line in open(path):
+        if line.startswith("# kernels.hip sha256="):
+            recorded = line.split("=", 1)[1].strip()
         if line.startswith('"' + kernel_prefix):
             name, n, fetch, write = line.rsplit(",", 3)
             launches += int(n)
             gbytes += int(n) * (float(fetch) + float(write))
-    return gbytes / launches * 1e9 if launches else None
+    if recorded != kernels_hash():
+        return None, f"{TRAFFIC_CSV} is stale (collected with kernels.hip {str(recorded)[:12]}, now {kernels_hash()[:12]})"
+    if not launches:
+        return None, f"{TRAFFIC_CSV} has no launch of {kernel_prefix}"
+    return gbytes / launches * 1e9, f"{TRAFFIC_CSV} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, kernels.hip {recorded[:12]})"
 
 
 def launch_ranks(n, argv, script=None):
@@ -107,6 +125,10 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-diis", action="store_true")
+    ap.add_argument("--events", choices=("auto", "timed", "separate"), default="auto",
+                    help="where the per-GEMM HIP events of `roofline` are taken: inside the timed steps (eager launches), "
+                         "or in a separate pass after them so that the timed steps can replay the launch graph; auto = "
+                         "separate for small single-rank problems (nocc*nvirt <= 4000, the launch-bound regime)")
     ap.add_argument("--backend", default=os.environ.get("PYMES_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend; 'gloo' lets several ranks share one GPU in test rigs")
     args = ap.parse_args()
@@ -138,9 +160,10 @@ def main():
 
     no, nv = args.nocc, args.nvirt
     B, eps = synthetic.factors(no, nv, seed=args.seed)
-    stream = torch.cuda.current_stream().cuda_stream
     t0 = time.time()
-    ints = DeviceIntegrals.from_factors(no, B, device=local, stream=stream)
+    # the engine runs on a stream of its own (launch-graph capture needs one); under torch.distributed the solver binds
+    # it to torch's current stream instead, so that RCCL collectives and kernels are ordered on the device (dist.py)
+    ints = DeviceIntegrals.from_factors(no, B, device=local)
     ctx = ints.ctx
     ctx.sync()
     t_build = time.time() - t0
@@ -166,8 +189,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    separate = args.events == "separate" or (args.events == "auto" and world == 1 and no * nv <= 4000 and
+                                             not dist.is_initialized())
     ctx.stats(reset=True)
-    ctx.prof_enable(True)
+    ctx.prof_enable(not separate)
     ctx.prof_reset()
     fence()
     t0 = time.perf_counter()
@@ -175,6 +200,15 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    timed_energy = energies[-1]
+    replayed = bool(st.get("graph") is not None and separate)
+    if separate:        # the same number of steps again, eagerly, with one event pair per GEMM call
+        ctx.stats(reset=True)
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        for _ in range(args.steps):
+            step()
+        fence()
     prof = ctx.prof_query()
     prof_dma = ctx.prof_query(kernel_class=1)
     stats = ctx.stats()
@@ -196,6 +230,8 @@ def main():
         achieved = tf(dom)
         ref_fl = reference_flops(no, nv, args.dcsd)
         cap, high = ctx.workspace()
+        traffic, traffic_source = pmc_traffic_per_launch(no, nv, world, "void dgemm_glds_kernel" if
+                                                         prof_dma["launches"] else "void dgemm_")
         line = {
             "metric": "ccsd_iteration_time", "value": s_per_step, "unit": "s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * s_per_step,
@@ -210,8 +246,8 @@ def main():
                        f"({args.backend})"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": pmc_traffic_per_launch(no, nv, world, "void dgemm_glds_kernel" if
-                                                           prof_dma["launches"] else "void dgemm_"),
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "events": "separate eager pass after the timed steps" if separate else "inside the timed steps",
                          "kernel": ("dgemm_glds_kernel" if prof_dma["launches"] else "dgemm_kernel") +
                                    " (v_mfma_f64_16x16x4_f64)",
                          "launches_per_step": dom["kernel_launches"] / args.steps,
@@ -228,7 +264,7 @@ def main():
                           "executed_gemm_tflops_over_step": stats["gemm_flops"] / args.steps / s_per_step / 1e12,
                           "permute_gbytes_per_step": stats["permute_bytes"] / args.steps / 1e9,
                           "integral_build_s": t_build, "workspace_high_water_gb": high / 1e9,
-                          "last_energy": energies[-1]},
+                          "launch_graph_replay": replayed, "last_energy": timed_energy},
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle.baseline import sample, algorithmic_fma

@@ -263,6 +263,23 @@ int pymes_fcidump_read_host(const char* path, int is_tc, double* e_core, double*
 int pymes_fcidump_load(pymes_ctx* ctx, const char* path, int is_tc, double* e_core, double* eps_host, double* h_host,
                        int64_t* n_two_electron_lines);
 
+/* ---- packed binary integral files: the on-disk form of the 16 blocks (or of density-fitting factors) -------------
+ * The reference has only text ingestion (fcidump.py:124-161, one Python iteration per line) plus the hdf5 branch of its
+ * TCDUMP reader (tcdump.py:44-48,88-92).  Format "PYMESPK1" (pymes_amd/csrc/packed.h): 64-byte header, eps[n], h[n,n],
+ * then either the 16 partition.py blocks as raw little-endian fp64 (kind 1) or factors B[naux,n,n] with
+ * V[p,q,r,s] = sum_Q B[Q,p,r] B[Q,q,s] (kind 2).
+ *   pymes_packed_header:         kind, NELEC, NORB, naux (to size the context)
+ *   pymes_packed_load:           e_core / eps[n] / h[n,n] on the host, the payload straight into the context's 16
+ *                                device blocks (kind 1: streamed block by block; kind 2: formed by the MFMA GEMM)
+ *   pymes_packed_write:          the context's 16 blocks + the caller's one-body data -> file (kind 1)
+ *   pymes_packed_write_factors:  host factors -> file (kind 2) */
+int pymes_packed_header(const char* path, int* kind, int* n_elec, int* n_orb, int* naux);
+int pymes_packed_load(pymes_ctx* ctx, const char* path, double* e_core, double* eps_host, double* h_host);
+int pymes_packed_write(pymes_ctx* ctx, const char* path, int n_elec, double e_core, const double* eps_host,
+                       const double* h_host);
+int pymes_packed_write_factors(const char* path, int n_elec, int n_orb, int naux, double e_core, const double* eps_host,
+                               const double* h_host, const double* B_host);
+
 /* ---- explicit 3-body (transcorrelated) operator ---------------------------------------
  * pymes/util/tcdump.py:52-56: dense fill of L[nb]^6 from (flat index, value) pairs — the host parser hands over
  * unique targets (the last of duplicate entries, as the reference's sequential assignment keeps). */

@@ -93,6 +93,12 @@ SIGNATURES = {
     "pymes_fcidump_header": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pymes_fcidump_read_host": (C.c_int, [C.c_char_p, C.c_int, c_double_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pymes_fcidump_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, c_double_p, C.c_void_p, C.c_void_p, c_i64_p]),
+    "pymes_packed_header": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int)]),
+    "pymes_packed_load": (C.c_int, [C.c_void_p, C.c_char_p, c_double_p, C.c_void_p, C.c_void_p]),
+    "pymes_packed_write": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]),
+    "pymes_packed_write_factors": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
+                                             C.c_void_p]),
     "pymes_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, c_i64_p, c_double_p, C.c_int64]),
     "pymes_tc_single_contraction": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pymes_tc_double_contraction": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

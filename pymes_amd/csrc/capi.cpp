@@ -1,11 +1,14 @@
 // extern "C" surface of libpymes_amd (see include/pymes_amd.h).
 #include <cstring>
 #include <exception>
+#include <algorithm>
 #include <string>
+#include <vector>
 
 #include "../../include/pymes_amd.h"
 #include "engine.h"
 #include "fcidump.h"
+#include "packed.h"
 
 using pymes::Engine;
 using pymes::TView;
@@ -555,6 +558,73 @@ int pymes_fcidump_load(pymes_ctx* ctx, const char* path, int is_tc, double* e_co
             throw;
         }
         dev::dfree(Vd);
+    });
+}
+// ---- packed binary integral files (packed.h) -------------------------------------------------------------------
+int pymes_packed_header(const char* path, int* kind, int* n_elec, int* n_orb, int* naux) {
+    return guarded([&] {
+        if (!path || !kind || !n_elec || !n_orb || !naux) throw pymes::Error("null argument");
+        pymes::PackedReader r(path);
+        *kind = r.head.kind; *n_elec = r.head.n_elec; *n_orb = r.head.n_orb; *naux = r.head.naux;
+    });
+}
+int pymes_packed_load(pymes_ctx* ctx, const char* path, double* e_core, double* eps, double* h) {
+    return guarded([&] {
+        if (!path || !e_core || !eps || !h) throw pymes::Error("null argument");
+        pymes::Engine& e = E(ctx);
+        pymes::PackedReader r(path);
+        if (r.head.n_orb != e.n || r.head.n_occ != e.no) throw pymes::Error("packed file does not match the context (no, nv)");
+        *e_core = r.head.e_core;
+        std::copy(r.eps.begin(), r.eps.end(), eps);
+        std::copy(r.h.begin(), r.h.end(), h);
+        if (r.head.kind == pymes::kPackedFactors) {
+            std::vector<double> B(static_cast<size_t>(r.head.payload_doubles));
+            r.read(B.data(), r.head.payload_doubles);
+            e.set_V_from_factors(B.data(), r.head.naux);
+            return;
+        }
+        // blocks: file -> staging buffer -> device block, 32 Mi doubles at a time (V_pqrs never exists as a whole)
+        const uint64_t chunk = uint64_t(1) << 25;
+        std::vector<double> stage(static_cast<size_t>(std::min<uint64_t>(chunk, r.head.payload_doubles)));
+        for (int pat = 0; pat < 16; ++pat) {
+            double* dst = e.ensure_block(pat);
+            const uint64_t total = static_cast<uint64_t>(pymes::packed_block_doubles(pat, e.no, e.nv));
+            for (uint64_t off = 0; off < total; off += chunk) {
+                const uint64_t nb = std::min(chunk, total - off);
+                r.read(stage.data(), nb);
+                dev::memcpy_h2d(dst + off, stage.data(), sizeof(double) * nb, e.stream);
+            }
+        }
+    });
+}
+int pymes_packed_write(pymes_ctx* ctx, const char* path, int n_elec, double e_core, const double* eps, const double* h) {
+    return guarded([&] {
+        if (!path || !eps || !h) throw pymes::Error("null argument");
+        pymes::Engine& e = E(ctx);
+        if (n_elec != 2 * e.no) throw pymes::Error("packed write: NELEC must be twice the context's nocc");
+        pymes::PackedWriter w(path, pymes::kPackedBlocks, e.n, n_elec, 0, e_core, eps, h);
+        const uint64_t chunk = uint64_t(1) << 25;
+        std::vector<double> stage(static_cast<size_t>(std::min<uint64_t>(chunk, static_cast<uint64_t>(e.n) * e.n * e.n * e.n)));
+        for (int pat = 0; pat < 16; ++pat) {
+            const double* src = e.block(pat).p;          // throws if a block has not been set
+            const uint64_t total = static_cast<uint64_t>(pymes::packed_block_doubles(pat, e.no, e.nv));
+            for (uint64_t off = 0; off < total; off += chunk) {
+                const uint64_t nb = std::min(chunk, total - off);
+                dev::memcpy_d2h(stage.data(), src + off, sizeof(double) * nb, e.stream);
+                w.write(stage.data(), nb);
+            }
+        }
+        w.close();
+    });
+}
+int pymes_packed_write_factors(const char* path, int n_elec, int n_orb, int naux, double e_core, const double* eps,
+                               const double* h, const double* B) {
+    return guarded([&] {
+        if (!path || !eps || !h || !B) throw pymes::Error("null argument");
+        if (naux < 1) throw pymes::Error("packed write: naux must be positive");
+        pymes::PackedWriter w(path, pymes::kPackedFactors, n_orb, n_elec, naux, e_core, eps, h);
+        w.write(B, static_cast<uint64_t>(naux) * n_orb * n_orb);
+        w.close();
     });
 }
 int pymes_scatter(pymes_ctx* ctx, double* dst, uint64_t dst_elements, const int64_t* index_host,

@@ -230,6 +230,12 @@ TView Engine::block(int pattern, bool dressed) {
                     "' has not been set");
     return block_view(p, pattern);
 }
+double* Engine::ensure_block(int pattern) {
+    pattern &= 15;
+    invalidate_static();
+    if (!V_[pattern]) V_[pattern] = static_cast<double*>(dev::dmalloc(sizeof(double) * block_size(pattern)));
+    return V_[pattern];
+}
 double* Engine::ensure_dressed(int pattern) {
     if (!Vd_[pattern]) Vd_[pattern] = static_cast<double*>(dev::dmalloc(sizeof(double) * block_size(pattern)));
     return Vd_[pattern];

@@ -120,6 +120,8 @@ class Engine {
     void set_V_block(const char* name, const double* data, bool on_device, const int64_t strides[4]);
     void set_V_from_factors(const double* B_host, int naux);
     TView block(int pattern, bool dressed = false);       // throws if the block is absent
+    double* ensure_block(int pattern);                    // storage of an undressed block (allocated if absent); cached
+                                                          // derived quantities are invalidated
     bool has_block(int pattern, bool dressed = false) const;
     void set_orbital_energies(const double* eo_host, const double* ev_host);
 

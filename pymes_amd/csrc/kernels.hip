@@ -436,32 +436,32 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_glds_kernel(const GemmK g) 
         ua += a_kstep;
         ub += b_kstep;
     };
-    auto stage_tail = [&](int buf, int k0) {   // partial k-tile through registers, zero beyond kend
-        double* as = As + buf * A_TILE;
-        double* bs = Bs + buf * B_TILE;
+    // partial k-tile: the same DMA with the lanes (K-contiguous: 16-byte chunks; M/N-contiguous: whole k-rows) beyond
+    // kend switched off; their LDS slots are zero-filled instead.  A slot is written by exactly one of the two, so no
+    // ordering between the ds_write and the DMA is needed, and the tail costs three VGPRs instead of a register-staged
+    // copy of both tiles (which used to push the kernel's accumulators into scratch).
+    auto stage_tail = [&](int buf, int k0) {
+        const unsigned as = a_lds + buf * (A_TILE * 8), bs = b_lds + buf * (B_TILE * 8);
+        const v2d zero = {0.0, 0.0};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            v2d va = {0.0, 0.0}, vb = {0.0, 0.0};
+            bool in_a, in_b;
             if (AKC) {
                 const int row = wave * 32 + (lane >> 3) + 8 * j;
-                const int cg = (lane & 7) ^ ((row >> 1) & 7);
-                if (k0 + cg * 2 < kend) va = *reinterpret_cast<const v2d*>(ua + ao[j]);
-                *reinterpret_cast<v2d*>(as + row * BK + (lane & 7) * 2) = va;
+                in_a = k0 + (((lane & 7) ^ ((row >> 1) & 7)) << 1) < kend;
             } else {
-                const int krow = wave * 4 + j;
-                if (k0 + krow < kend) va = *reinterpret_cast<const v2d*>(ua + ao[j]);
-                *reinterpret_cast<v2d*>(as + krow * A_PITCH + 2 * lane) = va;
+                in_a = k0 + wave * 4 + j < kend;
             }
             if (BKC) {
                 const int row = wave * 32 + (lane >> 3) + 8 * j;
-                const int cg = (lane & 7) ^ ((row >> 1) & 7);
-                if (k0 + cg * 2 < kend) vb = *reinterpret_cast<const v2d*>(ub + bo[j]);
-                *reinterpret_cast<v2d*>(bs + row * BK + (lane & 7) * 2) = vb;
+                in_b = k0 + (((lane & 7) ^ ((row >> 1) & 7)) << 1) < kend;
             } else {
-                const int krow = wave * 4 + j;
-                if (k0 + krow < kend) vb = *reinterpret_cast<const v2d*>(ub + bo[j]);
-                *reinterpret_cast<v2d*>(bs + krow * B_PITCH + 2 * lane) = vb;
+                in_b = k0 + wave * 4 + j < kend;
             }
+            if (in_a) glds16_su(ua, ao[j], as + j * (A_DSTEP * 8));
+            else *reinterpret_cast<v2d*>(As + buf * A_TILE + a_dst + j * A_DSTEP + 2 * lane) = zero;
+            if (in_b) glds16_su(ub, bo[j], bs + j * (B_DSTEP * 8));
+            else *reinterpret_cast<v2d*>(Bs + buf * B_TILE + b_dst + j * B_DSTEP + 2 * lane) = zero;
         }
     };
 
@@ -533,10 +533,13 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_glds_kernel(const GemmK g) 
             ktile(buf0, 1, 0);
             ktile(buf1, 1, 0);
         }
-        for (; kt < nkt; ++kt) {
-            const int next = kt + 1 < nfull ? 1 : (kt + 1 < nkt ? 2 : 0);
-            if (kt & 1) ktile(buf1, next, kbeg + (kt + 1) * BK);
-            else ktile(buf0, next, kbeg + (kt + 1) * BK);
+        // what is left: at most two full tiles and the partial one, starting in buffer 0 (kt is even) — straight-line
+        // code with compile-time buffers (a loop over the parity made the compiler spill the accumulators)
+        auto next_of = [&](int t) { return t + 1 < nfull ? 1 : (t + 1 < nkt ? 2 : 0); };
+        ktile(buf0, next_of(kt), kbeg + (kt + 1) * BK);
+        if (kt + 1 < nkt) {
+            ktile(buf1, next_of(kt + 1), kbeg + (kt + 2) * BK);
+            if (kt + 2 < nkt) ktile(buf0, 0, 0);
         }
     } else {
         landed();
