@@ -121,6 +121,10 @@ int pymes_ccsd_dress_V_slab(pymes_ctx* ctx, const double* t1_dev, uint32_t block
 /* CCSD.get_singles_residual, ccsd.py:423-438 */
 int pymes_ccsd_singles_residual(pymes_ctx* ctx, const double* fd_dev, const double* t1_dev, const double* t2_dev,
                                 double* r1_dev);
+/* The same residual as a partial sum over rank `rank`'s chunk of the occupied summation index (one process per GPU; needs
+ * T_abij = T_baji): the caller all-reduces the [nv][no] results (f~_ai enters on rank 0).  world = 1 is the whole residual. */
+int pymes_ccsd_singles_residual_partial(pymes_ctx* ctx, const double* fd_dev, const double* t1_dev, const double* t2_dev,
+                                        double* r1_dev, int rank, int world);
 /* CCD.get_residual, ccd.py:164-254 (and CCSD.get_doubles_residual, ccsd.py:440-456, with
  * PYMES_USE_DRESSED).  flags: */
 #define PYMES_DCD 1u          /* is_dcd / is_dcsd */

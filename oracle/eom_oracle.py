@@ -225,6 +225,7 @@ def eom_solve(no, f, Vd, t2, n_excit=3, max_iter=500, e_epsilon=1e-8, sigma=None
         for l in range(dim):
             for j in range(dim):
                 B[j, l] = np.vdot(us1[j], ws[l][0]) + np.vdot(us2[j], ws[l][1])
+        e_old = e_excit                                                 # :110, every pass
         lam, vec = np.linalg.eig(B)
         pick = lam.argsort()[:n_excit]
         e = np.real(lam[pick])

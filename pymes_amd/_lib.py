@@ -57,6 +57,8 @@ SIGNATURES = {
     "pymes_ccsd_dress_V": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "pymes_ccsd_dress_V_slab": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int]),
     "pymes_ccsd_singles_residual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pymes_ccsd_singles_residual_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                      C.c_int]),
     "pymes_doubles_residual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "pymes_ladder": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]),
     "pymes_ladder_sym": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int]),

@@ -276,6 +276,13 @@ int pymes_ccsd_singles_residual(pymes_ctx* ctx, const double* fd, const double* 
         E(ctx).singles_residual(fd, t1, t2, r1);
     });
 }
+int pymes_ccsd_singles_residual_partial(pymes_ctx* ctx, const double* fd, const double* t1, const double* t2, double* r1,
+                                        int rank, int world) {
+    return guarded([&] {
+        need(fd, "fd"); need(t1, "t1"); need(t2, "t2"); need(r1, "r1");
+        E(ctx).singles_residual_partial(fd, t1, t2, r1, rank, world);
+    });
+}
 int pymes_doubles_residual(pymes_ctx* ctx, const double* f, const double* t2, double* r2, uint32_t flags) {
     return guarded([&] {
         need(f, "f"); need(t2, "t2"); need(r2, "r2");

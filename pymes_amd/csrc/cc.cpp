@@ -1005,6 +1005,42 @@ void Engine::singles_residual(const double* fd, const double* t1, const double* 
     contract(-1.0, S4, "ac", t, "ci", 1.0, R, "ai");                                         // :436
 }
 
+// The same residual as a K-sharded partial sum (one process per GPU; exchange-symmetric T2 only): every term contracts
+// over one occupied index j together with virtual ones — (b,j), (j,b,c), (j,b,k) — so rank r sums over its chunk of j and
+// the v x o partial results are all-reduced (80 KB at (50,200)); the dressed-Fock term enters on rank 0.  With
+// T_abij = T_baji, Tt'[a,b,i,j] = 2 T_abij - T_abji is symmetric as an (a,i) x (b,j) matrix, so one permuted piece
+// Tq[a,j,b,k] (j in the chunk) serves ccsd.py:432, :435 and :436; P1[j,b,c,i] = Tt'[b,c,i,j] serves :433 and :434.
+void Engine::singles_residual_partial(const double* fd, const double* t1, const double* t2, double* r1, int rank, int world) {
+    const int64_t o = no, v = nv, nn = n;
+    if (world < 1 || rank < 0 || rank >= world) throw Error("singles_residual_partial: bad rank/world");
+    const int64_t c = (o + world - 1) / world, j0 = std::min<int64_t>(rank * c, o), j1 = std::min<int64_t>(j0 + c, o);
+    const int64_t nj = j1 - j0;
+    TView D = make_view(const_cast<double*>(fd), {nn, nn});
+    TView Dov = slice(slice(D, 0, 0, o), 1, o, nn), Dvo = slice(slice(D, 0, o, nn), 1, 0, o);
+    TView t = make_view(const_cast<double*>(t1), {v, o});
+    TView T = make_view(const_cast<double*>(t2), {v, v, o, o});
+    TView R = make_view(r1, {v, o});
+    if (rank == 0) copy(Dvo, R);                                                             // :431
+    else zero(R);
+    if (nj <= 0) return;
+    ArenaScope scope(arena);
+    TView Tq = make_view(arena.alloc(v * nj * v * o), {v, nj, v, o});                        // Tq[a,j,b,k], j in the chunk
+    TView P1 = make_view(arena.alloc(nj * v * v * o), {nj, v, v, o});                        // P1[j,b,c,i]
+    permute(2.0, slice(T, 2, j0, j1), "abjk", 0.0, Tq, "ajbk");
+    permute(-1.0, slice(T, 3, j0, j1), "abkj", 1.0, Tq, "ajbk");
+    permute(2.0, slice(T, 3, j0, j1), "bcij", 0.0, P1, "jbci");
+    permute(-1.0, slice(T, 2, j0, j1), "bcji", 1.0, P1, "jbci");
+    contract(1.0, Tq, "bjai", slice(Dov, 0, j0, j1), "jb", 1.0, R, "ai");                    // :432 (Tt' symmetric)
+    contract(1.0, slice(block(P_aibc), 1, j0, j1), "ajbc", P1, "jbci", 1.0, R, "ai");        // :433
+    TView S2 = make_view(arena.alloc(o * o), {o, o});
+    contract(1.0, slice(make_view(get_static("Vjbck"), {o, v, v, o}), 0, j0, j1), "jbck", P1, "jbci", 0.0, S2, "ki");
+    contract(-1.0, t, "ak", S2, "ki", 1.0, R, "ai");                                         // :434
+    contract(-1.0, Tq, "ajbk", slice(block(P_ijka), 0, j0, j1), "jkib", 1.0, R, "ai");       // :435
+    TView S4 = make_view(arena.alloc(v * v), {v, v});
+    contract(1.0, Tq, "ajbk", slice(block(P_ijab), 0, j0, j1), "jkcb", 0.0, S4, "ac");
+    contract(-1.0, S4, "ac", t, "ci", 1.0, R, "ai");                                         // :436
+}
+
 // -----------------------------------------------------------------------------------
 // ccsd.py:176-179, ccd.py:123-124
 // -----------------------------------------------------------------------------------

@@ -137,6 +137,8 @@ class Engine {
     // ccsd.py:290-421; cut = {p0,p1,q0,q1} (optional): only these ranges of the first / second (virtual) index
     void dress_V(const double* t1, uint32_t mask, const int64_t* cut = nullptr);
     void singles_residual(const double* fd, const double* t1, const double* t2, double* r1);  // ccsd.py:423-438
+    // the same as a partial sum over this rank's chunk of the occupied summation index (exchange-symmetric T2), see cc.cpp
+    void singles_residual_partial(const double* fd, const double* t1, const double* t2, double* r1, int rank, int world);
     // ccd.py:164-254; flags: bit0 = DCD/DCSD, bit1 = use dressed blocks, bit2 = skip ladder,
     // bit3 = pair-packed ladder (T and V exchange-symmetric)
     void doubles_residual(const double* f, const double* t2, double* r2, unsigned flags);

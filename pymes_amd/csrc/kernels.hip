@@ -621,6 +621,85 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmK g, int B
     C[off] = v;
 }
 
+__device__ __forceinline__ double wave_sum(double v);
+
+// ------------------------------------------------------------------------------------
+// Matrix-vector products (the M = 1 / N = 1 contractions of the dressed Fock matrix and the singles residual):
+// HBM-streaming, no MFMA.  W is [R][C] with unit stride along C (row pitch ld).
+//   gemv_cols:  part[s][c] = sum_{r in chunk s} x[r * xs] W[r][c]      (weighted column sums; grid = column blocks x row chunks)
+//   gemv_finish: y[c * ys] = alpha * sum_s part[s][c] + beta * yin[c * ys]
+//   gemv_rows:  y[r * ys] = alpha * sum_c W[r][c] x[c * xs] + beta * yin[r * ys]   (one wave per row, shuffle reduction)
+// ------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(256) gemv_cols_kernel(const double* __restrict__ W, long ld, const double* __restrict__ x,
+                                                        long xs, long R, long C, long rchunk, double* __restrict__ part) {
+    const long c = ((long)blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (c >= C) return;
+    const long r0 = (long)blockIdx.y * rchunk, r1 = min(R, r0 + rchunk);
+    const double* __restrict__ w = W + r0 * ld + c;
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    long r = r0;
+    for (; r + 2 <= r1; r += 2) {
+        const double x0 = x[r * xs], x1 = x[(r + 1) * xs];
+        if constexpr (VEC == 2) {
+            const v2d u = *reinterpret_cast<const v2d*>(w), v = *reinterpret_cast<const v2d*>(w + ld);
+            a0 += x0 * u[0]; a1 += x0 * u[1];
+            b0 += x1 * v[0]; b1 += x1 * v[1];
+        } else {
+            a0 += x0 * w[0];
+            b0 += x1 * w[ld];
+        }
+        w += 2 * ld;
+    }
+    if (r < r1) {
+        const double x0 = x[r * xs];
+        if constexpr (VEC == 2) {
+            const v2d u = *reinterpret_cast<const v2d*>(w);
+            a0 += x0 * u[0]; a1 += x0 * u[1];
+        } else {
+            a0 += x0 * w[0];
+        }
+    }
+    double* __restrict__ p = part + (long)blockIdx.y * C + c;
+    p[0] = a0 + b0;
+    if constexpr (VEC == 2) p[1] = a1 + b1;
+}
+__global__ void __launch_bounds__(256) gemv_finish_kernel(const double* __restrict__ part, int nchunk, long C, double alpha,
+                                                          double beta, const double* yin, double* y, long ys) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < nchunk; ++k) s += part[(long)k * C + c];
+    double v = alpha * s;
+    if (beta != 0.0) v += beta * yin[c * ys];
+    y[c * ys] = v;
+}
+template <int VEC>
+__global__ void __launch_bounds__(256) gemv_rows_kernel(const double* __restrict__ W, long ld, const double* __restrict__ x,
+                                                        long xs, long R, long C, double alpha, double beta, const double* yin,
+                                                        double* y, long ys) {
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int lane = threadIdx.x & 63;
+    const double* __restrict__ w = W + r * ld;
+    double s0 = 0.0, s1 = 0.0;
+    if constexpr (VEC == 2) {
+        for (long c = 2 * lane; c < C; c += 128) {
+            const v2d u = *reinterpret_cast<const v2d*>(w + c);
+            s0 += u[0] * x[c * xs];
+            s1 += u[1] * x[(c + 1) * xs];
+        }
+    } else {
+        for (long c = lane; c < C; c += 64) s0 += w[c] * x[c * xs];
+    }
+    const double s = wave_sum(s0 + s1);
+    if (lane == 0) {
+        double v = alpha * s;
+        if (beta != 0.0) v += beta * yin[r * ys];
+        y[r * ys] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // permutation / strided copy
 // ------------------------------------------------------------------------------------
@@ -1438,12 +1517,20 @@ void launch_gemm_glds(const GemmK& k, long nblocks, hipStream_t st) {
     HIP_CHECK(hipGetLastError());
 }
 
+// tuning knob (experiments): smallest K range per block that still goes to the LDS-DMA kernel
+inline long dma_min_k() {
+    static const long v = [] {
+        const char* e = getenv("PYMES_DMA_MIN_K");
+        return e ? std::max<long>(64, atol(e)) : 384L;
+    }();
+    return v;
+}
 template <int BM, int BN>
 bool dispatch_layout(const GemmK& k, bool akc, bool bkc, int vec, long nblocks, hipStream_t st) {   // true: LDS-DMA kernel
     // the LDS-DMA kernel addresses a tile as uniform base + 32-bit byte offset per lane
     const bool off32 = (akc ? 128 : 16) * k.a_ld * 8 + 4096 < (1L << 32) && (bkc ? 128 : 16) * k.b_ld * 8 + 4096 < (1L << 32);
     // ... and pays off from about 64 k-tiles per block on (measured: below that the register-staged kernel wins)
-    if (BM == 128 && BN == 128 && vec == 2 && off32 && k.kchunk >= 1024 && !getenv("PYMES_GEMM_NO_LDSDMA")) {
+    if (BM == 128 && BN == 128 && vec == 2 && off32 && k.kchunk >= dma_min_k() && !getenv("PYMES_GEMM_NO_LDSDMA")) {
         if (akc && bkc) launch_gemm_glds<true, true>(k, nblocks, st);
         else if (akc) launch_gemm_glds<true, false>(k, nblocks, st);
         else if (bkc) launch_gemm_glds<false, true>(k, nblocks, st);
@@ -1467,6 +1554,10 @@ bool dispatch_layout(const GemmK& k, bool akc, bool bkc, int vec, long nblocks, 
 inline bool even(long x) { return (x & 1) == 0; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+
+// M = 1 or N = 1 (no batch): matrix-vector product on the streaming kernels above.  Returns false when the shape does not
+// qualify (then the MFMA GEMM handles it).  Timed under the same profiling events as a GEMM call (class 0).
+bool gemv_dispatch(const dev::Gemm& g, long a_sm, long a_sk, long b_sk, long b_sn, hipStream_t st);
 }  // namespace
 
 namespace dev {
@@ -1588,6 +1679,7 @@ void gemm(const Gemm& g, stream_t s) {
     if (!(b_sk == 1 || b_sn == 1)) throw std::runtime_error("gemm: B has no unit stride");
     const bool a_kcontig = (a_sk == 1);
     const bool b_kcontig = (b_sk == 1);
+    if (gemv_dispatch(g, a_sm, a_sk, b_sk, b_sn, st)) return;
     GemmK k;
     k.A = g.A; k.B = g.B; k.C = g.C;
     k.Cin = g.Cin ? g.Cin : g.C;
@@ -1610,7 +1702,7 @@ void gemm(const Gemm& g, stream_t s) {
     // the chip by k-splitting with >= 1024 per split, which keeps the (faster) 128x128 LDS-DMA kernel
     if (BM == 128 && BN == 128 && ntiles(128, 128) < 256) {
         const long nt = ntiles(128, 128), want = (512 + nt - 1) / nt;
-        const bool deep = g.splitk_ws && g.K / want >= 1024 && nt * want * 128L * 128L <= g.splitk_ws_doubles;
+        const bool deep = g.splitk_ws && g.K / want >= dma_min_k() && nt * want * 128L * 128L <= g.splitk_ws_doubles;
         if (!deep) { BM = 64; BN = 64; }
     }
     else if (BM == 128 && BN == 64 && ntiles(128, 64) < 256) { BM = 64; }
@@ -1661,7 +1753,7 @@ void gemm(const Gemm& g, stream_t s) {
             long smax = std::min<long>(512, std::max<long>(8, 2048 / rem));
             // per split: >= 1024 deep when the launch is deep enough for the LDS-DMA kernel (the split blocks then run on
             // it too), else >= 256 (128x128) / 128 (smaller tiles)
-            const long min_kt = (BM == 128 && BN == 128) ? (ktiles >= 128 ? 64 : 16) : 8;
+            const long min_kt = (BM == 128 && BN == 128) ? (ktiles >= 2 * dma_min_k() / BK ? dma_min_k() / BK : 16) : 8;
             smax = std::min<long>(smax, ktiles / min_kt);
             smax = std::min<long>(smax, ws_tiles / rem);
             for (long sp = 2; sp <= smax; ++sp) {
@@ -2102,3 +2194,67 @@ void ueg_two_body(const UegParams& prm, const int* k_int_dev, const int* index_m
 }
 
 }  // namespace dev
+
+namespace {
+
+bool gemv_dispatch(const dev::Gemm& g, long a_sm, long a_sk, long b_sk, long b_sn, hipStream_t st) {
+    if (getenv("PYMES_NO_GEMV")) return false;
+    if (g.nb1 != 1 || g.nb2 != 1 || g.K < 256) return false;
+    const double* W; const double* x; long ld, xs, R, C, ys; bool cols;
+    if (g.M == 1 && g.N >= 64) {                 // y[n] = sum_k A(0,k) B(k,n)
+        x = g.A; xs = a_sk; W = g.B; ys = 1;
+        if (b_sn == 1) { cols = true; R = g.K; C = g.N; ld = b_sk; }          // B[k][n]: weighted column sums
+        else { cols = false; R = g.N; C = g.K; ld = b_sn; }                    // B[n][k]: one dot per row
+    } else if (g.N == 1 && g.M >= 64) {          // y[m] = sum_k A(m,k) B(k,0)
+        x = g.B; xs = b_sk; W = g.A; ys = g.ldc;
+        if (a_sk == 1) { cols = false; R = g.M; C = g.K; ld = a_sm; }
+        else { cols = true; R = g.K; C = g.M; ld = a_sk; }
+    } else {
+        return false;
+    }
+    if (!cols && R < 512) return false;          // too few rows to fill the chip with one wave per row
+    const double* yin = g.Cin ? g.Cin : g.C;
+    const int vec = (even(ld) && even(C) && aligned16(W)) ? 2 : 1;
+    const long cblocks = (C + 256L * vec - 1) / (256L * vec);
+    long nchunk = 1, rchunk = R;
+    if (cols) {        // row chunks so that about 2048 blocks are in flight; their partial sums go through the workspace
+        if (!g.splitk_ws || C > g.splitk_ws_doubles) return false;
+        nchunk = std::max<long>(1, std::min<long>((2048 + cblocks - 1) / cblocks, R / 32));
+        nchunk = std::min<long>(nchunk, g.splitk_ws_doubles / C);
+        rchunk = (R + nchunk - 1) / nchunk;
+        nchunk = (R + rchunk - 1) / rchunk;
+    }
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (g_prof.on) {
+        if (!g_prof.pool.empty()) { ev = g_prof.pool.back(); g_prof.pool.pop_back(); }
+        else { HIP_CHECK(hipEventCreate(&ev.first)); HIP_CHECK(hipEventCreate(&ev.second)); }
+        HIP_CHECK(hipEventRecord(ev.first, st));
+    }
+    if (cols) {
+        if (vec == 2) hipLaunchKernelGGL(gemv_cols_kernel<2>, dim3((unsigned)cblocks, (unsigned)nchunk), dim3(256), 0, st, W, ld, x, xs, R, C, rchunk, g.splitk_ws);
+        else hipLaunchKernelGGL(gemv_cols_kernel<1>, dim3((unsigned)cblocks, (unsigned)nchunk), dim3(256), 0, st, W, ld, x, xs, R, C, rchunk, g.splitk_ws);
+        HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(gemv_finish_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, g.splitk_ws, (int)nchunk, C,
+                           g.alpha, g.beta, yin, g.C, ys);
+    } else {
+        if (vec == 2) hipLaunchKernelGGL(gemv_rows_kernel<2>, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, W, ld, x, xs, R, C, g.alpha, g.beta, yin, g.C, ys);
+        else hipLaunchKernelGGL(gemv_rows_kernel<1>, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, W, ld, x, xs, R, C, g.alpha, g.beta, yin, g.C, ys);
+    }
+    HIP_CHECK(hipGetLastError());
+    if (g_prof.on) {
+        HIP_CHECK(hipEventRecord(ev.second, st));
+        g_prof.ev.push_back(ev);
+        const double fl = 2.0 * (double)g.M * (double)g.N * (double)g.K;
+        g_prof.flops += fl;
+        g_prof.fl.push_back(fl);
+        g_prof.klass.push_back(0);
+        g_prof.nk.push_back(1);
+        char buf[256];
+        snprintf(buf, sizeof buf, "M=%ld N=%ld K=%ld batch=1 gemv=%s vec=%d flops=%.4e", (long)g.M, (long)g.N, (long)g.K,
+                 cols ? "cols" : "rows", vec, fl);
+        g_prof.what.push_back(buf);
+    }
+    return true;
+}
+
+}  // namespace

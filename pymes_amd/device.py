@@ -286,6 +286,12 @@ class Context:
                       C.c_void_p(t2.ptr), C.c_void_p(out.ptr))
         return out
 
+    def singles_residual_partial(self, fd, t1, t2, out, rank, world):
+        """This rank's K-sharded share of the singles residual (exchange-symmetric T2; the caller all-reduces)."""
+        self.lib.call("pymes_ccsd_singles_residual_partial", self.handle, C.c_void_p(fd.ptr), C.c_void_p(t1.ptr),
+                      C.c_void_p(t2.ptr), C.c_void_p(out.ptr), int(rank), int(world))
+        return out
+
     def doubles_residual(self, f, t2, out, is_dcd=False, dressed=False, skip_ladder=False, sym_ladder=False,
                          sym_rings=None):
         """``sym_ladder`` / ``sym_rings``: T_abij = T_baji and V_pqrs = V_qpsr hold, use the symmetry-reduced

@@ -107,6 +107,8 @@ class CCSD(ccd.CCD):
                 st["W_t"], st["W"] = reduced(ctx.dress_fock_ws())
                 st["Xvv_t"], st["Xvv"] = reduced(nv * nv)
                 st["P_t"], st["P"] = reduced(ctx.slab_prepare_ws())
+                st["R1_t"], st["R1"] = reduced(nv * no)
+                st["R1"] = st["R1"].reshape(nv, no)
             else:
                 st["lad_rows"] = nv * nv
                 st["lad_t"], st["lad"] = shared(nv * nv, no * no)
@@ -188,7 +190,8 @@ class CCSD(ccd.CCD):
             ctx.dress_fock_finish(st["f"], t1, st["W"], st["fd"])
         else:
             ctx.dress_fock(st["f"], t1, st["fd"])                    # :163
-        r1 = ctx.pool_get(t1.shape)
+        # the singles residual of the symmetric path is an all-reduced partial sum: it lives in its exchange buffer
+        r1 = st["R1"] if st["sym"] else ctx.pool_get(t1.shape)
         if st["sym"]:
             # Symmetry-reduced, sharded form (world = 1 included): this rank's column slab of the ring products,
             # its rows of the pair-packed particle + hole ladders and of Q_kb; all-gathers; remainder.
@@ -212,7 +215,9 @@ class CCSD(ccd.CCD):
                 pending = [pdist.exchange_rows_start(st[key], rank, world, ctx) for key in keys]
                 if st["pairs"]:
                     pending.append(pdist.allreduce_tensor_start(st["Xvv_t"], ctx))
-            ctx.singles_residual(st["fd"], t1, t2, r1)                                # :167
+            # :167 as a partial sum over this rank's chunk of the occupied summation index, all-reduced (80 KB)
+            ctx.singles_residual_partial(st["fd"], t1, t2, r1, rank, world)
+            pending.append(pdist.allreduce_tensor_start(st["R1_t"], ctx))
             for work in pending:
                 work.wait()
             if st["pairs"]:
@@ -240,7 +245,8 @@ class CCSD(ccd.CCD):
         dt1, dt2 = ctx.pool_get(t1.shape), ctx.pool_get(t2.shape)
         ctx.cc_update(t1, dt1, r1, shift, self.delta)               # :176-179
         ctx.cc_update(t2, dt2, r2, shift, self.delta)
-        ctx.pool_put(r1)
+        if not st["sym"]:
+            ctx.pool_put(r1)
         ctx.pool_put(r2)
         if st["first"] and st["amps"] is not None:
             np.copyto(st["amps"][0], t1.get())      # the reference updates the caller's arrays in place
@@ -275,7 +281,6 @@ class CCSD(ccd.CCD):
         dt1, dtc, tc = ctx.pool_get(t1.shape), self._compact(ctx, st), st["Tc"]
         ctx.cc_update(t1, dt1, r1, shift, self.delta)                                 # :176-179
         ctx.cc_update_pairs(tc, dtc, rc, shift, self.delta, rank, world)
-        ctx.pool_put(r1)
         ctx.pool_put(rc)
         st["first"] = False
         if self.is_diis:

@@ -79,6 +79,14 @@ class _Sigma:
         self.MDU = c.empty(self.M1.shape)
         c.lincomb(self.MDU, [self.M_D, self.Ud], [1.0, -1.0])
         del M_A, M_B, Vd, Vx, Vq, Tq
+        # V_kacd.T products of the u1 terms (eom_ccsd.py:334, :343, :345, :346), u-independent like the pair matrices above:
+        #   WA[a,d,b,j] = sum_ck (2 V[k,a,c,d] - V[k,a,d,c]) T[c,b,k,j] - V[k,a,c,d] T[b,c,k,j],   W3[a,d,b,i] = sum_ck V[k,a,d,c] T[b,c,k,i]
+        # so that a sigma build contracts them with u1 over d (o^2 v^3, HBM-bound) instead of forming V.u1 first and paying
+        # three (ov)^3 products per trial vector.  Two v^3 o arrays (0.4 GB each at (30,120)).
+        self.WA = c.contract("kacd,cbkj->adbj", V["iabc"], T, alpha=2.0)
+        c.contract("kadc,cbkj->adbj", V["iabc"], T, out=self.WA, alpha=-1.0, beta=1.0)
+        c.contract("kacd,bckj->adbj", V["iabc"], T, out=self.WA, alpha=-1.0, beta=1.0)
+        self.W3 = c.contract("kadc,bcki->adbi", V["iabc"], T)
         # small hoisted V.T blocks
         self.A3 = c.contract("klci,cbkj->libj", V["ijak"], T, alpha=-2.0)                 # A_oovo
         c.contract("klic,cbkj->libj", V["ijka"], T, out=self.A3, alpha=1.0, beta=1.0)
@@ -138,13 +146,6 @@ class _Sigma:
         else:
             Dx = c.contract("ajdl,dlbi->ajbi", self.M_D, u2x)                     # :372  u2[d,b,i,l]
             c.contract("ajck,bick->ajbi", u2x, self.Ud, out=Dx, alpha=-1.0, beta=1.0)  # :364
-        Cd = c.contract("kacd,di->aick", V["iabc"], u1)                           # sum_d V[k,a,c,d] u1[d,i]
-        Cp = c.contract("kadc,di->aick", V["iabc"], u1)                           # sum_d V[k,a,d,c] u1[d,i]
-        Cc = c.empty(Cd.shape)
-        c.lincomb(Cc, [Cd, Cp], [2.0, -1.0])
-        c.contract("aick,ckbj->aibj", Cc, self.Td, out=Dd, beta=1.0)              # :334, :345
-        c.contract("aick,bjck->aibj", Cd, self.Tx, out=Dd, alpha=-1.0, beta=1.0)  # :343
-        c.contract("ajck,bick->ajbi", Cp, self.Tx, out=Dx, alpha=-1.0, beta=1.0)  # :346
         # ---- one-index dressings -----------------------------------------------------------------------
         Xoo = c.contract("klid,dl->ki", V["ijka"], u1, alpha=-2.0)
         c.contract("kldi,dl->ki", V["ijak"], u1, out=Xoo, beta=1.0)
@@ -158,6 +159,9 @@ class _Sigma:
         c.contract("lkcd,adlk->ac", V["ijab"], u2, out=Xvv, alpha=-2.0, beta=1.0)
         c.contract("lkcd,dalk->ac", V["ijab"], u2, out=Xvv, beta=1.0)
         D = c.contract("ac,cbij->abij", Xvv, T)
+        # V_kacd.T.u1 terms (:334, :343, :345, :346) through the hoisted V.T intermediates: o^2 v^3 instead of (ov)^3 each
+        c.contract("adbj,di->abij", self.WA, u1, out=D, beta=1.0)
+        c.contract("adbi,dj->abij", self.W3, u1, out=D, alpha=-1.0, beta=1.0)
         c.contract("ad,dbij->abij", self.Gvv, u2, out=D, beta=1.0)
         c.contract("li,ablj->abij", self.Goo, u2, out=D, beta=1.0, batch="ab")
         c.contract("al,libj->abij", u1, self.A3, out=D, beta=1.0)
@@ -255,7 +259,8 @@ class EOM_CCSD:
                 B = np.zeros((dim, dim))
                 for l in range(dim):                                             # :103-109
                     B[:, l] = ctx.dots(us, [ws[l]] * dim)
-                lam, vec = np.linalg.eig(B)                                      # :112
+                e_old = self.e_excit                                             # :110 (every pass, so the collapse
+                lam, vec = np.linalg.eig(B)                                      # :112  branch's restore is a no-op)
                 pick = lam.argsort()[:self.n_excit]
                 e_imag = np.imag(lam[pick])
                 e = np.real(lam[pick])

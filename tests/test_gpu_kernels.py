@@ -68,6 +68,24 @@ def test_dgemm_lds_dma_kernel(ctx, a_kc, b_kc):
     _gemm_case(ctx, 4000, 1275, 2052, a_kc, b_kc, 1.0, 0.0, rng, ldb_pad=0 if b_kc else 1)        # ladder-like N
 
 
+@pytest.mark.parametrize("a_kc", [True, False])
+@pytest.mark.parametrize("b_kc", [True, False])
+def test_matrix_vector_kernels(ctx, a_kc, b_kc):
+    """M = 1 / N = 1 products run on the HBM-streaming matrix-vector kernels (weighted column sums through the
+    workspace, one wave per row with a shuffle reduction): both orientations of the matrix, odd extents and pitches
+    (scalar loads), alpha/beta, a strided result (N = 1 with ldc > 1)."""
+    rng = np.random.default_rng(11)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    for (M, N, K) in ((1, 4000, 3000), (1, 3999, 3001), (1, 700, 100000), (1, 130000, 300), (3000, 1, 4000),
+                      (3001, 1, 2999), (100000, 1, 700), (600, 1, 130000)):
+        _gemm_case(ctx, M, N, K, a_kc, b_kc, 1.0, 0.0, rng)
+        _gemm_case(ctx, M, N, K, a_kc, b_kc, -0.5, 2.0, rng, lda_pad=2, ldb_pad=1, ldc_pad=3)
+    q = ctx.prof_query()
+    ctx.prof_enable(False)
+    assert q["launches"] == 16
+
+
 def test_lds_dma_kernel_batched(ctx):
     """Batched products big enough for the LDS-DMA kernel: per-batch base pointers (moved to SGPRs in the kernel), a
     stride-0 operand shared by all batches, and k-split remainder tiles across batch boundaries."""

@@ -136,9 +136,27 @@ def c5(args):
     flag = sig.exchange_symmetric(u2)                        # decided once per vector by the Davidson driver
     dt = timed(lambda: sig.apply(u1, u2, u2_sym=flag), ctx.sync, 5)
     flops = 2.0 * (6.4e9 + 1.502e12)
+    # roofline of the sigma build: executed GEMM flops / summed HIP-event time of the GEMM calls (a pass of its own)
+    ctx.stats(reset=True)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    reps = 3
+    for _ in range(reps):
+        sig.apply(u1, u2, u2_sym=flag)
+    ctx.sync()
+    prof, dma = ctx.prof_query(), ctx.prof_query(kernel_class=1)
+    ctx.prof_enable(False)
+    peak = 78.6
+    tf = lambda q: q["flops"] / (q["ms"] * 1e-3) / 1e12 if q["ms"] > 0 else 0.0
     out = {"config": "C5 one EOM-CCSD sigma build (singles + doubles), synthetic (nocc=30, nvirt=120)", "gpu_s": dt,
            "hoisted_intermediates_once_per_solve_s": t_hoist, "reference_algorithmic_flops": flops,
-           "algorithmic_tflops": flops / dt / 1e12}
+           "algorithmic_tflops": flops / dt / 1e12,
+           "roofline": {"bound": "mfma", "peak": peak, "unit": "TFLOP/s", "kernel": "dgemm_glds_kernel",
+                        "achieved": tf(dma), "frac": tf(dma) / peak, "ms_per_sigma": dma["ms"] / reps,
+                        "launches_per_sigma": dma["kernel_launches"] / reps,
+                        "all_gemm": {"achieved": tf(prof), "frac": tf(prof) / peak, "ms_per_sigma": prof["ms"] / reps,
+                                     "calls_per_sigma": prof["launches"] / reps,
+                                     "executed_flops_per_sigma": prof["flops"] / reps}}}
     if not args.skip_cpu:
         from oracle import eom_oracle as eo, cc_oracle as oc
         from oracle.cases import synthetic_case
