@@ -237,6 +237,23 @@ int pymes_ccd_energy(pymes_ctx* ctx, const double* t2_dev, double* e_out_host);
 int pymes_ueg_eval_2b(pymes_ctx* ctx, int n_p, int n_ele, int imax, int mode, double L, double k_cutoff, double gamma,
                       int lattice_cutoff, const int32_t* k_int_host, const int32_t* index_map_host, double* V_dev);
 
+/* The same with the reference's other correlators, evaluated inside the kernels from the same float k^2 the reference forms
+ * (so that a cut-off lying exactly on a lattice shell is resolved the way the reference's roundings resolve it):
+ * correlator 1 UEG.gaskell (ueg.py:836-883) params {mu, cut}, 2 gaskell_modified (:802-834) {cut}, 3 coulomb (:905-915)
+ * {-4 pi gamma}, 4 yukawa (:740-770) {gamma, floor}, 5 stg (:917-935) {gamma^2, floor, -4 pi / gamma}, 6 smooth (:885-903)
+ * {kc, kc gamma, (kc gamma)^2}; params[4], derived from the model by pymes_amd/model/ueg.py with the reference's expressions. */
+int pymes_ueg_eval_2b_corr(pymes_ctx* ctx, int n_p, int n_ele, int imax, int mode, double L, int lattice_cutoff,
+                           int correlator, const double* params_host, const int32_t* k_int_host,
+                           const int32_t* index_map_host, double* V_dev);
+/* The same for a correlator u(k^2) of the caller's own (any Python callable): every argument of u is |2 pi n / L|^2 for an integer vector n, so u is handed over as
+ * two host tables over m = |n|^2 (tab_len >= 3 (lattice_cutoff + 2 imax)^2 + 1): tab_scalar[m] is what the reference's
+ * correlator returns when called with a float (the main loop's `d_k_vec.dot(d_k_vec)`, ueg.py:409), tab_array[m] what it
+ * returns when called with an ndarray (everything else: sumNablaUSquare, the 3-body contractions) — the two forms of
+ * `gaskell` differ at its cut-off.  modes 1-3 as above. */
+int pymes_ueg_eval_2b_tab(pymes_ctx* ctx, int n_p, int n_ele, int imax, int mode, double L, int lattice_cutoff,
+                          const int32_t* k_int_host, const int32_t* index_map_host, const double* tab_scalar_host,
+                          const double* tab_array_host, int64_t tab_len, double* V_dev);
+
 /* ---- vector helpers for DIIS (pymes/mixer/diis.py:65-103) and norms ----------------- */
 /* out_host[p] = sum_i x[p][i]*y[p][i], npairs <= 16, deterministic reduction (synchronises) */
 int pymes_dots(pymes_ctx* ctx, int npairs, const double* const* x_dev, const double* const* y_dev, int64_t n,

@@ -15,6 +15,7 @@ class Ueg:
         self.Omega = self.L ** 3
         self.k_cutoff = None
         self.gamma = None
+        self.correlator = "trunc"          # name of the correlator u(k^2) (ueg.py:740-984)
         self._lattice = None
         self._nabla_cache = {}
 
@@ -57,6 +58,77 @@ class Ueg:
         np.divide(-4.0 * np.pi, k2 ** 2, out=out, where=(k2 > 1e-12))
         return out * self.gamma
 
+    # ---- the other correlators of the reference (ueg.py:740-770, 802-984), restated branch by branch.  Each has an
+    # "array" form (called with an ndarray) and a "scalar" form (called with a float; what `k.dot(k)` and
+    # einsum("i,i->") produce) — the two differ AT the cut-off in gaskell / gaskell_modified, so both are kept.
+    def _rho(self):
+        return self.n_ele / self.Omega
+
+    def _masked(self, num, den, keep):
+        out = np.zeros_like(den, dtype=np.float64)
+        np.divide(num, den, out=out, where=keep)
+        return out
+
+    def u(self, k2, scalar=False):
+        """u(k^2) of the selected correlator.  Returns (values, k2 as the reference leaves it): `trunc` zeroes the
+        sub-cutoff entries of an array argument in place (ueg.py:794), the others do not touch it."""
+        name = self.correlator
+        tw = 2 * np.pi / self.L
+        if name == "trunc":
+            if self.k_cutoff is None:
+                self.k_cutoff = int(np.ceil(np.sqrt(self.cutoff)))
+            kc2 = (self.k_cutoff * 2 * np.pi / self.L) ** 2
+            k2m = np.array(k2, dtype=np.float64, copy=True)
+            k2m[k2m <= kc2 * (1 + 0.00001)] = 0.0
+            return self.trunc(k2), k2m
+        k2 = np.array(k2, dtype=np.float64, copy=True)
+        if name == "gaskell":                                               # ueg.py:836-883
+            mu = np.sqrt(4.0 * np.pi / self._rho()) * (self.gamma if self.gamma is not None else 1.0)
+            kf = self.kp[self.n_ele // 2]
+            kf2 = kf.dot(kf)
+            cut = (self.k_cutoff ** 2 if self.k_cutoff is not None else 4.0) * kf2
+            if scalar:
+                res = np.where((k2 < cut) & (k2 > 1e-12), mu / np.where(k2 > 1e-12, k2, 1.0), 0.0)
+            else:
+                res = self._masked(mu, k2, k2 > 1e-12)
+                res[k2 > cut] = 0.0
+            return -res, k2
+        if name == "gaskell_modified":                                      # ueg.py:802-834
+            cut = (self.k_cutoff * tw) ** 2 if self.k_cutoff is not None else 2.0
+            mu = np.pi
+            if scalar:
+                inner = (k2 < cut) & (k2 > 1e-12)
+                with np.errstate(divide="ignore"):
+                    res = np.where(inner, 0.0, 4 * mu / k2 ** 2)
+            else:
+                res = self._masked(4 * mu, k2 ** 2, k2 >= cut)
+            return -res, k2
+        if name == "coulomb":                                               # ueg.py:905-915
+            g = 1.0 if self.gamma is None else self.gamma
+            return self._masked(-4.0 * np.pi * g, k2, k2 > 1e-12), k2
+        if name == "yukawa":                                                # ueg.py:740-770
+            g0 = np.sqrt(self._rho() / 4.0 * np.pi)
+            g = g0 if self.gamma is None else self.gamma * g0
+            den_cut = (self.k_cutoff * tw ** 2 + g) if self.k_cutoff is not None else 1e-12
+            b = k2 + g
+            return self._masked(-4.0 * np.pi, b, np.abs(b) > den_cut), k2
+        if name == "stg":                                                   # ueg.py:917-935
+            g = np.sqrt(4.0 * np.pi * self._rho()) if self.gamma is None else self.gamma
+            den_cut = (self.k_cutoff * tw ** 2 + g ** 2) ** 2 if self.k_cutoff is not None else 1e-12
+            b = (k2 + g ** 2) ** 2
+            return self._masked(-4.0 * np.pi / g, b, np.abs(b) > den_cut), k2
+        if name == "smooth":                                                # ueg.py:885-903
+            from scipy import special
+            if self.k_cutoff is None:
+                self.k_cutoff = int(np.ceil(np.sqrt(self.cutoff)))
+            if self.gamma is None:
+                self.gamma = 0.01
+            kc = np.sqrt((self.k_cutoff * tw) ** 2)
+            k = np.sqrt(k2)
+            num = -4.0 * np.pi * (1.0 + special.erf((k - kc) / (kc * self.gamma))) / 2.0
+            return self._masked(num, k2 ** 2, k2 > (kc * self.gamma) ** 2), k2
+        raise ValueError(name)
+
     def sum_nabla_u_square(self, dk, cutoff=30):
         """ueg.py:581-596: sum_k' (k'.(k-k')) u(k'^2) u((k-k')^2) / Omega over a (2*30+1)^3 lattice."""
         key = tuple(np.round(dk * self.L / (2 * np.pi)).astype(int))
@@ -67,7 +139,7 @@ class Ueg:
             k1 = 2 * np.pi * self._lattice / self.L
             k2 = dk - k1
             k1s, k2s = np.einsum("ni,ni->n", k1, k1), np.einsum("ni,ni->n", k2, k2)
-            val = np.einsum("ni,ni->n", k1, k2) * self.trunc(k1s) * self.trunc(k2s)
+            val = np.einsum("ni,ni->n", k1, k2) * self.u(k1s)[0] * self.u(k2s)[0]
             self._nabla_cache[key] = np.einsum("n->", val) / self.Omega
         return self._nabla_cache[key]
 
@@ -75,15 +147,16 @@ class Ueg:
         return self.kp[: self.n_ele // 2]
 
     def exchange_3b(self, pvec, kvec):
-        """ueg.py:518-543."""
+        """ueg.py:518-543.  k.k comes out of einsum(optimize=True) as a 0-d ARRAY there, so it takes the correlator's array
+        branch — only the `d_k_vec.dot(d_k_vec)` of the main loop (ueg.py:409) is a scalar."""
         d = pvec - self._occ()
-        return np.sum((d @ kvec) * self.trunc(kvec @ kvec) * self.trunc(np.einsum("ni,ni->n", d, d))) / self.Omega
+        return np.sum((d @ kvec) * self.u(kvec @ kvec)[0] * self.u(np.einsum("ni,ni->n", d, d))[0]) / self.Omega
 
     def p_k_with_q(self, pvec, kvec):
         """ueg.py:545-573."""
         v1, v2 = pvec - kvec - self._occ(), pvec - self._occ()
-        return np.sum(np.einsum("ni,ni->n", v1, v2) * self.trunc(np.einsum("ni,ni->n", v1, v1))
-                      * self.trunc(np.einsum("ni,ni->n", v2, v2))) / self.Omega
+        return np.sum(np.einsum("ni,ni->n", v1, v2) * self.u(np.einsum("ni,ni->n", v1, v1))[0]
+                      * self.u(np.einsum("ni,ni->n", v2, v2))[0]) / self.Omega
 
     # ---- two-body integrals (ueg.py:265-516) --------------------------------------------------
     def two_body(self, mode="coulomb"):
@@ -107,18 +180,18 @@ class Ueg:
                 if mode == "coulomb":
                     w = np.full(n, 4 * np.pi / dk2 / self.Omega if abs(dk2) > 0 else 0.0)
                 elif mode == "rpa":
-                    w = np.full(n, -self.n_ele * dk2 * self.trunc(dk2) ** 2 / self.Omega / self.Omega if abs(dk2) > 0 else 0.0)
+                    w = np.full(n, -self.n_ele * dk2 * float(self.u(dk2, scalar=True)[0]) ** 2 / self.Omega / self.Omega if abs(dk2) > 0 else 0.0)
                 elif mode == "only_2b":
                     u_mat = self.sum_nabla_u_square(dk)
                     if abs(dk2) > 0:
                         rs_dk = self.kp[r] - self.kp[np.clip(s, 0, n - 1)]
-                        u = self.trunc(dk2)
+                        u = float(self.u(dk2, scalar=True)[0])
                         w = (4 * np.pi / dk2 + u_mat + dk2 * u - (rs_dk @ dk) * u) / self.Omega
                     else:
                         w = np.full(n, u_mat / self.Omega)
                 elif mode == "effect_2b":
                     if abs(dk2) > 0:
-                        val = (-self.n_ele * dk2 * self.trunc(dk2) ** 2 / self.Omega
+                        val = (-self.n_ele * dk2 * float(self.u(dk2, scalar=True)[0]) ** 2 / self.Omega
                                + 2.0 * self.exchange_3b(self.kp[r], dk) - 2.0 * self.exchange_3b(self.kp[p], dk)
                                + 2.0 * self.p_k_with_q(self.kp[r], dk))
                     else:
@@ -136,8 +209,7 @@ class Ueg:
         occ = self._occ()
         d = occ[:, None, :] - occ[None, :, :]
         d2 = np.einsum("pqi,pqi->pq", d, d)
-        u = self.trunc(d2)
-        d2m = np.where(d2 <= (self.k_cutoff * 2 * np.pi / self.L) ** 2 * (1 + 0.00001), 0.0, d2)   # trunc zeroes its input
+        u, d2m = self.u(d2)                       # trunc zeroes the sub-cutoff entries of its input (ueg.py:794)
         dir_e = np.sum(u ** 2 * d2m) * self.n_ele / 2 / self.Omega ** 2 * 2
         exc_e = -2 * 2 * np.einsum("pqo,pqo->", np.einsum("poi,pqi->pqo", d, d), np.einsum("pq,po->pqo", u, u)) / 2.0 / self.Omega ** 2
         return dir_e + exc_e
@@ -147,13 +219,12 @@ class Ueg:
         kp, ki = self.kp, self.kp[:no]
         dpi = kp[:, None, :] - ki[None, :, :]
         dpi2 = np.einsum("pij,pij->pi", dpi, dpi)
-        u_pi = self.trunc(dpi2)
-        kc = (self.k_cutoff * 2 * np.pi / self.L) ** 2 * (1 + 0.00001)
-        e_perl = 2.0 * self.n_ele / self.Omega ** 2 / 2 * np.sum(u_pi ** 2 * np.where(dpi2 <= kc, 0.0, dpi2), axis=1)
+        u_pi, dpi2m = self.u(dpi2)
+        e_perl = 2.0 * self.n_ele / self.Omega ** 2 / 2 * np.sum(u_pi ** 2 * dpi2m, axis=1)
         e_wave = -np.einsum("pij,pij->p", np.einsum("pik,pjk->pij", dpi, dpi), np.einsum("pi,pj->pij", u_pi, u_pi)) * 2 / self.Omega ** 2 / 2
         dij = ki[:, None, :] - ki[None, :, :]
         dij2 = np.einsum("ijk,ijk->ij", dij, dij)
-        u_ij = self.trunc(dij2)
-        e_shield = np.ones(self.n_p) * np.einsum("ij,ij->", u_ij ** 2, np.where(dij2 <= kc, 0.0, dij2)) * 2 / 2 / self.Omega ** 2
+        u_ij, dij2m = self.u(dij2)
+        e_shield = np.ones(self.n_p) * np.einsum("ij,ij->", u_ij ** 2, dij2m) * 2 / 2 / self.Omega ** 2
         e_frog = -np.einsum("ijp,ijp->p", np.einsum("ijk,pik->ijp", dij, -dpi), np.einsum("ij,pi->ijp", u_ij, u_pi)) * 4 / self.Omega ** 2 / 2
         return e_perl + e_wave + e_shield + e_frog

@@ -91,6 +91,10 @@ SIGNATURES = {
     "pymes_ccd_energy": (C.c_int, [C.c_void_p, C.c_void_p, c_double_p]),
     "pymes_ueg_eval_2b": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                     C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pymes_ueg_eval_2b_corr": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                         c_double_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pymes_ueg_eval_2b_tab": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "pymes_hf_fock_matrix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pymes_fcidump_header": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pymes_fcidump_read_host": (C.c_int, [C.c_char_p, C.c_int, c_double_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -445,25 +445,55 @@ int pymes_ccd_energy(pymes_ctx* ctx, const double* t2, double* e_out) {
     });
 }
 
+static void ueg_eval(pymes_ctx* ctx, int n_p, int n_ele, int imax, int mode, double L, double k_cutoff, double gamma,
+                     int lattice_cutoff, const int32_t* k_int, const int32_t* index_map, const double* tab_scalar,
+                     const double* tab_array, int64_t tab_len, double* V, int kind = 0, const double* params = nullptr) {
+    Engine& e = E(ctx);
+    need(k_int, "k_int"); need(index_map, "index_map"); need(V, "V");
+    if (n_p < 1 || imax < 0 || mode < 0 || mode > 3) throw pymes::Error("ueg: bad arguments");
+    if (tab_array) {       // largest |n|^2 any kernel looks up: lattice vector (<= lattice_cutoff) minus a momentum transfer (<= 2 imax)
+        const int64_t r = static_cast<int64_t>(lattice_cutoff) + 2 * imax, need_len = 3 * r * r + 1;
+        if (!tab_scalar || tab_len < need_len || tab_len > (int64_t(1) << 30)) throw pymes::Error("ueg: correlator tables must cover |n|^2 <= 3 (lattice_cutoff + 2 imax)^2");
+    }
+    const size_t m3 = size_t(2 * imax + 1) * (2 * imax + 1) * (2 * imax + 1);
+    int* kd = static_cast<int*>(dev::dmalloc(sizeof(int) * 3 * n_p));
+    int* md = static_cast<int*>(dev::dmalloc(sizeof(int) * m3));
+    try {
+        dev::memcpy_h2d(kd, k_int, sizeof(int) * 3 * n_p, e.stream);
+        dev::memcpy_h2d(md, index_map, sizeof(int) * m3, e.stream);
+        dev::UegParams p{n_p, n_ele, imax, mode, L, L * L * L, k_cutoff, gamma, lattice_cutoff};
+        p.tab_scalar = tab_scalar; p.tab_array = tab_array; p.tab_len = static_cast<int>(tab_len);
+        p.corr_kind = kind;
+        for (int i = 0; i < 4 && params; ++i) p.corr_p[i] = params[i];
+        dev::ueg_two_body(p, kd, md, V, e.stream);
+    } catch (...) {
+        dev::dfree(kd); dev::dfree(md);
+        throw;
+    }
+    dev::dfree(kd); dev::dfree(md);
+}
 int pymes_ueg_eval_2b(pymes_ctx* ctx, int n_p, int n_ele, int imax, int mode, double L, double k_cutoff, double gamma,
                       int lattice_cutoff, const int32_t* k_int, const int32_t* index_map, double* V) {
     return guarded([&] {
-        Engine& e = E(ctx);
-        need(k_int, "k_int"); need(index_map, "index_map"); need(V, "V");
-        if (n_p < 1 || imax < 0 || mode < 0 || mode > 3) throw pymes::Error("ueg: bad arguments");
-        const size_t m3 = size_t(2 * imax + 1) * (2 * imax + 1) * (2 * imax + 1);
-        int* kd = static_cast<int*>(dev::dmalloc(sizeof(int) * 3 * n_p));
-        int* md = static_cast<int*>(dev::dmalloc(sizeof(int) * m3));
-        try {
-            dev::memcpy_h2d(kd, k_int, sizeof(int) * 3 * n_p, e.stream);
-            dev::memcpy_h2d(md, index_map, sizeof(int) * m3, e.stream);
-            dev::UegParams p{n_p, n_ele, imax, mode, L, L * L * L, k_cutoff, gamma, lattice_cutoff};
-            dev::ueg_two_body(p, kd, md, V, e.stream);
-        } catch (...) {
-            dev::dfree(kd); dev::dfree(md);
-            throw;
-        }
-        dev::dfree(kd); dev::dfree(md);
+        ueg_eval(ctx, n_p, n_ele, imax, mode, L, k_cutoff, gamma, lattice_cutoff, k_int, index_map, nullptr, nullptr, 0, V);
+    });
+}
+int pymes_ueg_eval_2b_corr(pymes_ctx* ctx, int n_p, int n_ele, int imax, int mode, double L, int lattice_cutoff,
+                           int correlator, const double* params, const int32_t* k_int, const int32_t* index_map, double* V) {
+    return guarded([&] {
+        need(params, "params");
+        if (mode == 0) throw pymes::Error("ueg: mode 0 (Coulomb) has no correlator");
+        if (correlator < 1 || correlator > 6) throw pymes::Error("ueg: correlator must be 1..6 (0 = trunc: pymes_ueg_eval_2b)");
+        ueg_eval(ctx, n_p, n_ele, imax, mode, L, 0.0, 1.0, lattice_cutoff, k_int, index_map, nullptr, nullptr, 0, V, correlator, params);
+    });
+}
+int pymes_ueg_eval_2b_tab(pymes_ctx* ctx, int n_p, int n_ele, int imax, int mode, double L, int lattice_cutoff,
+                          const int32_t* k_int, const int32_t* index_map, const double* tab_scalar, const double* tab_array,
+                          int64_t tab_len, double* V) {
+    return guarded([&] {
+        need(tab_scalar, "tab_scalar"); need(tab_array, "tab_array");
+        if (mode == 0) throw pymes::Error("ueg: mode 0 (Coulomb) has no correlator");
+        ueg_eval(ctx, n_p, n_ele, imax, mode, L, 0.0, 1.0, lattice_cutoff, k_int, index_map, tab_scalar, tab_array, tab_len, V);
     });
 }
 

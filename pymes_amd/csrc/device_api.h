@@ -175,6 +175,19 @@ struct UegParams {
     double L, Omega;
     double k_cutoff, gamma; // `trunc` correlator: u(k^2) = -4 pi gamma / k^4 for k > k_cutoff * 2 pi / L
     int lattice_cutoff;     // k' lattice of sumNablaUSquare (ueg.py:581), 30 in the reference
+    // The reference's other correlators (ueg.py:740-935) evaluated in the kernels like trunc, from the same float k^2 the
+    // reference forms: corr_kind 0 trunc (k_cutoff, gamma above), 1 gaskell {mu, cut}, 2 gaskell_modified {cut},
+    // 3 coulomb {-4 pi gamma}, 4 yukawa {gamma, floor}, 5 stg {gamma^2, floor, -4 pi / gamma}, 6 smooth {kc, kc gamma,
+    // (kc gamma)^2}.  The reference calls a correlator either with a float (ueg.py:409 `d_k_vec.dot(d_k_vec)`) or with an
+    // ndarray (everything else); the two forms of gaskell / gaskell_modified differ AT the cut-off and both are kept.
+    int corr_kind = 0;
+    double corr_p[4] = {0.0, 0.0, 0.0, 0.0};
+    // A correlator of the caller's own: every argument of u is |2 pi n / L|^2 for an integer vector n, so u is handed
+    // over as HOST tables over m = |n|^2 < tab_len (tab_scalar / tab_array: the two call forms).  A jump of u exactly on
+    // a lattice shell is then resolved per shell, not per rounding of the individual k^2 as in the reference.
+    const double* tab_scalar = nullptr;
+    const double* tab_array = nullptr;
+    int tab_len = 0;
 };
 void ueg_two_body(const UegParams& prm, const int* k_int_dev, const int* index_map_dev, double* V_dev, stream_t s);
 

@@ -1343,17 +1343,44 @@ __global__ void fcidump_fill_kernel(double* __restrict__ V, const double* __rest
 struct UegK {
     int n_p, n_occ, imax, m, mode, n_ele, lat;
     double L, Omega, kc2g, gamma;
+    const double* tab_s;      // correlator tables over m = |n|^2 (device_api.h UegParams); null: evaluated in place
+    const double* tab_a;
+    int tab_len;
+    int kind;                 // 0 trunc, 1 gaskell, 2 gaskell_modified, 3 coulomb, 4 yukawa, 5 stg, 6 smooth
+    double p0, p1, p2;
 };
-__device__ __forceinline__ double ueg_u(double x, const UegK& u) {      // trunc, ueg.py:772-800
-    if (x <= u.kc2g) x = 0.0;
+// u(k^2) for k = 2 pi n / L: x is the float k^2 the reference would pass, m = |n|^2 its integer shell;
+// ARR = the reference calls the correlator with an ndarray there (else with a float)
+template <bool ARR>
+__device__ __forceinline__ double ueg_u(double x, long m, const UegK& u) {
+    if (u.tab_a) return m < u.tab_len ? (ARR ? u.tab_a[m] : u.tab_s[m]) : 0.0;
+    switch (u.kind) {
+        case 1:                                                         // gaskell, ueg.py:836-883 (p0 = mu, p1 = cut)
+            if (ARR) return x > u.p1 ? -0.0 : (x > 1e-12 ? -(u.p0 / x) : -0.0);
+            return (x < u.p1 && x > 1e-12) ? -(u.p0 / x) : -0.0;
+        case 2:                                                         // gaskell_modified, ueg.py:802-834 (p0 = cut)
+            if (ARR) return x >= u.p0 ? -((4.0 * M_PI) / (x * x)) : -0.0;
+            return (x < u.p0 && x > 1e-12) ? -0.0 : -((4.0 * M_PI) / (x * x));
+        case 3: return x > 1e-12 ? u.p0 / x : 0.0;                      // coulomb, ueg.py:905-915 (p0 = -4 pi gamma)
+        case 4: { const double b = x + u.p0; return fabs(b) > u.p1 ? (-4.0 * M_PI) / b : 0.0; }      // yukawa, :740-770
+        case 5: { const double t = x + u.p0, b = t * t; return fabs(b) > u.p1 ? u.p2 / b : 0.0; }    // stg, :917-935
+        case 6: {                                                       // smooth, ueg.py:885-903
+            if (!(x > u.p2)) return 0.0;
+            return (-4.0 * M_PI * (1.0 + erf((sqrt(x) - u.p0) / u.p1)) / 2.0) / (x * x);
+        }
+        default: break;
+    }
+    if (x <= u.kc2g) x = 0.0;                                           // trunc, ueg.py:772-800
     return x > 1e-12 ? (-4.0 * M_PI / (x * x)) * u.gamma : 0.0;
 }
 __device__ __forceinline__ double ueg_kp(int k, double L) { return ((double)(k * 2) * M_PI) / L; }   // planewave.py:15
 
 // u_mat[d] = sum_k' (k'.(k-k')) u(k'^2) u((k-k')^2) / Omega, one block per momentum transfer d  (ueg.py:581-596)
-__global__ void __launch_bounds__(256) ueg_nabla_kernel(const UegK u, const double* __restrict__ dk, double* __restrict__ out) {
+__global__ void __launch_bounds__(256) ueg_nabla_kernel(const UegK u, const double* __restrict__ dk, const int* __restrict__ dint,
+                                                        double* __restrict__ out) {
     __shared__ double sh[4];
     const double kx = dk[3 * blockIdx.x], ky = dk[3 * blockIdx.x + 1], kz = dk[3 * blockIdx.x + 2];
+    const long dx = dint[3 * blockIdx.x], dy = dint[3 * blockIdx.x + 1], dz = dint[3 * blockIdx.x + 2];
     const int w = 2 * u.lat + 1;
     const long total = (long)w * w * w;
     double s = 0.0;
@@ -1362,7 +1389,9 @@ __global__ void __launch_bounds__(256) ueg_nabla_kernel(const UegK u, const doub
         const double x1 = 2.0 * M_PI * (a - u.lat) / u.L, y1 = 2.0 * M_PI * (b - u.lat) / u.L,
                      z1 = 2.0 * M_PI * (c - u.lat) / u.L;
         const double x2 = kx - x1, y2 = ky - y1, z2 = kz - z1;
-        s += (x1 * x2 + y1 * y2 + z1 * z2) * ueg_u(x1 * x1 + y1 * y1 + z1 * z1, u) * ueg_u(x2 * x2 + y2 * y2 + z2 * z2, u);
+        const long a1 = a - u.lat, b1 = b - u.lat, c1 = c - u.lat, a2 = dx - a1, b2 = dy - b1, c2 = dz - c1;
+        s += (x1 * x2 + y1 * y2 + z1 * z2) * ueg_u<true>(x1 * x1 + y1 * y1 + z1 * z1, a1 * a1 + b1 * b1 + c1 * c1, u) *
+             ueg_u<true>(x2 * x2 + y2 * y2 + z2 * z2, a2 * a2 + b2 * b2 + c2 * c2, u);
     }
     s = block_sum(s, sh);
     if (threadIdx.x == 0) out[blockIdx.x] = s / u.Omega;
@@ -1374,31 +1403,38 @@ __global__ void ueg_effective_kernel(const UegK u, const int* __restrict__ kint,
     if (idx >= u.n_p * u.n_p) return;
     const int p = idx / u.n_p, r = idx - p * u.n_p;
     double kp[3], kr[3], dk[3];
+    long di[3], md = 0;
     for (int c = 0; c < 3; ++c) {
         kp[c] = ueg_kp(kint[3 * p + c], u.L);
         kr[c] = ueg_kp(kint[3 * r + c], u.L);
         dk[c] = kr[c] - kp[c];
+        di[c] = kint[3 * r + c] - kint[3 * p + c];
+        md += di[c] * di[c];
     }
     const double dk2 = dk[0] * dk[0] + dk[1] * dk[1] + dk[2] * dk[2];
-    const double udk = ueg_u(dk2, u);
+    const double udk_a = ueg_u<true>(dk2, md, u);      // inside contract_exchange_3_body: a 0-d array (ueg.py:536)
+    const double udk_s = ueg_u<false>(dk2, md, u);     // in the main loop: a float (ueg.py:409, :461)
     double xr = 0.0, xp = 0.0, pk = 0.0;
     for (int n = 0; n < u.n_occ; ++n) {
         double o[3];
         for (int c = 0; c < 3; ++c) o[c] = ueg_kp(kint[3 * n + c], u.L);
         double a2 = 0, ad = 0, b2 = 0, bd = 0, v12 = 0, v11 = 0;
+        long ma = 0, mb = 0, mv = 0;
         for (int c = 0; c < 3; ++c) {
             const double a = kr[c] - o[c], b = kp[c] - o[c], v1 = kr[c] - dk[c] - o[c];
             a2 += a * a; ad += a * dk[c];
             b2 += b * b; bd += b * dk[c];
             v12 += v1 * a; v11 += v1 * v1;
+            const long ai = kint[3 * r + c] - kint[3 * n + c], bi = kint[3 * p + c] - kint[3 * n + c], vi = ai - di[c];
+            ma += ai * ai; mb += bi * bi; mv += vi * vi;
         }
-        xr += ad * udk * ueg_u(a2, u);
-        xp += bd * udk * ueg_u(b2, u);
-        pk += v12 * ueg_u(v11, u) * ueg_u(a2, u);
+        xr += ad * udk_a * ueg_u<true>(a2, ma, u);
+        xp += bd * udk_a * ueg_u<true>(b2, mb, u);
+        pk += v12 * ueg_u<true>(v11, mv, u) * ueg_u<true>(a2, ma, u);
     }
     xr /= u.Omega; xp /= u.Omega; pk /= u.Omega;
     double val;
-    if (fabs(dk2) > 0.0) val = -(double)u.n_ele * dk2 * udk * udk / u.Omega + 2.0 * xr - 2.0 * xp + 2.0 * pk;
+    if (fabs(dk2) > 0.0) val = -(double)u.n_ele * dk2 * udk_s * udk_s / u.Omega + 2.0 * xr - 2.0 * xp + 2.0 * pk;
     else val = 2.0 * pk;
     E[idx] = val / u.Omega;
 }
@@ -1421,22 +1457,24 @@ __global__ void ueg_scatter_kernel(const UegK u, const int* __restrict__ kint, c
     const int s = map[loc];
     if (s < 0 || s >= u.n_p) return;
     double dk[3], dk2 = 0.0;
+    long md = 0;
     for (int c = 0; c < 3; ++c) {
         dk[c] = ueg_kp(kint[3 * r + c], u.L) - ueg_kp(kint[3 * p + c], u.L);
         dk2 += dk[c] * dk[c];
+        md += (long)d[c] * d[c];
     }
     double w = 0.0;
     if (u.mode == 0) {
         if (fabs(dk2) > 0.0) w = 4.0 * M_PI / dk2 / u.Omega;
     } else if (u.mode == 3) {
-        if (fabs(dk2) > 0.0) { const double x = ueg_u(dk2, u); w = -(double)u.n_ele * dk2 * x * x / u.Omega / u.Omega; }
+        if (fabs(dk2) > 0.0) { const double x = ueg_u<false>(dk2, md, u); w = -(double)u.n_ele * dk2 * x * x / u.Omega / u.Omega; }
     } else if (u.mode == 1) {
         const int w4 = 4 * u.imax + 1;
         const double um = umat[umat_index[((long)(d[0] + 2 * u.imax) * w4 + (d[1] + 2 * u.imax)) * w4 + d[2] + 2 * u.imax]];
         if (fabs(dk2) > 0.0) {
             double rsdk = 0.0;
             for (int c = 0; c < 3; ++c) rsdk += (ueg_kp(kint[3 * r + c], u.L) - ueg_kp(kint[3 * s + c], u.L)) * dk[c];
-            const double x = ueg_u(dk2, u);
+            const double x = ueg_u<false>(dk2, md, u);
             w = (4.0 * M_PI / dk2 + um + dk2 * x - rsdk * x) / u.Omega;
         } else {
             w = um / u.Omega;
@@ -2141,19 +2179,32 @@ void ueg_two_body(const UegParams& prm, const int* k_int_dev, const int* index_m
     u.n_ele = prm.n_ele; u.lat = prm.lattice_cutoff; u.L = prm.L; u.Omega = prm.Omega; u.gamma = prm.gamma;
     const double kc = prm.k_cutoff * 2 * M_PI / prm.L;
     u.kc2g = kc * kc * (1 + 0.00001);
+    u.tab_s = u.tab_a = nullptr;
+    u.tab_len = 0;
+    u.kind = prm.corr_kind; u.p0 = prm.corr_p[0]; u.p1 = prm.corr_p[1]; u.p2 = prm.corr_p[2];
+    if (u.kind < 0 || u.kind > 6) throw std::runtime_error("ueg: unknown correlator kind");
     const long n = prm.n_p;
+    double* tabs = nullptr;
+    if (prm.tab_array) {
+        if (!prm.tab_scalar || prm.tab_len < 1) throw std::runtime_error("ueg: both correlator tables are needed");
+        tabs = (double*)dmalloc(sizeof(double) * 2 * prm.tab_len);
+        HIP_CHECK(hipMemcpyAsync(tabs, prm.tab_scalar, sizeof(double) * prm.tab_len, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(tabs + prm.tab_len, prm.tab_array, sizeof(double) * prm.tab_len, hipMemcpyHostToDevice, st));
+        u.tab_s = tabs; u.tab_a = tabs + prm.tab_len; u.tab_len = prm.tab_len;
+    }
     HIP_CHECK(hipMemsetAsync(V_dev, 0, sizeof(double) * n * n * n * n, st));
     std::vector<int> kint(3 * n);
     HIP_CHECK(hipMemcpyAsync(kint.data(), k_int_dev, sizeof(int) * 3 * n, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     double *umat = nullptr, *E = nullptr, *dk_dev = nullptr;
-    int* uidx = nullptr;
+    int *uidx = nullptr, *dint_dev = nullptr;
     try {
         if (prm.mode == 1) {
             // distinct momentum transfers d = k_r - k_p, with the float d_k of their first (p,r) pair
             const int w4 = 4 * prm.imax + 1;
             std::vector<int> index((size_t)w4 * w4 * w4, -1);
             std::vector<double> dks;
+            std::vector<int> dints;
             for (long p = 0; p < n; ++p)
                 for (long r = 0; r < n; ++r) {
                     int d[3];
@@ -2164,6 +2215,7 @@ void ueg_two_body(const UegParams& prm, const int* k_int_dev, const int* index_m
                     int& slot = index[((size_t)(d[0] + 2 * prm.imax) * w4 + (d[1] + 2 * prm.imax)) * w4 + d[2] + 2 * prm.imax];
                     if (slot < 0) {
                         slot = (int)(dks.size() / 3);
+                        for (int c = 0; c < 3; ++c) dints.push_back(d[c]);
                         for (int c = 0; c < 3; ++c)
                             dks.push_back(((double)(kint[3 * r + c] * 2) * M_PI) / prm.L - ((double)(kint[3 * p + c] * 2) * M_PI) / prm.L);
                     }
@@ -2172,9 +2224,11 @@ void ueg_two_body(const UegParams& prm, const int* k_int_dev, const int* index_m
             umat = (double*)dmalloc(sizeof(double) * nd);
             dk_dev = (double*)dmalloc(sizeof(double) * 3 * nd);
             uidx = (int*)dmalloc(sizeof(int) * index.size());
+            dint_dev = (int*)dmalloc(sizeof(int) * 3 * nd);
+            HIP_CHECK(hipMemcpyAsync(dint_dev, dints.data(), sizeof(int) * 3 * nd, hipMemcpyHostToDevice, st));
             HIP_CHECK(hipMemcpyAsync(dk_dev, dks.data(), sizeof(double) * 3 * nd, hipMemcpyHostToDevice, st));
             HIP_CHECK(hipMemcpyAsync(uidx, index.data(), sizeof(int) * index.size(), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(ueg_nabla_kernel, dim3(nd), dim3(256), 0, st, u, dk_dev, umat);
+            hipLaunchKernelGGL(ueg_nabla_kernel, dim3(nd), dim3(256), 0, st, u, dk_dev, dint_dev, umat);
             HIP_CHECK(hipGetLastError());
         } else if (prm.mode == 2) {
             E = (double*)dmalloc(sizeof(double) * n * n);
@@ -2187,10 +2241,10 @@ void ueg_two_body(const UegParams& prm, const int* k_int_dev, const int* index_m
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(st));
     } catch (...) {
-        (void)hipFree(umat); (void)hipFree(E); (void)hipFree(dk_dev); (void)hipFree(uidx);
+        dfree(umat); dfree(E); dfree(dk_dev); dfree(uidx); dfree(dint_dev); dfree(tabs);
         throw;
     }
-    (void)hipFree(umat); (void)hipFree(E); (void)hipFree(dk_dev); (void)hipFree(uidx);
+    dfree(umat); dfree(E); dfree(dk_dev); dfree(uidx); dfree(dint_dev); dfree(tabs);
 }
 
 }  // namespace dev

@@ -3,7 +3,9 @@ two-body integrals, mean-field pieces of the three-body operator.
 
 Drop-in for the parts of ``pymes.model.ueg.UEG`` that feed the CCD/DCSD path (BASELINE config 4):
 ``init_single_basis``, ``eval_2b_integrals`` (Coulomb, ``is_only_2b``, ``is_effect_2b``,
-``is_rpa_approx`` with the ``trunc`` correlator), ``double_contractions_in_3_body``,
+``is_rpa_approx``; the reference's correlators ``trunc``, ``yukawa``, ``gaskell``, ``gaskell_modified``, ``smooth``,
+``coulomb``, ``stg`` are evaluated inside the kernels from the same float k^2 the reference forms, a callable of the
+caller's own is tabulated over the lattice shells and looked up on the device), ``double_contractions_in_3_body``,
 ``triple_contractions_in_3_body``.  The O(n_pw^3) integral evaluation — a Python triple loop with a
 (2*30+1)^3 lattice sum per (p,r) pair in the reference — runs as HIP kernels (``pymes_ueg_eval_2b``);
 the O(n_occ^2 n_pw) mean-field contractions stay on the host like the reference's.
@@ -84,12 +86,124 @@ class UEG:
         result = np.divide(-4. * np.pi, kSquare ** 2, out=np.zeros_like(kSquare), where=(kSquare > 1e-12))
         return result * self.gamma
 
+    # ---- the other correlators of the reference, with its two call forms: an ndarray argument goes through np.divide
+    # masks, a float through an if/else — the two agree except AT the cut-off of gaskell / gaskell_modified
+    @staticmethod
+    def _masked(num, den, keep):
+        den = np.asarray(den, dtype=np.float64)
+        return np.divide(num, den, out=np.zeros_like(den), where=keep)
+
+    def yukawa(self, kSquare, multiply_by_k_square=False):
+        """ueg.py:740-770: -4 pi / (k^2 + gamma), gamma in units of sqrt(rho pi / 4)."""
+        if multiply_by_k_square:
+            raise NotImplementedError("multiply_by_k_square is not used by the integral builder")
+        g0 = np.sqrt(self.n_ele / self.Omega / 4. * np.pi)
+        g = g0 if self.gamma is None else self.gamma * g0
+        floor = self.k_cutoff * (2 * np.pi / self.L) ** 2 + g if self.k_cutoff is not None else 1e-12
+        b = kSquare + g
+        return self._masked(-4. * np.pi, b, np.abs(b) > floor)
+
+    def gaskell(self, kSquare, multiply_by_k_square=False):
+        """ueg.py:836-883: -mu / k^2 below k_cutoff^2 k_F^2 (default 4 k_F^2), mu = gamma sqrt(4 pi / rho)."""
+        mu = np.sqrt(4. * np.pi / (self.n_ele / self.Omega)) * (self.gamma if self.gamma is not None else 1.)
+        kf = self.basis_fns[int(self.n_ele / 2) * 2].kp
+        cut = (self.k_cutoff ** 2 if self.k_cutoff is not None else 4.) * kf.dot(kf)
+        if not isinstance(kSquare, np.ndarray):
+            return -(mu / kSquare) if (kSquare < cut and kSquare > 1e-12) else -0.
+        res = self._masked(mu, kSquare, kSquare > 1e-12)
+        res[kSquare > cut] = 0.
+        return -res
+
+    def gaskell_modified(self, kSquare, multiply_by_k_square=False):
+        """ueg.py:802-834: -4 pi / k^4 from (k_cutoff 2 pi / L)^2 (default 2) on."""
+        cut = (self.k_cutoff * (2 * np.pi / self.L)) ** 2 if self.k_cutoff is not None else 2
+        if not isinstance(kSquare, np.ndarray):
+            if kSquare < cut and kSquare > 1e-12:
+                return -0.
+            with np.errstate(divide="ignore"):
+                return -(4 * np.pi / np.float64(kSquare) ** 2)
+        return -self._masked(4 * np.pi, kSquare ** 2, kSquare >= cut)
+
+    def smooth(self, kSquare, multiply_by_k_square=False):
+        """ueg.py:885-903: trunc with an error-function switch of relative width gamma (default 0.01)."""
+        from scipy import special
+        if self.k_cutoff is None:
+            self.k_cutoff = int(np.ceil(np.sqrt(self.cutoff)))
+        if self.gamma is None:
+            self.gamma = 0.01
+        kc = np.sqrt((self.k_cutoff * 2 * np.pi / self.L) ** 2)
+        k = np.sqrt(kSquare)
+        return self._masked(-4. * np.pi * (1. + special.erf((k - kc) / (kc * self.gamma))) / 2., np.asarray(kSquare) ** 2,
+                            kSquare > (kc * self.gamma) ** 2)
+
+    def coulomb(self, kSquare, multiply_by_k_square=False):
+        """ueg.py:905-915: -4 pi gamma / k^2."""
+        return self._masked(-4. * np.pi * (1. if self.gamma is None else self.gamma), kSquare, np.asarray(kSquare) > 1e-12)
+
+    def stg(self, kSquare, multiply_by_k_square=False):
+        """ueg.py:917-935: Slater-type geminal, -4 pi / gamma / (k^2 + gamma^2)^2, gamma default sqrt(4 pi rho)."""
+        g = np.sqrt(4. * np.pi * self.n_ele / self.Omega) if self.gamma is None else self.gamma
+        floor = (self.k_cutoff * (2 * np.pi / self.L) ** 2 + g ** 2) ** 2 if self.k_cutoff is not None else 1e-12
+        b = (kSquare + g ** 2) ** 2
+        return self._masked(-4. * np.pi / g, b, np.abs(b) > floor)
+
+    def _correlator_spec(self, correlator):
+        """(kind, params) of pymes_ueg_eval_2b_corr for the reference's named correlators bound to this model, with the
+        parameters formed by the same float expressions as the methods above; None for anything else (-> tables)."""
+        if getattr(correlator, "__self__", None) is not self:
+            return None
+        name = getattr(correlator, "__name__", "")
+        tw2 = (2 * np.pi / self.L) ** 2
+        if name == "gaskell":
+            mu = np.sqrt(4. * np.pi / (self.n_ele / self.Omega)) * (self.gamma if self.gamma is not None else 1.)
+            kf = self.basis_fns[int(self.n_ele / 2) * 2].kp
+            return 1, [mu, (self.k_cutoff ** 2 if self.k_cutoff is not None else 4.) * kf.dot(kf)]
+        if name == "gaskell_modified":
+            return 2, [(self.k_cutoff * (2 * np.pi / self.L)) ** 2 if self.k_cutoff is not None else 2.]
+        if name == "coulomb":
+            return 3, [-4. * np.pi * (1. if self.gamma is None else self.gamma)]
+        if name == "yukawa":
+            g0 = np.sqrt(self.n_ele / self.Omega / 4. * np.pi)
+            g = g0 if self.gamma is None else self.gamma * g0
+            return 4, [g, self.k_cutoff * tw2 + g if self.k_cutoff is not None else 1e-12]
+        if name == "stg":
+            g = np.sqrt(4. * np.pi * self.n_ele / self.Omega) if self.gamma is None else self.gamma
+            return 5, [g ** 2, (self.k_cutoff * tw2 + g ** 2) ** 2 if self.k_cutoff is not None else 1e-12, -4. * np.pi / g]
+        if name == "smooth":
+            kc = np.sqrt((self.k_cutoff * 2 * np.pi / self.L) ** 2)
+            return 6, [kc, kc * self.gamma, (kc * self.gamma) ** 2]
+        return None
+
+    def _correlator_tables(self, correlator, lattice_cutoff=30):
+        """u over the lattice shells m = |n|^2 (every argument the integral builder passes to the correlator is
+        |2 pi n / L|^2 for an integer n): (called with a float, called with an ndarray).  The argument of shell m is the
+        reference's own float expression kp.dot(kp) for the first vector of the shell; a correlator with a jump exactly
+        on a shell whose members round differently would be evaluated at that member's value."""
+        r = lattice_cutoff + 2 * self.imax
+        g = np.arange(-r, r + 1)
+        vec = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+        m_all = np.einsum("ni,ni->n", vec, vec)
+        m_max = 3 * r * r
+        shells, first = np.unique(m_all, return_index=True)
+        x = (2 * np.pi / self.L) ** 2 * np.arange(m_max + 1, dtype=np.float64)     # shells without a vector: never looked up
+        kp = vec[first] * 2 * np.pi / self.L
+        x[shells] = np.einsum("ni,ni->n", kp, kp)
+        with np.errstate(all="ignore"):
+            arr = np.asarray(correlator(x.copy()), dtype=np.float64)
+            try:
+                sca = np.array([float(correlator(np.float64(v))) for v in x])
+            except (TypeError, IndexError, ValueError):      # a callable written for arrays only
+                sca = arr.copy()
+        arr[~np.isfinite(arr)] = 0.0          # u(0) of a float call may divide by zero; k = 0 terms are never used
+        sca[~np.isfinite(sca)] = 0.0
+        return np.ascontiguousarray(sca), np.ascontiguousarray(arr)
+
     # ---- two-body integrals (ueg.py:265-516) on the device -----------------------------------------
     def _mode(self, correlator, flags):
         if correlator is None:
             return 0
-        if getattr(correlator, "__name__", "") != "trunc" or getattr(correlator, "__self__", None) is not self:
-            raise NotImplementedError("only the `trunc` correlator of this UEG instance runs on the HIP path")
+        if not callable(correlator):
+            raise TypeError("correlator must be a callable u(k^2)")
         on = [k for k, v in flags.items() if v]
         if on == ["is_rpa_approx"] or (flags["is_rpa_approx"]):
             return 3
@@ -113,13 +227,17 @@ class UEG:
         if is_only_non_hermi_2b or is_only_hermi_2b or is_exchange_1 or is_exchange_2 or is_exchange_3:
             raise NotImplementedError("test-only switches of the reference are not on the HIP path")
         mode = self._mode(correlator, dict(is_rpa_approx=is_rpa_approx, is_only_2b=is_only_2b, is_effect_2b=is_effect_2b))
+        is_trunc = correlator is not None and getattr(correlator, "__name__", "") == "trunc" and \
+            getattr(correlator, "__self__", None) is self
         if correlator is not None:
             self.correlator = correlator
-            self.trunc(0.0)                      # fixes k_cutoff / gamma defaults exactly like the first call would
             print_logging_info("Using TC method", level=1)
-            print_logging_info("Using correlator: ", correlator.__name__, level=1)
-            print_logging_info("k_cutoff in correlator = {:.8f}".format(self.k_cutoff), level=1)
-            print_logging_info("Gamma in correlator = {:.8f}".format(self.gamma), level=1)
+            print_logging_info("Using correlator: ", getattr(correlator, "__name__", repr(correlator)), level=1)
+            if self.k_cutoff is not None:
+                print_logging_info("k_cutoff in correlator = {:.8f}".format(self.k_cutoff), level=1)
+            if self.gamma is not None:
+                print_logging_info("Gamma in correlator = {:.8f}".format(self.gamma), level=1)
+            correlator(np.float64(1.0))          # fixes the correlator's k_cutoff / gamma defaults like its first call would
         n_p = len(self.basis_fns) // 2
         k_int = np.ascontiguousarray([self.basis_fns[2 * i].k for i in range(n_p)], dtype=np.int32)
         imap = np.ascontiguousarray(self.basis_indices_map, dtype=np.int32)
@@ -128,9 +246,21 @@ class UEG:
             ctx = Context(1, 1, device=self.device, workspace_bytes=1 << 20)
         try:
             V = ctx.empty((n_p,) * 4)
-            ctx.lib.call("pymes_ueg_eval_2b", ctx.handle, n_p, self.n_ele, self.imax, mode, float(self.L),
-                         float(self.k_cutoff or 0.0), float(self.gamma or 1.0), 30,
-                         k_int.ctypes.data_as(C.c_void_p), imap.ctypes.data_as(C.c_void_p), C.c_void_p(V.ptr))
+            if correlator is None or is_trunc:       # trunc is evaluated inside the kernels
+                ctx.lib.call("pymes_ueg_eval_2b", ctx.handle, n_p, self.n_ele, self.imax, mode, float(self.L),
+                             float(self.k_cutoff or 0.0), float(self.gamma or 1.0), 30,
+                             k_int.ctypes.data_as(C.c_void_p), imap.ctypes.data_as(C.c_void_p), C.c_void_p(V.ptr))
+            elif self._correlator_spec(correlator) is not None:       # the reference's other correlators, in the kernels
+                kind, prm = self._correlator_spec(correlator)
+                prm = (C.c_double * 4)(*(list(map(float, prm)) + [0.0] * (4 - len(prm))))
+                ctx.lib.call("pymes_ueg_eval_2b_corr", ctx.handle, n_p, self.n_ele, self.imax, mode, float(self.L), 30, kind,
+                             prm, k_int.ctypes.data_as(C.c_void_p), imap.ctypes.data_as(C.c_void_p), C.c_void_p(V.ptr))
+            else:                                    # a u(k^2) of the caller's own: tabulated over the lattice shells
+                tab_s, tab_a = self._correlator_tables(correlator, 30)
+                ctx.lib.call("pymes_ueg_eval_2b_tab", ctx.handle, n_p, self.n_ele, self.imax, mode, float(self.L), 30,
+                             k_int.ctypes.data_as(C.c_void_p), imap.ctypes.data_as(C.c_void_p),
+                             tab_s.ctypes.data_as(C.c_void_p), tab_a.ctypes.data_as(C.c_void_p), len(tab_a),
+                             C.c_void_p(V.ptr))
             if mode == 2:                        # ueg.py:509-513: symmetrise w.r.t. the electron labels
                 Vs = ctx.permute("pqrs->pqrs", V, alpha=0.5)
                 ctx.permute("qpsr->pqrs", V, out=Vs, alpha=0.5, beta=1.0)

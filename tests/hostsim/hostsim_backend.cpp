@@ -469,8 +469,24 @@ void ladder_unpack(const double* L, double* R, double beta, int no, int nv, stre
 
 // ---- UEG integrals: plain loops with the same formulas as the HIP kernels ------------------------
 namespace {
-struct UegH { int n_p, n_occ, imax, m, mode, n_ele, lat; double L, Omega, kc2g, gamma; };
-inline double u_of(double x, const UegH& u) { if (x <= u.kc2g) x = 0.0; return x > 1e-12 ? (-4.0 * M_PI / (x * x)) * u.gamma : 0.0; }
+struct UegH { int n_p, n_occ, imax, m, mode, n_ele, lat; double L, Omega, kc2g, gamma; const double* ts = nullptr; const double* ta = nullptr; long tl = 0; int kind = 0; double p0 = 0, p1 = 0, p2 = 0; };
+// m = |n|^2 of the integer vector behind x; arr: the reference passes an ndarray there (device_api.h UegParams)
+inline double u_of(double x, long m, bool arr, const UegH& u) {
+    if (u.ta) return m < u.tl ? (arr ? u.ta[m] : u.ts[m]) : 0.0;
+    switch (u.kind) {       // the reference's named correlators (device_api.h UegParams::corr_kind)
+        case 1: if (arr) return x > u.p1 ? -0.0 : (x > 1e-12 ? -(u.p0 / x) : -0.0);
+                return (x < u.p1 && x > 1e-12) ? -(u.p0 / x) : -0.0;
+        case 2: if (arr) return x >= u.p0 ? -((4.0 * M_PI) / (x * x)) : -0.0;
+                return (x < u.p0 && x > 1e-12) ? -0.0 : -((4.0 * M_PI) / (x * x));
+        case 3: return x > 1e-12 ? u.p0 / x : 0.0;
+        case 4: { const double b = x + u.p0; return std::fabs(b) > u.p1 ? (-4.0 * M_PI) / b : 0.0; }
+        case 5: { const double t = x + u.p0, b = t * t; return std::fabs(b) > u.p1 ? u.p2 / b : 0.0; }
+        case 6: return x > u.p2 ? (-4.0 * M_PI * (1.0 + std::erf((std::sqrt(x) - u.p0) / u.p1)) / 2.0) / (x * x) : 0.0;
+        default: break;
+    }
+    if (x <= u.kc2g) x = 0.0;
+    return x > 1e-12 ? (-4.0 * M_PI / (x * x)) * u.gamma : 0.0;
+}
 inline double kp_of(int k, double L) { return ((double)(k * 2) * M_PI) / L; }
 }  // namespace
 
@@ -478,13 +494,19 @@ void ueg_two_body(const UegParams& prm, const int* kint, const int* map, double*
     UegH u{prm.n_p, prm.n_ele / 2, prm.imax, 2 * prm.imax + 1, prm.mode, prm.n_ele, prm.lattice_cutoff, prm.L, prm.Omega, 0.0, prm.gamma};
     const double kc = prm.k_cutoff * 2 * M_PI / prm.L;
     u.kc2g = kc * kc * (1 + 0.00001);
+    u.ts = prm.tab_scalar; u.ta = prm.tab_array; u.tl = prm.tab_len;
+    u.kind = prm.corr_kind; u.p0 = prm.corr_p[0]; u.p1 = prm.corr_p[1]; u.p2 = prm.corr_p[2];
     const int64_t n = prm.n_p;
     std::memset(V, 0, sizeof(double) * n * n * n * n);
     std::vector<double> E(n * n, 0.0), umat(n * n, 0.0);
     for (int64_t p = 0; p < n; ++p)
         for (int64_t r = 0; r < n; ++r) {
             double kpv[3], kr[3], dk[3], dk2 = 0;
-            for (int c = 0; c < 3; ++c) { kpv[c] = kp_of(kint[3 * p + c], u.L); kr[c] = kp_of(kint[3 * r + c], u.L); dk[c] = kr[c] - kpv[c]; dk2 += dk[c] * dk[c]; }
+            long di[3], md = 0;
+            for (int c = 0; c < 3; ++c) {
+                kpv[c] = kp_of(kint[3 * p + c], u.L); kr[c] = kp_of(kint[3 * r + c], u.L); dk[c] = kr[c] - kpv[c]; dk2 += dk[c] * dk[c];
+                di[c] = kint[3 * r + c] - kint[3 * p + c]; md += di[c] * di[c];
+            }
             if (u.mode == 1) {
                 bool done = false;   // reuse the value of an earlier pair with the same integer transfer
                 for (int64_t p2 = 0; p2 <= p && !done; ++p2)
@@ -500,24 +522,30 @@ void ueg_two_body(const UegParams& prm, const int* kint, const int* map, double*
                     for (int a = 0; a < w; ++a) for (int b = 0; b < w; ++b) for (int c = 0; c < w; ++c) {
                         const double x1 = 2.0 * M_PI * (a - u.lat) / u.L, y1 = 2.0 * M_PI * (b - u.lat) / u.L, z1 = 2.0 * M_PI * (c - u.lat) / u.L;
                         const double x2 = dk[0] - x1, y2 = dk[1] - y1, z2 = dk[2] - z1;
-                        s += (x1 * x2 + y1 * y2 + z1 * z2) * u_of(x1 * x1 + y1 * y1 + z1 * z1, u) * u_of(x2 * x2 + y2 * y2 + z2 * z2, u);
+                        const long a1 = a - u.lat, b1 = b - u.lat, c1 = c - u.lat, a2 = di[0] - a1, b2 = di[1] - b1, c2 = di[2] - c1;
+                        s += (x1 * x2 + y1 * y2 + z1 * z2) * u_of(x1 * x1 + y1 * y1 + z1 * z1, a1 * a1 + b1 * b1 + c1 * c1, true, u) *
+                             u_of(x2 * x2 + y2 * y2 + z2 * z2, a2 * a2 + b2 * b2 + c2 * c2, true, u);
                     }
                     umat[p * n + r] = s / u.Omega;
                 }
             } else if (u.mode == 2) {
-                const double udk = u_of(dk2, u);
+                const double udk = u_of(dk2, md, true, u), udk_s = u_of(dk2, md, false, u);
                 double xr = 0, xp = 0, pk = 0;
                 for (int o = 0; o < u.n_occ; ++o) {
                     double a2 = 0, ad = 0, b2 = 0, bd = 0, v12 = 0, v11 = 0;
+                    long ma = 0, mb = 0, mv = 0;
                     for (int c = 0; c < 3; ++c) {
                         const double oc = kp_of(kint[3 * o + c], u.L);
                         const double a = kr[c] - oc, b = kpv[c] - oc, v1 = kr[c] - dk[c] - oc;
                         a2 += a * a; ad += a * dk[c]; b2 += b * b; bd += b * dk[c]; v12 += v1 * a; v11 += v1 * v1;
+                        const long ai = kint[3 * r + c] - kint[3 * o + c], bi = kint[3 * p + c] - kint[3 * o + c], vi = ai - di[c];
+                        ma += ai * ai; mb += bi * bi; mv += vi * vi;
                     }
-                    xr += ad * udk * u_of(a2, u); xp += bd * udk * u_of(b2, u); pk += v12 * u_of(v11, u) * u_of(a2, u);
+                    xr += ad * udk * u_of(a2, ma, true, u); xp += bd * udk * u_of(b2, mb, true, u);
+                    pk += v12 * u_of(v11, mv, true, u) * u_of(a2, ma, true, u);
                 }
                 xr /= u.Omega; xp /= u.Omega; pk /= u.Omega;
-                const double val = std::fabs(dk2) > 0.0 ? -(double)u.n_ele * dk2 * udk * udk / u.Omega + 2.0 * xr - 2.0 * xp + 2.0 * pk : 2.0 * pk;
+                const double val = std::fabs(dk2) > 0.0 ? -(double)u.n_ele * dk2 * udk_s * udk_s / u.Omega + 2.0 * xr - 2.0 * xp + 2.0 * pk : 2.0 * pk;
                 E[p * n + r] = val / u.Omega;
             }
             for (int64_t q = 0; q < n; ++q) {
@@ -529,12 +557,12 @@ void ueg_two_body(const UegParams& prm, const int* kint, const int* map, double*
                 if (s < 0 || s >= u.n_p) continue;
                 double w = 0.0;
                 if (u.mode == 0) { if (std::fabs(dk2) > 0.0) w = 4.0 * M_PI / dk2 / u.Omega; }
-                else if (u.mode == 3) { if (std::fabs(dk2) > 0.0) { const double x = u_of(dk2, u); w = -(double)u.n_ele * dk2 * x * x / u.Omega / u.Omega; } }
+                else if (u.mode == 3) { if (std::fabs(dk2) > 0.0) { const double x = u_of(dk2, md, false, u); w = -(double)u.n_ele * dk2 * x * x / u.Omega / u.Omega; } }
                 else if (u.mode == 1) {
                     if (std::fabs(dk2) > 0.0) {
                         double rsdk = 0.0;
                         for (int c = 0; c < 3; ++c) rsdk += (kr[c] - kp_of(kint[3 * s + c], u.L)) * dk[c];
-                        const double x = u_of(dk2, u);
+                        const double x = u_of(dk2, md, false, u);
                         w = (4.0 * M_PI / dk2 + umat[p * n + r] + dk2 * x - rsdk * x) / u.Omega;
                     } else w = umat[p * n + r] / u.Omega;
                 } else w = E[p * n + r];

@@ -91,6 +91,77 @@ def check_product(lib, monkeypatch, cutoffs, solve):
             assert abs(r["ccsd e"] - en["dcsd"]) < 1e-9 and np.abs(r["t1"]).max() < 1e-14
 
 
+CORR = np.load(os.path.join(GOLD, "ueg_correlators.npz"))
+CORR_MODES = (("only_2b", dict(is_only_2b=True)), ("effect_2b", dict(is_effect_2b=True)), ("rpa", dict(is_rpa_approx=True)))
+
+
+def corr_case(ci):
+    name, kc, gamma = str(CORR["cases"][ci]).split("|")
+    return name, (None if kc == "None" else float(kc)), (None if gamma == "None" else float(gamma))
+
+
+def compare_with_reference(ci, mode, V):
+    """Sampled entries, sum, absolute sum, a seeded random projection and the number of non-zeros of the reference's V."""
+    idx = CORR["sample_idx"]
+    proj = np.random.default_rng(int(CORR["proj_seed"][0])).standard_normal(V.shape)
+    sums = CORR[f"c{ci}_{mode}_sums"]
+    scale = max(1.0, np.abs(CORR[f"c{ci}_{mode}_samples"]).max())
+    assert np.abs(V.reshape(-1)[idx] - CORR[f"c{ci}_{mode}_samples"]).max() < 1e-11 * scale, (ci, mode)
+    got = np.array([V.sum(), np.abs(V).sum(), (V * proj).sum(), float(np.count_nonzero(V))])
+    assert np.abs(got[:3] - sums[:3]).max() < 1e-9 * max(1.0, sums[1]) and got[3] == sums[3], (ci, mode)
+
+
+@pytest.mark.parametrize("ci", [0, 5])
+def test_oracle_correlators_match_reference(ci):
+    """gaskell with its default cut-off (the jump sits exactly on a lattice shell: scalar and array call forms differ
+    there) and yukawa with explicit parameters; the other six cases are pinned by make_golden_ueg_correlators.py."""
+    name, kc, gamma = corr_case(ci)
+    u = Ueg(14, 1.0)
+    u.init_basis(2)
+    u.k_cutoff, u.gamma, u.correlator = kc, gamma, name
+    with np.errstate(all="ignore"):
+        for mode, _ in CORR_MODES:
+            compare_with_reference(ci, mode, u.two_body(mode))
+        assert np.abs(u.double_contractions() - CORR[f"c{ci}_double"]).max() < 1e-12
+        assert abs(u.triple_contractions() - CORR[f"c{ci}_triple"][0]) < 1e-12
+
+
+def check_correlators(lib, monkeypatch):
+    """Every correlator of the reference other than trunc (tabulated over the lattice shells, looked up on the device)
+    against the reference's integrals and mean-field pieces; trunc through the table path against its in-kernel form."""
+    from pymes_amd.model.ueg import UEG
+    monkeypatch.setattr(_lib, "_default", lib)
+    for ci in range(len(CORR["cases"])):
+        name, kc, gamma = corr_case(ci)
+        m = UEG(14, 7, 7, 1.0)
+        m.init_single_basis(2)
+        m.k_cutoff, m.gamma = kc, gamma
+        for mode, flags in CORR_MODES:
+            compare_with_reference(ci, mode, quiet(m.eval_2b_integrals, correlator=getattr(m, name), sp=0, **flags))
+        with np.errstate(all="ignore"):
+            assert np.abs(quiet(m.double_contractions_in_3_body) - CORR[f"c{ci}_double"]).max() < 1e-12
+            assert abs(quiet(m.triple_contractions_in_3_body) - CORR[f"c{ci}_triple"][0]) < 1e-12
+        prm = CORR[f"c{ci}_params"]       # defaults a correlator fills in at its first call (smooth: k_cutoff, gamma)
+        for got, want in zip((m.k_cutoff, m.gamma), prm):
+            assert (got is None and np.isnan(want)) or got == want
+    m = UEG(14, 7, 7, 1.0)
+    m.init_single_basis(2)
+    m.k_cutoff = 1.0
+    for mode, flags in CORR_MODES:
+        direct = quiet(m.eval_2b_integrals, correlator=m.trunc, sp=0, **flags)
+        tabled = quiet(m.eval_2b_integrals, correlator=lambda k2: m.trunc(k2), sp=0, **flags)
+        assert np.abs(direct - tabled).max() < 1e-12 * max(1.0, np.abs(direct).max())
+
+
+def test_correlators_host_logic(hostsim_lib, monkeypatch):
+    check_correlators(hostsim_lib, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_correlators_gpu(gpu_lib, monkeypatch):
+    check_correlators(gpu_lib, monkeypatch)
+
+
 def test_product_host_logic(hostsim_lib, monkeypatch):
     check_product(hostsim_lib, monkeypatch, (2,), solve=False)
 
