@@ -129,8 +129,10 @@ class PymesError(RuntimeError):
 class Library:
     """Loaded C-ABI library with typed entry points and error checking."""
 
-    def __init__(self, path=None, _testing_backend=None):
-        path = path or os.environ.get("PYMES_AMD_LIB", DEFAULT_PATH)
+    BACKEND = "hip-gfx950"       # the only backend the package accepts: there is no CPU fallback
+
+    def __init__(self, path=None):
+        path = path or DEFAULT_PATH
         if not os.path.exists(path):
             raise PymesError(
                 f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; "
@@ -141,9 +143,8 @@ class Library:
             fn = getattr(self.dll, name)      # AttributeError if a declared symbol is missing
             fn.restype, fn.argtypes = res, args
         self.backend = self.dll.pymes_backend().decode()
-        expected = _testing_backend or "hip-gfx950"
-        if self.backend != expected:
-            raise PymesError(f"{path} reports backend '{self.backend}', expected '{expected}'")
+        if self.backend != self.BACKEND:
+            raise PymesError(f"{path} reports backend '{self.backend}', expected '{self.BACKEND}'")
 
     def call(self, name, *args):
         rc = getattr(self.dll, name)(*args)

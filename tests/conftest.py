@@ -13,13 +13,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def hostsim_library(path):
+    """The host engine linked against the CPU stand-in for the kernels, bound with the package's own ctypes table.  The
+    product loader accepts the HIP build only; the acceptance of the simulator lives here, under tests/."""
+    from pymes_amd import _lib
+
+    class HostsimLibrary(_lib.Library):
+        BACKEND = "hostsim"
+    return HostsimLibrary(path)
+
+
 @pytest.fixture(scope="session")
 def hostsim_lib():
     """Host engine linked against the CPU stand-in for the kernels (tests/hostsim): checks HOST logic only."""
     from pymes_amd import _lib
     d = os.path.join(ROOT, "tests", "hostsim")
     subprocess.run(["make", "-s", "-C", d], check=True)
-    return _lib.Library(os.path.join(d, "_build", "libpymes_hostsim.so"), _testing_backend="hostsim")
+    return hostsim_library(os.path.join(d, "_build", "libpymes_hostsim.so"))
 
 
 @pytest.fixture(scope="session")

@@ -118,7 +118,8 @@ def _solver_worker(rank, world, port, libpath, out):
         from oracle.cases import synthetic_case
         from pymes_amd import _lib
         from pymes_amd.solver.ccsd import CCSD
-        _lib._default = _lib.Library(libpath, _testing_backend="hostsim")
+        from tests.conftest import hostsim_library
+        _lib._default = hostsim_library(libpath)
         res = {}
         for no, nv, dcsd, diis in ((3, 7, False, True), (2, 5, True, True), (3, 6, False, False)):
             f, V, B, eps = synthetic_case(no, nv, seed=3, scale=0.3)
