@@ -124,7 +124,7 @@ int pymes_ccsd_singles_residual(pymes_ctx* ctx, const double* fd_dev, const doub
 /* The same residual as a partial sum over rank `rank`'s chunk of the occupied summation index (one process per GPU; needs
  * T_abij = T_baji): the caller all-reduces the [nv][no] results (f~_ai enters on rank 0).  world = 1 is the whole residual. */
 int pymes_ccsd_singles_residual_partial(pymes_ctx* ctx, const double* fd_dev, const double* t1_dev, const double* t2_dev,
-                                        double* r1_dev, int rank, int world);
+                                        double* r1_dev, int rank, int world, uint32_t flags /* PYMES_REUSE_LAYOUTS or 0 */);
 /* CCD.get_residual, ccd.py:164-254 (and CCSD.get_doubles_residual, ccsd.py:440-456, with
  * PYMES_USE_DRESSED).  flags: */
 #define PYMES_DCD 1u          /* is_dcd / is_dcsd */
@@ -133,6 +133,9 @@ int pymes_ccsd_singles_residual_partial(pymes_ctx* ctx, const double* fd_dev, co
 #define PYMES_SYM_LADDER 8u   /* evaluate V_abcd.T in pair-packed form (1/4 of the flops); requires
                                  V_abcd = V_badc and T_cdij = T_dcji, true for every closed-shell solve that
                                  starts from MP2 or from symmetric amplitudes */
+#define PYMES_REUSE_LAYOUTS 32u /* the caller's promise that t2 has not changed since the preceding pymes_residual_slab call
+                                 on it: its pair layouts (Td, Tx, 2T - T^(ab)) are read again instead of being rebuilt
+                                 (pymes_residual_finish, pymes_ccsd_singles_residual_partial) */
 #define PYMES_SYM_RINGS 16u   /* same precondition: merge the o^3v^3 ring/exchange products through the symmetry of
                                  the pair matrices (6 products instead of 10; 4 instead of 5 for DCSD) */
 int pymes_doubles_residual(pymes_ctx* ctx, const double* f_dev, const double* t2_dev, double* r2_dev,

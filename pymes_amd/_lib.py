@@ -58,7 +58,7 @@ SIGNATURES = {
     "pymes_ccsd_dress_V_slab": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int]),
     "pymes_ccsd_singles_residual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pymes_ccsd_singles_residual_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                                      C.c_int]),
+                                                      C.c_int, C.c_uint32]),
     "pymes_doubles_residual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "pymes_ladder": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]),
     "pymes_ladder_sym": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int]),
@@ -119,6 +119,7 @@ SIGNATURES = {
 }
 
 PYMES_DCD, PYMES_USE_DRESSED, PYMES_SKIP_LADDER, PYMES_SYM_LADDER, PYMES_SYM_RINGS = 1, 2, 4, 8, 16
+PYMES_REUSE_LAYOUTS = 32
 PYMES_DRESS_ABIJ_REDUCED = 1 << 16
 
 

@@ -277,10 +277,10 @@ int pymes_ccsd_singles_residual(pymes_ctx* ctx, const double* fd, const double* 
     });
 }
 int pymes_ccsd_singles_residual_partial(pymes_ctx* ctx, const double* fd, const double* t1, const double* t2, double* r1,
-                                        int rank, int world) {
+                                        int rank, int world, uint32_t flags) {
     return guarded([&] {
         need(fd, "fd"); need(t1, "t1"); need(t2, "t2"); need(r1, "r1");
-        E(ctx).singles_residual_partial(fd, t1, t2, r1, rank, world);
+        E(ctx).singles_residual_partial(fd, t1, t2, r1, rank, world, (flags & PYMES_REUSE_LAYOUTS) != 0);
     });
 }
 int pymes_doubles_residual(pymes_ctx* ctx, const double* f, const double* t2, double* r2, uint32_t flags) {

@@ -246,7 +246,10 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
     auto pairm = [&](double* p) { return make_view(p, {ov, ov}); };
     auto slab = [&]() { return make_view(arena.alloc(ov * nc), {ov, nc}); };
     TView Vd = pairm(get_static("Vd"));
-    TView Td = pairm(arena.alloc(ov * ov)), Tx = pairm(arena.alloc(ov * ov)), Ttd = pairm(arena.alloc(ov * ov));
+    for (auto& p : lay_)
+        if (!p) p = static_cast<double*>(dev::dmalloc(sizeof(double) * ov * ov));
+    lay_t2_ = nullptr;
+    TView Td = pairm(lay_[0]), Tx = pairm(lay_[1]), Ttd = pairm(lay_[2]);
     if (dev::fused_pair_kernels_ok(no)) {
         dev::t2_layouts(t2, Td.p, Tx.p, Ttd.p, no, nv, stream);
         stats.permute_calls++;
@@ -260,6 +263,7 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
         permute(2.0, T, "abij", 0.0, t4, "aibj");
         permute(-1.0, T, "baij", 1.0, t4, "aibj");
     }
+    lay_t2_ = t2;
     TView ETd = slice(pairm(ETd_p), 0, c0, c1), ETx = slice(pairm(ETx_p), 0, c0, c1);
     auto cols = [&](const TView& m) { return slice(m, 1, c0, c1); };
     // column slabs (b,j) in [c0,c1) of the static / dressed right-hand factors, straight from the 4-index blocks:
@@ -403,13 +407,17 @@ void Engine::residual_finish(const double* f, const double* t2, const double* ET
         ladder_sym_unpack(L, r2, 1.0);                  // particle (:187) + hole (:175-186) ladders, pair-packed
     }
     // X_ac = f_ac - w sum Tt[a,d,k,l] V[l,k,d,c]  (:206-221);  Ex += X_ac T[c,b,i,j]  (:231)
-    TView Ttd = make_view(arena.alloc(o * o * v * v), {v, o, v, o});
-    permute(2.0, T, "abij", 0.0, Ttd, "aibj");
-    permute(-1.0, T, "baij", 1.0, Ttd, "aibj");
+    const bool reuse = (flags & 32u) && lay_t2_ == t2 && lay_[2];     // Tt_d of the preceding residual_slab on this t2
+    TView Ttd = make_view(reuse ? lay_[2] : arena.alloc(o * o * v * v), {v, o, v, o});
+    if (!reuse) {
+        permute(2.0, T, "abij", 0.0, Ttd, "aibj");
+        permute(-1.0, T, "baij", 1.0, Ttd, "aibj");
+    }
     TView Xvv = make_view(arena.alloc(v * v), {v, v});
     copy(Fvv, Xvv);
     contract(-w, Ttd, "akdl", make_view(get_static("Vk"), {o, v, o, v}), "kdlc", 1.0, Xvv, "ac");
-    TView Exn = make_view(Ttd.p, {v, v, o, o});      // Ttd is dead after X_ac: reuse its storage
+    // a private Tt_d is dead after X_ac and lends its storage to Exn; the kept one must survive
+    TView Exn = make_view(reuse ? arena.alloc(o * o * v * v) : Ttd.p, {v, v, o, o});
     contract(1.0, Xvv, "ac", T, "cbij", 0.0, Exn, "abij");
     if (amp_side) {
         if (!QK) throw Error("residual_finish: QK buffer missing");
@@ -1010,7 +1018,8 @@ void Engine::singles_residual(const double* fd, const double* t1, const double* 
 // the v x o partial results are all-reduced (80 KB at (50,200)); the dressed-Fock term enters on rank 0.  With
 // T_abij = T_baji, Tt'[a,b,i,j] = 2 T_abij - T_abji is symmetric as an (a,i) x (b,j) matrix, so one permuted piece
 // Tq[a,j,b,k] (j in the chunk) serves ccsd.py:432, :435 and :436; P1[j,b,c,i] = Tt'[b,c,i,j] serves :433 and :434.
-void Engine::singles_residual_partial(const double* fd, const double* t1, const double* t2, double* r1, int rank, int world) {
+void Engine::singles_residual_partial(const double* fd, const double* t1, const double* t2, double* r1, int rank, int world,
+                                      bool reuse_layouts) {
     const int64_t o = no, v = nv, nn = n;
     if (world < 1 || rank < 0 || rank >= world) throw Error("singles_residual_partial: bad rank/world");
     const int64_t c = (o + world - 1) / world, j0 = std::min<int64_t>(rank * c, o), j1 = std::min<int64_t>(j0 + c, o);
@@ -1024,16 +1033,27 @@ void Engine::singles_residual_partial(const double* fd, const double* t1, const 
     else zero(R);
     if (nj <= 0) return;
     ArenaScope scope(arena);
-    TView Tq = make_view(arena.alloc(v * nj * v * o), {v, nj, v, o});                        // Tq[a,j,b,k], j in the chunk
-    TView P1 = make_view(arena.alloc(nj * v * v * o), {nj, v, v, o});                        // P1[j,b,c,i]
-    permute(2.0, slice(T, 2, j0, j1), "abjk", 0.0, Tq, "ajbk");
-    permute(-1.0, slice(T, 3, j0, j1), "abkj", 1.0, Tq, "ajbk");
-    permute(2.0, slice(T, 3, j0, j1), "bcij", 0.0, P1, "jbci");
-    permute(-1.0, slice(T, 2, j0, j1), "bcji", 1.0, P1, "jbci");
+    TView Tq, P1;
+    const char* lp1 = "jbci";
+    if (reuse_layouts && lay_t2_ == t2 && lay_[2]) {
+        // Tt'[a,b,j,k] = Tt_d[(a,j),(b,k)] (exchange-symmetric T), and Tt_d is a symmetric matrix: both operands are
+        // strided views of the layout residual_slab has just built — no transposition at all
+        TView Ttd = make_view(lay_[2], {v, o, v, o});
+        Tq = slice(Ttd, 1, j0, j1);                                                          // [a, j in chunk, b, k]
+        P1 = slice(Ttd, 1, j0, j1);                                                          // read as P1[c,j,b,i]
+        lp1 = "cjbi";
+    } else {
+        Tq = make_view(arena.alloc(v * nj * v * o), {v, nj, v, o});                          // Tq[a,j,b,k], j in the chunk
+        P1 = make_view(arena.alloc(nj * v * v * o), {nj, v, v, o});                          // P1[j,b,c,i]
+        permute(2.0, slice(T, 2, j0, j1), "abjk", 0.0, Tq, "ajbk");
+        permute(-1.0, slice(T, 3, j0, j1), "abkj", 1.0, Tq, "ajbk");
+        permute(2.0, slice(T, 3, j0, j1), "bcij", 0.0, P1, "jbci");
+        permute(-1.0, slice(T, 2, j0, j1), "bcji", 1.0, P1, "jbci");
+    }
     contract(1.0, Tq, "bjai", slice(Dov, 0, j0, j1), "jb", 1.0, R, "ai");                    // :432 (Tt' symmetric)
-    contract(1.0, slice(block(P_aibc), 1, j0, j1), "ajbc", P1, "jbci", 1.0, R, "ai");        // :433
+    contract(1.0, slice(block(P_aibc), 1, j0, j1), "ajbc", P1, lp1, 1.0, R, "ai");           // :433
     TView S2 = make_view(arena.alloc(o * o), {o, o});
-    contract(1.0, slice(make_view(get_static("Vjbck"), {o, v, v, o}), 0, j0, j1), "jbck", P1, "jbci", 0.0, S2, "ki");
+    contract(1.0, slice(make_view(get_static("Vjbck"), {o, v, v, o}), 0, j0, j1), "jbck", P1, lp1, 0.0, S2, "ki");
     contract(-1.0, t, "ak", S2, "ki", 1.0, R, "ai");                                         // :434
     contract(-1.0, Tq, "ajbk", slice(block(P_ijka), 0, j0, j1), "jkib", 1.0, R, "ai");       // :435
     TView S4 = make_view(arena.alloc(v * v), {v, v});

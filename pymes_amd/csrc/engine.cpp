@@ -119,6 +119,7 @@ Engine::~Engine() {
         dev::stream_sync(stream);
         for (auto g : graphs_) dev::graph_destroy(g);
         for (void* p : user_allocs_) dev::dfree(p);
+        for (auto& p : lay_) dev::dfree(p);
         for (auto& p : V_) dev::dfree(p);
         for (auto& p : Vd_) dev::dfree(p);
         for (auto& kv : static_) dev::dfree(kv.second);

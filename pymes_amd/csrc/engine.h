@@ -138,7 +138,10 @@ class Engine {
     void dress_V(const double* t1, uint32_t mask, const int64_t* cut = nullptr);
     void singles_residual(const double* fd, const double* t1, const double* t2, double* r1);  // ccsd.py:423-438
     // the same as a partial sum over this rank's chunk of the occupied summation index (exchange-symmetric T2), see cc.cpp
-    void singles_residual_partial(const double* fd, const double* t1, const double* t2, double* r1, int rank, int world);
+    // reuse_layouts: the pair layouts that the preceding residual_slab built from this very t2 (content unchanged since) are
+    // read in place of freshly permuted copies — the caller's promise (flag PYMES_REUSE_LAYOUTS)
+    void singles_residual_partial(const double* fd, const double* t1, const double* t2, double* r1, int rank, int world,
+                                  bool reuse_layouts = false);
     // ccd.py:164-254; flags: bit0 = DCD/DCSD, bit1 = use dressed blocks, bit2 = skip ladder,
     // bit3 = pair-packed ladder (T and V exchange-symmetric)
     void doubles_residual(const double* f, const double* t2, double* r2, unsigned flags);
@@ -188,6 +191,10 @@ class Engine {
     int64_t splitk_ws_doubles() const { return splitk_doubles_; }
 
   private:
+    // pair layouts Td, Tx, Tt_d of the amplitudes (cc.cpp), kept between residual_slab and the calls of the same iteration
+    // that read them again (singles residual, residual_finish): persistent buffers, valid for the t2 pointer recorded
+    double* lay_[3] = {nullptr, nullptr, nullptr};
+    const double* lay_t2_ = nullptr;
     dev::stream_t own_stream_ = nullptr;
     std::set<void*> user_allocs_;
     std::set<dev::graph_t> graphs_;

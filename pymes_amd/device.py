@@ -286,10 +286,12 @@ class Context:
                       C.c_void_p(t2.ptr), C.c_void_p(out.ptr))
         return out
 
-    def singles_residual_partial(self, fd, t1, t2, out, rank, world):
-        """This rank's K-sharded share of the singles residual (exchange-symmetric T2; the caller all-reduces)."""
+    def singles_residual_partial(self, fd, t1, t2, out, rank, world, reuse_layouts=False):
+        """This rank's K-sharded share of the singles residual (exchange-symmetric T2; the caller all-reduces).
+        ``reuse_layouts``: t2 is unchanged since the preceding ``residual_slab`` call on it (its pair layouts are read)."""
         self.lib.call("pymes_ccsd_singles_residual_partial", self.handle, C.c_void_p(fd.ptr), C.c_void_p(t1.ptr),
-                      C.c_void_p(t2.ptr), C.c_void_p(out.ptr), int(rank), int(world))
+                      C.c_void_p(t2.ptr), C.c_void_p(out.ptr), int(rank), int(world),
+                      _lib.PYMES_REUSE_LAYOUTS if reuse_layouts else 0)
         return out
 
     def doubles_residual(self, f, t2, out, is_dcd=False, dressed=False, skip_ladder=False, sym_ladder=False,
@@ -333,10 +335,11 @@ class Context:
                       _lib.PYMES_DCD if is_dcd else 0)
         return P
 
-    def residual_finish(self, f, t2, ETd, ETx, L, out, is_dcd=False, dressed=False, t1=None, QK=None):
+    def residual_finish(self, f, t2, ETd, ETx, L, out, is_dcd=False, dressed=False, t1=None, QK=None, reuse_layouts=False):
         self.lib.call("pymes_residual_finish", self.handle, C.c_void_p(f.ptr), C.c_void_p(t2.ptr), C.c_void_p(ETd.ptr),
                       C.c_void_p(ETx.ptr), C.c_void_p(L.ptr if L is not None else 0), C.c_void_p(out.ptr),
-                      self._flags(is_dcd, dressed, False, True, True), C.c_void_p(t1.ptr if t1 is not None else 0),
+                      self._flags(is_dcd, dressed, False, True, True) | (_lib.PYMES_REUSE_LAYOUTS if reuse_layouts else 0),
+                      C.c_void_p(t1.ptr if t1 is not None else 0),
                       C.c_void_p(QK.ptr if QK is not None else 0))
         return out
 

@@ -142,9 +142,10 @@ class CCSD(ccd.CCD):
             ctx.dress_V(t1, ("klij", "iajb", "iabj"))                                 # :165
             ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], 0, 1, is_dcd=self.is_dcd, dressed=True, t1=t1,
                               QK=st["QK"])                                            # :171
-            ctx.singles_residual(st["fd"], t1, t2, r1)                                # :167
+            # both read the pair layouts residual_slab has just built from this t2 (no transpositions of their own)
+            ctx.singles_residual_partial(st["fd"], t1, t2, r1, 0, 1, reuse_layouts=True)      # :167
             ctx.residual_finish(st["fd"], t2, st["ETd"], st["ETx"], st["L"], r2, is_dcd=self.is_dcd, dressed=True,
-                                t1=t1, QK=st["QK"])
+                                t1=t1, QK=st["QK"], reuse_layouts=True)
         else:
             # general path (amplitudes or integrals without the exchange symmetry): explicitly dressed blocks
             ctx.singles_residual(st["fd"], t1, t2, r1)                                # :167
@@ -216,7 +217,7 @@ class CCSD(ccd.CCD):
                 if st["pairs"]:
                     pending.append(pdist.allreduce_tensor_start(st["Xvv_t"], ctx))
             # :167 as a partial sum over this rank's chunk of the occupied summation index, all-reduced (80 KB)
-            ctx.singles_residual_partial(st["fd"], t1, t2, r1, rank, world)
+            ctx.singles_residual_partial(st["fd"], t1, t2, r1, rank, world, reuse_layouts=True)
             pending.append(pdist.allreduce_tensor_start(st["R1_t"], ctx))
             for work in pending:
                 work.wait()
@@ -224,7 +225,7 @@ class CCSD(ccd.CCD):
                 return self._pair_sharded_tail(st, r1)
             r2 = ctx.pool_get(t2.shape)
             ctx.residual_finish(st["fd"], t2, st["ETd"], st["ETx"], st["L"], r2, is_dcd=self.is_dcd, dressed=True,
-                                t1=t1, QK=st["QK"])
+                                t1=t1, QK=st["QK"], reuse_layouts=True)
         else:
             # general path (user amplitudes without the exchange symmetry): explicitly dressed blocks
             r2 = ctx.pool_get(t2.shape)

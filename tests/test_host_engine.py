@@ -209,10 +209,12 @@ def sharded_residual_check(lib, cases, worlds, tol):
                 Xref = fd_ref[no:, no:] - (0.5 if dcd else 1.0) * np.einsum("adkl,lkdc->ac", Tt, Vb["ijab"])
                 assert np.abs(Xsum - Xref).max() < 1e-12
                 # singles residual (ccsd.py:423-438) as K-sharded partial sums over the occupied summation index
-                Rsum = np.zeros((nv, no))
-                for rank in range(world):
-                    Rsum += ctx.singles_residual_partial(dF, dT1, dT2, ctx.empty((nv, no)), rank, world).get()
-                assert np.abs(Rsum - oc.singles_residual(no, fd_ref, t1, t2, Vb)).max() < 1e-12
+                for reuse in (False, True):       # True: read the pair layouts residual_slab left behind for this t2
+                    Rsum = np.zeros((nv, no))
+                    for rank in range(world):
+                        Rsum += ctx.singles_residual_partial(dF, dT1, dT2, ctx.empty((nv, no)), rank, world,
+                                                             reuse_layouts=reuse).get()
+                    assert np.abs(Rsum - oc.singles_residual(no, fd_ref, t1, t2, Vb)).max() < 1e-12, reuse
                 dXvv = ctx.array(Xsum)
                 if not lib.dll.pymes_backend().decode().startswith("hip") and no > 3:
                     continue            # the host simulator declares the fused pair kernels available for no <= 3 only
