@@ -222,7 +222,9 @@ int pymes_cc_update(pymes_ctx* ctx, double* t_dev, double* dt_dev, const double*
 int pymes_cc_update_to(pymes_ctx* ctx, double* t_out_dev, double* dt_dev, const double* t_in_dev, const double* r_dev,
                        double level_shift, double delta, int rank);
 /* ccsd.py:458-466 (ccd.py:256-262 when f_dev and t1_dev are NULL) and the norms of ccsd.py:196-197 in ONE pass over
- * T2: out = {one-body, direct, exchange, |t2|^2, |dt2|^2} (dt2_dev may be NULL); one host synchronisation */
+ * T2: out[6] = {one-body, direct, exchange, |t2|^2, |dt2|^2, |t1|^2} (dt2_dev may be NULL); one host synchronisation.
+ * |t1|^2 == 0 exactly (the MP2 start; every iteration of a momentum-conserving system such as the UEG) lets the caller take
+ * the T1-free form of the residual: exp(-T1) H exp(T1) = H then, no dressing at all (pymes_amd/solver/ccsd.py). */
 int pymes_energy_norms(pymes_ctx* ctx, const double* f_dev, const double* t1_dev, const double* t2_dev,
                        const double* dt2_dev, double* out_host);
 /* CCSD.get_energy, ccsd.py:458-466: e_out = {one-body, direct, exchange}; f is the UNDRESSED Fock */

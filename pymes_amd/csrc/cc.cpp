@@ -1078,18 +1078,19 @@ void Engine::cc_update_to(double* t_out, double* dt, const double* t_in, const d
     dev::cc_update_to(t_out, dt, t_in, r, eps_o, eps_v, shift, delta, no, nv, rank, stream);
 }
 
-void Engine::energy_norms(const double* f, const double* t1, const double* t2, const double* dt2, double out[5]) {
-    double r[5];
+void Engine::energy_norms(const double* f, const double* t1, const double* t2, const double* dt2, double out[6]) {
+    double r[6];
     dev::energy_norms(f, t1, t2, get_static("Edir"), get_static("Eex"), dt2, no, nv, r, stream);
     out[0] = 2.0 * r[0];      // ccsd.py:465
     out[1] = 2.0 * r[1];      // :463 / ccd.py:260
     out[2] = -1.0 * r[2];     // :464 / ccd.py:261
     out[3] = r[3];
     out[4] = r[4];
+    out[5] = r[5];
 }
 
 void Engine::ccsd_energy(const double* f, const double* t1, const double* t2, double out[3]) {
-    double r[5];
+    double r[6];
     energy_norms(f, t1, t2, nullptr, r);
     out[0] = r[0];
     out[1] = r[1];
@@ -1097,7 +1098,7 @@ void Engine::ccsd_energy(const double* f, const double* t1, const double* t2, do
 }
 
 void Engine::ccd_energy(const double* t2, double out[2]) {
-    double r[5];
+    double r[6];
     energy_norms(nullptr, nullptr, t2, nullptr, r);
     out[0] = r[1];
     out[1] = r[2];

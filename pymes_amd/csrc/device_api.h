@@ -92,10 +92,10 @@ void dots(int npairs, const double* const* x, const double* const* y, const int6
 // ccsd.py:458-466 and the norms of ccsd.py:196-197 in one pass over T2 (tau = t2 + t1 t1 formed on the fly):
 //   out[0] = sum f_ov[i,a] t1[a,i]   (f is the [n,n] Fock matrix on the device)
 //   out[1] = sum tau Edir,  out[2] = sum tau Eex   (Edir = V_ijab as [a,b,i,j], Eex = V_ijba as [a,b,i,j])
-//   out[3] = sum t2^2,  out[4] = sum dt2^2  (dt2 may be null: 0)
-// t1 / f may be null (CCD: out[0] = 0, tau = t2).  Result on host (synchronises the stream).
+//   out[3] = sum t2^2,  out[4] = sum dt2^2  (dt2 may be null: 0),  out[5] = sum t1^2
+// t1 / f may be null (CCD: out[0] = out[5] = 0, tau = t2).  Result on host (synchronises the stream).
 void energy_norms(const double* f, const double* t1, const double* t2, const double* Edir, const double* Eex,
-                  const double* dt2, int no, int nv, double out_host[5], stream_t s);
+                  const double* dt2, int no, int nv, double out_host[6], stream_t s);
 // max |A[p,q,r,s] - B[q,p,s,r]| and max |A| for A [d0,d1,d2,d3], B [d1,d0,d3,d2] (electron-exchange partner; B may be
 // A itself when d0 == d1 and d2 == d3).  Result on host (synchronises the stream).
 void exchange_asymmetry(const double* A, const double* B, const int64_t d[4], double out_host[2], stream_t s);

@@ -181,8 +181,8 @@ class Engine {
     void ccsd_energy(const double* f, const double* t1, const double* t2, double out[3]);     // ccsd.py:458-466
     void ccd_energy(const double* t2, double out[2]);                                         // ccd.py:256-262
     // energies (ccsd.py:458-466 / ccd.py:256-262 when f, t1 are null) and the squared norms of t2 and dt2
-    // (ccsd.py:196-197) in one pass: out = {one-body, direct, exchange, |t2|^2, |dt2|^2}
-    void energy_norms(const double* f, const double* t1, const double* t2, const double* dt2, double out[5]);
+    // (ccsd.py:196-197) in one pass: out = {one-body, direct, exchange, |t2|^2, |dt2|^2, |t1|^2}
+    void energy_norms(const double* f, const double* t1, const double* t2, const double* dt2, double out[6]);
     void invalidate_static();
 
     double* eps_o = nullptr;

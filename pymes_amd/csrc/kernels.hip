@@ -868,7 +868,7 @@ __global__ void __launch_bounds__(256) energy_norms_kernel(const double* __restr
                                                            const double* __restrict__ Eex, const double* __restrict__ dt2,
                                                            int no, int nv, long total, double* __restrict__ partial) {
     __shared__ double sh[4];
-    double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s0 = 0.0;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s0 = 0.0, s5 = 0.0;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const double x = t2[idx];
         double tau = x;
@@ -889,12 +889,15 @@ __global__ void __launch_bounds__(256) energy_norms_kernel(const double* __restr
         const long n = no + nv, ov = (long)no * nv;
         for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < ov; e += (long)gridDim.x * blockDim.x) {
             const long a = e / no, i = e - a * no;
-            s0 += f[i * n + no + a] * t1[e];
+            const double y = t1[e];
+            s0 += f[i * n + no + a] * y;
+            s5 += y * y;
         }
     }
     const double r0 = block_sum(s0, sh), r1 = block_sum(s1, sh), r2 = block_sum(s2, sh), r3 = block_sum(s3, sh),
-                 r4 = block_sum(s4, sh);
+                 r4 = block_sum(s4, sh), r5 = block_sum(s5, sh);
     if (threadIdx.x == 0) {
+        partial[5 * kDotBlocks + blockIdx.x] = r5;
         partial[0 * kDotBlocks + blockIdx.x] = r0;
         partial[1 * kDotBlocks + blockIdx.x] = r1;
         partial[2 * kDotBlocks + blockIdx.x] = r2;
@@ -1959,7 +1962,7 @@ void dots(int npairs, const double* const* x, const double* const* y, const int6
 }
 
 void energy_norms(const double* f, const double* t1, const double* t2, const double* Edir, const double* Eex,
-                  const double* dt2, int no, int nv, double out_host[5], stream_t s) {
+                  const double* dt2, int no, int nv, double out_host[6], stream_t s) {
     hipStream_t st = (hipStream_t)s;
     const int dv = current_device();
     ensure_dot_ws(dv);
@@ -1969,11 +1972,11 @@ void energy_norms(const double* f, const double* t1, const double* t2, const dou
                        g_dot_ws[dv]);
     HIP_CHECK(hipGetLastError());
     double* out_dev = g_dot_ws[dv] + 16 * kDotBlocks;
-    hipLaunchKernelGGL(dots_stage2_kernel, dim3(5), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);
+    hipLaunchKernelGGL(dots_stage2_kernel, dim3(6), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipMemcpyAsync(g_dot_host[dv], out_dev, sizeof(double) * 5, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(g_dot_host[dv], out_dev, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    for (int i = 0; i < 5; ++i) out_host[i] = g_dot_host[dv][i];
+    for (int i = 0; i < 6; ++i) out_host[i] = g_dot_host[dv][i];
 }
 
 void exchange_asymmetry(const double* A, const double* B, const int64_t d[4], double out_host[2], stream_t s) {

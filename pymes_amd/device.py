@@ -415,8 +415,8 @@ class Context:
                       C.c_void_p(r.ptr), float(level_shift), float(delta), len(t_in.shape))
 
     def energy_norms(self, f, t1, t2, dt2=None):
-        """(one-body, direct, exchange, |t2|^2, |dt2|^2) in one pass and one synchronisation; f/t1 None for CCD."""
-        out = (C.c_double * 5)()
+        """(one-body, direct, exchange, |t2|^2, |dt2|^2, |t1|^2) in one pass and one synchronisation; f/t1 None for CCD."""
+        out = (C.c_double * 6)()
         self.lib.call("pymes_energy_norms", self.handle, C.c_void_p(f.ptr if f is not None else 0),
                       C.c_void_p(t1.ptr if t1 is not None else 0), C.c_void_p(t2.ptr),
                       C.c_void_p(dt2.ptr if dt2 is not None else 0), out)

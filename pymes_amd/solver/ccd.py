@@ -14,27 +14,33 @@ from pymes_amd.log import print_logging_info
 from pymes_amd.mixer import diis
 
 
-def run_replayable(ctx, st, body):
+def run_replayable(ctx, st, body, key="residual"):
     """Run ``body`` (a callable that only ENQUEUES kernels on fixed buffers: the residual part of a solver's loop body)
     — eagerly the first time (lazy set-up work: cached permutations, packed integrals), then recorded once as a launch
-    graph and replayed.  Small problems are launch-bound (about 130 kernels per CCSD iteration); at benchmark sizes the
-    graph changes nothing.  Timing of individual GEMMs with events (``prof_enable``) needs the eager form."""
-    if st.get("graph") is not None and not ctx.profiling:
-        ctx.graph_launch(st["graph"])
+    graph and replayed.  ``key`` names the variant of the body (a solver may alternate between several, each with its own
+    graph).  Per-GEMM event timing (``prof_enable``) needs the eager form.  Measured: replay does not
+    shorten an iteration, the device executes the same latency-bound kernels either way — kept because it costs nothing
+    and frees the host."""
+    graphs, passes = st.setdefault("graphs", {}), st.setdefault("eager_passes_of", {})
+    g = graphs.get(key)
+    if g is not None and not ctx.profiling:
+        ctx.graph_launch(g)
         return
-    if st.get("graph_ok") and st["eager_passes"] >= 1 and st.get("graph") is None and not ctx.profiling:
+    if st.get("graph_ok") and passes.get(key, 0) >= 1 and g is None and not ctx.profiling:
         try:
             ctx.graph_begin()
             body()
-            st["graph"] = ctx.graph_end()
+            graphs[key] = ctx.graph_end()
         except PymesError:
             ctx.graph_abort()
             st["graph_ok"] = False       # something in the body cannot be recorded: stay eager
         else:
-            ctx.graph_launch(st["graph"])
+            st["graph"] = graphs[key]
+            ctx.graph_launch(graphs[key])
             return
     body()
-    st["eager_passes"] += 1
+    passes[key] = passes.get(key, 0) + 1
+    st["eager_passes"] = st.get("eager_passes", 0) + 1
 
 
 class CCD:
@@ -124,7 +130,7 @@ class CCD:
                     first = False
                     if self.is_diis:
                         self.mixer.mix([dt2], [t2n], release=ctx.pool_put, out=[t2])   # :126-127
-                    _, e_dir_ccd, e_ex_ccd, nt2, nr2 = ctx.energy_norms(None, None, t2, dt2)   # :132 + norms, one pass
+                    _, e_dir_ccd, e_ex_ccd, nt2, nr2, _ = ctx.energy_norms(None, None, t2, dt2)   # :132 + norms, one pass
                     nt, nr = np.sqrt(nt2), np.sqrt(nr2)
                 e_ccd = e_dir_ccd + e_ex_ccd
                 dE = e_ccd - e_last

@@ -122,6 +122,8 @@ class CCSD(ccd.CCD):
             if not self.is_diis:
                 st["dt1"], st["dt2"] = ctx.pool_get(t1.shape), ctx.pool_get(t2.shape)
             st["graph"], st["eager_passes"] = None, 0
+            # T1 starts at zero (MP2) unless the caller brought amplitudes
+            st["t1_zero"] = amps is None and not os.environ.get("PYMES_NO_T1_SHORTCUT")
             st["graph_ok"] = ctx.graphs_supported() and not os.environ.get("PYMES_NO_GRAPH")
         return st
 
@@ -134,6 +136,13 @@ class CCSD(ccd.CCD):
         """ccsd.py:161-171: dressed Fock, dressed V blocks, R1, R2 from the fixed T1/T2 buffers into the fixed residual
         buffers.  Only enqueues kernels (no host read-back), hence replayable as a launch graph."""
         ctx, t1, t2, r1, r2 = st["ctx"], st["t1"], st["t2"], st["r1"], st["r2"]
+        if st["sym"] and st["t1_zero"]:
+            # T1 = 0 exactly (the MP2 start; every iteration of a momentum-conserving system such as the UEG):
+            # exp(-T1) H exp(T1) = H, so :163 and :165 are identities — the residuals straight from the undressed f and V
+            ctx.residual_slab(st["f"], t2, st["ETd"], st["ETx"], st["L"], 0, 1, is_dcd=self.is_dcd)          # :171
+            ctx.singles_residual_partial(st["f"], t1, t2, r1, 0, 1, reuse_layouts=True)                      # :167
+            ctx.residual_finish(st["f"], t2, st["ETd"], st["ETx"], st["L"], r2, is_dcd=self.is_dcd, reuse_layouts=True)
+            return
         ctx.dress_fock(st["f"], t1, st["fd"])                                         # :163
         if st["sym"]:
             # Symmetry-reduced form = the one-rank case of the sharded form: V_abcd is never dressed, its T1 dressing
@@ -155,7 +164,7 @@ class CCSD(ccd.CCD):
     def _iterate_single(self, st):
         ctx, t1, t2, r1, r2 = st["ctx"], st["t1"], st["t2"], st["r1"], st["r2"]
         shift = st["level_shift"]
-        ccd.run_replayable(ctx, st, lambda: self._residuals(st))
+        ccd.run_replayable(ctx, st, lambda: self._residuals(st), key="t1=0" if st["t1_zero"] else "t1")
         if self.is_diis:
             # the DIIS history keeps the updated amplitudes (:176-183); the extrapolation goes back into the fixed buffers
             t1n, t2n, dt1, dt2 = (ctx.pool_get(t1.shape), ctx.pool_get(t2.shape), ctx.pool_get(t1.shape),
@@ -172,7 +181,8 @@ class CCSD(ccd.CCD):
         st["first"] = False
         if self.is_diis:
             self.mixer.mix([dt1, dt2], [t1n, t2n], release=ctx.pool_put, out=[t1, t2])    # :181-183
-        e1, ed, ex, nt2, nr2 = ctx.energy_norms(st["f"], t1, t2, dt2)                 # :189-197, one pass
+        e1, ed, ex, nt2, nr2, n1 = ctx.energy_norms(st["f"], t1, t2, dt2)             # :189-197, one pass
+        st["t1_zero"] = bool(n1 == 0.0) and not os.environ.get("PYMES_NO_T1_SHORTCUT")
         return e1, ed, ex, np.sqrt(nt2), np.sqrt(nr2)
 
     # ---- one process per GPU ----------------------------------------------------------------------------------------

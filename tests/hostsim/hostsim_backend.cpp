@@ -141,8 +141,8 @@ void dots(int npairs, const double* const* x, const double* const* y, const int6
 }
 
 void energy_norms(const double* f, const double* t1, const double* t2, const double* Edir, const double* Eex,
-                  const double* dt2, int no, int nv, double out[5], stream_t) {
-    for (int q = 0; q < 5; ++q) out[q] = 0.0;
+                  const double* dt2, int no, int nv, double out[6], stream_t) {
+    for (int q = 0; q < 6; ++q) out[q] = 0.0;
     int64_t idx = 0;
     for (int a = 0; a < nv; ++a)
         for (int b = 0; b < nv; ++b)
@@ -156,7 +156,10 @@ void energy_norms(const double* f, const double* t1, const double* t2, const dou
                 }
     if (t1 && f)
         for (int a = 0; a < nv; ++a)
-            for (int i = 0; i < no; ++i) out[0] += f[(int64_t)i * (no + nv) + no + a] * t1[a * no + i];
+            for (int i = 0; i < no; ++i) {
+                out[0] += f[(int64_t)i * (no + nv) + no + a] * t1[a * no + i];
+                out[5] += t1[a * no + i] * t1[a * no + i];
+            }
 }
 
 void exchange_asymmetry(const double* A, const double* B, const int64_t d[4], double out[2], stream_t) {

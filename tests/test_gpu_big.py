@@ -109,7 +109,7 @@ def test_c2_functions_vs_oracle(gpu_lib, symmetric):
 
 
 def test_c3_slab_vs_oracle(gpu_lib):
-    """Config 3 (50,200): after two real CCSD iterations (T2 of realistic size; T1 perturbed to 0.02) the dressed Fock, R1 and the rows
+    """Config 3 (50,200): after three real CCSD iterations (T2 of realistic size; T1 perturbed to 0.02) the dressed Fock, R1 and the rows
     a in [37,39) and [199,200) of R2 (CCSD and DCSD) of the path bench.py times, against the slab oracle; R2 again from
     three simulated ranks (slab + finish, and the pair-sharded tail)."""
     from pymes_amd.model import synthetic
@@ -122,9 +122,9 @@ def test_c3_slab_vs_oracle(gpu_lib):
         solver = ccsd.CCSD(no, is_diis=False)
         with contextlib.redirect_stdout(io.StringIO()):
             st = solver.setup(f, ints)
-            for _ in range(2):
+            for _ in range(3):       # T1 = 0 form (eager), full form eager, full form recorded + replayed
                 solver.iterate(st)
-        assert st["sym"] and st["graph"] is not None        # second pass was recorded and replayed
+        assert st["sym"] and st["graph"] is not None and not st["t1_zero"]
         dT1, dT2, dF = st["t1"], st["t2"], st["f"]
         # the synthetic Fock matrix is diagonal, so the iterated T1 stays tiny (1e-4): add singles of realistic size,
         # otherwise the T1 dressing (ccsd.py:226-421) would hardly be exercised

@@ -118,12 +118,13 @@ def test_fused_reductions(sim):
     ctx = Context(no, nv)
     ctx.set_V_pqrs(V)
     Vb = oc.split_blocks(no, V)
-    e1, ed, ex, nt, nr = ctx.energy_norms(ctx.array(f), ctx.array(t1), ctx.array(t2), ctx.array(dt2))
+    e1, ed, ex, nt, nr, n1 = ctx.energy_norms(ctx.array(f), ctx.array(t1), ctx.array(t2), ctx.array(dt2))
+    assert abs(n1 - (t1 ** 2).sum()) < 1e-13
     ref = oc.ccsd_energy(f[:no, no:], t1, t2, Vb["ijab"])
     assert np.allclose([e1, ed, ex], ref, rtol=0, atol=1e-13)
     assert abs(nt - (t2 ** 2).sum()) < 1e-12 and abs(nr - (dt2 ** 2).sum()) < 1e-12
-    _, ed, ex, _, nr0 = ctx.energy_norms(None, None, ctx.array(t2))
-    assert np.allclose([ed, ex], oc.ccd_energy(t2, Vb["ijab"]), rtol=0, atol=1e-13) and nr0 == 0.0
+    _, ed, ex, _, nr0, n10 = ctx.energy_norms(None, None, ctx.array(t2))
+    assert np.allclose([ed, ex], oc.ccd_energy(t2, Vb["ijab"]), rtol=0, atol=1e-13) and nr0 == 0.0 and n10 == 0.0
     # pairs of different lengths in one call
     a, b = rng.standard_normal(7), rng.standard_normal(1000)
     out = ctx.dots([ctx.array(a), ctx.array(b)], [ctx.array(a), ctx.array(b)])
@@ -156,3 +157,25 @@ def test_amps_are_updated_in_place(sim, diis):
     if not diis:
         assert np.array_equal(a2, res["t2"]) and np.array_equal(a1, res["t1"])
     assert abs(res["ccsd e"] - ref["e"]) < 1e-12
+
+
+def test_t1_zero_shortcut_is_exact(sim, monkeypatch):
+    """T1 = 0 exactly lets the solver skip every T1 dressing (exp(-T1) H exp(T1) = H): same energies and amplitudes as
+    the full path, on a momentum-conserving-like problem (T1 stays zero: diagonal blocks only) and on a generic one
+    (T1 = 0 in the first iteration only)."""
+    no, nv = 3, 5
+    f, V, _, _ = synthetic_case(no, nv, seed=4, scale=0.3)
+    for dcsd in (False, True):
+        res = {}
+        for off in ("", "1"):
+            if off:
+                monkeypatch.setenv("PYMES_NO_T1_SHORTCUT", "1")
+            else:
+                monkeypatch.delenv("PYMES_NO_T1_SHORTCUT", raising=False)
+            s = CCSD(no, delta_e=1e-11, is_dcsd=dcsd)
+            res[off] = (quiet(s.solve, f, V), s.iterations)
+        assert res[""][1] == res["1"][1]
+        assert abs(res[""][0]["ccsd e"] - res["1"][0]["ccsd e"]) < 1e-13
+        assert np.abs(res[""][0]["t2"] - res["1"][0]["t2"]).max() < 1e-12
+        ref = oc.ccsd_solve(no, f, V, is_dcsd=dcsd, delta_e=1e-11)
+        assert abs(res[""][0]["ccsd e"] - ref["e"]) < 1e-11 and res[""][1] == ref["iterations"]
