@@ -19,6 +19,29 @@ class DIIS:
         self.amplitude_list = []
         self.last_coefficients = None
 
+    # -- history across contexts: the reference's mixer outlives a solve() call ---------
+    def park(self, ctx):
+        """Move the stored vectors that live in ``ctx`` to host memory (the context is about to be destroyed)."""
+        for lst in (self.error_list, self.amplitude_list):
+            for vec in lst:
+                for k, arr in enumerate(vec):
+                    if not isinstance(arr, np.ndarray) and arr.ctx is ctx:
+                        vec[k] = arr.get()
+
+    def _unpark(self, ctx, like):
+        """Bring parked vectors into ``ctx``; a history of a different problem size cannot be mixed with (the reference
+        would fail in its einsum there) and is dropped."""
+        shapes = [a.shape for a in like]
+        for lst in (self.error_list, self.amplitude_list):
+            for vec in lst:
+                if any(isinstance(a, np.ndarray) for a in vec):
+                    if [tuple(a.shape) for a in vec] != [tuple(sh) for sh in shapes]:
+                        self.error_list, self.amplitude_list, self.L = [], [], np.zeros((1, 1))
+                        return
+                    for k, arr in enumerate(vec):
+                        if isinstance(arr, np.ndarray):
+                            vec[k] = ctx.pool_get(arr.shape).set(arr)
+
     # -- host part: identical arithmetic to the reference ------------------------------
     def _update_L(self, overlaps, was_full):
         m = len(overlaps)
@@ -53,6 +76,7 @@ class DIIS:
         ``allreduce`` (a callable on a small numpy vector), the extrapolation itself is local.  ``out``: arrays to
         write the extrapolated amplitudes into instead of fresh ones (the solvers keep T1/T2 in fixed buffers so that
         their loop body can be replayed as a launch graph); they must not be among the stored vectors."""
+        self._unpark(error[0].ctx, error)
         was_full = len(self.error_list) == self.dim_space
         if was_full:
             old_e, old_a = self.error_list.pop(0), self.amplitude_list.pop(0)

@@ -153,7 +153,7 @@ class CCD:
             self.iterations = iteration
             return result
         finally:
-            if self.is_diis:     # stored vectors belong to this context
+            if self.is_diis and own:     # stored vectors belong to this context, which is about to close
                 self._drop_mixer_history_of(ctx)
             if own:
                 ctx.close()
@@ -218,12 +218,12 @@ class CCD:
         return nt, nr
 
     def _drop_mixer_history_of(self, ctx):
-        """The reference's mixer keeps growing across solve() calls on one instance
-        (diis history is never reset); device history cannot outlive its context, so it is
-        cleared when the context it lives in is closed."""
-        m = self.mixer
-        if any(arr.ctx is ctx for vec in m.error_list for arr in vec):
-            m.error_list, m.amplitude_list, m.L = [], [], np.zeros((1, 1))
+        """The reference's mixer is never reset: a second solve() on the same instance starts from the history of the
+        first (diis.py:16-112 keeps its lists, ccsd.py:42 creates the mixer once).  Device vectors cannot outlive their
+        context, so when the context of this solve is about to close its stored vectors are parked on the host (at most
+        2 x dim_space amplitude sets); the mixer moves them into the next solve's context at its first call.  A history
+        that lives in a caller-owned context (``DeviceIntegrals``) stays where it is."""
+        self.mixer.park(ctx)
 
     def get_residual(self, t_fock_pq, t_T_abij, t_V_klij, t_V_ijab, t_V_abij, t_V_iajb, t_V_iabj, t_V_abcd):
         """ccd.py:164-254 with host arrays in and a host array out (the reference's call form)."""

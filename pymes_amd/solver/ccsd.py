@@ -372,7 +372,7 @@ class CCSD(ccd.CCD):
             return {"ccsd e": e_ccsd, "t1": self.t_T_ai, "t2": self.t_T_abij, "hole e": st["eps_i"],
                     "particle e": st["eps_a"], "dE": dE}
         finally:
-            if self.is_diis:
+            if self.is_diis and own:     # the history lives in this context, which is about to close: park it on the host
                 self._drop_mixer_history_of(ctx)
             if own:
                 ctx.close()

@@ -179,3 +179,28 @@ def test_t1_zero_shortcut_is_exact(sim, monkeypatch):
         assert np.abs(res[""][0]["t2"] - res["1"][0]["t2"]).max() < 1e-12
         ref = oc.ccsd_solve(no, f, V, is_dcsd=dcsd, delta_e=1e-11)
         assert abs(res[""][0]["ccsd e"] - ref["e"]) < 1e-11 and res[""][1] == ref["iterations"]
+
+
+def test_mixer_history_survives_solve_calls(sim):
+    """ccsd.py:42 / diis.py:16-112: the mixer of a solver instance is never reset, a second solve() starts from the
+    history of the first.  The oracle restates that with a shared mixer object."""
+    no, nv = 3, 5
+    f, V, _, _ = synthetic_case(no, nv, seed=6, scale=0.3)
+    f2, V2, _, _ = synthetic_case(no, nv, seed=7, scale=0.3)
+    mixer = oc.Diis(6)
+    ref1 = oc.ccsd_solve(no, f, V, delta_e=1e-6, mixer=mixer)
+    ref2 = oc.ccsd_solve(no, f2, V2, delta_e=1e-10, mixer=mixer)
+    fresh = oc.ccsd_solve(no, f2, V2, delta_e=1e-10)
+    s = CCSD(no, delta_e=1e-6)
+    r1 = quiet(s.solve, f, V)
+    assert abs(r1["ccsd e"] - ref1["e"]) < 1e-12
+    s.delta_e = 1e-10
+    r2 = quiet(s.solve, f2, V2)
+    assert abs(r2["ccsd e"] - ref2["e"]) < 1e-11 and s.iterations == ref2["iterations"]
+    # (upstream's never-reset history steers the second solve somewhere else entirely — a stale subspace of another
+    # problem; the point here is only that the drop-in does what the reference does)
+    assert abs(ref2["e"] - fresh["e"]) > 1e-6
+    # a different problem size drops the parked history instead of mixing incompatible vectors
+    f3, V3, _, _ = synthetic_case(no, nv + 1, seed=8, scale=0.3)
+    r3 = quiet(s.solve, f3, V3)
+    assert abs(r3["ccsd e"] - oc.ccsd_solve(no, f3, V3, delta_e=1e-10)["e"]) < 1e-9

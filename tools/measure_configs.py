@@ -22,8 +22,9 @@ def quiet(fn, *a, **k):
         return fn(*a, **k)
 
 
-def timed(fn, sync, reps):
-    fn()
+def timed(fn, sync, reps, warm=3):
+    for _ in range(warm):       # lazy set-up (cached permutations, packed integrals) and launch-graph recording
+        fn()
     sync()
     t0 = time.perf_counter()
     for _ in range(reps):
