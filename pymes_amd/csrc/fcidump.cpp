@@ -2,6 +2,10 @@
 #include "fcidump.h"
 
 #include <algorithm>
+#include <charconv>
+#include <functional>
+#include <thread>
+#include <system_error>
 #include <cctype>
 #include <cerrno>
 #include <cmath>
@@ -62,7 +66,11 @@ void parse_fcidump(const std::string& path, FcidumpFile& out, bool header_only) 
     {
         char chunk[1 << 16];
         size_t got;
-        while ((got = std::fread(chunk, 1, sizeof chunk, fp)) > 0) buf.append(chunk, got);
+        // the header sits in the first lines: a header-only query (to size the context) does not read the body
+        while ((got = std::fread(chunk, 1, sizeof chunk, fp)) > 0) {
+            buf.append(chunk, got);
+            if (header_only && buf.size() >= (size_t(1) << 20)) break;
+        }
         std::fclose(fp);
     }
     // ---- header ---------------------------------------------------------------------------------------------
@@ -87,63 +95,134 @@ void parse_fcidump(const std::string& path, FcidumpFile& out, bool header_only) 
     out.eps.assign(static_cast<size_t>(n), 0.0);
     out.h.assign(static_cast<size_t>(n) * n, 0.0);
     // ---- body: "value i j k l", exactly five fields per line (fcidump.py:124-161) ----------------------------------
-    const char* p = buf.c_str() + pos;
+    // The body is cut into pieces at line boundaries and the pieces are parsed by worker threads (the reference walks
+    // the file in one Python loop); records are joined in file order, so "a later line overwrites an earlier one" holds
+    // exactly as in the sequential reader, and the first malformed line of the FILE is the one reported.
+    const char* body = buf.c_str() + pos;
     const char* end = buf.c_str() + buf.size();
-    long lineno = 0;
-    while (p < end) {
-        const char* eol = static_cast<const char*>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
-        if (!eol) eol = end;
-        ++lineno;
-        // tokenise
-        const char* tok[6];
-        size_t len[6];
-        int nt = 0;
-        const char* q = p;
-        while (q < eol && nt < 6) {
-            while (q < eol && std::isspace(static_cast<unsigned char>(*q))) ++q;
-            if (q >= eol) break;
-            tok[nt] = q;
-            while (q < eol && !std::isspace(static_cast<unsigned char>(*q))) ++q;
-            len[nt] = static_cast<size_t>(q - tok[nt]);
-            ++nt;
+    struct OneBody { long p, q, r, s; double v; };
+    struct Piece {
+        const char* b; const char* e;
+        std::vector<double> val;
+        std::vector<int32_t> pqrs;
+        std::vector<OneBody> small;      // core energy / orbital energies / h_pq records, in order
+        long lines = 0, bad_line = 0;    // bad_line: 1-based within the piece
+        std::string error;
+    };
+    const size_t nbytes = static_cast<size_t>(end - body);
+    unsigned nthreads = 1;
+    if (nbytes > (size_t(4) << 20)) {
+        nthreads = std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+        if (const char* e = std::getenv("PYMES_PARSE_THREADS")) nthreads = std::max(1, std::atoi(e));
+    }
+    std::vector<Piece> pieces(nthreads);
+    {
+        const char* cur = body;
+        for (unsigned t = 0; t < nthreads; ++t) {
+            const char* stop = (t + 1 == nthreads) ? end : body + nbytes * (t + 1) / nthreads;
+            if (stop < cur) stop = cur;
+            if (t + 1 < nthreads && stop < end) {          // move to the end of the line the cut fell into
+                const char* nl = static_cast<const char*>(std::memchr(stop, '\n', static_cast<size_t>(end - stop)));
+                stop = nl ? nl + 1 : end;
+            }
+            pieces[t].b = cur;
+            pieces[t].e = stop;
+            cur = stop;
         }
-        if (nt != 5) {
-            throw std::runtime_error("malformed FCIDUMP line " + std::to_string(lineno) + ": expected 5 fields, got " +
-                                     std::to_string(nt == 6 ? 6 : nt) + (nt == 0 ? " (blank line)" : ""));
+    }
+    auto parse_piece = [n](Piece& pc) {
+        const char* p = pc.b;
+        pc.val.reserve(static_cast<size_t>(pc.e - pc.b) / 40 + 16);
+        pc.pqrs.reserve(4 * (static_cast<size_t>(pc.e - pc.b) / 40 + 16));
+        auto fail = [&](const std::string& what) { pc.bad_line = pc.lines; pc.error = what; };
+        while (p < pc.e) {
+            const char* eol = static_cast<const char*>(std::memchr(p, '\n', static_cast<size_t>(pc.e - p)));
+            if (!eol) eol = pc.e;
+            ++pc.lines;
+            const char* tok[6];
+            size_t len[6];
+            int nt = 0;
+            const char* q = p;
+            while (q < eol && nt < 6) {
+                while (q < eol && std::isspace(static_cast<unsigned char>(*q))) ++q;
+                if (q >= eol) break;
+                tok[nt] = q;
+                while (q < eol && !std::isspace(static_cast<unsigned char>(*q))) ++q;
+                len[nt] = static_cast<size_t>(q - tok[nt]);
+                ++nt;
+            }
+            if (nt != 5) {
+                fail(": expected 5 fields, got " + std::to_string(nt == 6 ? 6 : nt) + (nt == 0 ? " (blank line)" : ""));
+                return;
+            }
+            // value: std::from_chars (correctly rounded, no locale, no copy); anything it does not take whole goes to strtod
+            double v = 0.0;
+            {
+                const char* f0 = tok[0] + (tok[0][0] == '+' ? 1 : 0);
+                auto res = std::from_chars(f0, tok[0] + len[0], v);
+                if (res.ec != std::errc() || res.ptr != tok[0] + len[0]) {
+                    char tmp[64];
+                    if (len[0] >= sizeof tmp) { fail(": bad value"); return; }
+                    std::memcpy(tmp, tok[0], len[0]);
+                    tmp[len[0]] = 0;
+                    char* stop = nullptr;
+                    v = std::strtod(tmp, &stop);
+                    if (stop == tmp || *stop) { fail(": bad value"); return; }
+                }
+            }
+            long id[4];
+            for (int i = 0; i < 4; ++i) {
+                const char* f0 = tok[i + 1] + (tok[i + 1][0] == '+' ? 1 : 0);
+                auto res = std::from_chars(f0, tok[i + 1] + len[i + 1], id[i], 10);
+                if (res.ec != std::errc() || res.ptr != tok[i + 1] + len[i + 1]) { fail(": bad index"); return; }
+            }
+            p = eol + 1;
+            if (std::fabs(v) < 1e-19) continue;                                        // :138
+            const long pp = id[0] - 1, rr = id[1] - 1, qq = id[2] - 1, ss = id[3] - 1;   // i j k l -> p r q s (:130)
+            if (pp >= n || qq >= n || rr >= n || ss >= n) { fail(": orbital index beyond NORB"); return; }
+            if (pp >= 0 && qq >= 0 && rr >= 0 && ss >= 0) {
+                pc.val.push_back(v);
+                pc.pqrs.push_back(static_cast<int32_t>(pp));
+                pc.pqrs.push_back(static_cast<int32_t>(qq));
+                pc.pqrs.push_back(static_cast<int32_t>(rr));
+                pc.pqrs.push_back(static_cast<int32_t>(ss));
+            } else {
+                pc.small.push_back({pp, qq, rr, ss, v});
+            }
         }
-        char tmp[64];
-        auto field = [&](int i) {
-            if (len[i] >= sizeof tmp) throw std::runtime_error("malformed FCIDUMP line " + std::to_string(lineno));
-            std::memcpy(tmp, tok[i], len[i]);
-            tmp[len[i]] = 0;
-            return tmp;
-        };
-        char* stop = nullptr;
-        const double v = std::strtod(field(0), &stop);
-        if (stop == tmp || *stop) throw std::runtime_error("malformed FCIDUMP line " + std::to_string(lineno) + ": bad value");
-        long id[4];
-        for (int i = 0; i < 4; ++i) {
-            id[i] = std::strtol(field(i + 1), &stop, 10);
-            if (stop == tmp || *stop) throw std::runtime_error("malformed FCIDUMP line " + std::to_string(lineno) + ": bad index");
+    };
+    if (nthreads == 1) {
+        parse_piece(pieces[0]);
+    } else {
+        std::vector<std::thread> workers;
+        for (unsigned t = 0; t < nthreads; ++t) workers.emplace_back(parse_piece, std::ref(pieces[t]));
+        for (auto& w : workers) w.join();
+    }
+    long before = 0;
+    size_t total = 0;
+    for (auto& pc : pieces) {
+        if (!pc.error.empty()) {
+            const std::string where = std::to_string(before + pc.bad_line);
+            if (pc.error.find("beyond NORB") != std::string::npos) throw std::runtime_error("FCIDUMP line " + where + pc.error);
+            throw std::runtime_error("malformed FCIDUMP line " + where + pc.error);
         }
-        p = eol + 1;
-        if (std::fabs(v) < 1e-19) continue;                                        // :138
-        const long pp = id[0] - 1, rr = id[1] - 1, qq = id[2] - 1, ss = id[3] - 1;   // i j k l -> p r q s (:130)
-        if (pp >= n || qq >= n || rr >= n || ss >= n)
-            throw std::runtime_error("FCIDUMP line " + std::to_string(lineno) + ": orbital index beyond NORB");
-        if (pp >= 0 && qq >= 0 && rr >= 0 && ss >= 0) {
-            out.val.push_back(v);
-            out.pqrs.push_back(static_cast<int32_t>(pp));
-            out.pqrs.push_back(static_cast<int32_t>(qq));
-            out.pqrs.push_back(static_cast<int32_t>(rr));
-            out.pqrs.push_back(static_cast<int32_t>(ss));
-        } else if (pp < 0 && qq < 0 && rr < 0 && ss < 0) {
-            out.e_core = v;                                                        // :151-152
-        } else if (pp >= 0 && qq < 0 && rr < 0 && ss < 0) {
-            out.eps[pp] = v;                                                       // :154-155
-        } else if (pp >= 0 && rr >= 0 && qq < 0 && ss < 0) {
-            out.h[static_cast<size_t>(pp) * n + rr] = v;                           // :157-160
-            out.h[static_cast<size_t>(rr) * n + pp] = v;
+        before += pc.lines;
+        total += pc.val.size();
+    }
+    out.val.reserve(total);
+    out.pqrs.reserve(4 * total);
+    for (auto& pc : pieces) {
+        out.val.insert(out.val.end(), pc.val.begin(), pc.val.end());
+        out.pqrs.insert(out.pqrs.end(), pc.pqrs.begin(), pc.pqrs.end());
+        for (const auto& r : pc.small) {
+            if (r.p < 0 && r.q < 0 && r.r < 0 && r.s < 0) {
+                out.e_core = r.v;                                                  // :151-152
+            } else if (r.p >= 0 && r.q < 0 && r.r < 0 && r.s < 0) {
+                out.eps[r.p] = r.v;                                                // :154-155
+            } else if (r.p >= 0 && r.r >= 0 && r.q < 0 && r.s < 0) {
+                out.h[static_cast<size_t>(r.p) * n + r.r] = r.v;                   // :157-160
+                out.h[static_cast<size_t>(r.r) * n + r.p] = r.v;
+            }
         }
     }
 }

@@ -62,16 +62,20 @@ def main():
     lines = write_text(txt, n, ne, B, h, 0.5)
     size = os.path.getsize(txt)
     base = {"norb": n, "two_electron_lines": lines, "text_bytes": size, "host_cores": os.cpu_count()}
-    t0 = time.perf_counter()
-    mine = quiet(fcidump.read, txt)
-    t_native = time.perf_counter() - t0
+    t_native = 1e30
+    for _ in range(3):          # best of three (page cache, first touch of the 150-MB result)
+        t0 = time.perf_counter()
+        mine = quiet(fcidump.read, txt)
+        t_native = min(t_native, time.perf_counter() - t0)
     print(json.dumps(dict(base, what="native text parser + host fill (pymes_fcidump_read_host)", seconds=t_native,
                           lines_per_s=lines / t_native, MB_per_s=size / t_native / 1e6)), flush=True)
     if args.reference:
         from pymes.util import fcidump as ref_fcidump
-        t0 = time.perf_counter()
-        ref = quiet(ref_fcidump.read, txt)
-        t_ref = time.perf_counter() - t0
+        t_ref = 1e30
+        for _ in range(2):
+            t0 = time.perf_counter()
+            ref = quiet(ref_fcidump.read, txt)
+            t_ref = min(t_ref, time.perf_counter() - t0)
         same = all(np.array_equal(a, b) for a, b in zip(mine[3:], ref[3:])) and mine[:3] == tuple(ref[:3])
         print(json.dumps(dict(base, what="reference fcidump.read (per-line Python loop, fcidump.py:124-161)", seconds=t_ref,
                               lines_per_s=lines / t_ref, MB_per_s=size / t_ref / 1e6, identical_to_native=bool(same),
