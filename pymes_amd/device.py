@@ -61,9 +61,11 @@ class DeviceArray:
         return DeviceArray(self.ctx, self.ptr, shape, owned=False, keepalive=self)
 
     def free(self):
-        # a closed context has released every buffer it handed out (pymes_ctx_destroy)
+        # a closed context has released every buffer it handed out (pymes_ctx_destroy); a live one keeps the buffer for
+        # the next array of that size (Context._recycle): all work of a context is ordered on one stream, so reuse needs
+        # neither hipFree nor the stream synchronisation that goes with it
         if self._owned and self.ptr and self.ctx.handle:
-            self.ctx.lib.call("pymes_free", self.ctx.handle, C.c_void_p(self.ptr))
+            self.ctx._recycle(self.ptr, self.size)
         self.ptr, self._owned = 0, False
 
     def __del__(self):
@@ -84,6 +86,7 @@ class Context:
         self.handle = h
         self._allocator = allocator      # optional callable(n_doubles) -> (ptr, keepalive), e.g. torch-backed
         self._pool = {}
+        self._spare, self._spare_bytes = {}, 0      # released buffers by size, for reuse (see _recycle)
         self.profiling = False           # per-GEMM event timing is on (launch graphs are bypassed then)
         if stream is not None:
             self.set_stream(stream)
@@ -93,6 +96,7 @@ class Context:
         """Destroys the context; every buffer it handed out (pool, arrays still referenced by the caller) is released
         with it, DeviceArrays of a closed context are dead."""
         self._pool = {}
+        self._spare, self._spare_bytes = {}, 0
         if self.handle:
             self.lib.call("pymes_ctx_destroy", self.handle)
             self.handle = None
@@ -115,15 +119,39 @@ class Context:
         return cap.value, high.value
 
     # ---- arrays -------------------------------------------------------------------
+    RECYCLE_BYTES = 16 << 30       # at most this much released memory is kept for reuse; beyond it buffers are freed
+
     def empty(self, shape):
         shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
         n = int(np.prod(shape)) if shape else 1
         if self._allocator is not None:
             ptr, keep = self._allocator(n)
             return DeviceArray(self, ptr, shape, owned=False, keepalive=keep)
+        spare = self._spare.get(max(n, 1))
+        if spare:
+            self._spare_bytes -= 8 * max(n, 1)
+            return DeviceArray(self, spare.pop(), shape)
         p = C.c_void_p()
         self.lib.call("pymes_malloc", self.handle, 8 * max(n, 1), C.byref(p))
         return DeviceArray(self, p.value, shape)
+
+    def _recycle(self, ptr, n):
+        """A released owned buffer: kept for the next ``empty`` of the same size (the drivers written in Python — EOM sigma,
+        Davidson, UEG — create and drop dozens of temporaries per step; hipMalloc / hipFree + a stream synchronisation for
+        each of them cost more than the kernels in between)."""
+        n = max(int(n), 1)
+        if self._spare_bytes + 8 * n > self.RECYCLE_BYTES:
+            self.lib.call("pymes_free", self.handle, C.c_void_p(ptr))
+            return
+        self._spare.setdefault(n, []).append(ptr)
+        self._spare_bytes += 8 * n
+
+    def trim(self):
+        """Return the recycled buffers to the device allocator."""
+        for ptrs in self._spare.values():
+            for ptr in ptrs:
+                self.lib.call("pymes_free", self.handle, C.c_void_p(ptr))
+        self._spare, self._spare_bytes = {}, 0
 
     def zeros(self, shape):
         return self.empty(shape).zero_()
