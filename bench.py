@@ -60,7 +60,8 @@ def pmc_traffic_per_launch(no, nv, world, kernel_prefix):
     for line in open(path):
         if line.startswith("# kernels.hip sha256="):
             recorded = line.split("=", 1)[1].strip()
-        if line.startswith('"' + kernel_prefix):
+        # <false, false> (both operands M/N-contiguous) occurs only in the integral build from the factors, not in an iteration
+        if line.startswith('"' + kernel_prefix) and "<false, false>" not in line:
             name, n, fetch, write = line.rsplit(",", 3)
             launches += int(n)
             gbytes += int(n) * (float(fetch) + float(write))
