@@ -300,8 +300,23 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_kernel(const GemmK g) {
     const double* Cin = g.Cin + z1 * g.c_b1 + z2 * g.c_b2;
     const long ldc = g.ldc;
     const double alpha = g.alpha, beta = g.beta;
+    // beta term: Cin may be C itself, so the compiler cannot move a load above an earlier store — read the FN x 4 values of
+    // one row of MFMA tiles first (independent loads, all in flight together), then combine and store.  An element-wise
+    // load -> store chain costs one memory latency per element: the whole time of a short-K accumulating product.
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
+        double cin[FN][4];
+        if (beta != 0.0) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * WM + i * 16 + l4 + 4 * r;
+                    cin[j][r] = (m < g.M && n < g.N) ? Cin[(long)m * ldc + n] : 0.0;
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             const int n = n0 + wn * WN + j * 16 + l15;
@@ -309,10 +324,9 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_kernel(const GemmK g) {
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm * WM + i * 16 + l4 + 4 * r;
                 if (m < g.M && n < g.N) {
-                    const long off = (long)m * ldc + n;
                     double v = alpha * acc[i][j][r];
-                    if (beta != 0.0) v += beta * Cin[off];
-                    C[off] = v;
+                    if (beta != 0.0) v += beta * cin[j][r];
+                    C[(long)m * ldc + n] = v;
                 }
             }
         }
@@ -561,6 +575,8 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_glds_kernel(const GemmK g) 
     const double* Cin = g.Cin + z1 * g.c_b1 + z2 * g.c_b2;
     const long ldc = g.ldc;
     const double alpha = g.alpha, beta = g.beta;
+    // (element-wise beta term on purpose: this kernel runs long k loops, where the epilogue does not count, and batching the
+    // Cin loads as dgemm_kernel does pushes two of the four variants to the 256-VGPR limit and costs 3 % in the k loop)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -906,22 +922,37 @@ __global__ void __launch_bounds__(256) energy_norms_kernel(const double* __restr
     }
 }
 
-// out[0] = max |A[p,q,r,s] - B[q,p,s,r]|, out[1] = max |A| as bit patterns (non-negative doubles order like integers)
+// out[0] = max |A[p,q,r,s] - B[q,p,s,r]|, out[1] = max |A| as bit patterns (non-negative doubles order like integers).
+// One block per (p, q, 32 x 32 tile of (r,s)): the partner tile B[q,p,s0:,r0:] is read row-wise and transposed through LDS,
+// so both tensors stream with full lines (the V_abcd check is a 12.8-GB read at (50,200)).
 __global__ void __launch_bounds__(256) exchange_asym_kernel(const double* __restrict__ A, const double* __restrict__ B,
-                                                            long d0, long d1, long d2, long d3, long total,
+                                                            long d0, long d1, long d2, long d3, int tr, int ts,
                                                             unsigned long long* __restrict__ out) {
+    __shared__ double tile[32][33];
     __shared__ double sh[8];
+    long bid = blockIdx.x;
+    const int t_s = (int)(bid % ts); bid /= ts;
+    const int t_r = (int)(bid % tr); bid /= tr;
+    const long q = bid % d1, p = bid / d1;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long r0 = (long)t_r * 32, s0 = (long)t_s * 32;
+    const double* __restrict__ Apq = A + (p * d1 + q) * d2 * d3;      // [d2][d3]
+    const double* __restrict__ Bqp = B + (q * d0 + p) * d3 * d2;      // [d3][d2]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {       // tile[s - s0][r - r0] = B[q,p,s,r], rows of r contiguous
+        const long sg = s0 + ty + 8 * j, rg = r0 + tx;
+        if (sg < d3 && rg < d2) tile[ty + 8 * j][tx] = Bqp[sg * d2 + rg];
+    }
+    __syncthreads();
     double m1 = 0.0, m2 = 0.0;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        long r = idx;
-        const long s_ = r % d3; r /= d3;
-        const long r_ = r % d2; r /= d2;
-        const long q = r % d1;
-        const long p = r / d1;
-        const double a = A[idx], b = B[((q * d0 + p) * d3 + s_) * d2 + r_];
-        const double d = fabs(a - b);
-        m1 = d > m1 || d != d ? d : m1;           // a NaN difference must not pass as symmetric
-        m2 = fmax(m2, fabs(a));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long rg = r0 + ty + 8 * j, sg = s0 + tx;
+        if (rg < d2 && sg < d3) {
+            const double a = Apq[rg * d3 + sg], d = fabs(a - tile[tx][ty + 8 * j]);
+            m1 = (d > m1 || d != d) ? d : m1;          // a NaN difference must not pass as symmetric
+            m2 = fmax(m2, fabs(a));
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -1988,8 +2019,10 @@ void exchange_asymmetry(const double* A, const double* B, const int64_t d[4], do
     if (!total) return;
     unsigned long long* out_dev = reinterpret_cast<unsigned long long*>(g_dot_ws[dv] + 16 * kDotBlocks);
     HIP_CHECK(hipMemsetAsync(out_dev, 0, 2 * sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(exchange_asym_kernel, dim3(grid_for(total, 256, 256 * 8)), dim3(256), 0, st, A, B, (long)d[0],
-                       (long)d[1], (long)d[2], (long)d[3], total, out_dev);
+    const long tr = (d[2] + 31) / 32, ts = (d[3] + 31) / 32, nblk = d[0] * d[1] * tr * ts;
+    if (nblk > 0x7fffffffL) throw std::runtime_error("exchange_asymmetry: grid too large");
+    hipLaunchKernelGGL(exchange_asym_kernel, dim3((unsigned)nblk), dim3(256), 0, st, A, B, (long)d[0], (long)d[1], (long)d[2],
+                       (long)d[3], (int)tr, (int)ts, out_dev);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(g_dot_host[dv], out_dev, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));

@@ -185,3 +185,32 @@ def test_elementwise_and_reductions(ctx):
     cs = rng.standard_normal(5)
     ctx.lincomb(out, xs, cs)
     assert np.abs(out.get() - sum(c * x.get() for c, x in zip(cs, xs))).max() < 1e-13
+
+
+def test_exchange_asymmetry_kernel(gpu_lib):
+    """max |A[p,q,r,s] - B[q,p,s,r]| and max |A| through the LDS-tiled kernel: ragged tiles, a planted difference, NaN."""
+    import ctypes as C
+    from pymes_amd import _lib
+    rng = np.random.default_rng(3)
+    for (d0, d1, d2, d3) in ((3, 5, 7, 33), (5, 5, 40, 40), (2, 9, 65, 31), (4, 4, 1, 1)):
+        A = rng.standard_normal((d0, d1, d2, d3))
+        B = A.transpose(1, 0, 3, 2).copy()
+        ctx = Context(2, 2, lib=gpu_lib, workspace_bytes=1 << 20)
+        try:
+            out = (C.c_double * 2)()
+
+            dA = ctx.array(A)
+
+            def asym(Bh):
+                dB = ctx.array(Bh)
+                ctx.lib.call("pymes_exchange_asymmetry", ctx.handle, C.c_void_p(dA.ptr), C.c_void_p(dB.ptr),
+                             _lib.i64_array(A.shape), out)
+                return out[0], out[1]
+            assert asym(B) == (0.0, np.abs(A).max())
+            B2 = B.copy()
+            B2[d1 - 1, d0 - 1, d3 - 1, d2 - 1] += 0.125
+            assert asym(B2) == (0.125, np.abs(A).max())
+            B2[0, 0, 0, 0] = np.nan
+            assert asym(B2)[0] == np.inf
+        finally:
+            ctx.close()
