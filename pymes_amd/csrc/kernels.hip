@@ -863,8 +863,9 @@ __global__ void __launch_bounds__(256) dots_stage1_kernel(const DotPtrs p, doubl
     const double* __restrict__ y = p.y[pair];
     const long n = p.n[pair];
     double s = 0.0;
+#pragma unroll 4
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        s += x[i] * y[i];
+        s += x[i] * y[i];       // read-only operands: the unrolled loads are issued together
     s = block_sum(s, sh);
     if (threadIdx.x == 0) partial[pair * kDotBlocks + blockIdx.x] = s;
 }
@@ -885,6 +886,7 @@ __global__ void __launch_bounds__(256) energy_norms_kernel(const double* __restr
                                                            int no, int nv, long total, double* __restrict__ partial) {
     __shared__ double sh[4];
     double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s0 = 0.0, s5 = 0.0;
+#pragma unroll 4
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const double x = t2[idx];
         double tau = x;

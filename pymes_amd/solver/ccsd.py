@@ -117,7 +117,8 @@ class CCSD(ccd.CCD):
             st["L"], st["QK"] = ctx.empty((st["npp"], no * no)), ctx.empty((no * nv, no * no))
         if not dist_on:
             # single rank: T1, T2 and the residuals live in fixed buffers, so the residual part of the loop body (about
-            # 130 kernel launches) can be recorded once as a launch graph and replayed (small problems are launch-bound)
+            # 130 kernel launches) can be recorded once as a launch graph and replayed (frees the host; measured: the device
+            # executes the same latency-bound kernels either way)
             st["r1"], st["r2"] = ctx.pool_get(t1.shape), ctx.pool_get(t2.shape)
             if not self.is_diis:
                 st["dt1"], st["dt2"] = ctx.pool_get(t1.shape), ctx.pool_get(t2.shape)
