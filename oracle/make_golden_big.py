@@ -9,6 +9,7 @@ Run in the BUILD CONTAINER ONLY (the reference does not travel to the GPU box):
       ``CCSD.solve`` (pymes/solver/ccsd.py:47-224, ~80 s per iteration here) -> per-iteration energies,
       final energy, |T1|, |T2| into tests/golden/solves.json["syn_20_80"]; the oracle solve is pinned
       against it on the way (aborts on mismatch).
+  c2dcsd / c2ccd / c2dcd  the other solver variants (DCSD; CCD.solve / DCD, ccd.py:24-162) on the same problem.
   c5  config 5, EOM-CCSD sigma build (pymes/solver/eom_ccsd.py:268-385) at (nocc=30, nvirt=120): the reference's
       ``update_singles`` / ``update_doubles`` on seeded inputs -> checksums and sampled entries of sigma1 / sigma2
       into tests/golden/eom_sigma_30_120.npz; the oracle is pinned against it on the way.
@@ -48,40 +49,51 @@ def history_from_log(text):
     return [float(x) for x in re.findall(r"Correlation Energy = (-?[0-9.eE+-]+)", text)]
 
 
-def c2():
-    from pymes.solver import ccsd as ref_ccsd
+def c2(kind="ccsd"):
+    """kind: ccsd (the config itself), dcsd, ccd, dcd — the other three solver variants on the same problem."""
+    from pymes.solver import ccd as ref_ccd, ccsd as ref_ccsd
     no, nv, scale, delta_e = 20, 80, 0.15, 1e-10
     f, V, _, _ = synthetic_case(no, nv, seed=0, scale=scale)
     t0 = time.time()
-    s = ref_ccsd.CCSD(no, delta_e=delta_e)
-    res, log = quiet(s.solve, f, V)
+    if kind in ("ccsd", "dcsd"):
+        s = ref_ccsd.CCSD(no, delta_e=delta_e, is_dcsd=(kind == "dcsd"))
+        res, log = quiet(s.solve, f, V)
+        e_ref, t2, t1 = res["ccsd e"], res["t2"], res["t1"]
+    else:
+        s = ref_ccd.CCD(no, delta_e=delta_e, is_dcd=(kind == "dcd"))
+        res, log = quiet(s.solve, f, V)
+        e_ref, t2, t1 = res["ccd e"], res["t2 amp"], None
     hist = history_from_log(log)
     t_ref = time.time() - t0
-    print(f"reference CCSD.solve (20,80): E = {res['ccsd e']:+.15f}, {len(hist)} iterations, {t_ref:.0f} s", flush=True)
+    print(f"reference {kind} solve (20,80): E = {e_ref:+.15f}, {len(hist)} iterations, {t_ref:.0f} s", flush=True)
     t0 = time.time()
-    r = oc.ccsd_solve(no, f, V, delta_e=delta_e)
-    print(f"oracle ccsd_solve (20,80): E = {r['e']:+.15f}, {r['iterations']} iterations, {time.time() - t0:.0f} s", flush=True)
+    opt = lambda *a: np.einsum(*a, optimize=True)          # the oracle's BLAS-backed mode: same algebra, minutes instead of tens
+    if kind in ("ccsd", "dcsd"):
+        r = oc.ccsd_solve(no, f, V, is_dcsd=(kind == "dcsd"), delta_e=delta_e, ein=opt)
+    else:
+        r = oc.ccd_solve(no, f, V, is_dcd=(kind == "dcd"), delta_e=delta_e, ein=opt)
+    print(f"oracle {kind} solve (20,80): E = {r['e']:+.15f}, {r['iterations']} iterations, {time.time() - t0:.0f} s", flush=True)
     assert r["iterations"] == len(hist), (r["iterations"], len(hist))
     h_or = [h[0] for h in r["history"]]
     assert np.max(np.abs(np.array(h_or) - np.array(hist))) < 1e-9, "oracle history != reference"
-    assert abs(r["e"] - res["ccsd e"]) < 1e-10, "oracle energy != reference"
-    assert np.max(np.abs(r["t2"] - res["t2"])) < 1e-8, "oracle t2 != reference"
-    assert np.max(np.abs(r["t1"] - res["t1"])) < 1e-8, "oracle t1 != reference"
+    assert abs(r["e"] - e_ref) < 1e-10, "oracle energy != reference"
+    assert np.max(np.abs(r["t2"] - t2)) < 1e-8, "oracle t2 != reference"
+    if t1 is not None:
+        assert np.max(np.abs(r["t1"] - t1)) < 1e-8, "oracle t1 != reference"
     path = os.path.join(GOLD, "solves.json")
     solves = json.load(open(path))
-    t2 = res["t2"]
-    solves["syn_20_80"] = {
-        "ccsd": {"e": float(res["ccsd e"]), "iterations": len(hist), "converged": True, "history": hist,
-                 "delta_e": delta_e, "level_shift": 0.0, "t2_norm": float(np.linalg.norm(t2)),
-                 "t1_norm": float(np.linalg.norm(res["t1"])),
-                 # a few entries of the converged amplitudes (index -> value) for a cheap element-wise check
-                 "t2_samples": [[a, b, i, j, float(t2[a, b, i, j])] for (a, b, i, j) in
-                                ((0, 0, 0, 0), (3, 7, 2, 5), (79, 0, 19, 0), (41, 40, 10, 11), (17, 63, 19, 3))],
-                 "reference_seconds": t_ref},
-        "recipe": {"seed": 0, "scale": scale, "gap": 3.0}}
+    entry = solves.setdefault("syn_20_80", {})
+    entry[kind] = {"e": float(e_ref), "iterations": len(hist), "converged": True, "history": hist,
+                   "delta_e": delta_e, "level_shift": 0.0, "t2_norm": float(np.linalg.norm(t2)),
+                   "t1_norm": None if t1 is None else float(np.linalg.norm(t1)),
+                   # a few entries of the converged amplitudes (index -> value) for a cheap element-wise check
+                   "t2_samples": [[a, b, i, j, float(t2[a, b, i, j])] for (a, b, i, j) in
+                                  ((0, 0, 0, 0), (3, 7, 2, 5), (79, 0, 19, 0), (41, 40, 10, 11), (17, 63, 19, 3))],
+                   "reference_seconds": t_ref}
+    entry["recipe"] = {"seed": 0, "scale": scale, "gap": 3.0}
     with open(path, "w") as fh:
         json.dump(solves, fh, indent=1)
-    print("syn_20_80 written to", path)
+    print(f"syn_20_80 / {kind} written to", path)
 
 
 def c5():
@@ -119,5 +131,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["c2", "c5"]
     if "c2" in which:
         c2()
+    for kind in ("dcsd", "ccd", "dcd"):
+        if "c2" + kind in which:
+            c2(kind)
     if "c5" in which:
         c5()
