@@ -133,6 +133,10 @@ int pymes_ccsd_singles_residual_partial(pymes_ctx* ctx, const double* fd_dev, co
 #define PYMES_SYM_LADDER 8u   /* evaluate V_abcd.T in pair-packed form (1/4 of the flops); requires
                                  V_abcd = V_badc and T_cdij = T_dcji, true for every closed-shell solve that
                                  starts from MP2 or from symmetric amplitudes */
+#define PYMES_SLAB_RINGS_ONLY 64u   /* pymes_residual_slab: only the ring products (rows of ETd / ETx) ... */
+#define PYMES_SLAB_LADDERS_ONLY 128u /* ... only the ladders (rows of L, Q_kb).  One process per GPU calls the two halves
+                                 separately: the all-gathers of ETd / ETx are started after the first and fly while the
+                                 second — whose output stays on the rank — is computed */
 #define PYMES_REUSE_LAYOUTS 32u /* the caller's promise that t2 has not changed since the preceding pymes_residual_slab call
                                  on it: its pair layouts (Td, Tx, 2T - T^(ab)) are read again instead of being rebuilt
                                  (pymes_residual_finish, pymes_ccsd_singles_residual_partial) */

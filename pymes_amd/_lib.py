@@ -120,6 +120,7 @@ SIGNATURES = {
 
 PYMES_DCD, PYMES_USE_DRESSED, PYMES_SKIP_LADDER, PYMES_SYM_LADDER, PYMES_SYM_RINGS = 1, 2, 4, 8, 16
 PYMES_REUSE_LAYOUTS = 32
+PYMES_SLAB_RINGS_ONLY, PYMES_SLAB_LADDERS_ONLY = 64, 128
 PYMES_DRESS_ABIJ_REDUCED = 1 << 16
 
 

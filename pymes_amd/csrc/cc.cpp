@@ -212,7 +212,7 @@ void Engine::doubles_residual(const double* f, const double* t2, double* r2, uns
 // -----------------------------------------------------------------------------------
 void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, double* ETx_p, double* L, int rank,
                            int world, unsigned flags, const double* t1, double* QK, const double* P) {
-    const bool dcd = flags & 1u, dressed = flags & 2u, skip_ladder = flags & 4u;
+    const bool dcd = flags & 1u, dressed = flags & 2u, skip_ladder = (flags & 4u) || (flags & 64u), skip_rings = flags & 128u;
     const bool quad = !dcd;
     const int64_t o = no, v = nv, nn = n, ov = o * v;
     if (world < 1 || rank < 0 || rank >= world) throw Error("residual_slab: bad rank/world");
@@ -236,6 +236,7 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
             ladder_sym(t2, L, r0, r1, dressed, quad ? 1 : 2);  // particle AND hole ladder rows of this rank
         }
     }
+    if (skip_rings) return;
     int64_t c0, c1;
     chunk(ov, c0, c1);
     const int64_t nc = c1 - c0;

@@ -345,12 +345,15 @@ class Context:
                (_lib.PYMES_SKIP_LADDER if skip_ladder else 0) | (_lib.PYMES_SYM_LADDER if sym_ladder else 0) | \
                (_lib.PYMES_SYM_RINGS if sym_rings else 0)
 
-    def residual_slab(self, f, t2, ETd, ETx, L, rank, world, is_dcd=False, dressed=False, t1=None, QK=None, P=None):
+    def residual_slab(self, f, t2, ETd, ETx, L, rank, world, is_dcd=False, dressed=False, t1=None, QK=None, P=None,
+                      part=None):
         """This rank's share of the symmetry-reduced residual (include/pymes_amd.h).  ``t1`` + ``QK``: T1 dressing
-        of V_abcd on the amplitude side; ``P``: all-reduced output of ``slab_prepare``."""
+        of V_abcd on the amplitude side; ``P``: all-reduced output of ``slab_prepare``; ``part``: "rings" / "ladders" to
+        compute only that half (the caller overlaps the exchange of the first with the second)."""
+        extra = {None: 0, "rings": _lib.PYMES_SLAB_RINGS_ONLY, "ladders": _lib.PYMES_SLAB_LADDERS_ONLY}[part]
         self.lib.call("pymes_residual_slab", self.handle, C.c_void_p(f.ptr), C.c_void_p(t2.ptr), C.c_void_p(ETd.ptr),
                       C.c_void_p(ETx.ptr), C.c_void_p(L.ptr if L is not None else 0), int(rank), int(world),
-                      self._flags(is_dcd, dressed, False, True, True), C.c_void_p(t1.ptr if t1 is not None else 0),
+                      self._flags(is_dcd, dressed, False, True, True) | extra, C.c_void_p(t1.ptr if t1 is not None else 0),
                       C.c_void_p(QK.ptr if QK is not None else 0), C.c_void_p(P.ptr if P is not None else 0))
 
     def slab_prepare_ws(self):

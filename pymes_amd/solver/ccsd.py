@@ -217,16 +217,22 @@ class CCSD(ccd.CCD):
                     ctx.dress_V(t1, ("iajb", "iabj"), q_range=(c0 // ctx.no, -(-c1 // ctx.no)))
             else:
                 ctx.dress_V(t1, ("klij", "iajb", "iabj"))                             # :165
-            ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], rank, world, is_dcd=self.is_dcd,
-                              dressed=True, t1=t1, QK=st["QK"], P=st["P"] if dist_on else None)   # :171
+            # :171 in two halves: the ring products first, so that the all-gathers of their rows (ETd, ETx: 1.6 of the 1.8 GB
+            # that an iteration exchanges at (50,200)) fly while the ladders — whose rows of L never leave the rank in the
+            # pair-sharded tail — and the singles residual are computed
+            slab = dict(is_dcd=self.is_dcd, dressed=True, t1=t1, QK=st["QK"], P=st["P"] if dist_on else None)
             pending = []
             if dist_on:
+                ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], rank, world, part="rings", **slab)
+                pending = [pdist.exchange_rows_start(st[key], rank, world, ctx) for key in ("ETd_t", "ETx_t")]
+                ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], rank, world, part="ladders", **slab)
+                pending += [pdist.exchange_rows_start(st[key], rank, world, ctx)
+                            for key in (("QK_t",) if st["pairs"] else ("L_t", "QK_t"))]
                 if st["pairs"]:      # X_ac (:206-221) as a partial sum over this rank's chunk of k, all-reduced below
                     ctx.xvv_partial(st["fd"], t2, st["Xvv"], rank, world, is_dcd=self.is_dcd)
-                keys = ("ETd_t", "ETx_t", "QK_t") if st["pairs"] else ("ETd_t", "ETx_t", "L_t", "QK_t")
-                pending = [pdist.exchange_rows_start(st[key], rank, world, ctx) for key in keys]
-                if st["pairs"]:
                     pending.append(pdist.allreduce_tensor_start(st["Xvv_t"], ctx))
+            else:
+                ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], rank, world, **slab)
             # :167 as a partial sum over this rank's chunk of the occupied summation index, all-reduced (80 KB)
             ctx.singles_residual_partial(st["fd"], t1, t2, r1, rank, world, reuse_layouts=True)
             pending.append(pdist.allreduce_tensor_start(st["R1_t"], ctx))
