@@ -174,7 +174,8 @@ int pymes_ladder_sym_unpack(pymes_ctx* ctx, const double* L_dev, double* r2_dev,
  * undressed and adds its T1 dressing through Ex + Ex^T as V_abcj t_ci - t_ak (V_kbij + V_kbcj t_ci + V_kbid t_dj + Q_kbij)
  * (the (k,l)-bra part rides in the hole ladder taken with tau).  Only V~_klij, V~_iajb, V~_iabj have to be dressed.
  * QK is a fourth exchange buffer, [o*v][o*o] on the device cut into the same row chunks
- * as ETd: QK[(k,b)] = [ QS | QA ] of sum_cd V_kbcd tau_cdij. */
+ * as ETd: QK[(k,b)][i][j] = sum_cd V_kbcd tau_cdij + V_kbij + V_kbcj t_ci + V_kbid t_dj — the whole bracket above, formed
+ * only for the rows (k,b) of the rank. */
 int pymes_residual_slab(pymes_ctx* ctx, const double* f_dev, const double* t2_dev, double* ETd_dev, double* ETx_dev,
                         double* L_dev, int rank, int world, uint32_t flags, const double* t1_dev, double* QK_dev,
                         const double* P_dev);

@@ -210,6 +210,11 @@ void Engine::doubles_residual(const double* f, const double* t2, double* r2, uns
 // ranks are contiguous row blocks of ETd / ETx = one all-gather each.  Since only Ex + Ex^T enters R
 // the transposition needs no undoing.  The pair-packed ladder rows of the same rank go to L.
 // -----------------------------------------------------------------------------------
+void Engine::ensure_xs() {
+    if (!xs_oo_) xs_oo_ = static_cast<double*>(dev::dmalloc(sizeof(double) * no * no));
+    if (!xs_vv_) xs_vv_ = static_cast<double*>(dev::dmalloc(sizeof(double) * nv * nv));
+}
+
 void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, double* ETx_p, double* L, int rank,
                            int world, unsigned flags, const double* t1, double* QK, const double* P) {
     const bool dcd = flags & 1u, dressed = flags & 2u, skip_ladder = (flags & 4u) || (flags & 64u), skip_rings = flags & 128u;
@@ -284,7 +289,22 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
     TView M = slab(), N1 = slab();
     load_cols(1.0, Viabj, "kbcj", M);                                                         // M = Wd
     load_cols(-1.0, Viajb, "kbjc", N1);                                                       // N1 = -UdT
+    // Y = Vd Tt_d (:202) carries the small V.T sums as partial traces: S_ac = sum_k Y[(c,k),(a,k)], S_ki = sum_c Y[(c,k),(c,i)]
+    // (exchange-symmetric V and T).  With all columns on this rank they are read off M = Wd + Y/2 before and after the
+    // product, 2 (tr M - tr Wd): no o^2 v^3 / o^3 v^2 products and no transposition for X_ac, X_ki and ccsd.py:434, :436
+    const bool traces = !P && nc == ov;
+    if (traces) {
+        ensure_xs();
+        xs_oo_tag_.clear();
+        xs_vv_tag_.clear();
+        dev::pair_traces(M.p, nc, -2.0, 0.0, xs_vv_, xs_oo_, no, nv, stream);
+    }
     contract(0.5, Vd, "xy", cols(Ttd), "yn", 1.0, M, "xn");                                  // M = Wd + Y/2   (:202)
+    if (traces) {
+        dev::pair_traces(M.p, nc, 2.0, 1.0, xs_vv_, xs_oo_, no, nv, stream);
+        xs_oo_tag_.set(t2, 0, 1);
+        xs_vv_tag_.set(t2, 0, 1);
+    }
     contract(1.0, M, "kn", Ttd, "mk", 0.0, ETd, "nm");                                       // :204 (half) + :235
     if (quad) {
         // U = Vx Tx (:190), U' = Vx Td (:238):  X3 = U/2 - UdT,  M2 = -UdT + U - U' = 2 X3 + UdT - U'
@@ -307,6 +327,8 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
         copy(Foo, Xoo);
         if (P) {                 // the V.T part was summed over the ranks (slab_prepare)
             axpby(1.0, make_view(const_cast<double*>(P), {o, o}), 1.0, Xoo);
+        } else if (traces) {
+            axpby(w, make_view(xs_oo_, {o, o}), 1.0, Xoo);                                   // :215-220
         } else {
             TView Tp = make_view(arena.alloc(o * o * v * v), {v, v, o, o});
             permute(1.0, make_view(Ttd.p, {v, o, v, o}), "cidl", 0.0, Tp, "cdli");
@@ -335,6 +357,8 @@ void Engine::slab_prepare(const double* t2, double* P, int rank, int world, unsi
     dev::memset_zero(P, sizeof(double) * slab_prepare_ws_doubles(), stream);
     TView T = make_view(const_cast<double*>(t2), {v, v, o, o});
     ArenaScope scope(arena);
+    ensure_xs();
+    xs_oo_tag_.clear();
     {
         // X'_ki over c in [c0,c1)
         const int64_t cc = (v + world - 1) / world, c0 = std::min<int64_t>(rank * cc, v), c1 = std::min<int64_t>(c0 + cc, v);
@@ -345,8 +369,12 @@ void Engine::slab_prepare(const double* t2, double* P, int rank, int world, unsi
             permute(2.0, Tc, "cdil", 0.0, Tp, "cdli");                            // Tt[c,d,i,l] = 2 T[c,d,i,l] - T[d,c,i,l]
             permute(-1.0, slice(T, 1, c0, c1), "dcil", 1.0, Tp, "cdli");
             TView Vk3 = slice(make_view(get_static("Vk3"), {v, v, o, o}), 0, c0, c1);
-            contract(dcd ? 0.5 : 1.0, Vk3, "cdlk", Tp, "cdli", 0.0, make_view(P, {o, o}), "ki");   // :215-220
+            contract(1.0, Vk3, "cdlk", Tp, "cdli", 0.0, make_view(xs_oo_, {o, o}), "ki");         // :215-220
+            axpby(dcd ? 0.5 : 1.0, make_view(xs_oo_, {o, o}), 0.0, make_view(P, {o, o}));
+        } else {
+            dev::memset_zero(xs_oo_, sizeof(double) * o * o, stream);
         }
+        xs_oo_tag_.set(t2, rank, world);       // this rank's partial sum: the singles residual takes ccsd.py:434 from it
     }
     if (!static_.count("VpIjab")) {
         double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * npp));
@@ -409,16 +437,25 @@ void Engine::residual_finish(const double* f, const double* t2, const double* ET
     }
     // X_ac = f_ac - w sum Tt[a,d,k,l] V[l,k,d,c]  (:206-221);  Ex += X_ac T[c,b,i,j]  (:231)
     const bool reuse = (flags & 32u) && lay_t2_ == t2 && lay_[2];     // Tt_d of the preceding residual_slab on this t2
-    TView Ttd = make_view(reuse ? lay_[2] : arena.alloc(o * o * v * v), {v, o, v, o});
-    if (!reuse) {
-        permute(2.0, T, "abij", 0.0, Ttd, "aibj");
-        permute(-1.0, T, "baij", 1.0, Ttd, "aibj");
-    }
+    const bool have_sum = (flags & 32u) && xs_vv_tag_.is(t2, 0, 1);   // ... and its S_ac (all columns on this rank)
     TView Xvv = make_view(arena.alloc(v * v), {v, v});
     copy(Fvv, Xvv);
-    contract(-w, Ttd, "akdl", make_view(get_static("Vk"), {o, v, o, v}), "kdlc", 1.0, Xvv, "ac");
-    // a private Tt_d is dead after X_ac and lends its storage to Exn; the kept one must survive
-    TView Exn = make_view(reuse ? arena.alloc(o * o * v * v) : Ttd.p, {v, v, o, o});
+    TView Exn;
+    if (have_sum) {
+        axpby(-w, make_view(xs_vv_, {v, v}), 1.0, Xvv);
+        Exn = make_view(arena.alloc(o * o * v * v), {v, v, o, o});
+    } else {
+        TView Ttd = make_view(reuse ? lay_[2] : arena.alloc(o * o * v * v), {v, o, v, o});
+        if (!reuse) {
+            permute(2.0, T, "abij", 0.0, Ttd, "aibj");
+            permute(-1.0, T, "baij", 1.0, Ttd, "aibj");
+        }
+        contract(-w, Ttd, "akdl", make_view(get_static("Vk"), {o, v, o, v}), "kdlc", 1.0, Xvv, "ac");
+        // a private Tt_d is dead after X_ac and lends its storage to Exn; the kept one must survive
+        Exn = make_view(reuse ? arena.alloc(o * o * v * v) : Ttd.p, {v, v, o, o});
+    }
+    xs_oo_tag_.clear();                                               // last reader of the iteration
+    xs_vv_tag_.clear();
     contract(1.0, Xvv, "ac", T, "cbij", 0.0, Exn, "abij");
     if (amp_side) {
         if (!QK) throw Error("residual_finish: QK buffer missing");
@@ -462,7 +499,8 @@ void Engine::hf_fock_matrix(const double* h_host, double* f_host) {
 // The part of the T1 dressing of the residual that is linear in the rows a of R and enters through Ex + Ex^T(baji)
 // (amplitude-side mode; exchange symmetry V_pqrs = V_qpsr).  With W_kbij = V_kbij + V_kbcj t_ci + V_kbid t_dj:
 //     N[a,b,i,j] += V_abcj t_ci - t_ak (Q_kbij + W_kbij)          for a in [a0,a1)   (+ the (b,a,j,i) halves if asked)
-// Q_kb (from QK) carries the (c,d)-ket part of the bras (k,b)/(a,l); W the rest of those bras; V_abcj t_ci and its
+// QK holds Q + W (ladder_t1 forms both for the (k,b) rows of a rank; all-gathered by the caller).  Q_kb carries
+// the (c,d)-ket part of the bras (k,b)/(a,l); W the rest of those bras; V_abcj t_ci and its
 // partner V_abid t_dj = (V_abcj t_ci)_baji are the (c,j)/(i,d) kets of the bra (a,b).  Together with the undressed
 // V_abij in the assembly and the (k,l) bra inside the hole ladder this is all of V~_abij (ccsd.py:322-343).
 void Engine::amplitude_side_abij(const double* t1, const double* QK, const TView& N, int64_t a0, int64_t a1,
@@ -470,12 +508,7 @@ void Engine::amplitude_side_abij(const double* t1, const double* QK, const TView
     // N is [a1 - a0][b1][o][o]: rows a in [a0,a1), columns b in [0,b1)
     const int64_t o = no, v = nv;
     TView t = make_view(const_cast<double*>(t1), {v, o});
-    ArenaScope scope(arena);
-    TView Qf = make_view(arena.alloc(o * v * o * o), {o, v, o, o});
-    dev::rows_unpack(QK, Qf.p, o * v, no, stream);
-    axpby(1.0, block(P_iajk), 1.0, Qf);
-    contract(1.0, block(P_iabj), "kbcj", t, "ci", 1.0, Qf, "kbij");
-    contract(1.0, block(P_iajb), "kbid", t, "dj", 1.0, Qf, "kbij");
+    TView Qf = make_view(const_cast<double*>(QK), {o, v, o, o});        // Q + W, rows (k,b) plain [i][j] (ladder_t1)
     contract(-1.0, slice(t, 0, a0, a1), "ak", slice(Qf, 1, 0, b1), "kbij", 1.0, N, "abij");
     contract(1.0, slice(slice(block(P_abci), 0, a0, a1), 1, 0, b1), "abcj", t, "ci", 1.0, N, "abij");
     if (!with_partner) return;
@@ -513,7 +546,11 @@ void Engine::residual_finish_pairs(const double* f, const double* t2, const doub
     if (!dev::fused_pair_kernels_ok(no)) throw Error("residual_finish_pairs: nocc too large for the fused assembly");
     int64_t r0, r1;
     pair_chunk(rank, world, r0, r1);
-    if (r1 <= r0) return;
+    if (r1 <= r0) {
+        xs_oo_tag_.clear();
+        xs_vv_tag_.clear();
+        return;
+    }
     const int a0 = a_of_pair_row(r0), a1 = a_of_pair_row(r1 - 1) + 1;
     const int64_t na = a1 - a0;
     TView T = make_view(const_cast<double*>(t2), {v, v, o, o});
@@ -544,6 +581,8 @@ void Engine::residual_finish_pairs(const double* f, const double* t2, const doub
     dev::residual_assemble_pairs(Vabij.p, L, Np.p, ETd_p, ETx_p, Rc, no, nv, r0, r1, a0, static_cast<int>(nb), stream);
     stats.permute_calls++;
     stats.permute_bytes += 8.0 * 5.5 * double(r1 - r0) * 2.0 * double(o * o);
+    xs_oo_tag_.clear();                                               // last call of the iteration
+    xs_vv_tag_.clear();
 }
 
 // rows a in [a0,a1) of the T1-dressed V_abcd (ccsd.py:414-419): what a rank needs for its ladder rows.
@@ -721,13 +760,22 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
             }
         }
         if (qrows > 0) {
-            TView Qrows = make_view(QK + q0 * o * o, {qrows, o * o});
-            TView QS = slice(Qrows, 1, 0, opp), QA = slice(Qrows, 1, opp, o * o);
+            // rows (k,b) in [q0,q1) of Q_kbij + W_kbij, plain [i][j]: the pair-packed product [ QS | QA ] is unpacked
+            // into the exchange buffer and the small brackets of amplitude_side_abij are added for the same rows, so
+            // that they are sharded with Q instead of being repeated by every rank
+            TView Qp = make_view(arena.alloc(qrows * o * o), {qrows, o * o});
+            TView QS = slice(Qp, 1, 0, opp), QA = slice(Qp, 1, opp, o * o);
             contract(1.0, make_view(static_["VpK" + kkey], {qrows, npp}), "rk", SpT, "kn", 0.0, QS, "rn");
             if (opm > 0) {
                 if (npm > 0) contract(1.0, make_view(static_["VmK" + kkey], {qrows, npm}), "rk", AmT, "kn", 0.0, QA, "rn");
                 else zero(QA);
             }
+            dev::rows_unpack(Qp.p, QK + q0 * o * o, qrows, no, stream);
+            TView t = make_view(const_cast<double*>(t1), {v, o});
+            TView Qr = make_view(QK + q0 * o * o, {qrows, o, o});
+            axpby(1.0, make_view(block(P_iajk).p + q0 * o * o, {qrows, o, o}), 1.0, Qr);
+            contract(1.0, make_view(block(P_iabj).p + q0 * v * o, {qrows, v, o}), "qcj", t, "ci", 1.0, Qr, "qij", "q");
+            contract(1.0, make_view(block(P_iajb).p + q0 * o * v, {qrows, o, v}), "qid", t, "dj", 1.0, Qr, "qij");
         }
     }
     if (rows == 0) return;
@@ -885,15 +933,23 @@ void Engine::xvv_partial(const double* f, const double* t2, double* Xvv_p, int r
     TView F = make_view(const_cast<double*>(f), {nn, nn});
     if (rank == 0) copy(slice(slice(F, 0, o, nn), 1, o, nn), Xvv);
     else zero(Xvv);
-    if (k1 <= k0) return;
-    ArenaScope scope(arena);
-    TView T = make_view(const_cast<double*>(t2), {v, v, o, o});
-    TView Tk = slice(T, 2, k0, k1);                                      // T[a,d,k,l], k in the chunk
-    TView Ttd = make_view(arena.alloc(v * (k1 - k0) * v * o), {v, k1 - k0, v, o});
-    permute(2.0, Tk, "adkl", 0.0, Ttd, "akdl");
-    permute(-1.0, Tk, "dakl", 1.0, Ttd, "akdl");
-    TView Vk = slice(make_view(get_static("Vk"), {o, v, o, v}), 0, k0, k1);
-    contract(dcd ? -0.5 : -1.0, Ttd, "akdl", Vk, "kdlc", 1.0, Xvv, "ac");
+    ensure_xs();
+    xs_vv_tag_.clear();
+    TView S = make_view(xs_vv_, {v, v});
+    if (k1 <= k0) {
+        zero(S);
+    } else {
+        ArenaScope scope(arena);
+        TView T = make_view(const_cast<double*>(t2), {v, v, o, o});
+        TView Tk = slice(T, 2, k0, k1);                                      // T[a,d,k,l], k in the chunk
+        TView Ttd = make_view(arena.alloc(v * (k1 - k0) * v * o), {v, k1 - k0, v, o});
+        permute(2.0, Tk, "adkl", 0.0, Ttd, "akdl");
+        permute(-1.0, Tk, "dakl", 1.0, Ttd, "akdl");
+        TView Vk = slice(make_view(get_static("Vk"), {o, v, o, v}), 0, k0, k1);
+        contract(1.0, Ttd, "akdl", Vk, "kdlc", 0.0, S, "ac");
+        axpby(dcd ? -0.5 : -1.0, S, 1.0, Xvv);
+    }
+    xs_vv_tag_.set(t2, rank, world);       // this rank's partial sum: the singles residual takes ccsd.py:436 from it
 }
 
 // -----------------------------------------------------------------------------------
@@ -1032,6 +1088,12 @@ void Engine::singles_residual_partial(const double* fd, const double* t1, const 
     TView R = make_view(r1, {v, o});
     if (rank == 0) copy(Dvo, R);                                                             // :431
     else zero(R);
+    // ccsd.py:434 / :436 contract the same sums as X_ki / X_ac (ccd.py:213-220; exchange-symmetric V, T): when the
+    // calls before this one have left them (residual_slab with all columns, or slab_prepare / xvv_partial: ANY partition
+    // of the sums over the ranks will do, the partial residuals are added up) the two products are not repeated
+    const bool have_oo = reuse_layouts && xs_oo_tag_.is(t2, rank, world), have_vv = reuse_layouts && xs_vv_tag_.is(t2, rank, world);
+    if (have_oo) contract(-1.0, t, "ak", make_view(xs_oo_, {o, o}), "ki", 1.0, R, "ai");     // :434
+    if (have_vv) contract(-1.0, make_view(xs_vv_, {v, v}), "ac", t, "ci", 1.0, R, "ai");     // :436
     if (nj <= 0) return;
     ArenaScope scope(arena);
     TView Tq, P1;
@@ -1053,13 +1115,17 @@ void Engine::singles_residual_partial(const double* fd, const double* t1, const 
     }
     contract(1.0, Tq, "bjai", slice(Dov, 0, j0, j1), "jb", 1.0, R, "ai");                    // :432 (Tt' symmetric)
     contract(1.0, slice(block(P_aibc), 1, j0, j1), "ajbc", P1, lp1, 1.0, R, "ai");           // :433
-    TView S2 = make_view(arena.alloc(o * o), {o, o});
-    contract(1.0, slice(make_view(get_static("Vjbck"), {o, v, v, o}), 0, j0, j1), "jbck", P1, lp1, 0.0, S2, "ki");
-    contract(-1.0, t, "ak", S2, "ki", 1.0, R, "ai");                                         // :434
+    if (!have_oo) {
+        TView S2 = make_view(arena.alloc(o * o), {o, o});
+        contract(1.0, slice(make_view(get_static("Vjbck"), {o, v, v, o}), 0, j0, j1), "jbck", P1, lp1, 0.0, S2, "ki");
+        contract(-1.0, t, "ak", S2, "ki", 1.0, R, "ai");                                     // :434
+    }
     contract(-1.0, Tq, "ajbk", slice(block(P_ijka), 0, j0, j1), "jkib", 1.0, R, "ai");       // :435
-    TView S4 = make_view(arena.alloc(v * v), {v, v});
-    contract(1.0, Tq, "ajbk", slice(block(P_ijab), 0, j0, j1), "jkcb", 0.0, S4, "ac");
-    contract(-1.0, S4, "ac", t, "ci", 1.0, R, "ai");                                         // :436
+    if (!have_vv) {
+        TView S4 = make_view(arena.alloc(v * v), {v, v});
+        contract(1.0, Tq, "ajbk", slice(block(P_ijab), 0, j0, j1), "jkcb", 0.0, S4, "ac");
+        contract(-1.0, S4, "ac", t, "ci", 1.0, R, "ai");                                     // :436
+    }
 }
 
 // -----------------------------------------------------------------------------------

@@ -147,6 +147,10 @@ void residual_assemble_pairs(const double* V, const double* L, const double* Np,
                              double* Rc, int no, int nv, int64_t r0, int64_t r1, int a0, int nbp, stream_t s);
 // plain rows of the same [ S | A ] layout: out[r][i][j] = Q[r][P(i,j)] + sgn(i-j) Q[r][o(o+1)/2 + Q(i,j)]
 void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t s);
+// partial traces of a pair matrix M[(c,k)][(b,j)] (row pitch ld; (c,k) = c*no + k):
+//   out_vv[a][c] = beta out_vv[a][c] + alpha sum_k M[(c,k)][(a,k)],   out_oo[k][i] = beta out_oo[k][i] + alpha sum_c M[(c,k)][(c,i)]
+void pair_traces(const double* M, int64_t ld, double alpha, double beta, double* out_vv, double* out_oo, int no, int nv,
+                 stream_t s);
 
 // ---- Hartree-Fock matrix from the packed blocks (pymes/mean_field/hf.py:14-18); dir[tp*2+tq] = block (tp,o,tq,o),
 // exc[tp*2+tq] = block (tp,o,o,tq), tp/tq = 1 for a virtual index; h and f are [n,n] on the device

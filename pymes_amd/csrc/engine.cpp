@@ -120,6 +120,8 @@ Engine::~Engine() {
         for (auto g : graphs_) dev::graph_destroy(g);
         for (void* p : user_allocs_) dev::dfree(p);
         for (auto& p : lay_) dev::dfree(p);
+        dev::dfree(xs_oo_);
+        dev::dfree(xs_vv_);
         for (auto& p : V_) dev::dfree(p);
         for (auto& p : Vd_) dev::dfree(p);
         for (auto& kv : static_) dev::dfree(kv.second);

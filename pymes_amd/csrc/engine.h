@@ -195,6 +195,21 @@ class Engine {
     // that read them again (singles residual, residual_finish): persistent buffers, valid for the t2 pointer recorded
     double* lay_[3] = {nullptr, nullptr, nullptr};
     const double* lay_t2_ = nullptr;
+    // S_ki = sum_cdl Tt[c,d,i,l] V[l,k,d,c] and S_ac = sum_dkl Tt[a,d,k,l] V[l,k,d,c] (ccd.py:213-220), or this rank's partial
+    // sums of them: X_ki, X_ac AND the singles residual (ccsd.py:434, :436 are the same sums for exchange-symmetric V, T)
+    // read them; valid for the t2 pointer recorded, from the producer (residual_slab / slab_prepare / xvv_partial) to the
+    // residual_finish of the same iteration
+    struct SumTag {
+        const double* t2 = nullptr;
+        int rank = 0, world = 0;          // whose share of the sum (world 1: the whole sum)
+        bool is(const double* p, int r, int w) const { return t2 && t2 == p && rank == r && world == w; }
+        void set(const double* p, int r, int w) { t2 = p; rank = r; world = w; }
+        void clear() { t2 = nullptr; }
+    };
+    double* xs_oo_ = nullptr;
+    double* xs_vv_ = nullptr;
+    SumTag xs_oo_tag_, xs_vv_tag_;
+    void ensure_xs();
     dev::stream_t own_stream_ = nullptr;
     std::set<void*> user_allocs_;
     std::set<dev::graph_t> graphs_;

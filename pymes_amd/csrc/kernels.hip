@@ -1270,6 +1270,30 @@ __global__ void rows_unpack_kernel(const double* __restrict__ Q, double* __restr
     }
 }
 
+// partial traces of a pair matrix M[(c,k)][(b,j)] (device_api.h): blocks [0,nv) take one c each (thread a sums over k:
+// one element per 128-byte line, 1/3 of the lines of M in all), the blocks behind them the o x o trace (thread (k,i) sums
+// over c, runs of no contiguous elements).  Plain sums in a fixed order: deterministic.
+__global__ void pair_traces_kernel(const double* __restrict__ M, long ld, double alpha, double beta,
+                                   double* __restrict__ out_vv, double* __restrict__ out_oo, int no, int nv) {
+    if ((int)blockIdx.x < nv) {
+        const int c = blockIdx.x;
+        for (int a = threadIdx.x; a < nv; a += blockDim.x) {
+            const double* __restrict__ p = M + (long)c * no * ld + (long)a * no;
+            double acc = 0.0;
+            for (int k = 0; k < no; ++k) acc += p[(long)k * ld + k];
+            double* o = out_vv + (long)a * nv + c;
+            *o = (beta == 0.0 ? 0.0 : beta * *o) + alpha * acc;
+        }
+        return;
+    }
+    const long e = (long)(blockIdx.x - nv) * blockDim.x + threadIdx.x;
+    if (e >= (long)no * no) return;
+    const int k = (int)(e / no), i = (int)(e - (long)k * no);
+    double acc = 0.0;
+    for (int c = 0; c < nv; ++c) acc += M[((long)c * no + k) * ld + (long)c * no + i];
+    out_oo[e] = (beta == 0.0 ? 0.0 : beta * out_oo[e]) + alpha * acc;
+}
+
 // ------------------------------------------------------------------------------------
 // explicit 3-body operator: TCDUMP scatter (tcdump.py:52-56) and its mean-field foldings (contraction.py:17-95)
 // L is dense [nb]^6 in chemists' order (or|ps|qt)
@@ -1834,7 +1858,10 @@ void gemm(const Gemm& g, stream_t s) {
                 const double cost = (double)((rem * sp + slots - 1) / slots) / (double)sp + 1e-5 * sp;
                 if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
             }
-            if (best >= 2 && best_cost < 0.8) {
+            // worth it below 0.8 of a tile-time; below 0.9 when every split is still >= 2048 deep (the partial-tile
+            // traffic and the reduction are then small against the product: a 200-tile ladder slab of one rank in eight)
+            const bool deep_split = best >= 2 && (ktiles / best) * BK >= 2048;
+            if (best >= 2 && best_cost < (deep_split ? 0.9 : 0.8)) {
                 tail_tiles = rem;
                 main_tiles = tiles - rem;
                 tail_split = (int)best;
@@ -2207,6 +2234,15 @@ void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t s)
     const long total = (long)rows * no * no;
     if (!total) return;
     hipLaunchKernelGGL(rows_unpack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, Q, out, no, total);
+    HIP_CHECK(hipGetLastError());
+}
+
+void pair_traces(const double* M, int64_t ld, double alpha, double beta, double* out_vv, double* out_oo, int no, int nv,
+                 stream_t s) {
+    if (no <= 0 || nv <= 0) return;
+    const unsigned blocks = (unsigned)nv + (unsigned)(((long)no * no + 255) / 256);
+    hipLaunchKernelGGL(pair_traces_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, M, (long)ld, alpha, beta, out_vv, out_oo,
+                       no, nv);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -452,6 +452,24 @@ void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t) {
             }
 }
 
+void pair_traces(const double* M, int64_t ld, double alpha, double beta, double* out_vv, double* out_oo, int no, int nv,
+                 stream_t) {
+    for (int a = 0; a < nv; ++a)
+        for (int c = 0; c < nv; ++c) {
+            double acc = 0.0;
+            for (int k = 0; k < no; ++k) acc += M[((int64_t)c * no + k) * ld + (int64_t)a * no + k];
+            double& o = out_vv[(int64_t)a * nv + c];
+            o = (beta == 0.0 ? 0.0 : beta * o) + alpha * acc;
+        }
+    for (int k = 0; k < no; ++k)
+        for (int i = 0; i < no; ++i) {
+            double acc = 0.0;
+            for (int c = 0; c < nv; ++c) acc += M[((int64_t)c * no + k) * ld + (int64_t)c * no + i];
+            double& o = out_oo[(int64_t)k * no + i];
+            o = (beta == 0.0 ? 0.0 : beta * o) + alpha * acc;
+        }
+}
+
 void ladder_unpack(const double* L, double* R, double beta, int no, int nv, stream_t) {
     const int64_t opp = (int64_t)no * (no + 1) / 2, ld = (int64_t)no * no;
     int64_t idx = 0;
