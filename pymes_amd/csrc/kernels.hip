@@ -684,8 +684,17 @@ __global__ void __launch_bounds__(256) gemv_finish_kernel(const double* __restri
                                                           double beta, const double* yin, double* y, long ys) {
     const long c = (long)blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    double s = 0.0;
-    for (int k = 0; k < nchunk; ++k) s += part[(long)k * C + c];
+    // four running sums: the loads of a round are independent (a single chain waits for every load in turn)
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = 0;
+    for (; k + 4 <= nchunk; k += 4) {
+        s0 += part[(long)k * C + c];
+        s1 += part[(long)(k + 1) * C + c];
+        s2 += part[(long)(k + 2) * C + c];
+        s3 += part[(long)(k + 3) * C + c];
+    }
+    for (; k < nchunk; ++k) s0 += part[(long)k * C + c];
+    const double s = (s0 + s1) + (s2 + s3);
     double v = alpha * s;
     if (beta != 0.0) v += beta * yin[c * ys];
     y[c * ys] = v;
@@ -1270,28 +1279,56 @@ __global__ void rows_unpack_kernel(const double* __restrict__ Q, double* __restr
     }
 }
 
-// partial traces of a pair matrix M[(c,k)][(b,j)] (device_api.h): blocks [0,nv) take one c each (thread a sums over k:
-// one element per 128-byte line, 1/3 of the lines of M in all), the blocks behind them the o x o trace (thread (k,i) sums
-// over c, runs of no contiguous elements).  Plain sums in a fixed order: deterministic.
-__global__ void pair_traces_kernel(const double* __restrict__ M, long ld, double alpha, double beta,
-                                   double* __restrict__ out_vv, double* __restrict__ out_oo, int no, int nv) {
+// partial traces of a pair matrix M[(c,k)][(b,j)] (device_api.h).  Blocks [0,nv): one c each — a wave takes every
+// fourth a, its lanes the k of sum_k M[(c,k)][(a,k)] (one element per 128-byte line: 1/3 of the lines of M in all), summed
+// by a shuffle tree.  Blocks [nv, nv+no): one k each — lanes over i, the four waves over c = w, w+4, ..., added up in
+// wave order through LDS.  Fixed summation orders: deterministic.
+__global__ void __launch_bounds__(256) pair_traces_kernel(const double* __restrict__ M, long ld, double alpha, double beta,
+                                                          double* __restrict__ out_vv, double* __restrict__ out_oo,
+                                                          int no, int nv) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if ((int)blockIdx.x < nv) {
         const int c = blockIdx.x;
-        for (int a = threadIdx.x; a < nv; a += blockDim.x) {
-            const double* __restrict__ p = M + (long)c * no * ld + (long)a * no;
-            double acc = 0.0;
-            for (int k = 0; k < no; ++k) acc += p[(long)k * ld + k];
-            double* o = out_vv + (long)a * nv + c;
-            *o = (beta == 0.0 ? 0.0 : beta * *o) + alpha * acc;
+        const double* __restrict__ base = M + (long)c * no * ld;
+        for (int a0 = wave; a0 < nv; a0 += 16) {          // four a per round: their loads are in flight together
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int a = a0 + 4 * u;
+                if (a < nv)
+                    for (int k = lane; k < no; k += 64) acc[u] += base[(long)k * ld + (long)a * no + k];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) acc[u] += __shfl_down(acc[u], off, 64);
+                const int a = a0 + 4 * u;
+                if (lane == 0 && a < nv) {
+                    double* o = out_vv + (long)a * nv + c;
+                    *o = (beta == 0.0 ? 0.0 : beta * *o) + alpha * acc[u];
+                }
+            }
         }
         return;
     }
-    const long e = (long)(blockIdx.x - nv) * blockDim.x + threadIdx.x;
-    if (e >= (long)no * no) return;
-    const int k = (int)(e / no), i = (int)(e - (long)k * no);
-    double acc = 0.0;
-    for (int c = 0; c < nv; ++c) acc += M[((long)c * no + k) * ld + (long)c * no + i];
-    out_oo[e] = (beta == 0.0 ? 0.0 : beta * out_oo[e]) + alpha * acc;
+    __shared__ double part[4][64];
+    const int k = blockIdx.x - nv;
+    for (int i0 = 0; i0 < no; i0 += 64) {
+        const int i = i0 + lane;
+        double acc = 0.0;
+        if (i < no) {
+#pragma unroll 4
+            for (int c = wave; c < nv; c += 4) acc += M[((long)c * no + k) * ld + (long)c * no + i];
+        }
+        part[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && i < no) {
+            const double sum = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+            double* o = out_oo + (long)k * no + i;
+            *o = (beta == 0.0 ? 0.0 : beta * *o) + alpha * sum;
+        }
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -2240,7 +2277,7 @@ void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t s)
 void pair_traces(const double* M, int64_t ld, double alpha, double beta, double* out_vv, double* out_oo, int no, int nv,
                  stream_t s) {
     if (no <= 0 || nv <= 0) return;
-    const unsigned blocks = (unsigned)nv + (unsigned)(((long)no * no + 255) / 256);
+    const unsigned blocks = (unsigned)nv + (unsigned)no;
     hipLaunchKernelGGL(pair_traces_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, M, (long)ld, alpha, beta, out_vv, out_oo,
                        no, nv);
     HIP_CHECK(hipGetLastError());
