@@ -1842,6 +1842,10 @@ void gemm(const Gemm& g, stream_t s) {
     }
     else if (BM == 128 && BN == 64 && ntiles(128, 64) < 256) { BM = 64; }
     else if (BM == 64 && BN == 128 && ntiles(64, 128) < 256) { BN = 64; }
+    // short K against a skinny side (the T1 dressing: K = nv or nocc, one side <= nv): the big operand and C are streamed
+    // once from HBM and nothing is reused across tiles — 64x64 blocks (more of them resident, more loads in flight) move
+    // 13-18 % more bytes per second than the wider tiles (tools/probe_stream.py)
+    if (g.K <= 256 && std::min(g.M, g.N) <= 256) { BM = 64; BN = 64; }
     if (const char* ov = getenv("PYMES_GEMM_TILE")) {   // tuning experiments only
         int bm = 0, bn = 0;
         if (sscanf(ov, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) { BM = bm; BN = bn; }
