@@ -648,15 +648,19 @@ void Engine::ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1,
         lpack_.row0 = row0; lpack_.row1 = row1; lpack_.dressed = dressed; lpack_.valid = true;
     }
     ArenaScope scope(arena);
-    double* Sp = arena.alloc(npp * opp);
-    double* Am = arena.alloc(std::max<int64_t>(npm * opm, 1));
-    dev::ladder_pack_T(t2, nullptr, Sp, Am, no, nv, dev::PACK_ROW_HALF, 0, 0, stream);
+    // even pitches (zero pad column / pad row where the pair index is a GEMM K index): every operand qualifies for
+    // 16-byte loads and the LDS-DMA kernel also when o(o+1)/2 is odd — (30,120): 465, (50,200): 1275
+    const int64_t ldp = opp + (opp & 1), ldm = std::max<int64_t>(opm + (opm & 1), 2);
+    auto pitched = [&](double* p, int64_t r, int64_t c, int64_t ld) { return slice(make_view(p, {r, ld}), 1, 0, c); };
+    double* Sp = arena.alloc(npp * ldp);
+    double* Am = arena.alloc(std::max<int64_t>(npm * ldm, 1));
+    dev::ladder_pack_T(t2, nullptr, Sp, Am, no, nv, dev::PACK_ROW_HALF, ldp, ldm, stream);
     stats.permute_calls++;
     stats.permute_bytes += 8.0 * 2.0 * double(v * v * o * o);
     // L rows [row0,row1): [ LS (opp) | LA (opm) ], row length o*o
     TView Lrows = make_view(L + row0 * o * o, {rows, o * o});
     TView LS = slice(Lrows, 1, 0, opp), LA = slice(Lrows, 1, opp, o * o);
-    TView SpT = make_view(Sp, {npp, opp}), AmT = make_view(Am, {npm, opm});
+    TView SpT = pitched(Sp, npp, opp, ldp), AmT = pitched(Am, npm, opm, ldm);
     contract(1.0, make_view(lpack_.Vp, {rows, npp}), "rk", SpT, "kn", 0.0, LS, "rn");
     if (opm > 0) {
         if (npm > 0) contract(1.0, make_view(lpack_.Vm, {rows, npm}), "rk", AmT, "kn", 0.0, LA, "rn");
@@ -667,10 +671,15 @@ void Engine::ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1,
     // I = V~_klij (+ sum_cd V_klcd T_cdij for CCSD).  I_klij = I_lkji, so with S/A = (T_abkl +- T_bakl)/2:
     //   HLS[(a>=b),(i>=j)] = sum_{k>=l} g_kl S_abkl (I_klij + I_lkij),  HLA[(a>b),(i>j)] = sum_{k>l} A_abkl (I_klij - I_lkij)
     // and (I_klij +- I_lkij)/2 = pack(V~_klij) + sum_{c>=d} (V_klcd +- V_kldc) (f_cd S | A)_cdij.
-    double* Ip = arena.alloc(opp * opp);
-    double* Im = arena.alloc(std::max<int64_t>(opp * opm, 1));
-    dev::ladder_pack_T(block(P_klij, dressed).p, nullptr, Ip, Im, no, no, dev::PACK_AM_PROWS, 0, 0, stream);
-    TView Ipv = make_view(Ip, {opp, opp}), Imv = make_view(Im, {opp, opm});
+    double* Ip = arena.alloc(ldp * ldp);
+    double* Im = arena.alloc(ldp * ldm);
+    if (ldp > opp) {
+        dev::memset_zero(Ip + opp * ldp, sizeof(double) * ldp, stream);
+        dev::memset_zero(Im + opp * ldm, sizeof(double) * ldm, stream);
+    }
+    dev::ladder_pack_T(block(P_klij, dressed).p, nullptr, Ip, Im, no, no, dev::PACK_AM_PROWS, ldp, ldm, stream);
+    TView Ipv = pitched(Ip, opp, opp, ldp), Imv = pitched(Im, opp, opm, ldm);        // the defined part
+    TView IpK = pitched(Ip, ldp, opp, ldp), ImK = pitched(Im, ldp, opm, ldm);        // with the zero pad row
     if (hole == 1) {
         if (!static_.count("VpIjab")) {      // static per solve: dressed ijab == undressed ijab
             double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * npp));
@@ -686,13 +695,14 @@ void Engine::ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1,
         axpby(2.0, Ipv, 0.0, Ipv);
         if (opm > 0) axpby(2.0, Imv, 0.0, Imv);
     }
-    double* SpR = arena.alloc(npp * opp);
-    double* AmR = arena.alloc(npp * opp);
-    dev::ladder_pack_T(t2, nullptr, SpR, AmR, no, nv, dev::PACK_COL_HALF | dev::PACK_AM_PROWS | dev::PACK_AM_PCOLS, 0, 0, stream);
+    double* SpR = arena.alloc(npp * ldp);
+    double* AmR = arena.alloc(npp * ldp);
+    dev::ladder_pack_T(t2, nullptr, SpR, AmR, no, nv, dev::PACK_COL_HALF | dev::PACK_AM_PROWS | dev::PACK_AM_PCOLS, ldp, ldp, stream);
     stats.permute_calls += 2;
     stats.permute_bytes += 8.0 * 2.0 * double(v * v * o * o);
-    contract(1.0, slice(make_view(SpR, {npp, opp}), 0, row0, row1), "rk", Ipv, "kn", 1.0, LS, "rn");
-    if (opm > 0) contract(1.0, slice(make_view(AmR, {npp, opp}), 0, row0, row1), "rk", Imv, "kn", 1.0, LA, "rn");
+    // the (k,l) pair is the GEMM K index: it runs over the padded pitch (zero pad column in the rows of T, zero pad row in I)
+    contract(1.0, slice(make_view(SpR, {npp, ldp}), 0, row0, row1), "rk", IpK, "kn", 1.0, LS, "rn");
+    if (opm > 0) contract(1.0, slice(make_view(AmR, {npp, ldp}), 0, row0, row1), "rk", ImK, "kn", 1.0, LA, "rn");
 }
 
 // T1 dressing of the ladders on the amplitude side.  With X_a^p = delta_ap - t_ak delta_pk the dressed ladder and the

@@ -1279,40 +1279,39 @@ __global__ void rows_unpack_kernel(const double* __restrict__ Q, double* __restr
     }
 }
 
-// partial traces of a pair matrix M[(c,k)][(b,j)] (device_api.h).  Blocks [0,nv): one c each — a wave takes every
-// fourth a, its lanes the k of sum_k M[(c,k)][(a,k)] (one element per 128-byte line: 1/3 of the lines of M in all), summed
-// by a shuffle tree.  Blocks [nv, nv+no): one k each — lanes over i, the four waves over c = w, w+4, ..., added up in
-// wave order through LDS.  Fixed summation orders: deterministic.
+// partial traces of a pair matrix M[(c,k)][(b,j)] (device_api.h).  Blocks [0, nv * ceil(nv/16)): one c and sixteen a
+// each — a wave takes four a (their loads in flight together), its lanes the k of sum_k M[(c,k)][(a,k)] (one element per
+// 128-byte line: 1/3 of the lines of M in all), summed by a shuffle tree.  The no blocks behind them: one k each — lanes
+// over i, the four waves over c = w, w+4, ..., added up in wave order through LDS.  Fixed summation orders: deterministic.
 __global__ void __launch_bounds__(256) pair_traces_kernel(const double* __restrict__ M, long ld, double alpha, double beta,
                                                           double* __restrict__ out_vv, double* __restrict__ out_oo,
                                                           int no, int nv) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if ((int)blockIdx.x < nv) {
-        const int c = blockIdx.x;
+    const int agroups = (nv + 15) / 16, nvv = nv * agroups;
+    if ((int)blockIdx.x < nvv) {
+        const int c = blockIdx.x / agroups, a0 = (blockIdx.x - c * agroups) * 16 + wave;
         const double* __restrict__ base = M + (long)c * no * ld;
-        for (int a0 = wave; a0 < nv; a0 += 16) {          // four a per round: their loads are in flight together
-            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int a = a0 + 4 * u;
-                if (a < nv)
-                    for (int k = lane; k < no; k += 64) acc[u] += base[(long)k * ld + (long)a * no + k];
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int a = a0 + 4 * u;
+            if (a < nv)
+                for (int k = lane; k < no; k += 64) acc[u] += base[(long)k * ld + (long)a * no + k];
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 4; ++u) {
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) acc[u] += __shfl_down(acc[u], off, 64);
-                const int a = a0 + 4 * u;
-                if (lane == 0 && a < nv) {
-                    double* o = out_vv + (long)a * nv + c;
-                    *o = (beta == 0.0 ? 0.0 : beta * *o) + alpha * acc[u];
-                }
+            for (int off = 32; off > 0; off >>= 1) acc[u] += __shfl_down(acc[u], off, 64);
+            const int a = a0 + 4 * u;
+            if (lane == 0 && a < nv) {
+                double* o = out_vv + (long)a * nv + c;
+                *o = (beta == 0.0 ? 0.0 : beta * *o) + alpha * acc[u];
             }
         }
         return;
     }
     __shared__ double part[4][64];
-    const int k = blockIdx.x - nv;
+    const int k = blockIdx.x - nvv;
     for (int i0 = 0; i0 < no; i0 += 64) {
         const int i = i0 + lane;
         double acc = 0.0;
@@ -2281,7 +2280,7 @@ void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t s)
 void pair_traces(const double* M, int64_t ld, double alpha, double beta, double* out_vv, double* out_oo, int no, int nv,
                  stream_t s) {
     if (no <= 0 || nv <= 0) return;
-    const unsigned blocks = (unsigned)nv + (unsigned)no;
+    const unsigned blocks = (unsigned)nv * (unsigned)((nv + 15) / 16) + (unsigned)no;
     hipLaunchKernelGGL(pair_traces_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, M, (long)ld, alpha, beta, out_vv, out_oo,
                        no, nv);
     HIP_CHECK(hipGetLastError());
