@@ -37,6 +37,8 @@ def reference_flops(no, nv, is_dcsd=False):
 
 
 TRAFFIC_CSV = os.path.join("profiles", "r02", "bench_c3_pmc_hbm_traffic.csv")
+# workloads with committed counter passes: (nocc, nvirt) -> summary written by tools/profile_bench.sh
+TRAFFIC_CSVS = {(50, 200): TRAFFIC_CSV, (20, 80): os.path.join("profiles", "r02", "bench_c2_pmc_hbm_traffic.csv")}
 
 
 def kernels_hash():
@@ -48,12 +50,13 @@ def pmc_traffic_per_launch(no, nv, world, kernel_prefix):
     """(HBM bytes per launch of the kernels whose name starts with `kernel_prefix`, provenance string).
 
     Hardware counters cannot be read from inside the run, so the figure comes from the committed rocprofv3 PMC passes of
-    THIS command at the default workload (tools/profile_bench.sh -> TRAFFIC_CSV: FETCH_SIZE doubled per the gfx950
+    THIS command at the workloads of TRAFFIC_CSVS (tools/profile_bench.sh: FETCH_SIZE doubled per the gfx950
     correction + WRITE_SIZE, separate passes).  The CSV records the sha256 of kernels.hip it was collected with; when
     the kernels have changed since, or for any other workload, the value is null rather than stale."""
-    path = os.path.join(ROOT, TRAFFIC_CSV)
-    if (no, nv, world) != (50, 200, 1):
+    if world != 1 or (no, nv) not in TRAFFIC_CSVS:
         return None, "not collected for this workload"
+    TRAFFIC_CSV = TRAFFIC_CSVS[(no, nv)]
+    path = os.path.join(ROOT, TRAFFIC_CSV)
     if not os.path.exists(path):
         return None, f"{TRAFFIC_CSV} missing"
     launches, gbytes, recorded = 0, 0.0, None
