@@ -204,3 +204,26 @@ def test_mixer_history_survives_solve_calls(sim):
     f3, V3, _, _ = synthetic_case(no, nv + 1, seed=8, scale=0.3)
     r3 = quiet(s.solve, f3, V3)
     assert abs(r3["ccsd e"] - oc.ccsd_solve(no, f3, V3, delta_e=1e-10)["e"]) < 1e-9
+
+
+def test_singles_sums_are_partial_traces_of_the_ring_intermediate():
+    """for V_pqrs = V_qpsr and T_abij = T_baji the V.T sums of ccsd.py:434 / :436 equal those of X_ki / X_ac
+    (ccd.py:213-220), and both are partial traces of Y = Vd Tt_d (ccd.py:202) — the identity the product path relies on
+    when it drops the four products.  Pure numpy on the oracle's index conventions."""
+    rng = np.random.default_rng(7)
+    o, v = 3, 5
+    n = o + v
+    V = rng.standard_normal((n, n, n, n))
+    V = V + V.transpose(1, 0, 3, 2)                       # electron-exchange symmetry only (not hermitian: TC-like)
+    Vijab = V[:o, :o, o:, o:]
+    T = rng.standard_normal((v, v, o, o))
+    T = T + T.transpose(1, 0, 3, 2)
+    Tt = 2.0 * T - T.transpose(1, 0, 2, 3)                # ccd.py:199
+    Tp = 2.0 * T - T.transpose(0, 1, 3, 2)                # ccsd.py:430
+    S_ac = np.einsum("adkl,lkdc->ac", Tt, Vijab)          # ccd.py:213
+    S_ki = np.einsum("cdil,lkdc->ki", Tt, Vijab)          # ccd.py:215
+    assert np.abs(np.einsum("jkcb,abjk->ac", Vijab, Tp) - S_ac).max() < 1e-12       # ccsd.py:436
+    assert np.abs(np.einsum("kjbc,bcij->ki", Vijab, Tp) - S_ki).max() < 1e-12       # ccsd.py:434
+    Y = np.einsum("klcd,dblj->ckbj", Vijab, Tt)           # ccd.py:202 as the pair matrix [(c,k),(b,j)]
+    assert np.abs(np.einsum("ckak->ac", Y) - S_ac).max() < 1e-12
+    assert np.abs(np.einsum("ckci->ki", Y) - S_ki).max() < 1e-12
