@@ -227,3 +227,37 @@ def test_singles_sums_are_partial_traces_of_the_ring_intermediate():
     Y = np.einsum("klcd,dblj->ckbj", Vijab, Tt)           # ccd.py:202 as the pair matrix [(c,k),(b,j)]
     assert np.abs(np.einsum("ckak->ac", Y) - S_ac).max() < 1e-12
     assert np.abs(np.einsum("ckci->ki", Y) - S_ki).max() < 1e-12
+
+
+def test_slab_halves_equal_the_whole(sim):
+    """include/pymes_amd.h: PYMES_SLAB_RINGS_ONLY + PYMES_SLAB_LADDERS_ONLY (one process per GPU issues them separately so
+    that the all-gathers of the ring rows fly during the ladders) produce what the single call produces, for every
+    simulated rank, with and without the T1 dressing."""
+    no, nv = 3, 5
+    f, V, t1, t2 = random_case(no, nv, 11, symmetric=True)
+    ctx = Context(no, nv)
+    ctx.set_V_pqrs(V)
+    ov, npp = no * nv, nv * (nv + 1) // 2
+    dF, dT1, dT2 = ctx.array(f), ctx.array(t1), ctx.array(t2)
+    ctx.dress_V(dT1, ["klij", "iajb", "iabj", "abcd"])          # abcd: read by the ladders of the mode without t1 / QK
+    for world in (1, 3):
+        pad = lambda n: -(-n // world) * world
+        for dcd in (False, True):
+            for with_t1 in (False, True):
+                outs = []
+                for split in (False, True):
+                    ETd, ETx = ctx.zeros((pad(ov), ov)), ctx.zeros((pad(ov), ov))
+                    L, QK = ctx.zeros((pad(npp), no * no)), ctx.zeros((pad(ov), no * no))
+                    kw = dict(is_dcd=dcd, dressed=True)
+                    if with_t1:
+                        kw.update(t1=dT1, QK=QK)
+                    for rank in range(world):
+                        if split:
+                            ctx.residual_slab(dF, dT2, ETd, ETx, L, rank, world, part="rings", **kw)
+                            ctx.residual_slab(dF, dT2, ETd, ETx, L, rank, world, part="ladders", **kw)
+                        else:
+                            ctx.residual_slab(dF, dT2, ETd, ETx, L, rank, world, **kw)
+                    outs.append([x.get() for x in (ETd, ETx, L, QK)])
+                for a, b in zip(*outs):
+                    assert np.array_equal(a, b), (world, dcd, with_t1)
+    ctx.close()
