@@ -232,6 +232,12 @@ int pymes_cc_update_to(pymes_ctx* ctx, double* t_out_dev, double* dt_dev, const 
  * the T1-free form of the residual: exp(-T1) H exp(T1) = H then, no dressing at all (pymes_amd/solver/ccsd.py). */
 int pymes_energy_norms(pymes_ctx* ctx, const double* f_dev, const double* t1_dev, const double* t2_dev,
                        const double* dt2_dev, double* out_host);
+/* The same six sums over the virtual pairs of rank `rank` of `world` only, from the compact tiles [pairs][2][o*o] of the
+ * pair-sharded tail (tc_dev, dtc_dev: pymes_pairs_pack layout): partial sums that the caller all-reduces — the energy of
+ * ccsd.py:458-466 / ccd.py:256-262 then needs no replicated T2, so the all-gather of the new amplitudes can fly while the
+ * next iteration's T1-only work runs.  The T1 sums out[0], out[5] are non-zero on rank 0 only. */
+int pymes_energy_norms_pairs(pymes_ctx* ctx, const double* f_dev, const double* t1_dev, const double* tc_dev,
+                             const double* dtc_dev, int rank, int world, double* out_host);
 /* CCSD.get_energy, ccsd.py:458-466: e_out = {one-body, direct, exchange}; f is the UNDRESSED Fock */
 int pymes_ccsd_energy(pymes_ctx* ctx, const double* f_dev, const double* t1_dev, const double* t2_dev,
                       double* e_out_host);

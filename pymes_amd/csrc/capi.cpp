@@ -432,6 +432,14 @@ int pymes_energy_norms(pymes_ctx* ctx, const double* f, const double* t1, const 
         E(ctx).energy_norms(f, t1, t2, dt2, out);
     });
 }
+int pymes_energy_norms_pairs(pymes_ctx* ctx, const double* f, const double* t1, const double* tc, const double* dtc,
+                             int rank, int world, double* out) {
+    return guarded([&] {
+        need(tc, "tc"); need(out, "out");
+        if ((f == nullptr) != (t1 == nullptr)) throw pymes::Error("f and t1 must be given together");
+        E(ctx).energy_norms_pairs(f, t1, tc, dtc, rank, world, out);
+    });
+}
 int pymes_ccsd_energy(pymes_ctx* ctx, const double* f, const double* t1, const double* t2, double* e_out) {
     return guarded([&] {
         need(f, "f"); need(t1, "t1"); need(t2, "t2"); need(e_out, "e_out");

@@ -1166,6 +1166,22 @@ void Engine::energy_norms(const double* f, const double* t1, const double* t2, c
     out[5] = r[5];
 }
 
+// the same over the compact tiles of this rank's pairs (one process per GPU): partial sums, to be all-reduced; the T1
+// terms enter on rank 0
+void Engine::energy_norms_pairs(const double* f, const double* t1, const double* tc, const double* dtc, int rank, int world,
+                                double out[6]) {
+    int64_t r0, r1;
+    pair_chunk(rank, world, r0, r1);
+    double r[6];
+    dev::energy_norms_pairs(f, t1, tc, get_static("Edir"), get_static("Eex"), dtc, no, nv, r0, r1, rank == 0, r, stream);
+    out[0] = 2.0 * r[0];
+    out[1] = 2.0 * r[1];
+    out[2] = -1.0 * r[2];
+    out[3] = r[3];
+    out[4] = r[4];
+    out[5] = r[5];
+}
+
 void Engine::ccsd_energy(const double* f, const double* t1, const double* t2, double out[3]) {
     double r[6];
     energy_norms(f, t1, t2, nullptr, r);

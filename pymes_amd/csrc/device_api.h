@@ -96,6 +96,11 @@ void dots(int npairs, const double* const* x, const double* const* y, const int6
 // t1 / f may be null (CCD: out[0] = out[5] = 0, tau = t2).  Result on host (synchronises the stream).
 void energy_norms(const double* f, const double* t1, const double* t2, const double* Edir, const double* Eex,
                   const double* dt2, int no, int nv, double out_host[6], stream_t s);
+// the same sums over the virtual pairs P(a,b) in [r0,r1) only, amplitudes given as compact tiles tc / dtc
+// [pair][2][o*o] (tile (a,b), tile (b,a); pairs_pack); the T1 sums out[0], out[5] only when with_t1 (one rank of many)
+void energy_norms_pairs(const double* f, const double* t1, const double* tc, const double* Edir, const double* Eex,
+                        const double* dtc, int no, int nv, int64_t r0, int64_t r1, bool with_t1, double out_host[6],
+                        stream_t s);
 // max |A[p,q,r,s] - B[q,p,s,r]| and max |A| for A [d0,d1,d2,d3], B [d1,d0,d3,d2] (electron-exchange partner; B may be
 // A itself when d0 == d1 and d2 == d3).  Result on host (synchronises the stream).
 void exchange_asymmetry(const double* A, const double* B, const int64_t d[4], double out_host[2], stream_t s);

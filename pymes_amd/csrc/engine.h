@@ -183,6 +183,8 @@ class Engine {
     // energies (ccsd.py:458-466 / ccd.py:256-262 when f, t1 are null) and the squared norms of t2 and dt2
     // (ccsd.py:196-197) in one pass: out = {one-body, direct, exchange, |t2|^2, |dt2|^2, |t1|^2}
     void energy_norms(const double* f, const double* t1, const double* t2, const double* dt2, double out[6]);
+    void energy_norms_pairs(const double* f, const double* t1, const double* tc, const double* dtc, int rank, int world,
+                            double out[6]);
     void invalidate_static();
 
     double* eps_o = nullptr;

@@ -1177,6 +1177,60 @@ __global__ void __launch_bounds__(256) residual_assemble_kernel(const double* V,
 // ---- pair-sharded tail of the iteration (one process per GPU): a rank owns the virtual pairs P(a,b) in [r0,r1), a >= b,
 // and keeps the tiles X[a,b,:,:] and X[b,a,:,:] of every amplitude-sized quantity in the compact layout
 // Xc[P - r0][2][o*o] (tile 1 is zero for a == b, so that dot products over Xc equal those over the full array) -----
+// energy_norms over the compact tiles of the pairs [r0, r0 + npairs): block-stride over the tiles (pair, half)
+__global__ void __launch_bounds__(256) energy_norms_pairs_kernel(const double* __restrict__ f, const double* __restrict__ t1,
+                                                                 const double* __restrict__ tc, const double* __restrict__ Edir,
+                                                                 const double* __restrict__ Eex, const double* __restrict__ dtc,
+                                                                 int no, int nv, long r0, long npairs, int with_t1,
+                                                                 double* __restrict__ partial) {
+    __shared__ double sh[4];
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s0 = 0.0, s5 = 0.0;
+    const long o2 = (long)no * no;
+    for (long tile = blockIdx.x; tile < 2 * npairs; tile += gridDim.x) {
+        int a, b;
+        unrank_pair(r0 + (tile >> 1), a, b);
+        if (tile & 1) {
+            if (a == b) continue;          // a diagonal pair has one tile only
+            const int x = a; a = b; b = x;
+        }
+        const double* __restrict__ x = tc + tile * o2;
+        const double* __restrict__ d = dtc ? dtc + tile * o2 : nullptr;
+        const double* __restrict__ ed = Edir + ((long)a * nv + b) * o2;
+        const double* __restrict__ ex = Eex + ((long)a * nv + b) * o2;
+        for (int e = threadIdx.x; e < o2; e += blockDim.x) {
+            const double v = x[e];
+            double tau = v;
+            if (t1) {
+                const int i = e / no, j = e - i * no;
+                tau += t1[a * no + i] * t1[b * no + j];
+            }
+            s1 += tau * ed[e];
+            s2 += tau * ex[e];
+            s3 += v * v;
+            if (d) s4 += d[e] * d[e];
+        }
+    }
+    if (with_t1 && t1 && f) {
+        const long n = no + nv, ov = (long)no * nv;
+        for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < ov; e += (long)gridDim.x * blockDim.x) {
+            const long a = e / no, i = e - a * no;
+            const double y = t1[e];
+            s0 += f[i * n + no + a] * y;
+            s5 += y * y;
+        }
+    }
+    const double q0 = block_sum(s0, sh), q1 = block_sum(s1, sh), q2 = block_sum(s2, sh), q3 = block_sum(s3, sh),
+                 q4 = block_sum(s4, sh), q5 = block_sum(s5, sh);
+    if (threadIdx.x == 0) {
+        partial[0 * kDotBlocks + blockIdx.x] = q0;
+        partial[1 * kDotBlocks + blockIdx.x] = q1;
+        partial[2 * kDotBlocks + blockIdx.x] = q2;
+        partial[3 * kDotBlocks + blockIdx.x] = q3;
+        partial[4 * kDotBlocks + blockIdx.x] = q4;
+        partial[5 * kDotBlocks + blockIdx.x] = q5;
+    }
+}
+
 __global__ void __launch_bounds__(256) pairs_pack_kernel(const double* __restrict__ full, double* __restrict__ Xc,
                                                          int no, int nv, long r0) {
     int a, b;
@@ -2247,6 +2301,24 @@ void pairs_pack(const double* full, double* Xc, int no, int nv, int64_t r0, int6
     if (r1 <= r0) return;
     hipLaunchKernelGGL(pairs_pack_kernel, dim3((unsigned)(r1 - r0)), dim3(256), 0, (hipStream_t)s, full, Xc, no, nv, (long)r0);
     HIP_CHECK(hipGetLastError());
+}
+void energy_norms_pairs(const double* f, const double* t1, const double* tc, const double* Edir, const double* Eex,
+                        const double* dtc, int no, int nv, int64_t r0, int64_t r1, bool with_t1, double out_host[6],
+                        stream_t s) {
+    hipStream_t st = (hipStream_t)s;
+    const int dv = current_device();
+    ensure_dot_ws(dv);
+    const long npairs = std::max<long>(0, (long)(r1 - r0));
+    const int nb = (int)std::max<long>(1, std::min<long>(kDotBlocks, 2 * npairs));
+    hipLaunchKernelGGL(energy_norms_pairs_kernel, dim3(nb), dim3(256), 0, st, f, t1, tc, Edir, Eex, dtc, no, nv, (long)r0,
+                       npairs, with_t1 ? 1 : 0, g_dot_ws[dv]);
+    HIP_CHECK(hipGetLastError());
+    double* out_dev = g_dot_ws[dv] + 16 * kDotBlocks;
+    hipLaunchKernelGGL(dots_stage2_kernel, dim3(6), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(g_dot_host[dv], out_dev, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    for (int i = 0; i < 6; ++i) out_host[i] = g_dot_host[dv][i];
 }
 void pairs_unpack(const double* Xc, double* full, int no, int nv, int64_t r0, int64_t r1, stream_t s) {
     if (r1 <= r0) return;

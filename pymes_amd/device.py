@@ -453,6 +453,14 @@ class Context:
                       C.c_void_p(dt2.ptr if dt2 is not None else 0), out)
         return tuple(out[:])
 
+    def energy_norms_pairs(self, f, t1, tc, dtc, rank, world):
+        """This rank's partial sums of ``energy_norms`` from the compact tiles of its pairs (to be all-reduced)."""
+        out = (C.c_double * 6)()
+        self.lib.call("pymes_energy_norms_pairs", self.handle, C.c_void_p(f.ptr if f is not None else 0),
+                      C.c_void_p(t1.ptr if t1 is not None else 0), C.c_void_p(tc.ptr),
+                      C.c_void_p(dtc.ptr if dtc is not None else 0), int(rank), int(world), out)
+        return np.array(out[:])
+
     # ---- launch graphs ----------------------------------------------------------------
     def graph_begin(self):
         self.lib.call("pymes_graph_begin", self.handle)

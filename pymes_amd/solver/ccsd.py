@@ -194,13 +194,24 @@ class CCSD(ccd.CCD):
         if dist_on and st["sym"]:
             # K-sharded partial sums, all-reduced: the T1.V intermediates of the dressed Fock (:163, this rank's chunk of
             # j) and the slab's small V.T intermediates (X_ki, hole-ladder V_klcd T_cdij; this rank's chunk of c / (c,d))
+            # What needs T1 only comes first: the all-gather of the new T2 that the previous iteration's tail started is
+            # still in flight (0.8 GB at (50,200)) and is awaited — and unpacked into the replicated array — right
+            # before the first kernel that reads T2.
             ctx.dress_fock_partial(t1, st["W"], rank, world)
+            red = [pdist.allreduce_tensor_start(st["W_t"], ctx)]
+            # V~_iajb / V~_iabj only for the second-index range that this rank's column slab reads
+            c0, c1 = pdist.slab_rows(ctx.no * ctx.nv, rank, world)
+            ctx.dress_V(t1, ("klij",))                                                # :165
+            if c1 > c0:
+                ctx.dress_V(t1, ("iajb", "iabj"), q_range=(c0 // ctx.no, -(-c1 // ctx.no)))
+            self._await_t2(st)
             ctx.slab_prepare(t2, st["P"], rank, world, is_dcd=self.is_dcd)
-            red = [pdist.allreduce_tensor_start(st["W_t"], ctx), pdist.allreduce_tensor_start(st["P_t"], ctx)]
+            red.append(pdist.allreduce_tensor_start(st["P_t"], ctx))
             for work in red:
                 work.wait()
             ctx.dress_fock_finish(st["f"], t1, st["W"], st["fd"])
         else:
+            self._await_t2(st)
             ctx.dress_fock(st["f"], t1, st["fd"])                    # :163
         # the singles residual of the symmetric path is an all-reduced partial sum: it lives in its exchange buffer
         r1 = st["R1"] if st["sym"] else ctx.pool_get(t1.shape)
@@ -210,12 +221,7 @@ class CCSD(ccd.CCD):
             # V_abcd is never dressed: its T1 dressing (:165, ccsd.py:414-419) is carried by tau = T2 + T1 T1
             # inside the ladders, that of V_abij by Q_kb and two small products inside the finish (include/pymes_amd.h,
             # pymes_residual_slab).  The singles residual is enqueued after the all-gathers have been started: overlap.
-            if dist_on:      # V~_iajb / V~_iabj only for the second-index range that this rank's column slab reads
-                c0, c1 = pdist.slab_rows(ctx.no * ctx.nv, rank, world)
-                ctx.dress_V(t1, ("klij",))                                            # :165
-                if c1 > c0:
-                    ctx.dress_V(t1, ("iajb", "iabj"), q_range=(c0 // ctx.no, -(-c1 // ctx.no)))
-            else:
+            if not dist_on:  # (one process per GPU: dressed above, before T2 was needed)
                 ctx.dress_V(t1, ("klij", "iajb", "iabj"))                             # :165
             # :171 in two halves: the ring products first, so that the all-gathers of their rows (ETd, ETx: 1.6 of the 1.8 GB
             # that an iteration exchanges at (50,200)) fly while the ladders — whose rows of L never leave the rank in the
@@ -309,15 +315,25 @@ class CCSD(ccd.CCD):
             mine = DeviceArray(ctx, st["Tall"].ptr + 8 * lo * 2 * ctx.no * ctx.no, (hi - lo, 2, ctx.no * ctx.no),
                                owned=False, keepalive=st["Tall"])
             mine.copy_from(DeviceArray(ctx, tc.ptr, mine.shape, owned=False, keepalive=tc))
-        pdist.exchange_rows(st["Tall_t"], rank, world, ctx)
-        ctx.pairs_unpack(st["Tall"], t2, world)
-        e = ctx.ccsd_energy(st["f"], t1, t2)                                          # :189-192
-        nt, nr = np.sqrt(pdist.allreduce_sum(ctx.dots([tc, dtc], [tc, dtc])))        # :196-197
+        # the all-gather of the new T2 is only STARTED: the energy and the norms (:189-197) come from the compact tiles
+        # (partial sums, one all-reduce of six doubles), so nothing below needs the replicated array; the next iteration
+        # — or whoever reads st["t2"] — completes it (_await_t2)
+        st["t2_pending"] = pdist.exchange_rows_start(st["Tall_t"], rank, world, ctx)
+        e1, ed, ex, nt2, nr2, _ = pdist.allreduce_sum(ctx.energy_norms_pairs(st["f"], t1, tc, dtc, rank, world))
         if not self.is_diis:
             ctx.pool_put(dt1)
             ctx.pool_put(dtc)
         st["t1"], st["Tc"] = t1, tc
-        return e[0], e[1], e[2], nt, nr
+        return e1, ed, ex, np.sqrt(nt2), np.sqrt(nr2)
+
+    @staticmethod
+    def _await_t2(st):
+        """Complete the exchange of the new amplitudes that the pair-sharded tail left in flight: wait for the all-gather
+        of the compact tiles and unpack them into the replicated T2."""
+        work = st.pop("t2_pending", None)
+        if work is not None:
+            work.wait()
+            st["ctx"].pairs_unpack(st["Tall"], st["t2"], st["world"])
 
     @staticmethod
     def _ladder_rows_plain(ctx, t2, lad, lo, hi):
@@ -370,6 +386,7 @@ class CCSD(ccd.CCD):
             print_logging_info("CCSD correlation energy = {:.12f}".format(e_ccsd), level=1)
             print_logging_info("{:.3f} seconds spent on ccsd".format((time.time() - time_ccsd)), level=1)
             self.t_T_ai = st["t1"].get()
+            self._await_t2(st)
             self.t_T_abij = st["t2"].get()
             if amps is not None and not self.is_diis and iteration > 0:
                 # without DIIS the reference keeps updating the caller's arrays in place (ccsd.py:178-179)

@@ -162,6 +162,38 @@ void energy_norms(const double* f, const double* t1, const double* t2, const dou
             }
 }
 
+void energy_norms_pairs(const double* f, const double* t1, const double* tc, const double* Edir, const double* Eex,
+                        const double* dtc, int no, int nv, int64_t r0, int64_t r1, bool with_t1, double out[6], stream_t) {
+    for (int q = 0; q < 6; ++q) out[q] = 0.0;
+    const int64_t o2 = (int64_t)no * no;
+    for (int64_t r = r0; r < r1; ++r) {
+        int a = 0;
+        while ((int64_t)(a + 1) * (a + 2) / 2 <= r) ++a;
+        const int b = (int)(r - (int64_t)a * (a + 1) / 2);
+        for (int half = 0; half < 2; ++half) {
+            if (half && a == b) continue;
+            const int p = half ? b : a, q = half ? a : b;
+            const double* x = tc + ((r - r0) * 2 + half) * o2;
+            const double* d = dtc ? dtc + ((r - r0) * 2 + half) * o2 : nullptr;
+            for (int i = 0; i < no; ++i)
+                for (int j = 0; j < no; ++j) {
+                    const int64_t e = (int64_t)i * no + j, full = ((int64_t)p * nv + q) * o2 + e;
+                    const double tau = x[e] + (t1 ? t1[p * no + i] * t1[q * no + j] : 0.0);
+                    out[1] += tau * Edir[full];
+                    out[2] += tau * Eex[full];
+                    out[3] += x[e] * x[e];
+                    if (d) out[4] += d[e] * d[e];
+                }
+        }
+    }
+    if (with_t1 && t1 && f)
+        for (int a = 0; a < nv; ++a)
+            for (int i = 0; i < no; ++i) {
+                out[0] += f[(int64_t)i * (no + nv) + no + a] * t1[a * no + i];
+                out[5] += t1[a * no + i] * t1[a * no + i];
+            }
+}
+
 void exchange_asymmetry(const double* A, const double* B, const int64_t d[4], double out[2], stream_t) {
     out[0] = out[1] = 0.0;
     for (int64_t p = 0; p < d[0]; ++p)

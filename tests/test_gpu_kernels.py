@@ -214,3 +214,37 @@ def test_exchange_asymmetry_kernel(gpu_lib):
             assert asym(B2)[0] == np.inf
         finally:
             ctx.close()
+
+
+def test_energy_norms_over_pairs(gpu_lib):
+    """pymes_energy_norms_pairs: the partial sums of all ranks (compact tiles of their pairs) add up to the one-pass sums
+    over the full arrays, for ragged pair chunks and with the T1 terms entering once."""
+    from oracle.cases import random_case
+    no, nv = 5, 9
+    f, V, t1, t2 = random_case(no, nv, 3, symmetric=True)
+    rng = np.random.default_rng(5)
+    ctx = Context(no, nv, lib=gpu_lib)
+    try:
+        ctx.set_V_pqrs(V)
+        dF, dT1, dT2, dD = ctx.array(f), ctx.array(t1), ctx.array(t2), ctx.array(rng.standard_normal(t2.shape))
+        full = np.array(ctx.energy_norms(dF, dT1, dT2, dD))
+        npp = nv * (nv + 1) // 2
+        for world in (1, 3, 4, 7):
+            chunk = -(-npp // world)
+            tot = np.zeros(6)
+            for rank in range(world):
+                tc, dtc = ctx.zeros((chunk, 2, no * no)), ctx.zeros((chunk, 2, no * no))
+                ctx.pairs_pack(dT2, tc, rank, world)
+                ctx.pairs_pack(dD, dtc, rank, world)
+                tot += ctx.energy_norms_pairs(dF, dT1, tc, dtc, rank, world)
+            assert np.allclose(tot, full, rtol=1e-12, atol=1e-12), (world, tot, full)
+        # CCD form: no T1
+        full = np.array(ctx.energy_norms(None, None, dT2, None))
+        tot = np.zeros(6)
+        for rank in range(3):
+            tc = ctx.zeros((-(-npp // 3), 2, no * no))
+            ctx.pairs_pack(dT2, tc, rank, 3)
+            tot += ctx.energy_norms_pairs(None, None, tc, None, rank, 3)
+        assert np.allclose(tot, full, rtol=1e-12, atol=1e-12)
+    finally:
+        ctx.close()

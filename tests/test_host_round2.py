@@ -261,3 +261,25 @@ def test_slab_halves_equal_the_whole(sim):
                 for a, b in zip(*outs):
                     assert np.array_equal(a, b), (world, dcd, with_t1)
     ctx.close()
+
+
+def test_energy_norms_over_pairs(sim):
+    """Host logic of pymes_energy_norms_pairs (the GPU kernel has the same test in test_gpu_kernels.py)."""
+    no, nv = 3, 5
+    f, V, t1, t2 = random_case(no, nv, 3, symmetric=True)
+    rng = np.random.default_rng(5)
+    ctx = Context(no, nv)
+    ctx.set_V_pqrs(V)
+    dF, dT1, dT2, dD = ctx.array(f), ctx.array(t1), ctx.array(t2), ctx.array(rng.standard_normal(t2.shape))
+    full = np.array(ctx.energy_norms(dF, dT1, dT2, dD))
+    npp = nv * (nv + 1) // 2
+    for world in (1, 2, 4):
+        chunk = -(-npp // world)
+        tot = np.zeros(6)
+        for rank in range(world):
+            tc, dtc = ctx.zeros((chunk, 2, no * no)), ctx.zeros((chunk, 2, no * no))
+            ctx.pairs_pack(dT2, tc, rank, world)
+            ctx.pairs_pack(dD, dtc, rank, world)
+            tot += ctx.energy_norms_pairs(dF, dT1, tc, dtc, rank, world)
+        assert np.allclose(tot, full, rtol=1e-12, atol=1e-13), world
+    ctx.close()

@@ -52,7 +52,7 @@ def main():
     calls = {name: getattr(ctx, name) for name in ("dress_fock", "dress_fock_partial", "dress_fock_finish", "xvv_partial",
                                                    "dress_V", "slab_prepare", "residual_slab", "singles_residual", "singles_residual_partial",
                                                    "residual_finish_pairs", "cc_update", "cc_update_pairs", "pairs_unpack",
-                                                   "ccsd_energy", "dots", "lincomb")}
+                                                   "ccsd_energy", "energy_norms_pairs", "dots", "lincomb")}
 
     def timed(name):
         fn = calls[name]
