@@ -113,7 +113,8 @@ int pymes_ccsd_dress_fock(pymes_ctx* ctx, const double* f_dev, const double* t1_
 #define PYMES_DRESS_ABIJ_REDUCED (1u << 16)
 int pymes_ccsd_dress_V(pymes_ctx* ctx, const double* t1_dev, uint32_t block_mask);
 /* the same for the range [p_begin,p_end) of the FIRST and [q_begin,q_end) of the SECOND index only (an empty range =
- * the whole index; a restricted index must be virtual in every selected block): "iajb" / "iabj" with a q-range is what
+ * the whole index; a block in which the restricted index is occupied is dressed as a whole, so "klij" may ride in the same
+ * call and share its V_klcd t_dj intermediate with "iabj"): "iajb" / "iabj" with a q-range is what
  * one rank's column slab of pymes_residual_slab reads, "abij" with (p,q) = (rows a of the rank's pairs, b below their
  * end) and the transposed pair of ranges is what the pair-sharded tail reads — no exchange */
 int pymes_ccsd_dress_V_slab(pymes_ctx* ctx, const double* t1_dev, uint32_t block_mask, int p_begin, int p_end,

@@ -697,7 +697,8 @@ void Engine::ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1,
     }
     double* SpR = arena.alloc(npp * ldp);
     double* AmR = arena.alloc(npp * ldp);
-    dev::ladder_pack_T(t2, nullptr, SpR, AmR, no, nv, dev::PACK_COL_HALF | dev::PACK_AM_PROWS | dev::PACK_AM_PCOLS, ldp, ldp, stream);
+    dev::ladder_pack_T(t2, nullptr, SpR, AmR, no, nv, dev::PACK_COL_HALF | dev::PACK_AM_PROWS | dev::PACK_AM_PCOLS, ldp, ldp, stream,
+                       row0, row1);                   // only the rows this call multiplies
     stats.permute_calls += 2;
     stats.permute_bytes += 8.0 * 2.0 * double(v * v * o * o);
     // the (k,l) pair is the GEMM K index: it runs over the padded pitch (zero pad column in the rows of T, zero pad row in I)
@@ -810,7 +811,7 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
         // DCSD keeps only V~_klij in the hole ladder proper (ccd.py:178), but the (k,l)-bra part still sees Ifull
         axpby(2.0, Ipv, 0.0, Ipv);
         if (opm > 0) axpby(2.0, Imv, 0.0, Imv);
-        dev::ladder_pack_T(t2, nullptr, SpR, AmR, no, nv, rflags, ldp, ldp, stream);
+        dev::ladder_pack_T(t2, nullptr, SpR, AmR, no, nv, rflags, ldp, ldp, stream, row0, row1);
         contract(1.0, rowsS(), "rk", IpK, "kn", 1.0, LS, "rn");
         if (opm > 0) contract(1.0, rowsA(), "rk", ImK, "kn", 1.0, LA, "rn");
     }
@@ -830,7 +831,7 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
         else if (opm > 0 && !dcd) axpby(2.0, Imv, 0.0, Imv);
     }
     // CCSD: rows of tau against Ifull;  DCSD: rows of t1 t1 against Ifull (rows of T were taken above)
-    dev::ladder_pack_T(dcd ? nullptr : t2, t1, SpR, AmR, no, nv, rflags, ldp, ldp, stream);
+    dev::ladder_pack_T(dcd ? nullptr : t2, t1, SpR, AmR, no, nv, rflags, ldp, ldp, stream, row0, row1);   // this rank's rows
     stats.permute_calls += 3;
     stats.permute_bytes += 8.0 * 4.0 * double(v * v * o * o);
     contract(1.0, rowsS(), "rk", IpK, "kn", 1.0, LS, "rn");
@@ -1008,8 +1009,12 @@ void Engine::dressed_into(int pattern, const std::vector<int>& pos, int k, const
     if (reduced && k == 2) depth = 0;        // r -> c: no s -> d on top of it
     ArenaScope scope(arena);
     TView oth;
+    long memo_key = ((long)other << 8) | (long)depth;
+    for (int i = 0; i < depth; ++i) memo_key = (memo_key << 3) | (long)(pos[i] + 1);
     if (depth == 0) {
         oth = cutq(block(other), other);
+    } else if (!reduced && dress_memo_.count(memo_key)) {
+        oth = dress_memo_[memo_key];        // formed once for all the blocks of this dress_V call (see there)
     } else {
         int64_t d[4];
         for (int i = 0; i < 4; ++i) d[i] = (other >> (3 - i) & 1) ? nv : no;
@@ -1032,12 +1037,29 @@ void Engine::dress_V(const double* t1, uint32_t mask, const int64_t* cut) {
     TView t = make_view(const_cast<double*>(t1), {(int64_t)nv, (int64_t)no});
     for (int axis = 0; axis < 2 && cut; ++axis)
         if (cut[2 * axis] < 0 || cut[2 * axis + 1] > nv || cut[2 * axis] > cut[2 * axis + 1]) throw Error("dress_V: bad index range");
+    ArenaScope memo_scope(arena);
+    struct MemoGuard {
+        std::map<long, TView>& m;
+        ~MemoGuard() { m.clear(); }
+    } memo_guard{dress_memo_};
+    dress_memo_.clear();
+    if ((mask >> P_klij & 1u) && (mask >> P_iabj & 1u)) {
+        // V_klcj + V_klcd t_dj (ccsd.py:346-352) is also the occupied-bra source of V~_iabj (:378-383): the same
+        // transform of the same block — one pass over V_ijab (0.8 GB at (50,200)) instead of two.  Both bra indices are
+        // occupied, so an index range of the call does not touch it.
+        const int pat = P_klij | 2;                                   // (o,o,v,o)
+        const std::vector<int> pos = {3};
+        int64_t d[4] = {no, no, nv, no};
+        TView oth = make_view(arena.alloc(d[0] * d[1] * d[2] * d[3]), 4, d, nullptr);
+        dressed_into(pat, pos, 1, t, oth, false, cut);
+        dress_memo_[(((long)pat << 8 | 1L) << 3) | 4L] = oth;
+    }
     for (int pat = 0; pat < 16; ++pat) {
         if (!(mask >> pat & 1u)) continue;
         TView dst = block_view(ensure_dressed(pat), pat);
         for (int axis = 0; axis < 2 && cut; ++axis) {
             if (cut[2 * axis + 1] <= cut[2 * axis]) continue;
-            if (!(pat >> (3 - axis) & 1)) throw Error("dress_V: an index range needs that index to be virtual");
+            if (!(pat >> (3 - axis) & 1)) continue;                   // an occupied index has no range: the whole block
             dst = slice(dst, axis, cut[2 * axis], cut[2 * axis + 1]);
         }
         std::vector<int> pos;

@@ -125,10 +125,11 @@ void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nc, int6
 //   Am[row][col] = (X[c,d,i,j] - X[d,c,i,j]) / 2 with row = Q(c,d) (c > d) or P(c,d) if PACK_AM_PROWS and
 //   col = Q(i,j) (i > j) or P(i,j) if PACK_AM_PCOLS; entries on a diagonal pair are zero.
 // If t1 ([nr,nc]) is given, t1[c,i] t1[d,j] is added to X[c,d,i,j] on the fly (tau of ccsd.py:462); X may then be
-// null.  ldp / ldm are the row pitches of Sp / Am (0 = dense).
+// null.  ldp / ldm are the row pitches of Sp / Am (0 = dense).  [rp0,rp1) (rp1 < 0: all): only these rows P(c,d) are
+// written, at their usual place (needs PACK_AM_PROWS: Am rows are then the same pairs) — a rank that reads only its rows.
 enum { PACK_ROW_HALF = 1, PACK_AM_PROWS = 2, PACK_COL_HALF = 4, PACK_AM_PCOLS = 8 };
 void ladder_pack_T(const double* X, const double* t1, double* Sp, double* Am, int nc, int nr, int flags, int64_t ldp,
-                   int64_t ldm, stream_t s);
+                   int64_t ldm, stream_t s, int64_t rp0 = 0, int64_t rp1 = -1);
 // L[P(a,b)] = [ LS row (o(o+1)/2) | LA row (o(o-1)/2) ], row length o*o:
 // R[a,b,i,j] = beta R + LS[P(ab)][P(ij)] + sgn(a-b) sgn(i-j) LA[P(ab)][Q(ij)]
 void ladder_unpack(const double* L, double* R, double beta, int no, int nv, stream_t s);

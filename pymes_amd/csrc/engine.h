@@ -228,6 +228,8 @@ class Engine {
     double* splitk_ws_ = nullptr;
     int64_t splitk_doubles_ = 0;
     double* get_static(const std::string& key);
+    // intermediates of one dress_V call that more than one block needs: (pattern, depth, transformed positions) -> view
+    std::map<long, TView> dress_memo_;
     void dressed_into(int pattern, const std::vector<int>& pos, int k, const TView& t1v, const TView& dst,
                       bool reduced = false, const int64_t* cut = nullptr);
     int64_t block_size(int pattern) const;

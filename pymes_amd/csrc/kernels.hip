@@ -1053,8 +1053,8 @@ __global__ void __launch_bounds__(256) ladder_pack_V_kernel(const double* __rest
 
 __global__ void ladder_pack_T_kernel(const double* __restrict__ T, const double* __restrict__ t1,
                                      double* __restrict__ Sp, double* __restrict__ Am, int no, int nv, int flags,
-                                     long ldp, long ldm) {
-    const long row = blockIdx.x;   // P(c,d)
+                                     long ldp, long ldm, long rp0) {
+    const long row = rp0 + blockIdx.x;   // P(c,d)
     int c, d;
     unrank_pair(row, c, d);
     const bool row_half = flags & dev::PACK_ROW_HALF, prow = flags & dev::PACK_AM_PROWS,
@@ -2181,13 +2181,17 @@ void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nc, int6
 }
 
 void ladder_pack_T(const double* X, const double* t1, double* Sp, double* Am, int nc, int nr, int flags, int64_t ldp,
-                   int64_t ldm, stream_t s) {
+                   int64_t ldm, stream_t s, int64_t rp0, int64_t rp1) {
     const long npp = (long)nr * (nr + 1) / 2, opp = (long)nc * (nc + 1) / 2, opm = (long)nc * (nc - 1) / 2;
     if (!ldp) ldp = opp;
     if (!ldm) ldm = (flags & PACK_AM_PCOLS) ? opp : opm;
     if (!X && !t1) throw std::runtime_error("ladder_pack_T: nothing to pack");
-    hipLaunchKernelGGL(ladder_pack_T_kernel, dim3((unsigned)npp), dim3(256), 0, (hipStream_t)s, X, t1, Sp, Am, nc, nr,
-                       flags, (long)ldp, (long)ldm);
+    if (rp1 < 0) { rp0 = 0; rp1 = npp; }
+    if (rp0 < 0 || rp1 > npp || rp0 > rp1) throw std::runtime_error("ladder_pack_T: bad row range");
+    if ((rp0 != 0 || rp1 != npp) && !(flags & PACK_AM_PROWS)) throw std::runtime_error("ladder_pack_T: a row range needs PACK_AM_PROWS");
+    if (rp1 == rp0) return;
+    hipLaunchKernelGGL(ladder_pack_T_kernel, dim3((unsigned)(rp1 - rp0)), dim3(256), 0, (hipStream_t)s, X, t1, Sp, Am, nc, nr,
+                       flags, (long)ldp, (long)ldm, (long)rp0);
     HIP_CHECK(hipGetLastError());
 }
 

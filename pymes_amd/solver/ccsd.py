@@ -201,9 +201,10 @@ class CCSD(ccd.CCD):
             red = [pdist.allreduce_tensor_start(st["W_t"], ctx)]
             # V~_iajb / V~_iabj only for the second-index range that this rank's column slab reads
             c0, c1 = pdist.slab_rows(ctx.no * ctx.nv, rank, world)
-            ctx.dress_V(t1, ("klij",))                                                # :165
-            if c1 > c0:
-                ctx.dress_V(t1, ("iajb", "iabj"), q_range=(c0 // ctx.no, -(-c1 // ctx.no)))
+            if c1 > c0:      # one call: V~_klij and V~_iabj share their V_klcd t_dj intermediate       # :165
+                ctx.dress_V(t1, ("klij", "iajb", "iabj"), q_range=(c0 // ctx.no, -(-c1 // ctx.no)))
+            else:
+                ctx.dress_V(t1, ("klij",))
             self._await_t2(st)
             ctx.slab_prepare(t2, st["P"], rank, world, is_dcd=self.is_dcd)
             red.append(pdist.allreduce_tensor_start(st["P_t"], ctx))

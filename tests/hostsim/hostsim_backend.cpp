@@ -250,7 +250,11 @@ void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nv, int6
 }
 
 void ladder_pack_T(const double* T, const double* t1, double* Sp, double* Am, int no, int nv, int flags, int64_t ldp,
-                   int64_t ldm, stream_t) {
+                   int64_t ldm, stream_t, int64_t rp0, int64_t rp1) {
+    if (rp1 < 0) { rp0 = 0; rp1 = (int64_t)nv * (nv + 1) / 2; }
+    if ((rp0 != 0 || rp1 != (int64_t)nv * (nv + 1) / 2) && !(flags & PACK_AM_PROWS))
+        throw std::runtime_error("ladder_pack_T: a row range needs PACK_AM_PROWS");
+    auto skip = [&](int c, int d) { const int64_t r = P2(c, d); return r < rp0 || r >= rp1; };
     const bool row_half = flags & PACK_ROW_HALF, prow = flags & PACK_AM_PROWS, col_half = flags & PACK_COL_HALF,
                pcol = flags & PACK_AM_PCOLS;
     const int64_t o2 = (int64_t)no * no, opp = (int64_t)no * (no + 1) / 2, opm = (int64_t)no * (no - 1) / 2;
@@ -258,6 +262,7 @@ void ladder_pack_T(const double* T, const double* t1, double* Sp, double* Am, in
     if (!ldm) ldm = pcol ? opp : opm;
     for (int c = 0; c < nv; ++c)
         for (int d = 0; d <= c; ++d) {
+            if (skip(c, d)) continue;
             if (ldp > opp) Sp[P2(c, d) * ldp + opp] = 0.0;
             if ((prow || c > d) && ldm > (pcol ? opp : opm)) Am[(prow ? P2(c, d) : Q2(c, d)) * ldm + (pcol ? opp : opm)] = 0.0;
         }
@@ -265,6 +270,7 @@ void ladder_pack_T(const double* T, const double* t1, double* Sp, double* Am, in
         for (int d = 0; d <= c; ++d)
             for (int i = 0; i < no; ++i)
                 for (int j = 0; j <= i; ++j) {
+                    if (skip(c, d)) continue;
                     double x1 = 0.0, x2 = 0.0;
                     if (T) {
                         x1 = T[((int64_t)c * nv + d) * o2 + i * no + j];
