@@ -17,7 +17,12 @@ cases = [
     ("qx,pxrs  batch 50 200x10000x50", "qx,pxrs->pqrs", (v, o), (o, o, v, o), "p", 1.0),
     ("px,xqrs  M=200 N=500k K=50", "px,xqrs->pqrs", (v, o), (o, v, o, o), "", 1.0),
     ("ac,cbij  M=200 N=500k K=200", "ac,cbij->abij", (v, v), (v, v, o, o), "", 0.0),
+    ("ak,kn  M=200 N=50 K=2M (singles :433)", "ak,kn->an", (v, o * v * v), (o * v * v, o), "", 1.0),
+    ("ak,kn  M=200 N=50 K=500k (singles :435)", "ak,kn->an", (v, o * o * v), (o * o * v, o), "", 1.0),
+    ("ka,kn  M=50 N=50 K=2M", "ka,kn->an", (o * v * v, o), (o * v * v, o), "", 0.0),
 ]
+if os.environ.get("PROBE_ONLY"):
+    cases = [c for c in cases if os.environ["PROBE_ONLY"] in c[0]]
 tiles = sys.argv[1:] or ["", "64x64", "128x64", "64x128", "128x128"]
 for (label, spec, sa, sb, batch, beta) in cases:
     A, B = ctx.empty(sa), ctx.empty(sb)
