@@ -114,8 +114,7 @@ class CCD:
             while np.abs(dE) > delta_e and iteration <= max_iter:
                 iteration += 1
                 if shard is not None:
-                    nt, nr = self._sharded_iteration(ctx, shard, f_dev, t2, level_shift, delta)
-                    e_dir_ccd, e_ex_ccd = ctx.ccd_energy(t2)                      # :132
+                    e_dir_ccd, e_ex_ccd, nt, nr = self._sharded_iteration(ctx, shard, f_dev, t2, level_shift, delta)  # :132
                 else:
                     run_replayable(ctx, st, lambda: ctx.doubles_residual(f_dev, t2, r2, is_dcd=self.is_dcd,
                                                                          sym_ladder=sym))     # ccd.py:100-102
@@ -209,13 +208,16 @@ class CCD:
             mine = DeviceArray(ctx, sh["Tall"].ptr + 8 * sh["lo"] * 2 * ctx.no * ctx.no, (n, 2, ctx.no * ctx.no),
                                owned=False, keepalive=sh["Tall"])
             mine.copy_from(DeviceArray(ctx, tc.ptr, mine.shape, owned=False, keepalive=tc))
-        pdist.exchange_rows(sh["Tall_t"], rank, world, ctx)
+        pending = pdist.exchange_rows_start(sh["Tall_t"], rank, world, ctx)
+        # energy (:132) and norms from the compact tiles of this rank's pairs: partial sums, one all-reduce of six doubles,
+        # enqueued while the all-gather of the new amplitudes is in flight
+        _, e_dir, e_ex, nt2, nr2, _ = pdist.allreduce_sum(ctx.energy_norms_pairs(None, None, tc, dtc, rank, world))
+        pending.wait()
         ctx.pairs_unpack(sh["Tall"], t2, world)
-        nt, nr = np.sqrt(pdist.allreduce_sum(ctx.dots([tc, dtc], [tc, dtc])))
         if not self.is_diis:
             ctx.pool_put(dtc)
         sh["Tc"] = tc
-        return nt, nr
+        return e_dir, e_ex, np.sqrt(nt2), np.sqrt(nr2)
 
     def _drop_mixer_history_of(self, ctx):
         """The reference's mixer is never reset: a second solve() on the same instance starts from the history of the
