@@ -29,8 +29,10 @@ FP64_MFMA_PEAK_TFLOPS = 78.6      # 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz (MI3
 def reference_flops(no, nv, is_dcsd=False):
     """Algorithmic flops of one reference iteration (2 x FMA of its contraction sequence)."""
     o, v = float(no), float(nv)
-    from oracle.baseline import algorithmic_fma
-    doubles = algorithmic_fma(no, nv, is_dcsd)
+    if is_dcsd:     # closed forms of the doubles residual, SURVEY §8(d) (ccd.py:164-254)
+        doubles = v**4 * o**2 + 5 * o**3 * v**3 + o**4 * v**2 + 2 * o**2 * v**3 + 2 * o**3 * v**2
+    else:
+        doubles = v**4 * o**2 + 10 * o**3 * v**3 + 2 * o**4 * v**2 + 3 * o**2 * v**3 + 3 * o**3 * v**2
     dressing = 5 * o * v**4 + 28 * o**2 * v**3          # ccsd.py:290-421 as the reference evaluates it
     singles = 2 * o**2 * v**3 + 2 * o**3 * v**2
     return 2.0 * (doubles + dressing + singles)

@@ -37,7 +37,6 @@ def c2(args):
     from pymes_amd.integral.device import DeviceIntegrals
     from pymes_amd.model import synthetic
     from pymes_amd.solver.ccsd import CCSD
-    from oracle.baseline import algorithmic_fma
     no, nv = 20, 80
     B, eps = synthetic.factors(no, nv, seed=0, scale=0.15)
     ints = DeviceIntegrals.from_factors(no, B)
@@ -45,7 +44,8 @@ def c2(args):
     st = quiet(solver.setup, np.diag(eps), ints)
     dt = timed(lambda: quiet(solver.iterate, st), ints.ctx.sync, 20)
     o, v = float(no), float(nv)
-    flops = 2.0 * (algorithmic_fma(no, nv, False) + 5 * o * v**4 + 28 * o**2 * v**3 + 2 * o**2 * v**3 + 2 * o**3 * v**2)
+    from bench import reference_flops
+    flops = reference_flops(no, nv)
     out = {"config": "C2 CCSD iteration, synthetic (nocc=20, nvirt=80, scale 0.15)", "gpu_s": dt,
            "reference_algorithmic_flops": flops, "algorithmic_tflops": flops / dt / 1e12}
     if not args.skip_cpu:
