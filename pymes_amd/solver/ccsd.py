@@ -207,7 +207,11 @@ class CCSD(ccd.CCD):
                 ctx.dress_V(t1, ("klij",))
             self._await_t2(st)
             ctx.slab_prepare(t2, st["P"], rank, world, is_dcd=self.is_dcd)
-            red.append(pdist.allreduce_tensor_start(st["P_t"], ctx))
+            # P = [ X'_ki (o^2 doubles: read by the ring half) | pair-packed 2 V_klcd T_cdij (26 MB at (50,200): read by the
+            # ladder half) ]: two all-reduces, the big one is awaited only in front of the ladders — behind the ring products
+            oo = ctx.no * ctx.no
+            red.append(pdist.allreduce_tensor_start(st["P_t"][:oo], ctx))
+            st["J_pending"] = pdist.allreduce_tensor_start(st["P_t"][oo:], ctx)
             for work in red:
                 work.wait()
             ctx.dress_fock_finish(st["f"], t1, st["W"], st["fd"])
@@ -232,6 +236,7 @@ class CCSD(ccd.CCD):
             if dist_on:
                 ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], rank, world, part="rings", **slab)
                 pending = [pdist.exchange_rows_start(st[key], rank, world, ctx) for key in ("ETd_t", "ETx_t")]
+                st.pop("J_pending").wait()
                 ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], rank, world, part="ladders", **slab)
                 pending += [pdist.exchange_rows_start(st[key], rank, world, ctx)
                             for key in (("QK_t",) if st["pairs"] else ("L_t", "QK_t"))]
