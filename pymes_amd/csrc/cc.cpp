@@ -855,21 +855,24 @@ void Engine::ladder_sym_unpack(const double* L, double* r2, double beta) {
 //   f~_vv = f_vv + G - t f_ov - t Mm                                  (:282-286)
 //   f~_vo = f_vo - t f_oo + f_vv t - t (f_ov t) + 2 K1^T - K2 - t L + G t - t Mm t   (:260-272)
 // -----------------------------------------------------------------------------------
-// The dressed Fock matrix is built in two stages.  Stage 1: the six intermediates that contract T1 with a V block over
+// The dressed Fock matrix is built in two stages.  Stage 1: the eight intermediates that contract T1 with a V block over
 // (b,j) — linear in V, so a rank may sum over its chunk of the occupied index j only (one process per GPU: the partial
-// buffers are all-reduced, 0.6 MB at (50,200)); W = [ G (v,v) | J2 (o,v) | Mm (o,v) | K1 (o,v) | K2 (v,o) | L (o,o) ].
-// Stage 2: the products of those with T1 and f (tiny, replicated).
+// buffers are all-reduced, 0.7 MB at (50,200)); W = [ G1 (v,v) | G2 (v,v) | J1 (o,v) | J2 (o,v) | L1 (o,o) | L2 (o,o) |
+// K1 (o,v) | K2 (v,o) ], every piece written by ONE matrix-vector product (beta = 0): they are independent and go to the
+// device as one batched launch (dev::gemv_batch_begin/end).  Stage 2: the combinations G = 2 G1 - G2, ... and their
+// products with T1 and f (matrices of n^2 elements) in two small kernels (dev::fock_finish).
 int64_t Engine::dress_fock_ws_doubles() const {
     const int64_t o = no, v = nv;
-    return v * v + 4 * o * v + o * o;
+    return 2 * v * v + 4 * o * v + 2 * o * o;
 }
 
 void Engine::dress_fock_partial(const double* t1, double* W, int rank, int world) {
     const int64_t o = no, v = nv;
     if (world < 1 || rank < 0 || rank >= world) throw Error("dress_fock_partial: bad rank/world");
     const int64_t c = (o + world - 1) / world, j0 = std::min<int64_t>(rank * c, o), j1 = std::min<int64_t>(j0 + c, o);
-    TView G = make_view(W, {v, v}), J2 = make_view(G.p + v * v, {o, v}), Mm = make_view(J2.p + o * v, {o, v}),
-          K1 = make_view(Mm.p + o * v, {o, v}), K2 = make_view(K1.p + o * v, {v, o}), L = make_view(K2.p + o * v, {o, o});
+    TView G1 = make_view(W, {v, v}), G2 = make_view(G1.p + v * v, {v, v}), J1 = make_view(G2.p + v * v, {o, v}),
+          J2 = make_view(J1.p + o * v, {o, v}), L1 = make_view(J2.p + o * v, {o, o}), L2 = make_view(L1.p + o * o, {o, o}),
+          K1 = make_view(L2.p + o * o, {o, v}), K2 = make_view(K1.p + o * v, {v, o});
     if (j1 <= j0) {
         dev::memset_zero(W, sizeof(double) * dress_fock_ws_doubles(), stream);
         return;
@@ -877,53 +880,27 @@ void Engine::dress_fock_partial(const double* t1, double* W, int rank, int world
     TView t = slice(make_view(const_cast<double*>(t1), {v, o}), 1, j0, j1);
     const bool all = (j0 == 0 && j1 == o);       // whole blocks: the planner may reuse its cached transposed copies
     auto js = [&](int pat) { return all ? block(pat) : slice(block(pat), 0, j0, j1); };
-    contract(2.0, t, "bj", js(P_iabc), "jabc", 0.0, G, "ac");
-    contract(-1.0, t, "bj", js(P_iabc), "jacb", 1.0, G, "ac");
-    contract(1.0, t, "bj", js(P_ijab), "jkcb", 0.0, J2, "kc");
-    contract(2.0, t, "bj", js(P_ijab), "jkbc", 0.0, Mm, "kc");
-    axpby(-1.0, J2, 1.0, Mm);
-    contract(2.0, t, "bj", js(P_ijak), "jkbi", 0.0, L, "ki");
-    contract(-1.0, t, "bj", js(P_ijka), "jkib", 1.0, L, "ki");
-    contract(1.0, t, "bj", js(P_iabj), "jabi", 0.0, K1, "ia");
-    contract(1.0, t, "bj", js(P_iajb), "jaib", 0.0, K2, "ai");
+    struct Batch {
+        Batch() { dev::gemv_batch_begin(); }
+        ~Batch() { try { dev::gemv_batch_end(); } catch (...) {} }
+    };
+    {
+        Batch batch;
+        contract(1.0, t, "bj", js(P_iabc), "jabc", 0.0, G1, "ac");
+        contract(1.0, t, "bj", js(P_iabc), "jacb", 0.0, G2, "ac");
+        contract(1.0, t, "bj", js(P_ijab), "jkbc", 0.0, J1, "kc");
+        contract(1.0, t, "bj", js(P_ijab), "jkcb", 0.0, J2, "kc");
+        contract(1.0, t, "bj", js(P_ijak), "jkbi", 0.0, L1, "ki");
+        contract(1.0, t, "bj", js(P_ijka), "jkib", 0.0, L2, "ki");
+        contract(1.0, t, "bj", js(P_iabj), "jabi", 0.0, K1, "ia");
+        contract(1.0, t, "bj", js(P_iajb), "jaib", 0.0, K2, "ai");
+        dev::gemv_batch_end();           // (errors surface here; the guard only covers an exception on the way)
+    }
 }
 
 void Engine::dress_fock_finish(const double* f, const double* t1, const double* W, double* fd) {
-    const int64_t o = no, v = nv, nn = n;
-    TView F = make_view(const_cast<double*>(f), {nn, nn}), D = make_view(fd, {nn, nn});
-    TView t = make_view(const_cast<double*>(t1), {v, o});
-    auto blk = [&](const TView& m, bool rv, bool cv) {
-        return slice(slice(m, 0, rv ? o : 0, rv ? nn : o), 1, cv ? o : 0, cv ? nn : o);
-    };
-    TView Foo = blk(F, 0, 0), Fov = blk(F, 0, 1), Fvv = blk(F, 1, 1);
-    TView Doo = blk(D, 0, 0), Dov = blk(D, 0, 1), Dvo = blk(D, 1, 0), Dvv = blk(D, 1, 1);
-    copy(F, D);
-    double* w = const_cast<double*>(W);
-    TView G = make_view(w, {v, v}), J2 = make_view(G.p + v * v, {o, v}), Mm = make_view(J2.p + o * v, {o, v}),
-          K1 = make_view(Mm.p + o * v, {o, v}), K2 = make_view(K1.p + o * v, {v, o}), L = make_view(K2.p + o * v, {o, o});
     ArenaScope scope(arena);
-    // ov
-    axpby(2.0, K1, 1.0, Dov);
-    axpby(-1.0, J2, 1.0, Dov);
-    // oo
-    axpby(1.0, L, 1.0, Doo);
-    contract(1.0, Fov, "ib", t, "bj", 1.0, Doo, "ij");
-    contract(1.0, Mm, "ib", t, "bj", 1.0, Doo, "ij");
-    // vv
-    axpby(1.0, G, 1.0, Dvv);
-    contract(-1.0, t, "ai", Fov, "ib", 1.0, Dvv, "ab");
-    contract(-1.0, t, "ai", Mm, "ib", 1.0, Dvv, "ab");
-    // vo
-    contract(-1.0, t, "aj", Foo, "ji", 1.0, Dvo, "ai");
-    contract(1.0, Fvv, "ab", t, "bi", 1.0, Dvo, "ai");
-    TView ft = make_view(arena.alloc(o * o), {o, o});   // (f_ov + Mm) t   -> shared by -t (f_ov t) and -t Mm t
-    contract(1.0, Fov, "jb", t, "bi", 0.0, ft, "ji");
-    contract(1.0, Mm, "jb", t, "bi", 1.0, ft, "ji");
-    axpby(1.0, L, 1.0, ft);            // ft = f_ov t + Mm t + L
-    contract(-1.0, t, "aj", ft, "ji", 1.0, Dvo, "ai");
-    permute(2.0, K1, "ia", 1.0, Dvo, "ai");
-    axpby(-1.0, K2, 1.0, Dvo);
-    contract(1.0, G, "ac", t, "ci", 1.0, Dvo, "ai");
+    dev::fock_finish(f, t1, W, fd, arena.alloc(static_cast<int64_t>(no) * no), no, nv, stream);
 }
 
 void Engine::dress_fock(const double* f, const double* t1, double* fd) {

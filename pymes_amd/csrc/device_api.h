@@ -66,6 +66,16 @@ struct Gemm {
     int64_t splitk_ws_doubles;
 };
 void gemm(const Gemm& g, stream_t s);
+// Second stage of the T1-dressed Fock matrix (ccsd.py:226-288) from the eight T1.V intermediates
+//   W = [ G1 (v,v) | G2 (v,v) | J1 (o,v) | J2 (o,v) | L1 (o,o) | L2 (o,o) | K1 (o,v) | K2 (v,o) ]
+// (cc.cpp, dress_fock_partial; G = 2 G1 - G2, Mm = 2 J1 - J2, L = 2 L1 - L2), f and fd [n,n], t1 [v,o], ft: o*o scratch:
+//   f~_ov = f_ov + 2 K1 - J2;   ft = (f_ov + Mm) t + L;   f~_oo = f_oo + ft;   f~_vv = f_vv + G - t (f_ov + Mm)
+//   f~_vo = f_vo - t (f_oo + ft) + (f_vv + G) t + 2 K1^T - K2
+void fock_finish(const double* f, const double* t1, const double* W, double* fd, double* ft, int no, int nv, stream_t s);
+// Matrix-vector-shaped gemm() calls (M == 1 or N == 1, beta == 0) issued between begin and end are independent of each
+// other by the caller's promise and may be launched together at end (or earlier: any permute / other GEMM flushes them).
+void gemv_batch_begin();
+void gemv_batch_end();
 
 // ---- strided copy / permutation:  out = alpha * in + beta * out ----------------
 // rank <= 6, both tensors described by the same extents and their own strides.

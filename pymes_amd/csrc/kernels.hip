@@ -699,6 +699,78 @@ __global__ void __launch_bounds__(256) gemv_finish_kernel(const double* __restri
     if (beta != 0.0) v += beta * yin[c * ys];
     y[c * ys] = v;
 }
+
+// Several independent weighted-column-sum products in ONE launch (dev::gemv_batch_begin/end): the T1.V intermediates of the
+// dressed Fock matrix are eight such products, each far too small at (20,80) to fill the chip or to hide its own latency.
+// The table travels as a kernel argument (launch-graph friendly).
+struct GemvItem {
+    const double* W; const double* x; double* y;
+    long ld, xs, R, C, rchunk, ys, ws_off;
+    double alpha;
+    int nchunk, cblocks, vec, blk0, out0;       // first block of the item in the product / in the finishing launch
+};
+constexpr int kGemvBatchMax = 12;
+struct GemvTable {
+    int n;
+    GemvItem it[kGemvBatchMax];
+};
+
+__global__ void __launch_bounds__(256) gemv_multi_cols_kernel(const GemvTable tab, double* __restrict__ ws) {
+    int i = 0;
+    while (i + 1 < tab.n && (int)blockIdx.x >= tab.it[i + 1].blk0) ++i;
+    const GemvItem& g = tab.it[i];
+    const int local = blockIdx.x - g.blk0, cb = local % g.cblocks, chunk = local / g.cblocks;
+    const long c = ((long)cb * 256 + threadIdx.x) * g.vec;
+    if (c >= g.C) return;
+    const long r0 = (long)chunk * g.rchunk, r1 = min(g.R, r0 + g.rchunk);
+    const double* __restrict__ w = g.W + r0 * g.ld + c;
+    const double* __restrict__ x = g.x;
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    long r = r0;
+    if (g.vec == 2) {
+        for (; r + 2 <= r1; r += 2) {
+            const double x0 = x[r * g.xs], x1 = x[(r + 1) * g.xs];
+            const v2d u = *reinterpret_cast<const v2d*>(w), v = *reinterpret_cast<const v2d*>(w + g.ld);
+            a0 += x0 * u[0]; a1 += x0 * u[1];
+            b0 += x1 * v[0]; b1 += x1 * v[1];
+            w += 2 * g.ld;
+        }
+        if (r < r1) {
+            const double x0 = x[r * g.xs];
+            const v2d u = *reinterpret_cast<const v2d*>(w);
+            a0 += x0 * u[0]; a1 += x0 * u[1];
+        }
+    } else {
+        for (; r + 2 <= r1; r += 2) {
+            a0 += x[r * g.xs] * w[0];
+            b0 += x[(r + 1) * g.xs] * w[g.ld];
+            w += 2 * g.ld;
+        }
+        if (r < r1) a0 += x[r * g.xs] * w[0];
+    }
+    double* __restrict__ p = ws + g.ws_off + (long)chunk * g.C + c;
+    p[0] = a0 + b0;
+    if (g.vec == 2) p[1] = a1 + b1;
+}
+
+__global__ void __launch_bounds__(256) gemv_multi_finish_kernel(const GemvTable tab, const double* __restrict__ ws) {
+    int i = 0;
+    while (i + 1 < tab.n && (int)blockIdx.x >= tab.it[i + 1].out0) ++i;
+    const GemvItem& g = tab.it[i];
+    const long c = (long)(blockIdx.x - g.out0) * 256 + threadIdx.x;
+    if (c >= g.C) return;
+    const double* __restrict__ part = ws + g.ws_off + c;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = 0;
+    for (; k + 4 <= g.nchunk; k += 4) {
+        s0 += part[(long)k * g.C];
+        s1 += part[(long)(k + 1) * g.C];
+        s2 += part[(long)(k + 2) * g.C];
+        s3 += part[(long)(k + 3) * g.C];
+    }
+    for (; k < g.nchunk; ++k) s0 += part[(long)k * g.C];
+    g.y[c * g.ys] = g.alpha * ((s0 + s1) + (s2 + s3));
+}
 template <int VEC>
 __global__ void __launch_bounds__(256) gemv_rows_kernel(const double* __restrict__ W, long ld, const double* __restrict__ x,
                                                         long xs, long R, long C, double alpha, double beta, const double* yin,
@@ -1333,6 +1405,58 @@ __global__ void rows_unpack_kernel(const double* __restrict__ Q, double* __restr
     }
 }
 
+// dev::fock_finish (device_api.h): two launches instead of twenty for matrices of n^2 <= 62500 elements
+struct FockW {
+    const double *G1, *G2, *J1, *J2, *L1, *L2, *K1, *K2;
+};
+__device__ __forceinline__ FockW fock_w(const double* W, int no, int nv) {
+    const long vv = (long)nv * nv, ov = (long)no * nv, oo = (long)no * no;
+    FockW w;
+    w.G1 = W; w.G2 = w.G1 + vv; w.J1 = w.G2 + vv; w.J2 = w.J1 + ov; w.L1 = w.J2 + ov; w.L2 = w.L1 + oo;
+    w.K1 = w.L2 + oo; w.K2 = w.K1 + ov;
+    return w;
+}
+__global__ void fock_ft_kernel(const double* __restrict__ f, const double* __restrict__ t1, const double* __restrict__ W,
+                               double* __restrict__ ft, int no, int nv) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= no * no) return;
+    const int j = e / no, i = e - j * no, n = no + nv;
+    const FockW w = fock_w(W, no, nv);
+    double acc = 2.0 * w.L1[e] - w.L2[e];
+    for (int b = 0; b < nv; ++b)
+        acc += (f[(long)j * n + no + b] + 2.0 * w.J1[(long)j * nv + b] - w.J2[(long)j * nv + b]) * t1[(long)b * no + i];
+    ft[e] = acc;
+}
+__global__ void fock_finish_kernel(const double* __restrict__ f, const double* __restrict__ t1, const double* __restrict__ W,
+                                   const double* __restrict__ ft, double* __restrict__ fd, int no, int nv) {
+    const int n = no + nv;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)n * n) return;
+    const int p = (int)(e / n), q = (int)(e - (long)p * n);
+    const FockW w = fock_w(W, no, nv);
+    double v = f[e];
+    if (p < no && q < no) {
+        v += ft[p * no + q];
+    } else if (p < no) {
+        const int a = q - no;
+        v += 2.0 * w.K1[(long)p * nv + a] - w.J2[(long)p * nv + a];
+    } else if (q >= no) {
+        const int a = p - no, b = q - no;
+        double acc = 2.0 * w.G1[(long)a * nv + b] - w.G2[(long)a * nv + b];
+        for (int i = 0; i < no; ++i)
+            acc -= t1[(long)a * no + i] * (f[(long)i * n + no + b] + 2.0 * w.J1[(long)i * nv + b] - w.J2[(long)i * nv + b]);
+        v += acc;
+    } else {
+        const int a = p - no, i = q;
+        double acc = 2.0 * w.K1[(long)i * nv + a] - w.K2[(long)a * no + i];
+        for (int j = 0; j < no; ++j) acc -= t1[(long)a * no + j] * (f[(long)j * n + i] + ft[j * no + i]);
+        for (int b = 0; b < nv; ++b)
+            acc += (f[(long)(no + a) * n + no + b] + 2.0 * w.G1[(long)a * nv + b] - w.G2[(long)a * nv + b]) * t1[(long)b * no + i];
+        v += acc;
+    }
+    fd[e] = v;
+}
+
 // partial traces of a pair matrix M[(c,k)][(b,j)] (device_api.h).  Blocks [0, nv * ceil(nv/16)): one c and sixteen a
 // each — a wave takes four a (their loads in flight together), its lanes the k of sum_k M[(c,k)][(a,k)] (one element per
 // 128-byte line: 1/3 of the lines of M in all), summed by a shuffle tree.  The no blocks behind them: one k each — lanes
@@ -1746,6 +1870,37 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // M = 1 or N = 1 (no batch): matrix-vector product on the streaming kernels above.  Returns false when the shape does not
 // qualify (then the MFMA GEMM handles it).  Timed under the same profiling events as a GEMM call (class 0).
 bool gemv_dispatch(const dev::Gemm& g, long a_sm, long a_sk, long b_sk, long b_sn, hipStream_t st);
+
+// dev::gemv_batch_begin/end: weighted-column-sum products with beta == 0 issued in between are collected and launched
+// together; any other launch that could read their results (permute, a GEMM of another kind) flushes them first, so the
+// order of effects on the stream is that of immediate execution.
+struct GemvBatch {
+    bool active = false;
+    GemvTable tab;
+    long ws_used = 0;
+    double* ws = nullptr;
+    hipStream_t st = nullptr;
+};
+thread_local GemvBatch g_gemv_batch;
+
+void gemv_batch_flush() {
+    GemvBatch& b = g_gemv_batch;
+    if (b.tab.n == 0) return;
+    int blocks = 0, outs = 0;
+    for (int i = 0; i < b.tab.n; ++i) {
+        GemvItem& it = b.tab.it[i];
+        it.blk0 = blocks;
+        it.out0 = outs;
+        blocks += it.cblocks * it.nchunk;
+        outs += (int)((it.C + 255) / 256);
+    }
+    hipLaunchKernelGGL(gemv_multi_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, b.st, b.tab, b.ws);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(gemv_multi_finish_kernel, dim3((unsigned)outs), dim3(256), 0, b.st, b.tab, b.ws);
+    HIP_CHECK(hipGetLastError());
+    b.tab.n = 0;
+    b.ws_used = 0;
+}
 }  // namespace
 
 namespace dev {
@@ -1868,6 +2023,7 @@ void gemm(const Gemm& g, stream_t s) {
     const bool a_kcontig = (a_sk == 1);
     const bool b_kcontig = (b_sk == 1);
     if (gemv_dispatch(g, a_sm, a_sk, b_sk, b_sn, st)) return;
+    gemv_batch_flush();
     GemmK k;
     k.A = g.A; k.B = g.B; k.C = g.C;
     k.Cin = g.Cin ? g.Cin : g.C;
@@ -2018,7 +2174,18 @@ void gemm(const Gemm& g, stream_t s) {
     }
 }
 
+void gemv_batch_begin() {
+    g_gemv_batch.active = true;
+    g_gemv_batch.tab.n = 0;
+    g_gemv_batch.ws_used = 0;
+}
+void gemv_batch_end() {
+    gemv_batch_flush();
+    g_gemv_batch.active = false;
+}
+
 void permute(const Permute& p, stream_t s) {
+    gemv_batch_flush();
     hipStream_t st = (hipStream_t)s;
     // canonicalise: drop extent-1 dims, sort by out-stride (descending), merge adjacent dims
     struct D { long n, si, so; };
@@ -2353,6 +2520,15 @@ void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t s)
     HIP_CHECK(hipGetLastError());
 }
 
+void fock_finish(const double* f, const double* t1, const double* W, double* fd, double* ft, int no, int nv, stream_t s) {
+    const long n = no + nv;
+    hipLaunchKernelGGL(fock_ft_kernel, dim3((unsigned)((no * no + 255) / 256)), dim3(256), 0, (hipStream_t)s, f, t1, W, ft, no, nv);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(fock_finish_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, (hipStream_t)s, f, t1, W, ft, fd,
+                       no, nv);
+    HIP_CHECK(hipGetLastError());
+}
+
 void pair_traces(const double* M, int64_t ld, double alpha, double beta, double* out_vv, double* out_oo, int no, int nv,
                  stream_t s) {
     if (no <= 0 || nv <= 0) return;
@@ -2467,6 +2643,23 @@ bool gemv_dispatch(const dev::Gemm& g, long a_sm, long a_sk, long b_sk, long b_s
         nchunk = std::min<long>(nchunk, g.splitk_ws_doubles / C);
         rchunk = (R + nchunk - 1) / nchunk;
         nchunk = (R + rchunk - 1) / rchunk;
+    }
+    {
+        GemvBatch& b = g_gemv_batch;
+        if (b.active && !g_prof.on) {        // (per-call event timing wants every product on its own)
+            const bool same = b.tab.n == 0 || (b.ws == g.splitk_ws && b.st == st);
+            if (cols && g.beta == 0.0 && same && b.tab.n < kGemvBatchMax && b.ws_used + nchunk * C <= g.splitk_ws_doubles) {
+                GemvItem& it = b.tab.it[b.tab.n++];
+                it.W = W; it.x = x; it.y = g.C; it.ld = ld; it.xs = xs; it.R = R; it.C = C; it.rchunk = rchunk; it.ys = ys;
+                it.ws_off = b.ws_used; it.alpha = g.alpha; it.nchunk = (int)nchunk; it.cblocks = (int)cblocks; it.vec = vec;
+                it.blk0 = it.out0 = 0;
+                b.ws_used += nchunk * C;
+                b.ws = g.splitk_ws;
+                b.st = st;
+                return true;
+            }
+            gemv_batch_flush();              // this one runs on its own, behind the collected ones
+        }
     }
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (g_prof.on) {

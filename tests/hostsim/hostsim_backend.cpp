@@ -57,6 +57,9 @@ void prof_enable(bool on) { g_prof = on; }
 void prof_reset() { g_launches = 0; g_flops = 0; }
 void prof_query(int, long* l, long* nk, double* ms, double* f) { *l = g_launches; *nk = g_launches; *ms = 0.0; *f = g_flops; }
 
+void gemv_batch_begin() {}          // the simulator executes every product at once
+void gemv_batch_end() {}
+
 void gemm(const Gemm& g, stream_t) {
     if (!((g.a_sm == 1 || g.a_sk == 1 || g.M == 1 || g.K == 1) && (g.b_sk == 1 || g.b_sn == 1 || g.N == 1 || g.K == 1)))
         throw std::runtime_error("hostsim gemm: operand without unit stride");
@@ -488,6 +491,37 @@ void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t) {
                 if (i != j) v += (i > j ? 1.0 : -1.0) * Q[r * ld + opp + Q2(ih, il)];
                 out[r * ld + i * no + j] = v;
             }
+}
+
+void fock_finish(const double* f, const double* t1, const double* W, double* fd, double* ft, int no, int nv, stream_t) {
+    const int64_t n = no + nv, vv = (int64_t)nv * nv, ov = (int64_t)no * nv, oo = (int64_t)no * no;
+    const double *G1 = W, *G2 = G1 + vv, *J1 = G2 + vv, *J2 = J1 + ov, *L1 = J2 + ov, *L2 = L1 + oo, *K1 = L2 + oo, *K2 = K1 + ov;
+    auto FM = [&](int i, int b) { return f[i * n + no + b] + 2.0 * J1[(int64_t)i * nv + b] - J2[(int64_t)i * nv + b]; };
+    auto G = [&](int a, int b) { return 2.0 * G1[(int64_t)a * nv + b] - G2[(int64_t)a * nv + b]; };
+    for (int j = 0; j < no; ++j)
+        for (int i = 0; i < no; ++i) {
+            double acc = 2.0 * L1[j * no + i] - L2[j * no + i];
+            for (int b = 0; b < nv; ++b) acc += FM(j, b) * t1[(int64_t)b * no + i];
+            ft[j * no + i] = acc;
+        }
+    for (int64_t e = 0; e < n * n; ++e) fd[e] = f[e];
+    for (int i = 0; i < no; ++i)
+        for (int j = 0; j < no; ++j) fd[i * n + j] += ft[i * no + j];
+    for (int i = 0; i < no; ++i)
+        for (int a = 0; a < nv; ++a) fd[i * n + no + a] += 2.0 * K1[(int64_t)i * nv + a] - J2[(int64_t)i * nv + a];
+    for (int a = 0; a < nv; ++a)
+        for (int b = 0; b < nv; ++b) {
+            double acc = G(a, b);
+            for (int i = 0; i < no; ++i) acc -= t1[(int64_t)a * no + i] * FM(i, b);
+            fd[(no + a) * n + no + b] += acc;
+        }
+    for (int a = 0; a < nv; ++a)
+        for (int i = 0; i < no; ++i) {
+            double acc = 2.0 * K1[(int64_t)i * nv + a] - K2[(int64_t)a * no + i];
+            for (int j = 0; j < no; ++j) acc -= t1[(int64_t)a * no + j] * (f[j * n + i] + ft[j * no + i]);
+            for (int b = 0; b < nv; ++b) acc += (f[(no + a) * n + no + b] + G(a, b)) * t1[(int64_t)b * no + i];
+            fd[(no + a) * n + i] += acc;
+        }
 }
 
 void pair_traces(const double* M, int64_t ld, double alpha, double beta, double* out_vv, double* out_oo, int no, int nv,
