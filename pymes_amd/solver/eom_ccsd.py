@@ -104,6 +104,9 @@ class _Sigma:
         # particle ladder (:383): pair-packed form (1/4 of the flops) whenever V_abcd = V_badc and the trial doubles
         # are exchange-symmetric, u2_abij = u2_baji — true for every vector the Davidson driver generates
         self.v_sym = c.exchange_symmetric(V["abcd"])
+        # T_abij = T_baji (every CCSD solution): P(ijab,jiba)[T B5] = T (B5 + B5^(lkji)), so that term rides in the
+        # product with B' of eom_ccsd.py:381 — one v^2 o^4 product less per sigma
+        self.t_sym = c.exchange_symmetric(T)
         self.L = c.empty((nv * (nv + 1) // 2, no * no)) if self.v_sym else None
 
     def exchange_symmetric(self, u2):
@@ -168,7 +171,8 @@ class _Sigma:
         c.contract("bl,liaj->abij", u1, self.A4, out=D, beta=1.0)
         c.contract("bl,laji->abij", u1, self.A6, out=D, alpha=-1.0, beta=1.0)
         B5 = c.contract("klid,dj->klij", V["ijka"], u1)
-        c.contract("abkl,klij->abij", T, B5, out=D, beta=1.0)
+        if not self.t_sym:
+            c.contract("abkl,klij->abij", T, B5, out=D, beta=1.0)
         c.contract("ak,kbij->abij", u1, V["iajk"], out=D, alpha=-1.0, beta=1.0)
         c.contract("abic,cj->abij", V["abic"], u1, out=D, beta=1.0)
         c.permute("aibj->abij", Dd, out=D, beta=1.0)
@@ -178,6 +182,9 @@ class _Sigma:
         c.lincomb(D, [D, S], [1.0, 1.0])
         c.contract("abkl,klij->abij", u2, self.B2, out=D, beta=1.0)               # :380, :382
         Bn = c.contract("kldc,dcij->klij", V["ijab"], u2)
+        if self.t_sym:           # + the symmetrised u1 term that was held back above
+            c.permute("klij->klij", B5, out=Bn, beta=1.0)
+            c.permute("lkji->klij", B5, out=Bn, beta=1.0)
         c.contract("abkl,klij->abij", T, Bn, out=D, beta=1.0)                     # :381
         if self.v_sym and u2_sym:                                                 # :383
             c.ladder_sym(u2, self.L, 0, self.L.shape[0])
