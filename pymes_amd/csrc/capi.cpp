@@ -301,6 +301,12 @@ int pymes_ladder_sym(pymes_ctx* ctx, const double* t2, double* L, int64_t r0, in
         E(ctx).ladder_sym(t2, L, r0, r1, dressed != 0, hole);
     });
 }
+int pymes_hole_ladder_packed(pymes_ctx* ctx, const double* x, const double* I, double* L, int64_t r0, int64_t r1) {
+    return guarded([&] {
+        need(x, "x"); need(I, "I"); need(L, "L");
+        E(ctx).hole_ladder_packed(x, I, L, r0, r1);
+    });
+}
 int pymes_ladder_sym_unpack(pymes_ctx* ctx, const double* L, double* r2, double beta) {
     return guarded([&] {
         need(L, "L"); need(r2, "r2");

@@ -706,6 +706,39 @@ void Engine::ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1,
     if (opm > 0) contract(1.0, slice(make_view(AmR, {npp, ldp}), 0, row0, row1), "rk", ImK, "kn", 1.0, LA, "rn");
 }
 
+// A hole-ladder-shaped term sum_kl I_klij X_abkl in the pair-packed rows of L (added to what the rows hold), for
+// I_klij = I_lkji and X_abkl = X_balk: the (k,l) part of ladder_sym for a caller-supplied I (EOM-CCSD: eom_ccsd.py:380-382
+// — u2 against V_klij + V_klcd T_cdij, T against V_kldc u2_dcij), 1/4 of the flops of the plain v^2 o^4 product.
+void Engine::hole_ladder_packed(const double* x, const double* I, double* L, int64_t row0, int64_t row1) {
+    const int64_t o = no, v = nv, npp = v * (v + 1) / 2, opp = o * (o + 1) / 2, opm = o * (o - 1) / 2;
+    if (row0 < 0 || row1 > npp || row0 > row1) throw Error("hole_ladder_packed: bad pair-row range");
+    if (row0 == row1) return;
+    const int64_t rows = row1 - row0;
+    const int64_t ldp = opp + (opp & 1), ldm = std::max<int64_t>(opm + (opm & 1), 2);
+    ArenaScope scope(arena);
+    auto pitched = [&](double* p, int64_t r, int64_t c, int64_t ld) { return slice(make_view(p, {r, ld}), 1, 0, c); };
+    TView Lrows = make_view(L + row0 * o * o, {rows, o * o});
+    TView LS = slice(Lrows, 1, 0, opp), LA = slice(Lrows, 1, opp, o * o);
+    double* Ip = arena.alloc(ldp * ldp);
+    double* Im = arena.alloc(ldp * ldm);
+    if (ldp > opp) {
+        dev::memset_zero(Ip + opp * ldp, sizeof(double) * ldp, stream);
+        dev::memset_zero(Im + opp * ldm, sizeof(double) * ldm, stream);
+    }
+    dev::ladder_pack_T(I, nullptr, Ip, Im, no, no, dev::PACK_AM_PROWS, ldp, ldm, stream);
+    TView Ipv = pitched(Ip, opp, opp, ldp), Imv = pitched(Im, opp, opm, ldm);
+    axpby(2.0, Ipv, 0.0, Ipv);
+    if (opm > 0) axpby(2.0, Imv, 0.0, Imv);
+    double* SpR = arena.alloc(npp * ldp);
+    double* AmR = arena.alloc(npp * ldp);
+    dev::ladder_pack_T(x, nullptr, SpR, AmR, no, nv, dev::PACK_COL_HALF | dev::PACK_AM_PROWS | dev::PACK_AM_PCOLS, ldp, ldp, stream,
+                       row0, row1);
+    stats.permute_calls++;
+    stats.permute_bytes += 8.0 * 2.0 * double(rows) * 2.0 * double(o * o);
+    contract(1.0, slice(make_view(SpR, {npp, ldp}), 0, row0, row1), "rk", pitched(Ip, ldp, opp, ldp), "kn", 1.0, LS, "rn");
+    if (opm > 0) contract(1.0, slice(make_view(AmR, {npp, ldp}), 0, row0, row1), "rk", pitched(Im, ldp, opm, ldm), "kn", 1.0, LA, "rn");
+}
+
 // T1 dressing of the ladders on the amplitude side.  With X_a^p = delta_ap - t_ak delta_pk the dressed ladder and the
 // (c,d)-ket part of V~_abij are  sum_pq X_a^p X_b^q sum_cd V_pqcd tau_cdij,  tau = T + t1 t1 (exchange-symmetric like T):
 //   (p,q) = (a,b): the pair-packed ladder with the UNDRESSED V_abcd, packed once per solve          -> L rows

@@ -107,6 +107,8 @@ class _Sigma:
         # T_abij = T_baji (every CCSD solution): P(ijab,jiba)[T B5] = T (B5 + B5^(lkji)), so that term rides in the
         # product with B' of eom_ccsd.py:381 — one v^2 o^4 product less per sigma
         self.t_sym = c.exchange_symmetric(T)
+        # eom_ccsd.py:380-382 in pair-packed rows needs B2_klij = B2_lkji and V_klcd = V_lkdc (then B' has it for symmetric u2)
+        self.hole_sym = self.t_sym and c.exchange_symmetric(self.B2) and c.exchange_symmetric(V["ijab"])
         self.L = c.empty((nv * (nv + 1) // 2, no * no)) if self.v_sym else None
 
     def exchange_symmetric(self, u2):
@@ -180,11 +182,20 @@ class _Sigma:
         # ---- P(ijab, jiba) (:377), then the unpermuted terms (:380-383) ----------------------------------
         S = c.permute("baji->abij", D)
         c.lincomb(D, [D, S], [1.0, 1.0])
-        c.contract("abkl,klij->abij", u2, self.B2, out=D, beta=1.0)               # :380, :382
         Bn = c.contract("kldc,dcij->klij", V["ijab"], u2)
         if self.t_sym:           # + the symmetrised u1 term that was held back above
             c.permute("klij->klij", B5, out=Bn, beta=1.0)
             c.permute("lkji->klij", B5, out=Bn, beta=1.0)
+        if self.v_sym and u2_sym and self.hole_sym:
+            # all three remaining terms in the pair-packed rows (a >= b, i >= j): the particle ladder (:383) and the two
+            # hole-ladder-shaped products (:380-382; B2 and B' are symmetric under (kl)(ij) -> (lk)(ji)) — 1/4 of their flops
+            npp = self.L.shape[0]
+            c.ladder_sym(u2, self.L, 0, npp)
+            c.hole_ladder_packed(u2, self.B2, self.L, 0, npp)
+            c.hole_ladder_packed(T, Bn, self.L, 0, npp)
+            c.ladder_sym_unpack(self.L, D, beta=1.0)
+            return D
+        c.contract("abkl,klij->abij", u2, self.B2, out=D, beta=1.0)               # :380, :382
         c.contract("abkl,klij->abij", T, Bn, out=D, beta=1.0)                     # :381
         if self.v_sym and u2_sym:                                                 # :383
             c.ladder_sym(u2, self.L, 0, self.L.shape[0])

@@ -283,3 +283,24 @@ def test_energy_norms_over_pairs(sim):
             tot += ctx.energy_norms_pairs(dF, dT1, tc, dtc, rank, world)
         assert np.allclose(tot, full, rtol=1e-12, atol=1e-13), world
     ctx.close()
+
+
+def test_hole_ladder_packed(sim):
+    """pymes_hole_ladder_packed: rows of the pair-packed L += sum_kl I_klij X_abkl for symmetric I and X; unpacked, it is
+    the plain product (eom_ccsd.py:380-382)."""
+    no, nv = 3, 5
+    rng = np.random.default_rng(9)
+    X = rng.standard_normal((nv, nv, no, no))
+    X = X + X.transpose(1, 0, 3, 2)
+    I = rng.standard_normal((no, no, no, no))
+    I = I + I.transpose(1, 0, 3, 2)
+    ctx = Context(no, nv)
+    npp = nv * (nv + 1) // 2
+    L = ctx.zeros((npp, no * no))
+    dX, dI = ctx.array(X), ctx.array(I)
+    for lo, hi in ((0, 4), (4, npp)):                     # two row chunks, as two ranks would
+        ctx.hole_ladder_packed(dX, dI, L, lo, hi)
+    out = ctx.zeros(X.shape)
+    ctx.ladder_sym_unpack(L, out, beta=0.0)
+    assert np.abs(out.get() - np.einsum("abkl,klij->abij", X, I)).max() < 1e-12
+    ctx.close()
