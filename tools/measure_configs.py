@@ -62,9 +62,7 @@ def c2(args):
         oc.singles_residual(so, fd, t1, t2, Vb)
         oc.ccsd_doubles_residual(so, fd, t2, Vd)
         cpu = time.perf_counter() - t0
-        so_, sv_ = float(so), float(sv)
-        sfl = 2.0 * (algorithmic_fma(so, sv, False) + 5 * so_ * sv_**4 + 28 * so_**2 * sv_**3 + 2 * so_**2 * sv_**3 +
-                     2 * so_**3 * sv_**2)
+        sfl = reference_flops(so, sv)
         out["cpu_baseline"] = {"value": cpu * flops / sfl, "unit": "s", "cores": 1, "kind": "port",
                                "sample": f"oracle residuals + dressing at ({so},{sv}) in {cpu:.2f} s, scaled by the "
                                          "algorithmic-flop ratio"}
