@@ -407,6 +407,7 @@ int pymes_cc_update_pairs(pymes_ctx* ctx, double* tc, double* dtc, const double*
         need(tc, "tc"); need(dtc, "dtc"); need(rc, "rc");
         pymes::Engine& e = E(ctx);
         int64_t r0, r1;
+        e.need_eps("cc_update_pairs");
         e.pair_chunk(rank, world, r0, r1);
         dev::cc_update_pairs(tc, dtc, rc, e.eps_o, e.eps_v, shift, delta, e.no, e.nv, r0, r1, e.stream);
     });

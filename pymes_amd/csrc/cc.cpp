@@ -56,6 +56,7 @@ double* Engine::get_static(const std::string& key) {
 // -----------------------------------------------------------------------------------
 void Engine::mp2(double shift, double* t2, double e_out[2]) {
     const int64_t o = no, v = nv, n4 = v * v * o * o;
+    need_eps("mp2");
     TView Vabij = block(P_abij);
     dev::mp2_amplitudes(t2, Vabij.p, eps_o, eps_v, shift, no, nv, stream);                 // :16-18
     ArenaScope scope(arena);
@@ -1175,6 +1176,7 @@ void Engine::singles_residual_partial(const double* fd, const double* t1, const 
 // -----------------------------------------------------------------------------------
 void Engine::cc_update(double* t, double* dt, const double* r, double shift, double delta, int rank) {
     if (rank != 2 && rank != 4) throw Error("cc_update: rank must be 2 (T1) or 4 (T2)");
+    need_eps("cc_update");
     dev::cc_update(t, dt, r, eps_o, eps_v, shift, delta, no, nv, rank, stream);
 }
 
@@ -1184,6 +1186,7 @@ void Engine::cc_update(double* t, double* dt, const double* r, double shift, dou
 void Engine::cc_update_to(double* t_out, double* dt, const double* t_in, const double* r, double shift, double delta,
                           int rank) {
     if (rank != 2 && rank != 4) throw Error("cc_update: rank must be 2 (T1) or 4 (T2)");
+    need_eps("cc_update");
     dev::cc_update_to(t_out, dt, t_in, r, eps_o, eps_v, shift, delta, no, nv, rank, stream);
 }
 

@@ -247,6 +247,11 @@ double* Engine::ensure_dressed(int pattern) {
 void Engine::set_orbital_energies(const double* eo_host, const double* ev_host) {
     dev::memcpy_h2d(eps_o, eo_host, sizeof(double) * no, stream);
     dev::memcpy_h2d(eps_v, ev_host, sizeof(double) * nv, stream);
+    eps_set = true;
+}
+
+void Engine::need_eps(const char* who) const {
+    if (!eps_set) throw Error(std::string(who) + ": the orbital energies have not been set (pymes_set_orbital_energies)");
 }
 
 // ---------------------------------------------------------------------------------

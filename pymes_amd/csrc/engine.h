@@ -190,6 +190,8 @@ class Engine {
 
     double* eps_o = nullptr;
     double* eps_v = nullptr;
+    bool eps_set = false;              // set_orbital_energies has been called (mp2 and the amplitude updates divide by them)
+    void need_eps(const char* who) const;
     double* splitk_ws() const { return splitk_ws_; }
     int64_t splitk_ws_doubles() const { return splitk_doubles_; }
 

@@ -255,7 +255,7 @@ class Context:
         ring products, amplitude-side dressing).  The reference makes no such assumption, so inputs that violate it
         (a user-built TC Hamiltonian, an FCIDUMP that lists only one of (ij|kl) / (kl|ij)) take the general path."""
         asym, vmax = self.V_exchange_asymmetry()
-        return bool(asym <= rtol * max(1.0, vmax))
+        return bool(np.isfinite(vmax) and asym <= rtol * max(1.0, vmax))
 
     def exchange_symmetric(self, x, rtol=1e-13):
         """X[p,q,r,s] = X[q,p,s,r] (amplitudes: T_abij = T_baji) for a DeviceArray with shape (d0,d0,d2,d2)."""
@@ -263,7 +263,7 @@ class Context:
             raise ValueError("exchange_symmetric: need a [p,p,r,r] array")
         out = (C.c_double * 2)()
         self.lib.call("pymes_exchange_asymmetry", self.handle, C.c_void_p(x.ptr), C.c_void_p(x.ptr), i64_array(x.shape), out)
-        return bool(out[0] <= rtol * max(1.0, out[1]))
+        return bool(np.isfinite(out[1]) and out[0] <= rtol * max(1.0, out[1]))     # inf / NaN entries: never "symmetric"
 
     def set_V_from_factors(self, B):
         B = np.ascontiguousarray(B, dtype=np.float64)

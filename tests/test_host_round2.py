@@ -304,3 +304,23 @@ def test_hole_ladder_packed(sim):
     ctx.ladder_sym_unpack(L, out, beta=0.0)
     assert np.abs(out.get() - np.einsum("abkl,klij->abij", X, I)).max() < 1e-12
     ctx.close()
+
+
+def test_unset_orbital_energies_and_non_finite_amplitudes_fail_loudly(sim):
+    """mp2 / the amplitude updates divide by orbital-energy differences: calling them on a context whose energies were
+    never set is an error, not a read of uninitialised memory; inf / NaN amplitudes never count as exchange-symmetric."""
+    from pymes_amd._lib import PymesError
+    no, nv = 2, 3
+    f, V, t1, t2 = random_case(no, nv, 2, symmetric=True)
+    ctx = Context(no, nv)
+    ctx.set_V_pqrs(V)
+    with pytest.raises(PymesError, match="orbital energies"):
+        ctx.mp2(ctx.empty(t2.shape), 0.0)
+    with pytest.raises(PymesError, match="orbital energies"):
+        ctx.cc_update(ctx.array(t2), ctx.empty(t2.shape), ctx.array(t2), 0.0, 1.0)
+    ctx.set_orbital_energies(np.diag(f)[:no], np.diag(f)[no:])
+    ctx.mp2(ctx.empty(t2.shape), 0.0)
+    bad = t2.copy()
+    bad[0, 0, 0, 0] = np.inf
+    assert ctx.exchange_symmetric(ctx.array(t2)) and not ctx.exchange_symmetric(ctx.array(bad))
+    ctx.close()

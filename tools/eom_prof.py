@@ -10,6 +10,7 @@ no, nv = 30, 120
 B, eps = synthetic.factors(no, nv, seed=0)
 ints = DeviceIntegrals.from_factors(no, B)
 ctx = ints.ctx
+ctx.set_orbital_energies(eps[:no], eps[no:])
 t2 = ctx.empty((nv, nv, no, no)); ctx.mp2(t2, 0.0)
 sig = _Sigma(ctx, np.diag(eps), t2)
 rng = np.random.default_rng(0)

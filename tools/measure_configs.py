@@ -121,6 +121,7 @@ def c5(args):
     B, eps = synthetic.factors(no, nv, seed=0)
     ints = DeviceIntegrals.from_factors(no, B)
     ctx = ints.ctx
+    ctx.set_orbital_energies(eps[:no], eps[no:])
     t2 = ctx.empty((nv, nv, no, no))
     ctx.mp2(t2, 0.0)
     f = np.diag(eps)
