@@ -160,9 +160,11 @@ int pymes_ladder_sym(pymes_ctx* ctx, const double* t2_dev, double* L_dev, int64_
 int pymes_ladder_sym_unpack(pymes_ctx* ctx, const double* L_dev, double* r2_dev, double beta);
 /* Rows [row_begin,row_end) of L += pair-packed sum_kl I_klij X_abkl for a caller-supplied I [o,o,o,o] with I_klij = I_lkji
  * and X [v,v,o,o] with X_abkl = X_balk: the hole-ladder-shaped terms of the EOM-CCSD sigma, eom_ccsd.py:380-382
- * (u2 against V_klij + V_klcd T_cdij; T against V_kldc u2_dcij), at 1/4 of the flops of the plain product. */
+ * (u2 against V_klij + V_klcd T_cdij; T against V_kldc u2_dcij), at 1/4 of the flops of the plain product.  y_dev
+ * (optional, [v,v,o,o], y_cdij = y_dcji): sum_cd V_klcd y_cdij is added to I on the way, formed pair-packed as well (the
+ * caller then passes only the y-independent part of I). */
 int pymes_hole_ladder_packed(pymes_ctx* ctx, const double* x_dev, const double* I_dev, double* L_dev, int64_t row_begin,
-                             int64_t row_end);
+                             int64_t row_end, const double* y_dev);
 /* The symmetry-reduced residual (PYMES_SYM_LADDER | PYMES_SYM_RINGS) in its shardable form, one process per
  * GPU.  pymes_residual_slab computes what rank `rank` of `world` owns: the rows [c0,c1) of ETd and ETx (both
  * [o*v][o*v] on the device; ET[(b,j),(a,i)] = Ex[(a,i),(b,j)], rows cut into `world` chunks of ceil(ov/world))

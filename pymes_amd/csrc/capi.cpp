@@ -301,10 +301,11 @@ int pymes_ladder_sym(pymes_ctx* ctx, const double* t2, double* L, int64_t r0, in
         E(ctx).ladder_sym(t2, L, r0, r1, dressed != 0, hole);
     });
 }
-int pymes_hole_ladder_packed(pymes_ctx* ctx, const double* x, const double* I, double* L, int64_t r0, int64_t r1) {
+int pymes_hole_ladder_packed(pymes_ctx* ctx, const double* x, const double* I, double* L, int64_t r0, int64_t r1,
+                             const double* y) {
     return guarded([&] {
         need(x, "x"); need(I, "I"); need(L, "L");
-        E(ctx).hole_ladder_packed(x, I, L, r0, r1);
+        E(ctx).hole_ladder_packed(x, I, L, r0, r1, y);
     });
 }
 int pymes_ladder_sym_unpack(pymes_ctx* ctx, const double* L, double* r2, double beta) {

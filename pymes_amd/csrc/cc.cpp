@@ -709,9 +709,10 @@ void Engine::ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1,
 
 // A hole-ladder-shaped term sum_kl I_klij X_abkl in the pair-packed rows of L (added to what the rows hold), for
 // I_klij = I_lkji and X_abkl = X_balk: the (k,l) part of ladder_sym for a caller-supplied I (EOM-CCSD: eom_ccsd.py:380-382
-// — u2 against V_klij + V_klcd T_cdij, T against V_kldc u2_dcij), 1/4 of the flops of the plain v^2 o^4 product.
-void Engine::hole_ladder_packed(const double* x, const double* I, double* L, int64_t row0, int64_t row1) {
-    const int64_t o = no, v = nv, npp = v * (v + 1) / 2, opp = o * (o + 1) / 2, opm = o * (o - 1) / 2;
+// — u2 against V_klij + V_klcd T_cdij, T against V_kldc u2_dcij), 1/4 of the flops of the plain v^2 o^4 product.  With y
+// (exchange-symmetric, [v,v,o,o]) the term sum_cd V_klcd y_cdij is added to I on the way, pair-packed too.
+void Engine::hole_ladder_packed(const double* x, const double* I, double* L, int64_t row0, int64_t row1, const double* y) {
+    const int64_t o = no, v = nv, npp = v * (v + 1) / 2, npm = v * (v - 1) / 2, opp = o * (o + 1) / 2, opm = o * (o - 1) / 2;
     if (row0 < 0 || row1 > npp || row0 > row1) throw Error("hole_ladder_packed: bad pair-row range");
     if (row0 == row1) return;
     const int64_t rows = row1 - row0;
@@ -728,8 +729,28 @@ void Engine::hole_ladder_packed(const double* x, const double* I, double* L, int
     }
     dev::ladder_pack_T(I, nullptr, Ip, Im, no, no, dev::PACK_AM_PROWS, ldp, ldm, stream);
     TView Ipv = pitched(Ip, opp, opp, ldp), Imv = pitched(Im, opp, opm, ldm);
-    axpby(2.0, Ipv, 0.0, Ipv);
-    if (opm > 0) axpby(2.0, Imv, 0.0, Imv);
+    if (y) {
+        // I += sum_cd V_klcd y_cdij, formed pair-packed as well (the V.T part of the CCSD hole ladder, ccd.py:180, with y
+        // in the place of T): [opp x npp] . [npp x opp] instead of the o^2 x v^2 x o^2 product
+        if (!static_.count("VpIjab")) {
+            double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * npp));
+            double* vm = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * std::max<int64_t>(npm, 1)));
+            static_["VpIjab"] = vp;
+            static_["VmIjab"] = vm;
+            dev::ladder_pack_V(block(P_ijab).p, vp, vm, no, nv, 0, opp, stream);
+        }
+        ArenaScope s2(arena);
+        double* Sp = arena.alloc(npp * ldp);
+        double* Am = arena.alloc(std::max<int64_t>(npm * ldm, 1));
+        dev::ladder_pack_T(y, nullptr, Sp, Am, no, nv, dev::PACK_ROW_HALF, ldp, ldm, stream);
+        contract(2.0, make_view(static_["VpIjab"], {opp, npp}), "rk", pitched(Sp, npp, opp, ldp), "kn", 2.0, Ipv, "rn");
+        if (opm > 0 && npm > 0)
+            contract(2.0, make_view(static_["VmIjab"], {opp, npm}), "rk", pitched(Am, npm, opm, ldm), "kn", 2.0, Imv, "rn");
+        else if (opm > 0) axpby(2.0, Imv, 0.0, Imv);
+    } else {
+        axpby(2.0, Ipv, 0.0, Ipv);
+        if (opm > 0) axpby(2.0, Imv, 0.0, Imv);
+    }
     double* SpR = arena.alloc(npp * ldp);
     double* AmR = arena.alloc(npp * ldp);
     dev::ladder_pack_T(x, nullptr, SpR, AmR, no, nv, dev::PACK_COL_HALF | dev::PACK_AM_PROWS | dev::PACK_AM_PCOLS, ldp, ldp, stream,

@@ -151,7 +151,8 @@ class Engine {
     // rows [row0,row1) of the pair-packed result L[v(v+1)/2][o*o] (device_api.h), then R = beta R + unpack(L)
     // hole = 1 / 2 adds the hole ladder (ccd.py:175-186; CCSD / DCSD form of I_klij) to the same rows
     void ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1, bool dressed, int hole = 0);
-    void hole_ladder_packed(const double* x, const double* I, double* L, int64_t row0, int64_t row1);
+    void hole_ladder_packed(const double* x, const double* I, double* L, int64_t row0, int64_t row1,
+                            const double* y = nullptr);
     void ladder_sym_unpack(const double* L, double* r2, double beta);
     // symmetry-reduced residual in shardable form (cc.cpp): this rank's column slab of the ring products
     // (rows of ETd/ETx) and its rows of the packed ladder L; then the replicated remainder + assembly

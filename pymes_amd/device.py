@@ -431,10 +431,11 @@ class Context:
                       int(row_end), int(dressed), int(hole_ladder))
         return L
 
-    def hole_ladder_packed(self, x, I, L, row_begin, row_end):
-        """Rows of the pair-packed L += sum_kl I_klij X_abkl (I_klij = I_lkji, X_abkl = X_balk); include/pymes_amd.h."""
+    def hole_ladder_packed(self, x, I, L, row_begin, row_end, y=None):
+        """Rows of the pair-packed L += sum_kl (I_klij + sum_cd V_klcd y_cdij) X_abkl (I_klij = I_lkji, X_abkl = X_balk,
+        y optional and exchange-symmetric); include/pymes_amd.h."""
         self.lib.call("pymes_hole_ladder_packed", self.handle, C.c_void_p(x.ptr), C.c_void_p(I.ptr), C.c_void_p(L.ptr),
-                      int(row_begin), int(row_end))
+                      int(row_begin), int(row_end), C.c_void_p(y.ptr if y is not None else 0))
         return L
 
     def ladder_sym_unpack(self, L, out, beta=1.0):

@@ -182,19 +182,23 @@ class _Sigma:
         # ---- P(ijab, jiba) (:377), then the unpermuted terms (:380-383) ----------------------------------
         S = c.permute("baji->abij", D)
         c.lincomb(D, [D, S], [1.0, 1.0])
+        if self.v_sym and u2_sym and self.hole_sym:
+            # all three remaining terms in the pair-packed rows (a >= b, i >= j): the particle ladder (:383) and the two
+            # hole-ladder-shaped products (:380-382; B2 and B' are symmetric under (kl)(ij) -> (lk)(ji)) — 1/4 of their
+            # flops; B' = V_kldc u2_dcij itself is formed pair-packed inside the second call, on top of the symmetrised
+            # u1 term that was held back above
+            npp = self.L.shape[0]
+            B5s = c.permute("klij->klij", B5)
+            c.permute("lkji->klij", B5, out=B5s, beta=1.0)
+            c.ladder_sym(u2, self.L, 0, npp)
+            c.hole_ladder_packed(u2, self.B2, self.L, 0, npp)
+            c.hole_ladder_packed(T, B5s, self.L, 0, npp, y=u2)
+            c.ladder_sym_unpack(self.L, D, beta=1.0)
+            return D
         Bn = c.contract("kldc,dcij->klij", V["ijab"], u2)
         if self.t_sym:           # + the symmetrised u1 term that was held back above
             c.permute("klij->klij", B5, out=Bn, beta=1.0)
             c.permute("lkji->klij", B5, out=Bn, beta=1.0)
-        if self.v_sym and u2_sym and self.hole_sym:
-            # all three remaining terms in the pair-packed rows (a >= b, i >= j): the particle ladder (:383) and the two
-            # hole-ladder-shaped products (:380-382; B2 and B' are symmetric under (kl)(ij) -> (lk)(ji)) — 1/4 of their flops
-            npp = self.L.shape[0]
-            c.ladder_sym(u2, self.L, 0, npp)
-            c.hole_ladder_packed(u2, self.B2, self.L, 0, npp)
-            c.hole_ladder_packed(T, Bn, self.L, 0, npp)
-            c.ladder_sym_unpack(self.L, D, beta=1.0)
-            return D
         c.contract("abkl,klij->abij", u2, self.B2, out=D, beta=1.0)               # :380, :382
         c.contract("abkl,klij->abij", T, Bn, out=D, beta=1.0)                     # :381
         if self.v_sym and u2_sym:                                                 # :383

@@ -303,6 +303,16 @@ def test_hole_ladder_packed(sim):
     out = ctx.zeros(X.shape)
     ctx.ladder_sym_unpack(L, out, beta=0.0)
     assert np.abs(out.get() - np.einsum("abkl,klij->abij", X, I)).max() < 1e-12
+    # with y: I + V_klcd y_cdij, the V.T part formed pair-packed too
+    f, V, _, _ = random_case(no, nv, 4, symmetric=True)
+    ctx.set_V_pqrs(V)
+    Y = rng.standard_normal((nv, nv, no, no))
+    Y = Y + Y.transpose(1, 0, 3, 2)
+    L.zero_()
+    ctx.hole_ladder_packed(dX, dI, L, 0, npp, y=ctx.array(Y))
+    ctx.ladder_sym_unpack(L, out, beta=0.0)
+    Ifull = I + np.einsum("klcd,cdij->klij", V[:no, :no, no:, no:], Y)
+    assert np.abs(out.get() - np.einsum("abkl,klij->abij", X, Ifull)).max() < 1e-11
     ctx.close()
 
 
