@@ -158,6 +158,12 @@ int pymes_ladder(pymes_ctx* ctx, const double* t2_dev, double* r2_dev, int a_beg
 int pymes_ladder_sym(pymes_ctx* ctx, const double* t2_dev, double* L_dev, int64_t row_begin, int64_t row_end,
                      int dressed, int hole_ladder);
 int pymes_ladder_sym_unpack(pymes_ctx* ctx, const double* L_dev, double* r2_dev, double beta);
+/* P(ijab,jiba) symmetrisation and assembly in one pass (ccd.py:249-252, eom_ccsd.py:377):
+ *   R_abij = V_abij + unpack(L)_abij + N_abij + N_baji + D[(a,i),(b,j)] + D[(b,j),(a,i)] + X[(a,j),(b,i)] + X[(b,i),(a,j)]
+ * with V [v,v,o,o] (NULL: 0; may be R), L the pair-packed rows of pymes_ladder_sym (NULL: none), N [v,v,o,o], D and X
+ * [o*v][o*v] pair matrices ((a,i) = a*o + i).  Needs o(o+1) doubles of LDS (pymes_residual_finish uses it internally). */
+int pymes_symmetrised_assemble(pymes_ctx* ctx, const double* V_dev, const double* L_dev, const double* N_dev,
+                               const double* D_dev, const double* X_dev, double* R_dev);
 /* Rows [row_begin,row_end) of L += pair-packed sum_kl I_klij X_abkl for a caller-supplied I [o,o,o,o] with I_klij = I_lkji
  * and X [v,v,o,o] with X_abkl = X_balk: the hole-ladder-shaped terms of the EOM-CCSD sigma, eom_ccsd.py:380-382
  * (u2 against V_klij + V_klcd T_cdij; T against V_kldc u2_dcij), at 1/4 of the flops of the plain product.  y_dev

@@ -301,6 +301,15 @@ int pymes_ladder_sym(pymes_ctx* ctx, const double* t2, double* L, int64_t r0, in
         E(ctx).ladder_sym(t2, L, r0, r1, dressed != 0, hole);
     });
 }
+int pymes_symmetrised_assemble(pymes_ctx* ctx, const double* V, const double* L, const double* N, const double* D,
+                               const double* X, double* R) {
+    return guarded([&] {
+        need(N, "N"); need(D, "D"); need(X, "X"); need(R, "R");
+        pymes::Engine& e = E(ctx);
+        if (!dev::fused_pair_kernels_ok(e.no)) throw pymes::Error("symmetrised_assemble: nocc too large for the LDS tile");
+        dev::residual_assemble(V, L, N, D, X, R, e.no, e.nv, e.stream);
+    });
+}
 int pymes_hole_ladder_packed(pymes_ctx* ctx, const double* x, const double* I, double* L, int64_t r0, int64_t r1,
                              const double* y) {
     return guarded([&] {

@@ -149,7 +149,7 @@ bool fused_pair_kernels_ok(int no);
 void t2_layouts(const double* T, double* Td, double* Tx, double* Ttd, int no, int nv, stream_t s);
 // Assembly of the symmetry-reduced residual (ccd.py:249-252) in one pass:
 //   R_abij = V_abij + unpack(L)_abij + N_abij + N_baji + D[(a,i),(b,j)] + D[(b,j),(a,i)] + X[(a,j),(b,i)] + X[(b,i),(a,j)]
-// L (pair-packed ladder rows, may be null), N [v,v,o,o], D and X [ov,ov]
+// L (pair-packed ladder rows, may be null), V (may be null: 0), N [v,v,o,o], D and X [ov,ov]
 void residual_assemble(const double* V, const double* L, const double* N, const double* D, const double* X, double* R,
                        int no, int nv, stream_t s);
 // ---- pair-sharded tail: compact storage Xc[P - r0][2][o*o] of the tiles X[a,b,:,:], X[b,a,:,:] (zeros for a == b)

@@ -1241,8 +1241,8 @@ __global__ void __launch_bounds__(256) residual_assemble_kernel(const double* V,
             if (a != b && i != j) la = row[opp + (long)ih * (ih - 1) / 2 + il];
         }
         const double sgn = i > j ? 1.0 : -1.0;
-        R[ab + e] = V[ab + e] + ls + sgn * la + S[i * p + j];
-        if (a != b) R[ba + e] = V[ba + e] + ls - sgn * la + S[j * p + i];
+        R[ab + e] = (V ? V[ab + e] : 0.0) + ls + sgn * la + S[i * p + j];
+        if (a != b) R[ba + e] = (V ? V[ba + e] : 0.0) + ls - sgn * la + S[j * p + i];
     }
 }
 

@@ -431,6 +431,14 @@ class Context:
                       int(row_end), int(dressed), int(hole_ladder))
         return L
 
+    def symmetrised_assemble(self, N, D, X, out, V=None, L=None):
+        """out_abij = V + unpack(L) + N_abij + N_baji + D[(a,i),(b,j)] + D[(b,j),(a,i)] + X[(a,j),(b,i)] + X[(b,i),(a,j)] in one
+        pass (include/pymes_amd.h); V / L optional."""
+        self.lib.call("pymes_symmetrised_assemble", self.handle, C.c_void_p(V.ptr if V is not None else 0),
+                      C.c_void_p(L.ptr if L is not None else 0), C.c_void_p(N.ptr), C.c_void_p(D.ptr), C.c_void_p(X.ptr),
+                      C.c_void_p(out.ptr))
+        return out
+
     def hole_ladder_packed(self, x, I, L, row_begin, row_end, y=None):
         """Rows of the pair-packed L += sum_kl (I_klij + sum_cd V_klcd y_cdij) X_abkl (I_klij = I_lkji, X_abkl = X_balk,
         y optional and exchange-symmetric); include/pymes_amd.h."""

@@ -106,6 +106,7 @@ class _Sigma:
         self.v_sym = c.exchange_symmetric(V["abcd"])
         # T_abij = T_baji (every CCSD solution): P(ijab,jiba)[T B5] = T (B5 + B5^(lkji)), so that term rides in the
         # product with B' of eom_ccsd.py:381 — one v^2 o^4 product less per sigma
+        self.fused_ok = c.pairs_supported()
         self.t_sym = c.exchange_symmetric(T)
         # eom_ccsd.py:380-382 in pair-packed rows needs B2_klij = B2_lkji and V_klcd = V_lkdc (then B' has it for symmetric u2)
         self.hole_sym = self.t_sym and c.exchange_symmetric(self.B2) and c.exchange_symmetric(V["ijab"])
@@ -177,12 +178,24 @@ class _Sigma:
             c.contract("abkl,klij->abij", T, B5, out=D, beta=1.0)
         c.contract("ak,kbij->abij", u1, V["iajk"], out=D, alpha=-1.0, beta=1.0)
         c.contract("abic,cj->abij", V["abic"], u1, out=D, beta=1.0)
+        packed = self.v_sym and u2_sym and self.hole_sym
+        if packed and self.fused_ok:
+            # the terms (:380-383) that stay outside P(ijab,jiba) all live in the pair-packed rows L here, so the
+            # symmetrisation (:377) of D and of the two pair matrices and the unpacking of L are ONE pass (the assembly
+            # kernel of the CCSD residual) instead of two transposed accumulations, a transposition, a sum and an unpack
+            npp = self.L.shape[0]
+            B5s = c.permute("klij->klij", B5)
+            c.permute("lkji->klij", B5, out=B5s, beta=1.0)
+            c.ladder_sym(u2, self.L, 0, npp)
+            c.hole_ladder_packed(u2, self.B2, self.L, 0, npp)
+            c.hole_ladder_packed(T, B5s, self.L, 0, npp, y=u2)
+            return c.symmetrised_assemble(D, Dd, Dx, c.empty(D.shape), L=self.L)
         c.permute("aibj->abij", Dd, out=D, beta=1.0)
         c.permute("ajbi->abij", Dx, out=D, beta=1.0)
         # ---- P(ijab, jiba) (:377), then the unpermuted terms (:380-383) ----------------------------------
         S = c.permute("baji->abij", D)
         c.lincomb(D, [D, S], [1.0, 1.0])
-        if self.v_sym and u2_sym and self.hole_sym:
+        if packed:
             # all three remaining terms in the pair-packed rows (a >= b, i >= j): the particle ladder (:383) and the two
             # hole-ladder-shaped products (:380-382; B2 and B' are symmetric under (kl)(ij) -> (lk)(ji)) — 1/4 of their
             # flops; B' = V_kldc u2_dcij itself is formed pair-packed inside the second call, on top of the symmetrised

@@ -318,7 +318,7 @@ void residual_assemble(const double* V, const double* L, const double* N, const 
             for (int i = 0; i < no; ++i)
                 for (int j = 0; j < no; ++j) {
                     const int64_t e = ((int64_t)a * nv + b) * o2 + i * no + j;
-                    double v = V[e] + N[e] + N[((int64_t)b * nv + a) * o2 + j * no + i] + pm(D, a, i, b, j) +
+                    double v = (V ? V[e] : 0.0) + N[e] + N[((int64_t)b * nv + a) * o2 + j * no + i] + pm(D, a, i, b, j) +
                                pm(D, b, j, a, i) + pm(X, a, j, b, i) + pm(X, b, i, a, j);
                     if (L) {
                         const int ah = a > b ? a : b, al = a > b ? b : a, ih = i > j ? i : j, il = i > j ? j : i;
