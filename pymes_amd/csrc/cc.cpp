@@ -39,6 +39,10 @@ double* Engine::get_static(const std::string& key) {
     // all keys: source labels of V_ijab are "klcd" (k,l occupied; c,d virtual)
     if (key == "Vd") permute(1.0, Vijab, "klcd", 0.0, make_view(p, {v, o, v, o}), "ckdl");        // [(c,k),(d,l)]
     else if (key == "Vx") permute(1.0, Vijab, "klcd", 0.0, make_view(p, {v, o, v, o}), "cldk");   // [(c,l),(d,k)]
+    else if (key == "Ld") {                                      // 2 Vd - Vx: Ld[(c,k),(d,l)] = 2 V_klcd - V_lkcd
+        permute(2.0, Vijab, "klcd", 0.0, make_view(p, {v, o, v, o}), "ckdl");
+        permute(-1.0, Vijab, "lkcd", 1.0, make_view(p, {v, o, v, o}), "ckdl");
+    }
     else if (key == "Vk") permute(1.0, Vijab, "lkdc", 0.0, make_view(p, {o, v, o, v}), "kdlc");   // [(k,d,l),c]
     else if (key == "Vk2") permute(1.0, Vijab, "lkdc", 0.0, make_view(p, {o, v, v, o}), "kcdl");  // [k,(c,d,l)]
     // K-major copies for the o x o results contracted over o v^2 (K = 2e6 at the benchmark size): with the long index
@@ -252,7 +256,6 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
     ArenaScope scope(arena);
     auto pairm = [&](double* p) { return make_view(p, {ov, ov}); };
     auto slab = [&]() { return make_view(arena.alloc(ov * nc), {ov, nc}); };
-    TView Vd = pairm(get_static("Vd"));
     for (auto& p : lay_)
         if (!p) p = static_cast<double*>(dev::dmalloc(sizeof(double) * ov * ov));
     lay_t2_ = nullptr;
@@ -287,39 +290,45 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
             copy(slice(tmp, 1, c0 - b0 * o, c1 - b0 * o), dst);
         }
     };
+    // ---- the o^3 v^3 terms in four products (three for DCSD).  With pair matrices on (a,i) = a*o + i, all symmetric,
+    //   Wd[(c,k),(b,j)] = V~_iabj[k,b,c,j],  Ud^T[(c,k),(b,j)] = V~_iajb[k,b,j,c],  Ld = 2 Vd - Vx  (L_ldkc = 2 g_ldkc - g_lckd)
+    // the ten ring products of ccd.py:190-191, :199-204, :233-240 are, for V_pqrs = V_qpsr and T_abij = T_baji, exactly
+    //   D-term:  Ex_d  = 1/2 Tt_d (2 Wd - Ud^T + 1/2 Ld Tt_d)            (one build, one application)
+    //   C-term:  Xc    = Tx (Ud^T - 1/2 Vx Tx),   Ex_d -= 1/2 Xc,   Ex_x = -Xc     (one build, ONE application, used in both
+    //            index placements — the (1/2 + P_ij) of the closed-shell CCSD doubles equations in their C / D form)
+    // (numerically identical to the reference's sequence to rounding: tests/test_host_round2.py pins the identity and every
+    // golden solve pins the result).  DCSD keeps ccd.py:202-204 only: 2 Wd - Ud^T + Vd Tt_d in the D-term, no build in the
+    // C-term.  Column slab [c0,c1): both builds are restricted to the rank's columns n, the applications give rows n.
     TView M = slab(), N1 = slab();
-    load_cols(1.0, Viabj, "kbcj", M);                                                         // M = Wd
+    load_cols(2.0, Viabj, "kbcj", M);                                                         // M = 2 Wd
     load_cols(-1.0, Viajb, "kbjc", N1);                                                       // N1 = -UdT
-    // Y = Vd Tt_d (:202) carries the small V.T sums as partial traces: S_ac = sum_k Y[(c,k),(a,k)], S_ki = sum_c Y[(c,k),(c,i)]
-    // (exchange-symmetric V and T).  With all columns on this rank they are read off M = Wd + Y/2 before and after the
-    // product, 2 (tr M - tr Wd): no o^2 v^3 / o^3 v^2 products and no transposition for X_ac, X_ki and ccsd.py:434, :436
+    axpby(1.0, N1, 1.0, M);                                                                  // M = 2 Wd - UdT
+    // The small V.T sums S_ac = sum_dkl Tt_adkl V_lkdc, S_ki = sum_cdl Tt_cdil V_lkdc (X_ac, X_ki, ccsd.py:434 / :436) are
+    // partial traces of the builds: tr(Vd Tt_d) for DCSD, (3 tr(Vx Tx) + tr(Ld Tt_d)) / 4 for CCSD — read off the
+    // accumulators before and after the products (all columns on this rank only)
     const bool traces = !P && nc == ov;
+    const double cz = quad ? 0.5 : 1.0, cu = 1.5;          // (tr after - tr before) x these = the contribution to S
     if (traces) {
         ensure_xs();
         xs_oo_tag_.clear();
         xs_vv_tag_.clear();
-        dev::pair_traces(M.p, nc, -2.0, 0.0, xs_vv_, xs_oo_, no, nv, stream);
+        dev::pair_traces(M.p, nc, -cz, 0.0, xs_vv_, xs_oo_, no, nv, stream);
+        if (quad) dev::pair_traces(N1.p, nc, -cu, 1.0, xs_vv_, xs_oo_, no, nv, stream);
     }
-    contract(0.5, Vd, "xy", cols(Ttd), "yn", 1.0, M, "xn");                                  // M = Wd + Y/2   (:202)
+    if (quad) {
+        contract(0.5, pairm(get_static("Ld")), "xy", cols(Ttd), "yn", 1.0, M, "xn");         // M = 2 Wd - UdT + Ld Tt_d / 2
+        contract(0.5, pairm(get_static("Vx")), "xy", cols(Tx), "yn", 1.0, N1, "xn");         // N1 = -(UdT - Vx Tx / 2)
+    } else {
+        contract(1.0, pairm(get_static("Vd")), "xy", cols(Ttd), "yn", 1.0, M, "xn");         // M = 2 Wd - UdT + Vd Tt_d
+    }
     if (traces) {
-        dev::pair_traces(M.p, nc, 2.0, 1.0, xs_vv_, xs_oo_, no, nv, stream);
+        dev::pair_traces(M.p, nc, cz, 1.0, xs_vv_, xs_oo_, no, nv, stream);
+        if (quad) dev::pair_traces(N1.p, nc, cu, 1.0, xs_vv_, xs_oo_, no, nv, stream);
         xs_oo_tag_.set(t2, 0, 1);
         xs_vv_tag_.set(t2, 0, 1);
     }
-    contract(1.0, M, "kn", Ttd, "mk", 0.0, ETd, "nm");                                       // :204 (half) + :235
-    if (quad) {
-        // U = Vx Tx (:190), U' = Vx Td (:238):  X3 = U/2 - UdT,  M2 = -UdT + U - U' = 2 X3 + UdT - U'
-        TView Vx = pairm(get_static("Vx"));
-        TView X3 = M;                                                                        // M is free again
-        contract(0.5, Vx, "xy", cols(Tx), "yn", 1.0, X3, "xn", "", &N1);                     // X3 = N1 + U/2
-        axpby(2.0, X3, -1.0, N1);                                                            // N1 = 2 X3 + UdT
-        contract(-1.0, Vx, "xy", cols(Td), "yn", 1.0, N1, "xn");                             // N1 = M2
-        contract(1.0, N1, "kn", Td, "mk", 1.0, ETd, "nm");                                   // :233, :238-240
-        contract(1.0, X3, "kn", Tx, "mk", 0.0, ETx, "nm");                                   // :234, :191 (half)
-    } else {
-        contract(1.0, N1, "kn", Td, "mk", 1.0, ETd, "nm");                                   // :233
-        contract(1.0, N1, "kn", Tx, "mk", 0.0, ETx, "nm");                                   // :234
-    }
+    contract(1.0, N1, "kn", Tx, "mk", 0.0, ETx, "nm");                                       // Ex_x = -Xc
+    contract(0.5, M, "kn", Ttd, "mk", 0.5, ETd, "nm", "", &ETx);                             // Ex_d = D-term - Xc / 2
     {
         // :232  Ex[a,b,i,j] -= X_ki T[a,b,k,j]  ->  ET[(b,j),(a,i)] -= sum_k Td[(b,j),(a,k)] X_ki   (Td symmetric)
         ArenaScope s2(arena);
