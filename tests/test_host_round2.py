@@ -334,3 +334,51 @@ def test_unset_orbital_energies_and_non_finite_amplitudes_fail_loudly(sim):
     bad[0, 0, 0, 0] = np.inf
     assert ctx.exchange_symmetric(ctx.array(t2)) and not ctx.exchange_symmetric(ctx.array(bad))
     ctx.close()
+
+
+def test_ring_terms_in_four_products():
+    """for V_pqrs = V_qpsr and T_abij = T_baji the ten o^3v^3 products of ccd.py:190-191, :199-204, :233-240 equal
+    the C / D form  Ex_d = 1/2 Tt_d (2 Wd - Ud^T + 1/2 Ld Tt_d) - 1/2 Xc,  Ex_x = -Xc,  Xc = Tx (Ud^T - 1/2 Vx Tx)  (four
+    products; DCSD: Vd in place of Ld/2 and no Vx Tx: three), and the small V.T sums are (3 tr(Vx Tx) + tr(Ld Tt_d)) / 4.
+    Pure numpy on the reference's expressions — what cc.cpp::residual_slab relies on."""
+    rng = np.random.default_rng(3)
+    o, v = 3, 4
+    n, ov = o + v, o * v
+    V = rng.standard_normal((n, n, n, n))
+    V = V + V.transpose(1, 0, 3, 2)                               # electron-exchange symmetry only
+    T = rng.standard_normal((v, v, o, o))
+    T = T + T.transpose(1, 0, 3, 2)
+    Vijab, Viajb, Viabj = V[:o, :o, o:, o:], V[:o, o:, :o, o:], V[:o, o:, o:, :o]
+    Tt = 2.0 * T - T.transpose(1, 0, 2, 3)
+    Td = T.transpose(0, 2, 1, 3).reshape(ov, ov)
+    Tx = T.transpose(0, 3, 1, 2).reshape(ov, ov)
+    Ttd = Tt.transpose(0, 2, 1, 3).reshape(ov, ov)
+    Vd = np.einsum("klcd->ckdl", Vijab).reshape(ov, ov)
+    Vx = np.einsum("klcd->cldk", Vijab).reshape(ov, ov)
+    Wd = np.einsum("kbcj->ckbj", Viabj).reshape(ov, ov)
+    UdT = np.einsum("kbjc->ckbj", Viajb).reshape(ov, ov)
+    for quad in (True, False):
+        # the reference's sequence
+        R = np.zeros_like(T)
+        if quad:
+            R += np.einsum("alcj,cbil->abij", np.einsum("klcd,adkj->alcj", Vijab, T), T)            # :190-191
+        R += np.einsum("acik,cbkj->abij", Tt, np.einsum("klcd,dblj->cbkj", Vijab, Tt))               # :202-204
+        Ex = -np.einsum("kaic,cbkj->abij", Viajb, T) - np.einsum("kbic,ackj->abij", Viajb, T)        # :233-234
+        Ex += np.einsum("acik,kbcj->abij", Tt, Viabj)                                                # :235
+        if quad:
+            Xa = np.einsum("klcd,daki->alci", Vijab, T)                                              # :238
+            Ex += np.einsum("alci,bclj->abij", Xa, T) - np.einsum("alci,cblj->abij", Xa, T)          # :239-240
+        ref = R + Ex + Ex.transpose(1, 0, 3, 2)
+        # the product path
+        M = 2.0 * Wd - UdT + (0.5 * (2.0 * Vd - Vx) if quad else Vd) @ Ttd
+        X3 = -UdT + (0.5 * Vx @ Tx if quad else 0.0)
+        ETx = X3.T @ Tx.T
+        ETd = 0.5 * (M.T @ Ttd.T) + 0.5 * ETx
+        new = np.einsum("aibj->abij", ETd.reshape(v, o, v, o)) + np.einsum("ajbi->abij", ETx.reshape(v, o, v, o))
+        new = new + new.transpose(1, 0, 3, 2)
+        assert np.abs(new - ref).max() < 1e-11 * np.abs(ref).max(), quad
+    S_ac = np.einsum("adkl,lkdc->ac", Tt, Vijab)
+    S_ki = np.einsum("cdil,lkdc->ki", Tt, Vijab)
+    Z4, U4 = ((2.0 * Vd - Vx) @ Ttd).reshape(v, o, v, o), (Vx @ Tx).reshape(v, o, v, o)
+    assert np.abs((3.0 * np.einsum("ckak->ac", U4) + np.einsum("ckak->ac", Z4)) / 4.0 - S_ac).max() < 1e-12
+    assert np.abs((3.0 * np.einsum("ckci->ki", U4) + np.einsum("ckci->ki", Z4)) / 4.0 - S_ki).max() < 1e-12
