@@ -203,13 +203,11 @@ void Engine::doubles_residual(const double* f, const double* t2, double* r2, uns
 // -----------------------------------------------------------------------------------
 // Symmetry-reduced, shardable T2 residual (requires T_abij = T_baji and V_pqrs = V_qpsr).
 //
-// Exchange-symmetric amplitudes make Td, Tx, Tt_d, Vd, Vx symmetric ov x ov matrices.  Then
-// (a) Tt_d Vd Tt_d (ccd.py:202-204) and Tx Vx Tx (:190-191) are symmetric, so half of each can be
-// carried inside Ex, which is symmetrised at :249 anyway, and (b) -Ud Td (:233) may be replaced by
-// its transpose -Td Ud^T.  Every o^3v^3 term then has Td, Tt_d or Tx as LEFT factor and the right
-// factors are summed first: 6 products instead of 10 (4 instead of 5 for DCSD):
-//     Exd = Tt_d (Wd + Y/2) + Td (-UdT + U - U'),   Exx = Tx (U/2 - UdT)
-//     Y = Vd Tt_d,  U = Vx Tx,  U' = Vx Td,  UdT[(c,k),(b,j)] = V_iajb[k,b,j,c]
+// Exchange-symmetric amplitudes make Td, Tx, Tt_d, Vd, Vx symmetric ov x ov matrices.  Round 1 merged the ten
+// o^3v^3 products of the reference into 6 (5 -> 4 for DCSD) inside its own term structure; round 2 uses the C / D form of
+// the closed-shell doubles equations, which is the same sum in 4 (3) products — see the comment at the products below:
+//     Exd = 1/2 Tt_d (2 Wd - UdT + 1/2 Ld Tt_d) - 1/2 Xc,   Exx = -Xc,   Xc = Tx (UdT - 1/2 Vx Tx),   Ld = 2 Vd - Vx,
+//     Wd[(c,k),(b,j)] = V_iabj[k,b,c,j],  UdT[(c,k),(b,j)] = V_iajb[k,b,j,c]
 // COLUMNS (b,j) of these products never mix, so a rank needs no communication to compute its column
 // slab; the slab is produced TRANSPOSED (ET[(b,j),(a,i)] = Ex[(a,i),(b,j)]) so that the slabs of all
 // ranks are contiguous row blocks of ETd / ETx = one all-gather each.  Since only Ex + Ex^T enters R
