@@ -68,11 +68,9 @@ class _Sigma:
         self.M2 = c.empty(self.M1.shape)
         c.lincomb(self.M2, [self.M_D, self.M_C, self.Ud], [1.0, -2.0, -1.0])
         # for exchange-symmetric trial doubles ut = 2 u2 - u2^(ab) is 2 u2d - u2x in the pair layout, so
-        # M1.utd + M2.u2d + M_C.u2x = (2 M1 + M2).u2d + (M_C - M1).u2x: two products instead of three
+        # M1.utd + M2.u2d + M_C.u2x = (2 M1 + M2).utd / 2 + (M_D - Ud).u2x / 2 (see doubles()): one product + half of Dx
         self.M12 = c.empty(self.M1.shape)
         c.lincomb(self.M12, [self.M1, self.M2], [2.0, 1.0])
-        self.MC1 = c.empty(self.M1.shape)
-        c.lincomb(self.MC1, [self.M_C, self.M1], [1.0, -1.0])
         # crossed layout: the result is symmetrised by P(ijab, jiba) (:377), i.e. only Dx + Dx^T counts, and u2x is a
         # symmetric matrix for exchange-symmetric u2, so -u2x.Ud^T (:364) may be replaced by its transpose -Ud.u2x:
         # M_D.u2x - Ud.u2x = (M_D - Ud).u2x, one product instead of two
@@ -133,23 +131,24 @@ class _Sigma:
         """eom_ccsd.py:312-385.  ``u2_sym``: the caller's knowledge that u2_abij = u2_baji (checked here, with a
         device-to-host synchronisation, when None)."""
         c, V, T = self.ctx, self.V, self.T
-        u2d = c.permute("abij->aibj", u2)
         u2x = c.permute("abij->ajbi", u2)
         if u2_sym is None:
             u2_sym = self.exchange_symmetric(u2)
         # ---- (ov)^3 products -----------------------------------------------------------------------
+        utd = c.permute("abij->aibj", u2, alpha=2.0)                  # ut[d,b,l,j] = 2u2[d,b,l,j] - u2[b,d,l,j]
+        c.permute("baij->aibj", u2, out=utd, alpha=-1.0, beta=1.0)
         if u2_sym:
-            Dd = c.contract("aidl,dlbj->aibj", self.M12, u2d)
-            c.contract("aidl,dlbj->aibj", self.MC1, u2x, out=Dd, beta=1.0)
+            # exchange-symmetric u2: utd = 2 u2d - u2x as matrices, hence M1.utd + M2.u2d + M_C.u2x =
+            # (2 M1 + M2).utd / 2 + (M_D - Ud).u2x / 2, and the second product IS Dx (the C / D form of the ring terms, as
+            # in the CCSD residual): TWO (ov)^3 products per sigma, Dd = M12.utd / 2 + Dx / 2
+            Dx = c.contract("ajdl,dlbi->ajbi", self.MDU, u2x)                     # :372 and :364 (transposed)
+            Dd = c.permute("ajbi->ajbi", Dx, alpha=0.5)                           # same memory layout as "aibj"
+            c.contract("aidl,dlbj->aibj", self.M12, utd, out=Dd, alpha=0.5, beta=1.0)
         else:
-            utd = c.permute("abij->aibj", u2, alpha=2.0)              # ut[d,b,l,j] = 2u2[d,b,l,j] - u2[b,d,l,j]
-            c.permute("baij->aibj", u2, out=utd, alpha=-1.0, beta=1.0)
+            u2d = c.permute("abij->aibj", u2)
             Dd = c.contract("aidl,dlbj->aibj", self.M1, utd)
             c.contract("aidl,dlbj->aibj", self.M2, u2d, out=Dd, beta=1.0)
             c.contract("aidl,dlbj->aibj", self.M_C, u2x, out=Dd, beta=1.0)      # u2x[(d,l),(b,j)] = u2[d,b,j,l]
-        if u2_sym:
-            Dx = c.contract("ajdl,dlbi->ajbi", self.MDU, u2x)                     # :372 and :364 (transposed)
-        else:
             Dx = c.contract("ajdl,dlbi->ajbi", self.M_D, u2x)                     # :372  u2[d,b,i,l]
             c.contract("ajck,bick->ajbi", u2x, self.Ud, out=Dx, alpha=-1.0, beta=1.0)  # :364
         # ---- one-index dressings -----------------------------------------------------------------------
