@@ -142,7 +142,7 @@ int pymes_ccsd_singles_residual_partial(pymes_ctx* ctx, const double* fd_dev, co
                                  on it: its pair layouts (Td, Tx, 2T - T^(ab)) are read again instead of being rebuilt
                                  (pymes_residual_finish, pymes_ccsd_singles_residual_partial) */
 #define PYMES_SYM_RINGS 16u   /* same precondition: merge the o^3v^3 ring/exchange products through the symmetry of
-                                 the pair matrices (6 products instead of 10; 4 instead of 5 for DCSD) */
+                                 the pair matrices (C / D form: 4 products instead of 10; 3 instead of 5 for DCSD) */
 int pymes_doubles_residual(pymes_ctx* ctx, const double* f_dev, const double* t2_dev, double* r2_dev,
                            uint32_t flags);
 /* the particle-particle ladder on an a-slab (ccd.py:187): R[a0:a1] = beta*R[a0:a1] + V_abcd[a0:a1].T */
