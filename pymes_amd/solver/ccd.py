@@ -208,10 +208,10 @@ class CCD:
             mine = DeviceArray(ctx, sh["Tall"].ptr + 8 * sh["lo"] * 2 * ctx.no * ctx.no, (n, 2, ctx.no * ctx.no),
                                owned=False, keepalive=sh["Tall"])
             mine.copy_from(DeviceArray(ctx, tc.ptr, mine.shape, owned=False, keepalive=tc))
-        pending = pdist.exchange_rows_start(sh["Tall_t"], rank, world, ctx)
-        # energy (:132) and norms from the compact tiles of this rank's pairs: partial sums, one all-reduce of six doubles,
-        # enqueued while the all-gather of the new amplitudes is in flight
+        # energy (:132) and norms from the compact tiles of this rank's pairs: partial sums, one all-reduce of six doubles
+        # (issued before the big transfer: collectives of one communicator run in order)
         _, e_dir, e_ex, nt2, nr2, _ = pdist.allreduce_sum(ctx.energy_norms_pairs(None, None, tc, dtc, rank, world))
+        pending = pdist.exchange_rows_start(sh["Tall_t"], rank, world, ctx)
         pending.wait()
         ctx.pairs_unpack(sh["Tall"], t2, world)
         if not self.is_diis:

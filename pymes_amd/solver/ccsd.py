@@ -321,11 +321,12 @@ class CCSD(ccd.CCD):
             mine = DeviceArray(ctx, st["Tall"].ptr + 8 * lo * 2 * ctx.no * ctx.no, (hi - lo, 2, ctx.no * ctx.no),
                                owned=False, keepalive=st["Tall"])
             mine.copy_from(DeviceArray(ctx, tc.ptr, mine.shape, owned=False, keepalive=tc))
-        # the all-gather of the new T2 is only STARTED: the energy and the norms (:189-197) come from the compact tiles
-        # (partial sums, one all-reduce of six doubles), so nothing below needs the replicated array; the next iteration
-        # — or whoever reads st["t2"] — completes it (_await_t2)
-        st["t2_pending"] = pdist.exchange_rows_start(st["Tall_t"], rank, world, ctx)
+        # the energy and the norms (:189-197) come from the compact tiles (partial sums, one all-reduce of six doubles), so
+        # nothing below needs the replicated array: the all-gather of the new T2 is only STARTED — after that small
+        # all-reduce (RCCL runs the collectives of a communicator in order: behind the 0.8-GB transfer the host would wait
+        # for it) — and the next iteration, or whoever reads st["t2"], completes it (_await_t2)
         e1, ed, ex, nt2, nr2, _ = pdist.allreduce_sum(ctx.energy_norms_pairs(st["f"], t1, tc, dtc, rank, world))
+        st["t2_pending"] = pdist.exchange_rows_start(st["Tall_t"], rank, world, ctx)
         if not self.is_diis:
             ctx.pool_put(dt1)
             ctx.pool_put(dtc)
