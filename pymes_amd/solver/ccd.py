@@ -194,8 +194,11 @@ class CCD:
         from pymes_amd import dist as pdist
         from pymes_amd.device import DeviceArray
         rank, world = sh["rank"], sh["world"]
-        ctx.residual_slab(f_dev, t2, sh["ETd"], sh["ETx"], sh["L"], rank, world, is_dcd=self.is_dcd)
-        for work in [pdist.exchange_rows_start(sh[k], rank, world, ctx) for k in ("ETd_t", "ETx_t")]:
+        # ring products first: the all-gathers of their rows fly while the ladders (rows that stay on the rank) are computed
+        ctx.residual_slab(f_dev, t2, sh["ETd"], sh["ETx"], sh["L"], rank, world, is_dcd=self.is_dcd, part="rings")
+        pending = [pdist.exchange_rows_start(sh[k], rank, world, ctx) for k in ("ETd_t", "ETx_t")]
+        ctx.residual_slab(f_dev, t2, sh["ETd"], sh["ETx"], sh["L"], rank, world, is_dcd=self.is_dcd, part="ladders")
+        for work in pending:
             work.wait()
         rc, dtc, tc = self._compact(ctx, sh), self._compact(ctx, sh), sh["Tc"]
         ctx.residual_finish_pairs(f_dev, t2, sh["ETd"], sh["ETx"], sh["L"], rc, rank, world, is_dcd=self.is_dcd)
