@@ -45,6 +45,7 @@ int pymes_ctx_workspace(pymes_ctx* ctx, uint64_t* capacity_bytes, uint64_t* high
 int pymes_malloc(pymes_ctx* ctx, uint64_t bytes, void** dev_ptr);
 int pymes_free(pymes_ctx* ctx, void* dev_ptr);
 int pymes_live_allocations(int64_t* n);          /* device allocations of this library not yet released (leak tests) */
+int pymes_mem_info(pymes_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);   /* hipMemGetInfo of the context's device */
 
 /* ---- launch graphs (hipGraph): the loop body of a small, launch-bound solve is recorded once and replayed.
  * Between begin and end the context's entry points only RECORD their kernels (nothing executes, nothing may

@@ -14,6 +14,10 @@ Run in the BUILD CONTAINER ONLY (the reference does not travel to the GPU box):
       ``update_singles`` / ``update_doubles`` on seeded inputs -> checksums and sampled entries of sigma1 / sigma2
       into tests/golden/eom_sigma_30_120.npz; the oracle is pinned against it on the way.
 
+  c5gen  the same build for a trial vector WITHOUT the exchange symmetry u2_abij = u2_baji (one entry of the c5 vector
+      displaced: the general sigma path — plain particle ladder, five (ov)^3 products) ->
+      tests/golden/eom_sigma_30_120_general.npz.
+
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 """
 import contextlib
@@ -96,13 +100,15 @@ def c2(kind="ccsd"):
     print(f"syn_20_80 / {kind} written to", path)
 
 
-def c5():
+def c5(general=False):
     from oracle import eom_oracle as eo
     from oracle.cases import eom_sigma_case
     from pymes.solver import eom_ccsd as ref_eom
     from pymes.integral.partition import part_2_body_int
     no, nv, seed = 30, 120, 31
     fd, V, t2, u1, u2 = eom_sigma_case(no, nv, seed, scale=0.12)
+    if general:         # what tests/test_gpu_big.py displaces: the vector loses u2_abij = u2_baji
+        u2[3, 5, 1, 2] += 0.25
     dictV = part_2_body_int(no, V)
     eom = ref_eom.EOM_CCSD(no)
     t0 = time.time()
@@ -120,11 +126,12 @@ def c5():
     assert e1 < 1e-11 and e2 < 1e-11
     # fixtures: sigma1 in full (3600 numbers), sigma2 as an a-slab + strided samples + checksums
     idx = np.random.default_rng(seed + 1).integers(0, s2.size, size=4096)
-    np.savez_compressed(os.path.join(GOLD, "eom_sigma_30_120.npz"), seed=seed, scale=0.12, sigma1=s1,
+    name = "eom_sigma_30_120_general.npz" if general else "eom_sigma_30_120.npz"
+    np.savez_compressed(os.path.join(GOLD, name), seed=seed, scale=0.12, sigma1=s1,
                         sigma2_slab=s2[7:8], sigma2_idx=idx, sigma2_val=s2.reshape(-1)[idx],
                         sigma2_sums=np.array([s2.sum(), np.abs(s2).sum(), np.linalg.norm(s2)]),
                         reference_seconds=t_ref)
-    print("eom_sigma_30_120.npz written")
+    print(name, "written")
 
 
 if __name__ == "__main__":
@@ -136,3 +143,5 @@ if __name__ == "__main__":
             c2(kind)
     if "c5" in which:
         c5()
+    if "c5gen" in which:
+        c5(general=True)

@@ -6,6 +6,10 @@ tests/golden/ueg_*.  BUILD CONTAINER ONLY:
 
 --full also reruns the reference's own N=14, rs=0.5, cutoff=5 TC driver
 (test_ueg/test_symmetrised_2body_integral.py:39-222, ~3 minutes) for its known answers.
+--c4 runs the same calling sequence at the size BASELINE config 4 is TIMED at (N=14, rs=1.0, cutoff=5 -> 57 plane
+waves, k_cutoff of test_ueg/test_ccd_dcd.py:99) followed by the reference's CCSD(no, is_dcsd=True) ("TC-DCSD").
+--coulomb57 reruns test_ueg/test_ccd_dcd.py:60-209 (plain Coulomb integrals, 57 plane waves, CCD then DCD warm-started
+from the CCD amplitudes, level_shift = -1, max_iter = 60) and checks its two literals (:208-209).
 """
 import contextlib
 import io
@@ -120,8 +124,49 @@ def main():
                                   "energies": {"ccd": float(r["ccd e"])}, "V_abs_sum": float(np.abs(V).sum()),
                                   "V_nnz": int(np.count_nonzero(V))}
         print("UEG N=14 rs=0.5 cutoff=5 (57 PW): reference literals reproduced", e_mp2, r["ccd e"])
+    if "--c4" in sys.argv:
+        nel, rs, cutoff = 14, 1.0, 5
+        m0 = ref_model(nel, rs, cutoff, None)
+        kc = m0.L / (2 * np.pi) * 2.3225029893472993 / rs                      # test_ccd_dcd.py:99
+        m, no, kin, V, f, e_hf, d2, e3, eps_i, eps_a = tc_problem_ref(nel, rs, cutoff, kc)
+        e_mp2, _ = quiet(ref_mp2.solve, eps_i, eps_a, t_V_abij=V[no:, no:, :no, :no], t_V_ijab=V[:no, :no, no:, no:])
+        s = ref_ccsd.CCSD(no, delta_e=1e-10, is_dcsd=True)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            r = s.solve(f, V)
+        import re
+        hist = [float(x) for x in re.findall(r"Correlation Energy = (-?[0-9.eE+-]+)", buf.getvalue())]
+        assert np.abs(r["t1"]).max() == 0.0
+        rd = quiet(ref_ccd.CCD(no, delta_e=1e-10, is_dcd=True).solve, f, V)
+        out["tc_N14_rs1.0_c5"] = {"nel": nel, "rs": rs, "cutoff": cutoff, "k_cutoff": float(kc), "n_pw": len(kin),
+                                  "e_hf": e_hf, "e_3b": e3, "double_contractions": d2.tolist(), "mp2": float(e_mp2),
+                                  "energies": {"dcsd": float(r["ccsd e"]), "dcd": float(rd["ccd e"])},
+                                  "dcsd_history": hist, "t2_norm": float(np.linalg.norm(r["t2"])),
+                                  "V_abs_sum": float(np.abs(V).sum()), "V_nnz": int(np.count_nonzero(V)),
+                                  "nonhermiticity": float(np.abs(V - V.transpose(2, 3, 0, 1)).max())}
+        print("UEG N=14 rs=1.0 cutoff=5 (57 PW, the size config 4 is timed at): TC-DCSD", r["ccsd e"], len(hist), "iterations")
+    if "--coulomb57" in sys.argv:
+        nel, rs, cutoff = 14, 0.5, 5
+        m = ref_model(nel, rs, cutoff, None)
+        m.k_cutoff = m.L / (2 * np.pi) * 2.3225029893472993 / rs               # :99 (unused by the Coulomb integrals)
+        no = nel // 2
+        n_p = len(m.basis_fns) // 2
+        kin = np.array([m.basis_fns[2 * i].kinetic for i in range(n_p)])
+        V = quiet(m.eval_2b_integrals, sp=1)                                     # :107
+        eps_i = ref_hf.calcOccupiedOrbE(kin, V[:no, :no, :no, :no], no)
+        eps_a = ref_hf.calcVirtualOrbE(kin, V[no:, :no, no:, :no], V[no:, :no, :no, no:], no, n_p - no)
+        e_mp2, _ = quiet(ref_mp2.solve, eps_i, eps_a, V[:no, :no, no:, no:], V[no:, no:, :no, :no])
+        f = ref_hf.construct_hf_matrix(no, np.diag(kin), V)
+        rc = quiet(ref_ccd.CCD(no, is_diis=True).solve, f, V, level_shift=-1., sp=0, max_iter=60)       # :174-178
+        amp = rc["t2 amp"].copy()
+        rdd = quiet(ref_ccd.CCD(no, is_dcd=True, is_diis=True).solve, f, V, level_shift=-1., sp=0, max_iter=60, amps=amp)
+        assert abs(rc["ccd e"] - -0.5120153512190824) < 1e-6 and abs(rdd["ccd e"] - -0.515296499349519) < 1e-6   # :208-209
+        out["coulomb_N14_rs0.5_c5"] = {"nel": nel, "rs": rs, "cutoff": cutoff, "n_pw": n_p, "level_shift": -1.0, "max_iter": 60,
+                                       "mp2": float(e_mp2), "V_abs_sum": float(np.abs(V).sum()),
+                                       "energies": {"ccd": float(rc["ccd e"]), "dcd_from_ccd_amps": float(rdd["ccd e"])}}
+        print("Coulomb UEG 57 PW, level_shift -1: CCD", rc["ccd e"], "DCD", rdd["ccd e"], "(reference literals reproduced)")
     path = os.path.join(GOLD, "ueg.json")
-    if os.path.exists(path) and "--full" not in sys.argv:
+    if os.path.exists(path):
         old = json.load(open(path))
         for k, v in old.items():
             out.setdefault(k, v)

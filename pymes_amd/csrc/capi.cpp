@@ -101,6 +101,13 @@ int pymes_live_allocations(int64_t* n) {
         *n = dev::live_allocations();
     });
 }
+int pymes_mem_info(pymes_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes) {
+    return guarded([&] {
+        E(ctx);
+        if (free_bytes) *free_bytes = dev::mem_free_bytes();
+        if (total_bytes) *total_bytes = dev::mem_total_bytes();
+    });
+}
 int pymes_graph_begin(pymes_ctx* ctx) {
     return guarded([&] { E(ctx).graph_begin(); });
 }

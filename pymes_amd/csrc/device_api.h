@@ -24,6 +24,7 @@ void  memcpy_d2d(void* d, const void* s_, size_t bytes, stream_t s);
 void  memset_zero(void* d, size_t bytes, stream_t s);
 void  stream_sync(stream_t s);
 size_t mem_free_bytes();
+size_t mem_total_bytes();
 // a stream of the engine's own (non-blocking with respect to the legacy default stream); null for the host simulator
 stream_t stream_create();
 void  stream_destroy(stream_t s);

@@ -1973,6 +1973,11 @@ size_t mem_free_bytes() {
     HIP_CHECK(hipMemGetInfo(&f, &t));
     return f;
 }
+size_t mem_total_bytes() {
+    size_t f = 0, t = 0;
+    HIP_CHECK(hipMemGetInfo(&f, &t));
+    return t;
+}
 
 void prof_enable(bool on) { g_prof.on = on; }
 void prof_reset() {

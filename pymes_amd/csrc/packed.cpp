@@ -1,6 +1,8 @@
 // Packed binary integral file (see packed.h).  Host code only.
 #include "packed.h"
 
+#include <sys/types.h>
+
 #include <cerrno>
 #include <cstring>
 #include <stdexcept>
@@ -38,10 +40,10 @@ static void get_header(const unsigned char* raw, PackedHeader& hd) {
 }
 
 PackedReader::PackedReader(const std::string& path) : path_(path) {
-    fp_ = std::fopen(path.c_str(), "rb");
+    fp_.reset(std::fopen(path.c_str(), "rb"));
     if (!fp_) throw std::runtime_error("cannot open " + path + ": " + std::strerror(errno));
     unsigned char raw[kPackedHeaderBytes];
-    if (std::fread(raw, 1, sizeof raw, fp_) != sizeof raw) throw std::runtime_error(path + ": truncated header");
+    if (std::fread(raw, 1, sizeof raw, fp_.get()) != sizeof raw) throw std::runtime_error(path + ": truncated header");
     get_header(raw, head);
     if (std::memcmp(head.magic, "PYMESPK1", 8) != 0) throw std::runtime_error(path + ": not a PYMESPK1 packed integral file");
     if (head.kind != kPackedBlocks && head.kind != kPackedFactors) throw std::runtime_error(path + ": unknown payload kind");
@@ -53,21 +55,18 @@ PackedReader::PackedReader(const std::string& path) : path_(path) {
     const size_t n = static_cast<size_t>(head.n_orb);
     eps.resize(n);
     h.resize(n * n);
-    if (std::fread(eps.data(), 8, n, fp_) != n || std::fread(h.data(), 8, n * n, fp_) != n * n)
+    if (std::fread(eps.data(), 8, n, fp_.get()) != n || std::fread(h.data(), 8, n * n, fp_.get()) != n * n)
         throw std::runtime_error(path + ": truncated one-body part");
     // the file must hold exactly the payload
-    const long here = std::ftell(fp_);
-    std::fseek(fp_, 0, SEEK_END);
-    const long end = std::ftell(fp_);
-    std::fseek(fp_, here, SEEK_SET);
-    if (static_cast<uint64_t>(end - here) != 8 * head.payload_doubles)
+    const off_t here = ftello(fp_.get());
+    fseeko(fp_.get(), 0, SEEK_END);
+    const off_t end = ftello(fp_.get());
+    fseeko(fp_.get(), here, SEEK_SET);
+    if (here < 0 || end < here || static_cast<uint64_t>(end - here) != 8 * head.payload_doubles)
         throw std::runtime_error(path + ": file length does not match the payload size");
 }
-PackedReader::~PackedReader() {
-    if (fp_) std::fclose(fp_);
-}
 void PackedReader::read(double* dst, uint64_t doubles) {
-    if (std::fread(dst, 8, doubles, fp_) != doubles) throw std::runtime_error(path_ + ": truncated payload");
+    if (std::fread(dst, 8, doubles, fp_.get()) != doubles) throw std::runtime_error(path_ + ": truncated payload");
 }
 
 PackedWriter::PackedWriter(const std::string& path, int kind, int n_orb, int n_elec, int naux, double e_core,
@@ -79,29 +78,22 @@ PackedWriter::PackedWriter(const std::string& path, int kind, int n_orb, int n_e
     hd.kind = kind; hd.n_orb = n_orb; hd.n_elec = n_elec; hd.n_occ = n_elec / 2; hd.naux = kind == kPackedFactors ? naux : 0;
     hd.e_core = e_core;
     hd.payload_doubles = expected_ = packed_payload_doubles(kind, n_orb, hd.n_occ, naux);
-    fp_ = std::fopen(path.c_str(), "wb");
+    fp_.reset(std::fopen(path.c_str(), "wb"));
     if (!fp_) throw std::runtime_error("cannot open " + path + " for writing: " + std::strerror(errno));
     unsigned char raw[kPackedHeaderBytes];
     put_header(raw, hd);
     const size_t n = static_cast<size_t>(n_orb);
-    if (std::fwrite(raw, 1, sizeof raw, fp_) != sizeof raw || std::fwrite(eps, 8, n, fp_) != n ||
-        std::fwrite(h, 8, n * n, fp_) != n * n)
+    if (std::fwrite(raw, 1, sizeof raw, fp_.get()) != sizeof raw || std::fwrite(eps, 8, n, fp_.get()) != n ||
+        std::fwrite(h, 8, n * n, fp_.get()) != n * n)
         throw std::runtime_error(path + ": write failed");
 }
-PackedWriter::~PackedWriter() {
-    if (fp_) std::fclose(fp_);
-}
 void PackedWriter::write(const double* src, uint64_t doubles) {
-    if (std::fwrite(src, 8, doubles, fp_) != doubles) throw std::runtime_error(path_ + ": write failed");
+    if (std::fwrite(src, 8, doubles, fp_.get()) != doubles) throw std::runtime_error(path_ + ": write failed");
     written_ += doubles;
 }
 void PackedWriter::close() {
     if (written_ != expected_) throw std::runtime_error(path_ + ": incomplete payload");
-    if (std::fclose(fp_) != 0) {
-        fp_ = nullptr;
-        throw std::runtime_error(path_ + ": close failed");
-    }
-    fp_ = nullptr;
+    if (std::fclose(fp_.release()) != 0) throw std::runtime_error(path_ + ": close failed");
 }
 
 }  // namespace pymes

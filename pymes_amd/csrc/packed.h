@@ -13,6 +13,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -26,6 +27,12 @@ struct PackedHeader {
 };
 static_assert(sizeof(PackedHeader) == 56 || sizeof(PackedHeader) == 64, "unexpected header packing");
 
+// closes on destruction — also when a constructor throws after the fopen (members are destroyed, the destructor is not run)
+struct FileCloser {
+    void operator()(FILE* f) const { if (f) std::fclose(f); }
+};
+using FileHandle = std::unique_ptr<FILE, FileCloser>;
+
 constexpr int kPackedBlocks = 1, kPackedFactors = 2;
 constexpr size_t kPackedHeaderBytes = 64;
 
@@ -36,13 +43,12 @@ uint64_t packed_payload_doubles(int kind, int n_orb, int n_occ, int naux);
 class PackedReader {
   public:
     explicit PackedReader(const std::string& path);
-    ~PackedReader();
     PackedHeader head{};
     std::vector<double> eps, h;
     void read(double* dst, uint64_t doubles);      // next `doubles` values of the payload
 
   private:
-    FILE* fp_ = nullptr;
+    FileHandle fp_;
     std::string path_;
 };
 
@@ -50,12 +56,11 @@ class PackedWriter {
   public:
     PackedWriter(const std::string& path, int kind, int n_orb, int n_elec, int naux, double e_core, const double* eps,
                  const double* h);
-    ~PackedWriter();
     void write(const double* src, uint64_t doubles);
     void close();                                   // checks that the whole payload was written
 
   private:
-    FILE* fp_ = nullptr;
+    FileHandle fp_;
     std::string path_;
     uint64_t expected_ = 0, written_ = 0;
 };

@@ -5,6 +5,7 @@
 device only through ``Context.array`` / ``DeviceArray.get``.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -87,6 +88,7 @@ class Context:
         self._allocator = allocator      # optional callable(n_doubles) -> (ptr, keepalive), e.g. torch-backed
         self._pool = {}
         self._spare, self._spare_bytes = {}, 0      # released buffers by size, for reuse (see _recycle)
+        self._closing = []               # weak callbacks run by close() while the buffers are still alive (on_close)
         self.profiling = False           # per-GEMM event timing is on (launch graphs are bypassed then)
         if stream is not None:
             self.set_stream(stream)
@@ -95,11 +97,26 @@ class Context:
     def close(self):
         """Destroys the context; every buffer it handed out (pool, arrays still referenced by the caller) is released
         with it, DeviceArrays of a closed context are dead."""
+        if self.handle:
+            for ref in self._closing:        # e.g. a DIIS mixer parking the vectors it keeps in this context
+                cb = ref()
+                if cb is not None:
+                    try:
+                        cb(self)
+                    except Exception:
+                        pass
+        self._closing = []
         self._pool = {}
         self._spare, self._spare_bytes = {}, 0
         if self.handle:
             self.lib.call("pymes_ctx_destroy", self.handle)
             self.handle = None
+
+    def on_close(self, method):
+        """Register a bound method ``method(ctx)`` to be called (once, weakly referenced) right before the context is
+        destroyed — holders of device vectors that must outlive it move them to the host there."""
+        if not any(ref() == method for ref in self._closing):
+            self._closing.append(weakref.WeakMethod(method))
 
     def __del__(self):
         try:
@@ -120,6 +137,13 @@ class Context:
 
     # ---- arrays -------------------------------------------------------------------
     RECYCLE_BYTES = 16 << 30       # at most this much released memory is kept for reuse; beyond it buffers are freed
+    RECYCLE_FRACTION = 0.25        # ... and never more than this fraction of what the device has free right now
+
+    def mem_info(self):
+        """(free, total) bytes of the context's device."""
+        free, total = C.c_uint64(), C.c_uint64()
+        self.lib.call("pymes_mem_info", self.handle, C.byref(free), C.byref(total))
+        return free.value, total.value
 
     def empty(self, shape):
         shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
@@ -132,7 +156,13 @@ class Context:
             self._spare_bytes -= 8 * max(n, 1)
             return DeviceArray(self, spare.pop(), shape)
         p = C.c_void_p()
-        self.lib.call("pymes_malloc", self.handle, 8 * max(n, 1), C.byref(p))
+        try:
+            self.lib.call("pymes_malloc", self.handle, 8 * max(n, 1), C.byref(p))
+        except PymesError:
+            if not self._spare_bytes:
+                raise
+            self.trim()                  # the memory may be sitting in the spare list under other sizes
+            self.lib.call("pymes_malloc", self.handle, 8 * max(n, 1), C.byref(p))
         return DeviceArray(self, p.value, shape)
 
     def _recycle(self, ptr, n):
@@ -140,14 +170,18 @@ class Context:
         Davidson, UEG — create and drop dozens of temporaries per step; hipMalloc / hipFree + a stream synchronisation for
         each of them cost more than the kernels in between)."""
         n = max(int(n), 1)
-        if self._spare_bytes + 8 * n > self.RECYCLE_BYTES:
+        cap = self.RECYCLE_BYTES
+        if 8 * n >= (64 << 20):          # large buffers: never sit on more than a fraction of what is still free
+            cap = min(cap, int(self.RECYCLE_FRACTION * self.mem_info()[0]))
+        if self._spare_bytes + 8 * n > cap:
             self.lib.call("pymes_free", self.handle, C.c_void_p(ptr))
             return
         self._spare.setdefault(n, []).append(ptr)
         self._spare_bytes += 8 * n
 
     def trim(self):
-        """Return the recycled buffers to the device allocator."""
+        """Return the recycled buffers to the device allocator (the engine's own allocations — integral blocks, packed
+        integrals, pair layouts — cannot see the spare list: the solvers call this before their set-up)."""
         for ptrs in self._spare.values():
             for ptr in ptrs:
                 self.lib.call("pymes_free", self.handle, C.c_void_p(ptr))

@@ -20,27 +20,59 @@ class DIIS:
         self.last_coefficients = None
 
     # -- history across contexts: the reference's mixer outlives a solve() call ---------
+    # Device vectors cannot outlive their context.  The mixer registers itself with every context it stores vectors in
+    # (``Context.on_close``); when such a context closes, its stored vectors are parked on the host — up to PARK_LIMIT
+    # bytes; a larger history (12 amplitude sets, 9.6 GB at (50,200)) is dropped instead: a second solve() on the same
+    # solver instance then starts from an empty subspace, the only place where this drop-in knowingly leaves the
+    # reference's never-reset semantics (PYMES_DIIS_PARK_LIMIT=<bytes> moves the limit).
+    PARK_LIMIT = 2 << 30
+
+    def _reset(self):
+        self.error_list, self.amplitude_list, self.L = [], [], np.zeros((1, 1))
+
+    def _stored(self):
+        return [arr for lst in (self.error_list, self.amplitude_list) for vec in lst for arr in vec]
+
     def park(self, ctx):
-        """Move the stored vectors that live in ``ctx`` to host memory (the context is about to be destroyed)."""
+        """Move the stored vectors that live in ``ctx`` to host memory (the context is about to be destroyed).  Never
+        raises: called from ``finally`` blocks and from ``Context.close``."""
+        import os
+        try:
+            mine = [a for a in self._stored() if not isinstance(a, np.ndarray) and a.ctx is ctx]
+            if not mine:
+                return
+            limit = int(os.environ.get("PYMES_DIIS_PARK_LIMIT", self.PARK_LIMIT))
+            if ctx.handle is None or sum(a.nbytes for a in mine) > limit:
+                self._reset()
+                return
+            for lst in (self.error_list, self.amplitude_list):
+                for vec in lst:
+                    for k, arr in enumerate(vec):
+                        if not isinstance(arr, np.ndarray) and arr.ctx is ctx:
+                            vec[k] = arr.get()
+        except Exception:
+            self._reset()
+
+    def _adopt(self, ctx, like):
+        """Make every stored vector a live array of ``ctx``: parked host copies are uploaded, vectors of another live
+        context are migrated through the host, and a history that cannot be mixed with — vectors of a closed context, or
+        of another problem size / sharding (the reference would fail in its einsum there) — is dropped."""
+        shapes = [tuple(a.shape) for a in like]
+        for arr in self._stored():
+            if not isinstance(arr, np.ndarray) and arr.ctx is not ctx and arr.ctx.handle is None:
+                return self._reset()
+        for lst in (self.error_list, self.amplitude_list):
+            for vec in lst:
+                if [tuple(a.shape) for a in vec] != shapes:
+                    return self._reset()
         for lst in (self.error_list, self.amplitude_list):
             for vec in lst:
                 for k, arr in enumerate(vec):
-                    if not isinstance(arr, np.ndarray) and arr.ctx is ctx:
-                        vec[k] = arr.get()
-
-    def _unpark(self, ctx, like):
-        """Bring parked vectors into ``ctx``; a history of a different problem size cannot be mixed with (the reference
-        would fail in its einsum there) and is dropped."""
-        shapes = [a.shape for a in like]
-        for lst in (self.error_list, self.amplitude_list):
-            for vec in lst:
-                if any(isinstance(a, np.ndarray) for a in vec):
-                    if [tuple(a.shape) for a in vec] != [tuple(sh) for sh in shapes]:
-                        self.error_list, self.amplitude_list, self.L = [], [], np.zeros((1, 1))
-                        return
-                    for k, arr in enumerate(vec):
-                        if isinstance(arr, np.ndarray):
-                            vec[k] = ctx.pool_get(arr.shape).set(arr)
+                    if isinstance(arr, np.ndarray):
+                        vec[k] = ctx.pool_get(arr.shape).set(arr)
+                    elif arr.ctx is not ctx:          # its old buffer goes back to its own context when the handle dies
+                        vec[k] = ctx.pool_get(arr.shape).set(arr.get())
+        ctx.on_close(self.park)
 
     # -- host part: identical arithmetic to the reference ------------------------------
     def _update_L(self, overlaps, was_full):
@@ -76,7 +108,7 @@ class DIIS:
         ``allreduce`` (a callable on a small numpy vector), the extrapolation itself is local.  ``out``: arrays to
         write the extrapolated amplitudes into instead of fresh ones (the solvers keep T1/T2 in fixed buffers so that
         their loop body can be replayed as a launch graph); they must not be among the stored vectors."""
-        self._unpark(error[0].ctx, error)
+        self._adopt(error[0].ctx, error)
         was_full = len(self.error_list) == self.dim_space
         if was_full:
             old_e, old_a = self.error_list.pop(0), self.amplitude_list.pop(0)

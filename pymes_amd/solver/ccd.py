@@ -14,6 +14,17 @@ from pymes_amd.log import print_logging_info
 from pymes_amd.mixer import diis
 
 
+def destroy_graphs(ctx, st):
+    """Release the launch graphs a solve recorded (a caller-owned context would otherwise keep them until it closes)."""
+    for g in (st or {}).pop("graphs", {}).values():
+        try:
+            ctx.graph_destroy(g)
+        except PymesError:
+            pass
+    if st is not None:
+        st["graph"] = None
+
+
 def run_replayable(ctx, st, body, key="residual"):
     """Run ``body`` (a callable that only ENQUEUES kernels on fixed buffers: the residual part of a solver's loop body)
     — eagerly the first time (lazy set-up work: cached permutations, packed integrals), then recorded once as a launch
@@ -34,6 +45,10 @@ def run_replayable(ctx, st, body, key="residual"):
         except PymesError:
             ctx.graph_abort()
             st["graph_ok"] = False       # something in the body cannot be recorded: stay eager
+        except BaseException:            # anything else (KeyboardInterrupt included) must not leave the stream recording
+            ctx.graph_abort()
+            st["graph_ok"] = False
+            raise
         else:
             st["graph"] = graphs[key]
             ctx.graph_launch(graphs[key])
@@ -79,7 +94,9 @@ class CCD:
 
         ints, own = self._integrals(t_fock_pq, t_V_pqrs)
         ctx = ints.ctx
+        st = None
         try:
+            ctx.trim()       # recycled temporaries of earlier work on this context: the set-up below allocates engine-side
             ctx.set_orbital_energies(t_epsilon_i, t_epsilon_a)
             f_dev = ctx.array(np.asarray(t_fock_pq, dtype=np.float64))
             print_logging_info(algo_name)
@@ -152,10 +169,10 @@ class CCD:
             self.iterations = iteration
             return result
         finally:
-            if self.is_diis and own:     # stored vectors belong to this context, which is about to close
-                self._drop_mixer_history_of(ctx)
             if own:
-                ctx.close()
+                ctx.close()      # (a DIIS history kept in this context is parked on the host on the way: Context.on_close)
+            elif ctx.handle:
+                destroy_graphs(ctx, st)
 
     # ---- one process per GPU (torch.distributed): the same sharding as CCSD.iterate, without T1 ----------------
     def _shard_setup(self, ctx, t2, allowed):
@@ -222,13 +239,11 @@ class CCD:
         sh["Tc"] = tc
         return e_dir, e_ex, np.sqrt(nt2), np.sqrt(nr2)
 
-    def _drop_mixer_history_of(self, ctx):
-        """The reference's mixer is never reset: a second solve() on the same instance starts from the history of the
-        first (diis.py:16-112 keeps its lists, ccsd.py:42 creates the mixer once).  Device vectors cannot outlive their
-        context, so when the context of this solve is about to close its stored vectors are parked on the host (at most
-        2 x dim_space amplitude sets); the mixer moves them into the next solve's context at its first call.  A history
-        that lives in a caller-owned context (``DeviceIntegrals``) stays where it is."""
-        self.mixer.park(ctx)
+    # The reference's mixer is never reset: a second solve() on the same instance starts from the history of the first
+    # (diis.py:16-112 keeps its lists, ccsd.py:42 creates the mixer once).  Device vectors cannot outlive their context:
+    # the mixer registers with every context it stores vectors in and parks them on the host when that context closes —
+    # the solver's own or a caller-owned ``DeviceIntegrals`` — and adopts them into the next solve's context at its
+    # first call (pymes_amd/mixer/diis.py).
 
     def get_residual(self, t_fock_pq, t_T_abij, t_V_klij, t_V_ijab, t_V_abij, t_V_iajb, t_V_iabj, t_V_abcd):
         """ccd.py:164-254 with host arrays in and a host array out (the reference's call form)."""

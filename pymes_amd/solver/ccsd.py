@@ -52,6 +52,7 @@ class CCSD(ccd.CCD):
     def setup(self, t_fock_pq, ints, level_shift=0., amps=None):
         """Everything before the while loop of ccsd.py:47-157.  Returns the state dict."""
         ctx = ints.ctx
+        ctx.trim()           # recycled temporaries of earlier work on this context: what follows allocates engine-side
         no, nv = self.no, ctx.nv
         f = np.asarray(t_fock_pq, dtype=np.float64)
         eps_i, eps_a = f.diagonal()[:no].copy(), f.diagonal()[no:].copy()
@@ -359,6 +360,7 @@ class CCSD(ccd.CCD):
         delta_e = kwargs.get("delta_e", self.delta_e)
         ints, own = self._integrals(t_fock_pq, t_V_pqrs)
         ctx = ints.ctx
+        st = None
         try:
             print_logging_info(algo_name)
             print_logging_info("Using dcsd: ", self.is_dcd, level=1)
@@ -403,10 +405,10 @@ class CCSD(ccd.CCD):
             return {"ccsd e": e_ccsd, "t1": self.t_T_ai, "t2": self.t_T_abij, "hole e": st["eps_i"],
                     "particle e": st["eps_a"], "dE": dE}
         finally:
-            if self.is_diis and own:     # the history lives in this context, which is about to close: park it on the host
-                self._drop_mixer_history_of(ctx)
             if own:
-                ctx.close()
+                ctx.close()      # (a DIIS history kept in this context is parked on the host on the way: Context.on_close)
+            elif ctx.handle:
+                ccd.destroy_graphs(ctx, st)
 
     # ------------------------------------------------------------------------------------
     # public helpers with the reference's host-array call forms (used by the EOM drivers)

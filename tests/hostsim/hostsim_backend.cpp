@@ -49,6 +49,7 @@ void memcpy_d2d(void* d, const void* s, size_t n, stream_t) { std::memmove(d, s,
 void memset_zero(void* d, size_t n, stream_t) { std::memset(d, 0, n); }
 void stream_sync(stream_t) {}
 size_t mem_free_bytes() { return size_t(1) << 34; }
+size_t mem_total_bytes() { return size_t(1) << 35; }
 
 static long g_launches = 0;
 static double g_flops = 0;

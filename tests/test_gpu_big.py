@@ -172,6 +172,35 @@ def test_c3_slab_vs_oracle(gpu_lib):
                 assert np.abs(rows(r2b, a0, a1) - ref).max() < tol, (dcd, a0, "3 simulated ranks")
                 assert np.abs(rows(r2c, a0, a1) - ref).max() < tol, (dcd, a0, "pair-sharded tail")
             r2c.free()
+        # ---- the HBM-bound remainder of the iteration at FULL size against numpy on the downloaded arrays: amplitude
+        # update (ccsd.py:149-156, :176-179), energies + norms in one pass (:189-197, :458-466), the DIIS overlaps of
+        # unequal lengths in one launch (diis.py:65-78) and the extrapolation (diis.py:97-103)
+        shift = 0.3
+        R2 = r2.get()                                   # the DCSD residual of the loop above, all of it
+        _, inv_d2 = oc.denominators(eps[:no], eps[no:], shift)
+        dt_ref = R2 * inv_d2
+        t2n, dt2 = ctx.empty(t2.shape), ctx.empty(t2.shape)
+        ctx.set_orbital_energies(eps[:no], eps[no:])
+        ctx.cc_update_to(t2n, dt2, dT2, r2, shift, 1.0)
+        assert np.array_equal(dt2.get(), dt_ref) or np.abs(dt2.get() - dt_ref).max() < 1e-15 * np.abs(dt_ref).max()
+        t2n_ref = t2 + dt_ref
+        assert np.abs(t2n.get() - t2n_ref).max() < 1e-15
+        Vijab = so.FactorBlocks(no, B)("ijab")
+        e_ref = oc.ccsd_energy(f[:no, no:] + 0.01, t1, t2n_ref, Vijab)
+        fpert = f.copy()
+        fpert[:no, no:] += 0.01                          # the synthetic f_ia is zero: give the one-body term something
+        got = ctx.energy_norms(ctx.array(fpert), dT1, t2n, dt2)
+        for g_, r_ in zip(got[:3], e_ref):
+            assert abs(g_ - r_) < 1e-11 * max(1.0, abs(r_)), (got, e_ref)
+        assert abs(got[3] - np.vdot(t2n_ref, t2n_ref)) < 1e-11 * np.vdot(t2n_ref, t2n_ref)
+        assert abs(got[4] - np.vdot(dt_ref, dt_ref)) < 1e-11 * np.vdot(dt_ref, dt_ref)
+        assert abs(got[5] - np.vdot(t1, t1)) < 1e-12 * np.vdot(t1, t1)
+        d = ctx.dots([t2n, dt2, dT1, dT2], [dt2, dt2, dT1, t2n])
+        d_ref = np.array([np.vdot(t2n_ref, dt_ref), np.vdot(dt_ref, dt_ref), np.vdot(t1, t1), np.vdot(t2, t2n_ref)])
+        assert np.abs(d - d_ref).max() < 1e-11 * np.abs(d_ref).max(), (d, d_ref)
+        mix = ctx.empty(t2.shape)
+        ctx.lincomb(mix, [dT2, t2n, dt2], [0.25, -1.5, 3.0])
+        assert np.abs(mix.get() - (0.25 * t2 - 1.5 * t2n_ref + 3.0 * dt_ref)).max() < 1e-14
     finally:
         ctx.close()
 
@@ -194,10 +223,16 @@ def test_c5_sigma_matches_reference(gpu_lib, monkeypatch):
     assert np.abs(s2.reshape(-1)[g["sigma2_idx"]] - g["sigma2_val"]).max() < 1e-10 * sc2
     sums = np.array([s2.sum(), np.abs(s2).sum(), np.linalg.norm(s2)])
     assert np.abs(sums - g["sigma2_sums"]).max() < 1e-9 * g["sigma2_sums"][1]
-    # a trial vector without the exchange symmetry takes the general sigma (plain particle ladder)
+    # a trial vector without the exchange symmetry takes the general sigma (plain particle ladder, five (ov)^3 products):
+    # against the reference's own output for that vector (oracle/make_golden_big.py c5gen)
+    gg = np.load(os.path.join(GOLD, "eom_sigma_30_120_general.npz"))
     u2n = u2.copy()
     u2n[3, 5, 1, 2] += 0.25
-    from oracle import eom_oracle as eo
-    if os.environ.get("PYMES_TEST_C5_GENERAL"):       # 45 s of host einsum: opt-in
-        ref = eo.sigma_doubles(no, fd, Vb, u1, u2n, t2)
-        assert np.abs(e.update_doubles(fd, Vb, u1, u2n, t2) - ref).max() < 1e-10 * sc2
+    s1 = e.update_singles(fd, Vb, u1, u2n, t2)
+    s2 = e.update_doubles(fd, Vb, u1, u2n, t2)
+    assert np.abs(s1 - gg["sigma1"]).max() < 1e-10 * sc1
+    assert np.abs(s2[7:8] - gg["sigma2_slab"]).max() < 1e-10 * sc2
+    assert np.abs(s2.reshape(-1)[gg["sigma2_idx"]] - gg["sigma2_val"]).max() < 1e-10 * sc2
+    sums = np.array([s2.sum(), np.abs(s2).sum(), np.linalg.norm(s2)])
+    assert np.abs(sums - gg["sigma2_sums"]).max() < 1e-9 * gg["sigma2_sums"][1]
+    assert np.abs(s2[3, 5] - s2[5, 3].T).max() > 1e-3 * sc2          # (the displaced entry did break the symmetry of sigma2)

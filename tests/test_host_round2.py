@@ -206,6 +206,71 @@ def test_mixer_history_survives_solve_calls(sim):
     assert abs(r3["ccsd e"] - oc.ccsd_solve(no, f3, V3, delta_e=1e-10)["e"]) < 1e-9
 
 
+def test_mixer_history_follows_caller_owned_contexts(sim):
+    """with caller-owned DeviceIntegrals the DIIS history stays on that context after solve().  A second solve()
+    on another context must neither read vectors of a closed context nor pool foreign pointers: the history is parked on
+    the host when its context closes (Context.on_close) or migrated from a live one, and the reference's never-reset
+    semantics (diis.py:16-112) is kept either way."""
+    from pymes_amd.integral.device import DeviceIntegrals
+    no, nv = 3, 5
+    f, V, _, _ = synthetic_case(no, nv, seed=6, scale=0.3)
+    f2, V2, _, _ = synthetic_case(no, nv, seed=7, scale=0.3)
+    base = live(sim)
+    for close_first in (True, False):
+        mixer = oc.Diis(6)
+        ref1 = oc.ccsd_solve(no, f, V, delta_e=1e-6, mixer=mixer)
+        ref2 = oc.ccsd_solve(no, f2, V2, delta_e=1e-10, mixer=mixer)
+        s = CCSD(no, delta_e=1e-6)
+        A = DeviceIntegrals.from_V_pqrs(no, V)
+        r1 = quiet(s.solve, f, A)
+        assert abs(r1["ccsd e"] - ref1["e"]) < 1e-12
+        assert all(a.ctx is A.ctx for vec in s.mixer.error_list for a in vec)        # device-resident, on A
+        if close_first:
+            A.ctx.close()                                                            # parks the history on the host
+            assert all(isinstance(a, np.ndarray) for vec in s.mixer.error_list for a in vec)
+        B = DeviceIntegrals.from_V_pqrs(no, V2)
+        s.delta_e = 1e-10
+        r2 = quiet(s.solve, f2, B)
+        assert abs(r2["ccsd e"] - ref2["e"]) < 1e-11 and s.iterations == ref2["iterations"]
+        assert all(a.ctx is B.ctx for vec in s.mixer.error_list + s.mixer.amplitude_list for a in vec)
+        # a history whose context died without parking (handle gone) is dropped, not dereferenced
+        h = B.ctx.handle
+        B.ctx._closing = []
+        B.ctx.close()
+        assert h is not None and B.ctx.handle is None
+        C_ = DeviceIntegrals.from_V_pqrs(no, V)
+        s.delta_e = 1e-9
+        r3 = quiet(s.solve, f, C_)
+        assert abs(r3["ccsd e"] - oc.ccsd_solve(no, f, V, delta_e=1e-9)["e"]) < 1e-9
+        C_.ctx.close()
+        if not close_first:
+            A.ctx.close()
+        del s, r1, r2, r3
+        assert live(sim) == base
+
+
+def test_recycled_buffers_are_given_back_on_allocation_failure(sim, monkeypatch):
+    """Context.empty retries after trimming its spare list when pymes_malloc fails."""
+    ctx = Context(2, 3)
+    a = ctx.empty((1000,))
+    a.free()
+    assert ctx._spare_bytes == 8000
+    calls = {"n": 0}
+    real = ctx.lib.call
+
+    def flaky(name, *args):
+        if name == "pymes_malloc":
+            calls["n"] += 1
+            if calls["n"] == 1:
+                raise _lib.PymesError("out of memory")
+        return real(name, *args)
+    monkeypatch.setattr(ctx.lib, "call", flaky)
+    b = ctx.empty((77,))
+    assert calls["n"] == 2 and ctx._spare_bytes == 0 and b.ptr
+    monkeypatch.setattr(ctx.lib, "call", real)
+    ctx.close()
+
+
 def test_singles_sums_are_partial_traces_of_the_ring_intermediate():
     """for V_pqrs = V_qpsr and T_abij = T_baji the V.T sums of ccsd.py:434 / :436 equal those of X_ki / X_ac
     (ccd.py:213-220), and both are partial traces of Y = Vd Tt_d (ccd.py:202) — the identity the product path relies on

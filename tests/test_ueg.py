@@ -57,12 +57,12 @@ def tc_problem(model_cls, nel, rs, cutoff, kc, ctx_kwargs=None):
     return no, V, f + np.diag(d2), e_hf, d2, e3, eps_i + d2[:no], eps_a + d2[no:]
 
 
-def check_product(lib, monkeypatch, cutoffs, solve):
+def check_product(lib, monkeypatch, cutoffs, solve, rs=None):
     from pymes_amd.model.ueg import UEG
     from pymes_amd.solver import ccd, ccsd, mp2
     monkeypatch.setattr(_lib, "_default", lib)
     for cutoff in cutoffs:
-        key = f"tc_N14_rs1.0_c{cutoff}" if cutoff < 5 else "tc_N14_rs0.5_c5"
+        key = f"tc_N14_rs{rs}_c{cutoff}" if rs is not None else f"tc_N14_rs1.0_c{cutoff}" if cutoff < 5 else "tc_N14_rs0.5_c5"
         if key not in G:
             pytest.skip(f"{key} not in golden file")
         ref = G[key]
@@ -81,14 +81,24 @@ def check_product(lib, monkeypatch, cutoffs, solve):
             e_mp2, _ = quiet(mp2.solve, eps_i, eps_a, V[:no, :no, no:, no:], V[no:, no:, :no, :no])
             assert abs(e_mp2 - ref["mp2"]) < 1e-9
         en = ref["energies"]
+        if "nonhermiticity" in ref:
+            assert abs(np.abs(V - V.transpose(2, 3, 0, 1)).max() - ref["nonhermiticity"]) < 1e-11
         if "ccd" in en:
             delta = 1e-8 if cutoff == 5 else 1e-10
             assert abs(quiet(ccd.CCD(no, delta_e=delta).solve, f, V)["ccd e"] - en["ccd"]) < (1e-8 if cutoff == 5 else 1e-9)
         if "dcd" in en:
             assert abs(quiet(ccd.CCD(no, delta_e=1e-10, is_dcd=True).solve, f, V)["ccd e"] - en["dcd"]) < 1e-9
         if "dcsd" in en:       # "transcorrelated DCSD": T1 stays exactly zero by momentum conservation
-            r = quiet(ccsd.CCSD(no, delta_e=1e-10, is_dcsd=True).solve, f, V)
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                r = ccsd.CCSD(no, delta_e=1e-10, is_dcsd=True).solve(f, V)
             assert abs(r["ccsd e"] - en["dcsd"]) < 1e-9 and np.abs(r["t1"]).max() < 1e-14
+            if "dcsd_history" in ref:       # every logged iteration energy of the reference's own run, and its length
+                import re
+                hist = [float(x) for x in re.findall(r"Correlation Energy = (-?[0-9.eE+-]+)", buf.getvalue())]
+                assert len(hist) == len(ref["dcsd_history"])
+                assert np.abs(np.array(hist) - np.array(ref["dcsd_history"])).max() < 1e-9
+                assert abs(np.linalg.norm(r["t2"]) - ref["t2_norm"]) < 1e-8
 
 
 CORR = np.load(os.path.join(GOLD, "ueg_correlators.npz"))
@@ -172,6 +182,58 @@ def test_product_gpu(gpu_lib, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_config4_size_tc_dcsd_gpu(gpu_lib, monkeypatch):
+    """BASELINE config 4 at the size it is TIMED at (N=14, rs=1.0, cutoff=5 -> 57 plane waves, k_cutoff of
+    test_ueg/test_ccd_dcd.py:99): TC integrals, mean-field pieces, MP2, DCD and the DCSD iteration history of the reference
+    run recorded by oracle/make_golden_ueg.py --c4."""
+    check_product(gpu_lib, monkeypatch, (5,), solve=True, rs=1.0)
+
+
+def coulomb_57(lib, monkeypatch):
+    """pymes/test/test_ueg/test_ccd_dcd.py:60-209: Coulomb integrals at 57 plane waves, CCD then DCD warm-started from the
+    CCD amplitudes, both with level_shift = -1 and max_iter = 60 — its two literals (:208-209, tolerance 1e-6 there) and
+    the reference's own run of it (oracle/make_golden_ueg.py --coulomb57) to 1e-8."""
+    from pymes_amd.mean_field import hf
+    from pymes_amd.model.ueg import UEG
+    from pymes_amd.solver import ccd, mp2
+    monkeypatch.setattr(_lib, "_default", lib)
+    ref = G["coulomb_N14_rs0.5_c5"]
+    nel, rs = ref["nel"], ref["rs"]
+    m = UEG(nel, nel // 2, nel // 2, rs)
+    m.init_single_basis(ref["cutoff"])
+    m.k_cutoff = m.L / (2 * np.pi) * 2.3225029893472993 / rs
+    no, n_p = nel // 2, len(m.basis_fns) // 2
+    assert n_p == ref["n_pw"]
+    kin = np.array([m.basis_fns[2 * i].kinetic for i in range(n_p)])
+    V = quiet(m.eval_2b_integrals, sp=1)
+    assert abs(np.abs(V).sum() - ref["V_abs_sum"]) < 1e-9
+    eps_i = hf.calcOccupiedOrbE(kin, V[:no, :no, :no, :no], no)
+    eps_a = hf.calcVirtualOrbE(kin, V[no:, :no, no:, :no], V[no:, :no, :no, no:], no, n_p - no)
+    e_mp2, _ = quiet(mp2.solve, eps_i, eps_a, V[:no, :no, no:, no:], V[no:, no:, :no, :no])
+    assert abs(e_mp2 - ref["mp2"]) < 1e-10
+    f = hf.construct_hf_matrix(no, np.diag(kin), V)
+    rc = quiet(ccd.CCD(no, is_diis=True).solve, f, V, level_shift=-1., sp=0, max_iter=60)
+    amps = rc["t2 amp"].copy()
+    rd = quiet(ccd.CCD(no, is_dcd=True, is_diis=True).solve, f, V, level_shift=-1., sp=0, max_iter=60, amps=amps)
+    assert abs(rc["ccd e"] - -0.5120153512190824) < 1e-6 and abs(rd["ccd e"] - -0.515296499349519) < 1e-6
+    assert abs(rc["ccd e"] - ref["energies"]["ccd"]) < 1e-8
+    assert abs(rd["ccd e"] - ref["energies"]["dcd_from_ccd_amps"]) < 1e-8
+
+
+@pytest.mark.gpu
+def test_coulomb_57_plane_waves_level_shift_gpu(gpu_lib, monkeypatch):
+    coulomb_57(gpu_lib, monkeypatch)
+
+
+@pytest.mark.gpu
 def test_product_gpu_57_plane_waves(gpu_lib, monkeypatch):
     """The reference's own driver literals (N=14, rs=0.5, cutoff=5; test_symmetrised_2body_integral.py:205-220)."""
     check_product(gpu_lib, monkeypatch, (5,), solve=True)
+
+
+def test_config4_size_tc_dcsd_host_logic(hostsim_lib, monkeypatch):
+    check_product(hostsim_lib, monkeypatch, (5,), solve=True, rs=1.0)
+
+
+def test_coulomb_57_plane_waves_level_shift_host_logic(hostsim_lib, monkeypatch):
+    coulomb_57(hostsim_lib, monkeypatch)
