@@ -77,10 +77,11 @@ def pmc_traffic_per_launch(no, nv, world, kernel_prefix):
     return gbytes / launches * 1e9, f"{TRAFFIC_CSV} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, kernels.hip {recorded[:12]})"
 
 
-def launch_ranks(n, argv, script=None):
+def launch_ranks(n, argv, script=None, timeout_s=1500.0):
     """`python bench.py --gpus N` without a launcher: start N rank processes of this script (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1) and relay rank 0's JSON line.  The parent never
-    touches the GPU (no HIP call, no exec of an initialised process); a failing rank takes the others down."""
+    touches the GPU (no HIP call, no exec of an initialised process); a failing rank takes the others down, and so does
+    the overall time limit (a hung collective must end the run with a non-zero status, not stall the driver)."""
     import socket
     import subprocess
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
@@ -99,12 +100,16 @@ def launch_ranks(n, argv, script=None):
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     reader.start()
     codes = [None] * n
+    t_start = time.time()
     while any(c is None for c in codes):
         for r, p in enumerate(procs):
             if codes[r] is None:
                 codes[r] = p.poll()
-        if any(c not in (None, 0) for c in codes):          # a rank failed: the others would wait for it forever
-            time.sleep(5.0)
+        timed_out = time.time() - t_start > timeout_s
+        if timed_out:
+            sys.stderr.write(f"bench.py: ranks still running after {timeout_s:.0f} s — stopping them\n")
+        if timed_out or any(c not in (None, 0) for c in codes):   # a rank failed: the others would wait for it forever
+            time.sleep(0.0 if timed_out else 5.0)
             for r, p in enumerate(procs):
                 if codes[r] is None and p.poll() is None:
                     p.kill()                                  # exactly the PIDs started above
@@ -137,10 +142,25 @@ def main():
                          "separate for small single-rank problems (nocc*nvirt <= 4000, the launch-bound regime)")
     ap.add_argument("--backend", default=os.environ.get("PYMES_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend; 'gloo' lets several ranks share one GPU in test rigs")
+    ap.add_argument("--collective-timeout-s", type=float, default=300.0,
+                    help="process-group timeout: a collective that does not complete ends the rank with an error")
+    ap.add_argument("--run-timeout-s", type=float, default=1500.0,
+                    help="overall limit of a self-launched multi-rank run (the launcher stops the ranks and exits non-zero)")
+    ap.add_argument("--owner-tiles", action="store_true",
+                    help="N > 1: all-to-all of the ring-product tiles each pair owner reads instead of two all-gathers")
+    ap.add_argument("--stub-collectives", action="store_true",
+                    help="ONE GPU: run rank --as-rank of a world of --of ranks with every collective a no-op — that rank's "
+                         "compute time (timings valid, energies not); the compute-only leg of the 1/2/4/8 curve")
+    ap.add_argument("--as-rank", type=int, default=0)
+    ap.add_argument("--of", type=int, default=8)
     args = ap.parse_args()
+    if args.owner_tiles:
+        os.environ["PYMES_OWNER_TILES"] = "1"
+    if args.stub_collectives and args.gpus != 1:
+        raise SystemExit("--stub-collectives rehearses one rank on ONE GPU: use --gpus 1 --as-rank r --of N")
 
     if args.gpus > 1 and "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1:
-        return launch_ranks(args.gpus, sys.argv[1:])      # no launcher around us: be the launcher
+        return launch_ranks(args.gpus, sys.argv[1:], timeout_s=args.run_timeout_s)   # no launcher around us: be the launcher
 
     import torch
     import torch.distributed as dist
@@ -149,16 +169,30 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    local = local % max(1, torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    if world > 1 and args.backend == "nccl" and world > ndev:
+        # RCCL with two ranks on one device fails or hangs in communicator set-up: refuse before touching the GPU
+        raise SystemExit(f"bench.py: --backend nccl needs one GPU per rank, but WORLD_SIZE={world} > {ndev} visible "
+                         f"device(s); use --backend gloo to let ranks share a GPU (test rigs only)")
+    local = local % max(1, ndev)          # several ranks per device: gloo test rigs only (refused above for RCCL)
     torch.cuda.set_device(local)
     # PYMES_FORCE_SHARDED=1 with one rank: rehearse the one-process-per-GPU path (RCCL communicator of one rank)
     if world > 1 or os.environ.get("PYMES_FORCE_SHARDED"):
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # a collective that never completes (a dead peer, a wedged link) aborts the rank after the timeout instead of
+        # hanging the run: RCCL's watchdog tears the process down, gloo raises; the launcher then stops the other ranks
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        limit = datetime.timedelta(seconds=args.collective_timeout_s)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),
+                                    timeout=limit)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=limit)
+    from pymes_amd import dist as pdist
+    if args.stub_collectives:
+        pdist.stub(args.as_rank, args.of)
 
     from pymes_amd.integral.device import DeviceIntegrals
     from pymes_amd.model import synthetic
@@ -170,6 +204,8 @@ def main():
     # the engine runs on a stream of its own (launch-graph capture needs one); under torch.distributed the solver binds
     # it to torch's current stream instead, so that RCCL collectives and kernels are ordered on the device (dist.py)
     ints = DeviceIntegrals.from_factors(no, B, device=local)
+    if args.stub_collectives and not ints.ctx.pairs_supported():
+        raise SystemExit("--stub-collectives: the pair-sharded tail is not available for this nocc")
     ctx = ints.ctx
     ctx.sync()
     t_build = time.time() - t0
@@ -195,8 +231,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    sharded_run = pdist.sharded()
     separate = args.events == "separate" or (args.events == "auto" and world == 1 and no * nv <= 4000 and
-                                             not dist.is_initialized())
+                                             not sharded_run)
+    if separate:          # the launch graph of a variant is recorded on its second pass: keep that out of the timed steps
+        for _ in range(max(0, 3 - args.warmup)):
+            step()
+    pdist.trace.enable(sharded_run)
     ctx.stats(reset=True)
     ctx.prof_enable(not separate)
     ctx.prof_reset()
@@ -215,6 +256,8 @@ def main():
         for _ in range(args.steps):
             step()
         fence()
+    phases, collectives = pdist.trace.summary(args.steps) if sharded_run else ({}, {})
+    pdist.trace.enable(False)
     prof = ctx.prof_query()
     prof_dma = ctx.prof_query(kernel_class=1)
     stats = ctx.stats()
@@ -223,7 +266,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if not all(np.isfinite(energies)):
+    if not all(np.isfinite(energies)) and not args.stub_collectives:
         raise SystemExit("non-finite energy in the timed region")
 
     if rank == 0:
@@ -272,7 +315,24 @@ def main():
                           "integral_build_s": t_build, "workspace_high_water_gb": high / 1e9,
                           "launch_graph_replay": replayed, "last_energy": timed_energy},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if sharded_run:
+            # rank 0's view of the sharded iteration: device time per phase (HIP events on the stream the kernels and the
+            # collectives are ordered on), per collective the time the stream stood still in its wait() (= exposed
+            # communication) and the bytes the rank put on the wire; the roofline block above is this rank's GEMMs
+            prank, pworld, _ = pdist.world()
+            line["multi_gpu"] = {
+                "rccl_world": dist.get_world_size() if dist.is_initialized() else 0,
+                "backend": args.backend if dist.is_initialized() else "none (collectives stubbed)",
+                "rank": prank, "of": pworld, "collectives_stubbed": bool(args.stub_collectives),
+                "owner_tiles": bool(os.environ.get("PYMES_OWNER_TILES")),
+                "phases_ms": phases, "collectives": collectives,
+                "exposed_wait_ms": sum(c["exposed_wait_ms"] for c in collectives.values()),
+                "wire_gbytes_per_step": sum(c["wire_bytes"] for c in collectives.values()) / 1e9,
+                "devices_visible": ndev}
+            if args.stub_collectives:
+                line["config"]["parallelism"] = (f"rank {prank} of {pworld}, collectives stubbed (compute only, one GPU): "
+                                                 "timings valid, energies not")
+        if world == 1 and not args.no_cpu_baseline and not args.stub_collectives:
             from oracle.baseline import sample, algorithmic_fma
             cpu = sample(no, nv)
             # the sample times the doubles residual (93 % of the reference's flops); dressing + singles + Fock are
@@ -286,6 +346,8 @@ def main():
                           f"one doubles residual with the SURVEY 8(d) flop table, x {to_iter:.3f} (flop ratio "
                           "iteration / doubles residual) for one CCSD iteration",
                 "doubles_residual_s": cpu["faithful"]["seconds_per_doubles_residual"],
+                # the same contractions through tensordot / dgemm on every host core (SURVEY 8(d) mode B)
+                "blas_value": cpu["blas"]["seconds_per_doubles_residual"] * to_iter, "blas_cores": cpu["cores"]["blas"],
                 "blas_all_cores": {"value": cpu["blas"]["seconds_per_doubles_residual"] * to_iter, "unit": "s",
                                    "cores": cpu["cores"]["blas"]}}
         print(json.dumps(line), flush=True)

@@ -9,9 +9,103 @@ so the all-gather moves 1/world of the bytes of the zero-padded all-reduce the n
 """
 import os
 
+# ---- rehearsal of one rank's share on a single GPU --------------------------------------------------------------------
+# ``stub(rank, world)``: the solvers take their one-process-per-GPU path as rank ``rank`` of ``world`` while every
+# collective is a no-op (the buffers of the other ranks stay as they are: timings are those of the rank's compute,
+# energies are meaningless).  bench.py --stub-collectives --as-rank r --of N: a compute-only 1/2/4/8 curve on one GPU.
+_STUB = None
+
+
+def stub(rank, world_size):
+    global _STUB
+    if not (0 <= int(rank) < int(world_size)):
+        raise ValueError("stub: need 0 <= rank < world")
+    _STUB = (int(rank), int(world_size))
+
+
+def stubbed():
+    return _STUB is not None
+
+
+class Trace:
+    """Per-phase device time and exposed communication of the sharded iteration (bench.py switches it on).
+
+    ``mark(name)`` records an event on the engine's stream (= torch's current stream under torch.distributed,
+    ``bind_stream``); the time between two marks is charged to the later mark's name.  Every collective handle records
+    an event pair around its ``wait()``: what the stream stood still for it — the EXPOSED part of the transfer (≈ 0 when
+    it was hidden behind kernels) — and the bytes it put on the wire are summed per label."""
+
+    def __init__(self):
+        self.on = False
+        self.reset()
+
+    def reset(self):
+        self._marks, self._waits, self.bytes, self.calls = [], [], {}, {}
+
+    def enable(self, on=True):
+        self.on = bool(on)
+        self.reset()
+
+    @staticmethod
+    def _event():
+        import torch
+        if not torch.cuda.is_available():
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def mark(self, name):
+        if self.on:
+            self._marks.append((name, self._event()))
+
+    def sent(self, label, nbytes):
+        if self.on:
+            self.bytes[label] = self.bytes.get(label, 0) + int(nbytes)
+            self.calls[label] = self.calls.get(label, 0) + 1
+
+    def waiting(self, label):
+        return _WaitSpan(self, label)
+
+    def summary(self, steps):
+        """({phase: ms per step}, {label: {"exposed_wait_ms", "wire_bytes", "calls"} per step}); synchronises."""
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        phases, waits = {}, {}
+        for (_, e0), (name, e1) in zip(self._marks, self._marks[1:]):
+            if name == "begin" or e0 is None or e1 is None:
+                continue
+            phases[name] = phases.get(name, 0.0) + e0.elapsed_time(e1)
+        for label, e0, e1 in self._waits:
+            if e0 is not None and e1 is not None:
+                waits[label] = waits.get(label, 0.0) + e0.elapsed_time(e1)
+        steps = max(1, int(steps))
+        coll = {label: {"exposed_wait_ms": waits.get(label, 0.0) / steps, "wire_bytes": self.bytes.get(label, 0) / steps,
+                        "calls": self.calls.get(label, 0) / steps} for label in sorted(set(self.bytes) | set(waits))}
+        return {k: v / steps for k, v in phases.items()}, coll
+
+
+class _WaitSpan:
+    def __init__(self, tr, label):
+        self.tr, self.label = tr, label
+
+    def __enter__(self):
+        self.e0 = self.tr._event() if self.tr.on else None
+
+    def __exit__(self, *exc):
+        if self.tr.on:
+            self.tr._waits.append((self.label, self.e0, self.tr._event()))
+        return False
+
+
+trace = Trace()
+
 
 def world():
     """(rank, world_size, local_rank) from torch.distributed if initialised, else (0, 1, 0)."""
+    if _STUB is not None:
+        return _STUB[0], _STUB[1], 0
     try:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
@@ -46,6 +140,8 @@ def forced():
 
 def sharded():
     """True when the solvers should run their sharded form."""
+    if _STUB is not None:
+        return True
     try:
         import torch.distributed as dist
     except ImportError:
@@ -87,7 +183,7 @@ def exchange_rows(full, rank, world_size, ctx=None):
     """``full`` is a torch tensor [padded_rows, ...] whose chunk ``rank`` was computed locally (by ``ctx``'s engine).
     On return every rank holds every chunk (stream-ordered under RCCL, complete on the host otherwise)."""
     import torch.distributed as dist
-    if not sharded():
+    if not sharded() or _STUB is not None:
         return full
     c = full.shape[0] // world_size
     if _staged(full):
@@ -109,8 +205,9 @@ def allreduce_sum(vec):
     import numpy as np
     import torch
     import torch.distributed as dist
-    if not sharded():
+    if not sharded() or _STUB is not None:
         return np.asarray(vec, dtype=np.float64)
+    trace.sent("scalars", 2 * 8 * len(vec))
     t = torch.from_numpy(np.array(vec, dtype=np.float64, copy=True))
     if dist.get_backend() == "nccl":
         t = t.cuda()
@@ -118,10 +215,19 @@ def allreduce_sum(vec):
     return t.cpu().numpy()
 
 
-def allreduce_tensor_start(t, ctx=None):
+def _ring_bytes(t, world_size, passes):
+    """Bytes one rank puts on the wire for a ring collective over ``t``: (world-1)/world of the buffer per pass
+    (all-gather: 1 pass; all-reduce = reduce-scatter + all-gather: 2)."""
+    return passes * t.numel() * t.element_size() * (world_size - 1) // max(world_size, 1)
+
+
+def allreduce_tensor_start(t, ctx=None, label="allreduce"):
     """In-place sum of a torch tensor over the ranks; returns a handle with ``wait()`` (async under RCCL)."""
     import torch.distributed as dist
     if not sharded():
+        return _Done()
+    trace.sent(label, _ring_bytes(t, world()[1], 2))
+    if _STUB is not None:
         return _Done()
     if _staged(t):
         _fence_before(t, ctx)
@@ -137,7 +243,7 @@ def allreduce_tensor_start(t, ctx=None):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         _fence_after(t)
         return _Done()
-    return _Pending(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True), t)
+    return _Pending(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True), t, label)
 
 
 class _Done:
@@ -149,21 +255,28 @@ class _Pending:
     """A collective in flight; keeps its send buffer alive until waited for.  ``wait()`` makes torch's current stream
     (= the engine's stream) wait for the collective; the host does not block."""
 
-    def __init__(self, work, send):
-        self.work, self.send = work, send
+    def __init__(self, work, send, label="collective", after=None):
+        self.work, self.send, self.label, self.after = work, send, label, after
 
     def wait(self):
-        self.work.wait()
+        with trace.waiting(self.label):
+            self.work.wait()
+        if self.after is not None:          # e.g. received tiles copied to their places, on the stream that just waited
+            self.after()
+            self.after = None
         self.send = None
         return True
 
 
-def exchange_rows_start(full, rank, world_size, ctx=None):
+def exchange_rows_start(full, rank, world_size, ctx=None, label="allgather"):
     """Asynchronous form of ``exchange_rows``: returns a handle whose ``wait()`` makes the current stream wait for
     the all-gather (RCCL runs it on its own stream, so kernels enqueued in between overlap with the transfer).
     The staged test rigs and PYMES_SYNC_EXCHANGE=1 fall back to the blocking exchange."""
     import torch.distributed as dist
     if not sharded():
+        return _Done()
+    trace.sent(label, _ring_bytes(full, world_size, 1))
+    if _STUB is not None:
         return _Done()
     if _staged(full) or os.environ.get("PYMES_SYNC_EXCHANGE"):
         exchange_rows(full, rank, world_size, ctx)
@@ -171,7 +284,76 @@ def exchange_rows_start(full, rank, world_size, ctx=None):
         return _Done()
     c = full.shape[0] // world_size
     mine = full[rank * c:(rank + 1) * c].clone()
-    return _Pending(dist.all_gather_into_tensor(full.view(-1), mine.view(-1), async_op=True), mine)
+    return _Pending(dist.all_gather_into_tensor(full.view(-1), mine.view(-1), async_op=True), mine, label)
+
+
+# ---- owner-tile exchange of the ring-product rows ------------------------------------------------------------------------
+# In the pair-sharded tail rank q assembles R only for its virtual pairs P(a,b), a >= b, a in [a0_q, a1_q): of the pair
+# matrices ETd / ETx (rows = this rank's column slab, see Engine::residual_slab) it reads the tiles [(a,.),(b,.)] and
+# [(b,.),(a,.)] only, i.e. rows [0, a1 o) x columns [a0 o, a1 o) and rows [a0 o, a1 o) x columns [0, a0 o).  Sending
+# every rank just those rectangles is an all-to-all of ~2 (a1-a0) a1 o^2 doubles per rank and matrix (0.2 GB at
+# (50,200) on 8 ranks) instead of the all-gather of the whole matrix (0.8 GB each): PYMES_OWNER_TILES=1.
+def owner_tile_plan(no, nv, world_size):
+    """plan[p][q] = rectangles (r0, r1, c0, c1) of a pair matrix [ov x ov] that the owner p of rows
+    ``slab_rows(ov, p)`` sends to rank q (empty for p == q: those rows are already in place)."""
+    ov, npp = no * nv, nv * (nv + 1) // 2
+    plan = [[[] for _ in range(world_size)] for _ in range(world_size)]
+    for q in range(world_size):
+        a0, a1 = a_range_of_pair_rows(*slab_rows(npp, q, world_size))
+        if a1 <= a0:
+            continue
+        A0, A1 = a0 * no, a1 * no
+        for p in range(world_size):
+            if p == q:
+                continue
+            r0, r1 = slab_rows(ov, p, world_size)
+            lo, hi = r0, min(r1, A1)
+            if hi > lo:
+                plan[p][q].append((lo, hi, A0, A1))                      # rows (b,.), b < a1;  columns (a,.)
+            lo, hi = max(r0, A0), min(r1, A1)
+            if hi > lo and A0 > 0:
+                plan[p][q].append((lo, hi, 0, A0))                       # rows (a,.);  columns (b,.), b < a0
+    return plan
+
+
+def exchange_pair_tiles_start(mats, no, nv, rank, world_size, ctx=None, label="owner tiles"):
+    """Owner-tile exchange of the pair matrices ``mats`` (torch tensors [padded ov, ov], this rank's row slab filled in):
+    one all-to-all for all of them.  Returns a handle; after ``wait()`` every rectangle this rank's assembly reads is in
+    place (bit-identical to what the all-gather would have put there)."""
+    import torch
+    import torch.distributed as dist
+    if not sharded():
+        return _Done()
+    plan = owner_tile_plan(no, nv, world_size)
+    area = lambda rects: sum((r1 - r0) * (c1 - c0) for r0, r1, c0, c1 in rects)
+    send_n = [len(mats) * area(plan[rank][q]) for q in range(world_size)]
+    recv_n = [len(mats) * area(plan[p][rank]) for p in range(world_size)]
+    trace.sent(label, 8 * sum(send_n))
+    if _STUB is not None:
+        return _Done()
+    staged = _staged(mats[0]) or bool(os.environ.get("PYMES_SYNC_EXCHANGE"))
+    if staged:
+        _fence_before(mats[0], ctx)
+    src = [m.cpu() if (staged and m.is_cuda) else m for m in mats]
+    pieces = [m[r0:r1, c0:c1].reshape(-1) for q in range(world_size) for m in src for (r0, r1, c0, c1) in plan[rank][q]]
+    dev = src[0].device
+    send = torch.cat(pieces) if pieces else torch.empty(0, dtype=torch.float64, device=dev)
+    recv = torch.empty(sum(recv_n), dtype=torch.float64, device=dev)
+
+    def scatter():
+        off = 0
+        for p in range(world_size):
+            for m in mats:
+                for (r0, r1, c0, c1) in plan[p][rank]:
+                    n = (r1 - r0) * (c1 - c0)
+                    m[r0:r1, c0:c1].copy_(recv[off:off + n].view(r1 - r0, c1 - c0))
+                    off += n
+    if staged:
+        dist.all_to_all_single(recv, send, recv_n, send_n)
+        scatter()
+        _fence_after(mats[0])
+        return _Done()
+    return _Pending(dist.all_to_all_single(recv, send, recv_n, send_n, async_op=True), (send, recv), label, after=scatter)
 
 
 def a_range_of_pair_rows(lo, hi):

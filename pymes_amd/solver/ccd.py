@@ -212,11 +212,18 @@ class CCD:
         from pymes_amd.device import DeviceArray
         rank, world = sh["rank"], sh["world"]
         # ring products first: the all-gathers of their rows fly while the ladders (rows that stay on the rank) are computed
+        pdist.trace.mark("begin")
         ctx.residual_slab(f_dev, t2, sh["ETd"], sh["ETx"], sh["L"], rank, world, is_dcd=self.is_dcd, part="rings")
-        pending = [pdist.exchange_rows_start(sh[k], rank, world, ctx) for k in ("ETd_t", "ETx_t")]
+        pdist.trace.mark("ring products")
+        if os.environ.get("PYMES_OWNER_TILES"):      # all-to-all of the tiles each pair owner reads (dist.py)
+            pending = [pdist.exchange_pair_tiles_start([sh["ETd_t"], sh["ETx_t"]], ctx.no, ctx.nv, rank, world, ctx,
+                                                       label="ETd+ETx owner tiles")]
+        else:
+            pending = [pdist.exchange_rows_start(sh[k], rank, world, ctx, label=k[:3]) for k in ("ETd_t", "ETx_t")]
         ctx.residual_slab(f_dev, t2, sh["ETd"], sh["ETx"], sh["L"], rank, world, is_dcd=self.is_dcd, part="ladders")
         for work in pending:
             work.wait()
+        pdist.trace.mark("ladders, waits")
         rc, dtc, tc = self._compact(ctx, sh), self._compact(ctx, sh), sh["Tc"]
         ctx.residual_finish_pairs(f_dev, t2, sh["ETd"], sh["ETx"], sh["L"], rc, rank, world, is_dcd=self.is_dcd)
         ctx.cc_update_pairs(tc, dtc, rc, level_shift, delta, rank, world)             # :123-124
@@ -231,9 +238,10 @@ class CCD:
         # energy (:132) and norms from the compact tiles of this rank's pairs: partial sums, one all-reduce of six doubles
         # (issued before the big transfer: collectives of one communicator run in order)
         _, e_dir, e_ex, nt2, nr2, _ = pdist.allreduce_sum(ctx.energy_norms_pairs(None, None, tc, dtc, rank, world))
-        pending = pdist.exchange_rows_start(sh["Tall_t"], rank, world, ctx)
+        pending = pdist.exchange_rows_start(sh["Tall_t"], rank, world, ctx, label="new T2")
         pending.wait()
         ctx.pairs_unpack(sh["Tall"], t2, world)
+        pdist.trace.mark("finish, update, DIIS, energy, T2 exchange")
         if not self.is_diis:
             ctx.pool_put(dtc)
         sh["Tc"] = tc

@@ -80,6 +80,9 @@ class CCSD(ccd.CCD):
         # world > 1: every rank keeps T2-sized quantities (residual, update, DIIS history) only for the virtual pairs it
         # owns ("pair-sharded tail", include/pymes_amd.h); user amplitudes keep the replicated tail (in-place contract)
         st["pairs"] = bool(dist_on and st["sym"] and amps is None and ctx.pairs_supported())
+        # PYMES_OWNER_TILES=1: the rows of the ring products travel as an all-to-all of the tiles each pair owner reads
+        # (0.2 GB per rank at (50,200) on 8 ranks) instead of two all-gathers of the whole matrices (1.6 GB); dist.py
+        st["owner_tiles"] = bool(st["pairs"] and os.environ.get("PYMES_OWNER_TILES"))
         lo, hi = pdist.slab_rows(st["npp"], rank, wsize)
         st["cshape"] = (max(hi - lo, 1), 2, no * no)
         if self.is_diis:     # DIIS keeps dim_space (dT, T) pairs + the mixed result + residual/update scratch
@@ -192,6 +195,8 @@ class CCSD(ccd.CCD):
         ctx, t1, t2 = st["ctx"], st["t1"], st["t2"]
         shift = st["level_shift"]
         world, rank, dist_on = st["world"], st["rank"], st["dist"]
+        mark = pdist.trace.mark          # per-phase device time + exposed communication for bench.py (no-ops otherwise)
+        mark("begin")
         if dist_on and st["sym"]:
             # K-sharded partial sums, all-reduced: the T1.V intermediates of the dressed Fock (:163, this rank's chunk of
             # j) and the slab's small V.T intermediates (X_ki, hole-ladder V_klcd T_cdij; this rank's chunk of c / (c,d))
@@ -199,23 +204,25 @@ class CCSD(ccd.CCD):
             # still in flight (0.8 GB at (50,200)) and is awaited — and unpacked into the replicated array — right
             # before the first kernel that reads T2.
             ctx.dress_fock_partial(t1, st["W"], rank, world)
-            red = [pdist.allreduce_tensor_start(st["W_t"], ctx)]
+            red = [pdist.allreduce_tensor_start(st["W_t"], ctx, label="fock intermediates")]
             # V~_iajb / V~_iabj only for the second-index range that this rank's column slab reads
             c0, c1 = pdist.slab_rows(ctx.no * ctx.nv, rank, world)
             if c1 > c0:      # one call: V~_klij and V~_iabj share their V_klcd t_dj intermediate       # :165
                 ctx.dress_V(t1, ("klij", "iajb", "iabj"), q_range=(c0 // ctx.no, -(-c1 // ctx.no)))
             else:
                 ctx.dress_V(t1, ("klij",))
+            mark("T1-only: fock partial, dress V slab")
             self._await_t2(st)
             ctx.slab_prepare(t2, st["P"], rank, world, is_dcd=self.is_dcd)
             # P = [ X'_ki (o^2 doubles: read by the ring half) | pair-packed 2 V_klcd T_cdij (26 MB at (50,200): read by the
             # ladder half) ]: two all-reduces, the big one is awaited only in front of the ladders — behind the ring products
             oo = ctx.no * ctx.no
-            red.append(pdist.allreduce_tensor_start(st["P_t"][:oo], ctx))
-            st["J_pending"] = pdist.allreduce_tensor_start(st["P_t"][oo:], ctx)
+            red.append(pdist.allreduce_tensor_start(st["P_t"][:oo], ctx, label="X_ki"))
+            st["J_pending"] = pdist.allreduce_tensor_start(st["P_t"][oo:], ctx, label="hole-ladder J")
             for work in red:
                 work.wait()
             ctx.dress_fock_finish(st["f"], t1, st["W"], st["fd"])
+            mark("await T2, slab prepare, fock finish")
         else:
             self._await_t2(st)
             ctx.dress_fock(st["f"], t1, st["fd"])                    # :163
@@ -236,21 +243,29 @@ class CCSD(ccd.CCD):
             pending = []
             if dist_on:
                 ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], rank, world, part="rings", **slab)
-                pending = [pdist.exchange_rows_start(st[key], rank, world, ctx) for key in ("ETd_t", "ETx_t")]
+                mark("ring products")
+                if st["owner_tiles"]:
+                    pending = [pdist.exchange_pair_tiles_start([st["ETd_t"], st["ETx_t"]], ctx.no, ctx.nv, rank, world, ctx,
+                                                               label="ETd+ETx owner tiles")]
+                else:
+                    pending = [pdist.exchange_rows_start(st[key], rank, world, ctx, label=key[:3])
+                               for key in ("ETd_t", "ETx_t")]
                 st.pop("J_pending").wait()
                 ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], rank, world, part="ladders", **slab)
-                pending += [pdist.exchange_rows_start(st[key], rank, world, ctx)
+                mark("ladders, Q_kb")
+                pending += [pdist.exchange_rows_start(st[key], rank, world, ctx, label=key[:-2])
                             for key in (("QK_t",) if st["pairs"] else ("L_t", "QK_t"))]
                 if st["pairs"]:      # X_ac (:206-221) as a partial sum over this rank's chunk of k, all-reduced below
                     ctx.xvv_partial(st["fd"], t2, st["Xvv"], rank, world, is_dcd=self.is_dcd)
-                    pending.append(pdist.allreduce_tensor_start(st["Xvv_t"], ctx))
+                    pending.append(pdist.allreduce_tensor_start(st["Xvv_t"], ctx, label="X_ac"))
             else:
                 ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], rank, world, **slab)
             # :167 as a partial sum over this rank's chunk of the occupied summation index, all-reduced (80 KB)
             ctx.singles_residual_partial(st["fd"], t1, t2, r1, rank, world, reuse_layouts=True)
-            pending.append(pdist.allreduce_tensor_start(st["R1_t"], ctx))
+            pending.append(pdist.allreduce_tensor_start(st["R1_t"], ctx, label="R1"))
             for work in pending:
                 work.wait()
+            mark("X_ac, singles residual, waits")
             if st["pairs"]:
                 return self._pair_sharded_tail(st, r1)
             r2 = ctx.pool_get(t2.shape)
@@ -314,9 +329,11 @@ class CCSD(ccd.CCD):
         ctx.cc_update_pairs(tc, dtc, rc, shift, self.delta, rank, world)
         ctx.pool_put(rc)
         st["first"] = False
+        pdist.trace.mark("finish + assembly (pairs), update")
         if self.is_diis:
             t1, tc = self.mixer.mix([dt1, dtc], [t1, tc], release=ctx.pool_put, sharded=(1,),
                                     allreduce=pdist.allreduce_sum)                    # :181-183
+        pdist.trace.mark("DIIS")
         lo, hi = pdist.slab_rows(st["npp"], rank, world)
         if hi > lo:
             mine = DeviceArray(ctx, st["Tall"].ptr + 8 * lo * 2 * ctx.no * ctx.no, (hi - lo, 2, ctx.no * ctx.no),
@@ -327,7 +344,8 @@ class CCSD(ccd.CCD):
         # all-reduce (RCCL runs the collectives of a communicator in order: behind the 0.8-GB transfer the host would wait
         # for it) — and the next iteration, or whoever reads st["t2"], completes it (_await_t2)
         e1, ed, ex, nt2, nr2, _ = pdist.allreduce_sum(ctx.energy_norms_pairs(st["f"], t1, tc, dtc, rank, world))
-        st["t2_pending"] = pdist.exchange_rows_start(st["Tall_t"], rank, world, ctx)
+        st["t2_pending"] = pdist.exchange_rows_start(st["Tall_t"], rank, world, ctx, label="new T2")
+        pdist.trace.mark("energy + norms (pairs)")
         if not self.is_diis:
             ctx.pool_put(dt1)
             ctx.pool_put(dtc)

@@ -10,6 +10,9 @@ import torch.distributed as dist
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 if "--fail" in sys.argv and rank == 1:
     sys.exit(3)
+if "--hang" in sys.argv:         # a rank stuck in a collective that never completes
+    import time
+    time.sleep(600)
 dist.init_process_group("gloo", rank=rank, world_size=world)
 t = torch.tensor([float(rank + 1)], dtype=torch.float64)
 dist.all_reduce(t)

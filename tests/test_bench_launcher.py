@@ -36,3 +36,17 @@ def test_bench_decides_to_launch_only_without_a_launcher():
     src = open(os.path.join(ROOT, "bench.py")).read()
     # the parent must decide before importing torch / touching the GPU
     assert src.index("launch_ranks(args.gpus") < src.index("import torch\n    import torch.distributed as dist")
+
+
+def test_rccl_run_refuses_more_ranks_than_devices():
+    """--backend nccl with WORLD_SIZE > visible GPUs must end at once with a non-zero status and say why (two ranks on one
+    device fail or hang in RCCL's communicator set-up); here no GPU is visible at all."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "nccl"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "one GPU per rank" in r.stderr and not r.stdout.strip()
+
+
+def test_launcher_stops_hung_ranks():
+    r = _run(f"import bench; bench.launch_ranks(2, ['--hang'], script={CHILD!r}, timeout_s=3.0)")
+    assert r.returncode != 0 and "still running" in r.stderr

@@ -148,9 +148,64 @@ def _solver_worker(rank, world, port, libpath, out):
                 r = s.solve(f, V)
             assert s.pair_sharded
             res[("ccd", no, nv, dcd, diis)] = (float(r["ccd e"]), int(s.iterations), float(np.abs(r["t2 amp"]).sum()), 0.0)
+        # owner-tile exchange (PYMES_OWNER_TILES=1): an all-to-all of the tiles each pair owner reads instead of the two
+        # all-gathers of the ring-product rows — must give the very same numbers, bit for bit
+        os.environ["PYMES_OWNER_TILES"] = "1"
+        try:
+            tiles = {}
+            for no, nv, dcsd, diis in ((3, 7, False, True), (2, 5, True, True)):
+                f, V, B, eps = synthetic_case(no, nv, seed=3, scale=0.3)
+                s = CCSD(no, delta_e=1e-10, is_dcsd=dcsd, is_diis=diis)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    r = s.solve(f, V)
+                assert s.pair_sharded
+                tiles[(no, nv, dcsd, diis)] = (float(r["ccsd e"]), int(s.iterations), float(np.abs(r["t2"]).sum()),
+                                               float(np.abs(r["t2"] - r["t2"].transpose(1, 0, 3, 2)).max()))
+            f, V, B, eps = synthetic_case(3, 7, seed=4, scale=0.3)
+            s = CCD(3, delta_e=1e-10)
+            with contextlib.redirect_stdout(io.StringIO()):
+                r = s.solve(f, V)
+            tiles[("ccd", 3, 7, False, True)] = (float(r["ccd e"]), int(s.iterations), float(np.abs(r["t2 amp"]).sum()), 0.0)
+        finally:
+            del os.environ["PYMES_OWNER_TILES"]
+        for key, val in tiles.items():
+            assert val == res[key], (key, val, res[key])
         out[rank] = res
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("no,nv,world", [(3, 7, 2), (2, 5, 3), (4, 9, 8), (5, 20, 8), (50, 200, 8), (1, 3, 4)])
+def test_owner_tile_plan_covers_what_the_assembly_reads(no, nv, world):
+    """Every tile [(a,.),(b,.)] / [(b,.),(a,.)] of a pair matrix that residual_assemble_pairs reads for the pairs a rank
+    owns is either in the rank's own row slab or inside a rectangle some owner sends it; no rectangle leaves the rows
+    of its sender."""
+    ov, npp = no * nv, nv * (nv + 1) // 2
+    plan = pdist.owner_tile_plan(no, nv, world)
+    for q in range(world):
+        have = np.zeros((nv, nv), dtype=bool)             # tile (x, y): rows (x,.) columns (y,.) present on rank q
+        own = pdist.slab_rows(ov, q, world)
+        rows_present = np.zeros((ov, nv), dtype=bool)     # (row, column tile)
+        rows_present[own[0]:own[1], :] = True
+        for p in range(world):
+            assert not plan[q][q]
+            r0p, r1p = pdist.slab_rows(ov, p, world)
+            for (r0, r1, c0, c1) in plan[p][q]:
+                assert r0p <= r0 < r1 <= r1p and 0 <= c0 < c1 <= ov and c0 % no == 0 and c1 % no == 0
+                rows_present[r0:r1, c0 // no:c1 // no] = True
+        have = rows_present.reshape(nv, no, nv).all(axis=1)
+        lo, hi = pdist.slab_rows(npp, q, world)
+        for r in range(lo, hi):
+            a = int((np.sqrt(8.0 * r + 1.0) - 1.0) / 2.0)
+            while a * (a + 1) // 2 > r:
+                a -= 1
+            while (a + 1) * (a + 2) // 2 <= r:
+                a += 1
+            b = r - a * (a + 1) // 2
+            assert have[a, b] and have[b, a], (q, a, b)
+    if world == 8 and (no, nv) == (50, 200):      # the point of it: ~0.2 GB per rank instead of 1.6 GB of all-gathers
+        recv = [2 * 8 * sum((r1 - r0) * (c1 - c0) for p in range(world) for r0, r1, c0, c1 in plan[p][q]) for q in range(world)]
+        assert max(recv) < 0.21e9 and 2 * 8 * ov * ov * 7 // 8 > 1.3e9
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])        # 8: more ranks than some index ranges have chunks (empty shares)
