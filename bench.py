@@ -213,7 +213,10 @@ def main():
     f = np.diag(eps)
     solver = CCSD(no, is_dcsd=args.dcsd, is_diis=not args.no_diis, device=local)
     import contextlib, io
-    st = solver.setup(f, ints)
+    t0 = time.time()
+    st = solver.setup(f, ints)          # orbital energies, exchange-symmetry test of all 16 blocks, MP2 amplitudes, buffers
+    ctx.sync()
+    t_setup = time.time() - t0
     energies = []
 
     def step():
@@ -221,8 +224,11 @@ def main():
             e = solver.iterate(st)
         energies.append(e[0] + e[1] + e[2])
 
+    t0 = time.time()
     for _ in range(args.warmup):
         step()
+    ctx.sync()
+    t_warm = time.time() - t0           # includes the per-solve statics the first passes build (packed V+-, permutations)
 
     def fence():
         ctx.sync()
@@ -257,7 +263,7 @@ def main():
             step()
         fence()
     phases, collectives = pdist.trace.summary(args.steps) if sharded_run else ({}, {})
-    pdist.trace.enable(False)
+    pdist.trace.on = False
     prof = ctx.prof_query()
     prof_dma = ctx.prof_query(kernel_class=1)
     stats = ctx.stats()
@@ -312,7 +318,9 @@ def main():
                           "algorithmic_frac_of_fp64_peak": ref_fl / s_per_step / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                           "executed_gemm_tflops_over_step": stats["gemm_flops"] / args.steps / s_per_step / 1e12,
                           "permute_gbytes_per_step": stats["permute_bytes"] / args.steps / 1e9,
-                          "integral_build_s": t_build, "workspace_high_water_gb": high / 1e9,
+                          "integral_build_s": t_build, "setup_s": t_setup,
+                          "first_passes_extra_s": max(0.0, t_warm - args.warmup * s_per_step) if args.warmup else None,
+                          "workspace_high_water_gb": high / 1e9,
                           "launch_graph_replay": replayed, "last_energy": timed_energy},
         }
         if sharded_run:
@@ -325,7 +333,7 @@ def main():
                 "backend": args.backend if dist.is_initialized() else "none (collectives stubbed)",
                 "rank": prank, "of": pworld, "collectives_stubbed": bool(args.stub_collectives),
                 "owner_tiles": bool(os.environ.get("PYMES_OWNER_TILES")),
-                "phases_ms": phases, "collectives": collectives,
+                "phases_ms": phases, "phases_host_ms": getattr(pdist.trace, "host_ms", {}), "collectives": collectives,
                 "exposed_wait_ms": sum(c["exposed_wait_ms"] for c in collectives.values()),
                 "wire_gbytes_per_step": sum(c["wire_bytes"] for c in collectives.values()) / 1e9,
                 "devices_visible": ndev}

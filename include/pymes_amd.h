@@ -159,6 +159,14 @@ int pymes_ladder(pymes_ctx* ctx, const double* t2_dev, double* r2_dev, int a_beg
 int pymes_ladder_sym(pymes_ctx* ctx, const double* t2_dev, double* L_dev, int64_t row_begin, int64_t row_end,
                      int dressed, int hole_ladder);
 int pymes_ladder_sym_unpack(pymes_ctx* ctx, const double* L_dev, double* r2_dev, double beta);
+/* The particle ladder of pymes_ladder_sym (all rows, no hole ladder) for k exchange-symmetric vectors at once:
+ * x_dev[z] are k device arrays [v,v,o,o], L_all_dev k consecutive arrays [v(v+1)/2][o*o].  One batched GEMM launch per half
+ * over all vectors — the sigma builds of every vector of an EOM-CCSD Davidson pass (eom_ccsd.py:95-101, :383). */
+int pymes_ladder_sym_multi(pymes_ctx* ctx, const double* const* x_dev, int k, double* L_all_dev, int dressed);
+/* The three pair layouts of an amplitude-like array X [v,v,o,o] in one pass: Xd[(a,i),(b,j)] = X_abij,
+ * Xx[(a,j),(b,i)] = X_abij, Xt[(a,i),(b,j)] = 2 X_abij - X_baij (each [o*v][o*v]; Xd_dev may be NULL).  ccd.py:199 /
+ * eom_ccsd.py:352-373 form these index orders implicitly inside their einsum calls. */
+int pymes_pair_layouts(pymes_ctx* ctx, const double* x_dev, double* Xd_dev, double* Xx_dev, double* Xt_dev);
 /* P(ijab,jiba) symmetrisation and assembly in one pass (ccd.py:249-252, eom_ccsd.py:377):
  *   R_abij = V_abij + unpack(L)_abij + N_abij + N_baji + D[(a,i),(b,j)] + D[(b,j),(a,i)] + X[(a,j),(b,i)] + X[(b,i),(a,j)]
  * with V [v,v,o,o] (NULL: 0; may be R), L the pair-packed rows of pymes_ladder_sym (NULL: none), N [v,v,o,o], D and X

@@ -324,6 +324,22 @@ int pymes_hole_ladder_packed(pymes_ctx* ctx, const double* x, const double* I, d
         E(ctx).hole_ladder_packed(x, I, L, r0, r1, y);
     });
 }
+int pymes_ladder_sym_multi(pymes_ctx* ctx, const double* const* xs, int k, double* L_all, int dressed) {
+    return guarded([&] {
+        need(xs, "x"); need(L_all, "L_all");
+        if (k < 1 || k > 64) throw pymes::Error("ladder_sym_multi: 1 <= k <= 64");
+        for (int z = 0; z < k; ++z) need(xs[z], "x[z]");
+        E(ctx).ladder_sym_multi(xs, k, L_all, dressed != 0);
+    });
+}
+int pymes_pair_layouts(pymes_ctx* ctx, const double* x, double* Xd, double* Xx, double* Xt) {
+    return guarded([&] {
+        need(x, "x"); need(Xx, "Xx"); need(Xt, "Xt");
+        pymes::Engine& e = E(ctx);
+        if (!dev::fused_pair_kernels_ok(e.no)) throw pymes::Error("pair_layouts: nocc too large for the LDS tile");
+        dev::t2_layouts(x, Xd, Xx, Xt, e.no, e.nv, e.stream);
+    });
+}
 int pymes_ladder_sym_unpack(pymes_ctx* ctx, const double* L, double* r2, double beta) {
     return guarded([&] {
         need(L, "L"); need(r2, "r2");

@@ -714,6 +714,52 @@ void Engine::ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1,
     if (opm > 0) contract(1.0, slice(make_view(AmR, {npp, ldp}), 0, row0, row1), "rk", ImK, "kn", 1.0, LA, "rn");
 }
 
+// The particle ladder (ladder_sym without the hole part) for k vectors in ONE batched launch per half: the packed
+// integrals V^+- are the shared left operand (batch stride 0), the packed amplitudes of vector z the right operand of
+// batch z.  EOM-CCSD builds sigma for every vector of the Davidson subspace per pass (eom_ccsd.py:95-101): at (30,120) one
+// vector is 228 tiles on 256 CUs, k vectors are k x 228 tiles with a k-split tail.
+void Engine::ladder_sym_multi(const double* const* xs, int k, double* L_all, bool dressed) {
+    const int64_t o = no, v = nv, npp = v * (v + 1) / 2, npm = v * (v - 1) / 2, opp = o * (o + 1) / 2,
+                  opm = o * (o - 1) / 2;
+    if (k < 1) return;
+    if (!(lpack_.valid && lpack_.dressed == dressed && lpack_.row0 == 0 && lpack_.row1 == npp)) {
+        if (!lpack_.Vp || lpack_.row1 - lpack_.row0 != npp) {
+            dev::stream_sync(stream);
+            dev::dfree(lpack_.Vp);
+            dev::dfree(lpack_.Vm);
+            lpack_.Vp = lpack_.Vm = nullptr;
+            lpack_.Vp = static_cast<double*>(dev::dmalloc(sizeof(double) * npp * npp));
+            lpack_.Vm = static_cast<double*>(dev::dmalloc(sizeof(double) * npp * std::max<int64_t>(npm, 1)));
+        }
+        dev::ladder_pack_V(block(P_abcd, dressed).p, lpack_.Vp, lpack_.Vm, nv, nv, 0, npp, stream);
+        stats.permute_calls++;
+        stats.permute_bytes += 8.0 * 2.0 * double(npp) * double(v * v);
+        lpack_.row0 = 0; lpack_.row1 = npp; lpack_.dressed = dressed; lpack_.valid = true;
+    }
+    ArenaScope scope(arena);
+    const int64_t ldp = opp + (opp & 1), ldm = std::max<int64_t>(opm + (opm & 1), 2);
+    const int64_t sp_sz = npp * ldp, am_sz = std::max<int64_t>(npm * ldm, 2);
+    double* Sp = arena.alloc(k * sp_sz);
+    double* Am = arena.alloc(k * am_sz);
+    for (int z = 0; z < k; ++z)
+        dev::ladder_pack_T(xs[z], nullptr, Sp + z * sp_sz, Am + z * am_sz, no, nv, dev::PACK_ROW_HALF, ldp, ldm, stream);
+    stats.permute_calls += k;
+    stats.permute_bytes += 8.0 * 2.0 * double(k) * double(v * v * o * o);
+    // operands with explicit batch strides: B_z = Sp + z sp_sz ([npp][ldp], columns 0..opp), C_z = L_all + z npp o^2
+    int64_t bd[3] = {k, npp, opp}, bs[3] = {sp_sz, ldp, 1}, cd[3] = {k, npp, opp}, cs[3] = {npp * o * o, o * o, 1};
+    contract(1.0, make_view(lpack_.Vp, {npp, npp}), "rk", make_view(Sp, 3, bd, bs), "zkn", 0.0, make_view(L_all, 3, cd, cs), "zrn", "z");
+    if (opm > 0) {
+        if (npm > 0) {
+            int64_t bd2[3] = {k, npm, opm}, bs2[3] = {am_sz, ldm, 1}, cd2[3] = {k, npp, opm};
+            contract(1.0, make_view(lpack_.Vm, {npp, npm}), "rk", make_view(Am, 3, bd2, bs2), "zkn", 0.0,
+                     make_view(L_all + opp, 3, cd2, cs), "zrn", "z");
+        } else {
+            int64_t cd2[3] = {k, npp, opm};
+            zero(make_view(L_all + opp, 3, cd2, cs));
+        }
+    }
+}
+
 // A hole-ladder-shaped term sum_kl I_klij X_abkl in the pair-packed rows of L (added to what the rows hold), for
 // I_klij = I_lkji and X_abkl = X_balk: the (k,l) part of ladder_sym for a caller-supplied I (EOM-CCSD: eom_ccsd.py:380-382
 // — u2 against V_klij + V_klcd T_cdij, T against V_kldc u2_dcij), 1/4 of the flops of the plain v^2 o^4 product.  With y

@@ -151,6 +151,9 @@ class Engine {
     // rows [row0,row1) of the pair-packed result L[v(v+1)/2][o*o] (device_api.h), then R = beta R + unpack(L)
     // hole = 1 / 2 adds the hole ladder (ccd.py:175-186; CCSD / DCSD form of I_klij) to the same rows
     void ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1, bool dressed, int hole = 0);
+    // the particle ladder of k exchange-symmetric vectors x_z [v,v,o,o] at once: L_all[z] (k consecutive [v(v+1)/2][o*o]
+    // arrays) = pair-packed V_abcd . x_z, one batched launch per half (S / A) over all k vectors
+    void ladder_sym_multi(const double* const* xs, int k, double* L_all, bool dressed);
     void hole_ladder_packed(const double* x, const double* I, double* L, int64_t row0, int64_t row1,
                             const double* y = nullptr);
     void ladder_sym_unpack(const double* L, double* r2, double beta);

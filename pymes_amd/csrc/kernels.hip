@@ -1005,37 +1005,67 @@ __global__ void __launch_bounds__(256) energy_norms_kernel(const double* __restr
     }
 }
 
-// out[0] = max |A[p,q,r,s] - B[q,p,s,r]|, out[1] = max |A| as bit patterns (non-negative doubles order like integers).
-// One block per (p, q, 32 x 32 tile of (r,s)): the partner tile B[q,p,s0:,r0:] is read row-wise and transposed through LDS,
-// so both tensors stream with full lines (the V_abcd check is a 12.8-GB read at (50,200)).
+// out[0] = max |A[p,q,r,s] - B[q,p,s,r]|, out[1] = max(|A|, |B|) as bit patterns (non-negative doubles order like integers).
+// Persistent blocks walk over (p, q, 64 x 64 tile of (r,s)): the partner tile B[q,p,s0:,r0:] is read row-wise with 16-byte
+// loads and transposed through LDS, the tile of A is read row-wise too, so both tensors stream with full lines; one pair of
+// atomics per BLOCK (round 2 had one block and one atomic pair per 32 x 32 tile — 1.5 M blocks of 16 KB for the V_abcd
+// check at (50,200): 45 ms for a 25-GB read).  A block that is its own partner (A == B: klij, ijab, abij, abcd) is
+// walked over p <= q only — every element is still touched once, as A[p,q] or as B[q,p].
+template <bool VEC>
 __global__ void __launch_bounds__(256) exchange_asym_kernel(const double* __restrict__ A, const double* __restrict__ B,
-                                                            long d0, long d1, long d2, long d3, int tr, int ts,
-                                                            unsigned long long* __restrict__ out) {
-    __shared__ double tile[32][33];
+                                                            long d0, long d1, long d2, long d3, int tr, int ts, long ntiles,
+                                                            int self, unsigned long long* __restrict__ out) {
+    __shared__ double tile[64][65];
     __shared__ double sh[8];
-    long bid = blockIdx.x;
-    const int t_s = (int)(bid % ts); bid /= ts;
-    const int t_r = (int)(bid % tr); bid /= tr;
-    const long q = bid % d1, p = bid / d1;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const long r0 = (long)t_r * 32, s0 = (long)t_s * 32;
-    const double* __restrict__ Apq = A + (p * d1 + q) * d2 * d3;      // [d2][d3]
-    const double* __restrict__ Bqp = B + (q * d0 + p) * d3 * d2;      // [d3][d2]
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {       // tile[s - s0][r - r0] = B[q,p,s,r], rows of r contiguous
-        const long sg = s0 + ty + 8 * j, rg = r0 + tx;
-        if (sg < d3 && rg < d2) tile[ty + 8 * j][tx] = Bqp[sg * d2 + rg];
-    }
-    __syncthreads();
     double m1 = 0.0, m2 = 0.0;
+    auto upd = [&](double a, double b) {
+        const double d = fabs(a - b);
+        m1 = (d > m1 || d != d) ? d : m1;          // a NaN difference must not pass as symmetric
+        m2 = fmax(m2, fmax(fabs(a), fabs(b)));
+    };
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        long bid = t;
+        const int t_s = (int)(bid % ts); bid /= ts;
+        const int t_r = (int)(bid % tr); bid /= tr;
+        const long q = bid % d1, p = bid / d1;
+        if (self && q < p) continue;                  // (block-uniform)
+        const long r0 = (long)t_r * 64, s0 = (long)t_s * 64;
+        const double* __restrict__ Apq = A + (p * d1 + q) * d2 * d3;      // [d2][d3]
+        const double* __restrict__ Bqp = B + (q * d0 + p) * d3 * d2;      // [d3][d2]
+        if constexpr (VEC) {       // d2, d3 even: pairs never straddle an edge
+            const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const long rg = r0 + ty + 8 * j, sg = s0 + tx;
-        if (rg < d2 && sg < d3) {
-            const double a = Apq[rg * d3 + sg], d = fabs(a - tile[tx][ty + 8 * j]);
-            m1 = (d > m1 || d != d) ? d : m1;          // a NaN difference must not pass as symmetric
-            m2 = fmax(m2, fabs(a));
+            for (int j = 0; j < 8; ++j) {       // tile[s - s0][r - r0] = B[q,p,s,r], rows of r contiguous
+                const long sg = s0 + ty + 8 * j, rg = r0 + 2 * tx;
+                if (sg < d3 && rg < d2) {
+                    const v2d v = *reinterpret_cast<const v2d*>(Bqp + sg * d2 + rg);
+                    tile[ty + 8 * j][2 * tx] = v[0];
+                    tile[ty + 8 * j][2 * tx + 1] = v[1];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const long rg = r0 + ty + 8 * j, sg = s0 + 2 * tx;
+                if (rg < d2 && sg < d3) {
+                    const v2d a = *reinterpret_cast<const v2d*>(Apq + rg * d3 + sg);
+                    upd(a[0], tile[2 * tx][ty + 8 * j]);
+                    upd(a[1], tile[2 * tx + 1][ty + 8 * j]);
+                }
+            }
+        } else {
+            const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+            for (int j = 0; j < 16; ++j) {
+                const long sg = s0 + ty + 4 * j, rg = r0 + tx;
+                if (sg < d3 && rg < d2) tile[ty + 4 * j][tx] = Bqp[sg * d2 + rg];
+            }
+            __syncthreads();
+            for (int j = 0; j < 16; ++j) {
+                const long rg = r0 + ty + 4 * j, sg = s0 + tx;
+                if (rg < d2 && sg < d3) upd(Apq[rg * d3 + sg], tile[tx][ty + 4 * j]);
+            }
         }
+        __syncthreads();                               // the tile is overwritten by the next pass
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -1197,7 +1227,7 @@ __global__ void __launch_bounds__(256) t2_layouts_kernel(const double* __restric
         const double x = Tab[e];
         tile[i * (no + 1) + j] = x;
         const long off = base + (long)i * ov + j;
-        Td[off] = x;
+        if (Td) Td[off] = x;
         Ttd[off] = 2.0 * x - Tba[e];
     }
     __syncthreads();
@@ -2314,10 +2344,16 @@ void exchange_asymmetry(const double* A, const double* B, const int64_t d[4], do
     if (!total) return;
     unsigned long long* out_dev = reinterpret_cast<unsigned long long*>(g_dot_ws[dv] + 16 * kDotBlocks);
     HIP_CHECK(hipMemsetAsync(out_dev, 0, 2 * sizeof(unsigned long long), st));
-    const long tr = (d[2] + 31) / 32, ts = (d[3] + 31) / 32, nblk = d[0] * d[1] * tr * ts;
-    if (nblk > 0x7fffffffL) throw std::runtime_error("exchange_asymmetry: grid too large");
-    hipLaunchKernelGGL(exchange_asym_kernel, dim3((unsigned)nblk), dim3(256), 0, st, A, B, (long)d[0], (long)d[1], (long)d[2],
-                       (long)d[3], (int)tr, (int)ts, out_dev);
+    const long tr = (d[2] + 63) / 64, ts = (d[3] + 63) / 64, ntiles = d[0] * d[1] * tr * ts;
+    const int self = (A == B && d[0] == d[1]) ? 1 : 0;
+    const unsigned grid = (unsigned)std::min<long>(ntiles, 256L * 8);
+    const bool vec = even(d[2]) && even(d[3]) && aligned16(A) && aligned16(B);
+    if (vec)
+        hipLaunchKernelGGL(exchange_asym_kernel<true>, dim3(grid), dim3(256), 0, st, A, B, (long)d[0], (long)d[1], (long)d[2],
+                           (long)d[3], (int)tr, (int)ts, ntiles, self, out_dev);
+    else
+        hipLaunchKernelGGL(exchange_asym_kernel<false>, dim3(grid), dim3(256), 0, st, A, B, (long)d[0], (long)d[1], (long)d[2],
+                           (long)d[3], (int)tr, (int)ts, ntiles, self, out_dev);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(g_dot_host[dv], out_dev, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));

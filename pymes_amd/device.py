@@ -465,6 +465,18 @@ class Context:
                       int(row_end), int(dressed), int(hole_ladder))
         return L
 
+    def ladder_sym_multi(self, xs, L_all, dressed=False):
+        """Particle ladder (ccd.py:187 / eom_ccsd.py:383, pair-packed) of the k exchange-symmetric arrays ``xs`` in one
+        batched launch per half; ``L_all`` is [k, v(v+1)/2, o*o] (include/pymes_amd.h)."""
+        self.lib.call("pymes_ladder_sym_multi", self.handle, ptr_array([x.ptr for x in xs]), len(xs), C.c_void_p(L_all.ptr),
+                      int(dressed))
+        return L_all
+
+    def pair_layouts(self, x, Xx, Xt, Xd=None):
+        """Xx[(a,j),(b,i)] = x_abij, Xt[(a,i),(b,j)] = 2 x_abij - x_baij (and Xd[(a,i),(b,j)] = x_abij) in one pass."""
+        self.lib.call("pymes_pair_layouts", self.handle, C.c_void_p(x.ptr), C.c_void_p(Xd.ptr if Xd is not None else 0),
+                      C.c_void_p(Xx.ptr), C.c_void_p(Xt.ptr))
+
     def symmetrised_assemble(self, N, D, X, out, V=None, L=None):
         """out_abij = V + unpack(L) + N_abij + N_baji + D[(a,i),(b,j)] + D[(b,j),(a,i)] + X[(a,j),(b,i)] + X[(b,i),(a,j)] in one
         pass (include/pymes_amd.h); V / L optional."""

@@ -40,7 +40,7 @@ class Trace:
         self.reset()
 
     def reset(self):
-        self._marks, self._waits, self.bytes, self.calls = [], [], {}, {}
+        self._marks, self._waits, self.bytes, self.calls, self._host = [], [], {}, {}, []
 
     def enable(self, on=True):
         self.on = bool(on)
@@ -57,7 +57,9 @@ class Trace:
 
     def mark(self, name):
         if self.on:
+            import time
             self._marks.append((name, self._event()))
+            self._host.append((name, time.perf_counter()))
 
     def sent(self, label, nbytes):
         if self.on:
@@ -81,6 +83,13 @@ class Trace:
             if e0 is not None and e1 is not None:
                 waits[label] = waits.get(label, 0.0) + e0.elapsed_time(e1)
         steps = max(1, int(steps))
+        # host wall time between the same marks: a phase whose host time is close to its device time is host-bound (the
+        # GPU stood idle waiting for launches or for a host decision), one with little host time was enqueued ahead
+        host = {}
+        for (_, t0), (name, t1) in zip(self._host, self._host[1:]):
+            if name != "begin":
+                host[name] = host.get(name, 0.0) + 1e3 * (t1 - t0)
+        self.host_ms = {k: v / steps for k, v in host.items()}
         coll = {label: {"exposed_wait_ms": waits.get(label, 0.0) / steps, "wire_bytes": self.bytes.get(label, 0) / steps,
                         "calls": self.calls.get(label, 0) / steps} for label in sorted(set(self.bytes) | set(waits))}
         return {k: v / steps for k, v in phases.items()}, coll

@@ -109,6 +109,16 @@ class _Sigma:
         # eom_ccsd.py:380-382 in pair-packed rows needs B2_klij = B2_lkji and V_klcd = V_lkdc (then B' has it for symmetric u2)
         self.hole_sym = self.t_sym and c.exchange_symmetric(self.B2) and c.exchange_symmetric(V["ijab"])
         self.L = c.empty((nv * (nv + 1) // 2, no * no)) if self.v_sym else None
+        # ---- multi-vector sigma (apply_many): what the stacked products read --------------------------------------------
+        self.many_ok = bool(self.v_sym and self.hole_sym and self.fused_ok and self.t_sym)
+        if self.many_ok:
+            self.fovT = c.array(np.ascontiguousarray(f[:no, no:].T))
+            # The four u1 terms with one free index on u1 (:336-338, :341 region: A_oovo, A4, A6 and V_iajk) as ONE product
+            # u1[a,l] A346[l,b,i,j].  Everything added to D is symmetrised by P(ijab,jiba) afterwards (:377), so a term
+            # X_abij may be replaced by its partner X_baji: sum_l u1[b,l] A4[l,i,a,j] -> sum_l u1[a,l] A4[l,j,b,i], etc.
+            self.A346 = c.permute("libj->lbij", self.A3)
+            c.permute("ljbi->lbij", self.A4, out=self.A346, beta=1.0)
+            c.lincomb(self.A346, [self.A346, self.A6, V["iajk"]], [1.0, -1.0, -1.0])
 
     def exchange_symmetric(self, u2):
         return self.ctx.exchange_symmetric(u2)      # one reduction kernel, no temporary
@@ -223,6 +233,78 @@ class _Sigma:
     def apply(self, u1, u2, u2_sym=None):
         return self.singles(u1, u2), self.doubles(u1, u2, u2_sym)
 
+    # ------------------------------------------------------------------------------------------
+    def apply_many(self, u1s, u2s, syms=None):
+        """sigma for k trial vectors at once: [(sigma1_z, sigma2_z)].  The reference builds sigma vector by vector for
+        the whole Davidson subspace (eom_ccsd.py:95-101); here the k vectors are stacked, so that every operand that does not
+        depend on the trial vector — the hoisted (ov)^2 pair matrices, V_abcd (pair-packed), T, the V.T intermediates — is
+        read ONCE for all of them: the (ov)^3 products become [k ov x ov x ov] GEMMs, the particle ladders one batched
+        launch, the one-index terms GEMMs with M = k v.  Needs exchange-symmetric vectors and the pair-packed forms
+        (``many_ok``); anything else goes vector by vector through ``apply``."""
+        k = len(u1s)
+        if syms is None:
+            syms = [self.exchange_symmetric(u2) for u2 in u2s]
+        if k < 2 or not self.many_ok or not all(syms):
+            return [self.apply(u1, u2, u2_sym=sy) for u1, u2, sy in zip(u1s, u2s, syms)]
+        c, V, T = self.ctx, self.V, self.T
+        no, nv = self.no, self.nv
+
+        def part(stack, z):
+            n = stack.size // k
+            return DeviceArray(c, stack.ptr + 8 * z * n, stack.shape[1:], owned=False, keepalive=stack)
+        U1 = c.empty((k, nv, no))
+        X = c.empty((k, nv, no, nv, no))        # X[z,(a,j),(b,i)] = u2_z[a,b,i,j]                   (symmetric matrices)
+        Tt = c.empty((k, nv, no, nv, no))       # Tt[z,(a,i),(b,j)] = 2 u2_z[a,b,i,j] - u2_z[b,a,i,j]  (symmetric matrices)
+        for z in range(k):
+            part(U1, z).copy_from(u1s[z])
+            c.pair_layouts(u2s[z], part(X, z), part(Tt, z))
+        # ---- singles (eom_ccsd.py:268-310), ut[a,b,i,j] = Tt[(a,i),(b,j)] --------------------------------------------------
+        S1 = c.contract("zck,ckai->zai", U1, self.W1)
+        c.contract("ac,zci->zai", self.Gvv_s, U1, out=S1, beta=1.0, batch="z")
+        c.contract("zak,ki->zai", U1, self.Goo_s, out=S1, beta=1.0)
+        c.contract("zaibj,bj->zai", Tt, self.fovT, out=S1, beta=1.0)
+        c.contract("zajbk,jkib->zai", Tt, V["ijka"], out=S1, alpha=-1.0, beta=1.0)
+        c.contract("jabc,zbjci->zai", V["iabc"], Tt, out=S1, beta=1.0)
+        # ---- (ov)^3 products, transposed: only Dx + Dx^T and Dd + Dd^T enter (:377), X and Tt are symmetric matrices ----------
+        DxT = c.contract("zajdl,bidl->zajbi", X, self.MDU)                        # (MDU . u2x)^T per vector
+        DdT = c.permute("zajbi->zajbi", DxT, alpha=0.5)                           # same memory layout as "zaibj"
+        c.contract("zaidl,bjdl->zaibj", Tt, self.M12, out=DdT, alpha=0.5, beta=1.0)
+        # ---- one-index dressings ---------------------------------------------------------------------------------------------
+        Xoo = c.contract("klid,zdl->zki", V["ijka"], U1, alpha=-2.0)
+        c.contract("kldi,zdl->zki", V["ijak"], U1, out=Xoo, beta=1.0)
+        c.contract("kd,zdi->zki", self.fov, U1, out=Xoo, alpha=-1.0, beta=1.0, batch="z")
+        c.contract("kldc,zdlci->zki", V["ijab"], X, out=Xoo, alpha=-2.0, beta=1.0)      # u2[d,c,i,l] = X[(d,l),(c,i)]
+        c.contract("kldc,zdicl->zki", V["ijab"], X, out=Xoo, beta=1.0)                  # u2[d,c,l,i] = X[(d,i),(c,l)]
+        c.contract("zki,akbj->zaibj", Xoo, self.Td, out=DdT, beta=1.0, batch="za")
+        Xvv = c.contract("ladc,zdl->zac", V["iabc"], U1, alpha=2.0)
+        c.contract("lacd,zdl->zac", V["iabc"], U1, out=Xvv, alpha=-1.0, beta=1.0)
+        c.contract("zal,lc->zac", U1, self.fov, out=Xvv, alpha=-1.0, beta=1.0)
+        c.contract("lkcd,zakdl->zac", V["ijab"], X, out=Xvv, alpha=-2.0, beta=1.0)      # u2[a,d,l,k] = X[(a,k),(d,l)]
+        c.contract("lkcd,zdkal->zac", V["ijab"], X, out=Xvv, beta=1.0)                  # u2[d,a,l,k] = X[(d,k),(a,l)]
+        D = c.contract("zac,cbij->zabij", Xvv, T)
+        c.contract("adbj,zdi->zabij", self.WA, U1, out=D, beta=1.0)
+        c.contract("adbi,zdj->zabij", self.W3, U1, out=D, alpha=-1.0, beta=1.0)
+        c.contract("zal,lbij->zabij", U1, self.A346, out=D, beta=1.0)
+        c.contract("abic,zcj->zabij", V["abic"], U1, out=D, beta=1.0, batch="z")
+        npp = self.L.shape[0]
+        Lall = c.empty((k, npp, no * no))
+        c.ladder_sym_multi(u2s, Lall)                                                   # :383, all vectors
+        out = []
+        S2 = c.empty(D.shape)
+        for z in range(k):
+            Dz, u2, u1 = part(D, z), u2s[z], part(U1, z)
+            c.contract("ad,dbij->abij", self.Gvv, u2, out=Dz, beta=1.0)
+            c.contract("li,ablj->abij", self.Goo, u2, out=Dz, beta=1.0, batch="ab")
+            B5 = c.contract("klid,dj->klij", V["ijka"], u1)
+            B5s = c.permute("klij->klij", B5)
+            c.permute("lkji->klij", B5, out=B5s, beta=1.0)
+            Lz = part(Lall, z)
+            c.hole_ladder_packed(u2, self.B2, Lz, 0, npp)                               # :380, :382
+            c.hole_ladder_packed(T, B5s, Lz, 0, npp, y=u2)                              # :381 (+ the symmetrised u1 term)
+            c.symmetrised_assemble(Dz, part(DdT, z), part(DxT, z), part(S2, z), L=Lz)   # :377 + unpacking in one pass
+            out.append((part(S1, z), part(S2, z)))
+        return out
+
 
 class EOM_CCSD:
     def __init__(self, no, n_excit=3, device=0):
@@ -283,9 +365,10 @@ class EOM_CCSD:
                 # exchange symmetry of the trial doubles, decided here (between the sigma builds) so that the builds
                 # themselves run without host synchronisation
                 sym = [sig.exchange_symmetric(self._part(ctx, u, n1, (nv, nv, no, no))) for u in us]
-                for l in range(dim):                                             # :95-101
-                    s1, s2 = sig.apply(self._part(ctx, us[l], 0, (nv, no)), self._part(ctx, us[l], n1, (nv, nv, no, no)),
-                                       u2_sym=sym[l])
+                sigmas = sig.apply_many([self._part(ctx, u, 0, (nv, no)) for u in us],       # :95-101, all vectors of the
+                                        [self._part(ctx, u, n1, (nv, nv, no, no)) for u in us], sym)   # subspace at once
+                for l in range(dim):
+                    s1, s2 = sigmas[l]
                     w = ctx.empty((n1 + n2,))
                     self._part(ctx, w, 0, (nv, no)).copy_from(s1)
                     self._part(ctx, w, n1, (nv, nv, no, no)).copy_from(s2)

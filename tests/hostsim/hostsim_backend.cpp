@@ -304,7 +304,7 @@ void t2_layouts(const double* T, double* Td, double* Tx, double* Ttd, int no, in
                 for (int j = 0; j < no; ++j) {
                     const double x = T[((int64_t)a * nv + b) * o2 + i * no + j];
                     const double y = T[((int64_t)b * nv + a) * o2 + i * no + j];
-                    Td[((int64_t)a * no + i) * ov + b * no + j] = x;
+                    if (Td) Td[((int64_t)a * no + i) * ov + b * no + j] = x;
                     Tx[((int64_t)a * no + j) * ov + b * no + i] = x;
                     Ttd[((int64_t)a * no + i) * ov + b * no + j] = 2.0 * x - y;
                 }

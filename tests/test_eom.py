@@ -101,6 +101,52 @@ def run_product(lib, monkeypatch):
             assert np.allclose(ee, [0.1180867117168979, 0.154376205595602])      # the literal itself, with its tolerance
 
 
+def check_apply_many(lib, monkeypatch, no, nv, k, tol):
+    """The stacked multi-vector sigma against the vector-by-vector build and against the oracle (= the reference's
+    update_singles / update_doubles, eom_ccsd.py:268-385)."""
+    from pymes_amd.device import Context
+    from pymes_amd.solver.eom_ccsd import _Sigma
+    monkeypatch.setattr(_lib, "_default", lib)
+    f, V, t1, t2 = random_case(no, nv, 91, symmetric=True)
+    Vb = oc.split_blocks(no, V)
+    rng = np.random.default_rng(92)
+    u1s = [rng.standard_normal((nv, no)) for _ in range(k)]
+    u2s = [rng.standard_normal((nv, nv, no, no)) for _ in range(k)]
+    u2s = [u + u.transpose(1, 0, 3, 2) for u in u2s]
+    ctx = Context(no, nv)
+    try:
+        for name, blk in Vb.items():
+            ctx.set_V_block(name, np.ascontiguousarray(blk))
+        sig = _Sigma(ctx, f, ctx.array(t2))
+        assert sig.many_ok
+        d1, d2 = [ctx.array(u) for u in u1s], [ctx.array(u) for u in u2s]
+        many = sig.apply_many(d1, d2)
+        for z in range(k):
+            s1, s2 = sig.apply(d1[z], d2[z])
+            r1, r2 = eo.sigma_singles(no, f, Vb, u1s[z], u2s[z], t2), eo.sigma_doubles(no, f, Vb, u1s[z], u2s[z], t2)
+            sc = max(1.0, np.abs(r2).max())
+            assert np.abs(many[z][0].get() - r1).max() < tol * sc and np.abs(many[z][1].get() - r2).max() < tol * sc, z
+            assert np.abs(many[z][0].get() - s1.get()).max() < tol * sc and np.abs(many[z][1].get() - s2.get()).max() < tol * sc
+        # a vector without the exchange symmetry in the batch: everything goes vector by vector, same numbers
+        u2s[1][0, 1, 0, 1] += 0.5
+        d2[1] = ctx.array(u2s[1])
+        mixed = sig.apply_many(d1, d2)
+        r2 = eo.sigma_doubles(no, f, Vb, u1s[1], u2s[1], t2)
+        assert np.abs(mixed[1][1].get() - r2).max() < tol * max(1.0, np.abs(r2).max())
+    finally:
+        ctx.close()
+
+
+def test_apply_many_host_logic(hostsim_lib, monkeypatch):
+    check_apply_many(hostsim_lib, monkeypatch, 3, 5, 3, 1e-11)
+
+
+@pytest.mark.gpu
+def test_apply_many_gpu(gpu_lib, monkeypatch):
+    check_apply_many(gpu_lib, monkeypatch, 3, 5, 3, 1e-11)
+    check_apply_many(gpu_lib, monkeypatch, 6, 17, 4, 1e-10)
+
+
 def test_product_host_logic(hostsim_lib, monkeypatch):
     run_product(hostsim_lib, monkeypatch)
 

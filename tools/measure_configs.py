@@ -48,6 +48,18 @@ def c2(args):
     flops = reference_flops(no, nv)
     out = {"config": "C2 CCSD iteration, synthetic (nocc=20, nvirt=80, scale 0.15)", "gpu_s": dt,
            "reference_algorithmic_flops": flops, "algorithmic_tflops": flops / dt / 1e12}
+    # the whole golden solve of tests/golden/solves.json["syn_20_80"] (the reference itself: 9 iterations, 706 s in the
+    # build container): integrals from the factors, set-up, iterations to delta_e = 1e-10, amplitudes back on the host
+    ints.ctx.close()
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                                       "solves.json")))["syn_20_80"]["ccsd"]
+    t0 = time.perf_counter()
+    ints = DeviceIntegrals.from_factors(no, B)
+    s2 = CCSD(no, delta_e=gold["delta_e"])
+    res = quiet(s2.solve, np.diag(eps), ints)
+    out["golden_solve"] = {"gpu_wall_s": time.perf_counter() - t0, "iterations": s2.iterations, "energy": res["ccsd e"],
+                           "energy_minus_reference": res["ccsd e"] - gold["e"],
+                           "reference_wall_s": gold.get("reference_seconds"), "reference_iterations": gold["iterations"]}
     if not args.skip_cpu:
         from oracle import cc_oracle as oc
         from oracle.cases import synthetic_case
@@ -157,6 +169,30 @@ def c5(args):
                         "all_gemm": {"achieved": tf(prof), "frac": tf(prof) / peak, "ms_per_sigma": prof["ms"] / reps,
                                      "calls_per_sigma": prof["launches"] / reps,
                                      "executed_flops_per_sigma": prof["flops"] / reps}}}
+    # multi-vector build (what the Davidson driver calls): k symmetric vectors stacked, per-vector time
+    kvec = 4
+    u1s = [ctx.array(rng.standard_normal((nv, no))) for _ in range(kvec)]
+    u2s = []
+    for _ in range(kvec):
+        h = rng.standard_normal((nv, nv, no, no))
+        u2s.append(ctx.array(h + h.transpose(1, 0, 3, 2)))
+    del h
+    syms = [True] * kvec
+    dtk = timed(lambda: sig.apply_many(u1s, u2s, syms), ctx.sync, 5)
+    ctx.stats(reset=True)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    for _ in range(reps):
+        sig.apply_many(u1s, u2s, syms)
+    ctx.sync()
+    profk, dmak = ctx.prof_query(), ctx.prof_query(kernel_class=1)
+    ctx.prof_enable(False)
+    out["multi_vector"] = {"k": kvec, "gpu_s_per_vector": dtk / kvec, "many_ok": bool(sig.many_ok),
+                           "roofline": {"achieved": tf(dmak), "frac": tf(dmak) / peak, "ms_per_vector": dmak["ms"] / reps / kvec,
+                                        "all_gemm": {"achieved": tf(profk), "frac": tf(profk) / peak,
+                                                     "ms_per_vector": profk["ms"] / reps / kvec,
+                                                     "calls_per_build": profk["launches"] / reps,
+                                                     "executed_flops_per_vector": profk["flops"] / reps / kvec}}}
     if not args.skip_cpu:
         from oracle import eom_oracle as eo, cc_oracle as oc
         from oracle.cases import synthetic_case
