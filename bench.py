@@ -139,7 +139,7 @@ def main():
     ap.add_argument("--events", choices=("auto", "timed", "separate"), default="auto",
                     help="where the per-GEMM HIP events of `roofline` are taken: inside the timed steps (eager launches), "
                          "or in a separate pass after them so that the timed steps can replay the launch graph; auto = "
-                         "separate for small single-rank problems (nocc*nvirt <= 4000, the launch-bound regime)")
+                         "separate for a single rank, timed for one process per GPU")
     ap.add_argument("--backend", default=os.environ.get("PYMES_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend; 'gloo' lets several ranks share one GPU in test rigs")
     ap.add_argument("--collective-timeout-s", type=float, default=300.0,
@@ -209,6 +209,12 @@ def main():
     ctx = ints.ctx
     ctx.sync()
     t_build = time.time() - t0
+    if not pdist.sharded():
+        # single rank: the engine works on a non-default stream that torch knows too, so that the per-phase events of
+        # pymes_amd.dist.trace (torch.cuda.Event) are recorded on the stream the kernels run on
+        engine_stream = torch.cuda.Stream(device=local)
+        ctx.set_stream(engine_stream.cuda_stream)
+        pdist.trace.stream = engine_stream
     del B
     f = np.diag(eps)
     solver = CCSD(no, is_dcsd=args.dcsd, is_diis=not args.no_diis, device=local)
@@ -238,12 +244,14 @@ def main():
             torch.cuda.synchronize()
 
     sharded_run = pdist.sharded()
-    separate = args.events == "separate" or (args.events == "auto" and world == 1 and no * nv <= 4000 and
-                                             not sharded_run)
+    # auto: a single rank times the loop body as the solver runs it (residual part replayed as a launch graph: one launch
+    # instead of ~130, so the figure does not depend on how fast this box's host happens to enqueue) and takes the per-GEMM
+    # events in a second, eager pass over the same number of steps
+    separate = args.events == "separate" or (args.events == "auto" and world == 1 and not sharded_run)
     if separate:          # the launch graph of a variant is recorded on its second pass: keep that out of the timed steps
         for _ in range(max(0, 3 - args.warmup)):
             step()
-    pdist.trace.enable(sharded_run)
+    pdist.trace.enable(True)
     ctx.stats(reset=True)
     ctx.prof_enable(not separate)
     ctx.prof_reset()
@@ -254,6 +262,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     timed_energy = energies[-1]
+    phases, collectives = pdist.trace.summary(args.steps)      # of the timed steps only
+    pdist.trace.on = False
     replayed = bool(st.get("graph") is not None and separate)
     if separate:        # the same number of steps again, eagerly, with one event pair per GEMM call
         ctx.stats(reset=True)
@@ -262,8 +272,6 @@ def main():
         for _ in range(args.steps):
             step()
         fence()
-    phases, collectives = pdist.trace.summary(args.steps) if sharded_run else ({}, {})
-    pdist.trace.on = False
     prof = ctx.prof_query()
     prof_dma = ctx.prof_query(kernel_class=1)
     stats = ctx.stats()
@@ -321,7 +329,10 @@ def main():
                           "integral_build_s": t_build, "setup_s": t_setup,
                           "first_passes_extra_s": max(0.0, t_warm - args.warmup * s_per_step) if args.warmup else None,
                           "workspace_high_water_gb": high / 1e9,
-                          "launch_graph_replay": replayed, "last_energy": timed_energy},
+                          "launch_graph_replay": replayed, "last_energy": timed_energy,
+                          # device time between phase marks (HIP events on the engine's stream) and host wall time between
+                          # the same marks: a phase whose host time is close to its device time waited for the host
+                          "phases_ms": phases, "phases_host_ms": getattr(pdist.trace, "host_ms", {})},
         }
         if sharded_run:
             # rank 0's view of the sharded iteration: device time per phase (HIP events on the stream the kernels and the

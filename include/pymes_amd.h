@@ -303,6 +303,10 @@ int pymes_dots_var(pymes_ctx* ctx, int npairs, const double* const* x_dev, const
 /* out = sum_k c[k]*x[k], nx <= 8 */
 int pymes_lincomb(pymes_ctx* ctx, double* out_dev, int nx, const double* const* x_dev, const double* c_host,
                   int64_t n);
+/* (yr + i yi)[e] = (mr + i mi)[e] (xr + i xi)[e], e < n: a complex diagonal applied to a complex vector held as two real
+ * arrays (y may alias x) — the preconditioner 1 / (z - diag + 0.01) of the FEAST linear solves, feast_eom_ccsd.py:342-343. */
+int pymes_cmul(pymes_ctx* ctx, const double* mr_dev, const double* mi_dev, const double* xr_dev, const double* xi_dev,
+               double* yr_dev, double* yi_dev, int64_t n);
 
 /* pymes/mean_field/hf.py:14-18 from the context's device blocks: f = h + 2 V_piqi - V_piiq (i occupied); h, f [n,n] host */
 int pymes_hf_fock_matrix(pymes_ctx* ctx, const double* h_host, double* f_host);

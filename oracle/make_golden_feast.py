@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Pin oracle/feast_oracle.py against the reference's FEAST-EOM-CCSD driver (pymes/solver/feast_eom_ccsd.py:72-181) and
+write tests/golden/feast.json.  BUILD CONTAINER ONLY:
+
+    PYTHONPATH=/root/reference:/root/repo python oracle/make_golden_feast.py
+
+The reference's driver does not run against the scipy of this image (1.15.3) as it stands: (1) its ``LinearOperator`` is
+created without ``dtype`` (:341), scipy then probes the operator with an int8 zero vector and the in-place ``+=`` of
+``update_singles`` (eom_ccsd.py:288) refuses the cast; (2) it passes ``tol=`` to ``gcrotmk`` (:344), a keyword scipy 1.14
+removed in favour of ``rtol=``.  Both are API drift of the third-party dependency, not part of the algorithm; this script
+wraps exactly those two scipy entry points (nothing of the reference is touched or copied) and runs the reference's own
+``solve``.  Its starting vectors come from the global ``np.random.rand`` (:90-91), so ``np.random.seed`` right before
+``solve`` makes the run reproducible; the oracle and the product draw the same numbers the same way.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+"""
+import contextlib
+import io
+import json
+import os
+import re
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+import scipy.sparse.linalg as spla                                    # noqa: E402
+
+_LinearOperator, _gcrotmk = spla.LinearOperator, spla.gcrotmk
+
+
+def _linear_operator(shape, matvec=None, **kw):                       # (1) complex operator, as every caller here means it
+    kw.setdefault("dtype", complex)
+    return _LinearOperator(shape, matvec=matvec, **kw)
+
+
+def _gcrotmk_tol(A, b, x0=None, tol=None, **kw):                      # (2) tol= of scipy < 1.14 is rtol= today
+    if tol is not None:
+        kw["rtol"] = tol
+    return _gcrotmk(A, b, x0=x0, **kw)
+
+
+spla.LinearOperator, spla.gcrotmk = _linear_operator, _gcrotmk_tol
+
+from oracle import cc_oracle as oc, feast_oracle as fo, io_oracle as oio   # noqa: E402
+from pymes.integral.partition import part_2_body_int                   # noqa: E402
+from pymes.mean_field import hf as ref_hf                               # noqa: E402
+from pymes.solver import ccsd as ref_ccsd, feast_eom_ccsd as ref_feast  # noqa: E402
+from pymes.util import fcidump as ref_fcidump                           # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+CASES = (  # tag, seed, e_c, e_r, n_trial, max_iter
+    ("LiH.sto6g", 1, 0.16, 0.05, 4, 6),
+    ("LiH.sto6g", 7, 0.15, 0.04, 3, 4),
+    ("H2.ccpvdz", 3, 0.40, 0.08, 4, 3),
+)
+
+
+def quiet(fn, *a, **k):
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        out = fn(*a, **k)
+    return out, buf.getvalue()
+
+
+def parse_history(log):
+    """'Iter = n, Eigenvalues: [...]' lines (printed for every pass that did not meet the stopping test, :174)."""
+    out = []
+    for m in re.finditer(r"Iter = \d+, Eigenvalues: \[(.*?)\]", log, flags=re.S):
+        out.append([complex(tok.replace(" ", "")) for tok in re.findall(r"[-+]?[0-9.eE+-]+\s*[-+][0-9.eE+-]+j", m.group(1))])
+    return out
+
+
+def ground_state(tag):
+    (ne, n, ec, eps, h, V), _ = quiet(ref_fcidump.read, os.path.join(GOLD, "fcidump", "FCIDUMP." + tag))
+    no = ne // 2
+    f = ref_hf.construct_hf_matrix(no, h, V)
+    cc = ref_ccsd.CCSD(no)
+    cc.delta_e = 1e-12
+    res, _ = quiet(cc.solve, f, V, max_iter=200)
+    Vb = part_2_body_int(no, V)
+    return no, cc.get_T1_dressed_fock(f, res["t1"], Vb), cc.get_T1_dressed_V(res["t1"], Vb), res["t2"].copy()
+
+
+def main():
+    np.set_printoptions(precision=17, linewidth=10000)
+    out = {}
+    for tag, seed, e_c, e_r, n_trial, max_iter in CASES:
+        no, fd, Vd, t2 = ground_state(tag)
+        t0 = time.time()
+        s = ref_feast.FEAST_EOM_CCSD(no, e_c=e_c, e_r=e_r, n_trial=n_trial, max_iter=max_iter)
+        np.random.seed(seed)
+        ev, log = quiet(s.solve, fd, Vd, t2)
+        t_ref = time.time() - t0
+        hist = parse_history(log)
+        np.random.seed(seed)
+        o = fo.feast_solve(no, fd, Vd, t2, e_c=e_c, e_r=e_r, n_trial=n_trial, max_iter=max_iter)
+        assert len(o["history"]) >= len(hist)
+        for a, b in zip(hist, o["history"]):
+            assert len(a) == len(b) and np.abs(np.array(a) - np.array(b)).max() < 1e-9, (tag, a, b)
+        err = float(np.abs(np.asarray(ev) - np.asarray(o["eigvals"])).max())
+        assert err < 1e-9, (tag, ev, o["eigvals"])
+        key = f"{tag}|seed{seed}"
+        out[key] = {"tag": tag, "seed": seed, "e_c": e_c, "e_r": e_r, "n_trial": n_trial, "max_iter": max_iter,
+                    "eigvals": [[float(np.real(x)), float(np.imag(x))] for x in ev],
+                    "history": [[[float(np.real(x)), float(np.imag(x))] for x in h] for h in o["history"]],
+                    "iterations": o["iterations"], "reference_seconds": t_ref, "oracle_minus_reference": err}
+        print(f"feast {key}: eigvals {np.real(ev)}  ({o['iterations']} passes, {t_ref:.0f} s) oracle == reference to {err:.1e}")
+    with open(os.path.join(GOLD, "feast.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("written")
+
+
+if __name__ == "__main__":
+    main()

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_PATH = os.path.join(_HERE, "lib", "libpymes_amd.so")
+# PYMES_AMD_LIBRARY=<path>: another build of the same library (A/B runs of kernel variants); the backend check below applies
+DEFAULT_PATH = os.environ.get("PYMES_AMD_LIBRARY") or os.path.join(_HERE, "lib", "libpymes_amd.so")
 
 c_double_p = C.POINTER(C.c_double)
 c_i64_p = C.POINTER(C.c_int64)
@@ -120,6 +121,7 @@ SIGNATURES = {
     "pymes_dots": (C.c_int, [C.c_void_p, C.c_int, c_pp, c_pp, C.c_int64, c_double_p]),
     "pymes_dots_var": (C.c_int, [C.c_void_p, C.c_int, c_pp, c_pp, c_i64_p, c_double_p]),
     "pymes_lincomb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_pp, c_double_p, C.c_int64]),
+    "pymes_cmul": (C.c_int, [C.c_void_p] * 7 + [C.c_int64]),
     "pymes_stats": (C.c_int, [C.c_void_p, C.c_int, c_i64_p, c_double_p, c_i64_p, c_double_p]),
     "pymes_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "pymes_prof_reset": (C.c_int, [C.c_void_p]),

@@ -569,6 +569,14 @@ int pymes_lincomb(pymes_ctx* ctx, double* out, int nx, const double* const* x, c
     });
 }
 
+int pymes_cmul(pymes_ctx* ctx, const double* mr, const double* mi, const double* xr, const double* xi, double* yr, double* yi,
+               int64_t n) {
+    return guarded([&] {
+        need(mr, "mr"); need(mi, "mi"); need(xr, "xr"); need(xi, "xi"); need(yr, "yr"); need(yi, "yi");
+        dev::cmul(mr, mi, xr, xi, yr, yi, n, E(ctx).stream);
+    });
+}
+
 int pymes_stats(pymes_ctx* ctx, int reset, int64_t* gemm_calls, double* gemm_flops, int64_t* permute_calls,
                 double* permute_bytes) {
     return guarded([&] {

@@ -120,6 +120,9 @@ void cc_update_to(double* t_out, double* dt, const double* t_in, const double* r
                   double shift, double delta, int no, int nv, int rank, stream_t s);
 // out = sum_k c[k] * x_k   (k < nx <= 8)
 void lincomb(double* out, int nx, const double* const* x, const double* c, int64_t n, stream_t s);
+// (yr + i yi)[e] = (mr + i mi)[e] * (xr + i xi)[e]: a complex diagonal applied to a complex vector held as two real arrays
+// (y may alias x)
+void cmul(const double* mr, const double* mi, const double* xr, const double* xi, double* yr, double* yi, int64_t n, stream_t s);
 // tau[a,b,i,j] = t2[a,b,i,j] + t1[a,i]*t1[b,j]                        (ccsd.py:462)
 void tau_build(double* tau, const double* t2, const double* t1, int no, int nv, stream_t s);
 

@@ -1096,6 +1096,16 @@ __global__ void lincomb_kernel(double* __restrict__ out, const LinPtrs p, int nx
     }
 }
 
+// diagonal preconditioner of the FEAST linear solves (feast_eom_ccsd.py:342: 1 / (z - diag + 0.01)) on a complex vector
+__global__ void cmul_kernel(const double* __restrict__ mr, const double* __restrict__ mi, const double* xr, const double* xi,
+                            double* yr, double* yi, long n) {
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const double a = xr[e], b = xi[e], c = mr[e], d = mi[e];
+        yr[e] = c * a - d * b;
+        yi[e] = c * b + d * a;
+    }
+}
+
 __global__ void tau_kernel(double* __restrict__ tau, const double* __restrict__ t2, const double* __restrict__ t1,
                            int no, int nv, long total) {
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
@@ -2367,6 +2377,12 @@ void lincomb(double* out, int nx, const double* const* x, const double* c, int64
     LinPtrs p;
     for (int i = 0; i < 8; ++i) { p.x[i] = i < nx ? x[i] : nullptr; p.c[i] = i < nx ? c[i] : 0.0; }
     hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, out, p, nx, (long)n);
+    HIP_CHECK(hipGetLastError());
+}
+
+void cmul(const double* mr, const double* mi, const double* xr, const double* xi, double* yr, double* yi, int64_t n, stream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(cmul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, mr, mi, xr, xi, yr, yi, (long)n);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -582,6 +582,12 @@ class Context:
             first = False
         return out
 
+    def cmul(self, mr, mi, xr, xi, yr, yi):
+        """(yr + i yi) = (mr + i mi) * (xr + i xi) element by element (y may alias x)."""
+        assert mr.size == mi.size == xr.size == xi.size == yr.size == yi.size
+        self.lib.call("pymes_cmul", self.handle, C.c_void_p(mr.ptr), C.c_void_p(mi.ptr), C.c_void_p(xr.ptr), C.c_void_p(xi.ptr),
+                      C.c_void_p(yr.ptr), C.c_void_p(yi.ptr), xr.size)
+
     # ---- measurement --------------------------------------------------------------------
     def stats(self, reset=False):
         gc, pc, gf, pb = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()

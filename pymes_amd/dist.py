@@ -46,13 +46,15 @@ class Trace:
         self.on = bool(on)
         self.reset()
 
-    @staticmethod
-    def _event():
+    stream = None        # torch stream the events are recorded on (None: torch's current stream, which the engine is bound
+                         # to under torch.distributed); bench.py sets the engine's own stream for single-rank runs
+
+    def _event(self):
         import torch
         if not torch.cuda.is_available():
             return None
         ev = torch.cuda.Event(enable_timing=True)
-        ev.record(torch.cuda.current_stream())
+        ev.record(self.stream if self.stream is not None else torch.cuda.current_stream())
         return ev
 
     def mark(self, name):

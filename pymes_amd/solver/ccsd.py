@@ -169,7 +169,10 @@ class CCSD(ccd.CCD):
     def _iterate_single(self, st):
         ctx, t1, t2, r1, r2 = st["ctx"], st["t1"], st["t2"], st["r1"], st["r2"]
         shift = st["level_shift"]
+        mark = pdist.trace.mark          # device and host time per phase when bench.py asks for it (no-ops otherwise)
+        mark("begin")
         ccd.run_replayable(ctx, st, lambda: self._residuals(st), key="t1=0" if st["t1_zero"] else "t1")
+        mark("residuals (dressing, R1, R2)")
         if self.is_diis:
             # the DIIS history keeps the updated amplitudes (:176-183); the extrapolation goes back into the fixed buffers
             t1n, t2n, dt1, dt2 = (ctx.pool_get(t1.shape), ctx.pool_get(t2.shape), ctx.pool_get(t1.shape),
@@ -184,9 +187,12 @@ class CCSD(ccd.CCD):
             np.copyto(st["amps"][0], t1n.get())     # the reference updates the caller's arrays in place
             np.copyto(st["amps"][1], t2n.get())
         st["first"] = False
+        mark("update")
         if self.is_diis:
             self.mixer.mix([dt1, dt2], [t1n, t2n], release=ctx.pool_put, out=[t1, t2])    # :181-183
+        mark("DIIS (overlaps: host sync, extrapolation)")
         e1, ed, ex, nt2, nr2, n1 = ctx.energy_norms(st["f"], t1, t2, dt2)             # :189-197, one pass
+        mark("energy + norms (host sync)")
         st["t1_zero"] = bool(n1 == 0.0) and not os.environ.get("PYMES_NO_T1_SHORTCUT")
         return e1, ed, ex, np.sqrt(nt2), np.sqrt(nr2)
 

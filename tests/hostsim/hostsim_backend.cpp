@@ -220,6 +220,14 @@ void lincomb(double* out, int nx, const double* const* x, const double* c, int64
     }
 }
 
+void cmul(const double* mr, const double* mi, const double* xr, const double* xi, double* yr, double* yi, int64_t n, stream_t) {
+    for (int64_t e = 0; e < n; ++e) {
+        const double a = xr[e], b = xi[e];
+        yr[e] = mr[e] * a - mi[e] * b;
+        yi[e] = mr[e] * b + mi[e] * a;
+    }
+}
+
 void tau_build(double* tau, const double* t2, const double* t1, int no, int nv, stream_t) {
     int64_t idx = 0;
     for (int a = 0; a < nv; ++a)
