@@ -72,12 +72,26 @@ int pymes_ctx_set_stream(pymes_ctx* ctx, void* s) {
     return guarded([&] {
         Engine& e = E(ctx);
         if (e.capturing()) throw pymes::Error("set_stream while a launch graph is being recorded");
+        e.side_join();
         dev::stream_sync(e.stream);       // work already enqueued on the old stream is complete before the switch
         e.set_stream(s);
     });
 }
 int pymes_ctx_sync(pymes_ctx* ctx) {
-    return guarded([&] { dev::stream_sync(E(ctx).stream); });
+    return guarded([&] {
+        Engine& e = E(ctx);
+        e.side_join();
+        dev::stream_sync(e.stream);
+    });
+}
+int pymes_side_begin(pymes_ctx* ctx) {
+    return guarded([&] { E(ctx).side_begin(); });
+}
+int pymes_side_end(pymes_ctx* ctx) {
+    return guarded([&] { E(ctx).side_end(); });
+}
+int pymes_side_join(pymes_ctx* ctx) {
+    return guarded([&] { E(ctx).side_join(); });
 }
 int pymes_ctx_workspace(pymes_ctx* ctx, uint64_t* cap, uint64_t* high) {
     return guarded([&] {

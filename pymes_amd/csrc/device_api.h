@@ -30,6 +30,13 @@ stream_t stream_create();
 void  stream_destroy(stream_t s);
 // device allocations made through dmalloc and not yet released (leak accounting in the tests)
 int64_t live_allocations();
+// cross-stream ordering (the engine's side stream, engine.h): `stream_wait_event(s, e)` makes work enqueued on s later wait
+// for what had been enqueued on the recording stream when e was recorded.  No-ops in the host simulator (one thread).
+typedef void* event_t;
+event_t event_create();
+void  event_destroy(event_t e);
+void  event_record(event_t e, stream_t s);
+void  stream_wait_event(stream_t s, event_t e);
 
 // ---- launch graphs: the launch-bound inner loop of a small problem is captured once and replayed -------------------
 // graph_begin puts the stream into capture mode (work enqueued until graph_end is recorded, not executed);

@@ -126,6 +126,14 @@ Engine::~Engine() {
         for (auto& p : Vd_) dev::dfree(p);
         for (auto& kv : static_) dev::dfree(kv.second);
         dev::dfree(splitk_ws_);
+        if (side_.stream) {
+            dev::stream_sync(side_.stream);
+            dev::dfree(side_.splitk);
+            side_.arena.release();
+            dev::event_destroy(side_.fork);
+            dev::event_destroy(side_.done);
+            dev::stream_destroy(side_.stream);
+        }
         dev::dfree(lpack_.Vp);
         dev::dfree(lpack_.Vm);
         dev::dfree(eps_o);
@@ -134,6 +142,39 @@ Engine::~Engine() {
         dev::stream_destroy(own_stream_);
     } catch (...) {
     }
+}
+
+void Engine::side_begin() {
+    if (side_.active) throw Error("side_begin: a side section is already open");
+    side_join();                                    // one side section in flight at a time
+    if (!side_.stream) {
+        side_.stream = dev::stream_create();
+        side_.arena.init(arena.capacity() / 2);
+        side_.splitk = static_cast<double*>(dev::dmalloc(sizeof(double) * splitk_doubles_));
+        side_.fork = dev::event_create();
+        side_.done = dev::event_create();
+    }
+    dev::event_record(side_.fork, stream);
+    dev::stream_wait_event(side_.stream, side_.fork);
+    std::swap(stream, side_.stream);
+    std::swap(arena, side_.arena);
+    std::swap(splitk_ws_, side_.splitk);
+    side_.active = true;
+}
+void Engine::side_end() {
+    if (!side_.active) throw Error("side_end: no side section is open");
+    dev::event_record(side_.done, stream);          // (stream is the side stream here)
+    std::swap(stream, side_.stream);
+    std::swap(arena, side_.arena);
+    std::swap(splitk_ws_, side_.splitk);
+    side_.active = false;
+    side_.pending = true;
+}
+void Engine::side_join() {
+    if (side_.active) throw Error("side_join inside a side section");
+    if (!side_.pending) return;
+    dev::stream_wait_event(stream, side_.done);
+    side_.pending = false;
 }
 
 void* Engine::user_malloc(size_t bytes) {
@@ -227,6 +268,7 @@ bool Engine::has_block(int pattern, bool dressed) const {
     return (dressed ? Vd_[pattern & 15] : V_[pattern & 15]) != nullptr;
 }
 TView Engine::block(int pattern, bool dressed) {
+    if (dressed && side_.pending && !side_.active) side_join();      // the dressing may have run on the side stream
     double* p = dressed ? Vd_[pattern & 15] : V_[pattern & 15];
     if (!p)
         throw Error(std::string(dressed ? "dressed" : "undressed") + " integral block '" + canonical_name(pattern) +

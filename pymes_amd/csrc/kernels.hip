@@ -1970,6 +1970,17 @@ void stream_destroy(stream_t s) {
     if (s) HIP_CHECK(hipStreamDestroy((hipStream_t)s));
 }
 
+event_t event_create() {
+    hipEvent_t e = nullptr;
+    HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return (event_t)e;
+}
+void event_destroy(event_t e) {
+    if (e) HIP_CHECK(hipEventDestroy((hipEvent_t)e));
+}
+void event_record(event_t e, stream_t s) { HIP_CHECK(hipEventRecord((hipEvent_t)e, (hipStream_t)s)); }
+void stream_wait_event(stream_t s, event_t e) { HIP_CHECK(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)e, 0)); }
+
 bool graphs_supported() { return true; }
 void graph_begin(stream_t s) {
     if (!s) throw std::runtime_error("graph capture needs a stream of its own (not the default stream)");

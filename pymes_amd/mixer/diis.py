@@ -10,6 +10,26 @@ import numpy as np
 
 from pymes_amd.log import print_logging_info
 
+_blas_threads = None
+
+
+def _single_threaded_blas():
+    """Context manager: the host BLAS / LAPACK runs the (<= 7) x (<= 7) algebra below on one thread.  A GPU node shows
+    hundreds of cores to OpenBLAS while the process may own a small share of them; waking that pool for a 7 x 7 matrix
+    costs more than the solve and — measured — leaves the GPU idle for milliseconds between the overlaps and the
+    extrapolation."""
+    global _blas_threads
+    if _blas_threads is None:
+        try:
+            from threadpoolctl import ThreadpoolController
+            _blas_threads = ThreadpoolController()
+        except Exception:          # not installed: run as numpy is configured
+            _blas_threads = False
+    if _blas_threads is False:
+        import contextlib
+        return contextlib.nullcontext()
+    return _blas_threads.limit(limits=1, user_api="blas")
+
 
 class DIIS:
     def __init__(self, dim_space=5):
@@ -89,6 +109,10 @@ class DIIS:
         self.L = L.copy()
 
     def _solve(self):
+        with _single_threaded_blas():
+            return self._solve_on_this_thread()
+
+    def _solve_on_this_thread(self):
         unit = np.zeros(self.L.shape[0])
         unit[-1] = -1.0
         lam, vec = np.linalg.eigh(self.L)
@@ -98,7 +122,7 @@ class DIIS:
             return np.dot(vec[:, ok] * (1.0 / lam[ok]), np.dot(vec[:, ok].T.conj(), unit))
         return np.linalg.inv(self.L).dot(unit)
 
-    def mix(self, error, amplitude, release=None, sharded=(), allreduce=None, out=None):
+    def mix(self, error, amplitude, release=None, sharded=(), allreduce=None, out=None, mark=None):
         """error / amplitude: lists of DeviceArray (one entry per amplitude type).
         Returns freshly allocated DeviceArrays with the extrapolated amplitudes.  The
         mixer keeps references to the arrays passed in (like the reference): the caller must
@@ -127,9 +151,13 @@ class DIIS:
         for nt in range(ntypes):
             part = parts[nt * m:(nt + 1) * m]
             overlaps += allreduce(part) if nt in sharded else part
+        if mark is not None:
+            mark("DIIS overlaps (reduction + host sync)")
         self._update_L(overlaps, was_full)
         c = self._solve()
         self.last_coefficients = c
+        if mark is not None:
+            mark("DIIS host solve")
         res = []
         for nt in range(ntypes):
             dst = out[nt] if out is not None else ctx.pool_get(amplitude[nt].shape)

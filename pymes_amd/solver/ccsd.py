@@ -127,6 +127,11 @@ class CCSD(ccd.CCD):
             if not self.is_diis:
                 st["dt1"], st["dt2"] = ctx.pool_get(t1.shape), ctx.pool_get(t2.shape)
             st["graph"], st["eager_passes"] = None, 0
+            st["eager_passes_of"] = {}
+            # side-stream overlap of the T1 dressing with the ladders: worth it when the ladders are long (PYMES_OVERLAP=0/1
+            # overrides; small problems are latency-bound and gain nothing from a second stream)
+            env = os.environ.get("PYMES_OVERLAP")
+            st["overlap"] = env == "1" or (env is None and ctx.lib.backend.startswith("hip") and no * nv >= 2000)
             # T1 starts at zero (MP2) unless the caller brought amplitudes
             st["t1_zero"] = amps is None and not os.environ.get("PYMES_NO_T1_SHORTCUT")
             st["graph_ok"] = ctx.graphs_supported() and not os.environ.get("PYMES_NO_GRAPH")
@@ -147,6 +152,22 @@ class CCSD(ccd.CCD):
             ctx.residual_slab(st["f"], t2, st["ETd"], st["ETx"], st["L"], 0, 1, is_dcd=self.is_dcd)          # :171
             ctx.singles_residual_partial(st["f"], t1, t2, r1, 0, 1, reuse_layouts=True)                      # :167
             ctx.residual_finish(st["f"], t2, st["ETd"], st["ETx"], st["L"], r2, is_dcd=self.is_dcd, reuse_layouts=True)
+            return
+        if st["sym"] and st.get("overlap") and st["eager_passes_of"].get("t1", 0) >= 1:
+            # The T1 dressing (:163, :165: streaming passes over the o v^3 blocks, HBM-bound) on the context's side stream,
+            # next to the particle ladders and Q_kb (MFMA-bound, from undressed integrals and tau = T2 + T1 T1): the main
+            # stream waits for the dressed blocks only where the hole ladder reads V~_klij (implicit join) and before the
+            # ring products.  Not in the first pass of a solve, which still builds its per-solve statics on the main stream.
+            with ctx.side():
+                ctx.dress_fock(st["f"], t1, st["fd"])                                 # :163
+                ctx.dress_V(t1, ("klij", "iajb", "iabj"))                             # :165
+            slab = dict(is_dcd=self.is_dcd, dressed=True, t1=t1, QK=st["QK"])
+            ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], 0, 1, part="ladders", **slab)   # :171, ladders
+            ctx.side_join()
+            ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], 0, 1, part="rings", **slab)     # :171, rings
+            ctx.singles_residual_partial(st["fd"], t1, t2, r1, 0, 1, reuse_layouts=True)      # :167
+            ctx.residual_finish(st["fd"], t2, st["ETd"], st["ETx"], st["L"], r2, is_dcd=self.is_dcd, dressed=True,
+                                t1=t1, QK=st["QK"], reuse_layouts=True)
             return
         ctx.dress_fock(st["f"], t1, st["fd"])                                         # :163
         if st["sym"]:
@@ -189,8 +210,8 @@ class CCSD(ccd.CCD):
         st["first"] = False
         mark("update")
         if self.is_diis:
-            self.mixer.mix([dt1, dt2], [t1n, t2n], release=ctx.pool_put, out=[t1, t2])    # :181-183
-        mark("DIIS (overlaps: host sync, extrapolation)")
+            self.mixer.mix([dt1, dt2], [t1n, t2n], release=ctx.pool_put, out=[t1, t2], mark=mark)    # :181-183
+        mark("DIIS extrapolation")
         e1, ed, ex, nt2, nr2, n1 = ctx.energy_norms(st["f"], t1, t2, dt2)             # :189-197, one pass
         mark("energy + norms (host sync)")
         st["t1_zero"] = bool(n1 == 0.0) and not os.environ.get("PYMES_NO_T1_SHORTCUT")
@@ -338,8 +359,8 @@ class CCSD(ccd.CCD):
         pdist.trace.mark("finish + assembly (pairs), update")
         if self.is_diis:
             t1, tc = self.mixer.mix([dt1, dtc], [t1, tc], release=ctx.pool_put, sharded=(1,),
-                                    allreduce=pdist.allreduce_sum)                    # :181-183
-        pdist.trace.mark("DIIS")
+                                    allreduce=pdist.allreduce_sum, mark=pdist.trace.mark)        # :181-183
+        pdist.trace.mark("DIIS extrapolation")
         lo, hi = pdist.slab_rows(st["npp"], rank, world)
         if hi > lo:
             mine = DeviceArray(ctx, st["Tall"].ptr + 8 * lo * 2 * ctx.no * ctx.no, (hi - lo, 2, ctx.no * ctx.no),

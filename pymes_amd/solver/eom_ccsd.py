@@ -19,6 +19,7 @@ import numpy as np
 from pymes_amd.device import Context, DeviceArray
 from pymes_amd.integral.partition import BLOCK_NAMES
 from pymes_amd.log import print_logging_info, print_title
+from pymes_amd.mixer.diis import _single_threaded_blas
 
 
 class _Sigma:
@@ -377,7 +378,8 @@ class EOM_CCSD:
                 for l in range(dim):                                             # :103-109
                     B[:, l] = ctx.dots(us, [ws[l]] * dim)
                 e_old = self.e_excit                                             # :110 (every pass, so the collapse
-                lam, vec = np.linalg.eig(B)                                      # :112  branch's restore is a no-op)
+                with _single_threaded_blas():                                    # (a <= 12 x 12 matrix: no thread pool)
+                    lam, vec = np.linalg.eig(B)                                  # :112  branch's restore is a no-op)
                 pick = lam.argsort()[:self.n_excit]
                 e_imag = np.imag(lam[pick])
                 e = np.real(lam[pick])

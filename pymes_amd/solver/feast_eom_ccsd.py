@@ -28,6 +28,7 @@ from scipy.linalg import eig, lstsq, qr_insert
 
 from pymes_amd.device import DeviceArray
 from pymes_amd.log import print_logging_info, print_title
+from pymes_amd.mixer.diis import _single_threaded_blas
 from pymes_amd.solver.eom_ccsd import EOM_CCSD, _Sigma
 
 
@@ -109,7 +110,8 @@ class FEAST_EOM_CCSD(EOM_CCSD):
         c = ops.c
         parts = lambda v: (EOM_CCSD._part(c, v, 0, shapes[0]), EOM_CCSD._part(c, v, n1, shapes[1]))
         (r1, r2), (i1, i2) = parts(x.re), parts(x.im)
-        (sr1, sr2), (si1, si2) = sig.apply_many([r1, i1], [r2, i2])
+        # (random trial vectors have no exchange symmetry, and neither have their Krylov iterates: the general sigma form)
+        (sr1, sr2), (si1, si2) = sig.apply_many([r1, i1], [r2, i2], syms=[False, False])
         zr, zi = float(np.real(ze)), float(np.imag(ze))
         y = _CVec(c.empty((ops.n,)), c.empty((ops.n,)))
         (yr1, yr2), (yi1, yi2) = parts(y.re), parts(y.im)
@@ -154,13 +156,15 @@ class FEAST_EOM_CCSD(EOM_CCSD):
             Q2[j + 1, j + 1] = 1
             R2 = np.zeros((j + 2, j), dtype=complex, order="F")
             R2[:j + 1, :] = R
-            Q, R = qr_insert(Q2, R2, hcur, j, which="col", overwrite_qru=True, check_finite=False)
+            with _single_threaded_blas():
+                Q, R = qr_insert(Q2, R2, hcur, j, which="col", overwrite_qru=True, check_finite=False)
             res = abs(Q[0, -1])
             if res < atol or breakdown:
                 break
         if not np.isfinite(R[j, j]):
             raise np.linalg.LinAlgError()
-        y, _, _, _ = lstsq(R[:j + 1, :j + 1], Q[0, :j + 1].conj())
+        with _single_threaded_blas():
+            y, _, _, _ = lstsq(R[:j + 1, :j + 1], Q[0, :j + 1].conj())
         return Q, R, B[:, :j + 1], vs, zs, y, res
 
     def _gcrotmk_device(self, ops, matvec, psolve, b, rtol=1e-4, maxiter=20, m=20, k=None):
@@ -290,7 +294,7 @@ class FEAST_EOM_CCSD(EOM_CCSD):
                         ctx.lincomb(Qs[l], [Qs[l], qe.re, qe.im], [1.0, -w[e] / 2 * ph.real, w[e] / 2 * ph.imag])
                 # projected problem (:124-149): H[i,j] = <Q_i, H̄ Q_j>, B[i,j] = <Q_i, Q_j>
                 part = lambda v: (self._part(ctx, v, 0, shapes[0]), self._part(ctx, v, n1, shapes[1]))
-                sigmas = sig.apply_many([part(q)[0] for q in Qs], [part(q)[1] for q in Qs])
+                sigmas = sig.apply_many([part(q)[0] for q in Qs], [part(q)[1] for q in Qs], syms=[False] * m)
                 Ws = []
                 for s1, s2 in sigmas:
                     wv = ctx.empty((n,))
@@ -303,7 +307,8 @@ class FEAST_EOM_CCSD(EOM_CCSD):
                     H[:, j] = ctx.dots(Qs, [Ws[j]] * m)
                     Bm[j:, j] = ctx.dots(Qs[j:], [Qs[j]] * (m - j))
                 Bm = np.tril(Bm) + np.tril(Bm, -1).T
-                self.eigvals, self.eigvecs = eig(H, Bm)
+                with _single_threaded_blas():
+                    self.eigvals, self.eigvecs = eig(H, Bm)
                 self.history.append(np.array(self.eigvals))
                 vr = np.real(self.eigvecs)
                 if m < self.n_trial:                                               # :152-160

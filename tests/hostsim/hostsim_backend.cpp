@@ -36,6 +36,10 @@ void dfree(void* p) {
 int64_t live_allocations() { return g_live; }
 stream_t stream_create() { return nullptr; }
 void stream_destroy(stream_t) {}
+event_t event_create() { return nullptr; }
+void event_destroy(event_t) {}
+void event_record(event_t, stream_t) {}
+void stream_wait_event(stream_t, event_t) {}
 // no launch graphs on the host: the solvers run their loop body eagerly
 bool graphs_supported() { return false; }
 void graph_begin(stream_t) { throw std::runtime_error("hostsim: no launch graphs"); }
