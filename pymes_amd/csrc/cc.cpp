@@ -20,6 +20,10 @@
 namespace pymes {
 
 namespace {
+// Row pitch of the pair-packed integrals V^+- (the K-contiguous left operand of the ladder GEMMs): a multiple of 16 doubles,
+// so that every 128-byte piece the LDS-DMA fetches is one cache line (v(v+1)/2 = 20100 is not: two lines per piece).
+inline int64_t lpitch(int64_t n) { return (n + 15) & ~int64_t(15); }
+inline TView packed_rows(double* p, int64_t rows, int64_t cols) { return slice(make_view(p, {rows, lpitch(cols)}), 1, 0, cols); }
 constexpr int P_klij = 0, P_ijka = 1, P_ijak = 2, P_ijab = 3, P_iajk = 4, P_iajb = 5, P_iabj = 6, P_iabc = 7,
               P_aibc = 11, P_abij = 12, P_abic = 13, P_abci = 14, P_abcd = 15;
 }
@@ -385,11 +389,11 @@ void Engine::slab_prepare(const double* t2, double* P, int rank, int world, unsi
         xs_oo_tag_.set(t2, rank, world);       // this rank's partial sum: the singles residual takes ccsd.py:434 from it
     }
     if (!static_.count("VpIjab")) {
-        double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * npp));
-        double* vm = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * std::max<int64_t>(npm, 1)));
+        double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * lpitch(npp)));
+        double* vm = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * lpitch(std::max<int64_t>(npm, 1))));
         static_["VpIjab"] = vp;
         static_["VmIjab"] = vm;
-        dev::ladder_pack_V(block(P_ijab).p, vp, vm, no, nv, 0, opp, stream);
+        dev::ladder_pack_V(block(P_ijab).p, vp, vm, no, nv, 0, opp, stream, lpitch(npp), lpitch(std::max<int64_t>(npm, 1)));
     }
     {
         // J over the packed pairs P(c,d) in the rank's chunk (Q(c,d) for the antisymmetric part)
@@ -405,11 +409,11 @@ void Engine::slab_prepare(const double* t2, double* P, int rank, int world, unsi
         int64_t k0, k1;
         cut(npp, k0, k1);
         if (k1 > k0)
-            contract(2.0, slice(make_view(static_["VpIjab"], {opp, npp}), 1, k0, k1), "rk",
+            contract(2.0, slice(packed_rows(static_["VpIjab"], opp, npp), 1, k0, k1), "rk",
                      slice(pitched(Sp, npp, opp, ldp), 0, k0, k1), "kn", 0.0, pitched(P + o * o, opp, opp, ldp), "rn");
         cut(npm, k0, k1);
         if (opm > 0 && k1 > k0)
-            contract(2.0, slice(make_view(static_["VmIjab"], {opp, npm}), 1, k0, k1), "rk",
+            contract(2.0, slice(packed_rows(static_["VmIjab"], opp, npm), 1, k0, k1), "rk",
                      slice(pitched(Am, npm, opm, ldm), 0, k0, k1), "kn", 0.0, pitched(P + o * o + opp * ldp, opp, opm, ldm), "rn");
     }
 }
@@ -518,8 +522,15 @@ void Engine::amplitude_side_abij(const double* t1, const double* QK, const TView
     TView t = make_view(const_cast<double*>(t1), {v, o});
     TView Qf = make_view(const_cast<double*>(QK), {o, v, o, o});        // Q + W, rows (k,b) plain [i][j] (ladder_t1)
     contract(-1.0, slice(t, 0, a0, a1), "ak", slice(Qf, 1, 0, b1), "kbij", 1.0, N, "abij");
+    if (!with_partner) {
+        // N is symmetrised by the caller (N_abij + N_baji, residual_assemble): instead of V_abcj t_ci, whose result has the
+        // contracted operand's index in the middle (a transposed temporary and an accumulating permutation, 2.4 GB per
+        // iteration at (50,200)), add its partner (V_bacj t_ci)_(ab)(ij swapped) = V_abic t_cj  (V_pqrs = V_qpsr), which
+        // the GEMM writes in place
+        contract(1.0, slice(slice(block(P_abic), 0, a0, a1), 1, 0, b1), "abic", t, "cj", 1.0, N, "abij");
+        return;
+    }
     contract(1.0, slice(slice(block(P_abci), 0, a0, a1), 1, 0, b1), "abcj", t, "ci", 1.0, N, "abij");
-    if (!with_partner) return;
     // the (b,a,j,i) halves for the same rows a (pair-sharded tail): -t_bk (Q+W)[k,a,j,i] and
     // (V_bacᵢ t_cj =) V_abic t_cj, the latter straight from the block with the roles of the kets exchanged
     contract(-1.0, slice(t, 0, 0, b1), "bk", slice(Qf, 1, a0, a1), "kaji", 1.0, N, "abij");
@@ -647,10 +658,10 @@ void Engine::ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1,
             dev::dfree(lpack_.Vp);
             dev::dfree(lpack_.Vm);
             lpack_.Vp = lpack_.Vm = nullptr;
-            lpack_.Vp = static_cast<double*>(dev::dmalloc(sizeof(double) * rows * npp));
-            lpack_.Vm = static_cast<double*>(dev::dmalloc(sizeof(double) * rows * std::max<int64_t>(npm, 1)));
+            lpack_.Vp = static_cast<double*>(dev::dmalloc(sizeof(double) * rows * lpitch(npp)));
+            lpack_.Vm = static_cast<double*>(dev::dmalloc(sizeof(double) * rows * lpitch(std::max<int64_t>(npm, 1))));
         }
-        dev::ladder_pack_V(block(P_abcd, dressed).p, lpack_.Vp, lpack_.Vm, nv, nv, row0, row1, stream);
+        dev::ladder_pack_V(block(P_abcd, dressed).p, lpack_.Vp, lpack_.Vm, nv, nv, row0, row1, stream, lpitch(npp), lpitch(std::max<int64_t>(npm, 1)));
         stats.permute_calls++;
         stats.permute_bytes += 8.0 * 2.0 * double(rows) * double(v * v);
         lpack_.row0 = row0; lpack_.row1 = row1; lpack_.dressed = dressed; lpack_.valid = true;
@@ -669,9 +680,9 @@ void Engine::ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1,
     TView Lrows = make_view(L + row0 * o * o, {rows, o * o});
     TView LS = slice(Lrows, 1, 0, opp), LA = slice(Lrows, 1, opp, o * o);
     TView SpT = pitched(Sp, npp, opp, ldp), AmT = pitched(Am, npm, opm, ldm);
-    contract(1.0, make_view(lpack_.Vp, {rows, npp}), "rk", SpT, "kn", 0.0, LS, "rn");
+    contract(1.0, packed_rows(lpack_.Vp, rows, npp), "rk", SpT, "kn", 0.0, LS, "rn");
     if (opm > 0) {
-        if (npm > 0) contract(1.0, make_view(lpack_.Vm, {rows, npm}), "rk", AmT, "kn", 0.0, LA, "rn");
+        if (npm > 0) contract(1.0, packed_rows(lpack_.Vm, rows, npm), "rk", AmT, "kn", 0.0, LA, "rn");
         else zero(LA);
     }
     if (!hole) return;
@@ -690,14 +701,14 @@ void Engine::ladder_sym(const double* t2, double* L, int64_t row0, int64_t row1,
     TView IpK = pitched(Ip, ldp, opp, ldp), ImK = pitched(Im, ldp, opm, ldm);        // with the zero pad row
     if (hole == 1) {
         if (!static_.count("VpIjab")) {      // static per solve: dressed ijab == undressed ijab
-            double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * npp));
-            double* vm = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * std::max<int64_t>(npm, 1)));
+            double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * lpitch(npp)));
+            double* vm = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * lpitch(std::max<int64_t>(npm, 1))));
             static_["VpIjab"] = vp;
             static_["VmIjab"] = vm;
-            dev::ladder_pack_V(block(P_ijab).p, vp, vm, no, nv, 0, opp, stream);
+            dev::ladder_pack_V(block(P_ijab).p, vp, vm, no, nv, 0, opp, stream, lpitch(npp), lpitch(std::max<int64_t>(npm, 1)));
         }
-        contract(2.0, make_view(static_["VpIjab"], {opp, npp}), "rk", SpT, "kn", 2.0, Ipv, "rn");
-        if (opm > 0 && npm > 0) contract(2.0, make_view(static_["VmIjab"], {opp, npm}), "rk", AmT, "kn", 2.0, Imv, "rn");
+        contract(2.0, packed_rows(static_["VpIjab"], opp, npp), "rk", SpT, "kn", 2.0, Ipv, "rn");
+        if (opm > 0 && npm > 0) contract(2.0, packed_rows(static_["VmIjab"], opp, npm), "rk", AmT, "kn", 2.0, Imv, "rn");
         else if (opm > 0) axpby(2.0, Imv, 0.0, Imv);
     } else {
         axpby(2.0, Ipv, 0.0, Ipv);
@@ -728,10 +739,10 @@ void Engine::ladder_sym_multi(const double* const* xs, int k, double* L_all, boo
             dev::dfree(lpack_.Vp);
             dev::dfree(lpack_.Vm);
             lpack_.Vp = lpack_.Vm = nullptr;
-            lpack_.Vp = static_cast<double*>(dev::dmalloc(sizeof(double) * npp * npp));
-            lpack_.Vm = static_cast<double*>(dev::dmalloc(sizeof(double) * npp * std::max<int64_t>(npm, 1)));
+            lpack_.Vp = static_cast<double*>(dev::dmalloc(sizeof(double) * npp * lpitch(npp)));
+            lpack_.Vm = static_cast<double*>(dev::dmalloc(sizeof(double) * npp * lpitch(std::max<int64_t>(npm, 1))));
         }
-        dev::ladder_pack_V(block(P_abcd, dressed).p, lpack_.Vp, lpack_.Vm, nv, nv, 0, npp, stream);
+        dev::ladder_pack_V(block(P_abcd, dressed).p, lpack_.Vp, lpack_.Vm, nv, nv, 0, npp, stream, lpitch(npp), lpitch(std::max<int64_t>(npm, 1)));
         stats.permute_calls++;
         stats.permute_bytes += 8.0 * 2.0 * double(npp) * double(v * v);
         lpack_.row0 = 0; lpack_.row1 = npp; lpack_.dressed = dressed; lpack_.valid = true;
@@ -747,11 +758,11 @@ void Engine::ladder_sym_multi(const double* const* xs, int k, double* L_all, boo
     stats.permute_bytes += 8.0 * 2.0 * double(k) * double(v * v * o * o);
     // operands with explicit batch strides: B_z = Sp + z sp_sz ([npp][ldp], columns 0..opp), C_z = L_all + z npp o^2
     int64_t bd[3] = {k, npp, opp}, bs[3] = {sp_sz, ldp, 1}, cd[3] = {k, npp, opp}, cs[3] = {npp * o * o, o * o, 1};
-    contract(1.0, make_view(lpack_.Vp, {npp, npp}), "rk", make_view(Sp, 3, bd, bs), "zkn", 0.0, make_view(L_all, 3, cd, cs), "zrn", "z");
+    contract(1.0, packed_rows(lpack_.Vp, npp, npp), "rk", make_view(Sp, 3, bd, bs), "zkn", 0.0, make_view(L_all, 3, cd, cs), "zrn", "z");
     if (opm > 0) {
         if (npm > 0) {
             int64_t bd2[3] = {k, npm, opm}, bs2[3] = {am_sz, ldm, 1}, cd2[3] = {k, npp, opm};
-            contract(1.0, make_view(lpack_.Vm, {npp, npm}), "rk", make_view(Am, 3, bd2, bs2), "zkn", 0.0,
+            contract(1.0, packed_rows(lpack_.Vm, npp, npm), "rk", make_view(Am, 3, bd2, bs2), "zkn", 0.0,
                      make_view(L_all + opp, 3, cd2, cs), "zrn", "z");
         } else {
             int64_t cd2[3] = {k, npp, opm};
@@ -786,19 +797,19 @@ void Engine::hole_ladder_packed(const double* x, const double* I, double* L, int
         // I += sum_cd V_klcd y_cdij, formed pair-packed as well (the V.T part of the CCSD hole ladder, ccd.py:180, with y
         // in the place of T): [opp x npp] . [npp x opp] instead of the o^2 x v^2 x o^2 product
         if (!static_.count("VpIjab")) {
-            double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * npp));
-            double* vm = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * std::max<int64_t>(npm, 1)));
+            double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * lpitch(npp)));
+            double* vm = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * lpitch(std::max<int64_t>(npm, 1))));
             static_["VpIjab"] = vp;
             static_["VmIjab"] = vm;
-            dev::ladder_pack_V(block(P_ijab).p, vp, vm, no, nv, 0, opp, stream);
+            dev::ladder_pack_V(block(P_ijab).p, vp, vm, no, nv, 0, opp, stream, lpitch(npp), lpitch(std::max<int64_t>(npm, 1)));
         }
         ArenaScope s2(arena);
         double* Sp = arena.alloc(npp * ldp);
         double* Am = arena.alloc(std::max<int64_t>(npm * ldm, 1));
         dev::ladder_pack_T(y, nullptr, Sp, Am, no, nv, dev::PACK_ROW_HALF, ldp, ldm, stream);
-        contract(2.0, make_view(static_["VpIjab"], {opp, npp}), "rk", pitched(Sp, npp, opp, ldp), "kn", 2.0, Ipv, "rn");
+        contract(2.0, packed_rows(static_["VpIjab"], opp, npp), "rk", pitched(Sp, npp, opp, ldp), "kn", 2.0, Ipv, "rn");
         if (opm > 0 && npm > 0)
-            contract(2.0, make_view(static_["VmIjab"], {opp, npm}), "rk", pitched(Am, npm, opm, ldm), "kn", 2.0, Imv, "rn");
+            contract(2.0, packed_rows(static_["VmIjab"], opp, npm), "rk", pitched(Am, npm, opm, ldm), "kn", 2.0, Imv, "rn");
         else if (opm > 0) axpby(2.0, Imv, 0.0, Imv);
     } else {
         axpby(2.0, Ipv, 0.0, Ipv);
@@ -837,26 +848,26 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
             dev::dfree(lpack_.Vp);
             dev::dfree(lpack_.Vm);
             lpack_.Vp = lpack_.Vm = nullptr;
-            lpack_.Vp = static_cast<double*>(dev::dmalloc(sizeof(double) * rows * npp));
-            lpack_.Vm = static_cast<double*>(dev::dmalloc(sizeof(double) * rows * std::max<int64_t>(npm, 1)));
+            lpack_.Vp = static_cast<double*>(dev::dmalloc(sizeof(double) * rows * lpitch(npp)));
+            lpack_.Vm = static_cast<double*>(dev::dmalloc(sizeof(double) * rows * lpitch(std::max<int64_t>(npm, 1))));
         }
-        dev::ladder_pack_V(block(P_abcd).p, lpack_.Vp, lpack_.Vm, nv, nv, row0, row1, stream);
+        dev::ladder_pack_V(block(P_abcd).p, lpack_.Vp, lpack_.Vm, nv, nv, row0, row1, stream, lpitch(npp), lpitch(std::max<int64_t>(npm, 1)));
         lpack_.row0 = row0; lpack_.row1 = row1; lpack_.dressed = false; lpack_.valid = true;
     }
     const std::string kkey = ":" + std::to_string(q0) + ":" + std::to_string(q1);
     if (qrows > 0 && !static_.count("VpK" + kkey)) {
-        double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * qrows * npp));
-        double* vm = static_cast<double*>(dev::dmalloc(sizeof(double) * qrows * std::max<int64_t>(npm, 1)));
+        double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * qrows * lpitch(npp)));
+        double* vm = static_cast<double*>(dev::dmalloc(sizeof(double) * qrows * lpitch(std::max<int64_t>(npm, 1))));
         static_["VpK" + kkey] = vp;
         static_["VmK" + kkey] = vm;
-        dev::ladder_pack_V(block(P_iabc).p, vp, vm, 0, nv, q0, q1, stream);          // rows (k,b) of V_kbcd as they are
+        dev::ladder_pack_V(block(P_iabc).p, vp, vm, 0, nv, q0, q1, stream, lpitch(npp), lpitch(std::max<int64_t>(npm, 1)));          // rows (k,b) of V_kbcd as they are
     }
     if (!static_.count("VpIjab")) {
-        double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * npp));
-        double* vm = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * std::max<int64_t>(npm, 1)));
+        double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * lpitch(npp)));
+        double* vm = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * lpitch(std::max<int64_t>(npm, 1))));
         static_["VpIjab"] = vp;
         static_["VmIjab"] = vm;
-        dev::ladder_pack_V(block(P_ijab).p, vp, vm, no, nv, 0, opp, stream);
+        dev::ladder_pack_V(block(P_ijab).p, vp, vm, no, nv, 0, opp, stream, lpitch(npp), lpitch(std::max<int64_t>(npm, 1)));
     }
     ArenaScope scope(arena);
     auto pitched = [&](double* p, int64_t r, int64_t c, int64_t ld) { return slice(make_view(p, {r, ld}), 1, 0, c); };
@@ -872,9 +883,9 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
         stats.permute_bytes += 8.0 * 2.0 * double(v * v * o * o);
         TView SpT = pitched(Sp, npp, opp, ldp), AmT = pitched(Am, npm, opm, ldm);
         if (rows > 0) {
-            contract(1.0, make_view(lpack_.Vp, {rows, npp}), "rk", SpT, "kn", 0.0, LS, "rn");
+            contract(1.0, packed_rows(lpack_.Vp, rows, npp), "rk", SpT, "kn", 0.0, LS, "rn");
             if (opm > 0) {
-                if (npm > 0) contract(1.0, make_view(lpack_.Vm, {rows, npm}), "rk", AmT, "kn", 0.0, LA, "rn");
+                if (npm > 0) contract(1.0, packed_rows(lpack_.Vm, rows, npm), "rk", AmT, "kn", 0.0, LA, "rn");
                 else zero(LA);
             }
         }
@@ -884,9 +895,9 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
             // that they are sharded with Q instead of being repeated by every rank
             TView Qp = make_view(arena.alloc(qrows * o * o), {qrows, o * o});
             TView QS = slice(Qp, 1, 0, opp), QA = slice(Qp, 1, opp, o * o);
-            contract(1.0, make_view(static_["VpK" + kkey], {qrows, npp}), "rk", SpT, "kn", 0.0, QS, "rn");
+            contract(1.0, packed_rows(static_["VpK" + kkey], qrows, npp), "rk", SpT, "kn", 0.0, QS, "rn");
             if (opm > 0) {
-                if (npm > 0) contract(1.0, make_view(static_["VmK" + kkey], {qrows, npm}), "rk", AmT, "kn", 0.0, QA, "rn");
+                if (npm > 0) contract(1.0, packed_rows(static_["VmK" + kkey], qrows, npm), "rk", AmT, "kn", 0.0, QA, "rn");
                 else zero(QA);
             }
             dev::rows_unpack(Qp.p, QK + q0 * o * o, qrows, no, stream);
@@ -933,9 +944,9 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
         double* Sp = arena.alloc(npp * ldp);
         double* Am = arena.alloc(std::max<int64_t>(npm * ldm, 1));
         dev::ladder_pack_T(t2, nullptr, Sp, Am, no, nv, dev::PACK_ROW_HALF, ldp, ldm, stream);
-        contract(2.0, make_view(static_["VpIjab"], {opp, npp}), "rk", pitched(Sp, npp, opp, ldp), "kn", bI, Ipv, "rn");
+        contract(2.0, packed_rows(static_["VpIjab"], opp, npp), "rk", pitched(Sp, npp, opp, ldp), "kn", bI, Ipv, "rn");
         if (opm > 0 && npm > 0)
-            contract(2.0, make_view(static_["VmIjab"], {opp, npm}), "rk", pitched(Am, npm, opm, ldm), "kn", bI, Imv, "rn");
+            contract(2.0, packed_rows(static_["VmIjab"], opp, npm), "rk", pitched(Am, npm, opm, ldm), "kn", bI, Imv, "rn");
         else if (opm > 0 && !dcd) axpby(2.0, Imv, 0.0, Imv);
     }
     // CCSD: rows of tau against Ifull;  DCSD: rows of t1 t1 against Ifull (rows of T were taken above)

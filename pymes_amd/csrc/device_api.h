@@ -139,7 +139,8 @@ void tau_build(double* tau, const double* t2, const double* t1, int no, int nv, 
 //   Vp[r - rp0][P(c,d)] = V[a,b,c,d] + V[a,b,d,c]
 //   Vm[r - rp0][Q(c,d)] = V[a,b,c,d] - V[a,b,d,c]   (zero row when a == b)
 // nr == 0: V is [rows,nc,nc] and the rows [rp0, rp1) are taken as they are (no zero rows in Vm).
-void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nc, int64_t rp0, int64_t rp1, stream_t s);
+void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nc, int64_t rp0, int64_t rp1, stream_t s,
+                   int64_t ldvp = 0, int64_t ldvm = 0);      // row pitches of Vp / Vm (0: nc(nc+1)/2, nc(nc-1)/2)
 // ladder_pack_T: X is [nr,nr,nc,nc]; pair (c,d) over nr, pair (i,j) over nc.
 //   Sp[P(c,d)][P(i,j)] = fr fc (X[c,d,i,j] + X[d,c,i,j]) / 2,  fr = 1/2 on c == d if PACK_ROW_HALF, fc = 1/2 on
 //   i == j if PACK_COL_HALF (a pair that is summed over carries the half on its diagonal);

@@ -488,7 +488,15 @@ void Engine::contract(double alpha, const TView& A, const char* sa, const TView&
         if (!merge_group(X, positions(g2, which), n2, s2)) return false;
         return s1 == 1 || s2 == 1 || n1 == 1 || n2 == 1;
     };
-    const double bytesA = 8.0 * A.size(), bytesB = 8.0 * B.size(), bytesC = 8.0 * C.size();
+    // a transposed copy of a whole undressed integral block is made once and kept (make_copy below): it costs next to
+    // nothing per call, so when one operand has to be copied the static one is the one to copy — not the amplitudes
+    auto kept = [&](const TView& X) {
+        for (int pat = 0; pat < 16; ++pat)
+            if (V_[pat] && X.p == V_[pat] && X.size() == block_size(pat) && is_contiguous(X)) return true;
+        return false;
+    };
+    const double bytesA = 8.0 * A.size() * (kept(A) ? 0.01 : 1.0), bytesB = 8.0 * B.size() * (kept(B) ? 0.01 : 1.0),
+                 bytesC = 8.0 * C.size();
     for (int im = 0; im < 2; ++im)
         for (int in_ = 0; in_ < 2; ++in_)
             for (int ik = 0; ik < 2; ++ik) {

@@ -1132,7 +1132,7 @@ __device__ __forceinline__ void unrank_pair(long r, int& x, int& y) {   // r = x
 
 __global__ void __launch_bounds__(256) ladder_pack_V_kernel(const double* __restrict__ V, double* __restrict__ Vp,
                                                             double* __restrict__ Vm, int nr, int nv, long rp0,
-                                                            int nt, long ntp) {
+                                                            int nt, long ntp, long npp, long npm) {     // npp, npm: row pitches
     __shared__ double sA[32][33], sB[32][33];
     const long bid = blockIdx.x;
     const long row = bid / ntp;               // local pair row
@@ -1140,7 +1140,6 @@ __global__ void __launch_bounds__(256) ladder_pack_V_kernel(const double* __rest
     int a = 1, b = 0, tc, td;
     if (nr > 0) unrank_pair(rp0 + row, a, b);
     unrank_pair(tp, tc, td);
-    const long npp = (long)nv * (nv + 1) / 2, npm = (long)nv * (nv - 1) / 2;
     const double* __restrict__ Vab = V + (nr > 0 ? (long)a * nr + b : rp0 + row) * nv * nv;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c0 = tc * 32, d0 = td * 32;
@@ -2404,14 +2403,16 @@ void tau_build(double* tau, const double* t2, const double* t1, int no, int nv, 
     HIP_CHECK(hipGetLastError());
 }
 
-void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nc, int64_t rp0, int64_t rp1, stream_t s) {
+void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nc, int64_t rp0, int64_t rp1, stream_t s, int64_t ldvp,
+                   int64_t ldvm) {
     if (rp1 <= rp0) return;
+    const long npp = ldvp ? (long)ldvp : (long)nc * (nc + 1) / 2, npm = ldvm ? (long)ldvm : (long)nc * (nc - 1) / 2;
     const int nt = (nc + 31) / 32;
     const long ntp = (long)nt * (nt + 1) / 2;
     const long nblk = (rp1 - rp0) * ntp;
     if (nblk > 0x7fffffffL) throw std::runtime_error("ladder_pack_V: grid too large");
     hipLaunchKernelGGL(ladder_pack_V_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)s, V, Vp, Vm, nr, nc,
-                       (long)rp0, nt, ntp);
+                       (long)rp0, nt, ntp, npp, npm);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -128,10 +128,10 @@ class CCSD(ccd.CCD):
                 st["dt1"], st["dt2"] = ctx.pool_get(t1.shape), ctx.pool_get(t2.shape)
             st["graph"], st["eager_passes"] = None, 0
             st["eager_passes_of"] = {}
-            # side-stream overlap of the T1 dressing with the ladders: worth it when the ladders are long (PYMES_OVERLAP=0/1
-            # overrides; small problems are latency-bound and gain nothing from a second stream)
-            env = os.environ.get("PYMES_OVERLAP")
-            st["overlap"] = env == "1" or (env is None and ctx.lib.backend.startswith("hip") and no * nv >= 2000)
+            # side-stream overlap of the T1 dressing with the ladders: opt-in (PYMES_OVERLAP=1).  Measured at (50,200): the
+            # streaming kernels take CU slots and LDS from the ladder GEMMs (92 -> 88.5 % of peak) and the iteration gets
+            # 2.5 ms slower, not faster (profiles/r03)
+            st["overlap"] = os.environ.get("PYMES_OVERLAP") == "1"
             # T1 starts at zero (MP2) unless the caller brought amplitudes
             st["t1_zero"] = amps is None and not os.environ.get("PYMES_NO_T1_SHORTCUT")
             st["graph_ok"] = ctx.graphs_supported() and not os.environ.get("PYMES_NO_GRAPH")

@@ -243,8 +243,9 @@ void tau_build(double* tau, const double* t2, const double* t1, int no, int nv, 
 static inline int64_t P2(int64_t x, int64_t y) { return x * (x + 1) / 2 + y; }
 static inline int64_t Q2(int64_t x, int64_t y) { return x * (x - 1) / 2 + y; }
 
-void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nv, int64_t rp0, int64_t rp1, stream_t) {
-    const int64_t npp = (int64_t)nv * (nv + 1) / 2, npm = (int64_t)nv * (nv - 1) / 2;
+void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nv, int64_t rp0, int64_t rp1, stream_t, int64_t ldvp,
+                   int64_t ldvm) {
+    const int64_t npp = ldvp ? ldvp : (int64_t)nv * (nv + 1) / 2, npm = ldvm ? ldvm : (int64_t)nv * (nv - 1) / 2;
     auto pack_row = [&](const double* Vab, int64_t r, bool diag) {
         for (int c = 0; c < nv; ++c)
             for (int d = 0; d <= c; ++d) {
