@@ -343,7 +343,8 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_kernel(const GemmK g) {
 //     destination of an LDS-DMA is lane-linear, so the bank-conflict fix cannot be padding: the 16-B
 //     chunk c of row r is stored at chunk slot c ^ ((r >> 1) & 7) by permuting the per-lane SOURCE address,
 //     and the fragment reads apply the same XOR (conflict-free ds_read_b64 for 16 consecutive rows).
-// The last, partial k-tile is staged through registers with zero fill.
+// The last, partial k-tile goes through the same DMA with the lanes beyond K switched off by EXEC and their LDS slots
+// zero-filled by a ds_write (stage_tail below).
 // ------------------------------------------------------------------------------------
 // wave-uniform values that the compiler computes on the VALU (64-bit divisions of the block id) are moved to
 // SGPRs explicitly, so that loop control and the LDS-DMA base addresses stay on the scalar unit
