@@ -329,8 +329,17 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
         xs_oo_tag_.set(t2, 0, 1);
         xs_vv_tag_.set(t2, 0, 1);
     }
-    contract(1.0, N1, "kn", Tx, "mk", 0.0, ETx, "nm");                                       // Ex_x = -Xc
-    contract(0.5, M, "kn", Ttd, "mk", 0.5, ETd, "nm", "", &ETx);                             // Ex_d = D-term - Xc / 2
+    if (nc == ov) {
+        // all columns on this rank: nothing is exchanged, and since only Ex + Ex^T enters R (residual_assemble) the slab
+        // need not be transposed — Ex_x = Tx N1 and Ex_d = Tt_d M / 2 + Ex_x / 2 with the K-contiguous symmetric amplitudes
+        // on the left: the same operand layout as the two builds (the LDS-DMA variant with the better L2 reuse: 6.4 GB of
+        // fetches per launch against 13.6 GB for the transposed form, profiles/r02/bench_c3_pmc_hbm_traffic.csv)
+        contract(1.0, Tx, "mk", N1, "kn", 0.0, ETx, "mn");                                   // Ex_x = -Xc
+        contract(0.5, Ttd, "mk", M, "kn", 0.5, ETd, "mn", "", &ETx);                         // Ex_d = D-term - Xc / 2
+    } else {
+        contract(1.0, N1, "kn", Tx, "mk", 0.0, ETx, "nm");                                   // (Ex_x)^T, rows = this rank's columns
+        contract(0.5, M, "kn", Ttd, "mk", 0.5, ETd, "nm", "", &ETx);                         // (Ex_d)^T
+    }
     {
         // :232  Ex[a,b,i,j] -= X_ki T[a,b,k,j]  ->  ET[(b,j),(a,i)] -= sum_k Td[(b,j),(a,k)] X_ki   (Td symmetric)
         ArenaScope s2(arena);
