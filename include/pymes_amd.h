@@ -313,6 +313,17 @@ int pymes_dots_var(pymes_ctx* ctx, int npairs, const double* const* x_dev, const
 /* out = sum_k c[k]*x[k], nx <= 8 */
 int pymes_lincomb(pymes_ctx* ctx, double* out_dev, int nx, const double* const* x_dev, const double* c_host,
                   int64_t n);
+/* One DIIS step (pymes/mixer/diis.py:40-103) with no host round trip.  state_dev: 96 doubles on the device —
+ * [0] order of L, [1..81] L (pitch 9), [82..90] coefficients of the last step, [91] 1 if the pseudo-inverse branch
+ * (diis.py:85-93) was taken, [92] steps taken; a fresh mixer starts from {1, 0, ...}.  The npairs = ntypes * m overlaps
+ * <x_p, y_p> (type-major: p = t * m + i) are reduced on the device, L is shifted / extended (including the reference's
+ * full-subspace quirk, diis.py:59-60) and L c = (0,..,0,-1) is solved by one device thread; pymes_lincomb_dev then forms
+ * sum_k c[k] x[k] with the coefficients read from state_dev + 82.  Nothing synchronises: the host reads the state
+ * (pymes_download) only when it wants to log it. */
+int pymes_diis_step(pymes_ctx* ctx, double* state_dev, int npairs, const double* const* x_dev, const double* const* y_dev,
+                    const int64_t* n, int ntypes, int m, int was_full);
+int pymes_lincomb_dev(pymes_ctx* ctx, double* out_dev, int nx, const double* const* x_dev, const double* coeff_dev,
+                      int64_t n);
 /* (yr + i yi)[e] = (mr + i mi)[e] (xr + i xi)[e], e < n: a complex diagonal applied to a complex vector held as two real
  * arrays (y may alias x) — the preconditioner 1 / (z - diag + 0.01) of the FEAST linear solves, feast_eom_ccsd.py:342-343. */
 int pymes_cmul(pymes_ctx* ctx, const double* mr_dev, const double* mi_dev, const double* xr_dev, const double* xi_dev,

@@ -583,6 +583,19 @@ int pymes_lincomb(pymes_ctx* ctx, double* out, int nx, const double* const* x, c
     });
 }
 
+int pymes_diis_step(pymes_ctx* ctx, double* state, int npairs, const double* const* x, const double* const* y, const int64_t* n,
+                    int ntypes, int m, int was_full) {
+    return guarded([&] {
+        need(state, "state"); need(x, "x"); need(y, "y"); need(n, "n");
+        dev::diis_step(state, npairs, x, y, n, ntypes, m, was_full, E(ctx).stream);
+    });
+}
+int pymes_lincomb_dev(pymes_ctx* ctx, double* out, int nx, const double* const* x, const double* coeff_dev, int64_t n) {
+    return guarded([&] {
+        need(out, "out"); need(x, "x"); need(coeff_dev, "coeff");
+        dev::lincomb_dev(out, nx, x, coeff_dev, n, E(ctx).stream);
+    });
+}
 int pymes_cmul(pymes_ctx* ctx, const double* mr, const double* mi, const double* xr, const double* xi, double* yr, double* yi,
                int64_t n) {
     return guarded([&] {

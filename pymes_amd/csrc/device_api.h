@@ -127,6 +127,12 @@ void cc_update_to(double* t_out, double* dt, const double* t_in, const double* r
                   double shift, double delta, int no, int nv, int rank, stream_t s);
 // out = sum_k c[k] * x_k   (k < nx <= 8)
 void lincomb(double* out, int nx, const double* const* x, const double* c, int64_t n, stream_t s);
+// One DIIS step without a host round trip (diis_small.h): the ntypes * m overlaps <x_p, y_p> are reduced on the device, the
+// (m+1) x (m+1) system is updated and solved by one thread, the coefficients land in state[82..]; nothing synchronises.
+void diis_step(double* state, int npairs, const double* const* x, const double* const* y, const int64_t* n, int ntypes, int m,
+               int was_full, stream_t s);
+// out = sum_k coeff[k] x[k] with the coefficients read from device memory (the output of diis_step)
+void lincomb_dev(double* out, int nx, const double* const* x, const double* coeff_dev, int64_t n, stream_t s);
 // (yr + i yi)[e] = (mr + i mi)[e] * (xr + i xi)[e]: a complex diagonal applied to a complex vector held as two real arrays
 // (y may alias x)
 void cmul(const double* mr, const double* mi, const double* xr, const double* xi, double* yr, double* yi, int64_t n, stream_t s);

@@ -1,0 +1,134 @@
+// The (<= 9) x (<= 9) algebra of one DIIS step (pymes/mixer/diis.py:40-103) as plain scalar code that compiles for the
+// device (one thread of a one-block kernel, kernels.hip) and for the host simulator: with it the overlaps never leave
+// the GPU and the extrapolation needs no host round trip — the reference does this part with numpy on the host
+// (np.linalg.eigh / inv, diis.py:85-95), which on a GPU costs a stream synchronisation and leaves the device idle while
+// Python solves a 7 x 7 system.
+//
+// State layout (doubles): S[0] = order of the stored matrix L (number of stored vectors + 1), S[1..81] = L row-major with
+// pitch 9, S[82..90] = the coefficients of the last step (c[0..m-1] amplitudes, c[m] Lagrange multiplier), S[91] = 1 if the
+// last step went through the pseudo-inverse ("linear dependence found", diis.py:86), S[92] = number of steps taken.
+#pragma once
+
+#if defined(__HIPCC__)
+#define PYMES_HD __host__ __device__
+#else
+#define PYMES_HD
+#endif
+
+namespace diis_small {
+
+constexpr int kMaxOrder = 9;        // dim_space <= 8
+constexpr int kStateDoubles = 96;
+
+// cyclic Jacobi eigen-decomposition of a symmetric n x n matrix A (pitch 9): A is overwritten, lam[i] / V[:,i] on return
+PYMES_HD inline void jacobi_eigh(int n, double* A, double* V, double* lam) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * 9 + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) (i == j ? diag : off) += A[i * 9 + j] * A[i * 9 + j];
+        if (off <= 1e-60 * (diag + off) || off == 0.0) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[p * 9 + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * 9 + q] - A[p * 9 + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / ((theta >= 0.0 ? theta : -theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; ++k) {                 // A <- A J
+                    const double akp = A[k * 9 + p], akq = A[k * 9 + q];
+                    A[k * 9 + p] = c * akp - s * akq;
+                    A[k * 9 + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {                 // A <- J^T A
+                    const double apk = A[p * 9 + k], aqk = A[q * 9 + k];
+                    A[p * 9 + k] = c * apk - s * aqk;
+                    A[q * 9 + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = V[k * 9 + p], vkq = V[k * 9 + q];
+                    V[k * 9 + p] = c * vkp - s * vkq;
+                    V[k * 9 + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < n; ++i) lam[i] = A[i * 9 + i];
+}
+
+// x = A^-1 b by Gaussian elimination with partial pivoting (A, b overwritten; pitch 9)
+PYMES_HD inline void solve_lu(int n, double* A, double* b, double* x) {
+    for (int k = 0; k < n; ++k) {
+        int piv = k;
+        double big = A[k * 9 + k] < 0 ? -A[k * 9 + k] : A[k * 9 + k];
+        for (int i = k + 1; i < n; ++i) {
+            const double v = A[i * 9 + k] < 0 ? -A[i * 9 + k] : A[i * 9 + k];
+            if (v > big) { big = v; piv = i; }
+        }
+        if (piv != k) {
+            for (int j = 0; j < n; ++j) { const double t = A[k * 9 + j]; A[k * 9 + j] = A[piv * 9 + j]; A[piv * 9 + j] = t; }
+            const double t = b[k]; b[k] = b[piv]; b[piv] = t;
+        }
+        for (int i = k + 1; i < n; ++i) {
+            const double f = A[i * 9 + k] / A[k * 9 + k];
+            for (int j = k; j < n; ++j) A[i * 9 + j] -= f * A[k * 9 + j];
+            b[i] -= f * b[k];
+        }
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int j = i + 1; j < n; ++j) s -= A[i * 9 + j] * x[j];
+        x[i] = s / A[i * 9 + i];
+    }
+}
+
+// One DIIS step on the state S.  overlaps[t * m + i] = <e_i, e_new> of amplitude type t (i < m; the new vector is i = m-1),
+// summed over the types in the order of the reference's loop (diis.py:65-78); was_full: the oldest vector has just been
+// dropped (diis.py:59-60, including its quirk: the row / column of the second-newest vector is NOT carried over).
+PYMES_HD inline void step(double* S, const double* overlaps, int ntypes, int m, int was_full) {
+    double L[81], Lold[81];
+    const int n = m + 1;
+    const int nold = (int)S[0];
+    for (int i = 0; i < 81; ++i) { Lold[i] = S[1 + i]; L[i] = 0.0; }
+    (void)nold;
+    for (int i = 0; i < m; ++i) { L[m * 9 + i] = -1.0; L[i * 9 + m] = -1.0; }                 // diis.py:56-57
+    if (was_full) {                                                                            // :59-60
+        for (int i = 0; i < n - 3; ++i)
+            for (int j = 0; j < n - 3; ++j) L[i * 9 + j] = Lold[(i + 1) * 9 + (j + 1)];
+    } else {                                                                                   // :62
+        for (int i = 0; i < n - 2; ++i)
+            for (int j = 0; j < n - 2; ++j) L[i * 9 + j] = Lold[i * 9 + j];
+    }
+    for (int i = 0; i < m; ++i) {                                                              // :65-80
+        double s = 0.0;
+        for (int t = 0; t < ntypes; ++t) s += overlaps[t * m + i];
+        L[i * 9 + (m - 1)] += s;
+    }
+    for (int j = 0; j < n; ++j) L[(m - 1) * 9 + j] = L[j * 9 + (m - 1)];
+    S[0] = (double)n;
+    for (int i = 0; i < 81; ++i) S[1 + i] = L[i];
+    // ---- coefficients (:82-95): L c = (0, ..., 0, -1); pseudo-inverse over |lambda| > 1e-12 when L is (nearly) singular
+    double A[81], V[81], lam[9], c[9], unit[9];
+    for (int i = 0; i < 81; ++i) A[i] = L[i];
+    jacobi_eigh(n, A, V, lam);
+    bool dependent = false;
+    for (int i = 0; i < n; ++i) dependent = dependent || (lam[i] < 1e-12 && lam[i] > -1e-12);
+    for (int i = 0; i < n; ++i) unit[i] = (i == n - 1) ? -1.0 : 0.0;
+    if (dependent) {
+        for (int i = 0; i < n; ++i) c[i] = 0.0;
+        for (int k = 0; k < n; ++k) {
+            if (lam[k] < 1e-12 && lam[k] > -1e-12) continue;
+            double proj = 0.0;
+            for (int i = 0; i < n; ++i) proj += V[i * 9 + k] * unit[i];
+            for (int i = 0; i < n; ++i) c[i] += V[i * 9 + k] * proj / lam[k];
+        }
+    } else {
+        for (int i = 0; i < 81; ++i) A[i] = L[i];
+        solve_lu(n, A, unit, c);
+    }
+    for (int i = 0; i < 9; ++i) S[82 + i] = i < n ? c[i] : 0.0;
+    S[91] = dependent ? 1.0 : 0.0;
+    S[92] += 1.0;
+}
+
+}  // namespace diis_small

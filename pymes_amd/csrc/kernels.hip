@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "device_api.h"
+#include "diis_small.h"
 
 #define HIP_CHECK(expr)                                                                   \
     do {                                                                                  \
@@ -959,6 +960,24 @@ __global__ void __launch_bounds__(256) dots_stage2_kernel(const double* __restri
     for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += partial[pair * kDotBlocks + i];
     s = block_sum(s, sh);
     if (threadIdx.x == 0) out[pair] = s;
+}
+
+// the small algebra of a DIIS step on the device: one thread (the matrices are at most 9 x 9), overlaps straight from
+// dots_stage2's output — no host round trip between the overlaps and the extrapolation
+__global__ void diis_step_kernel(double* __restrict__ state, const double* __restrict__ overlaps, int ntypes, int m, int was_full) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) diis_small::step(state, overlaps, ntypes, m, was_full);
+}
+struct LinPtrsDev {
+    const double* x[8];
+};
+__global__ void lincomb_dev_kernel(double* __restrict__ out, const LinPtrsDev p, const double* __restrict__ coeff, int nx, long n) {
+    double c[8];
+    for (int k = 0; k < 8; ++k) c[k] = k < nx ? coeff[k] : 0.0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int k = 0; k < nx; ++k) s += p.x[k][i] * c[k];
+        out[i] = s;
+    }
 }
 
 // five reductions in one pass over the amplitudes (device_api.h energy_norms); partial[q * kDotBlocks + block]
@@ -2336,6 +2355,36 @@ void dots(int npairs, const double* const* x, const double* const* y, const int6
     HIP_CHECK(hipMemcpyAsync(g_dot_host[dv], out_dev, sizeof(double) * npairs, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     for (int i = 0; i < npairs; ++i) out_host[i] = g_dot_host[dv][i];
+}
+
+void diis_step(double* state, int npairs, const double* const* x, const double* const* y, const int64_t* n, int ntypes, int m,
+               int was_full, stream_t s) {
+    if (npairs != ntypes * m || npairs < 1 || npairs > 16 || m + 1 > diis_small::kMaxOrder)
+        throw std::runtime_error("diis_step: bad sizes");
+    hipStream_t st = (hipStream_t)s;
+    const int dv = current_device();
+    ensure_dot_ws(dv);
+    DotPtrs p;
+    long nmax = 0;
+    for (int i = 0; i < npairs; ++i) { p.x[i] = x[i]; p.y[i] = y[i]; p.n[i] = (long)n[i]; nmax = std::max(nmax, p.n[i]); }
+    for (int i = npairs; i < 16; ++i) { p.x[i] = nullptr; p.y[i] = nullptr; p.n[i] = 0; }
+    const int nb = (int)std::max<long>(1, std::min<long>(kDotBlocks, (nmax + 255) / 256));
+    hipLaunchKernelGGL(dots_stage1_kernel, dim3(nb, npairs), dim3(256), 0, st, p, g_dot_ws[dv]);
+    HIP_CHECK(hipGetLastError());
+    double* out_dev = g_dot_ws[dv] + 16 * kDotBlocks;
+    hipLaunchKernelGGL(dots_stage2_kernel, dim3(npairs), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(diis_step_kernel, dim3(1), dim3(64), 0, st, state, out_dev, ntypes, m, was_full);
+    HIP_CHECK(hipGetLastError());
+}
+
+void lincomb_dev(double* out, int nx, const double* const* x, const double* coeff_dev, int64_t n, stream_t s) {
+    if (nx < 0 || nx > 8) throw std::runtime_error("lincomb_dev: at most 8 terms");
+    if (n <= 0) return;
+    LinPtrsDev p;
+    for (int i = 0; i < 8; ++i) p.x[i] = i < nx ? x[i] : nullptr;
+    hipLaunchKernelGGL(lincomb_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, out, p, coeff_dev, nx, (long)n);
+    HIP_CHECK(hipGetLastError());
 }
 
 void energy_norms(const double* f, const double* t1, const double* t2, const double* Edir, const double* Eex,

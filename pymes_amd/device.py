@@ -599,6 +599,19 @@ class Context:
             first = False
         return out
 
+    def diis_step(self, state, xs, ys, ntypes, m, was_full):
+        """One DIIS step on the device (include/pymes_amd.h): overlaps <xs[p], ys[p]>, p = t * m + i, into ``state``."""
+        assert len(xs) == len(ys) == ntypes * m and state.size >= 96
+        self.lib.call("pymes_diis_step", self.handle, C.c_void_p(state.ptr), len(xs), ptr_array([x.ptr for x in xs]),
+                      ptr_array([y.ptr for y in ys]), i64_array([x.size for x in xs]), int(ntypes), int(m), int(bool(was_full)))
+
+    def lincomb_dev(self, out, xs, coeff_ptr):
+        """out = sum_k c[k] xs[k] with c read from device memory at ``coeff_ptr`` (at most 8 terms)."""
+        assert len(xs) <= 8 and all(x.size == out.size for x in xs)
+        self.lib.call("pymes_lincomb_dev", self.handle, C.c_void_p(out.ptr), len(xs), ptr_array([x.ptr for x in xs]),
+                      C.c_void_p(int(coeff_ptr)), out.size)
+        return out
+
     def cmul(self, mr, mi, xr, xi, yr, yi):
         """(yr + i yi) = (mr + i mi) * (xr + i xi) element by element (y may alias x)."""
         assert mr.size == mi.size == xr.size == xi.size == yr.size == yi.size

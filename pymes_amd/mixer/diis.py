@@ -38,6 +38,7 @@ class DIIS:
         self.error_list = []
         self.amplitude_list = []
         self.last_coefficients = None
+        self._state, self._stale, self._log_pending = None, False, False
 
     # -- history across contexts: the reference's mixer outlives a solve() call ---------
     # Device vectors cannot outlive their context.  The mixer registers itself with every context it stores vectors in
@@ -49,6 +50,43 @@ class DIIS:
 
     def _reset(self):
         self.error_list, self.amplitude_list, self.L = [], [], np.zeros((1, 1))
+        self._state, self._stale = None, False
+
+    # -- the small algebra on the device (pymes_diis_step): L and the coefficients live in a 96-double device array; the
+    # host copies (self.L, self.last_coefficients) are refreshed only when somebody asks (logging, parking)
+    def _device_state(self, ctx):
+        st = getattr(self, "_state", None)
+        if st is None or st.ctx is not ctx or ctx.handle is None:
+            self._refresh_host()
+            buf = np.zeros(96)
+            n = self.L.shape[0]
+            buf[0] = n
+            pad = np.zeros((9, 9))
+            pad[:n, :n] = self.L
+            buf[1:82] = pad.ravel()
+            st = ctx.array(buf)
+            self._state, self._stale = st, False
+            ctx.on_close(self._state_closing)
+        return st
+
+    def _refresh_host(self):
+        """Bring self.L / self.last_coefficients up to date with the device state (one small download)."""
+        st = getattr(self, "_state", None)
+        if st is not None and getattr(self, "_stale", False) and st.ctx.handle is not None:
+            buf = st.get()
+            n = int(buf[0])
+            self.L = buf[1:82].reshape(9, 9)[:n, :n].copy()
+            self.last_coefficients = buf[82:82 + n].copy()
+            self.last_dependent = bool(buf[91])
+        self._stale = False
+
+    def _state_closing(self, ctx):
+        try:
+            if getattr(self, "_state", None) is not None and self._state.ctx is ctx:
+                self._refresh_host()
+                self._state = None
+        except Exception:
+            self._state = None
 
     def _stored(self):
         return [arr for lst in (self.error_list, self.amplitude_list) for vec in lst for arr in vec]
@@ -57,6 +95,7 @@ class DIIS:
         """Move the stored vectors that live in ``ctx`` to host memory (the context is about to be destroyed).  Never
         raises: called from ``finally`` blocks and from ``Context.close``."""
         import os
+        self._state_closing(ctx)
         try:
             mine = [a for a in self._stored() if not isinstance(a, np.ndarray) and a.ctx is ctx]
             if not mine:
@@ -122,7 +161,7 @@ class DIIS:
             return np.dot(vec[:, ok] * (1.0 / lam[ok]), np.dot(vec[:, ok].T.conj(), unit))
         return np.linalg.inv(self.L).dot(unit)
 
-    def mix(self, error, amplitude, release=None, sharded=(), allreduce=None, out=None, mark=None):
+    def mix(self, error, amplitude, release=None, sharded=(), allreduce=None, out=None, mark=None, on_device=False):
         """error / amplitude: lists of DeviceArray (one entry per amplitude type).
         Returns freshly allocated DeviceArrays with the extrapolated amplitudes.  The
         mixer keeps references to the arrays passed in (like the reference): the caller must
@@ -143,6 +182,22 @@ class DIIS:
         self.amplitude_list.append(list(amplitude))
         ctx = error[0].ctx
         m, ntypes = len(self.error_list), len(error)
+        if on_device and not sharded and ntypes * m <= 16 and m <= 8:
+            # ``on_device``: overlaps, the (m+1) x (m+1) solve and the extrapolation without a host round trip; returns the
+            # arrays and leaves the log lines to ``self.log_last()`` (the caller prints them once it has synchronised anyway)
+            state = self._device_state(ctx)
+            ctx.diis_step(state, [self.error_list[i][nt] for nt in range(ntypes) for i in range(m)],
+                          [error[nt] for nt in range(ntypes) for _ in range(m)], ntypes, m, was_full)
+            self._stale = True
+            res = []
+            for nt in range(ntypes):
+                dst = out[nt] if out is not None else ctx.pool_get(amplitude[nt].shape)
+                ctx.lincomb_dev(dst, [self.amplitude_list[a][nt] for a in range(m)], state.ptr + 8 * 82)
+                res.append(dst)
+            self._log_pending = True
+            return res
+        self._refresh_host()
+        self._state = None                      # (the host path owns L from here on)
         overlaps = np.zeros(m)
         # all <e_i, e_new> of all amplitude types in one launch and one synchronisation; summed per type on the host
         # in the order of the reference's loop (diis.py:65-78)
@@ -164,9 +219,22 @@ class DIIS:
             ctx.lincomb(dst, [self.amplitude_list[a][nt] for a in range(m)], c[:m])
             res.append(dst)
         out = res
+        self._log(c)
+        return out
+
+    def _log(self, c):
         print_logging_info("diis.mix", level=2)
         print_logging_info("Coefficients for combining amplitudes=", level=3)
         print_logging_info(c[:-1], level=3)
         print_logging_info("Sum of coefficients = {:.8f}".format(np.sum(c[:-1])), level=3)
         print_logging_info("Lagrangian multiplier = {:.8f}".format(c[-1]), level=3)
-        return out
+
+    def log_last(self):
+        """The log lines of the last ``mix(on_device=True)`` (diis.py:86, :104-111), printed once the device has been
+        synchronised for another reason (the energy read-back of the iteration)."""
+        if getattr(self, "_log_pending", False):
+            self._log_pending = False
+            self._refresh_host()
+            if getattr(self, "last_dependent", False):
+                print_logging_info("Linear dependence found in DIIS subspace.", level=2)
+            self._log(self.last_coefficients)

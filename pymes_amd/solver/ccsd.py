@@ -210,10 +210,15 @@ class CCSD(ccd.CCD):
         st["first"] = False
         mark("update")
         if self.is_diis:
-            self.mixer.mix([dt1, dt2], [t1n, t2n], release=ctx.pool_put, out=[t1, t2], mark=mark)    # :181-183
+            # :181-183 — overlaps, subspace solve and extrapolation on the device: the energy read-back below is the
+            # iteration's only host synchronisation (PYMES_HOST_DIIS=1: the host solves the small system, as the reference)
+            self.mixer.mix([dt1, dt2], [t1n, t2n], release=ctx.pool_put, out=[t1, t2], mark=mark,
+                           on_device=not os.environ.get("PYMES_HOST_DIIS"))
         mark("DIIS extrapolation")
         e1, ed, ex, nt2, nr2, n1 = ctx.energy_norms(st["f"], t1, t2, dt2)             # :189-197, one pass
         mark("energy + norms (host sync)")
+        if self.is_diis:
+            self.mixer.log_last()
         st["t1_zero"] = bool(n1 == 0.0) and not os.environ.get("PYMES_NO_T1_SHORTCUT")
         return e1, ed, ex, np.sqrt(nt2), np.sqrt(nr2)
 

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../pymes_amd/csrc/device_api.h"
+#include "../../pymes_amd/csrc/diis_small.h"
 
 namespace dev {
 
@@ -220,6 +221,27 @@ void lincomb(double* out, int nx, const double* const* x, const double* c, int64
     for (int64_t i = 0; i < n; ++i) {
         double s = 0.0;
         for (int k = 0; k < nx; ++k) s += x[k][i] * c[k];
+        out[i] = s;
+    }
+}
+
+void diis_step(double* state, int npairs, const double* const* x, const double* const* y, const int64_t* n, int ntypes, int m,
+               int was_full, stream_t) {
+    if (npairs != ntypes * m || npairs > 16 || m + 1 > diis_small::kMaxOrder) throw std::runtime_error("diis_step: bad sizes");
+    double ov[16];
+    for (int p = 0; p < npairs; ++p) {
+        double s = 0.0;
+        for (int64_t i = 0; i < n[p]; ++i) s += x[p][i] * y[p][i];
+        ov[p] = s;
+    }
+    diis_small::step(state, ov, ntypes, m, was_full);
+}
+
+void lincomb_dev(double* out, int nx, const double* const* x, const double* coeff, int64_t n, stream_t) {
+    if (nx < 0 || nx > 8) throw std::runtime_error("lincomb_dev: at most 8 terms");
+    for (int64_t i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (int k = 0; k < nx; ++k) s += x[k][i] * coeff[k];
         out[i] = s;
     }
 }

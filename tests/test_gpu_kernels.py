@@ -248,3 +248,10 @@ def test_energy_norms_over_pairs(gpu_lib):
         assert np.allclose(tot, full, rtol=1e-12, atol=1e-12)
     finally:
         ctx.close()
+
+
+def test_mixer_against_reference_golden_gpu(gpu_lib):
+    """The DIIS step on the device (pymes_diis_step: overlaps, the (m+1) x (m+1) solve by one thread, extrapolation with the
+    coefficients read from HBM) and the host solve, on the reference's own DIIS.mix sequence (tests/golden/diis.json)."""
+    from tests.test_host_round2 import check_mixer_against_reference_golden
+    check_mixer_against_reference_golden(gpu_lib)

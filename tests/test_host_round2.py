@@ -206,6 +206,38 @@ def test_mixer_history_survives_solve_calls(sim):
     assert abs(r3["ccsd e"] - oc.ccsd_solve(no, f3, V3, delta_e=1e-10)["e"]) < 1e-9
 
 
+def check_mixer_against_reference_golden(lib):
+    """pymes_amd.mixer.diis.DIIS — host solve and the device-resident step (pymes_diis_step) — on the seeded sequence of
+    tests/golden/diis.json, which the reference's DIIS.mix produced (oracle/make_golden.py): coefficients of every call,
+    the final L including the full-subspace quirk."""
+    import json
+    import os
+    from pymes_amd.mixer.diis import DIIS
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "diis.json")))
+    for on_device in (False, True):
+        rng = np.random.default_rng(g["seed"])
+        ctx = Context(2, 3, lib=lib)
+        mixer = DIIS(dim_space=6)
+        try:
+            for it in range(10):
+                err = [rng.standard_normal((3, 2)) * 0.5 ** it, rng.standard_normal((3, 3, 2, 2)) * 0.5 ** it]
+                amp = [rng.standard_normal((3, 2)), rng.standard_normal((3, 3, 2, 2))]
+                out = quiet(mixer.mix, [ctx.array(e) for e in err], [ctx.array(a) for a in amp], on_device=on_device)
+                if on_device:
+                    quiet(mixer.log_last)
+                assert np.allclose(mixer.last_coefficients, g["coeffs"][it], rtol=1e-9, atol=1e-11), (on_device, it)
+            mixer._refresh_host()
+            assert np.allclose(mixer.L, np.array(g["L_final"]), rtol=1e-12, atol=1e-14), on_device
+            assert mixer.L[4, 4] == 0.0 and np.all(mixer.L[4, :4] == 0.0)
+            assert all(o.get().shape == s for o, s in zip(out, ((3, 2), (3, 3, 2, 2))))
+        finally:
+            ctx.close()
+
+
+def test_mixer_against_reference_golden(sim):
+    check_mixer_against_reference_golden(sim)
+
+
 def test_side_stream_sections_give_the_same_solve(sim, monkeypatch):
     """The T1 dressing on the context's side stream (own arena / split-K workspace, joined before the hole ladder and the
     ring products): same iteration history as the one-stream order; the side section may not be nested, and a join
