@@ -28,7 +28,7 @@ PYMES_HD inline void jacobi_eigh(int n, double* A, double* V, double* lam) {
         double off = 0.0, diag = 0.0;
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < n; ++j) (i == j ? diag : off) += A[i * 9 + j] * A[i * 9 + j];
-        if (off <= 1e-60 * (diag + off) || off == 0.0) break;
+        if (off <= 1e-34 * (diag + off) || off == 0.0) break;       // off-diagonal elements below 1e-17 of the norm
         for (int p = 0; p < n - 1; ++p)
             for (int q = p + 1; q < n; ++q) {
                 const double apq = A[p * 9 + q];
@@ -85,12 +85,11 @@ PYMES_HD inline void solve_lu(int n, double* A, double* b, double* x) {
 // One DIIS step on the state S.  overlaps[t * m + i] = <e_i, e_new> of amplitude type t (i < m; the new vector is i = m-1),
 // summed over the types in the order of the reference's loop (diis.py:65-78); was_full: the oldest vector has just been
 // dropped (diis.py:59-60, including its quirk: the row / column of the second-newest vector is NOT carried over).
-PYMES_HD inline void step(double* S, const double* overlaps, int ntypes, int m, int was_full) {
-    double L[81], Lold[81];
+// L of this step from the stored one (S[1..81]) and the new overlaps, written back to S; returns in L (pitch 9)
+PYMES_HD inline void build_L(double* S, const double* overlaps, int ntypes, int m, int was_full, double* L) {
+    const double* Lold = S + 1;                   // (L is a separate array: the old matrix is read in place)
     const int n = m + 1;
-    const int nold = (int)S[0];
-    for (int i = 0; i < 81; ++i) { Lold[i] = S[1 + i]; L[i] = 0.0; }
-    (void)nold;
+    for (int i = 0; i < 81; ++i) L[i] = 0.0;
     for (int i = 0; i < m; ++i) { L[m * 9 + i] = -1.0; L[i * 9 + m] = -1.0; }                 // diis.py:56-57
     if (was_full) {                                                                            // :59-60
         for (int i = 0; i < n - 3; ++i)
@@ -107,10 +106,14 @@ PYMES_HD inline void step(double* S, const double* overlaps, int ntypes, int m, 
     for (int j = 0; j < n; ++j) L[(m - 1) * 9 + j] = L[j * 9 + (m - 1)];
     S[0] = (double)n;
     for (int i = 0; i < 81; ++i) S[1 + i] = L[i];
-    // ---- coefficients (:82-95): L c = (0, ..., 0, -1); pseudo-inverse over |lambda| > 1e-12 when L is (nearly) singular
-    double A[81], V[81], lam[9], c[9], unit[9];
-    for (int i = 0; i < 81; ++i) A[i] = L[i];
-    jacobi_eigh(n, A, V, lam);
+}
+
+// coefficients (:82-95) from L and its eigen-decomposition (lam, V): L c = (0, ..., 0, -1); pseudo-inverse over
+// |lambda| > 1e-12 when L is (nearly) singular, LU with partial pivoting otherwise (the reference inverts L there)
+PYMES_HD inline void finish(double* S, const double* L, const double* V, const double* lam, int n, double* work /* [99] */) {
+    double* A = work;
+    double* c = work + 81;
+    double* unit = work + 90;
     bool dependent = false;
     for (int i = 0; i < n; ++i) dependent = dependent || (lam[i] < 1e-12 && lam[i] > -1e-12);
     for (int i = 0; i < n; ++i) unit[i] = (i == n - 1) ? -1.0 : 0.0;
@@ -129,6 +132,14 @@ PYMES_HD inline void step(double* S, const double* overlaps, int ntypes, int m, 
     for (int i = 0; i < 9; ++i) S[82 + i] = i < n ? c[i] : 0.0;
     S[91] = dependent ? 1.0 : 0.0;
     S[92] += 1.0;
+}
+
+PYMES_HD inline void step(double* S, const double* overlaps, int ntypes, int m, int was_full) {
+    double L[81], A[81], V[81], lam[9], work[99];
+    build_L(S, overlaps, ntypes, m, was_full, L);
+    for (int i = 0; i < 81; ++i) A[i] = L[i];
+    jacobi_eigh(m + 1, A, V, lam);
+    finish(S, L, V, lam, m + 1, work);
 }
 
 }  // namespace diis_small

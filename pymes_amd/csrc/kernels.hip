@@ -964,8 +964,63 @@ __global__ void __launch_bounds__(256) dots_stage2_kernel(const double* __restri
 
 // the small algebra of a DIIS step on the device: one thread (the matrices are at most 9 x 9), overlaps straight from
 // dots_stage2's output — no host round trip between the overlaps and the extrapolation
-__global__ void diis_step_kernel(double* __restrict__ state, const double* __restrict__ overlaps, int ntypes, int m, int was_full) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) diis_small::step(state, overlaps, ntypes, m, was_full);
+__global__ void __launch_bounds__(64) diis_step_kernel(double* __restrict__ state, const double* __restrict__ overlaps, int ntypes,
+                                                        int m, int was_full) {
+    // one wave; the matrices live in LDS.  Cyclic Jacobi with the lanes over the row / column index of a rotation (a
+    // single thread with the matrices in scratch memory takes milliseconds: every element access is a memory round trip)
+    __shared__ double sL[81], sA[81], sV[81], slam[9], swork[99];
+    const int lane = threadIdx.x, n = m + 1;
+    if (lane == 0) diis_small::build_L(state, overlaps, ntypes, m, was_full, sL);
+    __syncthreads();
+    for (int e = lane; e < 81; e += 64) {
+        sA[e] = sL[e];
+        sV[e] = (e / 9 == e % 9) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        double off = 0.0, tot = 0.0;
+        for (int e = lane; e < 81; e += 64) {
+            const int i = e / 9, j = e - 9 * i;
+            if (i < n && j < n) {
+                const double v = sA[e] * sA[e];
+                tot += v;
+                if (i != j) off += v;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            off += __shfl_xor(off, o, 64);
+            tot += __shfl_xor(tot, o, 64);
+        }
+        if (off <= 1e-34 * tot || off == 0.0) break;            // (wave-uniform)
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = sA[p * 9 + q];
+                if (apq == 0.0) continue;                        // (wave-uniform: every lane reads the same word)
+                const double theta = (sA[q * 9 + q] - sA[p * 9 + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                __syncthreads();                                 // everyone has read the pivot elements
+                if (lane < n) {                                  // A <- A J and V <- V J: lane = row
+                    const double akp = sA[lane * 9 + p], akq = sA[lane * 9 + q];
+                    sA[lane * 9 + p] = c * akp - sn * akq;
+                    sA[lane * 9 + q] = sn * akp + c * akq;
+                    const double vkp = sV[lane * 9 + p], vkq = sV[lane * 9 + q];
+                    sV[lane * 9 + p] = c * vkp - sn * vkq;
+                    sV[lane * 9 + q] = sn * vkp + c * vkq;
+                }
+                __syncthreads();
+                if (lane < n) {                                  // A <- J^T A: lane = column
+                    const double apk = sA[p * 9 + lane], aqk = sA[q * 9 + lane];
+                    sA[p * 9 + lane] = c * apk - sn * aqk;
+                    sA[q * 9 + lane] = sn * apk + c * aqk;
+                }
+                __syncthreads();
+            }
+    }
+    if (lane < n) slam[lane] = sA[lane * 9 + lane];
+    __syncthreads();
+    if (lane == 0) diis_small::finish(state, sL, sV, slam, n, swork);
 }
 struct LinPtrsDev {
     const double* x[8];

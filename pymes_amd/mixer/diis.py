@@ -161,7 +161,8 @@ class DIIS:
             return np.dot(vec[:, ok] * (1.0 / lam[ok]), np.dot(vec[:, ok].T.conj(), unit))
         return np.linalg.inv(self.L).dot(unit)
 
-    def mix(self, error, amplitude, release=None, sharded=(), allreduce=None, out=None, mark=None, on_device=False):
+    def mix(self, error, amplitude, release=None, sharded=(), allreduce=None, out=None, mark=None, on_device=False,
+            defer_log=False):
         """error / amplitude: lists of DeviceArray (one entry per amplitude type).
         Returns freshly allocated DeviceArrays with the extrapolated amplitudes.  The
         mixer keeps references to the arrays passed in (like the reference): the caller must
@@ -219,7 +220,10 @@ class DIIS:
             ctx.lincomb(dst, [self.amplitude_list[a][nt] for a in range(m)], c[:m])
             res.append(dst)
         out = res
-        self._log(c)
+        if defer_log:           # the caller prints these lines (log_last) once its next kernels are on their way
+            self._log_pending, self.last_dependent = True, False
+        else:
+            self._log(c)
         return out
 
     def _log(self, c):

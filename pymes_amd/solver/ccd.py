@@ -145,8 +145,8 @@ class CCD:
                         np.copyto(amps, t2n.get())    # the reference updates the caller's array in place (:124)
                     first = False
                     if self.is_diis:
-                        self.mixer.mix([dt2], [t2n], release=ctx.pool_put, out=[t2],   # :126-127, on the device
-                                       on_device=not os.environ.get("PYMES_HOST_DIIS"))
+                        self.mixer.mix([dt2], [t2n], release=ctx.pool_put, out=[t2], defer_log=True,   # :126-127
+                                       on_device=bool(os.environ.get("PYMES_DEVICE_DIIS")))
                     _, e_dir_ccd, e_ex_ccd, nt2, nr2, _ = ctx.energy_norms(None, None, t2, dt2)   # :132 + norms, one pass
                     if self.is_diis:
                         self.mixer.log_last()

@@ -210,10 +210,12 @@ class CCSD(ccd.CCD):
         st["first"] = False
         mark("update")
         if self.is_diis:
-            # :181-183 — overlaps, subspace solve and extrapolation on the device: the energy read-back below is the
-            # iteration's only host synchronisation (PYMES_HOST_DIIS=1: the host solves the small system, as the reference)
-            self.mixer.mix([dt1, dt2], [t1n, t2n], release=ctx.pool_put, out=[t1, t2], mark=mark,
-                           on_device=not os.environ.get("PYMES_HOST_DIIS"))
+            # :181-183; the mixer's log lines are printed (log_last) after the energy kernel has been enqueued.
+            # PYMES_DEVICE_DIIS=1: overlaps, subspace solve and extrapolation without a host round trip (pymes_diis_step) —
+            # measured slower than the host solve for now: a one-wave Jacobi sweep is a chain of LDS / fp64-divide
+            # latencies, 0.40 ms per step against 0.15 ms (tools/probe_diis.py), so it is opt-in
+            self.mixer.mix([dt1, dt2], [t1n, t2n], release=ctx.pool_put, out=[t1, t2], mark=mark, defer_log=True,
+                           on_device=bool(os.environ.get("PYMES_DEVICE_DIIS")))
         mark("DIIS extrapolation")
         e1, ed, ex, nt2, nr2, n1 = ctx.energy_norms(st["f"], t1, t2, dt2)             # :189-197, one pass
         mark("energy + norms (host sync)")

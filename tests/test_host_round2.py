@@ -238,6 +238,21 @@ def test_mixer_against_reference_golden(sim):
     check_mixer_against_reference_golden(sim)
 
 
+@pytest.mark.parametrize("solver", ["ccsd", "ccd"])
+def test_device_resident_diis_gives_the_same_solve(sim, monkeypatch, solver):
+    """PYMES_DEVICE_DIIS=1: overlaps, subspace solve (pymes_diis_step) and extrapolation without a host round trip — same
+    iteration count and energy as the oracle's run of the reference algorithm (quirk included), and as the host solve."""
+    no, nv = 3, 6
+    f, V, _, _ = synthetic_case(no, nv, seed=4, scale=0.3)
+    ref = oc.ccsd_solve(no, f, V, delta_e=1e-11) if solver == "ccsd" else oc.ccd_solve(no, f, V, delta_e=1e-11)
+    monkeypatch.setenv("PYMES_DEVICE_DIIS", "1")
+    s = CCSD(no, delta_e=1e-11) if solver == "ccsd" else CCD(no, delta_e=1e-11)
+    r = quiet(s.solve, f, V)
+    e = r["ccsd e"] if solver == "ccsd" else r["ccd e"]
+    assert s.iterations == ref["iterations"] and abs(e - ref["e"]) < 1e-11
+    assert s.mixer._state is None and s.mixer.L.shape == (7, 7)          # the state came back to the host when the context closed
+
+
 def test_side_stream_sections_give_the_same_solve(sim, monkeypatch):
     """The T1 dressing on the context's side stream (own arena / split-K workspace, joined before the hole ladder and the
     ring products): same iteration history as the one-stream order; the side section may not be nested, and a join
