@@ -320,6 +320,13 @@ int pymes_lincomb(pymes_ctx* ctx, double* out_dev, int nx, const double* const* 
  * full-subspace quirk, diis.py:59-60) and L c = (0,..,0,-1) is solved by one device thread; pymes_lincomb_dev then forms
  * sum_k c[k] x[k] with the coefficients read from state_dev + 82.  Nothing synchronises: the host reads the state
  * (pymes_download) only when it wants to log it. */
+/* The same step with the small algebra on the calling host thread: overlaps reduced on the device (one synchronisation),
+ * L and the coefficients in state_host (96 doubles, layout as above), the extrapolations out[t] = sum_i c[i] amp_hist[t*m+i]
+ * enqueued before the call returns — what the solvers use: the device waits for the host only for the synchronisation itself,
+ * not for an interpreter to run numpy.linalg on a 7 x 7 matrix (diis.py:65-103 in one call). */
+int pymes_diis_mix(pymes_ctx* ctx, double* state_host, int ntypes, int m, int was_full, const double* const* err_hist_dev,
+                   const double* const* err_new_dev, const int64_t* sizes, const double* const* amp_hist_dev,
+                   double* const* out_dev);
 int pymes_diis_step(pymes_ctx* ctx, double* state_dev, int npairs, const double* const* x_dev, const double* const* y_dev,
                     const int64_t* n, int ntypes, int m, int was_full);
 int pymes_lincomb_dev(pymes_ctx* ctx, double* out_dev, int nx, const double* const* x_dev, const double* coeff_dev,

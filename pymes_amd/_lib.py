@@ -125,6 +125,7 @@ SIGNATURES = {
     "pymes_dots_var": (C.c_int, [C.c_void_p, C.c_int, c_pp, c_pp, c_i64_p, c_double_p]),
     "pymes_lincomb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_pp, c_double_p, C.c_int64]),
     "pymes_cmul": (C.c_int, [C.c_void_p] * 7 + [C.c_int64]),
+    "pymes_diis_mix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, c_pp, c_pp, c_i64_p, c_pp, c_pp]),
     "pymes_diis_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_pp, c_pp, c_i64_p, C.c_int, C.c_int, C.c_int]),
     "pymes_lincomb_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_pp, C.c_void_p, C.c_int64]),
     "pymes_stats": (C.c_int, [C.c_void_p, C.c_int, c_i64_p, c_double_p, c_i64_p, c_double_p]),

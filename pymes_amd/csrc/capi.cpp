@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../include/pymes_amd.h"
+#include "diis_small.h"
 #include "engine.h"
 #include "fcidump.h"
 #include "packed.h"
@@ -588,6 +589,28 @@ int pymes_diis_step(pymes_ctx* ctx, double* state, int npairs, const double* con
     return guarded([&] {
         need(state, "state"); need(x, "x"); need(y, "y"); need(n, "n");
         dev::diis_step(state, npairs, x, y, n, ntypes, m, was_full, E(ctx).stream);
+    });
+}
+int pymes_diis_mix(pymes_ctx* ctx, double* state_host, int ntypes, int m, int was_full, const double* const* err_hist,
+                   const double* const* err_new, const int64_t* sizes, const double* const* amp_hist, double* const* out) {
+    return guarded([&] {
+        need(state_host, "state"); need(err_hist, "err_hist"); need(err_new, "err_new"); need(sizes, "sizes");
+        need(amp_hist, "amp_hist"); need(out, "out");
+        if (ntypes < 1 || m < 1 || m > 8 || ntypes * m > 16) throw pymes::Error("diis_mix: need ntypes * m <= 16, m <= 8");
+        Engine& e = E(ctx);
+        const double* x[16];
+        const double* y[16];
+        int64_t n[16];
+        for (int t = 0; t < ntypes; ++t)
+            for (int i = 0; i < m; ++i) {
+                x[t * m + i] = err_hist[t * m + i];
+                y[t * m + i] = err_new[t];
+                n[t * m + i] = sizes[t];
+            }
+        double ov[16];
+        dev::dots(ntypes * m, x, y, n, ov, e.stream);                      // one launch pair, one synchronisation
+        diis_small::step(state_host, ov, ntypes, m, was_full);             // (m+1) x (m+1) algebra on this host thread
+        for (int t = 0; t < ntypes; ++t) dev::lincomb(out[t], m, amp_hist + t * m, state_host + 82, sizes[t], e.stream);
     });
 }
 int pymes_lincomb_dev(pymes_ctx* ctx, double* out, int nx, const double* const* x, const double* coeff_dev, int64_t n) {

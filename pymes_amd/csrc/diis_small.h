@@ -8,6 +8,7 @@
 // pitch 9, S[82..90] = the coefficients of the last step (c[0..m-1] amplitudes, c[m] Lagrange multiplier), S[91] = 1 if the
 // last step went through the pseudo-inverse ("linear dependence found", diis.py:86), S[92] = number of steps taken.
 #pragma once
+#include <cmath>
 
 #if defined(__HIPCC__)
 #define PYMES_HD __host__ __device__

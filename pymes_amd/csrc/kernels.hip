@@ -68,8 +68,12 @@ __device__ __forceinline__ long xcd_remap(long b, long nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
 }
 
-template <int BM, int BN, bool AKC, bool BKC, int VEC>
-__global__ void __launch_bounds__(kThreads, 2) dgemm_kernel(const GemmK g) {
+// STREAM (64 x 64 tiles only): ONE LDS buffer instead of two — the next k-tile waits in registers while this one is
+// consumed, two barriers per k-tile — so that twice as many blocks fit a CU (19 KB of LDS each) and more loads are in
+// flight: for the short-K / tiny-output products that stream a 3.2-GB integral block once (T1 dressing, singles residual),
+// which are bound by HBM latency x bytes in flight, not by the MFMA pipe.
+template <int BM, int BN, bool AKC, bool BKC, int VEC, bool STREAM = false>
+__global__ void __launch_bounds__(kThreads, STREAM ? 4 : 2) dgemm_kernel(const GemmK g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int WM = BM / 2, WN = BN / 2;      // wave tile (2x2 waves)
     constexpr int FM = WM / 16, FN = WN / 16;    // MFMA tiles per wave
@@ -87,7 +91,7 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_kernel(const GemmK g) {
     constexpr int B_RSTEP = kThreads / B_CH;
 
     double* As = smem;
-    double* Bs = smem + 2 * A_TILE;
+    double* Bs = smem + (STREAM ? 1 : 2) * A_TILE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -266,6 +270,27 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_kernel(const GemmK g) {
         store_tiles(0);
     }
     __syncthreads();
+    if constexpr (STREAM) {
+        for (int kt = 0; kt < nkt; ++kt) {
+            const bool has_next = kt + 1 < nkt;
+            if (has_next) load_tiles(kt + 1);        // in flight while this tile is consumed
+            const double* as = As + a_frag;
+            const double* bs = Bs + b_frag;
+            read_frags(as, bs, 0, a[0], b[0]);
+            read_frags(as, bs, 1, a[1], b[1]);
+            mfma_step(a[0], b[0]);
+            read_frags(as, bs, 2, a[0], b[0]);
+            mfma_step(a[1], b[1]);
+            read_frags(as, bs, 3, a[1], b[1]);
+            mfma_step(a[0], b[0]);
+            mfma_step(a[1], b[1]);
+            __syncthreads();                         // every wave has read the tile
+            if (has_next) {
+                store_tiles(0);
+                __syncthreads();
+            }
+        }
+    } else {
     if (nkt > 0) read_frags(As + a_frag, Bs + b_frag, 0, a[0], b[0]);
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
@@ -283,6 +308,7 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_kernel(const GemmK g) {
         __syncthreads();                         // tile kt fully consumed into registers; tile kt+1 visible
         if (has_next) read_frags(As + (cur ^ 1) * A_TILE + a_frag, Bs + (cur ^ 1) * B_TILE + b_frag, 0, a[0], b[0]);
         mfma_step(a[1], b[1]);
+    }
     }
 
     // ---- epilogue -------------------------------------------------------------------
@@ -1909,13 +1935,13 @@ void ensure_dot_ws(int d) {
     HIP_CHECK(hipHostMalloc((void**)&g_dot_host[d], sizeof(double) * 16));
 }
 
-template <int BM, int BN, bool AKC, bool BKC, int VEC>
+template <int BM, int BN, bool AKC, bool BKC, int VEC, bool STREAM = false>
 void launch_gemm(const GemmK& k, long nblocks, hipStream_t st) {
     constexpr int A_T = (AKC ? (BK + 2) * BM : (BM + 16) * BK);
     constexpr int B_T = (BKC ? (BK + 2) * BN : (BN + 16) * BK);
-    constexpr size_t lds = (size_t)2 * (A_T + B_T) * sizeof(double);
+    constexpr size_t lds = (size_t)(STREAM ? 1 : 2) * (A_T + B_T) * sizeof(double);
     static bool attr_set[kMaxDevices] = {false};
-    auto fn = dgemm_kernel<BM, BN, AKC, BKC, VEC>;
+    auto fn = dgemm_kernel<BM, BN, AKC, BKC, VEC, STREAM>;
     const int dv = current_device();
     if (!attr_set[dv]) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
@@ -1951,8 +1977,22 @@ inline long dma_min_k() {
     }();
     return v;
 }
+template <bool AKC, bool BKC>
+void launch_stream64(const GemmK& k, int vec, long nblocks, hipStream_t st) {
+    if (vec == 2) launch_gemm<64, 64, AKC, BKC, 2, true>(k, nblocks, st);
+    else launch_gemm<64, 64, AKC, BKC, 1, true>(k, nblocks, st);
+}
+thread_local bool g_stream64 = false;      // set by dev::gemm for the launches of one call
+
 template <int BM, int BN>
 bool dispatch_layout(const GemmK& k, bool akc, bool bkc, int vec, long nblocks, hipStream_t st) {   // true: LDS-DMA kernel
+    if (BM == 64 && BN == 64 && g_stream64) {
+        if (akc && bkc) launch_stream64<true, true>(k, vec, nblocks, st);
+        else if (akc) launch_stream64<true, false>(k, vec, nblocks, st);
+        else if (bkc) launch_stream64<false, true>(k, vec, nblocks, st);
+        else launch_stream64<false, false>(k, vec, nblocks, st);
+        return false;
+    }
     // the LDS-DMA kernel addresses a tile as uniform base + 32-bit byte offset per lane
     const bool off32 = (akc ? 128 : 16) * k.a_ld * 8 + 4096 < (1L << 32) && (bkc ? 128 : 16) * k.b_ld * 8 + 4096 < (1L << 32);
     // ... and pays off from about 64 k-tiles per block on (measured: below that the register-staged kernel wins)
@@ -2184,7 +2224,11 @@ void gemm(const Gemm& g, stream_t s) {
     // short K against a skinny side (the T1 dressing: K = nv or nocc, one side <= nv): the big operand and C are streamed
     // once from HBM and nothing is reused across tiles — 64x64 blocks (more of them resident, more loads in flight) move
     // 13-18 % more bytes per second than the wider tiles (tools/probe_stream.py)
-    if (g.K <= 256 && std::min(g.M, g.N) <= 256) { BM = 64; BN = 64; }
+    bool stream = false;
+    if (g.K <= 256 && std::min(g.M, g.N) <= 256) { BM = 64; BN = 64; stream = true; }
+    // ... and the tiny outputs contracted over a huge K (singles residual: 200 x 50 over o v^2 = 2e6), k-split over the chip
+    if (g.M <= 256 && g.N <= 256 && g.K >= 65536 && BM == 64 && BN == 64) stream = true;
+    if (const char* e = getenv("PYMES_GEMM_STREAM")) stream = stream && atoi(e) != 0;
     if (const char* ov = getenv("PYMES_GEMM_TILE")) {   // tuning experiments only
         int bm = 0, bn = 0;
         if (sscanf(ov, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) { BM = bm; BN = bn; }
@@ -2262,6 +2306,7 @@ void gemm(const Gemm& g, stream_t s) {
     }
     bool used_dma = false;
     int n_kernels = 0;
+    g_stream64 = stream && BM == 64 && BN == 64;
     auto launch = [&](long tile_begin, long ntiles, int nsplit) {
         const long kt_per = (ktiles + nsplit - 1) / nsplit;
         k.kchunk = (int)std::max<long>(kt_per * BK, BK);
@@ -2297,9 +2342,9 @@ void gemm(const Gemm& g, stream_t s) {
         g_prof.klass.push_back(used_dma ? 1 : 0);
         g_prof.nk.push_back(n_kernels);
         char buf[256];
-        snprintf(buf, sizeof buf, "M=%ld N=%ld K=%ld batch=%ld tile=%dx%d akc=%d bkc=%d vec=%d dma=%d split=%d flops=%.4e",
-                 (long)g.M, (long)g.N, (long)g.K, (long)nbatch, BM, BN, (int)a_kcontig, (int)b_kcontig, vec, (int)used_dma,
-                 nsplit, fl);
+        snprintf(buf, sizeof buf, "M=%ld N=%ld K=%ld batch=%ld tile=%dx%d%s akc=%d bkc=%d vec=%d dma=%d split=%d flops=%.4e",
+                 (long)g.M, (long)g.N, (long)g.K, (long)nbatch, BM, BN, g_stream64 ? "s" : "", (int)a_kcontig, (int)b_kcontig, vec,
+                 (int)used_dma, nsplit, fl);
         g_prof.what.push_back(buf);
     }
 }

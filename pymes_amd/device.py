@@ -599,6 +599,16 @@ class Context:
             first = False
         return out
 
+    def diis_mix(self, state_host, err_hist, err_new, amp_hist, outs, m, was_full):
+        """One DIIS step in one library call (include/pymes_amd.h, pymes_diis_mix): ``err_hist`` / ``amp_hist`` are the
+        stored vectors type-major ([t][i]), ``state_host`` a float64 numpy array of 96 (L and the coefficients)."""
+        ntypes = len(err_new)
+        assert len(err_hist) == len(amp_hist) == ntypes * m and len(outs) == ntypes and state_host.size >= 96
+        self.lib.call("pymes_diis_mix", self.handle, _lib.host_ptr(state_host), ntypes, int(m), int(bool(was_full)),
+                      ptr_array([x.ptr for x in err_hist]), ptr_array([x.ptr for x in err_new]),
+                      i64_array([x.size for x in err_new]), ptr_array([x.ptr for x in amp_hist]),
+                      ptr_array([x.ptr for x in outs]))
+
     def diis_step(self, state, xs, ys, ntypes, m, was_full):
         """One DIIS step on the device (include/pymes_amd.h): overlaps <xs[p], ys[p]>, p = t * m + i, into ``state``."""
         assert len(xs) == len(ys) == ntypes * m and state.size >= 96

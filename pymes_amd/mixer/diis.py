@@ -162,7 +162,7 @@ class DIIS:
         return np.linalg.inv(self.L).dot(unit)
 
     def mix(self, error, amplitude, release=None, sharded=(), allreduce=None, out=None, mark=None, on_device=False,
-            defer_log=False):
+            defer_log=False, native=False):
         """error / amplitude: lists of DeviceArray (one entry per amplitude type).
         Returns freshly allocated DeviceArrays with the extrapolated amplitudes.  The
         mixer keeps references to the arrays passed in (like the reference): the caller must
@@ -199,6 +199,29 @@ class DIIS:
             return res
         self._refresh_host()
         self._state = None                      # (the host path owns L from here on)
+        if native and not sharded and ntypes * m <= 16 and m <= 8:
+            # overlaps (device) -> synchronise -> small algebra in C on this thread -> extrapolation enqueued: one library call
+            # (pymes_diis_mix), no interpreter between the synchronisation and the next kernel
+            buf = np.zeros(96)
+            n0 = self.L.shape[0]
+            buf[0] = n0
+            pad = np.zeros((9, 9))
+            pad[:n0, :n0] = self.L
+            buf[1:82] = pad.ravel()
+            res = [out[nt] if out is not None else ctx.pool_get(amplitude[nt].shape) for nt in range(ntypes)]
+            ctx.diis_mix(buf, [self.error_list[i][nt] for nt in range(ntypes) for i in range(m)], list(error),
+                         [self.amplitude_list[a][nt] for nt in range(ntypes) for a in range(m)], res, m, was_full)
+            n1 = int(buf[0])
+            self.L = buf[1:82].reshape(9, 9)[:n1, :n1].copy()
+            self.last_coefficients = buf[82:82 + n1].copy()
+            self.last_dependent = bool(buf[91])
+            if mark is not None:
+                mark("DIIS overlaps + host solve (one call)")
+            if defer_log:
+                self._log_pending = True
+            else:
+                self.log_last(force=True)
+            return res
         overlaps = np.zeros(m)
         # all <e_i, e_new> of all amplitude types in one launch and one synchronisation; summed per type on the host
         # in the order of the reference's loop (diis.py:65-78)
@@ -233,10 +256,10 @@ class DIIS:
         print_logging_info("Sum of coefficients = {:.8f}".format(np.sum(c[:-1])), level=3)
         print_logging_info("Lagrangian multiplier = {:.8f}".format(c[-1]), level=3)
 
-    def log_last(self):
-        """The log lines of the last ``mix(on_device=True)`` (diis.py:86, :104-111), printed once the device has been
-        synchronised for another reason (the energy read-back of the iteration)."""
-        if getattr(self, "_log_pending", False):
+    def log_last(self, force=False):
+        """The log lines of the last ``mix(defer_log=True)`` (diis.py:86, :104-111), printed once the caller's next kernels
+        are on their way (the energy read-back of the iteration)."""
+        if getattr(self, "_log_pending", False) or force:
             self._log_pending = False
             self._refresh_host()
             if getattr(self, "last_dependent", False):

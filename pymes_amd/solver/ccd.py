@@ -146,7 +146,8 @@ class CCD:
                     first = False
                     if self.is_diis:
                         self.mixer.mix([dt2], [t2n], release=ctx.pool_put, out=[t2], defer_log=True,   # :126-127
-                                       on_device=bool(os.environ.get("PYMES_DEVICE_DIIS")))
+                                       on_device=bool(os.environ.get("PYMES_DEVICE_DIIS")),
+                           native=not os.environ.get("PYMES_NUMPY_DIIS"))
                     _, e_dir_ccd, e_ex_ccd, nt2, nr2, _ = ctx.energy_norms(None, None, t2, dt2)   # :132 + norms, one pass
                     if self.is_diis:
                         self.mixer.log_last()

@@ -215,7 +215,8 @@ class CCSD(ccd.CCD):
             # measured slower than the host solve for now: a one-wave Jacobi sweep is a chain of LDS / fp64-divide
             # latencies, 0.40 ms per step against 0.15 ms (tools/probe_diis.py), so it is opt-in
             self.mixer.mix([dt1, dt2], [t1n, t2n], release=ctx.pool_put, out=[t1, t2], mark=mark, defer_log=True,
-                           on_device=bool(os.environ.get("PYMES_DEVICE_DIIS")))
+                           on_device=bool(os.environ.get("PYMES_DEVICE_DIIS")),
+                           native=not os.environ.get("PYMES_NUMPY_DIIS"))
         mark("DIIS extrapolation")
         e1, ed, ex, nt2, nr2, n1 = ctx.energy_norms(st["f"], t1, t2, dt2)             # :189-197, one pass
         mark("energy + norms (host sync)")

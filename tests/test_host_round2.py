@@ -214,7 +214,8 @@ def check_mixer_against_reference_golden(lib):
     import os
     from pymes_amd.mixer.diis import DIIS
     g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "diis.json")))
-    for on_device in (False, True):
+    for mode in ("numpy", "native", "device"):          # host numpy.linalg / one native call / device-resident step
+        on_device = mode == "device"
         rng = np.random.default_rng(g["seed"])
         ctx = Context(2, 3, lib=lib)
         mixer = DIIS(dim_space=6)
@@ -222,12 +223,16 @@ def check_mixer_against_reference_golden(lib):
             for it in range(10):
                 err = [rng.standard_normal((3, 2)) * 0.5 ** it, rng.standard_normal((3, 3, 2, 2)) * 0.5 ** it]
                 amp = [rng.standard_normal((3, 2)), rng.standard_normal((3, 3, 2, 2))]
-                out = quiet(mixer.mix, [ctx.array(e) for e in err], [ctx.array(a) for a in amp], on_device=on_device)
+                out = quiet(mixer.mix, [ctx.array(e) for e in err], [ctx.array(a) for a in amp], on_device=on_device,
+                            native=(mode == "native"))
                 if on_device:
                     quiet(mixer.log_last)
-                assert np.allclose(mixer.last_coefficients, g["coeffs"][it], rtol=1e-9, atol=1e-11), (on_device, it)
+                assert np.allclose(mixer.last_coefficients, g["coeffs"][it], rtol=1e-9, atol=1e-11), (mode, it)
+                if it >= 2:      # the extrapolated amplitudes are that combination of the stored ones
+                    want = sum(c * a[1].get() for c, a in zip(mixer.last_coefficients, mixer.amplitude_list))
+                    assert np.abs(out[1].get() - want).max() < 1e-12, (mode, it)
             mixer._refresh_host()
-            assert np.allclose(mixer.L, np.array(g["L_final"]), rtol=1e-12, atol=1e-14), on_device
+            assert np.allclose(mixer.L, np.array(g["L_final"]), rtol=1e-12, atol=1e-14), mode
             assert mixer.L[4, 4] == 0.0 and np.all(mixer.L[4, :4] == 0.0)
             assert all(o.get().shape == s for o, s in zip(out, ((3, 2), (3, 3, 2, 2))))
         finally:
