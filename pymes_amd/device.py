@@ -189,7 +189,10 @@ class Context:
         n = max(int(n), 1)
         cap = self.RECYCLE_BYTES
         if 8 * n >= (64 << 20):          # large buffers: never sit on more than a fraction of what is still free
-            cap = min(cap, int(self.RECYCLE_FRACTION * self.mem_info()[0]))
+            self._free_probe = getattr(self, "_free_probe", 0) - 1        # (hipMemGetInfo every 32nd large release)
+            if self._free_probe <= 0:
+                self._free_seen, self._free_probe = self.mem_info()[0] + self._spare_bytes, 32
+            cap = min(cap, int(self.RECYCLE_FRACTION * self._free_seen))
         if self._spare_bytes + 8 * n > cap:
             self.lib.call("pymes_free", self.handle, C.c_void_p(ptr))
             return
