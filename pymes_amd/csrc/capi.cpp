@@ -1,4 +1,6 @@
 // extern "C" surface of libpymes_amd (see include/pymes_amd.h).
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <exception>
 #include <algorithm>
@@ -608,9 +610,23 @@ int pymes_diis_mix(pymes_ctx* ctx, double* state_host, int ntypes, int m, int wa
                 n[t * m + i] = sizes[t];
             }
         double ov[16];
+        static const bool trace = getenv("PYMES_DIIS_TRACE") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (trace) dev::stream_sync(e.stream);                             // (what was enqueued before: residual, update)
+        const auto t1 = std::chrono::steady_clock::now();
         dev::dots(ntypes * m, x, y, n, ov, e.stream);                      // one launch pair, one synchronisation
+        const auto t2 = std::chrono::steady_clock::now();
         diis_small::step(state_host, ov, ntypes, m, was_full);             // (m+1) x (m+1) algebra on this host thread
+        const auto t3 = std::chrono::steady_clock::now();
         for (int t = 0; t < ntypes; ++t) dev::lincomb(out[t], m, amp_hist + t * m, state_host + 82, sizes[t], e.stream);
+        if (trace) {
+            const auto t4 = std::chrono::steady_clock::now();
+            dev::stream_sync(e.stream);
+            const auto t5 = std::chrono::steady_clock::now();
+            auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+            fprintf(stderr, "diis_mix: wait-for-earlier %.0f us, dots+copy+sync %.0f us, solve %.0f us, lincomb enqueue %.0f us, lincomb run %.0f us\n",
+                    us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4), us(t4, t5));
+        }
     });
 }
 int pymes_lincomb_dev(pymes_ctx* ctx, double* out, int nx, const double* const* x, const double* coeff_dev, int64_t n) {

@@ -1923,6 +1923,8 @@ double* g_dot_ws[kMaxDevices] = {nullptr};
 double* g_dot_host[kMaxDevices] = {nullptr};
 long g_live_allocs = 0;
 
+void wait_idle(hipStream_t st) { HIP_CHECK(hipStreamSynchronize(st)); }
+
 int current_device() {
     int d = 0;
     HIP_CHECK(hipGetDevice(&d));
@@ -2122,17 +2124,17 @@ void graph_destroy(graph_t g) {
 }
 void memcpy_h2d(void* d, const void* h, size_t bytes, stream_t s) {
     HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, (hipStream_t)s));
-    HIP_CHECK(hipStreamSynchronize((hipStream_t)s));
+    wait_idle((hipStream_t)s);
 }
 void memcpy_d2h(void* h, const void* d, size_t bytes, stream_t s) {
     HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)s));
-    HIP_CHECK(hipStreamSynchronize((hipStream_t)s));
+    wait_idle((hipStream_t)s);
 }
 void memcpy_d2d(void* d, const void* s_, size_t bytes, stream_t s) {
     HIP_CHECK(hipMemcpyAsync(d, s_, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
 }
 void memset_zero(void* d, size_t bytes, stream_t s) { HIP_CHECK(hipMemsetAsync(d, 0, bytes, (hipStream_t)s)); }
-void stream_sync(stream_t s) { HIP_CHECK(hipStreamSynchronize((hipStream_t)s)); }
+void stream_sync(stream_t s) { wait_idle((hipStream_t)s); }
 size_t mem_free_bytes() {
     size_t f = 0, t = 0;
     HIP_CHECK(hipMemGetInfo(&f, &t));
@@ -2453,7 +2455,7 @@ void dots(int npairs, const double* const* x, const double* const* y, const int6
     hipLaunchKernelGGL(dots_stage2_kernel, dim3(npairs), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(g_dot_host[dv], out_dev, sizeof(double) * npairs, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
+    wait_idle(st);
     for (int i = 0; i < npairs; ++i) out_host[i] = g_dot_host[dv][i];
 }
 
@@ -2501,7 +2503,7 @@ void energy_norms(const double* f, const double* t1, const double* t2, const dou
     hipLaunchKernelGGL(dots_stage2_kernel, dim3(6), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(g_dot_host[dv], out_dev, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
+    wait_idle(st);
     for (int i = 0; i < 6; ++i) out_host[i] = g_dot_host[dv][i];
 }
 
@@ -2526,7 +2528,7 @@ void exchange_asymmetry(const double* A, const double* B, const int64_t d[4], do
                            (long)d[3], (int)tr, (int)ts, ntiles, self, out_dev);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(g_dot_host[dv], out_dev, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
+    wait_idle(st);
     out_host[0] = g_dot_host[dv][0];
     out_host[1] = g_dot_host[dv][1];
 }
@@ -2707,7 +2709,7 @@ void energy_norms_pairs(const double* f, const double* t1, const double* tc, con
     hipLaunchKernelGGL(dots_stage2_kernel, dim3(6), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(g_dot_host[dv], out_dev, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
+    wait_idle(st);
     for (int i = 0; i < 6; ++i) out_host[i] = g_dot_host[dv][i];
 }
 void pairs_unpack(const double* Xc, double* full, int no, int nv, int64_t r0, int64_t r1, stream_t s) {
@@ -2780,7 +2782,7 @@ void ueg_two_body(const UegParams& prm, const int* k_int_dev, const int* index_m
     HIP_CHECK(hipMemsetAsync(V_dev, 0, sizeof(double) * n * n * n * n, st));
     std::vector<int> kint(3 * n);
     HIP_CHECK(hipMemcpyAsync(kint.data(), k_int_dev, sizeof(int) * 3 * n, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
+    wait_idle(st);
     double *umat = nullptr, *E = nullptr, *dk_dev = nullptr;
     int *uidx = nullptr, *dint_dev = nullptr;
     try {
@@ -2824,7 +2826,7 @@ void ueg_two_body(const UegParams& prm, const int* k_int_dev, const int* index_m
         hipLaunchKernelGGL(ueg_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, u, k_int_dev,
                            index_map_dev, umat, uidx, E, V_dev);
         HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipStreamSynchronize(st));
+        wait_idle(st);
     } catch (...) {
         dfree(umat); dfree(E); dfree(dk_dev); dfree(uidx); dfree(dint_dev); dfree(tabs);
         throw;

@@ -414,6 +414,7 @@ class CCSD(ccd.CCD):
         ints, own = self._integrals(t_fock_pq, t_V_pqrs)
         ctx = ints.ctx
         st = None
+        collector = ccd.quiet_collector().__enter__()      # no 40-ms generation-2 collection in the middle of an iteration
         try:
             print_logging_info(algo_name)
             print_logging_info("Using dcsd: ", self.is_dcd, level=1)
@@ -458,6 +459,7 @@ class CCSD(ccd.CCD):
             return {"ccsd e": e_ccsd, "t1": self.t_T_ai, "t2": self.t_T_abij, "hole e": st["eps_i"],
                     "particle e": st["eps_a"], "dE": dE}
         finally:
+            collector.__exit__()
             if own:
                 ctx.close()      # (a DIIS history kept in this context is parked on the host on the way: Context.on_close)
             elif ctx.handle:

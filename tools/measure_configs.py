@@ -23,6 +23,16 @@ def quiet(fn, *a, **k):
 
 
 def timed(fn, sync, reps, warm=3):
+    import gc
+    gc.collect()
+    gc.disable()        # (a generation-2 collection is a 38-ms outlier; the solvers switch the collector off for their loops too)
+    try:
+        return _timed(fn, sync, reps, warm)
+    finally:
+        gc.enable()
+
+
+def _timed(fn, sync, reps, warm=3):
     for _ in range(warm):       # lazy set-up (cached permutations, packed integrals) and launch-graph recording
         fn()
     sync()
