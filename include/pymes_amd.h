@@ -173,6 +173,14 @@ int pymes_ladder_sym_unpack(pymes_ctx* ctx, const double* L_dev, double* r2_dev,
  * x_dev[z] are k device arrays [v,v,o,o], L_all_dev k consecutive arrays [v(v+1)/2][o*o].  One batched GEMM launch per half
  * over all vectors — the sigma builds of every vector of an EOM-CCSD Davidson pass (eom_ccsd.py:95-101, :383). */
 int pymes_ladder_sym_multi(pymes_ctx* ctx, const double* const* x_dev, int k, double* L_all_dev, int dressed);
+/* T1 dressing of the bra of the pair-packed V_abcd (ccsd.py:414-419, as far as the pair-packed ladder reads it):
+ * V_dev, W_dev [r1 - r0][ld] hold the rows P(a,b) = a(a+1)/2 + b in [r0,r1) of one half of the packed block (columns (c,d)
+ * packed, pitch ld = a multiple of 16 doubles), Pk_dev [v*o][ld] the rows x*o + k of V_kxcd packed the same way (x slow), t1_dev [v,o]:
+ *   W[P(a,b)] = V[P(a,b)] - sum_k t1[a,k] Pk[(b,k)] -+ sum_k t1[b,k] Pk[(a,k)]
+ * ("-" for the symmetric half V_abcd + V_abdc, "+" with minus_half = 1 for V_abcd - V_abdc, whose rows a == b stay zero).
+ * nocc <= 64. */
+int pymes_ladder_dress(pymes_ctx* ctx, const double* V_dev, const double* Pk_dev, const double* t1_dev, double* W_dev,
+                       int64_t ld, int64_t r0, int64_t r1, int minus_half);
 /* The three pair layouts of an amplitude-like array X [v,v,o,o] in one pass: Xd[(a,i),(b,j)] = X_abij,
  * Xx[(a,j),(b,i)] = X_abij, Xt[(a,i),(b,j)] = 2 X_abij - X_baij (each [o*v][o*v]; Xd_dev may be NULL).  ccd.py:199 /
  * eom_ccsd.py:352-373 form these index orders implicitly inside their einsum calls. */

@@ -349,6 +349,16 @@ int pymes_ladder_sym_multi(pymes_ctx* ctx, const double* const* xs, int k, doubl
         E(ctx).ladder_sym_multi(xs, k, L_all, dressed != 0);
     });
 }
+int pymes_ladder_dress(pymes_ctx* ctx, const double* V, const double* Pk, const double* t1, double* W, int64_t ld,
+                       int64_t r0, int64_t r1, int minus_half) {
+    return guarded([&] {
+        need(V, "V"); need(Pk, "Pk"); need(t1, "t1"); need(W, "W");
+        pymes::Engine& e = E(ctx);
+        pymes::ArenaScope scope(e.arena);
+        double* ws = e.arena.alloc(dev::ladder_dress_ws_doubles(e.no, e.nv));
+        dev::ladder_dress(V, Pk, t1, W, e.no, e.nv, ld, r0, r1, minus_half ? 1.0 : -1.0, ws, e.stream);
+    });
+}
 int pymes_pair_layouts(pymes_ctx* ctx, const double* x, double* Xd, double* Xx, double* Xt) {
     return guarded([&] {
         need(x, "x"); need(Xx, "Xx"); need(Xt, "Xt");

@@ -842,6 +842,18 @@ void Engine::hole_ladder_packed(const double* x, const double* I, double* L, int
 //                  instead of T_abkl also covers the (k,l)-bra part of V~_abij                      -> L rows
 // V~_abij must therefore be dressed in its reduced form (dress_V bit 16), V~_klij in full; V_abcd is never dressed:
 // no o v^4 work and no second copy of V_abcd per iteration.
+// Does the bra dressing of the packed V_abcd beat the Q_kb products?  Only for a rank that holds all pair rows and all
+// (k,b) rows (one GPU).  Model: the dressing streams V in and W out (16 B per element) at ~4 TB/s effective; the Q
+// products run 2 qrows (npp opp + npm opm) flops at ~70 TFLOP/s.  PYMES_LADDER_DRESS=0/1 overrides the model.
+bool Engine::bra_dress_pays(int64_t rows, int64_t qrows) const {
+    const int64_t o = no, v = nv, npp = v * (v + 1) / 2, npm = v * (v - 1) / 2, opp = o * (o + 1) / 2, opm = o * (o - 1) / 2;
+    if (rows != npp || qrows != o * v || !dev::ladder_dress_ok(no)) return false;
+    if (const char* e = getenv("PYMES_LADDER_DRESS")) return atoi(e) != 0;
+    const double t_dress = 16.0 * double(npp) * double(npp + npm) / 4.0e12 + 20e-6;
+    const double t_q = 2.0 * double(qrows) * (double(npp) * double(opp) + double(npm) * double(opm)) / 70e12;
+    return t_dress < 0.8 * t_q;
+}
+
 void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t row0, int64_t row1, double* QK,
                        int64_t q0, int64_t q1, bool dcd, const double* J) {
     const int64_t o = no, v = nv, npp = v * (v + 1) / 2, npm = v * (v - 1) / 2, opp = o * (o + 1) / 2,
@@ -863,8 +875,28 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
         dev::ladder_pack_V(block(P_abcd).p, lpack_.Vp, lpack_.Vm, nv, nv, row0, row1, stream, lpitch(npp), lpitch(std::max<int64_t>(npm, 1)));
         lpack_.row0 = row0; lpack_.row1 = row1; lpack_.dressed = false; lpack_.valid = true;
     }
+    // Bra dressing of the packed V_abcd instead of the Q_kb products (one rank, all rows): the two rank-no updates of
+    // dev::ladder_dress move 2 x 6.5 GB at (50,200) where Q_kbij = sum_cd V_kbcd tau_cdij costs 1.0e12 flops (13.9 ms);
+    // the dressed copy W takes the place of V in the ladder product and QK carries the small brackets only.
+    const bool dress = bra_dress_pays(rows, qrows);
     const std::string kkey = ":" + std::to_string(q0) + ":" + std::to_string(q1);
-    if (qrows > 0 && !static_.count("VpK" + kkey)) {
+    if (dress && !static_.count("VpKx")) {
+        // rows (x,k) of V_kxcd (x slow), pair-packed over (c,d): packed in the order of the block, rows transposed
+        const int64_t lp = lpitch(npp), lm = lpitch(std::max<int64_t>(npm, 1));
+        double* tp = static_cast<double*>(dev::dmalloc(sizeof(double) * ov * lp));
+        double* tm = static_cast<double*>(dev::dmalloc(sizeof(double) * ov * lm));
+        static_["VpKx"] = static_cast<double*>(dev::dmalloc(sizeof(double) * ov * lp));
+        static_["VmKx"] = static_cast<double*>(dev::dmalloc(sizeof(double) * ov * lm));
+        static_["VpDress"] = static_cast<double*>(dev::dmalloc(sizeof(double) * npp * lp));
+        static_["VmDress"] = static_cast<double*>(dev::dmalloc(sizeof(double) * npp * lm));
+        dev::ladder_pack_V(block(P_iabc).p, tp, tm, 0, nv, 0, ov, stream, lp, lm);
+        permute(1.0, make_view(tp, {o, v, lp}), "kxc", 0.0, make_view(static_["VpKx"], {v, o, lp}), "xkc");
+        permute(1.0, make_view(tm, {o, v, lm}), "kxc", 0.0, make_view(static_["VmKx"], {v, o, lm}), "xkc");
+        dev::stream_sync(stream);
+        dev::dfree(tp);
+        dev::dfree(tm);
+    }
+    if (!dress && qrows > 0 && !static_.count("VpK" + kkey)) {
         double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * qrows * lpitch(npp)));
         double* vm = static_cast<double*>(dev::dmalloc(sizeof(double) * qrows * lpitch(std::max<int64_t>(npm, 1))));
         static_["VpK" + kkey] = vp;
@@ -891,14 +923,34 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
         stats.permute_calls++;
         stats.permute_bytes += 8.0 * 2.0 * double(v * v * o * o);
         TView SpT = pitched(Sp, npp, opp, ldp), AmT = pitched(Am, npm, opm, ldm);
+        const double* Ap = lpack_.Vp;
+        const double* Am_ = lpack_.Vm;
+        if (dress) {
+            ArenaScope s3(arena);
+            double* ws = arena.alloc(dev::ladder_dress_ws_doubles(no, nv));
+            dev::ladder_dress(lpack_.Vp, static_["VpKx"], t1, static_["VpDress"], no, nv, lpitch(npp), 0, npp, -1.0, ws, stream);
+            if (npm > 0)
+                dev::ladder_dress(lpack_.Vm, static_["VmKx"], t1, static_["VmDress"], no, nv, lpitch(npm), 0, npp, 1.0, ws, stream);
+            stats.permute_calls += 2;
+            stats.permute_bytes += 8.0 * 2.0 * double(npp) * double(lpitch(npp) + (npm > 0 ? lpitch(npm) : 0));
+            Ap = static_["VpDress"];
+            Am_ = static_["VmDress"];
+        }
         if (rows > 0) {
-            contract(1.0, packed_rows(lpack_.Vp, rows, npp), "rk", SpT, "kn", 0.0, LS, "rn");
+            contract(1.0, packed_rows(const_cast<double*>(Ap), rows, npp), "rk", SpT, "kn", 0.0, LS, "rn");
             if (opm > 0) {
-                if (npm > 0) contract(1.0, packed_rows(lpack_.Vm, rows, npm), "rk", AmT, "kn", 0.0, LA, "rn");
+                if (npm > 0) contract(1.0, packed_rows(const_cast<double*>(Am_), rows, npm), "rk", AmT, "kn", 0.0, LA, "rn");
                 else zero(LA);
             }
         }
-        if (qrows > 0) {
+        if (qrows > 0 && dress) {
+            // QK = W_kbij alone (ccsd.py:322-343, the (i,j)-, (c,j)- and (i,d)-ket parts of the bras (k,b))
+            TView t = make_view(const_cast<double*>(t1), {v, o});
+            TView Qr = make_view(QK + q0 * o * o, {qrows, o, o});
+            axpby(1.0, make_view(block(P_iajk).p + q0 * o * o, {qrows, o, o}), 0.0, Qr);
+            contract(1.0, make_view(block(P_iabj).p + q0 * v * o, {qrows, v, o}), "qcj", t, "ci", 1.0, Qr, "qij", "q");
+            contract(1.0, make_view(block(P_iajb).p + q0 * o * v, {qrows, o, v}), "qid", t, "dj", 1.0, Qr, "qij");
+        } else if (qrows > 0) {
             // rows (k,b) in [q0,q1) of Q_kbij + W_kbij, plain [i][j]: the pair-packed product [ QS | QA ] is unpacked
             // into the exchange buffer and the small brackets of amplitude_side_abij are added for the same rows, so
             // that they are sharded with Q instead of being repeated by every rank

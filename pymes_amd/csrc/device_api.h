@@ -147,6 +147,15 @@ void tau_build(double* tau, const double* t2, const double* t1, int no, int nv, 
 // nr == 0: V is [rows,nc,nc] and the rows [rp0, rp1) are taken as they are (no zero rows in Vm).
 void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nc, int64_t rp0, int64_t rp1, stream_t s,
                    int64_t ldvp = 0, int64_t ldvm = 0);      // row pitches of Vp / Vm (0: nc(nc+1)/2, nc(nc-1)/2)
+// ladder_dress: T1 dressing of the bra of pair-packed rows (ccsd.py:414-419 as far as the packed ladder reads it).
+// V, W: [row1 - row0][ld], rows r = P(a,b) in [row0,row1); Pk: [nv*no][ld], rows (x,k) = x*no + k of V_kxcd packed like V:
+//   W[r] = V[r] - sum_k t1[a,k] Pk[(b,k)] + sgn sum_k t1[b,k] Pk[(a,k)]     (sgn = -1: "plus" half, +1: "minus" half, whose
+//   rows a == b stay zero).  ld must be a multiple of 16 doubles (all ld columns are processed), no <= 64.
+bool ladder_dress_ok(int no);
+// ws: ladder_dress_ws_doubles(no, nv) doubles of scratch (the t1 fragments in matrix-core operand order).
+int64_t ladder_dress_ws_doubles(int no, int nv);
+void ladder_dress(const double* V, const double* Pk, const double* t1, double* W, int no, int nv, int64_t ld, int64_t row0,
+                  int64_t row1, double sgn, double* ws, stream_t s);
 // ladder_pack_T: X is [nr,nr,nc,nc]; pair (c,d) over nr, pair (i,j) over nc.
 //   Sp[P(c,d)][P(i,j)] = fr fc (X[c,d,i,j] + X[d,c,i,j]) / 2,  fr = 1/2 on c == d if PACK_ROW_HALF, fc = 1/2 on
 //   i == j if PACK_COL_HALF (a pair that is summed over carries the half on its diagonal);

@@ -1263,6 +1263,154 @@ __global__ void __launch_bounds__(256) ladder_pack_V_kernel(const double* __rest
     }
 }
 
+// T1 dressing of the BRA of the pair-packed V_abcd (ccsd.py:414-419 restricted to what the packed ladder reads):
+//   W[P(a,b)][cd] = V[P(a,b)][cd] - sum_k t[a,k] Pk[(b,k)][cd] + sgn sum_k t[b,k] Pk[(a,k)][cd],     a >= b,
+// Pk = the rows (x,k) (x slow) of V_kxcd packed over (c,d) like V itself; sgn = -1 for the symmetric half (V_alcd + V_aldc =
+// V_lacd + V_ladc), +1 for the antisymmetric one (V_alcd - V_aldc = -(V_lacd - V_ladc)), whose rows a == b stay zero.
+// Two rank-no updates whose right factor depends on ONE index of the pair: the first is a matrix product for a fixed b
+// (rows a), the second for a fixed a (rows b).  One wave (= one block) owns a 16 x 16 tile of (a,b) and 16 columns (c,d):
+//   second term, per a of the tile ("chain"):  D2_a[b][cd] = sum_k (sgn t[b,k]) Pk[(a,k)][cd]      13 MFMA 16x16x4 for no = 50
+//   first term,  per b of the tile:            out_b[a][cd] = V + D2 - sum_k t[a,k] Pk[(b,k)][cd]   (V and D2 enter as C)
+// The MFMA result has its tile row in (lane >> 4) + 4 reg and the column (c,d) in lane & 15, so D2 comes out with b where
+// the first term has a: it is turned through LDS (34 KB per wave: written with b, read with a in the lane group).  Every global access is a 128-byte row segment
+// (16 lanes x 8 B), addressed as a wave-uniform base + a loop-invariant 32-bit lane offset; the right factors are read
+// straight from global memory (each segment serves 16 MFMA rows).  The tile state fills the register file (one wave per
+// SIMD), so the latencies are covered inside the wave: chains run in PAIRS with independent accumulators (no
+// back-to-back dependent MFMAs), and the right factors and V rows of the pairs AHEAD are loaded before the MFMAs of the
+// current one.  The t fragments stay in registers (the tile state, not the wave count, is what fills a SIMD: 4 waves per CU).  Blocks are dealt to the 8 XCDs round-robin: XCD x takes the column
+// blocks x, x + 8, ... and runs all tile pairs of a column block back to back, so the slab of Pk they share (no nv rows
+// x 128 B = 1.3 MB at (50,200)) stays in the 4-MB L2 of that XCD while V streams past it (non-temporal loads / stores).
+// Pad columns up to the 16-double pitch are processed like any other (never read by the GEMMs).  NK = ceil(no / 4) MFMA
+// steps; the k beyond no are zero on the t side and a clamped (finite) row on the Pk side.
+// -t1 in MFMA A-operand order, one 512-byte fragment per (tile of 16 rows, step kk): [tile][kk][lane] holds
+// -t1[16 tile + (lane & 15)][4 kk + (lane >> 4)], zero beyond nv / no.  Staged once per call so that the tile kernel
+// fetches its 2 NK fragments with plain coalesced loads (no clamps, no selects: all in flight together).
+__global__ void ladder_dress_tfrag_kernel(const double* __restrict__ t1, double* __restrict__ tf, int no, int nv, int nk, long total) {
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int L = (int)(e & 63), kk = (int)((e >> 6) % nk), tile = (int)((e >> 6) / nk);
+    const int a = 16 * tile + (L & 15), k = 4 * kk + (L >> 4);
+    tf[e] = (a < nv && k < no) ? -t1[(long)a * no + k] : 0.0;
+}
+
+template <int NK>
+__global__ void __launch_bounds__(64) ladder_dress_kernel(const double* __restrict__ V, const double* __restrict__ Pk,
+                                                          const double* __restrict__ tf, double* __restrict__ W, int no,
+                                                          int nv, long ld, long row0, long row1, double sgn, long ntp) {
+    constexpr int TP = 16 * 16 + 16;               // pitch of one a of the turn buffer (bank spread of the reads)
+    __shared__ double turn[16 * TP];               // second term, [a][b][cd]: written with b, read with a in the lane group
+    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    const long idx = blockIdx.x >> 3;
+    const long cdb = (blockIdx.x & 7) + 8 * (idx / ntp), tp = idx % ntp;
+    if (cdb * 16 >= ld) return;
+    int ta_, tb_;
+    unrank_pair(tp, ta_, tb_);
+    const int a0 = ta_ * 16, b0 = tb_ * 16;
+    const long tri0 = (long)a0 * (a0 + 1) / 2;
+    if (tri0 + (long)15 * a0 + 120 + b0 + 15 < row0 || tri0 + b0 >= row1) return;     // rows of the tile: [P(a0,b0), P(a0+15,b0+15)]
+    // MFMA A operand: lane holds [i = lane & 15][k = 4 kk + (lane >> 4)] of -t1, staged in that order (tf).  Both terms
+    // run with -t: the second one enters the first as V -+ D2 (sgn decides) when it is read back from the turn buffer.
+    double ta[NK], tb[NK];
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+        ta[kk] = tf[((long)ta_ * NK + kk) * 64 + lane];
+        tb[kk] = tf[((long)tb_ * NK + kk) * 64 + lane];
+    }
+    // MFMA B operand, step kk, partner x: Pk[(x no + 4 kk + g) ld + col] = (uniform base of (kk, x)) + 32-bit byte offset
+    // of the lane (the no rows of a partner are consecutive: one chain reads 8 MB of address space, not no pages);
+    // only the last step can run past no: its lanes are clamped to row no - 1 (their t is zero)
+    const long col = cdb * 16 + c, kstep = 4L * ld;
+    const unsigned lo = (unsigned)(8 * ((long)g * ld + col));
+    const unsigned lo_last = (unsigned)(8 * ((long)(min(4 * (NK - 1) + g, no - 1) - 4 * (NK - 1)) * ld + col));
+    auto at = [](const double* base, unsigned byte_off) {
+        return reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off);
+    };
+    // rows of V / W: P(a0 + g + 4 r, bb) - row0 = (tri0 + bb - row0) + [P(a0 + g + 4 r, 0) - tri0]
+    unsigned vo[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long a = a0 + g + 4 * r;
+        vo[r] = (unsigned)(8 * ((a * (a + 1) / 2 - tri0) * ld + col));
+    }
+    // Chains 0..15: second term, partner a0 + n; 16..31: first term, partner b0 + n - 16; run in pairs.  Register sets of
+    // the right factors: PA pairs ahead of the current one; of the V rows (HBM latency, non-temporal): VA pairs ahead.
+    constexpr int PA = 1, NBP = 2 * (PA + 1), VA = 3, NBV = 2 * (VA + 1);
+    double pf[NBP][NK], vin[NBV][4];
+    auto fetch_p = [&](int n) {
+        const int x = n < 16 ? a0 + n : b0 + n - 16;
+        const double* __restrict__ ps = Pk + (long)min(x, nv - 1) * no * ld;
+#pragma unroll
+        for (int kk = 0; kk < NK - 1; ++kk) pf[n % NBP][kk] = *at(ps + kk * kstep, lo);
+        pf[n % NBP][NK - 1] = *at(ps + (NK - 1) * kstep, lo_last);
+    };
+    auto fetch_v = [&](int n) {
+        const int x = b0 + n - 16;
+        const double* __restrict__ vs = V + (tri0 + x - row0) * ld;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = a0 + g + 4 * r;
+            const long row = (long)a * (a + 1) / 2 + x;
+            const bool ok = a < nv && x <= a && row >= row0 && row < row1;
+            // a valid address either way and no select on the value (it would be scheduled right behind the load and park
+            // the wave for an HBM round trip): rows that do not exist compute garbage that is never stored
+            vin[n % NBV][r] = __builtin_nontemporal_load(ok ? at(vs, vo[r]) : V);
+        }
+    };
+#pragma unroll
+    for (int n = 0; n < 2 * PA; ++n) fetch_p(n);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {                   // second term, chains 2p and 2p + 1: a = a0 + n
+        const int n0 = 2 * p, n1 = n0 + 1;
+        fetch_p(n0 + 2 * PA);
+        fetch_p(n1 + 2 * PA);
+        if (n0 + 2 * VA >= 16) { fetch_v(n0 + 2 * VA); fetch_v(n1 + 2 * VA); }
+        v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(tb[kk], pf[n0 % NBP][kk], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(tb[kk], pf[n1 % NBP][kk], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {            // result rows are b = b0 + g + 4 rb
+            turn[n0 * TP + (g + 4 * rb) * 16 + c] = acc0[rb];
+            turn[n1 * TP + (g + 4 * rb) * 16 + c] = acc1[rb];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const double s2 = sgn > 0.0 ? -1.0 : 1.0;      // turn holds -sum_k t[b,k] Pk[(a,k)]: wanted is sgn times the sum
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {                   // first term, partners b0 + 2p and b0 + 2p + 1; rows a = a0 + g + 4 r
+        const int b = 2 * p, n0 = 16 + b, n1 = n0 + 1;
+        if (n0 + 2 * PA < 32) { fetch_p(n0 + 2 * PA); fetch_p(n1 + 2 * PA); }
+        if (n0 + 2 * VA < 32) { fetch_v(n0 + 2 * VA); fetch_v(n1 + 2 * VA); }
+        v4d acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc0[r] = fma(s2, turn[(g + 4 * r) * TP + b * 16 + c], vin[n0 % NBV][r]);
+            acc1[r] = fma(s2, turn[(g + 4 * r) * TP + (b + 1) * 16 + c], vin[n1 % NBV][r]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[kk], pf[n0 % NBP][kk], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[kk], pf[n1 % NBP][kk], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int bb = b0 + b + h;
+            double* __restrict__ ws = W + (tri0 + bb - row0) * ld;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = a0 + g + 4 * r;
+                const long row = (long)a * (a + 1) / 2 + bb;
+                if (a < nv && bb <= a && row >= row0 && row < row1)
+                    __builtin_nontemporal_store((sgn > 0.0 && a == bb) ? 0.0 : (double)(h ? acc1[r] : acc0[r]),
+                                                const_cast<double*>(at(ws, vo[r])));
+            }
+        }
+    }
+}
+
 __global__ void ladder_pack_T_kernel(const double* __restrict__ T, const double* __restrict__ t1,
                                      double* __restrict__ Sp, double* __restrict__ Am, int no, int nv, int flags,
                                      long ldp, long ldm, long rp0) {
@@ -2565,6 +2713,38 @@ void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nc, int6
     if (nblk > 0x7fffffffL) throw std::runtime_error("ladder_pack_V: grid too large");
     hipLaunchKernelGGL(ladder_pack_V_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)s, V, Vp, Vm, nr, nc,
                        (long)rp0, nt, ntp, npp, npm);
+    HIP_CHECK(hipGetLastError());
+}
+
+bool ladder_dress_ok(int no) { return no >= 1 && no <= 64; }
+
+int64_t ladder_dress_ws_doubles(int no, int nv) { return (int64_t)((nv + 15) / 16) * ((no + 3) / 4) * 64; }
+
+void ladder_dress(const double* V, const double* Pk, const double* t1, double* W, int no, int nv, int64_t ld, int64_t row0,
+                  int64_t row1, double sgn, double* ws, stream_t s) {
+    if (!ladder_dress_ok(no)) throw std::runtime_error("ladder_dress: nocc outside 1..64");
+    if (ld <= 0 || (ld & 15)) throw std::runtime_error("ladder_dress: the row pitch must be a multiple of 16 doubles");
+    if ((reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(Pk) | reinterpret_cast<uintptr_t>(W)) & 127)
+        throw std::runtime_error("ladder_dress: operands must be 128-byte aligned");
+    if (!ws) throw std::runtime_error("ladder_dress: workspace missing");
+    const long npp = (long)nv * (nv + 1) / 2;
+    if (row0 < 0 || row1 > npp || row0 > row1) throw std::runtime_error("ladder_dress: bad pair-row range");
+    if (row1 == row0) return;
+    const long nt = (nv + 15) / 16, ntp = nt * (nt + 1) / 2, ncdb = ld / 16, nblk = 8 * ((ncdb + 7) / 8) * ntp;
+    if (nblk > 0x7fffffffL) throw std::runtime_error("ladder_dress: grid too large");
+    // per-lane byte offsets inside a tile are 32-bit: 16 rows of Pk / the rows of 16 a of V
+    if (8.0 * (double)ld * (15.0 * nv + 136.0) >= 4294967296.0) throw std::runtime_error("ladder_dress: tile extent exceeds 32-bit offsets");
+    const dim3 grid((unsigned)nblk), block(64);
+    hipStream_t st = (hipStream_t)s;
+    const int nk = (no + 3) / 4;
+    const long nfrag = ladder_dress_ws_doubles(no, nv);
+    hipLaunchKernelGGL(ladder_dress_tfrag_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, t1, ws, no, nv, nk, nfrag);
+#define PYMES_DRESS(NK) case NK: hipLaunchKernelGGL(ladder_dress_kernel<NK>, grid, block, 0, st, V, Pk, (const double*)ws, W, no, nv, (long)ld, (long)row0, (long)row1, sgn, ntp); break;
+    switch (nk) {
+        PYMES_DRESS(1) PYMES_DRESS(2) PYMES_DRESS(3) PYMES_DRESS(4) PYMES_DRESS(5) PYMES_DRESS(6) PYMES_DRESS(7) PYMES_DRESS(8)
+        PYMES_DRESS(9) PYMES_DRESS(10) PYMES_DRESS(11) PYMES_DRESS(12) PYMES_DRESS(13) PYMES_DRESS(14) PYMES_DRESS(15) PYMES_DRESS(16)
+    }
+#undef PYMES_DRESS
     HIP_CHECK(hipGetLastError());
 }
 

@@ -492,6 +492,12 @@ class Context:
                       int(dressed))
         return L_all
 
+    def ladder_dress(self, V, Pk, t1, W, ld, r0, r1, minus_half=False):
+        """T1 dressing of the bra of pair-packed rows [r0,r1) of V_abcd (ccsd.py:414-419; include/pymes_amd.h)."""
+        self.lib.call("pymes_ladder_dress", self.handle, C.c_void_p(V.ptr), C.c_void_p(Pk.ptr), C.c_void_p(t1.ptr),
+                      C.c_void_p(W.ptr), int(ld), int(r0), int(r1), int(minus_half))
+        return W
+
     def pair_layouts(self, x, Xx, Xt, Xd=None):
         """Xx[(a,j),(b,i)] = x_abij, Xt[(a,i),(b,j)] = 2 x_abij - x_baij (and Xd[(a,i),(b,j)] = x_abij) in one pass."""
         self.lib.call("pymes_pair_layouts", self.handle, C.c_void_p(x.ptr), C.c_void_p(Xd.ptr if Xd is not None else 0),

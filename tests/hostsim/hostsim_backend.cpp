@@ -288,6 +288,30 @@ void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nv, int6
         }
 }
 
+bool ladder_dress_ok(int no) { return no >= 1 && no <= 64; }
+
+int64_t ladder_dress_ws_doubles(int no, int nv) { return (int64_t)((nv + 15) / 16) * ((no + 3) / 4) * 64; }
+
+void ladder_dress(const double* V, const double* Pk, const double* t1, double* W, int no, int nv, int64_t ld, int64_t row0,
+                  int64_t row1, double sgn, double*, stream_t) {
+    if (!ladder_dress_ok(no)) throw std::runtime_error("ladder_dress: nocc outside 1..64");
+    for (int a = 0; a < nv; ++a)
+        for (int b = 0; b <= a; ++b) {
+            const int64_t r = P2(a, b);
+            if (r < row0 || r >= row1) continue;
+            const double* v = V + (r - row0) * ld;
+            double* w = W + (r - row0) * ld;
+            for (int64_t c = 0; c < ld; ++c) {
+                double s1 = 0.0, s2 = 0.0;
+                for (int k = 0; k < no; ++k) {
+                    s1 += t1[(int64_t)a * no + k] * Pk[((int64_t)b * no + k) * ld + c];
+                    s2 += t1[(int64_t)b * no + k] * Pk[((int64_t)a * no + k) * ld + c];
+                }
+                w[c] = (sgn > 0.0 && a == b) ? 0.0 : v[c] - s1 + sgn * s2;
+            }
+        }
+}
+
 void ladder_pack_T(const double* T, const double* t1, double* Sp, double* Am, int no, int nv, int flags, int64_t ldp,
                    int64_t ldm, stream_t, int64_t rp0, int64_t rp1) {
     if (rp1 < 0) { rp0 = 0; rp1 = (int64_t)nv * (nv + 1) / 2; }

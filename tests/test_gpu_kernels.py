@@ -255,3 +255,47 @@ def test_mixer_against_reference_golden_gpu(gpu_lib):
     coefficients read from HBM) and the host solve, on the reference's own DIIS.mix sequence (tests/golden/diis.json)."""
     from tests.test_host_round2 import check_mixer_against_reference_golden
     check_mixer_against_reference_golden(gpu_lib)
+
+
+def ladder_dress_reference(V, Pk, t1, no, nv, r0, r1, minus):
+    """numpy statement of pymes_ladder_dress (include/pymes_amd.h): rows P(a,b) in [r0,r1) of one packed half."""
+    W = np.empty_like(V)
+    P3 = Pk.reshape(nv, no, -1)
+    for a in range(nv):
+        for b in range(a + 1):
+            r = a * (a + 1) // 2 + b
+            if r0 <= r < r1:
+                s1 = t1[a] @ P3[b]
+                s2 = t1[b] @ P3[a]
+                W[r - r0] = 0.0 if (minus and a == b) else V[r - r0] - s1 + (s2 if minus else -s2)
+    return W
+
+
+def check_ladder_dress(lib, no, nv, ld, r0, r1, minus, seed=0):
+    rng = np.random.default_rng(seed)
+    V = rng.standard_normal((r1 - r0, ld))
+    Pk = rng.standard_normal((no * nv, ld))
+    t1 = rng.standard_normal((nv, no))
+    ctx = Context(no, nv, lib=lib, workspace_bytes=1 << 20)
+    try:
+        W = ctx.zeros((r1 - r0, ld))
+        ctx.ladder_dress(ctx.array(V), ctx.array(Pk), ctx.array(t1), W, ld, r0, r1, minus_half=minus)
+        got = W.get()
+    finally:
+        ctx.close()
+    ref = ladder_dress_reference(V, Pk, t1, no, nv, r0, r1, minus)
+    assert np.abs(got - ref).max() < 1e-12 * max(1.0, np.abs(ref).max()) * no, (no, nv, ld, r0, r1, minus)
+
+
+DRESS_CASES = [  # no, nv, ld, r0, r1
+    (3, 5, 16, 0, 15), (2, 16, 144, 0, 136), (5, 17, 160, 0, 153), (7, 33, 64, 0, 561), (13, 20, 208, 37, 161),
+    (50, 21, 80, 0, 231), (64, 18, 32, 5, 171), (1, 4, 16, 0, 10), (20, 40, 832, 100, 777), (4, 35, 48, 629, 630),
+]
+
+
+@pytest.mark.parametrize("minus", [False, True])
+def test_ladder_dress_kernel(gpu_lib, minus):
+    """Bra dressing of the pair-packed V_abcd (MFMA rank-nocc updates turned through LDS): ragged tiles in a, b and nocc,
+    diagonal tiles, row ranges that cut tiles, pitches that leave waves of the last column block without work."""
+    for i, (no, nv, ld, r0, r1) in enumerate(DRESS_CASES):
+        check_ladder_dress(gpu_lib, no, nv, ld, r0, r1, minus, seed=i)

@@ -528,3 +528,11 @@ def test_ring_terms_in_four_products():
     Z4, U4 = ((2.0 * Vd - Vx) @ Ttd).reshape(v, o, v, o), (Vx @ Tx).reshape(v, o, v, o)
     assert np.abs((3.0 * np.einsum("ckak->ac", U4) + np.einsum("ckak->ac", Z4)) / 4.0 - S_ac).max() < 1e-12
     assert np.abs((3.0 * np.einsum("ckci->ki", U4) + np.einsum("ckci->ki", Z4)) / 4.0 - S_ki).max() < 1e-12
+
+
+@pytest.mark.parametrize("minus", [False, True])
+def test_ladder_dress_host_statement(hostsim_lib, minus):
+    """The CPU stand-in of the dressing kernel against the numpy statement the GPU test uses."""
+    from tests.test_gpu_kernels import DRESS_CASES, check_ladder_dress
+    for i, (no, nv, ld, r0, r1) in enumerate(DRESS_CASES[:5]):
+        check_ladder_dress(hostsim_lib, no, nv, ld, r0, r1, minus, seed=i)
