@@ -1316,45 +1316,52 @@ __global__ void __launch_bounds__(64) ladder_dress_kernel(const double* __restri
         ta[kk] = tf[((long)ta_ * NK + kk) * 64 + lane];
         tb[kk] = tf[((long)tb_ * NK + kk) * 64 + lane];
     }
-    // MFMA B operand, step kk, partner x: Pk[(x no + 4 kk + g) ld + col] = (uniform base of (kk, x)) + 32-bit byte offset
-    // of the lane (the no rows of a partner are consecutive: one chain reads 8 MB of address space, not no pages);
-    // only the last step can run past no: its lanes are clamped to row no - 1 (their t is zero)
-    const long col = cdb * 16 + c, kstep = 4L * ld;
+    // MFMA B operand, step kk, partner x: Pk[(x no + 4 kk + g) ld + col] (the no rows of a partner are consecutive: one
+    // chain reads 8 MB of address space, not no pages).  All global accesses are raw buffer operations: resource base =
+    // first row of the tile's partners (Pk) / of the tile (V, W), a wave-uniform soffset picks the partner and the step,
+    // a loop-invariant 32-bit voffset the lane — no vector address arithmetic and no branch in the chains; a voffset at
+    // or above the 2-GB record count switches a lane off (loads return 0, stores are dropped): rows that do not exist.
+    // Only the last step can run past no: its lanes are clamped to row no - 1 (their t is zero).
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    constexpr unsigned kOff = 0x80000000u;          // num_records, and the "lane off" voffset
+    const long col = cdb * 16 + c;
     const unsigned lo = (unsigned)(8 * ((long)g * ld + col));
     const unsigned lo_last = (unsigned)(8 * ((long)(min(4 * (NK - 1) + g, no - 1) - 4 * (NK - 1)) * ld + col));
-    auto at = [](const double* base, unsigned byte_off) {
-        return reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off);
-    };
-    // rows of V / W: P(a0 + g + 4 r, bb) - row0 = (tri0 + bb - row0) + [P(a0 + g + 4 r, 0) - tri0]
+    const unsigned ldb = (unsigned)(8 * ld);       // row pitch in bytes (host: tile extents stay below 2 GB)
+    const __amdgpu_buffer_rsrc_t rPa = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Pk + (long)a0 * no * ld), 0, kOff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rPb = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Pk + (long)b0 * no * ld), 0, kOff, 0x00020000);
+    // rows of V / W: P(a0 + g + 4 r, bb) - row0 = (tri0 - row0) [base] + bb [soffset] + P(a0 + g + 4 r, 0) - tri0 [voffset]
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(V + (tri0 - row0) * ld), 0, kOff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(W + (tri0 - row0) * ld, 0, kOff, 0x00020000);
     unsigned vo[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const long a = a0 + g + 4 * r;
-        vo[r] = (unsigned)(8 * ((a * (a + 1) / 2 - tri0) * ld + col));
+        vo[r] = a < nv ? (unsigned)(8 * ((a * (a + 1) / 2 - tri0) * ld + col)) : kOff;
     }
+    auto row_off = [&](int r, int x) {              // voffset of row (a0 + g + 4 r, x), or "off"
+        const int a = a0 + g + 4 * r;
+        const long row = (long)a * (a + 1) / 2 + x;
+        return (x <= a && row >= row0 && row < row1) ? vo[r] : kOff;
+    };
     // Chains 0..15: second term, partner a0 + n; 16..31: first term, partner b0 + n - 16; run in pairs.  Register sets of
     // the right factors: PA pairs ahead of the current one; of the V rows (HBM latency, non-temporal): VA pairs ahead.
     constexpr int PA = 1, NBP = 2 * (PA + 1), VA = 3, NBV = 2 * (VA + 1);
     double pf[NBP][NK], vin[NBV][4];
     auto fetch_p = [&](int n) {
-        const int x = n < 16 ? a0 + n : b0 + n - 16;
-        const double* __restrict__ ps = Pk + (long)min(x, nv - 1) * no * ld;
+        const int x0 = n < 16 ? a0 : b0, i = n < 16 ? n : n - 16;
+        const unsigned so = (unsigned)(min(x0 + i, nv - 1) - x0) * (unsigned)no * ldb;
+        const __amdgpu_buffer_rsrc_t rs = n < 16 ? rPa : rPb;
 #pragma unroll
-        for (int kk = 0; kk < NK - 1; ++kk) pf[n % NBP][kk] = *at(ps + kk * kstep, lo);
-        pf[n % NBP][NK - 1] = *at(ps + (NK - 1) * kstep, lo_last);
+        for (int kk = 0; kk < NK - 1; ++kk)
+            pf[n % NBP][kk] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lo, so + 4u * kk * ldb, 0));
+        pf[n % NBP][NK - 1] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lo_last, so + 4u * (NK - 1) * ldb, 0));
     };
     auto fetch_v = [&](int n) {
         const int x = b0 + n - 16;
-        const double* __restrict__ vs = V + (tri0 + x - row0) * ld;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int a = a0 + g + 4 * r;
-            const long row = (long)a * (a + 1) / 2 + x;
-            const bool ok = a < nv && x <= a && row >= row0 && row < row1;
-            // a valid address either way and no select on the value (it would be scheduled right behind the load and park
-            // the wave for an HBM round trip): rows that do not exist compute garbage that is never stored
-            vin[n % NBV][r] = __builtin_nontemporal_load(ok ? at(vs, vo[r]) : V);
-        }
+        for (int r = 0; r < 4; ++r)
+            vin[n % NBV][r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rV, row_off(r, x), (unsigned)x * ldb, 2));
     };
 #pragma unroll
     for (int n = 0; n < 2 * PA; ++n) fetch_p(n);
@@ -1398,14 +1405,10 @@ __global__ void __launch_bounds__(64) ladder_dress_kernel(const double* __restri
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int bb = b0 + b + h;
-            double* __restrict__ ws = W + (tri0 + bb - row0) * ld;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int a = a0 + g + 4 * r;
-                const long row = (long)a * (a + 1) / 2 + bb;
-                if (a < nv && bb <= a && row >= row0 && row < row1)
-                    __builtin_nontemporal_store((sgn > 0.0 && a == bb) ? 0.0 : (double)(h ? acc1[r] : acc0[r]),
-                                                const_cast<double*>(at(ws, vo[r])));
+                const double val = (sgn > 0.0 && a0 + g + 4 * r == bb) ? 0.0 : (double)(h ? acc1[r] : acc0[r]);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, val), rW, row_off(r, bb), (unsigned)bb * ldb, 2);
             }
         }
     }
