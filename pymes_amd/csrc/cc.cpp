@@ -842,15 +842,16 @@ void Engine::hole_ladder_packed(const double* x, const double* I, double* L, int
 //                  instead of T_abkl also covers the (k,l)-bra part of V~_abij                      -> L rows
 // V~_abij must therefore be dressed in its reduced form (dress_V bit 16), V~_klij in full; V_abcd is never dressed:
 // no o v^4 work and no second copy of V_abcd per iteration.
-// Does the bra dressing of the packed V_abcd beat the Q_kb products?  Only for a rank that holds all pair rows and all
-// (k,b) rows (one GPU).  Model: the dressing streams V in and W out (16 B per element) at ~4 TB/s effective; the Q
-// products run 2 qrows (npp opp + npm opm) flops at ~70 TFLOP/s.  PYMES_LADDER_DRESS=0/1 overrides the model.
-bool Engine::bra_dress_pays(int64_t rows, int64_t qrows) const {
+// Does the bra dressing of the packed V_abcd beat the Q_kb products?  The answer must be the same on every rank (a rank
+// that dresses its rows expects QK without Q from all the others), so the model looks at the whole problem — both
+// costs shrink with the number of ranks alike: the dressing streams V in and W out (16 B per element) at ~4 TB/s
+// effective; the Q products run 2 ov (npp opp + npm opm) flops at ~70 TFLOP/s.  PYMES_LADDER_DRESS=0/1 overrides it.
+bool Engine::bra_dress_pays() const {
     const int64_t o = no, v = nv, npp = v * (v + 1) / 2, npm = v * (v - 1) / 2, opp = o * (o + 1) / 2, opm = o * (o - 1) / 2;
-    if (rows != npp || qrows != o * v || !dev::ladder_dress_ok(no)) return false;
+    if (!dev::ladder_dress_ok(no)) return false;
     if (const char* e = getenv("PYMES_LADDER_DRESS")) return atoi(e) != 0;
     const double t_dress = 16.0 * double(npp) * double(npp + npm) / 4.0e12 + 20e-6;
-    const double t_q = 2.0 * double(qrows) * (double(npp) * double(opp) + double(npm) * double(opm)) / 70e12;
+    const double t_q = 2.0 * double(o * v) * (double(npp) * double(opp) + double(npm) * double(opm)) / 70e12;
     return t_dress < 0.8 * t_q;
 }
 
@@ -875,10 +876,10 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
         dev::ladder_pack_V(block(P_abcd).p, lpack_.Vp, lpack_.Vm, nv, nv, row0, row1, stream, lpitch(npp), lpitch(std::max<int64_t>(npm, 1)));
         lpack_.row0 = row0; lpack_.row1 = row1; lpack_.dressed = false; lpack_.valid = true;
     }
-    // Bra dressing of the packed V_abcd instead of the Q_kb products (one rank, all rows): the two rank-no updates of
+    // Bra dressing of the rank's rows of the packed V_abcd instead of its share of the Q_kb products: the two rank-no updates of
     // dev::ladder_dress move 2 x 6.5 GB at (50,200) where Q_kbij = sum_cd V_kbcd tau_cdij costs 1.0e12 flops (13.9 ms);
     // the dressed copy W takes the place of V in the ladder product and QK carries the small brackets only.
-    const bool dress = bra_dress_pays(rows, qrows);
+    const bool dress = bra_dress_pays();
     const std::string kkey = ":" + std::to_string(q0) + ":" + std::to_string(q1);
     if (dress && !static_.count("VpKx")) {
         // rows (x,k) of V_kxcd (x slow), pair-packed over (c,d): packed in the order of the block, rows transposed
@@ -887,14 +888,17 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
         double* tm = static_cast<double*>(dev::dmalloc(sizeof(double) * ov * lm));
         static_["VpKx"] = static_cast<double*>(dev::dmalloc(sizeof(double) * ov * lp));
         static_["VmKx"] = static_cast<double*>(dev::dmalloc(sizeof(double) * ov * lm));
-        static_["VpDress"] = static_cast<double*>(dev::dmalloc(sizeof(double) * npp * lp));
-        static_["VmDress"] = static_cast<double*>(dev::dmalloc(sizeof(double) * npp * lm));
         dev::ladder_pack_V(block(P_iabc).p, tp, tm, 0, nv, 0, ov, stream, lp, lm);
         permute(1.0, make_view(tp, {o, v, lp}), "kxc", 0.0, make_view(static_["VpKx"], {v, o, lp}), "xkc");
         permute(1.0, make_view(tm, {o, v, lm}), "kxc", 0.0, make_view(static_["VmKx"], {v, o, lm}), "xkc");
         dev::stream_sync(stream);
         dev::dfree(tp);
         dev::dfree(tm);
+    }
+    const std::string rkey = ":" + std::to_string(row0) + ":" + std::to_string(row1);
+    if (dress && rows > 0 && !static_.count("VpDress" + rkey)) {        // the dressed copy of this rank's rows
+        static_["VpDress" + rkey] = static_cast<double*>(dev::dmalloc(sizeof(double) * rows * lpitch(npp)));
+        static_["VmDress" + rkey] = static_cast<double*>(dev::dmalloc(sizeof(double) * rows * lpitch(std::max<int64_t>(npm, 1))));
     }
     if (!dress && qrows > 0 && !static_.count("VpK" + kkey)) {
         double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * qrows * lpitch(npp)));
@@ -925,16 +929,16 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
         TView SpT = pitched(Sp, npp, opp, ldp), AmT = pitched(Am, npm, opm, ldm);
         const double* Ap = lpack_.Vp;
         const double* Am_ = lpack_.Vm;
-        if (dress) {
+        if (dress && rows > 0) {
             ArenaScope s3(arena);
             double* ws = arena.alloc(dev::ladder_dress_ws_doubles(no, nv));
-            dev::ladder_dress(lpack_.Vp, static_["VpKx"], t1, static_["VpDress"], no, nv, lpitch(npp), 0, npp, -1.0, ws, stream);
+            dev::ladder_dress(lpack_.Vp, static_["VpKx"], t1, static_["VpDress" + rkey], no, nv, lpitch(npp), row0, row1, -1.0, ws, stream);
             if (npm > 0)
-                dev::ladder_dress(lpack_.Vm, static_["VmKx"], t1, static_["VmDress"], no, nv, lpitch(npm), 0, npp, 1.0, ws, stream);
+                dev::ladder_dress(lpack_.Vm, static_["VmKx"], t1, static_["VmDress" + rkey], no, nv, lpitch(npm), row0, row1, 1.0, ws, stream);
             stats.permute_calls += 2;
-            stats.permute_bytes += 8.0 * 2.0 * double(npp) * double(lpitch(npp) + (npm > 0 ? lpitch(npm) : 0));
-            Ap = static_["VpDress"];
-            Am_ = static_["VmDress"];
+            stats.permute_bytes += 8.0 * 2.0 * double(rows) * double(lpitch(npp) + (npm > 0 ? lpitch(npm) : 0));
+            Ap = static_["VpDress" + rkey];
+            Am_ = static_["VmDress" + rkey];
         }
         if (rows > 0) {
             contract(1.0, packed_rows(const_cast<double*>(Ap), rows, npp), "rk", SpT, "kn", 0.0, LS, "rn");

@@ -251,7 +251,7 @@ class Engine {
         int64_t row0 = 0, row1 = 0;
         bool dressed = false, valid = false;
     } lpack_;
-    bool bra_dress_pays(int64_t rows, int64_t qrows) const;
+    bool bra_dress_pays() const;
     double* splitk_ws_ = nullptr;
     int64_t splitk_doubles_ = 0;
     double* get_static(const std::string& key);

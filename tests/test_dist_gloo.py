@@ -208,10 +208,13 @@ def test_owner_tile_plan_covers_what_the_assembly_reads(no, nv, world):
         assert max(recv) < 0.21e9 and 2 * 8 * ov * ov * 7 // 8 > 1.3e9
 
 
-@pytest.mark.parametrize("world", [2, 3, 8])        # 8: more ranks than some index ranges have chunks (empty shares)
-def test_distributed_solver_host_logic(hostsim_lib, world):
+@pytest.mark.parametrize("world,dress", [(2, "0"), (3, "0"), (8, "0"), (2, "1"), (8, "1")])
+def test_distributed_solver_host_logic(hostsim_lib, world, dress, monkeypatch):
+    """8: more ranks than some index ranges have chunks (empty shares).  dress = "1": every rank dresses the bra of its
+    rows of the packed V_abcd (PYMES_LADDER_DRESS, inherited by the spawned ranks) instead of forming its Q_kb share."""
     from oracle import cc_oracle as oc
     from oracle.cases import synthetic_case
+    monkeypatch.setenv("PYMES_LADDER_DRESS", dress)
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_solver_worker, args=(world, _free_port(), hostsim_lib.path, out), nprocs=world, join=True)

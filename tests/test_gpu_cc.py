@@ -156,3 +156,11 @@ def test_pair_packed_ladder(gpu_lib, no, nv, seed):
 def test_sharded_residual_simulated_ranks(gpu_lib):
     from tests.test_host_engine import sharded_residual_check
     sharded_residual_check(gpu_lib, [(3, 5, 2), (6, 17, 3), (8, 24, 4)], (1, 2, 8), 1e-11)
+
+
+def test_sharded_residual_simulated_ranks_bra_dressed(gpu_lib, monkeypatch):
+    """Every rank dresses the bra of its rows of the pair-packed V_abcd (ladder_dress_kernel with a row range) instead of
+    forming its share of Q_kb."""
+    from tests.test_host_engine import sharded_residual_check
+    monkeypatch.setenv("PYMES_LADDER_DRESS", "1")
+    sharded_residual_check(gpu_lib, [(3, 5, 2), (6, 17, 3), (8, 24, 4)], (1, 2, 8), 1e-11)

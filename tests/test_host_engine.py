@@ -246,6 +246,12 @@ def test_sharded_residual_host_logic(sim):
     sharded_residual_check(sim, [(2, 3, 1), (3, 5, 2)], (1, 2, 3, 8), 1e-12)
 
 
+def test_sharded_residual_host_logic_bra_dressed(sim, monkeypatch):
+    """The same with every rank dressing the bra of its rows of the packed V_abcd (QK then carries no Q_kb part)."""
+    monkeypatch.setenv("PYMES_LADDER_DRESS", "1")
+    sharded_residual_check(sim, [(2, 3, 1), (3, 5, 2)], (1, 2, 3, 8), 1e-12)
+
+
 def _problem(tag):
     if tag.startswith("syn_"):
         no, nv = (int(x) for x in tag.split("_")[1:])

@@ -35,9 +35,9 @@ def main():
     pdist.world = lambda: (args.rank, args.world, 0)
     pdist.sharded = lambda: True
     pdist.bind_stream = lambda ctx: None
-    pdist.exchange_rows = lambda full, rank, world, ctx=None: full
-    pdist.exchange_rows_start = lambda full, rank, world, ctx=None: Done()
-    pdist.allreduce_tensor_start = lambda t, ctx=None: Done()
+    pdist.exchange_rows = lambda full, rank, world, ctx=None, **kw: full
+    pdist.exchange_rows_start = lambda full, rank, world, ctx=None, **kw: Done()
+    pdist.allreduce_tensor_start = lambda t, ctx=None, **kw: Done()
     pdist.allreduce_sum = lambda v: np.asarray(v, dtype=np.float64)
 
     no, nv = args.nocc, args.nvirt
