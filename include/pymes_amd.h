@@ -198,6 +198,11 @@ int pymes_symmetrised_assemble(pymes_ctx* ctx, const double* V_dev, const double
  * caller then passes only the y-independent part of I). */
 int pymes_hole_ladder_packed(pymes_ctx* ctx, const double* x_dev, const double* I_dev, double* L_dev, int64_t row_begin,
                              int64_t row_end, const double* y_dev);
+/* pymes_hole_ladder_packed (all rows) for k vectors in batched launches: L_all_dev[z] += rows(x_dev[z]) . (2 I_dev[z]
+ * [+ 2 V_klcd y_dev[z]_cdij]); entries of x_dev (or of I_dev) may all be the same array, which is then packed once —
+ * eom_ccsd.py:380-382 over the vectors of a Davidson pass.  y_dev may be NULL. */
+int pymes_hole_ladder_packed_multi(pymes_ctx* ctx, const double* const* x_dev, const double* const* I_dev,
+                                   const double* const* y_dev, int k, double* L_all_dev);
 /* The symmetry-reduced residual (PYMES_SYM_LADDER | PYMES_SYM_RINGS) in its shardable form, one process per
  * GPU.  pymes_residual_slab computes what rank `rank` of `world` owns: the rows [c0,c1) of ETd and ETx (both
  * [o*v][o*v] on the device; ET[(b,j),(a,i)] = Ex[(a,i),(b,j)], rows cut into `world` chunks of ceil(ov/world))

@@ -68,6 +68,7 @@ SIGNATURES = {
     "pymes_ladder": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]),
     "pymes_ladder_sym": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int]),
     "pymes_ladder_sym_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]),
+    "pymes_hole_ladder_packed_multi": (C.c_int, [C.c_void_p, c_pp, c_pp, c_pp, C.c_int, C.c_void_p]),
     "pymes_ladder_sym_multi": (C.c_int, [C.c_void_p, c_pp, C.c_int, C.c_void_p, C.c_int]),
     "pymes_ladder_dress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int]),
     "pymes_pair_layouts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

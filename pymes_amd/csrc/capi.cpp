@@ -341,6 +341,15 @@ int pymes_hole_ladder_packed(pymes_ctx* ctx, const double* x, const double* I, d
         E(ctx).hole_ladder_packed(x, I, L, r0, r1, y);
     });
 }
+int pymes_hole_ladder_packed_multi(pymes_ctx* ctx, const double* const* xs, const double* const* Is, const double* const* ys,
+                                   int k, double* L_all) {
+    return guarded([&] {
+        need(xs, "x"); need(Is, "I"); need(L_all, "L_all");
+        if (k < 1 || k > 64) throw pymes::Error("hole_ladder_packed_multi: 1 <= k <= 64");
+        for (int z = 0; z < k; ++z) { need(xs[z], "x[z]"); need(Is[z], "I[z]"); if (ys) need(ys[z], "y[z]"); }
+        E(ctx).hole_ladder_packed_multi(xs, Is, ys, k, L_all);
+    });
+}
 int pymes_ladder_sym_multi(pymes_ctx* ctx, const double* const* xs, int k, double* L_all, int dressed) {
     return guarded([&] {
         need(xs, "x"); need(L_all, "L_all");

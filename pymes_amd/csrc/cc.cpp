@@ -834,6 +834,87 @@ void Engine::hole_ladder_packed(const double* x, const double* I, double* L, int
     if (opm > 0) contract(1.0, slice(make_view(AmR, {npp, ldp}), 0, row0, row1), "rk", pitched(Im, ldp, opm, ldm), "kn", 1.0, LA, "rn");
 }
 
+// hole_ladder_packed for k vectors in batched launches: L_z += rows(x_z) . (2 pack(I_z) [+ 2 V_klcd y_z, pair-packed]), all
+// rows.  Entries of xs (and of Is) may all be the same pointer — the EOM-CCSD sigma builds call it once with x_z = u2_z
+// against the shared V_klij + V_klcd T_cdij (eom_ccsd.py:380, :382) and once with the shared T against I_z = B5_z +
+// V_kldc u2_z (:381): the shared side is packed once and enters the batched GEMM with batch stride 0.
+void Engine::hole_ladder_packed_multi(const double* const* xs, const double* const* Is, const double* const* ys, int k,
+                                      double* L_all) {
+    const int64_t o = no, v = nv, npp = v * (v + 1) / 2, npm = v * (v - 1) / 2, opp = o * (o + 1) / 2, opm = o * (o - 1) / 2;
+    if (k < 1) return;
+    const int64_t ldp = opp + (opp & 1), ldm = std::max<int64_t>(opm + (opm & 1), 2);
+    bool same_x = true, same_I = true;
+    for (int z = 1; z < k; ++z) { same_x = same_x && xs[z] == xs[0]; same_I = same_I && Is[z] == Is[0]; }
+    if (ys) same_I = false;
+    const int kx = same_x ? 1 : k, ki = same_I ? 1 : k;
+    ArenaScope scope(arena);
+    const int64_t ip_sz = ldp * ldp, im_sz = ldp * ldm;
+    double* Ip = arena.alloc(ki * ip_sz);
+    double* Im = arena.alloc(ki * im_sz);
+    for (int z = 0; z < ki; ++z) {
+        if (ldp > opp) {       // the zero pad row of the K range
+            dev::memset_zero(Ip + z * ip_sz + opp * ldp, sizeof(double) * ldp, stream);
+            dev::memset_zero(Im + z * im_sz + opp * ldm, sizeof(double) * ldm, stream);
+        }
+        dev::ladder_pack_T(Is[z], nullptr, Ip + z * ip_sz, Im + z * im_sz, no, no, dev::PACK_AM_PROWS, ldp, ldm, stream);
+    }
+    int64_t id[3] = {ki, opp, opp}, is_[3] = {ip_sz, ldp, 1}, md[3] = {ki, opp, std::max<int64_t>(opm, 1)}, ms[3] = {im_sz, ldm, 1};
+    TView Ipv = make_view(Ip, 3, id, is_), Imv = make_view(Im, 3, md, ms);
+    if (ys) {
+        if (!static_.count("VpIjab")) {
+            double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * lpitch(npp)));
+            double* vm = static_cast<double*>(dev::dmalloc(sizeof(double) * opp * lpitch(std::max<int64_t>(npm, 1))));
+            static_["VpIjab"] = vp;
+            static_["VmIjab"] = vm;
+            dev::ladder_pack_V(block(P_ijab).p, vp, vm, no, nv, 0, opp, stream, lpitch(npp), lpitch(std::max<int64_t>(npm, 1)));
+        }
+        ArenaScope s2(arena);
+        const int64_t sp_sz = npp * ldp, am_sz = std::max<int64_t>(npm * ldm, 2);
+        double* Sp = arena.alloc(k * sp_sz);
+        double* Am = arena.alloc(k * am_sz);
+        for (int z = 0; z < k; ++z)
+            dev::ladder_pack_T(ys[z], nullptr, Sp + z * sp_sz, Am + z * am_sz, no, nv, dev::PACK_ROW_HALF, ldp, ldm, stream);
+        stats.permute_calls += k;
+        stats.permute_bytes += 8.0 * 2.0 * double(k) * double(v * v * o * o);
+        int64_t bd[3] = {k, npp, opp}, bs[3] = {sp_sz, ldp, 1};
+        contract(2.0, packed_rows(static_["VpIjab"], opp, npp), "rk", make_view(Sp, 3, bd, bs), "zkn", 2.0, Ipv, "zrn", "z");
+        if (opm > 0 && npm > 0) {
+            int64_t bd2[3] = {k, npm, opm}, bs2[3] = {am_sz, ldm, 1};
+            contract(2.0, packed_rows(static_["VmIjab"], opp, npm), "rk", make_view(Am, 3, bd2, bs2), "zkn", 2.0, Imv, "zrn", "z");
+        } else if (opm > 0) {
+            axpby(2.0, Imv, 0.0, Imv);
+        }
+    } else {
+        axpby(2.0, Ipv, 0.0, Ipv);
+        if (opm > 0) axpby(2.0, Imv, 0.0, Imv);
+    }
+    const int64_t xr_sz = npp * ldp;
+    double* SpR = arena.alloc(kx * xr_sz);
+    double* AmR = arena.alloc(kx * xr_sz);
+    for (int z = 0; z < kx; ++z)
+        dev::ladder_pack_T(xs[z], nullptr, SpR + z * xr_sz, AmR + z * xr_sz, no, nv,
+                           dev::PACK_COL_HALF | dev::PACK_AM_PROWS | dev::PACK_AM_PCOLS, ldp, ldp, stream, 0, npp);
+    stats.permute_calls += kx;
+    stats.permute_bytes += 8.0 * 2.0 * double(kx) * double(npp) * 2.0 * double(o * o);
+    // L_z[r][n] += sum_k' X_z[r][k'] I_z[k'][n], K over the padded pitch (zero pad column of X, zero pad row of I)
+    int64_t xd[3] = {kx, npp, ldp}, xst[3] = {xr_sz, ldp, 1};
+    int64_t ikd[3] = {ki, ldp, opp}, ikm[3] = {ki, ldp, std::max<int64_t>(opm, 1)};
+    int64_t cd[3] = {k, npp, opp}, cd2[3] = {k, npp, std::max<int64_t>(opm, 1)}, cs[3] = {npp * o * o, o * o, 1};
+    auto drop = [](const TView& t) { return t.dim[0] == 1 ? std::string() : std::string("z"); };
+    TView XS = make_view(SpR, 3, xd, xst), XA = make_view(AmR, 3, xd, xst);
+    TView IKp = make_view(Ip, 3, ikd, is_), IKm = make_view(Im, 3, ikm, ms);
+    auto spec = [&](const TView& t, const char* two) { return drop(t) + two; };
+    auto squeeze = [&](const TView& t) {
+        if (t.dim[0] != 1) return t;
+        int64_t d2[2] = {t.dim[1], t.dim[2]}, s2[2] = {t.st[1], t.st[2]};
+        return make_view(t.p, 2, d2, s2);
+    };
+    contract(1.0, squeeze(XS), spec(XS, "rk").c_str(), squeeze(IKp), spec(IKp, "kn").c_str(), 1.0, make_view(L_all, 3, cd, cs), "zrn", "z");
+    if (opm > 0)
+        contract(1.0, squeeze(XA), spec(XA, "rk").c_str(), squeeze(IKm), spec(IKm, "kn").c_str(), 1.0,
+                 make_view(L_all + opp, 3, cd2, cs), "zrn", "z");
+}
+
 // T1 dressing of the ladders on the amplitude side.  With X_a^p = delta_ap - t_ak delta_pk the dressed ladder and the
 // (c,d)-ket part of V~_abij are  sum_pq X_a^p X_b^q sum_cd V_pqcd tau_cdij,  tau = T + t1 t1 (exchange-symmetric like T):
 //   (p,q) = (a,b): the pair-packed ladder with the UNDRESSED V_abcd, packed once per solve          -> L rows
@@ -935,8 +1016,6 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
             dev::ladder_dress(lpack_.Vp, static_["VpKx"], t1, static_["VpDress" + rkey], no, nv, lpitch(npp), row0, row1, -1.0, ws, stream);
             if (npm > 0)
                 dev::ladder_dress(lpack_.Vm, static_["VmKx"], t1, static_["VmDress" + rkey], no, nv, lpitch(npm), row0, row1, 1.0, ws, stream);
-            stats.permute_calls += 2;
-            stats.permute_bytes += 8.0 * 2.0 * double(rows) * double(lpitch(npp) + (npm > 0 ? lpitch(npm) : 0));
             Ap = static_["VpDress" + rkey];
             Am_ = static_["VmDress" + rkey];
         }

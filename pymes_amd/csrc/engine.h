@@ -166,6 +166,7 @@ class Engine {
     // the particle ladder of k exchange-symmetric vectors x_z [v,v,o,o] at once: L_all[z] (k consecutive [v(v+1)/2][o*o]
     // arrays) = pair-packed V_abcd . x_z, one batched launch per half (S / A) over all k vectors
     void ladder_sym_multi(const double* const* xs, int k, double* L_all, bool dressed);
+    void hole_ladder_packed_multi(const double* const* xs, const double* const* Is, const double* const* ys, int k, double* L_all);
     void hole_ladder_packed(const double* x, const double* I, double* L, int64_t row0, int64_t row1,
                             const double* y = nullptr);
     void ladder_sym_unpack(const double* L, double* r2, double beta);

@@ -518,6 +518,15 @@ class Context:
                       int(row_begin), int(row_end), C.c_void_p(y.ptr if y is not None else 0))
         return L
 
+    def hole_ladder_packed_multi(self, xs, Is, L_all, ys=None):
+        """``hole_ladder_packed`` over all rows for the k vectors at once (batched launches; entries of ``xs`` / ``Is`` that
+        are all the same array are packed once): L_all[z] += rows(xs[z]) . (2 Is[z] [+ 2 V_klcd ys[z]_cdij])."""
+        k = len(xs)
+        self.lib.call("pymes_hole_ladder_packed_multi", self.handle, ptr_array([x.ptr for x in xs]),
+                      ptr_array([i.ptr for i in Is]), ptr_array([y.ptr for y in ys]) if ys is not None else None, k,
+                      C.c_void_p(L_all.ptr))
+        return L_all
+
     def ladder_sym_unpack(self, L, out, beta=1.0):
         self.lib.call("pymes_ladder_sym_unpack", self.handle, C.c_void_p(L.ptr), C.c_void_p(out.ptr), float(beta))
         return out

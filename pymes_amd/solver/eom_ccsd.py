@@ -292,17 +292,20 @@ class _Sigma:
         c.ladder_sym_multi(u2s, Lall)                                                   # :383, all vectors
         out = []
         S2 = c.empty(D.shape)
+        B5s = []
         for z in range(k):
             Dz, u2, u1 = part(D, z), u2s[z], part(U1, z)
             c.contract("ad,dbij->abij", self.Gvv, u2, out=Dz, beta=1.0)
             c.contract("li,ablj->abij", self.Goo, u2, out=Dz, beta=1.0, batch="ab")
             B5 = c.contract("klid,dj->klij", V["ijka"], u1)
-            B5s = c.permute("klij->klij", B5)
-            c.permute("lkji->klij", B5, out=B5s, beta=1.0)
-            Lz = part(Lall, z)
-            c.hole_ladder_packed(u2, self.B2, Lz, 0, npp)                               # :380, :382
-            c.hole_ladder_packed(T, B5s, Lz, 0, npp, y=u2)                              # :381 (+ the symmetrised u1 term)
-            c.symmetrised_assemble(Dz, part(DdT, z), part(DxT, z), part(S2, z), L=Lz)   # :377 + unpacking in one pass
+            B5s.append(c.permute("klij->klij", B5))
+            c.permute("lkji->klij", B5, out=B5s[z], beta=1.0)
+        # the hole-ladder-shaped terms of all vectors in batched launches (the shared side — V_klij + V_klcd T_cdij, then T —
+        # packed once)
+        c.hole_ladder_packed_multi(u2s, [self.B2] * k, Lall)                            # :380, :382
+        c.hole_ladder_packed_multi([T] * k, B5s, Lall, ys=u2s)                          # :381 (+ the symmetrised u1 term)
+        for z in range(k):
+            c.symmetrised_assemble(part(D, z), part(DdT, z), part(DxT, z), part(S2, z), L=part(Lall, z))   # :377 + unpacking
             out.append((part(S1, z), part(S2, z)))
         return out
 
