@@ -929,7 +929,7 @@ void Engine::hole_ladder_packed_multi(const double* const* xs, const double* con
 // effective; the Q products run 2 ov (npp opp + npm opm) flops at ~70 TFLOP/s.  PYMES_LADDER_DRESS=0/1 overrides it.
 bool Engine::bra_dress_pays() const {
     const int64_t o = no, v = nv, npp = v * (v + 1) / 2, npm = v * (v - 1) / 2, opp = o * (o + 1) / 2, opm = o * (o - 1) / 2;
-    if (!dev::ladder_dress_ok(no)) return false;
+    if (!dev::ladder_dress_ok(no) || dress_off_) return false;
     if (const char* e = getenv("PYMES_LADDER_DRESS")) return atoi(e) != 0;
     const double t_dress = 16.0 * double(npp) * double(npp + npm) / 4.0e12 + 20e-6;
     const double t_q = 2.0 * double(o * v) * (double(npp) * double(opp) + double(npm) * double(opm)) / 70e12;
@@ -960,26 +960,39 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
     // Bra dressing of the rank's rows of the packed V_abcd instead of its share of the Q_kb products: the two rank-no updates of
     // dev::ladder_dress move 2 x 6.5 GB at (50,200) where Q_kbij = sum_cd V_kbcd tau_cdij costs 1.0e12 flops (13.9 ms);
     // the dressed copy W takes the place of V in the ladder product and QK carries the small brackets only.
-    const bool dress = bra_dress_pays();
+    bool dress = bra_dress_pays();
     const std::string kkey = ":" + std::to_string(q0) + ":" + std::to_string(q1);
-    if (dress && !static_.count("VpKx")) {
-        // rows (x,k) of V_kxcd (x slow), pair-packed over (c,d): packed in the order of the block, rows transposed
-        const int64_t lp = lpitch(npp), lm = lpitch(std::max<int64_t>(npm, 1));
-        double* tp = static_cast<double*>(dev::dmalloc(sizeof(double) * ov * lp));
-        double* tm = static_cast<double*>(dev::dmalloc(sizeof(double) * ov * lm));
-        static_["VpKx"] = static_cast<double*>(dev::dmalloc(sizeof(double) * ov * lp));
-        static_["VmKx"] = static_cast<double*>(dev::dmalloc(sizeof(double) * ov * lm));
-        dev::ladder_pack_V(block(P_iabc).p, tp, tm, 0, nv, 0, ov, stream, lp, lm);
-        permute(1.0, make_view(tp, {o, v, lp}), "kxc", 0.0, make_view(static_["VpKx"], {v, o, lp}), "xkc");
-        permute(1.0, make_view(tm, {o, v, lm}), "kxc", 0.0, make_view(static_["VmKx"], {v, o, lm}), "xkc");
-        dev::stream_sync(stream);
-        dev::dfree(tp);
-        dev::dfree(tm);
-    }
     const std::string rkey = ":" + std::to_string(row0) + ":" + std::to_string(row1);
-    if (dress && rows > 0 && !static_.count("VpDress" + rkey)) {        // the dressed copy of this rank's rows
-        static_["VpDress" + rkey] = static_cast<double*>(dev::dmalloc(sizeof(double) * rows * lpitch(npp)));
-        static_["VmDress" + rkey] = static_cast<double*>(dev::dmalloc(sizeof(double) * rows * lpitch(std::max<int64_t>(npm, 1))));
+    if (dress && (!static_.count("VpKx") || (rows > 0 && !static_.count("VpDress" + rkey)))) {
+        // rows (x,k) of V_kxcd (x slow), pair-packed over (c,d): packed in the order of the block, rows transposed; and the
+        // dressed copy W of this rank's rows.  Out of memory (2 x 1.6 GB + 2 x 1.6 GB of scratch + the size of the packed
+        // rows at (50,200)): one rank falls back to the Q_kb form; among several ranks the choice must not diverge.
+        const int64_t lp = lpitch(npp), lm = lpitch(std::max<int64_t>(npm, 1));
+        const bool need_p = !static_.count("VpKx");
+        double *tp = nullptr, *tm = nullptr, *px = nullptr, *mx = nullptr, *wp = nullptr, *wm = nullptr;
+        bool ok = true;
+        auto grab = [&](double*& p, int64_t n) { if (ok) { p = static_cast<double*>(dev::try_dmalloc(sizeof(double) * n)); ok = p != nullptr; } };
+        if (rows > 0) { grab(wp, rows * lp); grab(wm, rows * lm); }
+        if (need_p) { grab(px, ov * lp); grab(mx, ov * lm); grab(tp, ov * lp); grab(tm, ov * lm); }
+        if (!ok) {
+            for (double* p : {tp, tm, px, mx, wp, wm}) dev::dfree(p);
+            if (!(rows == npp && qrows == ov))
+                throw Error("ladder_t1: out of device memory for the dressed copy of the packed V_abcd (PYMES_LADDER_DRESS=0 on every rank selects the Q_kb form)");
+            dress_off_ = true;
+            dress = false;
+        } else {
+            if (rows > 0) { static_["VpDress" + rkey] = wp; static_["VmDress" + rkey] = wm; }
+            if (need_p) {
+                static_["VpKx"] = px;
+                static_["VmKx"] = mx;
+                dev::ladder_pack_V(block(P_iabc).p, tp, tm, 0, nv, 0, ov, stream, lp, lm);
+                permute(1.0, make_view(tp, {o, v, lp}), "kxc", 0.0, make_view(px, {v, o, lp}), "xkc");
+                permute(1.0, make_view(tm, {o, v, lm}), "kxc", 0.0, make_view(mx, {v, o, lm}), "xkc");
+                dev::stream_sync(stream);
+                dev::dfree(tp);
+                dev::dfree(tm);
+            }
+        }
     }
     if (!dress && qrows > 0 && !static_.count("VpK" + kkey)) {
         double* vp = static_cast<double*>(dev::dmalloc(sizeof(double) * qrows * lpitch(npp)));

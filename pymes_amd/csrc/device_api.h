@@ -17,6 +17,7 @@ const char* backend_name();
 // throws std::runtime_error on failure
 void  set_device(int ordinal);
 void* dmalloc(size_t bytes);
+void* try_dmalloc(size_t bytes);      // nullptr when the device is out of memory (the error state is cleared)
 void  dfree(void* p);
 void  memcpy_h2d(void* d, const void* h, size_t bytes, stream_t s);
 void  memcpy_d2h(void* h, const void* d, size_t bytes, stream_t s);

@@ -253,6 +253,7 @@ class Engine {
         bool dressed = false, valid = false;
     } lpack_;
     bool bra_dress_pays() const;
+    bool dress_off_ = false;     // the dressed copy did not fit the device memory once: Q_kb form from then on
     double* splitk_ws_ = nullptr;
     int64_t splitk_doubles_ = 0;
     double* get_static(const std::string& key);

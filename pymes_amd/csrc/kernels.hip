@@ -2222,6 +2222,14 @@ void* dmalloc(size_t bytes) {
     ++g_live_allocs;
     return p;
 }
+void* try_dmalloc(size_t bytes) {
+    void* p = nullptr;
+    const hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return nullptr; }
+    HIP_CHECK(e);
+    ++g_live_allocs;
+    return p;
+}
 void dfree(void* p) {
     if (!p) return;
     HIP_CHECK(hipFree(p));

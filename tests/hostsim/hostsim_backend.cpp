@@ -29,6 +29,12 @@ void* dmalloc(size_t bytes) {
     ++g_live;
     return p;
 }
+void* try_dmalloc(size_t bytes) {
+    // failure injection for the out-of-memory paths of the host logic: requests above the limit "do not fit"
+    if (const char* e = std::getenv("PYMES_HOSTSIM_ALLOC_LIMIT"))
+        if (bytes > (size_t)std::atoll(e)) return nullptr;
+    return dmalloc(bytes);
+}
 void dfree(void* p) {
     if (!p) return;
     std::free(p);

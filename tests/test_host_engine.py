@@ -303,6 +303,26 @@ def test_bra_dressed_ladder_reproduces_reference_energies(sim, monkeypatch, tag,
     assert abs(np.linalg.norm(res["t2"]) - ref["t2_norm"]) < 1e-7
 
 
+def test_bra_dressing_falls_back_when_its_buffers_do_not_fit(sim, monkeypatch):
+    """Out of device memory for the dressed copy of the packed V_abcd (injected in the host simulator): one rank goes on in
+    the Q_kb form — same history, nothing leaked."""
+    import ctypes as C
+    from pymes_amd.solver import ccsd
+    monkeypatch.setenv("PYMES_LADDER_DRESS", "1")
+    monkeypatch.setenv("PYMES_HOSTSIM_ALLOC_LIMIT", "64")
+    ref = SOLVES["syn_4_12"]["ccsd"]
+    no, f, V = _problem("syn_4_12")
+    n0 = C.c_int64()
+    sim.call("pymes_live_allocations", C.byref(n0))
+    s = ccsd.CCSD(no, delta_e=ref["delta_e"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = s.solve(f, V)
+    assert s.iterations == ref["iterations"] and abs(res["ccsd e"] - ref["e"]) < 1e-9
+    n1 = C.c_int64()
+    sim.call("pymes_live_allocations", C.byref(n1))
+    assert n1.value == n0.value
+
+
 def test_public_helper_methods_match_oracle(sim, capsys):
     from pymes_amd.integral.partition import part_2_body_int
     from pymes_amd.solver import ccsd
