@@ -222,6 +222,29 @@ void Engine::ensure_xs() {
     if (!xs_vv_) xs_vv_ = static_cast<double*>(dev::dmalloc(sizeof(double) * nv * nv));
 }
 
+// The three pair layouts of T2 (Td, Tx, Tt_d) in the engine's persistent buffers
+void Engine::pair_layouts_of(const double* t2) {
+    const int64_t o = no, v = nv, ov = o * v;
+    for (auto& p : lay_)
+        if (!p) p = static_cast<double*>(dev::dmalloc(sizeof(double) * ov * ov));
+    lay_t2_ = nullptr;
+    if (dev::fused_pair_kernels_ok(no)) {
+        dev::t2_layouts(t2, lay_[0], lay_[1], lay_[2], no, nv, stream);
+        stats.permute_calls++;
+        stats.permute_bytes += 8.0 * 5.0 * double(ov * ov);
+    } else {
+        TView T = make_view(const_cast<double*>(t2), {v, v, o, o});
+        TView t4 = make_view(lay_[0], {v, o, v, o});
+        permute(1.0, T, "abij", 0.0, t4, "aibj");
+        t4.p = lay_[1];
+        permute(1.0, T, "abij", 0.0, t4, "ajbi");
+        t4.p = lay_[2];
+        permute(2.0, T, "abij", 0.0, t4, "aibj");
+        permute(-1.0, T, "baij", 1.0, t4, "aibj");
+    }
+    lay_t2_ = t2;
+}
+
 void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, double* ETx_p, double* L, int rank,
                            int world, unsigned flags, const double* t1, double* QK, const double* P) {
     const bool dcd = flags & 1u, dressed = flags & 2u, skip_ladder = (flags & 4u) || (flags & 64u), skip_rings = flags & 128u;
@@ -258,24 +281,8 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
     ArenaScope scope(arena);
     auto pairm = [&](double* p) { return make_view(p, {ov, ov}); };
     auto slab = [&]() { return make_view(arena.alloc(ov * nc), {ov, nc}); };
-    for (auto& p : lay_)
-        if (!p) p = static_cast<double*>(dev::dmalloc(sizeof(double) * ov * ov));
-    lay_t2_ = nullptr;
+    pair_layouts_of(t2);
     TView Td = pairm(lay_[0]), Tx = pairm(lay_[1]), Ttd = pairm(lay_[2]);
-    if (dev::fused_pair_kernels_ok(no)) {
-        dev::t2_layouts(t2, Td.p, Tx.p, Ttd.p, no, nv, stream);
-        stats.permute_calls++;
-        stats.permute_bytes += 8.0 * 5.0 * double(ov * ov);
-    } else {
-        TView t4 = make_view(Td.p, {v, o, v, o});
-        permute(1.0, T, "abij", 0.0, t4, "aibj");
-        t4.p = Tx.p;
-        permute(1.0, T, "abij", 0.0, t4, "ajbi");
-        t4.p = Ttd.p;
-        permute(2.0, T, "abij", 0.0, t4, "aibj");
-        permute(-1.0, T, "baij", 1.0, t4, "aibj");
-    }
-    lay_t2_ = t2;
     TView ETd = slice(pairm(ETd_p), 0, c0, c1), ETx = slice(pairm(ETx_p), 0, c0, c1);
     auto cols = [&](const TView& m) { return slice(m, 1, c0, c1); };
     // column slabs (b,j) in [c0,c1) of the static / dressed right-hand factors, straight from the 4-index blocks:

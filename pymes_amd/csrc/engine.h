@@ -217,6 +217,7 @@ class Engine {
     // that read them again (singles residual, residual_finish): persistent buffers, valid for the t2 pointer recorded
     double* lay_[3] = {nullptr, nullptr, nullptr};
     const double* lay_t2_ = nullptr;
+    void pair_layouts_of(const double* t2);
     // S_ki = sum_cdl Tt[c,d,i,l] V[l,k,d,c] and S_ac = sum_dkl Tt[a,d,k,l] V[l,k,d,c] (ccd.py:213-220), or this rank's partial
     // sums of them: X_ki, X_ac AND the singles residual (ccsd.py:434, :436 are the same sums for exchange-symmetric V, T)
     // read them; valid for the t2 pointer recorded, from the producer (residual_slab / slab_prepare / xvv_partial) to the
