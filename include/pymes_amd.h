@@ -178,7 +178,7 @@ int pymes_ladder_sym_multi(pymes_ctx* ctx, const double* const* x_dev, int k, do
  * packed, pitch ld = a multiple of 16 doubles), Pk_dev [v*o][ld] the rows x*o + k of V_kxcd packed the same way (x slow), t1_dev [v,o]:
  *   W[P(a,b)] = V[P(a,b)] - sum_k t1[a,k] Pk[(b,k)] -+ sum_k t1[b,k] Pk[(a,k)]
  * ("-" for the symmetric half V_abcd + V_abdc, "+" with minus_half = 1 for V_abcd - V_abdc, whose rows a == b stay zero).
- * nocc <= 64. */
+ * nocc <= 64; the packed rows of 16 consecutive a within 2 GB (nvirt up to ~320). */
 int pymes_ladder_dress(pymes_ctx* ctx, const double* V_dev, const double* Pk_dev, const double* t1_dev, double* W_dev,
                        int64_t ld, int64_t r0, int64_t r1, int minus_half);
 /* The three pair layouts of an amplitude-like array X [v,v,o,o] in one pass: Xd[(a,i),(b,j)] = X_abij,

@@ -936,7 +936,7 @@ void Engine::hole_ladder_packed_multi(const double* const* xs, const double* con
 // effective; the Q products run 2 ov (npp opp + npm opm) flops at ~70 TFLOP/s.  PYMES_LADDER_DRESS=0/1 overrides it.
 bool Engine::bra_dress_pays() const {
     const int64_t o = no, v = nv, npp = v * (v + 1) / 2, npm = v * (v - 1) / 2, opp = o * (o + 1) / 2, opm = o * (o - 1) / 2;
-    if (!dev::ladder_dress_ok(no) || dress_off_) return false;
+    if (!dev::ladder_dress_ok(no, nv) || dress_off_) return false;
     if (const char* e = getenv("PYMES_LADDER_DRESS")) return atoi(e) != 0;
     const double t_dress = 16.0 * double(npp) * double(npp + npm) / 4.0e12 + 20e-6;
     const double t_q = 2.0 * double(o * v) * (double(npp) * double(opp) + double(npm) * double(opm)) / 70e12;

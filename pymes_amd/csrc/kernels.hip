@@ -2727,13 +2727,18 @@ void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nc, int6
     HIP_CHECK(hipGetLastError());
 }
 
-bool ladder_dress_ok(int no) { return no >= 1 && no <= 64; }
+// nocc within the instantiated MFMA step counts, and the byte offsets inside a tile (16 a of packed rows of the widest half)
+// below the 2-GB record count of the buffer resources
+bool ladder_dress_ok(int no, int nv) {
+    const double ld = (double)((((long)nv * (nv + 1) / 2) + 15) & ~15L);
+    return no >= 1 && no <= 64 && nv >= 1 && 8.0 * ld * (15.0 * nv + 137.0) < 2147483648.0;
+}
 
 int64_t ladder_dress_ws_doubles(int no, int nv) { return (int64_t)((nv + 15) / 16) * ((no + 3) / 4) * 64; }
 
 void ladder_dress(const double* V, const double* Pk, const double* t1, double* W, int no, int nv, int64_t ld, int64_t row0,
                   int64_t row1, double sgn, double* ws, stream_t s) {
-    if (!ladder_dress_ok(no)) throw std::runtime_error("ladder_dress: nocc outside 1..64");
+    if (!ladder_dress_ok(no, nv)) throw std::runtime_error("ladder_dress: nocc outside 1..64 or tile extents beyond 2 GB");
     if (ld <= 0 || (ld & 15)) throw std::runtime_error("ladder_dress: the row pitch must be a multiple of 16 doubles");
     if ((reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(Pk) | reinterpret_cast<uintptr_t>(W)) & 127)
         throw std::runtime_error("ladder_dress: operands must be 128-byte aligned");
@@ -2743,8 +2748,8 @@ void ladder_dress(const double* V, const double* Pk, const double* t1, double* W
     if (row1 == row0) return;
     const long nt = (nv + 15) / 16, ntp = nt * (nt + 1) / 2, ncdb = ld / 16, nblk = 8 * ((ncdb + 7) / 8) * ntp;
     if (nblk > 0x7fffffffL) throw std::runtime_error("ladder_dress: grid too large");
-    // per-lane byte offsets inside a tile are 32-bit: 16 rows of Pk / the rows of 16 a of V
-    if (8.0 * (double)ld * (15.0 * nv + 136.0) >= 4294967296.0) throw std::runtime_error("ladder_dress: tile extent exceeds 32-bit offsets");
+    // per-lane byte offsets inside a tile stay below the record count of the buffer resources (2 GB): the rows of 16 a of V
+    if (8.0 * (double)ld * (15.0 * nv + 137.0) >= 2147483648.0) throw std::runtime_error("ladder_dress: tile extent exceeds the 2-GB buffer window");
     const dim3 grid((unsigned)nblk), block(64);
     hipStream_t st = (hipStream_t)s;
     const int nk = (no + 3) / 4;

@@ -294,13 +294,13 @@ void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nv, int6
         }
 }
 
-bool ladder_dress_ok(int no) { return no >= 1 && no <= 64; }
+bool ladder_dress_ok(int no, int nv) { return no >= 1 && no <= 64 && nv >= 1; }
 
 int64_t ladder_dress_ws_doubles(int no, int nv) { return (int64_t)((nv + 15) / 16) * ((no + 3) / 4) * 64; }
 
 void ladder_dress(const double* V, const double* Pk, const double* t1, double* W, int no, int nv, int64_t ld, int64_t row0,
                   int64_t row1, double sgn, double*, stream_t) {
-    if (!ladder_dress_ok(no)) throw std::runtime_error("ladder_dress: nocc outside 1..64");
+    if (!ladder_dress_ok(no, nv)) throw std::runtime_error("ladder_dress: nocc outside 1..64");
     for (int a = 0; a < nv; ++a)
         for (int b = 0; b <= a; ++b) {
             const int64_t r = P2(a, b);
