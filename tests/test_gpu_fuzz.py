@@ -90,3 +90,24 @@ def test_random_contractions(gpu_lib, seed):
             done += 1
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_random_bra_dressing_shapes(gpu_lib, seed):
+    """ladder_dress_kernel (ccsd.py:414-419 on pair-packed rows) on seeded random extents: every MFMA step count (nocc
+    1..64), ragged and single tiles, pitches of 1..20 column blocks (more than the 8 XCD shares and fewer), row ranges that
+    start and end inside tiles, both halves."""
+    from tests.test_gpu_kernels import check_ladder_dress
+    rng = np.random.default_rng(100 + seed)
+    for case in range(24):
+        no = int(rng.integers(1, 65))
+        nv = int(rng.choice([1, 2, 7, 15, 16, 17, 23, 31, 32, 33, 40, 48, 57]))
+        npp = nv * (nv + 1) // 2
+        ld = 16 * int(rng.integers(1, 21))
+        r0 = int(rng.integers(0, npp))
+        r1 = int(rng.integers(r0 + 1, npp + 1))
+        if rng.random() < 0.4:
+            r0, r1 = 0, npp
+        if no * nv * ld > 4_000_000:
+            ld = 16
+        check_ladder_dress(gpu_lib, no, nv, ld, r0, r1, bool(rng.integers(2)), seed=1000 * seed + case)
