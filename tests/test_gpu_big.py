@@ -62,6 +62,19 @@ def test_c2_solve_history_matches_reference(gpu_lib):
         del os.environ["PYMES_NO_GRAPH"]
         ints.ctx.close()
     assert abs(res2["ccsd e"] - ref["e"]) < 1e-9 and np.abs(res2["t2"] - res["t2"]).max() < 1e-9
+    # and with the T1 dressing of V_abcd carried by the bra dressing of its pair-packed rows (the cost model keeps the
+    # Q_kb form at this size; (50,200) runs this way by default) — same history
+    try:
+        os.environ["PYMES_LADDER_DRESS"] = "1"
+        buf = io.StringIO()
+        s3 = ccsd.CCSD(no, delta_e=ref["delta_e"])
+        with contextlib.redirect_stdout(buf):
+            res3 = s3.solve(f, V)
+    finally:
+        del os.environ["PYMES_LADDER_DRESS"]
+    hist3 = [float(x) for x in re.findall(r"Correlation Energy = (-?[0-9.eE+-]+)", buf.getvalue())]
+    assert s3.iterations == ref["iterations"] and np.abs(np.array(hist3) - np.array(ref["history"])).max() < 1e-9
+    assert np.abs(res3["t2"] - res["t2"]).max() < 1e-9 and np.abs(res3["t1"] - res["t1"]).max() < 1e-9
 
 
 @pytest.mark.parametrize("symmetric", [False, True])
