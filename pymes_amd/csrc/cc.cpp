@@ -970,7 +970,7 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
     bool dress = bra_dress_pays();
     const std::string kkey = ":" + std::to_string(q0) + ":" + std::to_string(q1);
     const std::string rkey = ":" + std::to_string(row0) + ":" + std::to_string(row1);
-    if (dress && (!static_.count("VpKx") || (rows > 0 && !static_.count("VpDress" + rkey)))) {
+    if (dress && rows > 0 && (!static_.count("VpKx") || !static_.count("VpDress" + rkey))) {
         // rows (x,k) of V_kxcd (x slow), pair-packed over (c,d): packed in the order of the block, rows transposed; and the
         // dressed copy W of this rank's rows.  Out of memory (2 x 1.6 GB + 2 x 1.6 GB of scratch + the size of the packed
         // rows at (50,200)): one rank falls back to the Q_kb form; among several ranks the choice must not diverge.
@@ -979,7 +979,7 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
         double *tp = nullptr, *tm = nullptr, *px = nullptr, *mx = nullptr, *wp = nullptr, *wm = nullptr;
         bool ok = true;
         auto grab = [&](double*& p, int64_t n) { if (ok) { p = static_cast<double*>(dev::try_dmalloc(sizeof(double) * n)); ok = p != nullptr; } };
-        if (rows > 0) { grab(wp, rows * lp); grab(wm, rows * lm); }
+        if (!static_.count("VpDress" + rkey)) { grab(wp, rows * lp); grab(wm, rows * lm); }
         if (need_p) { grab(px, ov * lp); grab(mx, ov * lm); grab(tp, ov * lp); grab(tm, ov * lm); }
         if (!ok) {
             for (double* p : {tp, tm, px, mx, wp, wm}) dev::dfree(p);
@@ -988,7 +988,7 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
             dress_off_ = true;
             dress = false;
         } else {
-            if (rows > 0) { static_["VpDress" + rkey] = wp; static_["VmDress" + rkey] = wm; }
+            if (wp) { static_["VpDress" + rkey] = wp; static_["VmDress" + rkey] = wm; }
             if (need_p) {
                 static_["VpKx"] = px;
                 static_["VmKx"] = mx;
