@@ -1707,6 +1707,96 @@ __device__ __forceinline__ FockW fock_w(const double* W, int no, int nv) {
     w.K1 = w.L2 + oo; w.K2 = w.K1 + ov;
     return w;
 }
+// The two T1.V sums of the dressed Fock matrix that read the o v^3 block (ccsd.py:226-288; G1, G2 of dress_fock_partial):
+//   G1[a][c] = sum_{j,b} t[b,j] V[j,a,b,c],     G2[a][c] = sum_{j,b} t[b,j] V[j,a,c,b]
+// in ONE pass over V_iabc in its own layout: for a tile X = V[j,a,:,:] the first is the t_j-weighted sum of its rows, the
+// second the dot of every row with t_j.  One block per (a, chunk of j): a wave takes every fourth row, its lanes two
+// columns each (16-byte loads), the row dots go through a wave reduction; partial results per chunk land in ws
+// [chunk][2][v][v] and are summed by fock_g12_finish_kernel in a fixed order (bit-reproducible).  Replaces two
+// matrix-vector passes over two transposed static copies of the block (2 x 3.2 GB at (50,200)).
+template <int VEC>
+__global__ void __launch_bounds__(256) fock_g12_kernel(const double* __restrict__ V, const double* __restrict__ t1,
+                                                       double* __restrict__ ws, int no, int nv, int j0, int j1, int jper) {
+    extern __shared__ double sm[];
+    double* tj = sm;                 // [nv]     t[:, j]
+    double* y2 = sm + nv;            // [nv]     row dots, summed over the chunk's j
+    double* y1s = sm + 2 * nv;       // [4][nv]  per-wave column sums
+    const int a = blockIdx.x % nv, chunk = blockIdx.x / nv;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int jb = j0 + chunk * jper, je = min(j1, jb + jper);
+    constexpr int QMAX = 8;          // columns per lane: VEC * QMAX * 64 >= nv (host checks)
+    double acc[QMAX][VEC];
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[q][e] = 0.0;
+    for (int i = threadIdx.x; i < nv; i += 256) y2[i] = 0.0;
+    for (int j = jb; j < je; ++j) {
+        __syncthreads();             // tj of the previous j is no longer read; y2 zeroed
+        for (int i = threadIdx.x; i < nv; i += 256) tj[i] = t1[(long)i * no + j];
+        __syncthreads();
+        const double* __restrict__ X = V + ((long)j * nv + a) * nv * nv;
+        for (int b = w; b < nv; b += 8) {          // two rows of the wave per pass: twice the loads in flight
+            const int b2 = b + 4;
+            const bool two = b2 < nv;
+            const double* __restrict__ row = X + (long)b * nv;
+            const double* __restrict__ row2 = X + (long)(two ? b2 : b) * nv;
+            const double tb = tj[b], tb2 = two ? tj[b2] : 0.0;
+            double d = 0.0, d2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q) {
+                const int c = (q * 64 + lane) * VEC;
+                if (c < nv) {
+                    if constexpr (VEC == 2) {
+                        const v2d x = *reinterpret_cast<const v2d*>(row + c), z = *reinterpret_cast<const v2d*>(row2 + c);
+                        const double t0 = tj[c], t1v = tj[c + 1];
+                        acc[q][0] += tb * x[0] + tb2 * z[0];
+                        acc[q][1] += tb * x[1] + tb2 * z[1];
+                        d += x[0] * t0 + x[1] * t1v;
+                        d2 += z[0] * t0 + z[1] * t1v;
+                    } else {
+                        const double x = row[c], z = row2[c], t0 = tj[c];
+                        acc[q][0] += tb * x + tb2 * z;
+                        d += x * t0;
+                        d2 += z * t0;
+                    }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { d += __shfl_down(d, off, 64); d2 += __shfl_down(d2, off, 64); }
+            if (lane == 0) { y2[b] += d; if (two) y2[b2] += d2; }      // rows b, b + 4 belong to this wave alone
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) {
+        const int c = (q * 64 + lane) * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            if (c + e < nv) y1s[w * nv + c + e] = acc[q][e];
+    }
+    __syncthreads();
+    double* __restrict__ o1 = ws + ((long)chunk * 2 * nv + a) * nv;
+    double* __restrict__ o2 = o1 + (long)nv * nv;
+    for (int i = threadIdx.x; i < nv; i += 256) {
+        o1[i] = (y1s[i] + y1s[nv + i]) + (y1s[2 * nv + i] + y1s[3 * nv + i]);
+        o2[i] = y2[i];
+    }
+}
+
+__global__ void fock_g12_finish_kernel(const double* __restrict__ ws, int nchunk, long vv, double* __restrict__ G1,
+                                       double* __restrict__ G2) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= vv) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int c = 0; c < nchunk; ++c) {
+        s1 += ws[(long)c * 2 * vv + i];
+        s2 += ws[(long)c * 2 * vv + vv + i];
+    }
+    G1[i] = s1;
+    G2[i] = s2;
+}
+
 __global__ void fock_ft_kernel(const double* __restrict__ f, const double* __restrict__ t1, const double* __restrict__ W,
                                double* __restrict__ ft, int no, int nv) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2934,6 +3024,31 @@ void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t s)
     const long total = (long)rows * no * no;
     if (!total) return;
     hipLaunchKernelGGL(rows_unpack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, Q, out, no, total);
+    HIP_CHECK(hipGetLastError());
+}
+
+bool fock_g12_ok(int nv) { return nv >= 1 && nv <= 1024; }
+int fock_g12_chunks(int nv, int nj) {          // about 1024 blocks, at least one j per chunk
+    const int want = (1024 + nv - 1) / nv;
+    return std::max(1, std::min(nj, want));
+}
+int64_t fock_g12_ws_doubles(int nv, int nj) { return (int64_t)fock_g12_chunks(nv, nj) * 2 * nv * nv; }
+
+void fock_g12(const double* V, const double* t1, double* G1, double* G2, int no, int nv, int j0, int j1, double* ws, stream_t s) {
+    if (!fock_g12_ok(nv)) throw std::runtime_error("fock_g12: nvirt above 1024");
+    if (j0 < 0 || j1 > no || j0 >= j1) throw std::runtime_error("fock_g12: bad j range");
+    hipStream_t st = (hipStream_t)s;
+    const int nj = j1 - j0, nchunk = fock_g12_chunks(nv, nj), jper = (nj + nchunk - 1) / nchunk;
+    const int used = (nj + jper - 1) / jper;                  // chunks that hold at least one j
+    const size_t lds = sizeof(double) * 6 * (size_t)nv;
+    const dim3 grid((unsigned)(nv * used)), block(256);
+    const bool vec2 = !(nv & 1) && !(reinterpret_cast<uintptr_t>(V) & 15);
+    if (vec2 && nv <= 2 * 8 * 64) hipLaunchKernelGGL(fock_g12_kernel<2>, grid, block, lds, st, V, t1, ws, no, nv, j0, j1, jper);
+    else if (nv <= 8 * 64) hipLaunchKernelGGL(fock_g12_kernel<1>, grid, block, lds, st, V, t1, ws, no, nv, j0, j1, jper);
+    else throw std::runtime_error("fock_g12: odd nvirt above 512");
+    HIP_CHECK(hipGetLastError());
+    const long vv = (long)nv * nv;
+    hipLaunchKernelGGL(fock_g12_finish_kernel, dim3((unsigned)((vv + 255) / 256)), dim3(256), 0, st, ws, used, vv, G1, G2);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -559,6 +559,23 @@ void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t) {
             }
 }
 
+bool fock_g12_ok(int nv) { return nv >= 1 && nv <= 1024; }
+int64_t fock_g12_ws_doubles(int nv, int) { return 2 * (int64_t)nv * nv; }
+void fock_g12(const double* V, const double* t1, double* G1, double* G2, int no, int nv, int j0, int j1, double*, stream_t) {
+    for (int a = 0; a < nv; ++a)
+        for (int c = 0; c < nv; ++c) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int j = j0; j < j1; ++j)
+                for (int b = 0; b < nv; ++b) {
+                    const double t = t1[(int64_t)b * no + j];
+                    s1 += t * V[(((int64_t)j * nv + a) * nv + b) * nv + c];
+                    s2 += t * V[(((int64_t)j * nv + a) * nv + c) * nv + b];
+                }
+            G1[(int64_t)a * nv + c] = s1;
+            G2[(int64_t)a * nv + c] = s2;
+        }
+}
+
 void fock_finish(const double* f, const double* t1, const double* W, double* fd, double* ft, int no, int nv, stream_t) {
     const int64_t n = no + nv, vv = (int64_t)nv * nv, ov = (int64_t)no * nv, oo = (int64_t)no * no;
     const double *G1 = W, *G2 = G1 + vv, *J1 = G2 + vv, *J2 = J1 + ov, *L1 = J2 + ov, *L2 = L1 + oo, *K1 = L2 + oo, *K2 = K1 + ov;
