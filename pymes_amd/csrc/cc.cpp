@@ -1164,11 +1164,14 @@ void Engine::dress_fock_partial(const double* t1, double* W, int rank, int world
     const bool all = (j0 == 0 && j1 == o);       // whole blocks: the planner may reuse its cached transposed copies
     auto js = [&](int pat) { return all ? block(pat) : slice(block(pat), 0, j0, j1); };
     // the two sums over the o v^3 block in one pass over it as stored (no transposed static copies of the block)
-    const bool fused_g12 = dev::fock_g12_ok(nv) && !((nv & 1) && nv > 512) && !getenv("PYMES_NO_FUSED_FOCK");
+    const bool fused_g12 = dev::fock_g12_ok(nv) && !getenv("PYMES_NO_FUSED_FOCK");
     if (fused_g12) {
         ArenaScope s2(arena);
-        double* ws = arena.alloc(dev::fock_g12_ws_doubles(nv, static_cast<int>(j1 - j0)));
-        dev::fock_g12(block(P_iabc).p, t1, G1.p, G2.p, no, nv, static_cast<int>(j0), static_cast<int>(j1), ws, stream);
+        const int ja = static_cast<int>(j0), jb = static_cast<int>(j1);
+        double* ws = arena.alloc(dev::fock_g12_ws_doubles(nv, nv, jb - ja));
+        dev::fock_g12(block(P_iabc).p, t1, G1.p, G2.p, no, nv, nv, ja, jb, ws, stream);
+        double* ws2 = arena.alloc(dev::fock_g12_ws_doubles(nv, no, jb - ja));
+        dev::fock_g12(block(P_ijab).p, t1, J1.p, J2.p, no, nv, no, ja, jb, ws2, stream);
     }
     struct Batch {
         Batch() { dev::gemv_batch_begin(); }
@@ -1180,8 +1183,10 @@ void Engine::dress_fock_partial(const double* t1, double* W, int rank, int world
             contract(1.0, t, "bj", js(P_iabc), "jabc", 0.0, G1, "ac");
             contract(1.0, t, "bj", js(P_iabc), "jacb", 0.0, G2, "ac");
         }
-        contract(1.0, t, "bj", js(P_ijab), "jkbc", 0.0, J1, "kc");
-        contract(1.0, t, "bj", js(P_ijab), "jkcb", 0.0, J2, "kc");
+        if (!fused_g12) {
+            contract(1.0, t, "bj", js(P_ijab), "jkbc", 0.0, J1, "kc");
+            contract(1.0, t, "bj", js(P_ijab), "jkcb", 0.0, J2, "kc");
+        }
         contract(1.0, t, "bj", js(P_ijak), "jkbi", 0.0, L1, "ki");
         contract(1.0, t, "bj", js(P_ijka), "jkib", 0.0, L2, "ki");
         contract(1.0, t, "bj", js(P_iabj), "jabi", 0.0, K1, "ia");

@@ -80,11 +80,13 @@ void gemm(const Gemm& g, stream_t s);
 // (cc.cpp, dress_fock_partial; G = 2 G1 - G2, Mm = 2 J1 - J2, L = 2 L1 - L2), f and fd [n,n], t1 [v,o], ft: o*o scratch:
 //   f~_ov = f_ov + 2 K1 - J2;   ft = (f_ov + Mm) t + L;   f~_oo = f_oo + ft;   f~_vv = f_vv + G - t (f_ov + Mm)
 //   f~_vo = f_vo - t (f_oo + ft) + (f_vv + G) t + 2 K1^T - K2
-// G1[a][c] = sum_{j in [j0,j1), b} t1[b,j] V[j,a,b,c],  G2[a][c] = sum_{j,b} t1[b,j] V[j,a,c,b]  (V = the o v^3 block as stored,
-// [o,v,v,v]) in one pass over V; ws: fock_g12_ws_doubles(nv, j1 - j0) doubles.  fock_g12_ok: nv <= 1024 (odd nv <= 512).
+// G1[a][c] = sum_{j in [j0,j1), b} t1[b,j] V[j,a,b,c],  G2[a][c] = sum_{j,b} t1[b,j] V[j,a,c,b]  for a block V [o,na,v,v] as
+// stored (na = v: the o v^3 block; na = o: the o^2 v^2 block), in one pass over it; G1, G2 are [na,v];
+// ws: fock_g12_ws_doubles(nv, na, j1 - j0) doubles.  fock_g12_ok: nv <= 1024 (odd nv <= 512).
 bool fock_g12_ok(int nv);
-int64_t fock_g12_ws_doubles(int nv, int nj);
-void fock_g12(const double* V, const double* t1, double* G1, double* G2, int no, int nv, int j0, int j1, double* ws, stream_t s);
+int64_t fock_g12_ws_doubles(int nv, int na, int nj);
+void fock_g12(const double* V, const double* t1, double* G1, double* G2, int no, int nv, int na, int j0, int j1, double* ws,
+              stream_t s);
 void fock_finish(const double* f, const double* t1, const double* W, double* fd, double* ft, int no, int nv, stream_t s);
 // Matrix-vector-shaped gemm() calls (M == 1 or N == 1, beta == 0) issued between begin and end are independent of each
 // other by the caller's promise and may be launched together at end (or earlier: any permute / other GEMM flushes them).

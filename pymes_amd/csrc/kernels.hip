@@ -1707,21 +1707,22 @@ __device__ __forceinline__ FockW fock_w(const double* W, int no, int nv) {
     w.K1 = w.L2 + oo; w.K2 = w.K1 + ov;
     return w;
 }
-// The two T1.V sums of the dressed Fock matrix that read the o v^3 block (ccsd.py:226-288; G1, G2 of dress_fock_partial):
+// The direct / exchange pairs of T1.V sums of the dressed Fock matrix (ccsd.py:226-288; G1, G2 and J1, J2 of
+// dress_fock_partial) over a block V[j,a,:,:] with the last two indices virtual (o v^3: a virtual; o^2 v^2: a occupied):
 //   G1[a][c] = sum_{j,b} t[b,j] V[j,a,b,c],     G2[a][c] = sum_{j,b} t[b,j] V[j,a,c,b]
-// in ONE pass over V_iabc in its own layout: for a tile X = V[j,a,:,:] the first is the t_j-weighted sum of its rows, the
+// in ONE pass over the block in its own layout: for a tile X = V[j,a,:,:] the first is the t_j-weighted sum of its rows, the
 // second the dot of every row with t_j.  One block per (a, chunk of j): a wave takes every fourth row, its lanes two
 // columns each (16-byte loads), the row dots go through a wave reduction; partial results per chunk land in ws
 // [chunk][2][v][v] and are summed by fock_g12_finish_kernel in a fixed order (bit-reproducible).  Replaces two
 // matrix-vector passes over two transposed static copies of the block (2 x 3.2 GB at (50,200)).
 template <int VEC>
 __global__ void __launch_bounds__(256) fock_g12_kernel(const double* __restrict__ V, const double* __restrict__ t1,
-                                                       double* __restrict__ ws, int no, int nv, int j0, int j1, int jper) {
+                                                       double* __restrict__ ws, int no, int nv, int na, int j0, int j1, int jper) {
     extern __shared__ double sm[];
     double* tj = sm;                 // [nv]     t[:, j]
     double* y2 = sm + nv;            // [nv]     row dots, summed over the chunk's j
     double* y1s = sm + 2 * nv;       // [4][nv]  per-wave column sums
-    const int a = blockIdx.x % nv, chunk = blockIdx.x / nv;
+    const int a = blockIdx.x % na, chunk = blockIdx.x / na;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int jb = j0 + chunk * jper, je = min(j1, jb + jper);
     constexpr int QMAX = 8;          // columns per lane: VEC * QMAX * 64 >= nv (host checks)
@@ -1735,7 +1736,7 @@ __global__ void __launch_bounds__(256) fock_g12_kernel(const double* __restrict_
         __syncthreads();             // tj of the previous j is no longer read; y2 zeroed
         for (int i = threadIdx.x; i < nv; i += 256) tj[i] = t1[(long)i * no + j];
         __syncthreads();
-        const double* __restrict__ X = V + ((long)j * nv + a) * nv * nv;
+        const double* __restrict__ X = V + ((long)j * na + a) * nv * nv;
         for (int b = w; b < nv; b += 8) {          // two rows of the wave per pass: twice the loads in flight
             const int b2 = b + 4;
             const bool two = b2 < nv;
@@ -1776,8 +1777,8 @@ __global__ void __launch_bounds__(256) fock_g12_kernel(const double* __restrict_
             if (c + e < nv) y1s[w * nv + c + e] = acc[q][e];
     }
     __syncthreads();
-    double* __restrict__ o1 = ws + ((long)chunk * 2 * nv + a) * nv;
-    double* __restrict__ o2 = o1 + (long)nv * nv;
+    double* __restrict__ o1 = ws + ((long)chunk * 2 * na + a) * nv;
+    double* __restrict__ o2 = o1 + (long)na * nv;
     for (int i = threadIdx.x; i < nv; i += 256) {
         o1[i] = (y1s[i] + y1s[nv + i]) + (y1s[2 * nv + i] + y1s[3 * nv + i]);
         o2[i] = y2[i];
@@ -3027,28 +3028,29 @@ void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t s)
     HIP_CHECK(hipGetLastError());
 }
 
-bool fock_g12_ok(int nv) { return nv >= 1 && nv <= 1024; }
-int fock_g12_chunks(int nv, int nj) {          // about 1024 blocks, at least one j per chunk
-    const int want = (1024 + nv - 1) / nv;
+bool fock_g12_ok(int nv) { return nv >= 1 && nv <= 1024 && !((nv & 1) && nv > 512); }
+static int fock_g12_chunks(int na, int nj) {          // about 1024 blocks, at least one j per chunk
+    const int want = (1024 + na - 1) / na;
     return std::max(1, std::min(nj, want));
 }
-int64_t fock_g12_ws_doubles(int nv, int nj) { return (int64_t)fock_g12_chunks(nv, nj) * 2 * nv * nv; }
+int64_t fock_g12_ws_doubles(int nv, int na, int nj) { return (int64_t)fock_g12_chunks(na, nj) * 2 * na * nv; }
 
-void fock_g12(const double* V, const double* t1, double* G1, double* G2, int no, int nv, int j0, int j1, double* ws, stream_t s) {
-    if (!fock_g12_ok(nv)) throw std::runtime_error("fock_g12: nvirt above 1024");
-    if (j0 < 0 || j1 > no || j0 >= j1) throw std::runtime_error("fock_g12: bad j range");
+void fock_g12(const double* V, const double* t1, double* G1, double* G2, int no, int nv, int na, int j0, int j1, double* ws,
+              stream_t s) {
+    if (!fock_g12_ok(nv)) throw std::runtime_error("fock_g12: nvirt above 1024 (odd: 512)");
+    if (j0 < 0 || j1 > no || j0 >= j1 || na < 1) throw std::runtime_error("fock_g12: bad ranges");
     hipStream_t st = (hipStream_t)s;
-    const int nj = j1 - j0, nchunk = fock_g12_chunks(nv, nj), jper = (nj + nchunk - 1) / nchunk;
+    const int nj = j1 - j0, nchunk = fock_g12_chunks(na, nj), jper = (nj + nchunk - 1) / nchunk;
     const int used = (nj + jper - 1) / jper;                  // chunks that hold at least one j
     const size_t lds = sizeof(double) * 6 * (size_t)nv;
-    const dim3 grid((unsigned)(nv * used)), block(256);
+    const dim3 grid((unsigned)(na * used)), block(256);
     const bool vec2 = !(nv & 1) && !(reinterpret_cast<uintptr_t>(V) & 15);
-    if (vec2 && nv <= 2 * 8 * 64) hipLaunchKernelGGL(fock_g12_kernel<2>, grid, block, lds, st, V, t1, ws, no, nv, j0, j1, jper);
-    else if (nv <= 8 * 64) hipLaunchKernelGGL(fock_g12_kernel<1>, grid, block, lds, st, V, t1, ws, no, nv, j0, j1, jper);
-    else throw std::runtime_error("fock_g12: odd nvirt above 512");
+    if (vec2) hipLaunchKernelGGL(fock_g12_kernel<2>, grid, block, lds, st, V, t1, ws, no, nv, na, j0, j1, jper);
+    else if (nv <= 512) hipLaunchKernelGGL(fock_g12_kernel<1>, grid, block, lds, st, V, t1, ws, no, nv, na, j0, j1, jper);
+    else throw std::runtime_error("fock_g12: unaligned block with nvirt above 512");
     HIP_CHECK(hipGetLastError());
-    const long vv = (long)nv * nv;
-    hipLaunchKernelGGL(fock_g12_finish_kernel, dim3((unsigned)((vv + 255) / 256)), dim3(256), 0, st, ws, used, vv, G1, G2);
+    const long av = (long)na * nv;
+    hipLaunchKernelGGL(fock_g12_finish_kernel, dim3((unsigned)((av + 255) / 256)), dim3(256), 0, st, ws, used, av, G1, G2);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -560,16 +560,16 @@ void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t) {
 }
 
 bool fock_g12_ok(int nv) { return nv >= 1 && nv <= 1024; }
-int64_t fock_g12_ws_doubles(int nv, int) { return 2 * (int64_t)nv * nv; }
-void fock_g12(const double* V, const double* t1, double* G1, double* G2, int no, int nv, int j0, int j1, double*, stream_t) {
-    for (int a = 0; a < nv; ++a)
+int64_t fock_g12_ws_doubles(int nv, int na, int) { return 2 * (int64_t)na * nv; }
+void fock_g12(const double* V, const double* t1, double* G1, double* G2, int no, int nv, int na, int j0, int j1, double*, stream_t) {
+    for (int a = 0; a < na; ++a)
         for (int c = 0; c < nv; ++c) {
             double s1 = 0.0, s2 = 0.0;
             for (int j = j0; j < j1; ++j)
                 for (int b = 0; b < nv; ++b) {
                     const double t = t1[(int64_t)b * no + j];
-                    s1 += t * V[(((int64_t)j * nv + a) * nv + b) * nv + c];
-                    s2 += t * V[(((int64_t)j * nv + a) * nv + c) * nv + b];
+                    s1 += t * V[(((int64_t)j * na + a) * nv + b) * nv + c];
+                    s2 += t * V[(((int64_t)j * na + a) * nv + c) * nv + b];
                 }
             G1[(int64_t)a * nv + c] = s1;
             G2[(int64_t)a * nv + c] = s2;
