@@ -252,7 +252,6 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
     const int64_t o = no, v = nv, nn = n, ov = o * v;
     if (world < 1 || rank < 0 || rank >= world) throw Error("residual_slab: bad rank/world");
     const double w = quad ? 1.0 : 0.5;
-    TView T = make_view(const_cast<double*>(t2), {v, v, o, o});
     TView F = make_view(const_cast<double*>(f), {nn, nn});
     auto chunk = [&](int64_t rows, int64_t& lo, int64_t& hi) {
         const int64_t c = (rows + world - 1) / world;
