@@ -299,3 +299,32 @@ def test_ladder_dress_kernel(gpu_lib, minus):
     diagonal tiles, row ranges that cut tiles, pitches that leave waves of the last column block without work."""
     for i, (no, nv, ld, r0, r1) in enumerate(DRESS_CASES):
         check_ladder_dress(gpu_lib, no, nv, ld, r0, r1, minus, seed=i)
+
+
+def check_dressed_fock_from_blocks(lib, no, nv, seed):
+    """ccsd.py:226-288 from the six blocks it reads alone (random, no permutational symmetry), against the oracle."""
+    from oracle import cc_oracle as oc
+    rng = np.random.default_rng(seed)
+    dims = {"o": no, "v": nv}
+    shape = lambda key: tuple(dims["o" if ch in "ijkl" else "v"] for ch in key)
+    Vb = {key: rng.standard_normal(shape(key)) * 0.1 for key in ("iabj", "ijab", "ijak", "iabc", "iajb", "ijka")}
+    n = no + nv
+    f = rng.standard_normal((n, n))
+    f = 0.5 * (f + f.T)
+    t1 = rng.standard_normal((nv, no)) * 0.1
+    ctx = Context(no, nv, lib=lib, workspace_bytes=1 << 24)
+    try:
+        for key, blk in Vb.items():
+            ctx.set_V_block(key, blk)
+        out = ctx.dress_fock(ctx.array(f), ctx.array(t1), ctx.empty((n, n))).get()
+    finally:
+        ctx.close()
+    ref = oc.dressed_fock(no, f, t1, Vb)
+    assert np.abs(out - ref).max() < 1e-11 * max(1.0, np.abs(ref).max()), (no, nv)
+
+
+def test_dressed_fock_one_pass_kernel_extents(gpu_lib):
+    """fock_g12_kernel (the direct / exchange pairs over the o v^3 and o^2 v^2 blocks in one pass): odd and even nvirt, up to
+    eight columns per lane, fewer j than chunks, one occupied orbital."""
+    for i, (no, nv) in enumerate(((3, 131), (2, 257), (5, 128), (1, 64), (7, 33), (2, 512), (4, 200))):
+        check_dressed_fock_from_blocks(gpu_lib, no, nv, i)

@@ -536,3 +536,10 @@ def test_ladder_dress_host_statement(hostsim_lib, minus):
     from tests.test_gpu_kernels import DRESS_CASES, check_ladder_dress
     for i, (no, nv, ld, r0, r1) in enumerate(DRESS_CASES[:5]):
         check_ladder_dress(hostsim_lib, no, nv, ld, r0, r1, minus, seed=i)
+
+
+def test_dressed_fock_from_its_six_blocks(hostsim_lib):
+    """Host logic of dress_fock with the fused direct / exchange sums (CPU stand-in), from the six blocks alone."""
+    from tests.test_gpu_kernels import check_dressed_fock_from_blocks
+    for i, (no, nv) in enumerate(((3, 7), (2, 9), (1, 4))):
+        check_dressed_fock_from_blocks(hostsim_lib, no, nv, i)
