@@ -326,6 +326,17 @@ int pymes_dots_var(pymes_ctx* ctx, int npairs, const double* const* x_dev, const
 /* out = sum_k c[k]*x[k], nx <= 8 */
 int pymes_lincomb(pymes_ctx* ctx, double* out_dev, int nx, const double* const* x_dev, const double* c_host,
                   int64_t n);
+/* Tall-skinny subspace algebra of the Davidson driver (pymes/solver/eom_ccsd.py:91 `QR`, :103-109 the subspace matrix
+ * B[j,l] = <u_j, w_l>, :122-147 collapse / expansion vectors; reference: numpy on host arrays, vector by vector) and of the
+ * FEAST driver (feast_eom_ccsd.py:110-150).  Every vector of a call is read once.
+ * pymes_gram: out_host[i*n + j] = <x_i, y_j>, i < m, j < n, vectors of `len` doubles on the device (m, n <= 64);
+ * deterministic; synchronises the context's stream.
+ * pymes_lincomb_multi: y_j = sum_{i<m} c_host[i*n + j] x_i + beta_host[j] y_j (beta_host NULL = 0; a y_j with beta 0 is
+ * never read); an output may be one of the inputs only when m <= 16 and n <= 4. */
+int pymes_gram(pymes_ctx* ctx, int m, int n, const double* const* x_dev, const double* const* y_dev, int64_t len,
+               double* out_host);
+int pymes_lincomb_multi(pymes_ctx* ctx, int m, int n, const double* const* x_dev, const double* c_host,
+                        const double* beta_host, double* const* y_dev, int64_t len);
 /* One DIIS step (pymes/mixer/diis.py:40-103) with no host round trip.  state_dev: 96 doubles on the device —
  * [0] order of L, [1..81] L (pitch 9), [82..90] coefficients of the last step, [91] 1 if the pseudo-inverse branch
  * (diis.py:85-93) was taken, [92] steps taken; a fresh mixer starts from {1, 0, ...}.  The npairs = ntypes * m overlaps

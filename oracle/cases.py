@@ -47,3 +47,18 @@ def eom_sigma_case(no, nv, seed, scale):
     u2 = rng.standard_normal((nv, nv, no, no)) * 0.05
     u2 = 0.5 * (u2 + u2.transpose(1, 0, 3, 2))
     return fd, V, t2, u1, u2
+
+
+def eom_davidson_case(no, nv, seed=0, scale=0.3):
+    """A synthetic closed-shell problem on which the reference's Davidson driver (eom_ccsd.py:46-167) CONVERGES: V as in
+    ``synthetic_case``; orbital energies with hand-set frontier levels — the three lowest single excitations out of the HOMO
+    are isolated (3.0, 3.4, 3.85; everything else above 4.1).  The driver preconditions with one number per root
+    (e - D_ai[guess] + 1e-5, :139), i.e. it is a restarted block Krylov method, and on the dense spectrum of the SURVEY 8(d)
+    orbital energies (spacing 0.02-0.08) it stalls at |dE| ~ 1e-5 for hundreds of passes, until rounding noise in the
+    exchange-antisymmetric doubles — whose Ritz values are O(s^2), below every physical root — takes the subspace over.
+    Returns (f = diag(eps), V_pqrs)."""
+    _, V, _, _ = synthetic_case(no, nv, seed=seed, scale=scale)
+    rng = np.random.default_rng(seed + 5)
+    eps_o = np.sort(np.concatenate([[-1.5], -2.7 - 0.8 * rng.random(no - 1)]))
+    eps_v = np.sort(np.concatenate([[1.5, 1.9, 2.35], 3.2 + 1.0 * rng.random(nv - 3)]))
+    return np.diag(np.concatenate([eps_o, eps_v])), V

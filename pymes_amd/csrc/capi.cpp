@@ -605,6 +605,27 @@ int pymes_lincomb(pymes_ctx* ctx, double* out, int nx, const double* const* x, c
     });
 }
 
+int pymes_gram(pymes_ctx* ctx, int m, int n, const double* const* x, const double* const* y, int64_t len, double* out) {
+    return guarded([&] {
+        need(x, "x"); need(y, "y"); need(out, "out");
+        if (m < 0 || n < 0 || len < 0) throw pymes::Error("gram: negative size");
+        for (int i = 0; i < m; ++i) need(x[i], "x[i]");
+        for (int j = 0; j < n; ++j) need(y[j], "y[j]");
+        dev::gram(m, n, x, y, len, out, E(ctx).stream);
+    });
+}
+int pymes_lincomb_multi(pymes_ctx* ctx, int m, int n, const double* const* x, const double* c, const double* beta,
+                        double* const* y, int64_t len) {
+    return guarded([&] {
+        need(y, "y");
+        if (m < 0 || n < 0 || len < 0) throw pymes::Error("lincomb_multi: negative size");
+        if (m > 0) { need(x, "x"); need(c, "c"); }
+        for (int i = 0; i < m; ++i) need(x[i], "x[i]");
+        for (int j = 0; j < n; ++j) need(y[j], "y[j]");
+        dev::lincomb_multi(m, n, x, c, beta, y, len, E(ctx).stream);
+    });
+}
+
 int pymes_diis_step(pymes_ctx* ctx, double* state, int npairs, const double* const* x, const double* const* y, const int64_t* n,
                     int ntypes, int m, int was_full) {
     return guarded([&] {

@@ -135,6 +135,15 @@ void cc_update_to(double* t_out, double* dt, const double* t_in, const double* r
                   double shift, double delta, int no, int nv, int rank, stream_t s);
 // out = sum_k c[k] * x_k   (k < nx <= 8)
 void lincomb(double* out, int nx, const double* const* x, const double* c, int64_t n, stream_t s);
+// ---- tall-skinny subspace algebra of the Davidson / FEAST drivers (eom_ccsd.py:91-147, :512-541): every vector is read ONCE
+// per call, whatever the number of inner products / combinations it enters ------------------------------------------------
+// out_host[i * n + j] = <x_i, y_j> for i < m, j < n over vectors of `len` doubles (m, n <= 64); deterministic two-stage
+// reduction; result on the host (synchronises the stream)
+void gram(int m, int n, const double* const* x, const double* const* y, int64_t len, double* out_host, stream_t s);
+// y_j = sum_{i < m} c[i * n + j] x_i + beta[j] y_j  for j < n (c, beta on the host; beta null = 0; m, n <= 64).  A y_j may
+// alias an x_i only when m <= 16 and n <= 4 (one launch: every element is read before it is written)
+void lincomb_multi(int m, int n, const double* const* x, const double* c, const double* beta, double* const* y, int64_t len,
+                   stream_t s);
 // One DIIS step without a host round trip (diis_small.h): the ntypes * m overlaps <x_p, y_p> are reduced on the device, the
 // (m+1) x (m+1) system is updated and solved by one thread, the coefficients land in state[82..]; nothing synchronises.
 void diis_step(double* state, int npairs, const double* const* x, const double* const* y, const int64_t* n, int ntypes, int m,

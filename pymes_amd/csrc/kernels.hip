@@ -1197,6 +1197,118 @@ __global__ void lincomb_kernel(double* __restrict__ out, const LinPtrs p, int nx
     }
 }
 
+// ---- tall-skinny subspace algebra of the Davidson / FEAST drivers (eom_ccsd.py:91-147, :512-541) -------------------------
+// The vectors are 13 M doubles at (30,120) and a pass needs their Gram blocks and a handful of linear combinations: one
+// thread keeps an MM x NN block of accumulators (resp. NN outputs) in registers, so every vector of a call is read ONCE
+// (HBM-bound: MM NN fused multiply-adds per 8 (MM + NN) bytes, far below the vector-ALU rate).  Unused slots of a template
+// size point at slot 0 and are discarded (Gram) / carry a zero coefficient (combination).
+constexpr int kGramBlocks = 1024;
+template <int MM, int NN>
+struct GramPtrs {
+    const double* x[MM];
+    const double* y[NN];
+};
+template <int MM, int NN, int VEC>
+__global__ void __launch_bounds__(256) gram_stage1_kernel(const GramPtrs<MM, NN> p, long len, double* __restrict__ partial) {
+    double acc[MM][NN];
+#pragma unroll
+    for (int i = 0; i < MM; ++i)
+#pragma unroll
+        for (int j = 0; j < NN; ++j) acc[i][j] = 0.0;
+    typedef double vec_t __attribute__((ext_vector_type(VEC)));
+    const long nvec = len / VEC;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < nvec; e += (long)gridDim.x * 256L) {
+        vec_t xv[MM], yv[NN];
+#pragma unroll
+        for (int i = 0; i < MM; ++i) xv[i] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(p.x[i]) + e);
+#pragma unroll
+        for (int j = 0; j < NN; ++j) yv[j] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(p.y[j]) + e);
+#pragma unroll
+        for (int i = 0; i < MM; ++i)
+#pragma unroll
+            for (int j = 0; j < NN; ++j)
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc[i][j] = fma(xv[i][q], yv[j][q], acc[i][j]);
+    }
+    if (VEC > 1 && blockIdx.x == 0 && threadIdx.x == 0)          // the elements past the last whole vector
+        for (long e = nvec * VEC; e < len; ++e)
+#pragma unroll
+            for (int i = 0; i < MM; ++i)
+#pragma unroll
+                for (int j = 0; j < NN; ++j) acc[i][j] = fma(p.x[i][e], p.y[j][e], acc[i][j]);
+    __shared__ double sh[4][MM * NN];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < MM; ++i)
+#pragma unroll
+        for (int j = 0; j < NN; ++j) {
+            const double s = wave_sum(acc[i][j]);
+            if (lane == 0) sh[w][i * NN + j] = s;
+        }
+    __syncthreads();
+    if (threadIdx.x < MM * NN)
+        partial[(long)blockIdx.x * (MM * NN) + threadIdx.x] =
+            (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+// out[idx] = sum over the blocks of partial[b][idx], in a fixed order (one block per output entry)
+__global__ void __launch_bounds__(256) gram_stage2_kernel(const double* __restrict__ partial, int nblocks, int cnt,
+                                                          double* __restrict__ out) {
+    __shared__ double sh[4];
+    const int idx = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += partial[(long)b * cnt + idx];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) out[idx] = s;
+}
+
+template <int MM, int NN>
+struct LinMulti {
+    const double* x[MM];
+    double* y[NN];
+    double c[MM][NN];
+    double beta[NN];
+};
+// y_j = sum_i c[i][j] x_i + beta_j y_j, j < n (n <= NN).  No __restrict__: an output may be one of the inputs (every element
+// is read before it is written, by the same thread)
+template <int MM, int NN, int VEC>
+__global__ void __launch_bounds__(256) lincomb_multi_kernel(const LinMulti<MM, NN> p, int n, long len) {
+    typedef double vec_t __attribute__((ext_vector_type(VEC)));
+    const long nvec = len / VEC;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < nvec; e += (long)gridDim.x * 256L) {
+        vec_t xv[MM], out[NN];
+#pragma unroll
+        for (int i = 0; i < MM; ++i) xv[i] = reinterpret_cast<const vec_t*>(p.x[i])[e];
+#pragma unroll
+        for (int j = 0; j < NN; ++j) {
+            vec_t s = 0.0;
+            if (j < n && p.beta[j] != 0.0) s = p.beta[j] * reinterpret_cast<const vec_t*>(p.y[j])[e];
+            out[j] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < MM; ++i)
+#pragma unroll
+            for (int j = 0; j < NN; ++j) out[j] += p.c[i][j] * xv[i];
+#pragma unroll
+        for (int j = 0; j < NN; ++j)
+            if (j < n) reinterpret_cast<vec_t*>(p.y[j])[e] = out[j];
+    }
+    if (VEC > 1 && blockIdx.x == 0 && threadIdx.x == 0)
+        for (long e = nvec * VEC; e < len; ++e) {
+            double xs[MM], out[NN];
+#pragma unroll
+            for (int i = 0; i < MM; ++i) xs[i] = p.x[i][e];
+#pragma unroll
+            for (int j = 0; j < NN; ++j) out[j] = (j < n && p.beta[j] != 0.0) ? p.beta[j] * p.y[j][e] : 0.0;
+#pragma unroll
+            for (int i = 0; i < MM; ++i)
+#pragma unroll
+                for (int j = 0; j < NN; ++j) out[j] += p.c[i][j] * xs[i];
+#pragma unroll
+            for (int j = 0; j < NN; ++j)
+                if (j < n) p.y[j][e] = out[j];
+        }
+}
+
 // diagonal preconditioner of the FEAST linear solves (feast_eom_ccsd.py:342: 1 / (z - diag + 0.01)) on a complex vector
 __global__ void cmul_kernel(const double* __restrict__ mr, const double* __restrict__ mi, const double* xr, const double* xi,
                             double* yr, double* yi, long n) {
@@ -2163,6 +2275,10 @@ struct Prof {
 constexpr int kMaxDevices = 16;
 double* g_dot_ws[kMaxDevices] = {nullptr};
 double* g_dot_host[kMaxDevices] = {nullptr};
+// Gram blocks: partial sums [kGramBlocks][64] + finished tiles [kGramTiles][64] on the device, the tiles pinned on the host
+constexpr int kGramTiles = 64;
+double* g_gram_ws[kMaxDevices] = {nullptr};
+double* g_gram_host[kMaxDevices] = {nullptr};
 long g_live_allocs = 0;
 
 void wait_idle(hipStream_t st) { HIP_CHECK(hipStreamSynchronize(st)); }
@@ -2790,6 +2906,139 @@ void lincomb(double* out, int nx, const double* const* x, const double* c, int64
     for (int i = 0; i < 8; ++i) { p.x[i] = i < nx ? x[i] : nullptr; p.c[i] = i < nx ? c[i] : 0.0; }
     hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, out, p, nx, (long)n);
     HIP_CHECK(hipGetLastError());
+}
+
+namespace {
+template <int MM, int NN>
+void gram_tile(const double* const* x, int mm, const double* const* y, int nn, long len, bool vec, int nblk, double* ws,
+               double* tile_dev, hipStream_t st) {
+    GramPtrs<MM, NN> p;
+    for (int i = 0; i < MM; ++i) p.x[i] = x[i < mm ? i : 0];
+    for (int j = 0; j < NN; ++j) p.y[j] = y[j < nn ? j : 0];
+    if (vec) hipLaunchKernelGGL((gram_stage1_kernel<MM, NN, 2>), dim3(nblk), dim3(256), 0, st, p, len, ws);
+    else hipLaunchKernelGGL((gram_stage1_kernel<MM, NN, 1>), dim3(nblk), dim3(256), 0, st, p, len, ws);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(gram_stage2_kernel, dim3(MM * NN), dim3(256), 0, st, ws, nblk, MM * NN, tile_dev);
+    HIP_CHECK(hipGetLastError());
+}
+template <int MM>
+void gram_tile_n(const double* const* x, int mm, const double* const* y, int nn, long len, bool vec, int nblk, double* ws,
+                 double* tile_dev, hipStream_t st, int& NNout) {
+    if (nn <= 1) { NNout = 1; gram_tile<MM, 1>(x, mm, y, nn, len, vec, nblk, ws, tile_dev, st); }
+    else if (nn <= 2) { NNout = 2; gram_tile<MM, 2>(x, mm, y, nn, len, vec, nblk, ws, tile_dev, st); }
+    else { NNout = 4; gram_tile<MM, 4>(x, mm, y, nn, len, vec, nblk, ws, tile_dev, st); }
+}
+template <int MM, int NN>
+void lincomb_multi_tile(const double* const* x, int mm, const double* c, int ldc, const double* beta, double* const* y, int nn,
+                        long len, bool vec, hipStream_t st) {
+    LinMulti<MM, NN> p;
+    for (int i = 0; i < MM; ++i) {
+        p.x[i] = x[i < mm ? i : 0];
+        for (int j = 0; j < NN; ++j) p.c[i][j] = (i < mm && j < nn) ? c[(long)i * ldc + j] : 0.0;
+    }
+    for (int j = 0; j < NN; ++j) { p.y[j] = y[j < nn ? j : 0]; p.beta[j] = j < nn ? beta[j] : 0.0; }
+    const long nvec = vec ? len / 2 : len;
+    const int nblk = (int)std::max<long>(1, std::min<long>(8192, (nvec + 255) / 256));
+    if (vec) hipLaunchKernelGGL((lincomb_multi_kernel<MM, NN, 2>), dim3(nblk), dim3(256), 0, st, p, nn, len);
+    else hipLaunchKernelGGL((lincomb_multi_kernel<MM, NN, 1>), dim3(nblk), dim3(256), 0, st, p, nn, len);
+    HIP_CHECK(hipGetLastError());
+}
+template <int MM>
+void lincomb_multi_tile_n(const double* const* x, int mm, const double* c, int ldc, const double* beta, double* const* y, int nn,
+                          long len, bool vec, hipStream_t st) {
+    if (nn <= 1) lincomb_multi_tile<MM, 1>(x, mm, c, ldc, beta, y, nn, len, vec, st);
+    else if (nn <= 2) lincomb_multi_tile<MM, 2>(x, mm, c, ldc, beta, y, nn, len, vec, st);
+    else lincomb_multi_tile<MM, 4>(x, mm, c, ldc, beta, y, nn, len, vec, st);
+}
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+}  // namespace
+
+void gram(int m, int n, const double* const* x, const double* const* y, int64_t len, double* out_host, stream_t s) {
+    if (m <= 0 || n <= 0) return;
+    if (m > 64 || n > 64) throw std::runtime_error("gram: at most 64 x 64 vectors per call");
+    hipStream_t st = (hipStream_t)s;
+    if (len <= 0) {
+        for (int i = 0; i < m * n; ++i) out_host[i] = 0.0;
+        return;
+    }
+    const int dv = current_device();
+    if (!g_gram_ws[dv]) {
+        HIP_CHECK(hipMalloc((void**)&g_gram_ws[dv], sizeof(double) * 64 * (kGramBlocks + kGramTiles)));
+        HIP_CHECK(hipHostMalloc((void**)&g_gram_host[dv], sizeof(double) * 64 * kGramTiles));
+    }
+    // the longer list takes the 16-wide side of the register tile: fewer passes over the vectors
+    const bool swap = n > m;
+    const double* const* X = swap ? y : x;
+    const double* const* Y = swap ? x : y;
+    const int mx = swap ? n : m, ny = swap ? m : n;
+    bool vec = true;
+    for (int i = 0; i < mx; ++i) vec = vec && aligned16(X[i]);
+    for (int j = 0; j < ny; ++j) vec = vec && aligned16(Y[j]);
+    const long nvec = vec ? len / 2 : len;
+    const int nblk = (int)std::max<long>(1, std::min<long>(kGramBlocks, (nvec + 255) / 256));
+    double* ws = g_gram_ws[dv];
+    double* tiles = ws + 64 * kGramBlocks;
+    struct Tile { int i0, mm, j0, nn, NN; };
+    std::vector<Tile> done;
+    auto flush = [&]() {
+        if (done.empty()) return;
+        HIP_CHECK(hipMemcpyAsync(g_gram_host[dv], tiles, sizeof(double) * 64 * done.size(), hipMemcpyDeviceToHost, st));
+        wait_idle(st);
+        for (size_t t = 0; t < done.size(); ++t)
+            for (int i = 0; i < done[t].mm; ++i)
+                for (int j = 0; j < done[t].nn; ++j) {
+                    const double v = g_gram_host[dv][64 * t + i * done[t].NN + j];
+                    const int gi = done[t].i0 + i, gj = done[t].j0 + j;
+                    if (swap) out_host[(long)gj * n + gi] = v;
+                    else out_host[(long)gi * n + gj] = v;
+                }
+        done.clear();
+    };
+    for (int i0 = 0; i0 < mx; i0 += 16)
+        for (int j0 = 0; j0 < ny; j0 += 4) {
+            const int mm = std::min(16, mx - i0), nn = std::min(4, ny - j0);
+            int NN = 4;
+            double* tile = tiles + 64 * done.size();
+            if (mm <= 4) gram_tile_n<4>(X + i0, mm, Y + j0, nn, (long)len, vec, nblk, ws, tile, st, NN);
+            else if (mm <= 8) gram_tile_n<8>(X + i0, mm, Y + j0, nn, (long)len, vec, nblk, ws, tile, st, NN);
+            else gram_tile_n<16>(X + i0, mm, Y + j0, nn, (long)len, vec, nblk, ws, tile, st, NN);
+            done.push_back({i0, mm, j0, nn, NN});
+            if ((int)done.size() == kGramTiles) flush();
+        }
+    flush();
+}
+
+void lincomb_multi(int m, int n, const double* const* x, const double* c, const double* beta, double* const* y, int64_t len,
+                   stream_t s) {
+    if (n <= 0 || len <= 0) return;
+    if (m < 0 || m > 64 || n > 64) throw std::runtime_error("lincomb_multi: at most 64 inputs and 64 outputs per call");
+    if (m > 16 || n > 4)
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < m; ++i)
+                if (y[j] == x[i]) throw std::runtime_error("lincomb_multi: an output may alias an input only for m <= 16, n <= 4");
+    hipStream_t st = (hipStream_t)s;
+    bool vec = true;
+    for (int i = 0; i < m; ++i) vec = vec && aligned16(x[i]);
+    for (int j = 0; j < n; ++j) vec = vec && aligned16(y[j]);
+    double one[4] = {1.0, 1.0, 1.0, 1.0}, b0[4];
+    for (int j0 = 0; j0 < n; j0 += 4) {
+        const int nn = std::min(4, n - j0);
+        for (int j = 0; j < nn; ++j) b0[j] = beta ? beta[j0 + j] : 0.0;
+        if (m == 0) {       // y_j = beta_j y_j
+            const double* none[1] = {y[j0]};
+            const double zero[4] = {0.0, 0.0, 0.0, 0.0};
+            lincomb_multi_tile_n<4>(none, 1, zero, 4, b0, y + j0, nn, (long)len, vec, st);
+            continue;
+        }
+        for (int i0 = 0; i0 < m; i0 += 16) {
+            const int mm = std::min(16, m - i0);
+            const double* bb = i0 == 0 ? b0 : one;
+            const double* cc = c + (long)i0 * n + j0;
+            if (mm <= 4) lincomb_multi_tile_n<4>(x + i0, mm, cc, n, bb, y + j0, nn, (long)len, vec, st);
+            else if (mm <= 8) lincomb_multi_tile_n<8>(x + i0, mm, cc, n, bb, y + j0, nn, (long)len, vec, st);
+            else lincomb_multi_tile_n<16>(x + i0, mm, cc, n, bb, y + j0, nn, (long)len, vec, st);
+        }
+    }
 }
 
 void cmul(const double* mr, const double* mi, const double* xr, const double* xi, double* yr, double* yi, int64_t n, stream_t s) {

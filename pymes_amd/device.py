@@ -617,6 +617,44 @@ class Context:
             first = False
         return out
 
+    def gram(self, xs, ys):
+        """G[i, j] = <xs[i], ys[j]> as a host array; every vector is read once per call (include/pymes_amd.h, pymes_gram)."""
+        m, n = len(xs), len(ys)
+        out = np.zeros((m, n))
+        if m == 0 or n == 0:
+            return out
+        size = xs[0].size
+        assert all(v.size == size for v in list(xs) + list(ys))
+        for i0 in range(0, m, 64):
+            for j0 in range(0, n, 64):
+                xi, yj = xs[i0:i0 + 64], ys[j0:j0 + 64]
+                buf = (C.c_double * (len(xi) * len(yj)))()
+                self.lib.call("pymes_gram", self.handle, len(xi), len(yj), ptr_array([x.ptr for x in xi]),
+                              ptr_array([y.ptr for y in yj]), size, buf)
+                out[i0:i0 + len(xi), j0:j0 + len(yj)] = np.frombuffer(buf, dtype=np.float64).reshape(len(xi), len(yj))
+        return out
+
+    def lincomb_multi(self, outs, xs, coeff, beta=None):
+        """outs[j] = sum_i coeff[i, j] xs[i] (+ beta[j] outs[j]); the inputs are read once for all outputs.  An output may be
+        one of the inputs only for len(xs) <= 16 and len(outs) <= 4 (include/pymes_amd.h, pymes_lincomb_multi)."""
+        m, n = len(xs), len(outs)
+        if n == 0:
+            return outs
+        coeff = np.ascontiguousarray(np.asarray(coeff, dtype=np.float64).reshape(m, n))
+        size = outs[0].size
+        assert all(v.size == size for v in list(xs) + list(outs))
+        bet = None if beta is None else np.ascontiguousarray(beta, dtype=np.float64)
+        for j0 in range(0, n, 64):
+            oj = outs[j0:j0 + 64]
+            for i0 in range(0, max(m, 1), 64):
+                xi = xs[i0:i0 + 64]
+                cc = np.ascontiguousarray(coeff[i0:i0 + 64, j0:j0 + 64])
+                bb = np.ones(len(oj)) if i0 > 0 else (bet[j0:j0 + 64].copy() if bet is not None else None)
+                self.lib.call("pymes_lincomb_multi", self.handle, len(xi), len(oj),
+                              ptr_array([x.ptr for x in xi]) if xi else None, _lib.host_ptr(cc) if xi else None,
+                              _lib.host_ptr(bb) if bb is not None else None, ptr_array([y.ptr for y in oj]), size)
+        return outs
+
     def diis_mix(self, state_host, err_hist, err_new, amp_hist, outs, m, was_full):
         """One DIIS step in one library call (include/pymes_amd.h, pymes_diis_mix): ``err_hist`` / ``amp_hist`` are the
         stored vectors type-major ([t][i]), ``state_host`` a float64 numpy array of 96 (L and the coefficients)."""

@@ -37,3 +37,35 @@ class DeviceIntegrals:
 
     def block(self, name, dressed=False):
         return self.ctx.V_block(name, dressed)
+
+
+class DressedDeviceIntegrals:
+    """The T1-dressed blocks of ``get_T1_dressed_V`` (pymes/solver/ccsd.py:290-421) held in HBM, in the context of the
+    integrals they were dressed from: what ``CCSD.get_T1_dressed_V(t1, ints)`` returns for a ``DeviceIntegrals`` and what
+    ``EOM_CCSD.solve`` / ``FEAST_EOM_CCSD.solve`` take in place of the reference's dictionary of host arrays
+    (pymes/test/test_eom_ccsd/test_eom_ccsd.py:24-48: CCSD.solve -> get_T1_dressed_* -> EOM_CCSD.solve) — no block crosses
+    PCIe.  Reads like the reference's dictionary: ``d["ijab"]`` is a DeviceArray, the five undressed names are None."""
+
+    def __init__(self, ints, keys):
+        self.ints, self.ctx = ints, ints.ctx
+        self.no, self.nv = ints.no, ints.nv
+        self._keys = tuple(keys)
+
+    def keys(self):
+        from pymes_amd.integral.partition import BLOCK_NAMES
+        return BLOCK_NAMES
+
+    def __contains__(self, name):
+        return name in self.keys()
+
+    def __getitem__(self, name):
+        if name not in self.keys():
+            raise KeyError(name)
+        return self.ctx.V_block(name, dressed=True) if name in self._keys else None
+
+    def get(self, name, default=None):
+        return self[name] if name in self else default
+
+    def to_host(self):
+        """The reference's dictionary (host arrays) — for callers that leave the device."""
+        return {k: (self[k].get() if k in self._keys else None) for k in self.keys()}

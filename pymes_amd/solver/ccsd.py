@@ -13,7 +13,7 @@ import numpy as np
 
 from pymes_amd import dist as pdist
 from pymes_amd.device import Context, DeviceArray
-from pymes_amd.integral.device import DeviceIntegrals
+from pymes_amd.integral.device import DeviceIntegrals, DressedDeviceIntegrals
 from pymes_amd.integral.partition import BLOCK_NAMES
 from pymes_amd.log import print_logging_info
 from pymes_amd.mixer import diis
@@ -448,9 +448,18 @@ class CCSD(ccd.CCD):
             print_logging_info("Exchange contribution = {:.12f}".format(e_ex), level=1)
             print_logging_info("CCSD correlation energy = {:.12f}".format(e_ccsd), level=1)
             print_logging_info("{:.3f} seconds spent on ccsd".format((time.time() - time_ccsd)), level=1)
-            self.t_T_ai = st["t1"].get()
             self._await_t2(st)
-            self.t_T_abij = st["t2"].get()
+            if kwargs.get("device_amplitudes"):
+                # device-resident hand-over to the callers of the solution (EOM-CCSD / FEAST: get_T1_dressed_V on the same
+                # DeviceIntegrals, EOM_CCSD.solve on the result): "t1" / "t2" are DeviceArrays of the integrals' context —
+                # private copies, the solver's own buffers go back to the pool of the next solve
+                if own:
+                    raise ValueError("device_amplitudes=True needs DeviceIntegrals (the context of a host V_pqrs dies with the call)")
+                self.t_T_ai = ctx.empty(st["t1"].shape).copy_from(st["t1"])
+                self.t_T_abij = ctx.empty(st["t2"].shape).copy_from(st["t2"])
+            else:
+                self.t_T_ai = st["t1"].get()
+                self.t_T_abij = st["t2"].get()
             if amps is not None and not self.is_diis and iteration > 0:
                 # without DIIS the reference keeps updating the caller's arrays in place (ccsd.py:178-179)
                 np.copyto(amps[0], self.t_T_ai)
@@ -476,7 +485,14 @@ class CCSD(ccd.CCD):
         return ctx
 
     def get_T1_dressed_fock(self, t_fock_pq, t_T_ai, dict_t_V):
-        """ccsd.py:226-288."""
+        """ccsd.py:226-288.  ``dict_t_V`` may be a ``DeviceIntegrals`` (and ``t_T_ai`` a DeviceArray of its context): the
+        blocks are read where they are; the n x n result comes back as a host array either way."""
+        if isinstance(dict_t_V, DeviceIntegrals):
+            ctx = dict_t_V.ctx
+            t1 = t_T_ai if isinstance(t_T_ai, DeviceArray) else ctx.array(t_T_ai)
+            fd = ctx.empty(t_fock_pq.shape)
+            ctx.dress_fock(ctx.array(np.asarray(t_fock_pq, dtype=np.float64)), t1, fd)
+            return fd.get()
         ctx = self._ctx_from_blocks(dict_t_V, t_T_ai.shape[0])
         try:
             fd = ctx.empty(t_fock_pq.shape)
@@ -486,7 +502,15 @@ class CCSD(ccd.CCD):
             ctx.close()
 
     def get_T1_dressed_V(self, t_T_ai, dict_t_V, dict_t_V_dressed=None):
-        """ccsd.py:290-421; the optional third argument selects the blocks (:316-317)."""
+        """ccsd.py:290-421; the optional third argument selects the blocks (:316-317).  ``dict_t_V`` may be a
+        ``DeviceIntegrals`` (``t_T_ai`` a host array or a DeviceArray of its context): the blocks are dressed in HBM, next to
+        the undressed ones, and a ``DressedDeviceIntegrals`` — the dictionary's device-resident stand-in — is returned."""
+        if isinstance(dict_t_V, DeviceIntegrals):
+            ctx = dict_t_V.ctx
+            t1 = t_T_ai if isinstance(t_T_ai, DeviceArray) else ctx.array(t_T_ai)
+            want = [k for k in (dict_t_V_dressed or DRESSED_KEYS) if k in DRESSED_KEYS]
+            ctx.dress_V(t1, want)
+            return DressedDeviceIntegrals(dict_t_V, want)
         if dict_t_V_dressed is None or len(dict_t_V_dressed) == 0:
             dict_t_V_dressed = {}.fromkeys(dict_t_V, None)
         ctx = self._ctx_from_blocks(dict_t_V, t_T_ai.shape[0])

@@ -12,11 +12,13 @@ three-operand einsums.  The subspace algebra (QR, B = Uᵀσ, eig, collapse/expa
 eom_ccsd.py:46-167 and stays on the host: the trial vectors live on the device, the host sees
 only overlaps and coefficients.
 """
+import os
 import time
 
 import numpy as np
 
-from pymes_amd.device import Context, DeviceArray
+from pymes_amd.device import Context, DeviceArray, PymesError
+from pymes_amd.integral.device import DressedDeviceIntegrals
 from pymes_amd.integral.partition import BLOCK_NAMES
 from pymes_amd.log import print_logging_info, print_title
 from pymes_amd.mixer.diis import _single_threaded_blas
@@ -27,14 +29,17 @@ class _Sigma:
 
     Pair layouts (ov x ov matrices): Xd[(a,i),(b,j)] = X[a,b,i,j], Xx[(a,j),(b,i)] = X[a,b,i,j]."""
 
-    def __init__(self, ctx, f, t2):
+    def __init__(self, ctx, f, t2, dressed=False):
+        """``dressed``: read the context's T1-DRESSED blocks (the context of a CCSD solve whose integrals were dressed in
+        place, ``CCSD.get_T1_dressed_V`` on a ``DeviceIntegrals``) instead of blocks uploaded as they are."""
         self.ctx, c = ctx, ctx
         no, nv = ctx.no, ctx.nv
         self.no, self.nv = no, nv
+        self.dressed = bool(dressed)
         f = np.asarray(f, dtype=np.float64)
         self.foo, self.fov, self.fvv = c.array(f[:no, :no]), c.array(f[:no, no:]), c.array(f[no:, no:])
-        V = {nm: c.V_block(nm) for nm in ("ijab", "iabj", "iajb", "ijka", "ijak", "iabc", "iajk", "abic", "klij",
-                                          "abcd")}
+        V = {nm: c.V_block(nm, self.dressed) for nm in ("ijab", "iabj", "iajb", "ijka", "ijak", "iabc", "iajk", "abic",
+                                                          "klij", "abcd")}
         self.V = V
         T = t2
         self.T = T
@@ -196,7 +201,7 @@ class _Sigma:
             npp = self.L.shape[0]
             B5s = c.permute("klij->klij", B5)
             c.permute("lkji->klij", B5, out=B5s, beta=1.0)
-            c.ladder_sym(u2, self.L, 0, npp)
+            c.ladder_sym(u2, self.L, 0, npp, dressed=self.dressed)
             c.hole_ladder_packed(u2, self.B2, self.L, 0, npp)
             c.hole_ladder_packed(T, B5s, self.L, 0, npp, y=u2)
             return c.symmetrised_assemble(D, Dd, Dx, c.empty(D.shape), L=self.L)
@@ -213,7 +218,7 @@ class _Sigma:
             npp = self.L.shape[0]
             B5s = c.permute("klij->klij", B5)
             c.permute("lkji->klij", B5, out=B5s, beta=1.0)
-            c.ladder_sym(u2, self.L, 0, npp)
+            c.ladder_sym(u2, self.L, 0, npp, dressed=self.dressed)
             c.hole_ladder_packed(u2, self.B2, self.L, 0, npp)
             c.hole_ladder_packed(T, B5s, self.L, 0, npp, y=u2)
             c.ladder_sym_unpack(self.L, D, beta=1.0)
@@ -225,7 +230,7 @@ class _Sigma:
         c.contract("abkl,klij->abij", u2, self.B2, out=D, beta=1.0)               # :380, :382
         c.contract("abkl,klij->abij", T, Bn, out=D, beta=1.0)                     # :381
         if self.v_sym and u2_sym:                                                 # :383
-            c.ladder_sym(u2, self.L, 0, self.L.shape[0])
+            c.ladder_sym(u2, self.L, 0, self.L.shape[0], dressed=self.dressed)
             c.ladder_sym_unpack(self.L, D, beta=1.0)
         else:
             c.contract("abcd,cdij->abij", V["abcd"], u2, out=D, beta=1.0)
@@ -235,7 +240,55 @@ class _Sigma:
         return self.singles(u1, u2), self.doubles(u1, u2, u2_sym)
 
     # ------------------------------------------------------------------------------------------
-    def apply_many(self, u1s, u2s, syms=None):
+    MAX_STACK = 16          # vectors per stacked build (the batched ladder launches take at most 64)
+
+    def stack_limit(self):
+        """How many trial vectors one stacked build may take: nine (ov)^2-sized temporaries per vector (X, Tt, DxT, DdT, D,
+        S2, the packed ladder rows and their operands) must fit in half of what the device has free right now."""
+        free = self.ctx.mem_info()[0] + self.ctx._spare_bytes
+        per_vector = 9 * 8 * (self.no * self.nv) ** 2
+        return int(max(1, min(self.MAX_STACK, (free // 2) // max(per_vector, 1))))
+
+    def apply_many(self, u1s, u2s, syms=None, out1=None, out2=None):
+        """sigma for any number of trial vectors: stacked builds (``_apply_stack``) over chunks of at most ``stack_limit()``
+        vectors — every batched kernel and every temporary is sized by the chunk, not by the subspace; a chunk whose
+        temporaries cannot be allocated after all is built vector by vector.  ``out1`` / ``out2``: device arrays that receive
+        sigma1_z / sigma2_z (e.g. the two parts of a flat subspace vector) instead of fresh ones."""
+        k = len(u1s)
+        if syms is None:
+            syms = [self.exchange_symmetric(u2) for u2 in u2s]
+        res = []
+        step = self.stack_limit()
+        for lo in range(0, k, step):
+            hi = min(k, lo + step)
+            o1 = out1[lo:hi] if out1 is not None else None
+            o2 = out2[lo:hi] if out2 is not None else None
+            try:
+                res += self._apply_stack(u1s[lo:hi], u2s[lo:hi], syms[lo:hi], o1, o2)
+            except PymesError as err:
+                if hi - lo < 2 or "memory" not in str(err).lower():
+                    raise
+                self.ctx.trim()          # out of device memory in the middle of a stacked build: one vector at a time
+                for z in range(lo, hi):
+                    res += self._apply_stack(u1s[z:z + 1], u2s[z:z + 1], syms[z:z + 1],
+                                             o1[z - lo:z - lo + 1] if o1 is not None else None,
+                                             o2[z - lo:z - lo + 1] if o2 is not None else None)
+        return res
+
+    def _into(self, pairs, out1, out2):
+        """Results of the vector-by-vector build copied into the caller's output arrays, if any."""
+        if out1 is None and out2 is None:
+            return pairs
+        res = []
+        for z, (s1, s2) in enumerate(pairs):
+            if out1 is not None:
+                s1 = out1[z].copy_from(s1)
+            if out2 is not None:
+                s2 = out2[z].copy_from(s2)
+            res.append((s1, s2))
+        return res
+
+    def _apply_stack(self, u1s, u2s, syms, out1=None, out2=None):
         """sigma for k trial vectors at once: [(sigma1_z, sigma2_z)].  The reference builds sigma vector by vector for
         the whole Davidson subspace (eom_ccsd.py:95-101); here the k vectors are stacked, so that every operand that does not
         depend on the trial vector — the hoisted (ov)^2 pair matrices, V_abcd (pair-packed), T, the V.T intermediates — is
@@ -243,10 +296,8 @@ class _Sigma:
         launch, the one-index terms GEMMs with M = k v.  Needs exchange-symmetric vectors and the pair-packed forms
         (``many_ok``); anything else goes vector by vector through ``apply``."""
         k = len(u1s)
-        if syms is None:
-            syms = [self.exchange_symmetric(u2) for u2 in u2s]
         if k < 2 or not self.many_ok or not all(syms):
-            return [self.apply(u1, u2, u2_sym=sy) for u1, u2, sy in zip(u1s, u2s, syms)]
+            return self._into([self.apply(u1, u2, u2_sym=sy) for u1, u2, sy in zip(u1s, u2s, syms)], out1, out2)
         c, V, T = self.ctx, self.V, self.T
         no, nv = self.no, self.nv
 
@@ -289,9 +340,9 @@ class _Sigma:
         c.contract("abic,zcj->zabij", V["abic"], U1, out=D, beta=1.0, batch="z")
         npp = self.L.shape[0]
         Lall = c.empty((k, npp, no * no))
-        c.ladder_sym_multi(u2s, Lall)                                                   # :383, all vectors
+        c.ladder_sym_multi(u2s, Lall, dressed=self.dressed)                                                   # :383, all vectors
         out = []
-        S2 = c.empty(D.shape)
+        S2 = c.empty(D.shape) if out2 is None else None
         B5s = []
         for z in range(k):
             Dz, u2, u1 = part(D, z), u2s[z], part(U1, z)
@@ -305,8 +356,10 @@ class _Sigma:
         c.hole_ladder_packed_multi(u2s, [self.B2] * k, Lall)                            # :380, :382
         c.hole_ladder_packed_multi([T] * k, B5s, Lall, ys=u2s)                          # :381 (+ the symmetrised u1 term)
         for z in range(k):
-            c.symmetrised_assemble(part(D, z), part(DdT, z), part(DxT, z), part(S2, z), L=part(Lall, z))   # :377 + unpacking
-            out.append((part(S1, z), part(S2, z)))
+            s2 = part(S2, z) if out2 is None else out2[z]
+            c.symmetrised_assemble(part(D, z), part(DdT, z), part(DxT, z), s2, L=part(Lall, z))            # :377 + unpacking
+            s1 = part(S1, z) if out1 is None else out1[z].copy_from(part(S1, z))
+            out.append((s1, s2))
         return out
 
 
@@ -336,77 +389,131 @@ class EOM_CCSD:
         return ctx
 
     def solve(self, t_fock_dressed_pq, dict_t_V_dressed, t_T_abij):
-        """eom_ccsd.py:46-167."""
+        """eom_ccsd.py:46-167.
+
+        Call forms: the reference's (dressed Fock matrix, dictionary of dressed host blocks, host T2) — a context is built,
+        the blocks are uploaded, and the context dies with the call —, or the device-resident hand-over from a CCSD solve
+        (``DressedDeviceIntegrals`` from ``CCSD.get_T1_dressed_V(t1, DeviceIntegrals)``, T2 as a DeviceArray of the same
+        context; the Fock matrix may be a host array or a DeviceArray): nothing crosses PCIe but n^2 numbers of the Fock
+        matrix before the loop and the subspace matrices inside it.
+
+        The subspace bookkeeping is the reference's (QR of the trial vectors :91, B = U^T sigma(U) :103-109, eig :112,
+        collapse at 4 n_excit vectors :122-133, expansion by (W v - e U v) / (e - D_ai[guess] + 1e-5) :135-147), evaluated
+        incrementally: sigma is linear and the orthonormalisation leaves the vectors it already made orthonormal unchanged,
+        so each pass builds sigma for the n_excit NEW vectors only and extends B by their rows and columns; after a
+        collapse U v, sigma(U v) = W v.  (The reference rebuilds all <= 4 n_excit sigma vectors every pass, :95-101.)
+        ``self.reuse_sigma = False`` (or PYMES_EOM_REBUILD_ALL=1) restores that schedule."""
         print_title("EOM-CCSD Solver", )
         time_init = time.time()
         no = self.no
+        device_form = isinstance(dict_t_V_dressed, DressedDeviceIntegrals)
+        if isinstance(t_fock_dressed_pq, DeviceArray):
+            t_fock_dressed_pq = t_fock_dressed_pq.get()
         f = np.asarray(t_fock_dressed_pq, dtype=np.float64)
         eps_i, eps_a = f.diagonal()[:no], f.diagonal()[no:]
         nv = eps_a.shape[0]
         D_ai = -(eps_i[None, :] - eps_a[:, None]).ravel()
         lowest_ex_ind_init = np.argsort(D_ai)[:self.n_excit]
-        ctx = self._context(dict_t_V_dressed, nv)
+        if device_form:
+            ctx = dict_t_V_dressed.ctx
+            if ctx.no != no or ctx.nv != nv:
+                raise ValueError("the integrals' context does not match (no, nv) of the Fock matrix")
+            t2 = t_T_abij if isinstance(t_T_abij, DeviceArray) else ctx.array(t_T_abij)
+            if isinstance(t_T_abij, DeviceArray) and t_T_abij.ctx is not ctx:
+                raise ValueError("t_T_abij lives in another context than the dressed integrals")
+        else:
+            ctx = self._context(dict_t_V_dressed, nv)
+            t2 = ctx.array(t_T_abij)
         from pymes_amd.solver.ccd import quiet_collector
         collector = quiet_collector().__enter__()
+        reuse = getattr(self, "reuse_sigma", True) and not os.environ.get("PYMES_EOM_REBUILD_ALL")
+        self.history = []
+        self.timings = {"hoist_s": 0.0, "sigma_s": 0.0, "orth_s": 0.0, "subspace_s": 0.0, "sigma_vectors": 0, "passes": 0}
+        tm, timed = self.timings, bool(getattr(self, "profile_phases", False))
+
+        def lap(key, t0):          # per-phase wall time (with a device synchronisation) only when asked for
+            if timed:
+                ctx.sync()
+                tm[key] += time.time() - t0
+            return time.time()
         try:
-            sig = _Sigma(ctx, f, ctx.array(t_T_abij))
+            t0 = time.time()
+            sig = _Sigma(ctx, f, t2, dressed=device_form)
+            t0 = lap("hoist_s", t0)
             print_logging_info("Initialising u tensors...", level=1)
-            n1, n2 = nv * no, nv * nv * no * no
-            us = []                                   # device vectors [u1 | u2], one flat buffer each
+            lay = self._layout(no, nv)
+            n1, off2, nflat = lay
+            fresh = lambda: ctx.zeros((nflat,)) if off2 > n1 else ctx.empty((nflat,))     # (the pad must stay zero)
+            new = []                                  # raw new trial vectors of this pass [u1 | pad | u2], flat
             for i in range(self.n_excit):
-                vec = ctx.zeros((n1 + n2,))
+                vec = ctx.zeros((nflat,))
                 one = np.zeros(n1)
                 one[lowest_ex_ind_init[i]] = 1.0
-                self._part(ctx, vec, 0, (nv, no)).set(one.reshape(nv, no))
-                us.append(vec)
+                self._u1(ctx, vec, lay).set(one.reshape(nv, no))
+                new.append(vec)
+            us, ws, B = [], [], np.zeros((0, 0))      # orthonormal basis, its sigma vectors, U^T W
+            # exchange symmetry u2_abij = u2_baji: the start vectors have it (zero doubles), and the stacked sigma build,
+            # the projections and the expansions keep it exactly — tested only where that chain is broken
+            all_sym = sig.many_ok
             e = self.e_excit
             e_old = self.e_excit
             e_imag = np.zeros(self.n_excit)
             diff_e_norm = np.inf
             for it in range(self.max_iter):
                 time_iter_init = time.time()
+                t0 = time.time()
+                if not reuse and us:                                                 # the reference's schedule: everything anew
+                    new, us, ws, B = us + new, [], [], np.zeros((0, 0))
+                if new:
+                    new = self._orthonormalise_block(ctx, us, new, lay)              # :91
+                    t0 = lap("orth_s", t0)
+                    u2s = [self._u2(ctx, u, lay) for u in new]
+                    sym = [True] * len(new) if all_sym else [sig.exchange_symmetric(u2) for u2 in u2s]
+                    wn = [fresh() for _ in new]
+                    sig.apply_many([self._u1(ctx, u, lay) for u in new], u2s, sym,                  # :95-101, new vectors only
+                                   out1=[self._u1(ctx, w, lay) for w in wn], out2=[self._u2(ctx, w, lay) for w in wn])
+                    tm["sigma_vectors"] += len(new)
+                    t0 = lap("sigma_s", t0)
+                    d0 = len(us)
+                    us, ws = us + new, ws + wn
+                    Bn = np.zeros((len(us), len(us)))                                # :103-109, the new rows and columns
+                    Bn[:d0, :d0] = B
+                    Bn[:, d0:] = ctx.gram(us, wn)
+                    if d0:
+                        Bn[d0:, :d0] = ctx.gram(new, ws[:d0])
+                    B, new = Bn, []
                 dim = len(us)
-                us = self._orthonormalise(ctx, us)                               # :91
-                ws = []
-                # exchange symmetry of the trial doubles, decided here (between the sigma builds) so that the builds
-                # themselves run without host synchronisation
-                sym = [sig.exchange_symmetric(self._part(ctx, u, n1, (nv, nv, no, no))) for u in us]
-                sigmas = sig.apply_many([self._part(ctx, u, 0, (nv, no)) for u in us],       # :95-101, all vectors of the
-                                        [self._part(ctx, u, n1, (nv, nv, no, no)) for u in us], sym)   # subspace at once
-                for l in range(dim):
-                    s1, s2 = sigmas[l]
-                    w = ctx.empty((n1 + n2,))
-                    self._part(ctx, w, 0, (nv, no)).copy_from(s1)
-                    self._part(ctx, w, n1, (nv, nv, no, no)).copy_from(s2)
-                    ws.append(w)
-                B = np.zeros((dim, dim))
-                for l in range(dim):                                             # :103-109
-                    B[:, l] = ctx.dots(us, [ws[l]] * dim)
-                e_old = self.e_excit                                             # :110 (every pass, so the collapse
-                with _single_threaded_blas():                                    # (a <= 12 x 12 matrix: no thread pool)
-                    lam, vec = np.linalg.eig(B)                                  # :112  branch's restore is a no-op)
+                e_old = self.e_excit                                                 # :110 (every pass, so the collapse
+                with _single_threaded_blas():                                        # (a <= 12 x 12 matrix: no thread pool)
+                    lam, vec = np.linalg.eig(B)                                      # :112  branch's restore is a no-op)
                 pick = lam.argsort()[:self.n_excit]
                 e_imag = np.imag(lam[pick])
                 e = np.real(lam[pick])
                 v = np.real(vec[:, pick])
-                if dim >= self.max_dim:                                          # collapse :122-133
-                    new = []
-                    for n in range(self.n_excit):
-                        y = ctx.empty((n1 + n2,))
-                        ctx.lincomb(y, us, v[:, n])
-                        new.append(y)
-                    us = new
+                self.history.append(np.array(e))      # (the Ritz values of the pass; the reference only logs them)
+                if dim >= self.max_dim:                                              # collapse :122-133
+                    cu = [fresh() for _ in range(self.n_excit)]
+                    cw = [fresh() for _ in range(self.n_excit)]
+                    ctx.lincomb_multi(cu, us, v)
+                    ctx.lincomb_multi(cw, ws, v)                                     # sigma(U v) = W v
+                    # the next pass of the reference orthonormalises these Ritz vectors (:91) and builds their sigma
+                    # vectors again; here the same triangular map goes over both sets, and the pass costs no sigma build
+                    us, ws = self._orthonormalise_block(ctx, [], cu, lay, shadows=cw)
+                    B = ctx.gram(us, ws)
                     self.e_excit = e_old
-                else:                                                            # expand :135-147
-                    basis = list(us)
+                else:                                                                # expand :135-147
+                    coef = np.zeros((2 * dim, self.n_excit))
                     for n in range(self.n_excit):
                         den = e[n] - D_ai[lowest_ex_ind_init[n]] + 1e-5
-                        y = ctx.empty((n1 + n2,))
-                        ctx.lincomb(y, ws + basis, list(v[:, n] / den) + list(-e[n] * v[:, n] / den))
-                        us.append(y)
+                        coef[:dim, n] = v[:, n] / den
+                        coef[dim:, n] = -e[n] * v[:, n] / den
+                    new = [fresh() for _ in range(self.n_excit)]
+                    ctx.lincomb_multi(new, ws + us, coef)
                     e_old = self.e_excit
                     diff_e_norm = np.linalg.norm(self.e_excit - e)
                     self.e_excit = e
+                t0 = lap("subspace_s", t0)
+                tm["passes"] += 1
                 if diff_e_norm < self.e_epsilon:
                     print_logging_info("Iterative solver converged.", level=1)
                     print_logging_info("Norm of energy difference = {:.12f}".format(diff_e_norm), level=2)
@@ -425,34 +532,110 @@ class EOM_CCSD:
             for r in range(self.n_excit):
                 print_logging_info("Excited state {:d} energy = {:.12f}".format(r, e[r]), level=2)
             self.iterations = it + 1
-            self.u_singles = [self._part(ctx, u, 0, (nv, no)).get() for u in us[:self.n_excit]]
-            self.u_doubles = [self._part(ctx, u, n1, (nv, nv, no, no)).get() for u in us[:self.n_excit]]
+            # (as in the reference the attributes hold the trial space as the loop left it: basis first, then the expansion
+            # vectors; in the device form they stay device arrays of the caller's context)
+            keep = (us + new)[:self.n_excit]
+            self.u_singles = [self._u1(ctx, u, lay) for u in keep]
+            self.u_doubles = [self._u2(ctx, u, lay) for u in keep]
+            if not device_form:
+                self.u_singles = [x.get() for x in self.u_singles]
+                self.u_doubles = [x.get() for x in self.u_doubles]
             return self.e_excit
         finally:
             collector.__exit__()
-            ctx.close()
+            if not device_form:
+                ctx.close()
 
     @staticmethod
     def _part(ctx, vec, offset, shape):
         return DeviceArray(ctx, vec.ptr + 8 * offset, shape, owned=False, keepalive=vec)
 
+    # ---- flat subspace vectors [u1 (nv no) | zero pad | u2 (nv^2 no^2)], the doubles on a 256-byte boundary ----------------
     @staticmethod
-    def _orthonormalise(ctx, us):
-        """EOM_CCSD.QR (eom_ccsd.py:512-541): thin QR of the column block, done as Cholesky-free
-        modified Gram-Schmidt with re-orthogonalisation on the device (the host sees overlaps only).
-        The span and the orthonormality are those of numpy's Householder QR; individual columns can
-        differ from it by a sign, which the Rayleigh-Ritz step does not see."""
-        out = []
-        for u in us:
-            q = ctx.empty(u.shape).copy_from(u)
-            for _ in range(2):
-                if out:
-                    proj = ctx.dots(out, [q] * len(out))
-                    ctx.lincomb(q, [q] + out, [1.0] + list(-proj))
-            nrm = ctx.norm(q)
-            ctx.lincomb(q, [q], [1.0 / nrm])
-            out.append(q)
-        return out
+    def _layout(no, nv):
+        n1 = nv * no
+        off2 = -(-n1 // 32) * 32
+        return n1, off2, off2 + nv * nv * no * no
+
+    def _u1(self, ctx, vec, lay):
+        return self._part(ctx, vec, 0, (ctx.nv, ctx.no))
+
+    def _u2(self, ctx, vec, lay):
+        return self._part(ctx, vec, lay[1], (ctx.nv, ctx.nv, ctx.no, ctx.no))
+
+    def _orthonormalise_block(self, ctx, us, ys, lay, shadows=None):
+        """EOM_CCSD.QR (eom_ccsd.py:512-541) for a trial space [us | ys] whose leading vectors ``us`` are orthonormal already
+        (Householder QR leaves those as they are, up to a sign the Rayleigh-Ritz step does not see): the block ``ys`` is
+        projected against ``us`` and orthonormalised in itself by two rounds of block Gram-Schmidt in its Pythagorean form
+        — ONE Gram product [us | ys]^T ys (every vector read once), the Cholesky factor of ys^T ys - P^T P on the host, ONE
+        multi-output combination (ys - us P) R^-1 — so a round costs two passes over the subspace instead of a dot product
+        and an update per pair of vectors.  Returns the new orthonormal block; with ``shadows`` (vectors that any linear
+        map of ``ys`` must follow, e.g. their sigma vectors; only for an empty ``us``) returns (block, mapped shadows)."""
+        assert shadows is None or not us
+        k, d, nflat = len(ys), len(us), lay[2]
+        fresh = lambda: ctx.zeros((nflat,)) if lay[1] > lay[0] else ctx.empty((nflat,))
+        for _ in range(2):
+            G = ctx.gram(us + ys, ys)
+            P, S = G[:d], G[d:] - G[:d].T @ G[:d]
+            S = 0.5 * (S + S.T)
+            scale = np.sqrt(np.abs(np.diag(S)))
+            ok = bool(np.all(np.isfinite(scale)) and np.all(scale > 0.0) and np.all(np.diag(S) > 0.0))
+            if ok:
+                try:
+                    with _single_threaded_blas():
+                        Lc = np.linalg.cholesky(S / np.outer(scale, scale))          # equilibrated: S = D L L^T D
+                        ok = bool(np.diag(Lc).min() > 1e-7)                          # (condition number of ys below ~1e7)
+                        Rinv = np.linalg.inv(Lc.T * scale[None, :]) if ok else None  # R = L^T D, ys_new = ys' R^-1
+                except np.linalg.LinAlgError:
+                    ok = False
+            if not ok:       # (numerically) dependent new vectors: vector by vector, null vectors replaced
+                return self._orthonormalise_sequential(ctx, us, ys, lay, shadows)
+            coef = np.vstack([-P @ Rinv, Rinv])
+            out = [fresh() for _ in range(k)]
+            ctx.lincomb_multi(out, us + ys, coef)
+            if shadows is not None:
+                sh = [fresh() for _ in range(k)]
+                ctx.lincomb_multi(sh, shadows, Rinv)
+                shadows = sh
+            ys = out
+        return ys if shadows is None else (ys, shadows)
+
+    def _orthonormalise_sequential(self, ctx, us, ys, lay, shadows=None):
+        """The fall-back of ``_orthonormalise_block``: modified Gram-Schmidt with re-orthogonalisation, one vector at a time
+        (one Gram product and one combination per sweep).  A vector that vanishes against the others — the reference's
+        Householder QR would return an arbitrary unit vector orthogonal to them — is replaced by a seeded random,
+        exchange-symmetric direction."""
+        done, sh_done = list(us), []
+        n1, off2, nflat = lay
+        rng = np.random.default_rng(len(us) + 1000 * len(ys))
+        for z, y in enumerate(ys):
+            q = ctx.empty((nflat,)).copy_from(y)
+            sh = None if shadows is None else ctx.empty((nflat,)).copy_from(shadows[z])
+            for attempt in range(3):
+                nrm0 = np.sqrt(ctx.gram([q], [q])[0, 0])
+                for _ in range(2):
+                    if done:
+                        proj = ctx.gram(done, [q])[:, 0]
+                        ctx.lincomb_multi([q], done, -proj[:, None], beta=[1.0])
+                        if sh is not None:
+                            ctx.lincomb_multi([sh], sh_done, -proj[len(us):, None], beta=[1.0])
+                nrm = np.sqrt(ctx.gram([q], [q])[0, 0])
+                if np.isfinite(nrm) and nrm > 1e-12 * max(nrm0, 1e-300) and nrm > 0.0:
+                    break
+                if shadows is not None:
+                    raise np.linalg.LinAlgError("linearly dependent Ritz vectors in the Davidson collapse")
+                r1 = rng.standard_normal((ctx.nv, ctx.no))
+                r2 = rng.standard_normal((ctx.nv, ctx.nv, ctx.no, ctx.no))
+                q.zero_()
+                self._u1(ctx, q, lay).set(r1)
+                self._u2(ctx, q, lay).set(r2 + r2.transpose(1, 0, 3, 2))
+            ctx.lincomb_multi([q], [], np.zeros((0, 1)), beta=[1.0 / nrm])
+            if sh is not None:
+                ctx.lincomb_multi([sh], [], np.zeros((0, 1)), beta=[1.0 / nrm])
+                sh_done.append(sh)
+            done.append(q)
+        block = done[len(us):]
+        return block if shadows is None else (block, sh_done)
 
     # ---- the reference's host-array call forms (eom_ccsd.py:268-385) ---------------------------
     def _host_sigma(self, t_fock_pq, dict_t_V, t_u_ai, t_u_abij, t_T_abij, which):

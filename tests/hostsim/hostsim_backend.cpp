@@ -231,6 +231,35 @@ void lincomb(double* out, int nx, const double* const* x, const double* c, int64
     }
 }
 
+void gram(int m, int n, const double* const* x, const double* const* y, int64_t len, double* out, stream_t) {
+    if (m > 64 || n > 64) throw std::runtime_error("gram: at most 64 x 64 vectors per call");
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = 0.0;
+            for (int64_t e = 0; e < len; ++e) s += x[i][e] * y[j][e];
+            out[(int64_t)i * n + j] = s;
+        }
+}
+
+void lincomb_multi(int m, int n, const double* const* x, const double* c, const double* beta, double* const* y, int64_t len,
+                   stream_t) {
+    if (m < 0 || m > 64 || n > 64) throw std::runtime_error("lincomb_multi: at most 64 inputs and 64 outputs per call");
+    if (m > 16 || n > 4)
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < m; ++i)
+                if (y[j] == x[i]) throw std::runtime_error("lincomb_multi: an output may alias an input only for m <= 16, n <= 4");
+    std::vector<double> xs(m > 0 ? m : 1), out(n > 0 ? n : 1);
+    for (int64_t e = 0; e < len; ++e) {           // element by element: every input is read before any output is written
+        for (int i = 0; i < m; ++i) xs[i] = x[i][e];
+        for (int j = 0; j < n; ++j) {
+            double s = (beta && beta[j] != 0.0) ? beta[j] * y[j][e] : 0.0;
+            for (int i = 0; i < m; ++i) s += c[(int64_t)i * n + j] * xs[i];
+            out[j] = s;
+        }
+        for (int j = 0; j < n; ++j) y[j][e] = out[j];
+    }
+}
+
 void diis_step(double* state, int npairs, const double* const* x, const double* const* y, const int64_t* n, int ntypes, int m,
                int was_full, stream_t) {
     if (npairs != ntypes * m || npairs > 16 || m + 1 > diis_small::kMaxOrder) throw std::runtime_error("diis_step: bad sizes");

@@ -9,11 +9,12 @@ import numpy as np
 import pytest
 
 from oracle import cc_oracle as oc, eom_oracle as eo, io_oracle as oio
-from oracle.cases import random_case
+from oracle.cases import eom_davidson_case, random_case
 from pymes_amd import _lib
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 SOLVES = json.load(open(os.path.join(GOLD, "eom_solves.json")))
+DAVIDSON = json.load(open(os.path.join(GOLD, "eom_davidson.json")))      # oracle/make_golden_eom_davidson.py
 
 
 def sigma_inputs(no, nv, seed, with_imag=False):
@@ -127,6 +128,15 @@ def check_apply_many(lib, monkeypatch, no, nv, k, tol):
             sc = max(1.0, np.abs(r2).max())
             assert np.abs(many[z][0].get() - r1).max() < tol * sc and np.abs(many[z][1].get() - r2).max() < tol * sc, z
             assert np.abs(many[z][0].get() - s1.get()).max() < tol * sc and np.abs(many[z][1].get() - s2.get()).max() < tol * sc
+        # more vectors than one stacked build takes (the batched launches stop at 64 vectors, the temporaries at
+        # the device memory): chunks of two, results into arrays of the caller
+        sig.MAX_STACK = 2
+        o1, o2 = [ctx.empty((nv, no)) for _ in range(k)], [ctx.empty((nv, nv, no, no)) for _ in range(k)]
+        chunked = sig.apply_many(d1, d2, out1=o1, out2=o2)
+        for z in range(k):
+            assert chunked[z][0] is o1[z] and chunked[z][1] is o2[z]
+            assert np.abs(o1[z].get() - many[z][0].get()).max() < tol and np.abs(o2[z].get() - many[z][1].get()).max() < tol
+        sig.MAX_STACK = 16
         # a vector without the exchange symmetry in the batch: everything goes vector by vector, same numbers
         u2s[1][0, 1, 0, 1] += 0.5
         d2[1] = ctx.array(u2s[1])
@@ -165,3 +175,69 @@ def test_sigma_gpu_larger(gpu_lib, monkeypatch):
     e = EOM_CCSD(no, 2)
     assert np.abs(e.update_singles(f, Vb, u1, u2, t2) - eo.sigma_singles(no, f, Vb, u1, u2, t2)).max() < 1e-11
     assert np.abs(e.update_doubles(f, Vb, u1, u2, t2) - eo.sigma_doubles(no, f, Vb, u1, u2, t2)).max() < 1e-10
+
+
+def check_davidson_golden(lib, monkeypatch, tag, device_form, reuse=True):
+    """The reference's chain CCSD.solve -> get_T1_dressed_fock / get_T1_dressed_V -> EOM_CCSD.solve
+    (pymes/test/test_eom_ccsd/test_eom_ccsd.py:24-48) against what the reference itself printed and returned on the same
+    problem (tests/golden/eom_davidson.json): CCSD energy, excitation energies, number of Davidson passes and the Ritz values
+    of every pass.  ``device_form``: DeviceIntegrals -> device amplitudes -> DressedDeviceIntegrals, nothing on the host."""
+    from pymes_amd.integral.device import DeviceIntegrals, DressedDeviceIntegrals
+    from pymes_amd.integral.partition import part_2_body_int
+    from pymes_amd.solver.ccsd import CCSD
+    from pymes_amd.solver.eom_ccsd import EOM_CCSD
+    monkeypatch.setattr(_lib, "_default", lib)
+    g = DAVIDSON[tag]
+    no, nv = g["no"], g["nv"]
+    f, V = eom_davidson_case(no, nv, seed=g["seed"], scale=g["scale"])
+    cc = CCSD(no, delta_e=1e-11)
+    eom = EOM_CCSD(no, n_excit=g["n_excit"])
+    eom.max_iter = 400
+    eom.reuse_sigma = reuse
+    with contextlib.redirect_stdout(io.StringIO()):
+        if device_form:
+            ints = DeviceIntegrals.from_V_pqrs(no, V)
+            try:
+                res = cc.solve(f, ints, max_iter=100, device_amplitudes=True)
+                fd = cc.get_T1_dressed_fock(f, res["t1"], ints)
+                Vd = cc.get_T1_dressed_V(res["t1"], ints)
+                assert isinstance(Vd, DressedDeviceIntegrals) and Vd["aibj"] is None and Vd["abcd"].shape == (nv,) * 4
+                ee = eom.solve(fd, Vd, res["t2"])
+                assert eom.u_doubles[0].ctx is ints.ctx          # the trial space stays in HBM
+            finally:
+                ints.ctx.close()
+        else:
+            res = cc.solve(f, V, max_iter=100)
+            Vb = part_2_body_int(no, V)
+            fd = cc.get_T1_dressed_fock(f, res["t1"], Vb)
+            Vd = cc.get_T1_dressed_V(res["t1"], Vb)
+            ee = eom.solve(fd, Vd, res["t2"])
+    assert abs(res["ccsd e"] - g["ccsd_e"]) < 1e-9
+    assert np.abs(np.array(ee) - np.array(g["ee"])).max() < 1e-8, (ee, g["ee"])
+    assert eom.iterations == g["passes"], (eom.iterations, g["passes"])
+    hist = np.array(eom.history)
+    assert hist.shape == np.array(g["ritz_per_pass"]).shape
+    assert np.abs(hist - np.array(g["ritz_per_pass"])).max() < 5e-8          # (the log prints 12 decimals)
+    # sigma by linearity: n_excit builds per pass, none in the pass after a collapse (the reference rebuilds <= 4 n_excit)
+    if reuse:
+        assert eom.timings["sigma_vectors"] <= g["n_excit"] * g["passes"]
+    else:
+        assert eom.timings["sigma_vectors"] > 2 * g["n_excit"] * g["passes"]
+
+
+@pytest.mark.parametrize("device_form", [False, True])
+def test_davidson_golden_host_logic(hostsim_lib, monkeypatch, device_form):
+    check_davidson_golden(hostsim_lib, monkeypatch, "small", device_form)
+
+
+def test_davidson_reference_schedule_host_logic(hostsim_lib, monkeypatch):
+    check_davidson_golden(hostsim_lib, monkeypatch, "small", False, reuse=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_form", [False, True])
+def test_davidson_golden_gpu(gpu_lib, monkeypatch, device_form):
+    """(12,48): the LDS-DMA GEMM, the batched pair-packed ladders and the stacked multi-vector sigma inside a SOLVE that is
+    compared with the reference (38 passes with collapses)."""
+    check_davidson_golden(gpu_lib, monkeypatch, "small", device_form)
+    check_davidson_golden(gpu_lib, monkeypatch, "big", device_form)

@@ -1,0 +1,78 @@
+"""Tall-skinny subspace algebra of the Davidson / FEAST drivers (pymes_gram, pymes_lincomb_multi: the device side of
+pymes/solver/eom_ccsd.py:91-147, :512-541) against numpy — through the host simulator on the CPU (C-ABI plumbing, chunking),
+on the GPU for the kernels."""
+import numpy as np
+import pytest
+
+from pymes_amd.device import Context, DeviceArray
+
+
+def _vectors(ctx, rng, count, n, misalign=False):
+    """``count`` device vectors of length n; with ``misalign`` they start 8 bytes into their buffers (no 16-byte loads)."""
+    host, dev = [], []
+    for _ in range(count):
+        h = rng.standard_normal(n)
+        if misalign:
+            buf = ctx.empty((n + 1,))
+            d = DeviceArray(ctx, buf.ptr + 8, (n,), owned=False, keepalive=buf)
+            d.set(h)
+        else:
+            d = ctx.array(h)
+        host.append(h)
+        dev.append(d)
+    return host, dev
+
+
+def check_subspace_algebra(lib, sizes):
+    ctx = Context(2, 3, lib=lib)
+    rng = np.random.default_rng(7)
+    try:
+        for (m, n, length, mis) in sizes:
+            xh, xd = _vectors(ctx, rng, m, length, mis)
+            yh, yd = _vectors(ctx, rng, n, length, mis)
+            G = ctx.gram(xd, yd)
+            ref = np.array(xh) @ np.array(yh).T if length else np.zeros((m, n))
+            assert G.shape == (m, n)
+            assert np.abs(G - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()) * max(1, length) ** 0.5, (m, n, length, mis)
+            # combinations: fresh outputs (beta = 0, never read: NaN-filled), accumulation (beta != 0)
+            Cm = rng.standard_normal((m, n))
+            outs = [ctx.array(np.full(length, np.nan)) for _ in range(n)]
+            ctx.lincomb_multi(outs, xd, Cm)
+            want = (np.array(xh).T @ Cm).T if m else np.zeros((n, length))
+            for j in range(n):
+                assert np.abs(outs[j].get() - want[j]).max() <= 1e-13 * max(1.0, np.abs(want).max()) if length else True
+            beta = rng.standard_normal(n)
+            ctx.lincomb_multi(yd, xd, Cm, beta=beta)
+            for j in range(n):
+                w = want[j] + beta[j] * yh[j]
+                assert np.abs(yd[j].get() - w).max() <= 1e-13 * max(1.0, np.abs(w).max()) if length else True
+        # in place: the outputs ARE inputs (orthonormalisation of a block by its own triangular factor)
+        xh, xd = _vectors(ctx, rng, 3, 1001)
+        R = np.triu(rng.standard_normal((3, 3))) + 3.0 * np.eye(3)
+        ctx.lincomb_multi(xd, xd, R)
+        want = (np.array(xh).T @ R).T
+        for j in range(3):
+            assert np.abs(xd[j].get() - want[j]).max() < 1e-12
+        xh, xd = _vectors(ctx, rng, 17, 64)
+        with pytest.raises(Exception):
+            ctx.lincomb_multi(xd[:1], xd, np.ones((17, 1)))          # aliasing beyond one launch is refused
+        # no inputs at all: a pure scaling
+        yh, yd = _vectors(ctx, rng, 2, 77)
+        ctx.lincomb_multi(yd, [], np.zeros((0, 2)), beta=[2.0, -1.0])
+        assert np.abs(yd[0].get() - 2.0 * yh[0]).max() < 1e-14 and np.abs(yd[1].get() + yh[1]).max() < 1e-14
+    finally:
+        ctx.close()
+
+
+SMALL = [(1, 1, 1, False), (3, 2, 17, False), (3, 2, 17, True), (12, 3, 1000, False), (3, 9, 513, False), (16, 4, 300, False),
+         (17, 5, 256, False), (5, 17, 255, True), (2, 2, 0, False), (24, 3, 129, False)]
+
+
+def test_subspace_algebra_host_logic(hostsim_lib):
+    check_subspace_algebra(hostsim_lib, SMALL)
+
+
+@pytest.mark.gpu
+def test_subspace_algebra_gpu(gpu_lib):
+    check_subspace_algebra(gpu_lib, SMALL + [(12, 12, 300001, False), (9, 3, 1 << 20, False), (3, 9, (1 << 20) + 3, True),
+                                             (33, 7, 70001, False)])
