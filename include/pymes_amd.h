@@ -326,6 +326,14 @@ int pymes_dots_var(pymes_ctx* ctx, int npairs, const double* const* x_dev, const
 /* out = sum_k c[k]*x[k], nx <= 8 */
 int pymes_lincomb(pymes_ctx* ctx, double* out_dev, int nx, const double* const* x_dev, const double* c_host,
                   int64_t n);
+/* Grouped launches of small products.  The reference evaluates its term sequences one einsum after the other
+ * (pymes/solver/ccd.py:175-240, eom_ccsd.py:288-383); on the device the small ones are 5-50 us kernels on a quarter-filled
+ * chip.  Products (pymes_contract / pymes_dgemm) issued between begin and end are INDEPENDENT by the caller's promise — none
+ * reads or accumulates into the output of another — and those that run on 64 x 64 tiles are launched together, up to 16
+ * per launch (one launch per dependency level).  Anything else the context enqueues in between launches the queue first.
+ * _end reports the grouped launches made and the products they carried (either pointer may be NULL). */
+int pymes_gemm_group_begin(pymes_ctx* ctx);
+int pymes_gemm_group_end(pymes_ctx* ctx, int64_t* launches, int64_t* products);
 /* Tall-skinny subspace algebra of the Davidson driver (pymes/solver/eom_ccsd.py:91 `QR`, :103-109 the subspace matrix
  * B[j,l] = <u_j, w_l>, :122-147 collapse / expansion vectors; reference: numpy on host arrays, vector by vector) and of the
  * FEAST driver (feast_eom_ccsd.py:110-150).  Every vector of a call is read once.

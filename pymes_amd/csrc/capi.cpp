@@ -35,10 +35,15 @@ int guarded(F&& f) {
     }
     return 1;
 }
-Engine& E(pymes_ctx* c) {
+Engine& Eq(pymes_ctx* c) {             // entry points that may add to an open group of products (pymes_gemm_group_begin)
     if (!c || !c->e) throw pymes::Error("null context");
     dev::set_device(c->e->device);      // a process may hold contexts on several GPUs: every entry runs on its own
     return *c->e;
+}
+Engine& E(pymes_ctx* c) {               // every other entry point: what is queued in an open group goes first
+    Engine& e = Eq(c);
+    dev::gemm_group_sync();
+    return e;
 }
 void need(const void* p, const char* what) {
     if (!p) throw pymes::Error(std::string("null pointer: ") + what);
@@ -170,7 +175,7 @@ int pymes_contract(pymes_ctx* ctx, double alpha, const double* A, const char* la
                    double beta, double* C, const char* lc, const int64_t* dC, const int64_t* sC,
                    const char* batch) {
     return guarded([&] {
-        E(ctx).contract(alpha, view_of(A, la, dA, sA), la, view_of(B, lb, dB, sB), lb, beta, view_of(C, lc, dC, sC),
+        Eq(ctx).contract(alpha, view_of(A, la, dA, sA), la, view_of(B, lb, dB, sB), lb, beta, view_of(C, lc, dC, sC),
                         lc, batch ? batch : "");
     });
 }
@@ -196,7 +201,7 @@ int pymes_permute(pymes_ctx* ctx, double alpha, const double* in, const char* li
 int pymes_dgemm(pymes_ctx* ctx, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t a_sm,
                 int64_t a_sk, const double* B, int64_t b_sk, int64_t b_sn, double beta, double* C, int64_t ldc) {
     return guarded([&] {
-        Engine& e = E(ctx);
+        Engine& e = Eq(ctx);
         dev::Gemm g{};
         g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
         g.A = A; g.a_sm = a_sm; g.a_sk = a_sk;
@@ -605,6 +610,19 @@ int pymes_lincomb(pymes_ctx* ctx, double* out, int nx, const double* const* x, c
     });
 }
 
+int pymes_gemm_group_begin(pymes_ctx* ctx) {
+    return guarded([&] { dev::gemm_group_begin(Eq(ctx).stream); });
+}
+int pymes_gemm_group_end(pymes_ctx* ctx, int64_t* launches, int64_t* products) {
+    return guarded([&] {
+        Eq(ctx);
+        dev::gemm_group_end();
+        long l = 0, p = 0;
+        dev::gemm_group_stats(&l, &p);
+        if (launches) *launches = l;
+        if (products) *products = p;
+    });
+}
 int pymes_gram(pymes_ctx* ctx, int m, int n, const double* const* x, const double* const* y, int64_t len, double* out) {
     return guarded([&] {
         need(x, "x"); need(y, "y"); need(out, "out");

@@ -47,6 +47,10 @@ double* Engine::get_static(const std::string& key) {
         permute(2.0, Vijab, "klcd", 0.0, make_view(p, {v, o, v, o}), "ckdl");
         permute(-1.0, Vijab, "lkcd", 1.0, make_view(p, {v, o, v, o}), "ckdl");
     }
+    else if (key == "Ldh") {                                     // Ld / 2 = Vd - Vx / 2 (the D-term build of the paired ring products)
+        permute(1.0, Vijab, "klcd", 0.0, make_view(p, {v, o, v, o}), "ckdl");
+        permute(-0.5, Vijab, "lkcd", 1.0, make_view(p, {v, o, v, o}), "ckdl");
+    }
     else if (key == "Vk") permute(1.0, Vijab, "lkdc", 0.0, make_view(p, {o, v, o, v}), "kdlc");   // [(k,d,l),c]
     else if (key == "Vk2") permute(1.0, Vijab, "lkdc", 0.0, make_view(p, {o, v, v, o}), "kcdl");  // [k,(c,d,l)]
     // K-major copies for the o x o results contracted over o v^2 (K = 2e6 at the benchmark size): with the long index
@@ -308,14 +312,41 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
     // golden solve pins the result).  DCSD keeps ccd.py:202-204 only: 2 Wd - Ud^T + Vd Tt_d in the D-term, no build in the
     // C-term.  Column slab [c0,c1): both builds are restricted to the rank's columns n, the applications give rows n.
     TView M = slab(), N1 = slab();
-    load_cols(2.0, Viabj, "kbcj", M);                                                         // M = 2 Wd
+    // One rank with all columns: the two builds are independent, and so are the two applications once the D-term no longer
+    // carries the half of the C-term (Ex_d = D + Ex_x / 2: the assembly reads Ex_x in both placements, `ring_xd_`) — each pair
+    // is ONE batched launch of 2 x tiles (the second operand set addressed through pointer differences as batch strides).
+    // At (20,80) a product is 169 tiles of 128 x 128 on 256 CUs, 3-way k-split with its reduction; a pair is 338 tiles:
+    // 256 whole ones and an 82-tile tail.  M is kept halved (M_h = Wd - UdT / 2 + Ld Tt_d / 4) so that both products of a
+    // pair share alpha.
+    const bool paired = nc == ov && !getenv("PYMES_NO_RING_PAIRS");
+    ring_xd_ = paired ? 0.5 : 0.0;
+    auto pair_gemm = [&](double alpha, const double* A0, const double* A1, const double* B0, const double* B1, double beta,
+                         double* C0, double* C1) {
+        auto diff = [](const double* x, const double* y) {
+            return static_cast<int64_t>((reinterpret_cast<intptr_t>(x) - reinterpret_cast<intptr_t>(y)) / 8);
+        };
+        dev::Gemm g{};
+        g.M = ov; g.N = ov; g.K = ov; g.alpha = alpha; g.beta = beta;
+        g.A = A0; g.a_sm = ov; g.a_sk = 1;          // symmetric pair matrices on the left, K-contiguous
+        g.B = B0; g.b_sk = ov; g.b_sn = 1;
+        g.C = C0; g.ldc = ov;
+        g.nb1 = 2; g.nb2 = 1;
+        g.a_b1 = diff(A1, A0); g.b_b1 = diff(B1, B0); g.c_b1 = diff(C1, C0);
+        g.a_b2 = g.b_b2 = g.c_b2 = 0;
+        g.splitk_ws = splitk_ws_;
+        g.splitk_ws_doubles = splitk_doubles_;
+        dev::gemm(g, stream);
+        stats.gemm_calls++;
+        stats.gemm_flops += 4.0 * double(ov) * double(ov) * double(ov);
+    };
+    load_cols(paired ? 1.0 : 2.0, Viabj, "kbcj", M);                                          // M = 2 Wd  (paired: Wd)
     load_cols(-1.0, Viajb, "kbjc", N1);                                                       // N1 = -UdT
-    axpby(1.0, N1, 1.0, M);                                                                  // M = 2 Wd - UdT
+    axpby(paired ? 0.5 : 1.0, N1, 1.0, M);                                                   // M = 2 Wd - UdT  (paired: half of it)
     // The small V.T sums S_ac = sum_dkl Tt_adkl V_lkdc, S_ki = sum_cdl Tt_cdil V_lkdc (X_ac, X_ki, ccsd.py:434 / :436) are
     // partial traces of the builds: tr(Vd Tt_d) for DCSD, (3 tr(Vx Tx) + tr(Ld Tt_d)) / 4 for CCSD — read off the
     // accumulators before and after the products (all columns on this rank only)
     const bool traces = !P && nc == ov;
-    const double cz = quad ? 0.5 : 1.0, cu = 1.5;          // (tr after - tr before) x these = the contribution to S
+    const double cz = (quad ? 0.5 : 1.0) * (paired ? 2.0 : 1.0), cu = 1.5;   // (tr after - tr before) x these = the contribution to S
     if (traces) {
         ensure_xs();
         xs_oo_tag_.clear();
@@ -323,11 +354,13 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
         dev::pair_traces(M.p, nc, -cz, 0.0, xs_vv_, xs_oo_, no, nv, stream);
         if (quad) dev::pair_traces(N1.p, nc, -cu, 1.0, xs_vv_, xs_oo_, no, nv, stream);
     }
-    if (quad) {
+    if (quad && paired) {
+        pair_gemm(0.5, get_static("Ldh"), get_static("Vx"), Ttd.p, Tx.p, 1.0, M.p, N1.p);    // M_h += Ld Tt_d / 4, N1 += Vx Tx / 2
+    } else if (quad) {
         contract(0.5, pairm(get_static("Ld")), "xy", cols(Ttd), "yn", 1.0, M, "xn");         // M = 2 Wd - UdT + Ld Tt_d / 2
         contract(0.5, pairm(get_static("Vx")), "xy", cols(Tx), "yn", 1.0, N1, "xn");         // N1 = -(UdT - Vx Tx / 2)
     } else {
-        contract(1.0, pairm(get_static("Vd")), "xy", cols(Ttd), "yn", 1.0, M, "xn");         // M = 2 Wd - UdT + Vd Tt_d
+        contract(paired ? 0.5 : 1.0, pairm(get_static("Vd")), "xy", cols(Ttd), "yn", 1.0, M, "xn");   // M = 2 Wd - UdT + Vd Tt_d
     }
     if (traces) {
         dev::pair_traces(M.p, nc, cz, 1.0, xs_vv_, xs_oo_, no, nv, stream);
@@ -335,7 +368,9 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
         xs_oo_tag_.set(t2, 0, 1);
         xs_vv_tag_.set(t2, 0, 1);
     }
-    if (nc == ov) {
+    if (paired) {
+        pair_gemm(1.0, Tx.p, Ttd.p, N1.p, M.p, 0.0, ETx.p, ETd.p);                           // Ex_x = -Xc,  D = Tt_d M_h
+    } else if (nc == ov) {
         // all columns on this rank: nothing is exchanged, and since only Ex + Ex^T enters R (residual_assemble) the slab
         // need not be transposed — Ex_x = Tx N1 and Ex_d = Tt_d M / 2 + Ex_x / 2 with the K-contiguous symmetric amplitudes
         // on the left: the same operand layout as the two builds (the LDS-DMA variant with the better L2 reuse: 6.4 GB of
@@ -491,7 +526,7 @@ void Engine::residual_finish(const double* f, const double* t2, const double* ET
     if (fused) {
         // R = V~_abij (or what R holds already) + ladders + Ex + Ex^T in one pass              (:185-187, :249-252)
         dev::residual_assemble(packed ? Vabij_src.p : r2, packed ? L : nullptr, Exn.p, ETd_p, ETx_p, r2, no,
-                               nv, stream);
+                               nv, stream, ring_xd_);
         stats.permute_calls++;
         stats.permute_bytes += 8.0 * 5.5 * double(o * o * v * v);
         return;
@@ -503,6 +538,10 @@ void Engine::residual_finish(const double* f, const double* t2, const double* ET
     permute(1.0, ETd, "bjai", 1.0, R, "abij");
     permute(1.0, ETx, "ajbi", 1.0, R, "abij");
     permute(1.0, ETx, "biaj", 1.0, R, "abij");
+    if (ring_xd_ != 0.0) {                                                                  // Ex_d = D + Ex_x / 2 (residual_slab)
+        permute(ring_xd_, ETx, "aibj", 1.0, R, "abij");
+        permute(ring_xd_, ETx, "bjai", 1.0, R, "abij");
+    }
 }
 
 // hf.py:14-18 from the packed blocks: f = h + 2 V_piqi - V_piiq (i occupied)
@@ -612,7 +651,7 @@ void Engine::residual_finish_pairs(const double* f, const double* t2, const doub
     if (t1) amplitude_side_abij(t1, QK, Np, a0, a1, nb, true);
     // V_abij is read undressed in the amplitude-side mode (CCSD); CCD/DCD have nothing to dress
     const TView Vabij = block(P_abij, t1 ? false : dressed);
-    dev::residual_assemble_pairs(Vabij.p, L, Np.p, ETd_p, ETx_p, Rc, no, nv, r0, r1, a0, static_cast<int>(nb), stream);
+    dev::residual_assemble_pairs(Vabij.p, L, Np.p, ETd_p, ETx_p, Rc, no, nv, r0, r1, a0, static_cast<int>(nb), stream, ring_xd_);
     stats.permute_calls++;
     stats.permute_bytes += 8.0 * 5.5 * double(r1 - r0) * 2.0 * double(o * o);
     xs_oo_tag_.clear();                                               // last call of the iteration
@@ -1038,13 +1077,27 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
             Ap = static_["VpDress" + rkey];
             Am_ = static_["VmDress" + rkey];
         }
-        if (rows > 0) {
-            contract(1.0, packed_rows(const_cast<double*>(Ap), rows, npp), "rk", SpT, "kn", 0.0, LS, "rn");
-            if (opm > 0) {
-                if (npm > 0) contract(1.0, packed_rows(const_cast<double*>(Am_), rows, npm), "rk", AmT, "kn", 0.0, LA, "rn");
-                else zero(LA);
-            }
+        // the two halves of the particle ladder (and of Q_kb below) are independent products: small problems run them as
+        // one grouped launch (dev::gemm_group_*), big ones keep their LDS-DMA launches
+        TView Qp, QS, QA;
+        if (qrows > 0 && !dress) {
+            Qp = make_view(arena.alloc(qrows * o * o), {qrows, o * o});
+            QS = slice(Qp, 1, 0, opp);
+            QA = slice(Qp, 1, opp, o * o);
         }
+        {
+            GemmGroupScope grp(stream);
+            if (rows > 0) {
+                contract(1.0, packed_rows(const_cast<double*>(Ap), rows, npp), "rk", SpT, "kn", 0.0, LS, "rn");
+                if (opm > 0 && npm > 0) contract(1.0, packed_rows(const_cast<double*>(Am_), rows, npm), "rk", AmT, "kn", 0.0, LA, "rn");
+            }
+            if (qrows > 0 && !dress) {
+                contract(1.0, packed_rows(static_["VpK" + kkey], qrows, npp), "rk", SpT, "kn", 0.0, QS, "rn");
+                if (opm > 0 && npm > 0) contract(1.0, packed_rows(static_["VmK" + kkey], qrows, npm), "rk", AmT, "kn", 0.0, QA, "rn");
+            }
+            grp.close();
+        }
+        if (rows > 0 && opm > 0 && npm <= 0) zero(LA);
         if (qrows > 0 && dress) {
             // QK = W_kbij alone (ccsd.py:322-343, the (i,j)-, (c,j)- and (i,d)-ket parts of the bras (k,b))
             TView t = make_view(const_cast<double*>(t1), {v, o});
@@ -1056,13 +1109,7 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
             // rows (k,b) in [q0,q1) of Q_kbij + W_kbij, plain [i][j]: the pair-packed product [ QS | QA ] is unpacked
             // into the exchange buffer and the small brackets of amplitude_side_abij are added for the same rows, so
             // that they are sharded with Q instead of being repeated by every rank
-            TView Qp = make_view(arena.alloc(qrows * o * o), {qrows, o * o});
-            TView QS = slice(Qp, 1, 0, opp), QA = slice(Qp, 1, opp, o * o);
-            contract(1.0, packed_rows(static_["VpK" + kkey], qrows, npp), "rk", SpT, "kn", 0.0, QS, "rn");
-            if (opm > 0) {
-                if (npm > 0) contract(1.0, packed_rows(static_["VmK" + kkey], qrows, npm), "rk", AmT, "kn", 0.0, QA, "rn");
-                else zero(QA);
-            }
+            if (opm > 0 && npm <= 0) zero(QA);
             dev::rows_unpack(Qp.p, QK + q0 * o * o, qrows, no, stream);
             TView t = make_view(const_cast<double*>(t1), {v, o});
             TView Qr = make_view(QK + q0 * o * o, {qrows, o, o});
@@ -1107,17 +1154,21 @@ void Engine::ladder_t1(const double* t1, const double* t2, double* L, int64_t ro
         double* Sp = arena.alloc(npp * ldp);
         double* Am = arena.alloc(std::max<int64_t>(npm * ldm, 1));
         dev::ladder_pack_T(t2, nullptr, Sp, Am, no, nv, dev::PACK_ROW_HALF, ldp, ldm, stream);
+        GemmGroupScope grp(stream);
         contract(2.0, packed_rows(static_["VpIjab"], opp, npp), "rk", pitched(Sp, npp, opp, ldp), "kn", bI, Ipv, "rn");
         if (opm > 0 && npm > 0)
             contract(2.0, packed_rows(static_["VmIjab"], opp, npm), "rk", pitched(Am, npm, opm, ldm), "kn", bI, Imv, "rn");
-        else if (opm > 0 && !dcd) axpby(2.0, Imv, 0.0, Imv);
+        grp.close();
+        if (opm > 0 && npm <= 0 && !dcd) axpby(2.0, Imv, 0.0, Imv);
     }
     // CCSD: rows of tau against Ifull;  DCSD: rows of t1 t1 against Ifull (rows of T were taken above)
     dev::ladder_pack_T(dcd ? nullptr : t2, t1, SpR, AmR, no, nv, rflags, ldp, ldp, stream, row0, row1);   // this rank's rows
     stats.permute_calls += 3;
     stats.permute_bytes += 8.0 * 4.0 * double(v * v * o * o);
+    GemmGroupScope grp(stream);
     contract(1.0, rowsS(), "rk", IpK, "kn", 1.0, LS, "rn");
     if (opm > 0) contract(1.0, rowsA(), "rk", ImK, "kn", 1.0, LA, "rn");
+    grp.close();
 }
 
 void Engine::ladder_sym_unpack(const double* L, double* r2, double beta) {
@@ -1419,18 +1470,27 @@ void Engine::singles_residual_partial(const double* fd, const double* t1, const 
         permute(-1.0, slice(T, 2, j0, j1), "bcji", 1.0, P1, "jbci");
     }
     contract(1.0, Tq, "bjai", slice(Dov, 0, j0, j1), "jb", 1.0, R, "ai");                    // :432 (Tt' symmetric)
-    contract(1.0, slice(block(P_aibc), 1, j0, j1), "ajbc", P1, lp1, 1.0, R, "ai");           // :433
-    if (!have_oo) {
-        TView S2 = make_view(arena.alloc(o * o), {o, o});
-        contract(1.0, slice(make_view(get_static("Vjbck"), {o, v, v, o}), 0, j0, j1), "jbck", P1, lp1, 0.0, S2, "ki");
-        contract(-1.0, t, "ak", S2, "ki", 1.0, R, "ai");                                     // :434
+    // :433 and :435 (and the sums of :434 / :436 when they were not left by the slab) are independent products over the
+    // same amplitudes: each into a buffer of its own, as ONE grouped launch, then one sum — at (20,80) four 15-50 us
+    // k-split launches with their reductions otherwise
+    TView R3 = make_view(arena.alloc(v * o), {v, o}), R5 = make_view(arena.alloc(v * o), {v, o});
+    TView S2 = make_view(arena.alloc(o * o), {o, o}), S4 = make_view(arena.alloc(v * v), {v, v});
+    {
+        GemmGroupScope grp(stream);
+        contract(1.0, slice(block(P_aibc), 1, j0, j1), "ajbc", P1, lp1, 0.0, R3, "ai");                                   // :433
+        contract(-1.0, Tq, "ajbk", slice(block(P_ijka), 0, j0, j1), "jkib", 0.0, R5, "ai");                              // :435
+        if (!have_oo)
+            contract(1.0, slice(make_view(get_static("Vjbck"), {o, v, v, o}), 0, j0, j1), "jbck", P1, lp1, 0.0, S2, "ki");
+        if (!have_vv) contract(1.0, Tq, "ajbk", slice(block(P_ijab), 0, j0, j1), "jkcb", 0.0, S4, "ac");
+        grp.close();
     }
-    contract(-1.0, Tq, "ajbk", slice(block(P_ijka), 0, j0, j1), "jkib", 1.0, R, "ai");       // :435
-    if (!have_vv) {
-        TView S4 = make_view(arena.alloc(v * v), {v, v});
-        contract(1.0, Tq, "ajbk", slice(block(P_ijab), 0, j0, j1), "jkcb", 0.0, S4, "ac");
-        contract(-1.0, S4, "ac", t, "ci", 1.0, R, "ai");                                     // :436
+    {
+        const double* xs[3] = {R.p, R3.p, R5.p};
+        const double cs[3] = {1.0, 1.0, 1.0};
+        dev::lincomb(R.p, 3, xs, cs, v * o, stream);
     }
+    if (!have_oo) contract(-1.0, t, "ak", S2, "ki", 1.0, R, "ai");                           // :434
+    if (!have_vv) contract(-1.0, S4, "ac", t, "ci", 1.0, R, "ai");                           // :436
 }
 
 // -----------------------------------------------------------------------------------

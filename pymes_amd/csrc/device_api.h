@@ -93,6 +93,16 @@ void fock_finish(const double* f, const double* t1, const double* W, double* fd,
 void gemv_batch_begin();
 void gemv_batch_end();
 
+// Small products (64 x 64 tiles; see kernels.hip, dgemm_group_kernel) issued between begin and end are INDEPENDENT of each
+// other by the caller's promise — none reads or accumulates into what another writes — and are launched together, up to 16
+// per launch: one launch per dependency level of a term sequence.  Anything else enqueued on the stream in between (a
+// permutation, a copy, a big product, a synchronisation) launches the queue first, so the order of effects is that of
+// immediate execution; gemm_group_sync() does the same explicitly (a level boundary).  A no-op region in the host simulator.
+void gemm_group_begin(stream_t s);
+void gemm_group_end();
+void gemm_group_sync();
+void gemm_group_stats(long* launches, long* products);    // grouped launches / queued products since the last begin
+
 // ---- strided copy / permutation:  out = alpha * in + beta * out ----------------
 // rank <= 6, both tensors described by the same extents and their own strides.
 struct Permute {
@@ -195,8 +205,10 @@ void t2_layouts(const double* T, double* Td, double* Tx, double* Ttd, int no, in
 // Assembly of the symmetry-reduced residual (ccd.py:249-252) in one pass:
 //   R_abij = V_abij + unpack(L)_abij + N_abij + N_baji + D[(a,i),(b,j)] + D[(b,j),(a,i)] + X[(a,j),(b,i)] + X[(b,i),(a,j)]
 // L (pair-packed ladder rows, may be null), V (may be null: 0), N [v,v,o,o], D and X [ov,ov]
+// xd != 0: X enters in the direct placement too, + xd (X[(a,i),(b,j)] + X[(b,j),(a,i)]) — the half of the C-term that the
+// D-term carries (Ex_d = D + Ex_x / 2, cc.cpp residual_slab) read from X itself, so that the products D and X are independent
 void residual_assemble(const double* V, const double* L, const double* N, const double* D, const double* X, double* R,
-                       int no, int nv, stream_t s);
+                       int no, int nv, stream_t s, double xd = 0.0);
 // ---- pair-sharded tail: compact storage Xc[P - r0][2][o*o] of the tiles X[a,b,:,:], X[b,a,:,:] (zeros for a == b)
 // of the virtual pairs P(a,b) in [r0,r1) ------------------------------------------------------------------------
 void pairs_pack(const double* full, double* Xc, int no, int nv, int64_t r0, int64_t r1, stream_t s);
@@ -205,7 +217,7 @@ void cc_update_pairs(double* tc, double* dtc, const double* rc, const double* eo
                      double delta, int no, int nv, int64_t r0, int64_t r1, stream_t s);
 // residual_assemble for the pairs [r0,r1), compact output; Np[a - a0][b][o*o] (b < nbp) = N_ab + N_ba^T already combined
 void residual_assemble_pairs(const double* V, const double* L, const double* Np, const double* D, const double* X,
-                             double* Rc, int no, int nv, int64_t r0, int64_t r1, int a0, int nbp, stream_t s);
+                             double* Rc, int no, int nv, int64_t r0, int64_t r1, int a0, int nbp, stream_t s, double xd = 0.0);
 // plain rows of the same [ S | A ] layout: out[r][i][j] = Q[r][P(i,j)] + sgn(i-j) Q[r][o(o+1)/2 + Q(i,j)]
 void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t s);
 // partial traces of a pair matrix M[(c,k)][(b,j)] (row pitch ld; (c,k) = c*no + k):

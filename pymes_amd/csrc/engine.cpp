@@ -641,6 +641,9 @@ void Engine::contract(double alpha, const TView& A, const char* sa, const TView&
         stats.gemm_flops += 2.0 * double(Msz) * double(Nsz) * double(Ksz) * double(g.nb1) * double(g.nb2);
     }
     if (best.copyC) permute(1.0, Cv, lc.c_str(), beta, C, sc);
+    // a product that went through temporaries of this call's arena scope must not wait in an open group (dev::gemm_group_*):
+    // the scope ends here and the next call may reuse the memory
+    if (best.copyA || best.copyB || best.copyC) dev::gemm_group_sync();
 }
 
 // ---------------------------------------------------------------------------------

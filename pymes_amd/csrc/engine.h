@@ -63,6 +63,17 @@ struct ArenaScope {
     ~ArenaScope() { a.reset(m); }
 };
 
+// Products issued inside the scope are independent of each other (the caller's promise) and may share launches
+// (dev::gemm_group_begin / _end); level() closes a dependency level.  Only contract / permute / copy / zero calls belong inside.
+struct GemmGroupScope {
+    explicit GemmGroupScope(dev::stream_t s) { dev::gemm_group_begin(s); }
+    ~GemmGroupScope() {
+        try { dev::gemm_group_end(); } catch (...) {}
+    }
+    void level() { dev::gemm_group_sync(); }
+    void close() { dev::gemm_group_end(); }       // (errors of the launches surface here)
+};
+
 struct ContractStats {
     long gemm_calls = 0, permute_calls = 0;
     double gemm_flops = 0.0;       // executed 2*M*N*K*batch
@@ -229,6 +240,9 @@ class Engine {
         void set(const double* p, int r, int w) { t2 = p; rank = r; world = w; }
         void clear() { t2 = nullptr; }
     };
+    // weight of Ex_x in the direct placement that the assembly adds (residual_slab -> residual_finish[_pairs] of the same
+    // iteration): 1/2 when the D-term product was computed without the half of the C-term (paired ring products), else 0
+    double ring_xd_ = 0.0;
     double* xs_oo_ = nullptr;
     double* xs_vv_ = nullptr;
     SumTag xs_oo_tag_, xs_vv_tag_;

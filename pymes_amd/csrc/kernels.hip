@@ -72,8 +72,9 @@ __device__ __forceinline__ long xcd_remap(long b, long nblk) {
 // consumed, two barriers per k-tile — so that twice as many blocks fit a CU (19 KB of LDS each) and more loads are in
 // flight: for the short-K / tiny-output products that stream a 3.2-GB integral block once (T1 dressing, singles residual),
 // which are bound by HBM latency x bytes in flight, not by the MFMA pipe.
+// `bid`: the block's logical id inside this product (already remapped over the XCDs)
 template <int BM, int BN, bool AKC, bool BKC, int VEC, bool STREAM = false>
-__global__ void __launch_bounds__(kThreads, STREAM ? 4 : 2) dgemm_kernel(const GemmK g) {
+__device__ __forceinline__ void dgemm_body(const GemmK& g, const long bid) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int WM = BM / 2, WN = BN / 2;      // wave tile (2x2 waves)
     constexpr int FM = WM / 16, FN = WN / 16;    // MFMA tiles per wave
@@ -99,7 +100,6 @@ __global__ void __launch_bounds__(kThreads, STREAM ? 4 : 2) dgemm_kernel(const G
     const int l15 = lane & 15, l4 = lane >> 4;
 
     // ---- block -> (batch z, k-split ks, tile tm/tn) -------------------------------
-    const long bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tiles = g.tiles_m * g.tiles_n;
     const long lt = bid / g.nsplit;                  // launch-local tile; its k-splits are adjacent blocks
     const int ks = (int)(bid - lt * g.nsplit);
@@ -357,6 +357,42 @@ __global__ void __launch_bounds__(kThreads, STREAM ? 4 : 2) dgemm_kernel(const G
                 }
             }
         }
+    }
+}
+
+template <int BM, int BN, bool AKC, bool BKC, int VEC, bool STREAM = false>
+__global__ void __launch_bounds__(kThreads, STREAM ? 4 : 2) dgemm_kernel(const GemmK g) {
+    dgemm_body<BM, BN, AKC, BKC, VEC, STREAM>(g, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// Grouped launch: up to kGroupMax INDEPENDENT small products (64 x 64 tiles, any operand layout, with or without k-split)
+// in ONE grid — one launch per dependency level of a term sequence instead of one per product.  The (20,80) iteration and the
+// per-vector terms of an EOM sigma build are chains of 5-50 us kernels, each a latency chain (global -> LDS -> barrier -> MFMA)
+// on a quarter-filled chip; grouped, the blocks of all products of a level share the chip and one launch / drain.
+// Blocks are dealt to the products by a prefix table (uniform scan of <= 16 entries in SGPRs); a block then runs the body of
+// its product's layout variant.  Descriptors travel as kernel arguments (3 KB): nothing to upload, graph capture keeps them.
+constexpr int kGroupMax = 16;
+struct GroupK {
+    int n, pad;
+    int blk_end[kGroupMax];     // running block count
+    int variant[kGroupMax];     // bit 2: A K-contiguous, bit 1: B K-contiguous, bit 0: 16-byte loads
+    GemmK g[kGroupMax];
+};
+__global__ void __launch_bounds__(kThreads, 2) dgemm_group_kernel(const GroupK grp) {
+    const long gb = xcd_remap(blockIdx.x, gridDim.x);      // an XCD runs a contiguous range of logical blocks
+    int it = 0;
+    while (it + 1 < grp.n && gb >= grp.blk_end[it]) ++it;
+    const long bid = gb - (it ? grp.blk_end[it - 1] : 0);
+    const GemmK& g = grp.g[it];
+    switch (grp.variant[it]) {
+        case 0: dgemm_body<64, 64, false, false, 1>(g, bid); break;
+        case 1: dgemm_body<64, 64, false, false, 2>(g, bid); break;
+        case 2: dgemm_body<64, 64, false, true, 1>(g, bid); break;
+        case 3: dgemm_body<64, 64, false, true, 2>(g, bid); break;
+        case 4: dgemm_body<64, 64, true, false, 1>(g, bid); break;
+        case 5: dgemm_body<64, 64, true, false, 2>(g, bid); break;
+        case 6: dgemm_body<64, 64, true, true, 1>(g, bid); break;
+        default: dgemm_body<64, 64, true, true, 2>(g, bid); break;
     }
 }
 
@@ -625,8 +661,7 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_glds_kernel(const GemmK g) 
 }
 
 // C tile = alpha * sum_ks ws[tile][ks] + beta * C tile, for the tiles [tile_begin, tile_begin + ntiles)
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmK g, int BM, int BN) {
-    const long lt = blockIdx.x;
+__device__ __forceinline__ void splitk_reduce_body(const GemmK& g, const int BM, const int BN, const long lt, const int piece) {
     const int tiles = g.tiles_m * g.tiles_n;
     const long gt = g.tile_begin + lt;
     const long z = gt / tiles;
@@ -645,13 +680,20 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmK g, int B
     const double* __restrict__ W = g.ws + lt * g.nsplit * (long)(BM * BN);
     // blockIdx.y cuts the tile into 256-element pieces: a launch with few tiles and many splits (huge K, tiny
     // output) still spreads over the chip
-    const int e = blockIdx.y * 256 + threadIdx.x;
+    const int e = piece * 256 + threadIdx.x;
     const int r = e / BN, c = e - r * BN;
     const int m = tm * BM + r, n = tn * BN + c;
     if (m >= g.M || n >= g.N) return;
     const long st = (long)BM * BN;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int k = 0;
+    for (; k + 16 <= g.nsplit; k += 16) {       // sixteen loads in flight (a chain of single loads is a latency chain:
+        double w[16];                           // 40 us for 256 partials); same summation order as the loop below
+#pragma unroll
+        for (int q = 0; q < 16; ++q) w[q] = W[(long)(k + q) * st + e];
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) { s0 += w[q]; s1 += w[q + 1]; s2 += w[q + 2]; s3 += w[q + 3]; }
+    }
     for (; k + 4 <= g.nsplit; k += 4) {
         s0 += W[(long)k * st + e];
         s1 += W[(long)(k + 1) * st + e];
@@ -663,6 +705,16 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmK g, int B
     double v = g.alpha * ((s0 + s1) + (s2 + s3));
     if (g.beta != 0.0) v += g.beta * Cin[off];
     C[off] = v;
+}
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmK g, int BM, int BN) {
+    splitk_reduce_body(g, BM, BN, blockIdx.x, blockIdx.y);
+}
+// the k-split products of one grouped launch, reduced by one launch (64 x 64 tiles: 16 pieces of 256 elements per tile)
+__global__ void __launch_bounds__(256) splitk_reduce_group_kernel(const GroupK grp) {
+    int it = 0;
+    while (it + 1 < grp.n && (int)blockIdx.x >= grp.blk_end[it]) ++it;
+    const int local = blockIdx.x - (it ? grp.blk_end[it - 1] : 0);
+    splitk_reduce_body(grp.g[it], 64, 64, local >> 4, local & 15);
 }
 
 __device__ __forceinline__ double wave_sum(double v);
@@ -1616,7 +1668,7 @@ __global__ void __launch_bounds__(256) t2_layouts_kernel(const double* __restric
 __global__ void __launch_bounds__(256) residual_assemble_kernel(const double* V, const double* __restrict__ L,
                                                                 const double* __restrict__ N, const double* __restrict__ D,
                                                                 const double* __restrict__ X, double* R,   // V may be R
-                                                                int no, int nv) {
+                                                                int no, int nv, double xd) {
     extern __shared__ double S[];             // [no][no + 1]
     int a, b;
     unrank_pair(blockIdx.x, a, b);
@@ -1626,12 +1678,16 @@ __global__ void __launch_bounds__(256) residual_assemble_kernel(const double* V,
     const long tab = (long)a * no * ov + (long)b * no, tba = (long)b * no * ov + (long)a * no;
     for (int e = threadIdx.x; e < o2; e += blockDim.x) {      // sources read in (i,j) order
         const int i = e / no, j = e - i * no;
-        S[i * p + j] = N[ab + e] + D[tab + (long)i * ov + j] + X[tba + (long)i * ov + j];
+        double v = N[ab + e] + D[tab + (long)i * ov + j] + X[tba + (long)i * ov + j];
+        if (xd != 0.0) v += xd * X[tab + (long)i * ov + j];      // X in the direct placement as well (see device_api.h)
+        S[i * p + j] = v;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < o2; e += blockDim.x) {      // sources read in (j,i) order
         const int j = e / no, i = e - j * no;
-        S[i * p + j] += N[ba + e] + D[tba + (long)j * ov + i] + X[tab + (long)j * ov + i];
+        double v = N[ba + e] + D[tba + (long)j * ov + i] + X[tab + (long)j * ov + i];
+        if (xd != 0.0) v += xd * X[tba + (long)j * ov + i];
+        S[i * p + j] += v;
     }
     __syncthreads();
     const double* __restrict__ row = L ? L + ((long)a * (a + 1) / 2 + b) * o2 : nullptr;
@@ -1754,7 +1810,7 @@ __global__ void __launch_bounds__(256) cc_update_pairs_kernel(double* __restrict
 __global__ void __launch_bounds__(256) residual_assemble_pairs_kernel(const double* __restrict__ V, const double* __restrict__ L,
                                                                       const double* __restrict__ Np, const double* __restrict__ D,
                                                                       const double* __restrict__ X, double* __restrict__ Rc,
-                                                                      int no, int nv, long r0, int a0, int nbp) {
+                                                                      int no, int nv, long r0, int a0, int nbp, double xd) {
     extern __shared__ double S[];             // [no][no + 1]
     int a, b;
     unrank_pair(r0 + blockIdx.x, a, b);
@@ -1765,12 +1821,16 @@ __global__ void __launch_bounds__(256) residual_assemble_pairs_kernel(const doub
     const double* __restrict__ n = Np + ((long)(a - a0) * nbp + b) * o2;       // Np is [a1 - a0][nbp][o*o], nbp > b
     for (int e = threadIdx.x; e < o2; e += blockDim.x) {
         const int i = e / no, j = e - i * no;
-        S[i * p + j] = n[e] + D[tab + (long)i * ov + j] + X[tba + (long)i * ov + j];
+        double v = n[e] + D[tab + (long)i * ov + j] + X[tba + (long)i * ov + j];
+        if (xd != 0.0) v += xd * X[tab + (long)i * ov + j];
+        S[i * p + j] = v;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < o2; e += blockDim.x) {
         const int j = e / no, i = e - j * no;
-        S[i * p + j] += D[tba + (long)j * ov + i] + X[tab + (long)j * ov + i];
+        double v = D[tba + (long)j * ov + i] + X[tab + (long)j * ov + i];
+        if (xd != 0.0) v += xd * X[tba + (long)j * ov + i];
+        S[i * p + j] += v;
     }
     __syncthreads();
     const double* __restrict__ row = L ? L + ((long)a * (a + 1) / 2 + b) * o2 : nullptr;
@@ -2415,6 +2475,96 @@ void gemv_batch_flush() {
     b.tab.n = 0;
     b.ws_used = 0;
 }
+
+// ---- dev::gemm_group_begin / _end: small products issued in between are queued and launched together ----------------
+struct GemmGroup {
+    bool active = false;
+    hipStream_t st = nullptr;
+    int n = 0;
+    GemmK k[kGroupMax];
+    int variant[kGroupMax];
+    long tiles[kGroupMax], ktiles[kGroupMax];
+    double flops[kGroupMax];
+    double* ws = nullptr;
+    long ws_doubles = 0;
+    long launches = 0, products = 0;      // statistics since gemm_group_begin (tests, tuning)
+};
+thread_local GemmGroup g_group;
+
+void gemm_group_flush() {
+    GemmGroup& q = g_group;
+    if (q.n == 0) return;
+    hipStream_t st = q.st;
+    // k-splitting: 64 x 64 tiles fill the chip from ~1024 blocks (four co-resident per CU); with fewer tiles in the whole
+    // group every product that is deep enough is cut along K by a common factor (>= 8 k-tiles per cut, workspace permitting)
+    long total = 0;
+    for (int i = 0; i < q.n; ++i) total += q.tiles[i];
+    long want = total < 768 ? (1024 + total - 1) / total : 1;
+    GroupK grp, red;
+    grp.n = q.n; grp.pad = 0; red.n = 0; red.pad = 0;
+    long blocks = 0, ws_used = 0, red_blocks = 0;
+    double flops = 0.0;
+    for (int i = 0; i < q.n; ++i) {
+        GemmK& k = q.k[i];
+        long sp = std::max<long>(1, std::min<long>(std::min<long>(want, 64), q.ktiles[i] / 8));
+        while (sp > 1 && ws_used + q.tiles[i] * sp * 4096 > q.ws_doubles) --sp;
+        const long kt_per = (q.ktiles[i] + sp - 1) / sp;
+        k.kchunk = (int)std::max<long>(kt_per * BK, BK);
+        k.nsplit = (int)std::max<long>(1, (q.ktiles[i] + kt_per - 1) / std::max<long>(kt_per, 1));
+        k.tile_begin = 0;
+        k.ws = nullptr;
+        if (k.nsplit > 1) {
+            k.ws = q.ws + ws_used;
+            ws_used += q.tiles[i] * k.nsplit * 4096;
+            red.g[red.n] = k;
+            red.variant[red.n] = 0;
+            red_blocks += q.tiles[i] * 16;
+            red.blk_end[red.n] = (int)red_blocks;
+            ++red.n;
+        }
+        blocks += q.tiles[i] * k.nsplit;
+        grp.blk_end[i] = (int)blocks;
+        grp.variant[i] = q.variant[i];
+        grp.g[i] = k;
+        flops += q.flops[i];
+    }
+    for (int i = q.n; i < kGroupMax; ++i) { grp.blk_end[i] = (int)blocks; grp.variant[i] = 0; }
+    for (int i = red.n; i < kGroupMax; ++i) { red.blk_end[i] = (int)red_blocks; red.variant[i] = 0; }
+    const int nq = q.n;
+    q.n = 0;                                   // (an exception below must not leave the queue half-consumed)
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (g_prof.on) {
+        if (!g_prof.pool.empty()) { ev = g_prof.pool.back(); g_prof.pool.pop_back(); }
+        else { HIP_CHECK(hipEventCreate(&ev.first)); HIP_CHECK(hipEventCreate(&ev.second)); }
+        HIP_CHECK(hipEventRecord(ev.first, st));
+    }
+    constexpr size_t lds = (size_t)2 * 2 * ((64 + 16) * BK) * sizeof(double);       // the widest variant, double buffered
+    static bool attr_set[kMaxDevices] = {false};
+    const int dv = current_device();
+    if (!attr_set[dv]) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dgemm_group_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dv] = true;
+    }
+    hipLaunchKernelGGL(dgemm_group_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, st, grp);
+    HIP_CHECK(hipGetLastError());
+    if (red.n > 0) {
+        hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3((unsigned)red_blocks), dim3(256), 0, st, red);
+        HIP_CHECK(hipGetLastError());
+    }
+    ++q.launches;
+    if (g_prof.on) {
+        HIP_CHECK(hipEventRecord(ev.second, st));
+        g_prof.ev.push_back(ev);
+        g_prof.flops += flops;
+        g_prof.fl.push_back(flops);
+        g_prof.klass.push_back(0);
+        g_prof.nk.push_back(1);
+        char buf[128];
+        snprintf(buf, sizeof buf, "group of %d products, %ld blocks, %d k-split, flops=%.4e", nq, blocks, red.n, flops);
+        g_prof.what.push_back(buf);
+    }
+}
 }  // namespace
 
 namespace dev {
@@ -2469,6 +2619,7 @@ void graph_begin(stream_t s) {
     HIP_CHECK(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeRelaxed));
 }
 graph_t graph_end(stream_t s) {
+    gemm_group_flush();
     hipGraph_t g = nullptr;
     HIP_CHECK(hipStreamEndCapture((hipStream_t)s, &g));
     if (!g) throw std::runtime_error("graph capture produced no graph");
@@ -2489,18 +2640,27 @@ void graph_destroy(graph_t g) {
     if (g) HIP_CHECK(hipGraphExecDestroy((hipGraphExec_t)g));
 }
 void memcpy_h2d(void* d, const void* h, size_t bytes, stream_t s) {
+    gemm_group_flush();
     HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, (hipStream_t)s));
     wait_idle((hipStream_t)s);
 }
 void memcpy_d2h(void* h, const void* d, size_t bytes, stream_t s) {
+    gemm_group_flush();
     HIP_CHECK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)s));
     wait_idle((hipStream_t)s);
 }
 void memcpy_d2d(void* d, const void* s_, size_t bytes, stream_t s) {
+    gemm_group_flush();
     HIP_CHECK(hipMemcpyAsync(d, s_, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
 }
-void memset_zero(void* d, size_t bytes, stream_t s) { HIP_CHECK(hipMemsetAsync(d, 0, bytes, (hipStream_t)s)); }
-void stream_sync(stream_t s) { wait_idle((hipStream_t)s); }
+void memset_zero(void* d, size_t bytes, stream_t s) {
+    gemm_group_flush();
+    HIP_CHECK(hipMemsetAsync(d, 0, bytes, (hipStream_t)s));
+}
+void stream_sync(stream_t s) {
+    gemm_group_flush();
+    wait_idle((hipStream_t)s);
+}
 size_t mem_free_bytes() {
     size_t f = 0, t = 0;
     HIP_CHECK(hipMemGetInfo(&f, &t));
@@ -2547,6 +2707,75 @@ void prof_query(int kernel_class, long* calls, long* kernel_launches, double* ms
     *flops = fl;
 }
 
+namespace {
+// Queue a product for the open group.  false: not a small product (it runs as its own launch, after the queue).
+bool gemm_group_take(const Gemm& g, bool a_kcontig, bool b_kcontig, int64_t a_sm, int64_t a_sk, int64_t b_sk, int64_t b_sn,
+                     hipStream_t st) {
+    GemmGroup& q = g_group;
+    if (q.st != st) return false;
+    const long nbatch = g.nb1 * g.nb2;
+    const long t64 = ((g.M + 63) / 64) * ((g.N + 63) / 64) * nbatch, t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128) * nbatch;
+    const long ktiles = (g.K + BK - 1) / BK;
+    // big products keep their own launches: enough 128 x 128 tiles for the chip, or deep enough for the LDS-DMA kernel's
+    // k-split; and so do the long streaming products (one pass over a multi-GB block: the single-buffer kernel moves more)
+    if (t128 >= 256 && ktiles * BK >= 256) return false;
+    if (t128 < 256 && g.K / std::max<long>(1, (512 + t128 - 1) / t128) >= dma_min_k() && g.M > 64 && g.N > 64) return false;
+    if (t64 * ktiles > 400000 || t64 > 0x3fffffffL / 16) return false;
+    GemmK k;
+    k.A = g.A; k.B = g.B; k.C = g.C;
+    k.Cin = g.Cin ? g.Cin : g.C;
+    k.a_ld = a_kcontig ? a_sm : a_sk;
+    k.b_ld = b_kcontig ? b_sn : b_sk;
+    k.ldc = g.ldc;
+    k.M = (int)g.M; k.N = (int)g.N; k.K = (int)g.K;
+    k.alpha = g.alpha; k.beta = g.beta;
+    k.nb2 = g.nb2;
+    k.a_b1 = g.a_b1; k.a_b2 = g.a_b2; k.b_b1 = g.b_b1; k.b_b2 = g.b_b2; k.c_b1 = g.c_b1; k.c_b2 = g.c_b2;
+    k.ws = nullptr;
+    k.tiles_m = (int)((g.M + 63) / 64);
+    k.tiles_n = (int)((g.N + 63) / 64);
+    int vec = 2;
+    k.Mc = k.M; k.Nc = k.N;
+    if (!a_kcontig && (g.M & 1) && k.a_ld > g.M) k.Mc = k.M + 1;
+    if (!b_kcontig && (g.N & 1) && k.b_ld > g.N) k.Nc = k.N + 1;
+    const long a_contig_extent = a_kcontig ? g.K : k.Mc, b_contig_extent = b_kcontig ? g.K : k.Nc;
+    if (!even(k.a_ld) || !even(k.b_ld) || !even(a_contig_extent) || !even(b_contig_extent) || !aligned16(g.A) || !aligned16(g.B) ||
+        !even(g.a_b1) || !even(g.a_b2) || !even(g.b_b1) || !even(g.b_b2))
+        vec = 1;
+    if (q.n == kGroupMax) gemm_group_flush();
+    // the grid of a group is one int: flush early when the running block count would not fit comfortably
+    long queued = 0;
+    for (int i = 0; i < q.n; ++i) queued += q.tiles[i];
+    if (queued + t64 > 0x3fffffffL / 16) gemm_group_flush();
+    const int i = q.n++;
+    q.k[i] = k;
+    q.variant[i] = (a_kcontig ? 4 : 0) | (b_kcontig ? 2 : 0) | (vec == 2 ? 1 : 0);
+    q.tiles[i] = t64;
+    q.ktiles[i] = ktiles;
+    q.flops[i] = 2.0 * (double)g.M * (double)g.N * (double)g.K * (double)nbatch;
+    q.ws = g.splitk_ws;
+    q.ws_doubles = g.splitk_ws ? g.splitk_ws_doubles : 0;
+    ++q.products;
+    return true;
+}
+}  // namespace
+
+void gemm_group_begin(stream_t s) {
+    gemm_group_flush();
+    g_group.active = true;
+    g_group.st = (hipStream_t)s;
+    g_group.launches = g_group.products = 0;
+}
+void gemm_group_end() {
+    gemm_group_flush();
+    g_group.active = false;
+}
+void gemm_group_sync() { gemm_group_flush(); }
+void gemm_group_stats(long* launches, long* products) {
+    if (launches) *launches = g_group.launches;
+    if (products) *products = g_group.products;
+}
+
 void gemm(const Gemm& g, stream_t s) {
     hipStream_t st = (hipStream_t)s;
     if (g.M <= 0 || g.N <= 0 || g.nb1 <= 0 || g.nb2 <= 0) return;
@@ -2562,6 +2791,8 @@ void gemm(const Gemm& g, stream_t s) {
     const bool b_kcontig = (b_sk == 1);
     if (gemv_dispatch(g, a_sm, a_sk, b_sk, b_sn, st)) return;
     gemv_batch_flush();
+    if (g_group.active && gemm_group_take(g, a_kcontig, b_kcontig, a_sm, a_sk, b_sk, b_sn, st)) return;
+    gemm_group_flush();          // (a product that is launched on its own keeps its place in the order of effects)
     GemmK k;
     k.A = g.A; k.B = g.B; k.C = g.C;
     k.Cin = g.Cin ? g.Cin : g.C;
@@ -2661,6 +2892,28 @@ void gemm(const Gemm& g, stream_t s) {
         }
     }
 
+    // 128 x 128 tiles, between one and two blocks per CU (256 <= tiles < 512; the two ring builds of a (20,80) iteration as
+    // one batched launch: 338): a round of 256 WHOLE tiles leaves every SIMD with a single wave, and the LDS-DMA kernel then
+    // runs at ~54 TF instead of 70+ (rocprofv3, round 4) — it needs its second block per CU to hide the barrier phases.  Model:
+    // c = ceil(tiles s / 256) blocks per CU, time ~ (c / s) / (c >= 2 ? 1 : 0.75) tile-times; cutting EVERY tile s ways
+    // (338 x 3 = 4 blocks per CU, two at a time) gives 1.33 where whole tiles + split tail give 1.33 + 0.44.
+    if (BM == 128 && BN == 128 && tiles >= 256 && tiles < 512 && ktiles >= 2 * dma_min_k() / BK) {
+        long best = 1;
+        double best_cost = 1e30;
+        const long smax = std::min<long>(std::min<long>(8, ktiles / (dma_min_k() / BK)), ws_tiles / tiles);
+        for (long sp = 1; sp <= smax; ++sp) {
+            const long c = (tiles * sp + 255) / 256;
+            const double cost = ((double)c / (double)sp) / (c >= 2 ? 1.0 : 0.75) + 0.02 * (sp - 1);
+            if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
+        }
+        const long cm = (main_tiles + 255) / 256;
+        const double cur = (double)cm / (cm >= 2 ? 1.0 : 0.75) +
+                           (tail_tiles ? ((double)((tail_tiles * tail_split + 255) / 256) / tail_split) / 0.75 : 0.0);
+        if (best > 1 && best_cost < 0.95 * cur) {
+            main_tiles = tiles; main_split = (int)best; tail_tiles = 0; tail_split = 1;
+        }
+    }
+
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (g_prof.on) {
         if (!g_prof.pool.empty()) {
@@ -2729,6 +2982,7 @@ void gemv_batch_end() {
 
 void permute(const Permute& p, stream_t s) {
     gemv_batch_flush();
+    gemm_group_flush();
     hipStream_t st = (hipStream_t)s;
     // canonicalise: drop extent-1 dims, sort by out-stride (descending), merge adjacent dims
     struct D { long n, si, so; };
@@ -3136,11 +3390,11 @@ void t2_layouts(const double* T, double* Td, double* Tx, double* Ttd, int no, in
 }
 
 void residual_assemble(const double* V, const double* L, const double* N, const double* D, const double* X, double* R,
-                       int no, int nv, stream_t s) {
+                       int no, int nv, stream_t s, double xd) {
     if (!fused_pair_kernels_ok(no)) throw std::runtime_error("residual_assemble: nocc too large for the LDS tile");
     const size_t lds = sizeof(double) * no * (no + 1);
     hipLaunchKernelGGL(residual_assemble_kernel, dim3((unsigned)((long)nv * (nv + 1) / 2)), dim3(256), lds, (hipStream_t)s,
-                       V, L, N, D, X, R, no, nv);
+                       V, L, N, D, X, R, no, nv, xd);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -3261,12 +3515,12 @@ void cc_update_pairs(double* tc, double* dtc, const double* rc, const double* eo
     HIP_CHECK(hipGetLastError());
 }
 void residual_assemble_pairs(const double* V, const double* L, const double* Np, const double* D, const double* X,
-                             double* Rc, int no, int nv, int64_t r0, int64_t r1, int a0, int nbp, stream_t s) {
+                             double* Rc, int no, int nv, int64_t r0, int64_t r1, int a0, int nbp, stream_t s, double xd) {
     if (r1 <= r0) return;
     if (!fused_pair_kernels_ok(no)) throw std::runtime_error("residual_assemble_pairs: nocc too large for the LDS tile");
     const size_t lds = sizeof(double) * no * (no + 1);
     hipLaunchKernelGGL(residual_assemble_pairs_kernel, dim3((unsigned)(r1 - r0)), dim3(256), lds, (hipStream_t)s, V, L, Np,
-                       D, X, Rc, no, nv, (long)r0, a0, nbp);
+                       D, X, Rc, no, nv, (long)r0, a0, nbp, xd);
     HIP_CHECK(hipGetLastError());
 }
 

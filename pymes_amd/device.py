@@ -617,6 +617,26 @@ class Context:
             first = False
         return out
 
+    def gemm_group(self):
+        """``with ctx.gemm_group() as g: ...``: the contract / dgemm calls inside are independent of each other (none reads or
+        accumulates into the output of another) and the small ones share launches (include/pymes_amd.h,
+        pymes_gemm_group_begin).  After the block ``g.launches`` / ``g.products`` say what was grouped."""
+        ctx = self
+
+        class _Group:
+            launches = products = 0
+
+            def __enter__(self):
+                ctx.lib.call("pymes_gemm_group_begin", ctx.handle)
+                return self
+
+            def __exit__(self, *exc):
+                l, p = (C.c_int64 * 1)(), (C.c_int64 * 1)()
+                ctx.lib.call("pymes_gemm_group_end", ctx.handle, l, p)
+                self.launches, self.products = l[0], p[0]
+                return False
+        return _Group()
+
     def gram(self, xs, ys):
         """G[i, j] = <xs[i], ys[j]> as a host array; every vector is read once per call (include/pymes_amd.h, pymes_gram)."""
         m, n = len(xs), len(ys)

@@ -431,19 +431,25 @@ class EOM_CCSD:
         self.timings = {"hoist_s": 0.0, "sigma_s": 0.0, "orth_s": 0.0, "subspace_s": 0.0, "sigma_vectors": 0, "passes": 0}
         tm, timed = self.timings, bool(getattr(self, "profile_phases", False))
 
+        self.pass_log = []         # with profile_phases: one record per pass (subspace dimension, new vectors, phase times)
+        cur = {}
+
         def lap(key, t0):          # per-phase wall time (with a device synchronisation) only when asked for
             if timed:
                 ctx.sync()
-                tm[key] += time.time() - t0
-            return time.time()
+                dt = time.perf_counter() - t0
+                tm[key] += dt
+                cur[key] = cur.get(key, 0.0) + dt
+            return time.perf_counter()
         try:
-            t0 = time.time()
+            t0 = time.perf_counter()
             sig = _Sigma(ctx, f, t2, dressed=device_form)
             t0 = lap("hoist_s", t0)
             print_logging_info("Initialising u tensors...", level=1)
             lay = self._layout(no, nv)
             n1, off2, nflat = lay
-            fresh = lambda: ctx.zeros((nflat,)) if off2 > n1 else ctx.empty((nflat,))     # (the pad must stay zero)
+            # (a combination of vectors with a zero pad has a zero pad; a sigma vector gets its parts written one by one)
+            fresh = lambda: ctx.empty((nflat,))
             new = []                                  # raw new trial vectors of this pass [u1 | pad | u2], flat
             for i in range(self.n_excit):
                 vec = ctx.zeros((nflat,))
@@ -461,7 +467,9 @@ class EOM_CCSD:
             diff_e_norm = np.inf
             for it in range(self.max_iter):
                 time_iter_init = time.time()
-                t0 = time.time()
+                t0 = time.perf_counter()
+                cur.clear()
+                n_new = len(new) if (reuse or not us) else len(us) + len(new)
                 if not reuse and us:                                                 # the reference's schedule: everything anew
                     new, us, ws, B = us + new, [], [], np.zeros((0, 0))
                 if new:
@@ -469,7 +477,7 @@ class EOM_CCSD:
                     t0 = lap("orth_s", t0)
                     u2s = [self._u2(ctx, u, lay) for u in new]
                     sym = [True] * len(new) if all_sym else [sig.exchange_symmetric(u2) for u2 in u2s]
-                    wn = [fresh() for _ in new]
+                    wn = [self._zero_pad(ctx, fresh(), lay) for _ in new]
                     sig.apply_many([self._u1(ctx, u, lay) for u in new], u2s, sym,                  # :95-101, new vectors only
                                    out1=[self._u1(ctx, w, lay) for w in wn], out2=[self._u2(ctx, w, lay) for w in wn])
                     tm["sigma_vectors"] += len(new)
@@ -492,14 +500,23 @@ class EOM_CCSD:
                 v = np.real(vec[:, pick])
                 self.history.append(np.array(e))      # (the Ritz values of the pass; the reference only logs them)
                 if dim >= self.max_dim:                                              # collapse :122-133
+                    # The next pass of the reference orthonormalises the Ritz vectors U v (:91) and builds their sigma vectors
+                    # again.  U is orthonormal, so the Gram matrix of U v is v^T v: its Cholesky factor R is known without
+                    # touching a vector, U v R^-1 and sigma(U v R^-1) = W v R^-1 are ONE combination each, and the subspace
+                    # matrix of the new basis is (v R^-1)^T B (v R^-1) — the pass after a collapse costs no sigma build.
+                    with _single_threaded_blas():
+                        Rc = np.linalg.cholesky(v.T @ v).T
+                        cmat = v @ np.linalg.inv(Rc)
                     cu = [fresh() for _ in range(self.n_excit)]
                     cw = [fresh() for _ in range(self.n_excit)]
-                    ctx.lincomb_multi(cu, us, v)
-                    ctx.lincomb_multi(cw, ws, v)                                     # sigma(U v) = W v
-                    # the next pass of the reference orthonormalises these Ritz vectors (:91) and builds their sigma
-                    # vectors again; here the same triangular map goes over both sets, and the pass costs no sigma build
-                    us, ws = self._orthonormalise_block(ctx, [], cu, lay, shadows=cw)
-                    B = ctx.gram(us, ws)
+                    ctx.lincomb_multi(cu, us, cmat)
+                    ctx.lincomb_multi(cw, ws, cmat)
+                    B = cmat.T @ B @ cmat
+                    G = ctx.gram(cu, cu)
+                    if np.abs(G - np.eye(self.n_excit)).max() > self.ORTH_TOL:       # (nearly parallel Ritz vectors)
+                        cu, cw = self._orthonormalise_block(ctx, [], cu, lay, shadows=cw)
+                        B = ctx.gram(cu, cw)
+                    us, ws = cu, cw
                     self.e_excit = e_old
                 else:                                                                # expand :135-147
                     coef = np.zeros((2 * dim, self.n_excit))
@@ -514,6 +531,8 @@ class EOM_CCSD:
                     self.e_excit = e
                 t0 = lap("subspace_s", t0)
                 tm["passes"] += 1
+                if timed:
+                    self.pass_log.append(dict(cur, dim=dim, new_vectors=n_new, collapse=bool(dim >= self.max_dim)))
                 if diff_e_norm < self.e_epsilon:
                     print_logging_info("Iterative solver converged.", level=1)
                     print_logging_info("Norm of energy difference = {:.12f}".format(diff_e_norm), level=2)
@@ -566,16 +585,20 @@ class EOM_CCSD:
     def _orthonormalise_block(self, ctx, us, ys, lay, shadows=None):
         """EOM_CCSD.QR (eom_ccsd.py:512-541) for a trial space [us | ys] whose leading vectors ``us`` are orthonormal already
         (Householder QR leaves those as they are, up to a sign the Rayleigh-Ritz step does not see): the block ``ys`` is
-        projected against ``us`` and orthonormalised in itself by two rounds of block Gram-Schmidt in its Pythagorean form
+        projected against ``us`` and orthonormalised in itself by rounds of block Gram-Schmidt in its Pythagorean form
         — ONE Gram product [us | ys]^T ys (every vector read once), the Cholesky factor of ys^T ys - P^T P on the host, ONE
         multi-output combination (ys - us P) R^-1 — so a round costs two passes over the subspace instead of a dot product
-        and an update per pair of vectors.  Returns the new orthonormal block; with ``shadows`` (vectors that any linear
+        and an update per pair of vectors; a round is repeated only when the check of the result asks for it.  Returns the new orthonormal block; with ``shadows`` (vectors that any linear
         map of ``ys`` must follow, e.g. their sigma vectors; only for an empty ``us``) returns (block, mapped shadows)."""
         assert shadows is None or not us
         k, d, nflat = len(ys), len(us), lay[2]
-        fresh = lambda: ctx.zeros((nflat,)) if lay[1] > lay[0] else ctx.empty((nflat,))
-        for _ in range(2):
+        eye = np.vstack([np.zeros((d, k)), np.eye(k)])
+        for rnd in range(4):
             G = ctx.gram(us + ys, ys)
+            # a-posteriori check = the Gram product the next round needs anyway: expansion vectors are residuals, orthogonal
+            # to the basis up to rounding (U^T (W v - e U v) = B v - e v), and one round brings them to the unit matrix
+            if rnd > 0 and np.abs(G - eye).max() <= self.ORTH_TOL:
+                break
             P, S = G[:d], G[d:] - G[:d].T @ G[:d]
             S = 0.5 * (S + S.T)
             scale = np.sqrt(np.abs(np.diag(S)))
@@ -588,17 +611,25 @@ class EOM_CCSD:
                         Rinv = np.linalg.inv(Lc.T * scale[None, :]) if ok else None  # R = L^T D, ys_new = ys' R^-1
                 except np.linalg.LinAlgError:
                     ok = False
-            if not ok:       # (numerically) dependent new vectors: vector by vector, null vectors replaced
+            if not ok or rnd == 3:       # (numerically) dependent new vectors: vector by vector, null vectors replaced
                 return self._orthonormalise_sequential(ctx, us, ys, lay, shadows)
             coef = np.vstack([-P @ Rinv, Rinv])
-            out = [fresh() for _ in range(k)]
+            out = [ctx.empty((nflat,)) for _ in range(k)]
             ctx.lincomb_multi(out, us + ys, coef)
             if shadows is not None:
-                sh = [fresh() for _ in range(k)]
+                sh = [ctx.empty((nflat,)) for _ in range(k)]
                 ctx.lincomb_multi(sh, shadows, Rinv)
                 shadows = sh
             ys = out
         return ys if shadows is None else (ys, shadows)
+
+    ORTH_TOL = 1e-13       # max |U^T U - 1| accepted for the trial space (numpy's Householder QR: ~1e-15)
+
+    @staticmethod
+    def _zero_pad(ctx, vec, lay):
+        if lay[1] > lay[0]:
+            DeviceArray(ctx, vec.ptr + 8 * lay[0], (lay[1] - lay[0],), owned=False, keepalive=vec).zero_()
+        return vec
 
     def _orthonormalise_sequential(self, ctx, us, ys, lay, shadows=None):
         """The fall-back of ``_orthonormalise_block``: modified Gram-Schmidt with re-orthogonalisation, one vector at a time

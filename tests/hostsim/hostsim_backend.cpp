@@ -231,6 +231,17 @@ void lincomb(double* out, int nx, const double* const* x, const double* c, int64
     }
 }
 
+// grouped launches: the simulator runs every product at once, so a group is only counted
+static long g_group_launches = 0, g_group_products = 0;
+static bool g_group_open = false;
+void gemm_group_begin(stream_t) { g_group_open = true; g_group_launches = g_group_products = 0; }
+void gemm_group_end() { g_group_open = false; }
+void gemm_group_sync() {}
+void gemm_group_stats(long* launches, long* products) {
+    if (launches) *launches = g_group_launches;
+    if (products) *products = g_group_products;
+}
+
 void gram(int m, int n, const double* const* x, const double* const* y, int64_t len, double* out, stream_t) {
     if (m > 64 || n > 64) throw std::runtime_error("gram: at most 64 x 64 vectors per call");
     for (int i = 0; i < m; ++i)
@@ -405,7 +416,7 @@ void t2_layouts(const double* T, double* Td, double* Tx, double* Ttd, int no, in
 }
 
 void residual_assemble(const double* V, const double* L, const double* N, const double* D, const double* X, double* R,
-                       int no, int nv, stream_t) {
+                       int no, int nv, stream_t, double xd) {
     const int64_t o2 = (int64_t)no * no, ov = (int64_t)no * nv, opp = (int64_t)no * (no + 1) / 2;
     auto pm = [&](const double* M, int a, int i, int b, int j) { return M[((int64_t)a * no + i) * ov + b * no + j]; };
     for (int a = 0; a < nv; ++a)
@@ -415,6 +426,7 @@ void residual_assemble(const double* V, const double* L, const double* N, const 
                     const int64_t e = ((int64_t)a * nv + b) * o2 + i * no + j;
                     double v = (V ? V[e] : 0.0) + N[e] + N[((int64_t)b * nv + a) * o2 + j * no + i] + pm(D, a, i, b, j) +
                                pm(D, b, j, a, i) + pm(X, a, j, b, i) + pm(X, b, i, a, j);
+                    if (xd != 0.0) v += xd * (pm(X, a, i, b, j) + pm(X, b, j, a, i));
                     if (L) {
                         const int ah = a > b ? a : b, al = a > b ? b : a, ih = i > j ? i : j, il = i > j ? j : i;
                         const double* row = L + P2(ah, al) * o2;
@@ -549,7 +561,7 @@ void cc_update_pairs(double* tc, double* dtc, const double* rc, const double* eo
     }
 }
 void residual_assemble_pairs(const double* V, const double* L, const double* Np, const double* D, const double* X,
-                             double* Rc, int no, int nv, int64_t r0, int64_t r1, int a0, int nbp, stream_t) {
+                             double* Rc, int no, int nv, int64_t r0, int64_t r1, int a0, int nbp, stream_t, double xd) {
     const int64_t o2 = (int64_t)no * no, ov = (int64_t)no * nv, opp = (int64_t)no * (no + 1) / 2;
     auto pm = [&](const double* M, int a, int i, int b, int j) { return M[((int64_t)a * no + i) * ov + b * no + j]; };
     for (int64_t r = r0; r < r1; ++r) {
@@ -560,7 +572,7 @@ void residual_assemble_pairs(const double* V, const double* L, const double* Np,
             for (int j = 0; j < no; ++j) {
                 auto S = [&](int x, int y) {
                     return Np[((int64_t)(a - a0) * nbp + b) * o2 + x * no + y] + pm(D, a, x, b, y) + pm(D, b, y, a, x) +
-                           pm(X, a, y, b, x) + pm(X, b, x, a, y);
+                           pm(X, a, y, b, x) + pm(X, b, x, a, y) + (xd != 0.0 ? xd * (pm(X, a, x, b, y) + pm(X, b, y, a, x)) : 0.0);
                 };
                 const int ih = i > j ? i : j, il = i > j ? j : i;
                 double ls = 0.0, la = 0.0;

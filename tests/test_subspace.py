@@ -76,3 +76,59 @@ def test_subspace_algebra_host_logic(hostsim_lib):
 def test_subspace_algebra_gpu(gpu_lib):
     check_subspace_algebra(gpu_lib, SMALL + [(12, 12, 300001, False), (9, 3, 1 << 20, False), (3, 9, (1 << 20) + 3, True),
                                              (33, 7, 70001, False)])
+
+
+def check_grouped_products(lib, shapes, expect_grouped):
+    """Independent small products inside ``ctx.gemm_group()`` (pymes_gemm_group_begin / _end) against numpy: every operand
+    layout, odd extents and pitches (8-byte loads), k-split of an under-filled group, alpha / beta, more than 16 products
+    (two launches), a product too big for a group in the middle (launched on its own, order kept)."""
+    ctx = Context(2, 3, lib=lib, workspace_bytes=1 << 28)
+    rng = np.random.default_rng(11)
+    try:
+        jobs = []
+        for (M, N, K, a_kc, b_kc, alpha, beta) in shapes:
+            A = rng.standard_normal((M, K) if a_kc else (K, M))
+            B = rng.standard_normal((N, K) if b_kc else (K, N))
+            Cm = rng.standard_normal((M, N))
+            ref = alpha * ((A if a_kc else A.T) @ (B.T if b_kc else B)) + beta * Cm
+            jobs.append((M, N, K, a_kc, b_kc, alpha, beta, ctx.array(A), ctx.array(B), ctx.array(Cm), ref))
+        with ctx.gemm_group() as grp:
+            for (M, N, K, a_kc, b_kc, alpha, beta, dA, dB, dC, ref) in jobs:
+                a_sm, a_sk = (K, 1) if a_kc else (1, M)
+                b_sk, b_sn = (1, K) if b_kc else (N, 1)
+                ctx.dgemm(M, N, K, alpha, dA, a_sm, a_sk, dB, b_sk, b_sn, beta, dC, N)
+        for (M, N, K, a_kc, b_kc, alpha, beta, dA, dB, dC, ref) in jobs:
+            err = np.abs(dC.get() - ref).max() / max(1.0, np.abs(ref).max())
+            assert err < 1e-13 * max(1, K) ** 0.5 + 1e-14, (M, N, K, a_kc, b_kc, alpha, beta, err)
+        if expect_grouped is not None:
+            assert grp.products == expect_grouped[0] and grp.launches == expect_grouped[1], (grp.products, grp.launches)
+        # an einsum-style contraction that needs a transposed temporary inside a group: it must not wait in the queue
+        A, B = rng.standard_normal((5, 6, 7)), rng.standard_normal((7, 5, 4))
+        dA, dB = ctx.array(A), ctx.array(B)
+        with ctx.gemm_group():
+            o1 = ctx.contract("abc,cad->bd", dA, dB)
+            o2 = ctx.contract("abc,cad->db", dA, dB)
+        assert np.abs(o1.get() - np.einsum("abc,cad->bd", A, B)).max() < 1e-12
+        assert np.abs(o2.get() - np.einsum("abc,cad->db", A, B)).max() < 1e-12
+    finally:
+        ctx.close()
+
+
+GROUP_SHAPES = ([(M, N, K, a, b, 1.0, 0.0) for (M, N, K) in ((64, 64, 64), (70, 33, 129), (1, 1, 1), (130, 50, 17), (3, 200, 40))
+                 for a in (True, False) for b in (True, False)] +
+                [(200, 210, 3000, True, False, -0.5, 1.0), (64, 64, 4096, False, True, 2.0, 0.25), (97, 65, 500, True, True, 1.0, 1.0)])
+
+
+def test_grouped_products_host_logic(hostsim_lib):
+    check_grouped_products(hostsim_lib, GROUP_SHAPES, None)
+
+
+@pytest.mark.gpu
+def test_grouped_products_gpu(gpu_lib):
+    check_grouped_products(gpu_lib, GROUP_SHAPES, (23, 2))
+    # a big product between small ones keeps its own (LDS-DMA) launch; the small ones on either side are grouped
+    check_grouped_products(gpu_lib, [(100, 90, 80, True, False, 1.0, 0.0), (2048, 2048, 2048, True, False, 1.0, 0.0),
+                                     (90, 100, 70, False, False, 1.0, 0.0)], (2, 2))
+    # an under-filled group of deep products: k-split inside the group, one reduction launch
+    check_grouped_products(gpu_lib, [(64, 64, 20000, True, True, 1.0, 0.5), (128, 64, 9999, False, False, 1.0, 0.0),
+                                     (60, 60, 7, True, False, 1.0, 0.0)], (3, 1))

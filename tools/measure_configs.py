@@ -224,13 +224,76 @@ def c5(args):
     return out
 
 
+def c5dav(args):
+    """Config 5 end to end: CCSD ground state -> T1 dressing -> EOM-CCSD Davidson (eom_ccsd.py:46-167) at (30,120), everything
+    resident in HBM (DeviceIntegrals -> device amplitudes -> DressedDeviceIntegrals).  Orbital energies with isolated frontier
+    levels (as oracle/cases.py::eom_davidson_case: on the dense spectrum of SURVEY 8(d) the reference's driver stalls)."""
+    from pymes_amd.integral.device import DeviceIntegrals
+    from pymes_amd.model import synthetic
+    from pymes_amd.solver.ccsd import CCSD
+    from pymes_amd.solver.eom_ccsd import EOM_CCSD
+    (no, nv), n_excit = args.davidson_size, 3
+    B, _ = synthetic.factors(no, nv, seed=0, scale=args.davidson_scale)
+    rng = np.random.default_rng(5)
+    eps = np.concatenate([np.sort(np.concatenate([[-1.5], -2.7 - 0.8 * rng.random(no - 1)])),
+                          np.sort(np.concatenate([[1.5, 1.9, 2.35], 3.2 + 1.0 * rng.random(nv - 3)]))])
+    f = np.diag(eps)
+    ints = DeviceIntegrals.from_factors(no, B)
+    ctx = ints.ctx
+    out = {"config": f"C5 EOM-CCSD Davidson, synthetic (nocc={no}, nvirt={nv}), n_excit = {n_excit}, device-resident chain"}
+    t0 = time.perf_counter()
+    cc = CCSD(no, delta_e=1e-10)
+    res = quiet(cc.solve, f, ints, device_amplitudes=True)
+    ctx.sync()
+    out["ccsd"] = {"wall_s": time.perf_counter() - t0, "iterations": cc.iterations, "energy": res["ccsd e"]}
+    t0 = time.perf_counter()
+    fd = cc.get_T1_dressed_fock(f, res["t1"], ints)
+    Vd = cc.get_T1_dressed_V(res["t1"], ints)
+    ctx.sync()
+    out["dressing_11_blocks_s"] = time.perf_counter() - t0
+
+    def run(reuse, phases, max_iter):
+        eom = EOM_CCSD(no, n_excit=n_excit)
+        eom.max_iter, eom.reuse_sigma, eom.profile_phases = max_iter, reuse, phases
+        ctx.sync()
+        t0 = time.perf_counter()
+        ee = quiet(eom.solve, fd, Vd, res["t2"])
+        ctx.sync()
+        return eom, ee, time.perf_counter() - t0
+    run(True, False, 3)                                               # warm-up: lazy statics, cached transposed blocks
+    eom, ee, wall = run(True, False, args.davidson_passes)
+    out["davidson"] = {"passes": eom.iterations, "wall_s": wall, "s_per_pass": wall / eom.iterations,
+                       "sigma_vectors": eom.timings["sigma_vectors"], "ritz_values_last_pass": [float(x) for x in eom.history[-1]],
+                       "converged": bool(eom.iterations < args.davidson_passes)}
+    eom, ee, wall_p = run(True, True, args.davidson_passes)            # the same with a synchronisation per phase
+    tm = eom.timings
+    out["davidson"]["phases"] = {k: tm[k] for k in ("hoist_s", "sigma_s", "orth_s", "subspace_s")}
+    out["davidson"]["per_pass"] = eom.pass_log
+    full = [p for p in eom.pass_log if p["dim"] == eom.max_dim and p["new_vectors"] == n_excit]
+    if full:
+        sig_ms = 1e3 * np.mean([p.get("sigma_s", 0.0) for p in full])
+        rest_ms = 1e3 * np.mean([p.get("orth_s", 0.0) + p.get("subspace_s", 0.0) for p in full])
+        out["davidson"]["pass_at_full_dimension"] = {"dim": eom.max_dim, "sigma_ms": sig_ms, "orth_plus_subspace_ms": rest_ms,
+                                                     "pass_over_sigma": (sig_ms + rest_ms) / sig_ms}
+    eom_ref, ee_ref, wall_ref = run(False, False, args.davidson_passes)       # the reference's schedule: all vectors anew
+    out["davidson_reference_schedule"] = {"passes": eom_ref.iterations, "wall_s": wall_ref,
+                                          "s_per_pass": wall_ref / eom_ref.iterations,
+                                          "sigma_vectors": eom_ref.timings["sigma_vectors"],
+                                          "max_ritz_difference": float(np.abs(np.array(eom_ref.history) - np.array(eom.history)).max())}
+    ctx.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--davidson-passes", type=int, default=40)
+    ap.add_argument("--davidson-size", type=lambda t: tuple(int(x) for x in t.split(",")), default=(30, 120))
+    ap.add_argument("--davidson-scale", type=float, default=0.12)
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--only", default="c2,c4,c5")
     args = ap.parse_args()
     for name in args.only.split(","):
-        print(json.dumps({"c2": c2, "c4": c4, "c5": c5}[name](args)), flush=True)
+        print(json.dumps({"c2": c2, "c4": c4, "c5": c5, "c5dav": c5dav}[name](args)), flush=True)
 
 
 if __name__ == "__main__":

@@ -3,7 +3,10 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # find last t2_layouts and print from the previous one
 idx = [i for i, r in enumerate(rows) if 't2_layouts' in r['Kernel_Name']]
-a, b = idx[-2], idx[-1]
+# argv[2]: which iteration, counted from the end in t2_layouts launches (default 1: the last complete one; bench.py's
+# default run ends with an eager pass under per-GEMM events, its timed, graph-replayed steps come before that)
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+a, b = idx[-1 - back], idx[-back]
 t0 = int(rows[a]['Start_Timestamp'])
 prev_end = t0
 for r in rows[a:b]:
