@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(kThreads, STREAM ? 4 : 2) dgemm_kernel(const G
 // its product's layout variant.  Descriptors travel as kernel arguments (3 KB): nothing to upload, graph capture keeps them.
 constexpr int kGroupMax = 16;
 struct GroupK {
-    int n, pad;
+    int n, tile;                // tile: 64 or 128 (read by the grouped reduction)
     int blk_end[kGroupMax];     // running block count
     int variant[kGroupMax];     // bit 2: A K-contiguous, bit 1: B K-contiguous, bit 0: 16-byte loads
     GemmK g[kGroupMax];
@@ -433,7 +433,7 @@ __device__ __forceinline__ unsigned lds_addr_of(const double* p) {
 }
 
 template <bool AKC, bool BKC>
-__global__ void __launch_bounds__(kThreads, 2) dgemm_glds_kernel(const GemmK g) {
+__device__ __forceinline__ void dgemm_glds_body(const GemmK& g, const long bid) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int BM = 128, BN = 128, WM = 64, WN = 64, FM = 4, FN = 4;
     constexpr int A_PITCH = AKC ? BK : (BM + 16);
@@ -448,7 +448,6 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_glds_kernel(const GemmK g) 
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, l4 = lane >> 4;
 
-    const long bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tiles = g.tiles_m * g.tiles_n;
     const long lt = bid / g.nsplit;
     const int ks = uni((int)(bid - lt * g.nsplit));
@@ -660,6 +659,21 @@ __global__ void __launch_bounds__(kThreads, 2) dgemm_glds_kernel(const GemmK g) 
     }
 }
 
+template <bool AKC, bool BKC>
+__global__ void __launch_bounds__(kThreads, 2) dgemm_glds_kernel(const GemmK g) {
+    dgemm_glds_body<AKC, BKC>(g, xcd_remap(blockIdx.x, gridDim.x));
+}
+// Grouped launch of mid-size products on the LDS-DMA kernel (A K-contiguous, B N-contiguous — the layout of the pair-packed
+// ladders and of every product with a symmetric pair matrix on the left): the four halves of the particle ladder and of
+// Q_kb at (20,80) are 26-52 tiles of 128 x 128 each, K ~ 3200 — alone each under-fills the chip and falls back to 64 x 64
+// register-staged tiles at 40 TF; together, k-split to ~4 blocks per CU, they run on the kernel that reaches 55-60 TF there.
+__global__ void __launch_bounds__(kThreads, 2) dgemm_glds_group_kernel(const GroupK grp) {
+    const long gb = xcd_remap(blockIdx.x, gridDim.x);
+    int it = 0;
+    while (it + 1 < grp.n && gb >= grp.blk_end[it]) ++it;
+    dgemm_glds_body<true, false>(grp.g[it], gb - (it ? grp.blk_end[it - 1] : 0));
+}
+
 // C tile = alpha * sum_ks ws[tile][ks] + beta * C tile, for the tiles [tile_begin, tile_begin + ntiles)
 __device__ __forceinline__ void splitk_reduce_body(const GemmK& g, const int BM, const int BN, const long lt, const int piece) {
     const int tiles = g.tiles_m * g.tiles_n;
@@ -714,7 +728,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_group_kernel(const GroupK g
     int it = 0;
     while (it + 1 < grp.n && (int)blockIdx.x >= grp.blk_end[it]) ++it;
     const int local = blockIdx.x - (it ? grp.blk_end[it - 1] : 0);
-    splitk_reduce_body(grp.g[it], 64, 64, local >> 4, local & 15);
+    if (grp.tile == 64) splitk_reduce_body(grp.g[it], 64, 64, local >> 4, local & 15);
+    else splitk_reduce_body(grp.g[it], 128, 128, local >> 6, local & 63);
 }
 
 __device__ __forceinline__ double wave_sum(double v);
@@ -2488,11 +2503,92 @@ struct GemmGroup {
     double* ws = nullptr;
     long ws_doubles = 0;
     long launches = 0, products = 0;      // statistics since gemm_group_begin (tests, tuning)
+    // mid-size products for the grouped LDS-DMA launch (128 x 128 tiles, A K-contiguous, B N-contiguous)
+    int nd = 0;
+    GemmK kd[kGroupMax];
+    long tiles_d[kGroupMax], ktiles_d[kGroupMax];
+    double flops_d[kGroupMax];
 };
 thread_local GemmGroup g_group;
 
+void gemm_group_flush_dma() {
+    GemmGroup& q = g_group;
+    if (q.nd == 0) return;
+    hipStream_t st = q.st;
+    long total = 0;
+    for (int i = 0; i < q.nd; ++i) total += q.tiles_d[i];
+    // ~4 blocks per CU (two resident at a time: the kernel needs its second block per CU, see dev::gemm), every cut at least
+    // dma_min_k deep
+    const long want = std::max<long>(1, (1024 + total - 1) / total);
+    GroupK grp, red;
+    grp.n = q.nd; grp.tile = 128; red.n = 0; red.tile = 128;
+    long blocks = 0, ws_used = 0, red_blocks = 0;
+    double flops = 0.0;
+    for (int i = 0; i < q.nd; ++i) {
+        GemmK& k = q.kd[i];
+        long sp = std::max<long>(1, std::min<long>(std::min<long>(want, 16), q.ktiles_d[i] / (dma_min_k() / BK)));
+        while (sp > 1 && ws_used + q.tiles_d[i] * sp * 16384 > q.ws_doubles) --sp;
+        const long kt_per = (q.ktiles_d[i] + sp - 1) / sp;
+        k.kchunk = (int)std::max<long>(kt_per * BK, BK);
+        k.nsplit = (int)std::max<long>(1, (q.ktiles_d[i] + kt_per - 1) / std::max<long>(kt_per, 1));
+        k.tile_begin = 0;
+        k.ws = nullptr;
+        if (k.nsplit > 1) {
+            k.ws = q.ws + ws_used;
+            ws_used += q.tiles_d[i] * k.nsplit * 16384;
+            red.g[red.n] = k;
+            red.variant[red.n] = 0;
+            red_blocks += q.tiles_d[i] * 64;
+            red.blk_end[red.n] = (int)red_blocks;
+            ++red.n;
+        }
+        blocks += q.tiles_d[i] * k.nsplit;
+        grp.blk_end[i] = (int)blocks;
+        grp.variant[i] = 5;
+        grp.g[i] = k;
+        flops += q.flops_d[i];
+    }
+    for (int i = q.nd; i < kGroupMax; ++i) { grp.blk_end[i] = (int)blocks; grp.variant[i] = 0; }
+    for (int i = red.n; i < kGroupMax; ++i) { red.blk_end[i] = (int)red_blocks; red.variant[i] = 0; }
+    const int nq = q.nd;
+    q.nd = 0;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (g_prof.on) {
+        if (!g_prof.pool.empty()) { ev = g_prof.pool.back(); g_prof.pool.pop_back(); }
+        else { HIP_CHECK(hipEventCreate(&ev.first)); HIP_CHECK(hipEventCreate(&ev.second)); }
+        HIP_CHECK(hipEventRecord(ev.first, st));
+    }
+    constexpr size_t lds = (size_t)2 * (128 * BK + BK * (128 + 16)) * sizeof(double);
+    static bool attr_set[kMaxDevices] = {false};
+    const int dv = current_device();
+    if (!attr_set[dv]) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dgemm_glds_group_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[dv] = true;
+    }
+    hipLaunchKernelGGL(dgemm_glds_group_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, st, grp);
+    HIP_CHECK(hipGetLastError());
+    if (red.n > 0) {
+        hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3((unsigned)red_blocks), dim3(256), 0, st, red);
+        HIP_CHECK(hipGetLastError());
+    }
+    ++q.launches;
+    if (g_prof.on) {
+        HIP_CHECK(hipEventRecord(ev.second, st));
+        g_prof.ev.push_back(ev);
+        g_prof.flops += flops;
+        g_prof.fl.push_back(flops);
+        g_prof.klass.push_back(1);
+        g_prof.nk.push_back(1);
+        char buf[128];
+        snprintf(buf, sizeof buf, "LDS-DMA group of %d products, %ld blocks, %d k-split, flops=%.4e", nq, blocks, red.n, flops);
+        g_prof.what.push_back(buf);
+    }
+}
+
 void gemm_group_flush() {
     GemmGroup& q = g_group;
+    gemm_group_flush_dma();
     if (q.n == 0) return;
     hipStream_t st = q.st;
     // k-splitting: 64 x 64 tiles fill the chip from ~1024 blocks (four co-resident per CU); with fewer tiles in the whole
@@ -2501,7 +2597,7 @@ void gemm_group_flush() {
     for (int i = 0; i < q.n; ++i) total += q.tiles[i];
     long want = total < 768 ? (1024 + total - 1) / total : 1;
     GroupK grp, red;
-    grp.n = q.n; grp.pad = 0; red.n = 0; red.pad = 0;
+    grp.n = q.n; grp.tile = 64; red.n = 0; red.tile = 64;
     long blocks = 0, ws_used = 0, red_blocks = 0;
     double flops = 0.0;
     for (int i = 0; i < q.n; ++i) {
@@ -2719,6 +2815,41 @@ bool gemm_group_take(const Gemm& g, bool a_kcontig, bool b_kcontig, int64_t a_sm
     // big products keep their own launches: enough 128 x 128 tiles for the chip, or deep enough for the LDS-DMA kernel's
     // k-split; and so do the long streaming products (one pass over a multi-GB block: the single-buffer kernel moves more)
     if (t128 >= 256 && ktiles * BK >= 256) return false;
+    // mid-size products in the LDS-DMA layout: queued for the grouped 128 x 128 launch
+    {
+        const long a_ld = a_kcontig ? a_sm : a_sk, b_ld = b_kcontig ? b_sn : b_sk;
+        const bool vec2 = even(a_ld) && even(b_ld) && even(g.K) && (even(g.N) || b_ld > g.N) && aligned16(g.A) && aligned16(g.B) &&
+                          even(g.a_b1) && even(g.a_b2) && even(g.b_b1) && even(g.b_b2);
+        const bool off32 = 128 * a_ld * 8 + 4096 < (1L << 32) && 16 * b_ld * 8 + 4096 < (1L << 32);
+        // (enough blocks of >= dma_min_k depth for half the chip, else the 64 x 64 group fills it better)
+        const bool fills = t128 * std::min<long>(16, g.K / dma_min_k()) >= 128;
+        if (a_kcontig && !b_kcontig && vec2 && off32 && g.M > 64 && g.N > 64 && g.K >= 2 * dma_min_k() && g.splitk_ws && fills &&
+            !getenv("PYMES_GEMM_NO_LDSDMA") && !getenv("PYMES_NO_DMA_GROUP") && t128 <= 0x3fffffffL / 64) {
+            if (q.nd == kGroupMax) gemm_group_flush_dma();
+            GemmK k;
+            k.A = g.A; k.B = g.B; k.C = g.C;
+            k.Cin = g.Cin ? g.Cin : g.C;
+            k.a_ld = a_ld; k.b_ld = b_ld; k.ldc = g.ldc;
+            k.M = (int)g.M; k.N = (int)g.N; k.K = (int)g.K;
+            k.Mc = k.M;
+            k.Nc = ((g.N & 1) && b_ld > g.N) ? k.N + 1 : k.N;
+            k.alpha = g.alpha; k.beta = g.beta;
+            k.nb2 = g.nb2;
+            k.a_b1 = g.a_b1; k.a_b2 = g.a_b2; k.b_b1 = g.b_b1; k.b_b2 = g.b_b2; k.c_b1 = g.c_b1; k.c_b2 = g.c_b2;
+            k.ws = nullptr;
+            k.tiles_m = (int)((g.M + 127) / 128);
+            k.tiles_n = (int)((g.N + 127) / 128);
+            const int i = q.nd++;
+            q.kd[i] = k;
+            q.tiles_d[i] = t128;
+            q.ktiles_d[i] = ktiles;
+            q.flops_d[i] = 2.0 * (double)g.M * (double)g.N * (double)g.K * (double)nbatch;
+            q.ws = g.splitk_ws;
+            q.ws_doubles = g.splitk_ws_doubles;
+            ++q.products;
+            return true;
+        }
+    }
     if (t128 < 256 && g.K / std::max<long>(1, (512 + t128 - 1) / t128) >= dma_min_k() && g.M > 64 && g.N > 64) return false;
     if (t64 * ktiles > 400000 || t64 > 0x3fffffffL / 16) return false;
     GemmK k;
@@ -2897,7 +3028,7 @@ void gemm(const Gemm& g, stream_t s) {
     // runs at ~54 TF instead of 70+ (rocprofv3, round 4) — it needs its second block per CU to hide the barrier phases.  Model:
     // c = ceil(tiles s / 256) blocks per CU, time ~ (c / s) / (c >= 2 ? 1 : 0.75) tile-times; cutting EVERY tile s ways
     // (338 x 3 = 4 blocks per CU, two at a time) gives 1.33 where whole tiles + split tail give 1.33 + 0.44.
-    if (BM == 128 && BN == 128 && tiles >= 256 && tiles < 512 && ktiles >= 2 * dma_min_k() / BK) {
+    if (BM == 128 && BN == 128 && tiles >= 256 && tiles < 512 && ktiles >= 2 * dma_min_k() / BK && !getenv("PYMES_NO_FULL_SPLIT")) {
         long best = 1;
         double best_cost = 1e30;
         const long smax = std::min<long>(std::min<long>(8, ktiles / (dma_min_k() / BK)), ws_tiles / tiles);

@@ -129,6 +129,12 @@ def test_grouped_products_gpu(gpu_lib):
     # a big product between small ones keeps its own (LDS-DMA) launch; the small ones on either side are grouped
     check_grouped_products(gpu_lib, [(100, 90, 80, True, False, 1.0, 0.0), (2048, 2048, 2048, True, False, 1.0, 0.0),
                                      (90, 100, 70, False, False, 1.0, 0.0)], (2, 2))
+    # mid-size products in the LDS-DMA layout (A K-contiguous, B N-contiguous, 16-byte loads): the grouped 128 x 128 launch,
+    # k-split with one grouped reduction — ragged M / N edges, an odd N under an even pitch is not eligible (64 x 64 group),
+    # a partial last k-tile, alpha / beta
+    check_grouped_products(gpu_lib, [(3240, 210, 3240, True, False, 1.0, 0.0), (1600, 190, 3160, True, False, -1.0, 1.0),
+                                     (130, 200, 1000, True, False, 2.0, 0.5), (100, 90, 80, True, False, 1.0, 0.0),
+                                     (500, 129, 2050, True, False, 1.0, 0.0), (129, 66, 777 * 2, True, False, 1.0, 1.0)], (6, 2))
     # an under-filled group of deep products: k-split inside the group, one reduction launch
     check_grouped_products(gpu_lib, [(64, 64, 20000, True, True, 1.0, 0.5), (128, 64, 9999, False, False, 1.0, 0.0),
                                      (60, 60, 7, True, False, 1.0, 0.0)], (3, 1))
