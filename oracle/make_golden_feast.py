@@ -2,7 +2,7 @@
 """Pin oracle/feast_oracle.py against the reference's FEAST-EOM-CCSD driver (pymes/solver/feast_eom_ccsd.py:72-181) and
 write tests/golden/feast.json.  BUILD CONTAINER ONLY:
 
-    PYTHONPATH=/root/reference:/root/repo python oracle/make_golden_feast.py
+    PYTHONPATH=/root/reference:/root/repo python oracle/make_golden_feast.py [rt]
 
 The reference's driver does not run against the scipy of this image (1.15.3) as it stands: (1) its ``LinearOperator`` is
 created without ``dtype`` (:341), scipy then probes the operator with an int8 zero vector and the in-place ``+=`` of
@@ -86,8 +86,40 @@ def ground_state(tag):
     return no, cc.get_T1_dressed_fock(f, res["t1"], Vb), cc.get_T1_dressed_V(res["t1"], Vb), res["t2"].copy()
 
 
+def rt_case():
+    """The real-time hooks of the reference's linear solvers (``is_rt`` / ``dt`` / ``phase``: get_residual :197-200 / :211-214,
+    _jacobi :276-278, _gcrotmk :321-334) called directly on LiH/STO-6G — their own driver (rt_eom_ccsd.py) does not run
+    upstream (:84-85 call the removed CTF API), the solver methods do, through the same two scipy wrappers as above.
+    -> tests/golden/feast_rt.npz: the seeded inputs' recipe and the reference's outputs."""
+    no, fd, Vd, t2 = ground_state("LiH.sto6g")
+    nv = fd.shape[0] - no
+    s = ref_feast.FEAST_EOM_CCSD(no, e_c=0.15, e_r=0.04)
+    rng = np.random.default_rng(11)
+    s.u_singles = [rng.standard_normal((nv, no))]
+    s.u_doubles = [rng.standard_normal((nv, nv, no, no)) * 0.05]
+    q1 = rng.standard_normal((nv, no)) + 1j * rng.standard_normal((nv, no))
+    q2 = 0.05 * (rng.standard_normal((nv, nv, no, no)) + 1j * rng.standard_normal((nv, nv, no, no)))
+    d1 = s.get_diag_singles(fd, Vd, t2)
+    d2 = s.get_diag_doubles(fd, Vd, t2)
+    ze, dt, phase = 1.0 + 0.0j, 0.2, np.exp(0.3j)
+    (g1, g2), _ = quiet(s.get_residual, 0, ze, q1, q2, fd, Vd, t2, phase=phase, is_rt=True, dt=dt)
+    (k1, k2), _ = quiet(s._gcrotmk, 0, ze, d1, d2, fd, Vd, t2, phase=phase, is_rt=True, dt=dt)
+    (j1, j2), _ = quiet(s._jacobi, 0, ze, d1, d2, fd, Vd, t2, phase=phase, is_rt=True, dt=dt)
+    # the solutions must satisfy (ze - 1j dt H) Q = phase u to the solvers' tolerances: checked with the reference's own sigma
+    r1, r2 = s.get_residual(0, ze, k1, k2, fd, Vd, t2, phase=phase, is_rt=True, dt=dt)
+    bn = np.sqrt(np.vdot(s.u_singles[0], s.u_singles[0]) + np.vdot(s.u_doubles[0], s.u_doubles[0])).real
+    rel = np.sqrt(np.vdot(r1, r1) + np.vdot(r2, r2)).real / bn
+    assert rel < 1.01e-4, rel
+    np.savez_compressed(os.path.join(GOLD, "feast_rt.npz"), seed=11, ze=ze, dt=dt, phase=phase, g1=g1, g2=g2, k1=k1, k2=k2,
+                        j1=j1, j2=j2, gcrot_relative_residual=rel)
+    print(f"feast real-time hooks: GCROT relative residual {rel:.2e}; written feast_rt.npz")
+
+
 def main():
     np.set_printoptions(precision=17, linewidth=10000)
+    if "rt" in sys.argv[1:]:
+        rt_case()
+        return
     out = {}
     for tag, seed, e_c, e_r, n_trial, max_iter in CASES:
         no, fd, Vd, t2 = ground_state(tag)

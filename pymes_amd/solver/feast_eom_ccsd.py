@@ -104,20 +104,26 @@ class FEAST_EOM_CCSD(EOM_CCSD):
         pass
 
     # ---- device pieces -------------------------------------------------------------------------------------------------
-    def _matvec(self, sig, ops, ze, x, n1, shapes):
-        """(ze - H̄) x for a complex device vector (feast_eom_ccsd.py:309-340): H̄ on the real and the imaginary part in
-        one sigma call."""
+    def _matvec(self, sig, ops, ze, x, n1, shapes, hs=1.0):
+        """(ze - hs H̄) x for a complex device vector (feast_eom_ccsd.py:309-340): H̄ on the real and the imaginary part in
+        one sigma call.  ``hs``: 1 for FEAST, 1j dt for the real-time form of the reference's solvers (:321-334)."""
         c = ops.c
         parts = lambda v: (EOM_CCSD._part(c, v, 0, shapes[0]), EOM_CCSD._part(c, v, n1, shapes[1]))
         (r1, r2), (i1, i2) = parts(x.re), parts(x.im)
         # (random trial vectors have no exchange symmetry, and neither have their Krylov iterates: the general sigma form)
         (sr1, sr2), (si1, si2) = sig.apply_many([r1, i1], [r2, i2], syms=[False, False])
         zr, zi = float(np.real(ze)), float(np.imag(ze))
+        hr, hi = float(np.real(hs)), float(np.imag(hs))
         y = _CVec(c.empty((ops.n,)), c.empty((ops.n,)))
         (yr1, yr2), (yi1, yi2) = parts(y.re), parts(y.im)
-        for out, a, b, s, sa, sb in ((yr1, r1, i1, sr1, zr, -zi), (yr2, r2, i2, sr2, zr, -zi),
-                                     (yi1, i1, r1, si1, zr, zi), (yi2, i2, r2, si2, zr, zi)):
-            c.lincomb(out.reshape(out.size), [a.reshape(a.size), b.reshape(b.size), s.reshape(s.size)], [sa, sb, -1.0])
+        flat = lambda t: t.reshape(t.size)
+        # y = ze x - hs (sr + i si):  re = zr xr - zi xi - hr sr + hi si,  im = zr xi + zi xr - hr si - hi sr
+        for out, a, b, s, t, sa, sb, ss, st in ((yr1, r1, i1, sr1, si1, zr, -zi, -hr, hi), (yr2, r2, i2, sr2, si2, zr, -zi, -hr, hi),
+                                                (yi1, i1, r1, si1, sr1, zr, zi, -hr, -hi), (yi2, i2, r2, si2, sr2, zr, zi, -hr, -hi)):
+            if st == 0.0:
+                c.lincomb(flat(out), [flat(a), flat(b), flat(s)], [sa, sb, ss])
+            else:
+                c.lincomb(flat(out), [flat(a), flat(b), flat(s), flat(t)], [sa, sb, ss, st])
         return y
 
     def _fgmres(self, ops, matvec, psolve, v0, m, atol, cs):
@@ -339,7 +345,10 @@ class FEAST_EOM_CCSD(EOM_CCSD):
         return self.eigvals
 
     # ---- the reference's host-array call forms of the linear solvers (:252-350) ----------------------------------------------
-    def _host_linear_solve(self, which, l, ze, diag_ai, diag_abij, f, dict_t_V, t_T_abij, phase=None):
+    def _host_linear_solve(self, which, l, ze, diag_ai, diag_abij, f, dict_t_V, t_T_abij, phase=None, hs=1.0):
+        """``hs``: the factor of H̄ in the operator ze - hs H̄ (1j dt in the real-time form).  The preconditioner follows the
+        reference: 1 / (ze - hs diag + 0.01) for _jacobi (:276-278, :288-289), the UNSCALED 1 / (ze - diag + 0.01) for
+        _gcrotmk in either form (:342 reads diag_ai / diag_abij, not the shifted copies of :301-302)."""
         no = self.no
         nv = diag_ai.shape[0]
         n1, n = diag_ai.size, diag_ai.size + diag_abij.size
@@ -352,9 +361,9 @@ class FEAST_EOM_CCSD(EOM_CCSD):
             if phase is not None:
                 b = b * phase
             bv = _CVec(ctx.array(np.ascontiguousarray(b.real)), ctx.array(np.ascontiguousarray(b.imag)))
-            mv = 1.0 / (ze - np.concatenate((diag_ai.ravel(), diag_abij.ravel())) + 0.01)
+            mv = 1.0 / (ze - (hs if which == "jacobi" else 1.0) * np.concatenate((diag_ai.ravel(), diag_abij.ravel())) + 0.01)
             minv = _CVec(ctx.array(np.ascontiguousarray(mv.real)), ctx.array(np.ascontiguousarray(mv.imag)))
-            matvec = lambda v: self._matvec(sig, ops, ze, v, n1, shapes)
+            matvec = lambda v: self._matvec(sig, ops, ze, v, n1, shapes, hs)
             self._matvecs = 0
             if which == "jacobi":
                 q = self._jacobi_device(ops, matvec, minv, bv)
@@ -370,26 +379,30 @@ class FEAST_EOM_CCSD(EOM_CCSD):
         finally:
             ctx.close()
 
+    @staticmethod
+    def _h_scale(is_rt, dt):
+        """The reference's real-time switch (:197-200, :321-334): H̄ enters as 1j dt H̄ when ``is_rt and dt is not None``."""
+        return 1j * dt if (is_rt and dt is not None) else 1.0
+
     def _gcrotmk(self, l, ze, diag_ai, diag_abij, t_fock_dressed_pq, dict_t_V_dressed, t_T_abij, phase=None, is_rt=False,
                  dt=None, **kwargs):
-        """feast_eom_ccsd.py:293-350 (is_rt / dt belong to the real-time driver, which does not run upstream)."""
-        if is_rt:
-            raise NotImplementedError("real-time propagation (rt_eom_ccsd.py) is not part of the HIP hot path")
-        return self._host_linear_solve("gcrotmk", l, ze, diag_ai, diag_abij, t_fock_dressed_pq, dict_t_V_dressed, t_T_abij, phase)
+        """feast_eom_ccsd.py:293-350: (ze - H̄) Q = phase u_l, or (ze - 1j dt H̄) Q = phase u_l in the real-time form
+        (``is_rt`` / ``dt``, :321-334 — the hook of rt_eom_ccsd.py, whose own driver does not run upstream)."""
+        return self._host_linear_solve("gcrotmk", l, ze, diag_ai, diag_abij, t_fock_dressed_pq, dict_t_V_dressed, t_T_abij, phase,
+                                       self._h_scale(is_rt, dt))
 
     def _jacobi(self, l, ze, diag_ai, diag_abij, t_fock_dressed_pq, dict_t_V_dressed, t_T_abij, phase=None, is_rt=False,
                 dt=None, **kwargs):
-        """feast_eom_ccsd.py:252-291."""
-        if is_rt:
-            raise NotImplementedError("real-time propagation (rt_eom_ccsd.py) is not part of the HIP hot path")
-        return self._host_linear_solve("jacobi", l, ze, diag_ai, diag_abij, t_fock_dressed_pq, dict_t_V_dressed, t_T_abij, phase)
+        """feast_eom_ccsd.py:252-291 (real-time form: the diagonal shift is 1j dt diag, :276-278)."""
+        return self._host_linear_solve("jacobi", l, ze, diag_ai, diag_abij, t_fock_dressed_pq, dict_t_V_dressed, t_T_abij, phase,
+                                       self._h_scale(is_rt, dt))
 
     def get_residual(self, l, ze, trial_singles, trial_doubles, t_fock_dressed_pq, dict_t_V_dressed, t_T_abij, phase=None,
                      is_rt=False, dt=None):
-        """feast_eom_ccsd.py:183-218: u_l phase - ze Q + H̄ Q for host arrays."""
-        if is_rt:
-            raise NotImplementedError("real-time propagation (rt_eom_ccsd.py) is not part of the HIP hot path")
+        """feast_eom_ccsd.py:183-218: u_l phase - ze Q + H̄ Q (real-time form: + 1j dt H̄ Q, :197-200, :211-214) for host
+        arrays."""
         ph = 1.0 if phase is None else phase
+        hs = self._h_scale(is_rt, dt)
         s1 = self.update_singles(t_fock_dressed_pq, dict_t_V_dressed, trial_singles, trial_doubles, t_T_abij)
         s2 = self.update_doubles(t_fock_dressed_pq, dict_t_V_dressed, trial_singles, trial_doubles, t_T_abij)
-        return (self.u_singles[l] * ph - ze * trial_singles + s1, self.u_doubles[l] * ph - ze * trial_doubles + s2)
+        return (self.u_singles[l] * ph - ze * trial_singles + hs * s1, self.u_doubles[l] * ph - ze * trial_doubles + hs * s2)

@@ -105,6 +105,44 @@ def test_linear_solvers_host_forms(hostsim_lib, monkeypatch):
     assert np.abs(j1 - p1).max() < 1e-11 and np.abs(j2 - p2).max() < 1e-11
 
 
+def check_real_time_hooks(lib, monkeypatch, tol):
+    """get_residual / _gcrotmk / _jacobi with ``is_rt=True, dt, phase`` (feast_eom_ccsd.py:197-214, :276-278, :321-334) against
+    the outputs of the reference's own methods on the same seeded inputs (oracle/make_golden_feast.py rt)."""
+    from pymes_amd.solver.feast_eom_ccsd import FEAST_EOM_CCSD
+    monkeypatch.setattr(_lib, "_default", lib)
+    g = np.load(os.path.join(GOLD, "feast_rt.npz"))
+    no, fd, Vd, t2 = ground_state("LiH.sto6g")
+    nv = fd.shape[0] - no
+    s = FEAST_EOM_CCSD(no, e_c=0.15, e_r=0.04)
+    rng = np.random.default_rng(int(g["seed"]))
+    s.u_singles = [rng.standard_normal((nv, no))]
+    s.u_doubles = [rng.standard_normal((nv, nv, no, no)) * 0.05]
+    q1 = rng.standard_normal((nv, no)) + 1j * rng.standard_normal((nv, no))
+    q2 = 0.05 * (rng.standard_normal((nv, nv, no, no)) + 1j * rng.standard_normal((nv, nv, no, no)))
+    d1, d2 = s.get_diag_singles(fd, Vd, t2), s.get_diag_doubles(fd, Vd, t2)
+    ze, dt, phase = complex(g["ze"]), float(g["dt"]), complex(g["phase"])
+    g1, g2 = s.get_residual(0, ze, q1, q2, fd, Vd, t2, phase=phase, is_rt=True, dt=dt)
+    assert np.abs(g1 - g["g1"]).max() < 1e-11 and np.abs(g2 - g["g2"]).max() < 1e-11
+    with contextlib.redirect_stdout(io.StringIO()):
+        k1, k2 = s._gcrotmk(0, ze, d1, d2, fd, Vd, t2, phase=phase, is_rt=True, dt=dt)
+        j1, j2 = s._jacobi(0, ze, d1, d2, fd, Vd, t2, phase=phase, is_rt=True, dt=dt)
+    assert np.abs(k1 - g["k1"]).max() < tol and np.abs(k2 - g["k2"]).max() < tol
+    assert np.abs(j1 - g["j1"]).max() < 1e-10 and np.abs(j2 - g["j2"]).max() < 1e-10
+    # without dt the switch is off (the reference tests `is_rt and dt is not None`)
+    h1, _ = s.get_residual(0, ze, q1, q2, fd, Vd, t2, phase=phase, is_rt=True, dt=None)
+    f1, _ = s.get_residual(0, ze, q1, q2, fd, Vd, t2, phase=phase)
+    assert np.array_equal(h1, f1)
+
+
+def test_real_time_hooks_host_logic(hostsim_lib, monkeypatch):
+    check_real_time_hooks(hostsim_lib, monkeypatch, 1e-7)
+
+
+@pytest.mark.gpu
+def test_real_time_hooks_gpu(gpu_lib, monkeypatch):
+    check_real_time_hooks(gpu_lib, monkeypatch, 1e-7)
+
+
 @pytest.mark.gpu
 def test_product_gpu(gpu_lib, monkeypatch):
     run_product(gpu_lib, monkeypatch, list(G))
