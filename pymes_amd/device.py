@@ -261,15 +261,18 @@ class Context:
                       float(beta), C.c_void_p(out.ptr), lc.encode(), i64_array(out.shape), None, batch.encode())
         return out
 
-    def permute(self, spec, A, out=None, alpha=1.0, beta=0.0):
-        """``permute("abij->aibj", T)``: out[lo] = alpha*A[li] + beta*out[lo]."""
+    def permute(self, spec, A, out=None, alpha=1.0, beta=0.0, in_view=None):
+        """``permute("abij->aibj", T)``: out[lo] = alpha*A[li] + beta*out[lo].  ``in_view`` = (dims, strides in doubles): read
+        A through a strided view instead of its own shape (``li`` then labels the view), e.g. the diagonal V[a,b,a,b] of a
+        [v,v,v,v] block as dims (v, v), strides (v^3 + v, v^2 + 1)."""
         li, lo = spec.replace(" ", "").split("->")
-        shape_o = tuple(A.shape[li.index(ch)] for ch in lo)
+        dims = tuple(A.shape) if in_view is None else tuple(int(d) for d in in_view[0])
+        shape_o = tuple(dims[li.index(ch)] for ch in lo)
         if out is None:
             out = self.empty(shape_o)
             beta = 0.0
-        self.lib.call("pymes_permute", self.handle, float(alpha), C.c_void_p(A.ptr), li.encode(), i64_array(A.shape),
-                      None, float(beta), C.c_void_p(out.ptr), lo.encode(), None)
+        self.lib.call("pymes_permute", self.handle, float(alpha), C.c_void_p(A.ptr), li.encode(), i64_array(dims),
+                      None if in_view is None else i64_array(in_view[1]), float(beta), C.c_void_p(out.ptr), lo.encode(), None)
         return out
 
     def dgemm(self, M, N, K, alpha, A, a_sm, a_sk, B, b_sk, b_sn, beta, Cmat, ldc):

@@ -687,30 +687,51 @@ class EOM_CCSD:
         finally:
             ctx.close()
 
-    def get_diag_singles(self, t_fock_pq, dict_t_V, t_T_abij):
+    def _diag_inputs(self, dict_t_V, t_T_abij):
+        """What the two diagonals read, as host arrays: V_ijab, T and four diagonal slices of other blocks.  For the
+        reference's dictionary these are einsum views; for the device-resident hand-over (``DressedDeviceIntegrals``) V_ijab
+        and T come down once per solve (2 o^2 v^2 numbers) and the slices — V_iabj[i,a,a,i], V_iajb[i,a,i,a], V_klij[i,j,i,j],
+        V_abcd[a,b,a,b] — are gathered on the device through strided views (o v / o^2 / v^2 numbers), so neither the
+        16 blocks nor V_abcd ever cross PCIe."""
+        if isinstance(dict_t_V, DressedDeviceIntegrals):
+            c, o, v = dict_t_V.ctx, dict_t_V.no, dict_t_V.nv
+            T = t_T_abij.get() if isinstance(t_T_abij, DeviceArray) else np.asarray(t_T_abij)
+            gather = lambda name, dims, strides: c.permute("xy->xy", dict_t_V[name], in_view=(dims, strides)).get()
+            return {"V": dict_t_V["ijab"].get(), "T": T,
+                    "iaai": gather("iabj", (v, o), (v * o + o, v * v * o + 1)),          # [a,i] <- V[i,a,a,i]
+                    "iaia": gather("iajb", (v, o), (o * v + 1, v * o * v + v)),          # [a,i] <- V[i,a,i,a]
+                    "ijij": gather("klij", (o, o), (o * o * o + o, o * o + 1)),          # [i,j] <- V[i,j,i,j]
+                    "abab": gather("abcd", (v, v), (v * v * v + v, v * v + 1))}          # [a,b] <- V[a,b,a,b]
+        return {"V": np.asarray(dict_t_V["ijab"]), "T": np.asarray(t_T_abij),
+                "iaai": np.einsum("iaai->ai", dict_t_V["iabj"]), "iaia": np.einsum("iaia->ai", dict_t_V["iajb"]),
+                "ijij": np.einsum("ijij->ij", dict_t_V["klij"]), "abab": np.einsum("abab->ab", dict_t_V["abcd"])}
+
+    def get_diag_singles(self, t_fock_pq, dict_t_V, t_T_abij, _inputs=None):
         """eom_ccsd.py:169-198, terms grouped: with V~ = 2V - V^(ab), T~ = 2T - T^(ab) the four (a,i)-resolved
-        V.T terms are one Hadamard sum.  O(o^2 v^2) work on the caller's host arrays (preconditioner data)."""
+        V.T terms are one Hadamard sum.  O(o^2 v^2) work on host arrays (preconditioner data, once per solve)."""
         no = self.no
-        V, T = np.asarray(dict_t_V["ijab"]), np.asarray(t_T_abij)
-        f = np.asarray(t_fock_pq)
+        g = _inputs or self._diag_inputs(dict_t_V, t_T_abij)
+        V, T = g["V"], g["T"]
+        f = t_fock_pq.get() if isinstance(t_fock_pq, DeviceArray) else np.asarray(t_fock_pq)
         Vt = 2.0 * V - V.transpose(0, 1, 3, 2)
         Tt = 2.0 * T - T.transpose(1, 0, 2, 3)
         d = f.diagonal()[no:][:, None] - f.diagonal()[:no][None, :]
-        d = d + 2.0 * np.einsum("iaai->ai", dict_t_V["iabj"]) - np.einsum("iaia->ai", dict_t_V["iajb"])
+        d = d + 2.0 * g["iaai"] - g["iaia"]
         d = d + np.einsum("jiba,baji->ai", Vt, Tt)
         d = d - np.einsum("jkba,abjk->a", Vt, T)[:, None]
         d = d - np.einsum("jicb,bcji->i", V, T)[None, :]
         return d
 
-    def get_diag_doubles(self, t_fock_pq, dict_t_V, t_T_abij):
+    def get_diag_doubles(self, t_fock_pq, dict_t_V, t_T_abij, _inputs=None):
         """eom_ccsd.py:200-266 (same grouping; the reference's placement of the `ibib` term on the (a,i) axes is kept)."""
         no = self.no
-        V, T = np.asarray(dict_t_V["ijab"]), np.asarray(t_T_abij)
-        f = np.asarray(t_fock_pq)
+        g = _inputs or self._diag_inputs(dict_t_V, t_T_abij)
+        V, T = g["V"], g["T"]
+        f = t_fock_pq.get() if isinstance(t_fock_pq, DeviceArray) else np.asarray(t_fock_pq)
         Vx = V.transpose(0, 1, 3, 2)                         # V[k,i,a,c] read as [k,i,c,a]
         Tx = T.transpose(1, 0, 2, 3)                         # T[a,c,k,i] read as [c,a,k,i]
         ai = f.diagonal()[no:][:, None] - f.diagonal()[:no][None, :]
-        ai = ai + np.einsum("iaai->ai", dict_t_V["iabj"]) - 2.0 * np.einsum("iaia->ai", dict_t_V["iajb"])
+        ai = ai + g["iaai"] - 2.0 * g["iaia"]
         ai = ai + np.einsum("kica,caki->ai", 2.0 * V - 2.0 * Vx, T) + np.einsum("kica,caki->ai", Vx - 2.0 * V, Tx)
         ai = ai + np.einsum("kicb,acki->ai", V, T)
         a_ = np.einsum("klca,cakl->a", V, Tx - 2.0 * T)
@@ -721,8 +742,8 @@ class EOM_CCSD:
         d = d + np.einsum("kiab,abkj->abij", V, T) + np.einsum("ijca,cbij->abij", V, T)
         d = d + np.einsum("kjac,caki->aij", V, T)[:, None, :, :] + np.einsum("kjac,ackj->aj", V, T)[:, None, None, :]
         d = d + d.transpose(1, 0, 3, 2)                                                           # P(ijab, jiba), :253
-        d = d + (np.einsum("ijij->ij", dict_t_V["klij"]) + np.einsum("ijcd,cdij->ij", V, T))[None, None, :, :]
-        d = d + (np.einsum("klab,abkl->ab", V, T) + np.einsum("abab->ab", dict_t_V["abcd"]))[:, :, None, None]
+        d = d + (g["ijij"] + np.einsum("ijcd,cdij->ij", V, T))[None, None, :, :]
+        d = d + (np.einsum("klab,abkl->ab", V, T) + g["abab"])[:, :, None, None]
         return d
 
     def update_singles(self, t_fock_pq, dict_t_V, t_u_ai, t_u_abij, t_T_abij):

@@ -27,6 +27,7 @@ import numpy as np
 from scipy.linalg import eig, lstsq, qr_insert
 
 from pymes_amd.device import DeviceArray
+from pymes_amd.integral.device import DressedDeviceIntegrals
 from pymes_amd.log import print_logging_info, print_title
 from pymes_amd.mixer.diis import _single_threaded_blas
 from pymes_amd.solver.eom_ccsd import EOM_CCSD, _Sigma
@@ -239,12 +240,23 @@ class FEAST_EOM_CCSD(EOM_CCSD):
         print_title("FEAST-EOM-CCSD Solver")
         time_init = time.time()
         no = self.no
+        device_form = isinstance(dict_t_V_dressed, DressedDeviceIntegrals)      # the hand-over of EOM_CCSD.solve: everything in HBM
+        if isinstance(t_fock_dressed_pq, DeviceArray):
+            t_fock_dressed_pq = t_fock_dressed_pq.get()
         f = np.asarray(t_fock_dressed_pq, dtype=np.float64)
         nv = f.shape[0] - no
-        diag_ai = self.get_diag_singles(f, dict_t_V_dressed, t_T_abij)
-        diag_abij = self.get_diag_doubles(f, dict_t_V_dressed, t_T_abij)
+        dg = self._diag_inputs(dict_t_V_dressed, t_T_abij)
+        diag_ai = self.get_diag_singles(f, dict_t_V_dressed, t_T_abij, _inputs=dg)
+        diag_abij = self.get_diag_doubles(f, dict_t_V_dressed, t_T_abij, _inputs=dg)
+        del dg
         print_logging_info("Initialising u tensors...", level=1)
+        # the reference APPENDS its two random vectors to whatever self.u_singles / u_doubles hold (:89-91): a second solve()
+        # on the same object continues from the trial space of the first
         host_us = []
+        for a0, b0 in zip(self.u_singles, self.u_doubles):
+            a0 = a0.get() if isinstance(a0, DeviceArray) else np.asarray(a0)
+            b0 = b0.get() if isinstance(b0, DeviceArray) else np.asarray(b0)
+            host_us.append(np.concatenate((np.real(a0).ravel(), np.real(b0).ravel())))
         for _ in range(self.n_excit):                                              # :89-91 (global numpy generator)
             a = 0.5 - np.random.rand(*diag_ai.shape)
             b = (0.5 - np.random.rand(*diag_abij.shape)) * 0.01
@@ -256,12 +268,13 @@ class FEAST_EOM_CCSD(EOM_CCSD):
         n = n1 + n2
         shapes = ((nv, no), (nv, nv, no, no))
         diag = np.concatenate((diag_ai.ravel(), diag_abij.ravel()))
-        ctx = self._context(dict_t_V_dressed, nv)
+        ctx = dict_t_V_dressed.ctx if device_form else self._context(dict_t_V_dressed, nv)
         self.history, self.linear_solver_info = [], []
         from pymes_amd.solver.ccd import quiet_collector
         collector = quiet_collector().__enter__()
         try:
-            sig = _Sigma(ctx, f, ctx.array(t_T_abij))
+            t2 = t_T_abij if isinstance(t_T_abij, DeviceArray) else ctx.array(t_T_abij)
+            sig = _Sigma(ctx, f, t2, dressed=device_form)
             ops = _Ops(ctx, n)
             zero = ctx.zeros((n,))
             us = [ctx.array(u) for u in host_us]
@@ -284,7 +297,12 @@ class FEAST_EOM_CCSD(EOM_CCSD):
                 for e in range(len(z)):                                            # :113-121
                     print_logging_info(f"e = {e}, z = {z[e]}, theta = {theta[e]}, w = {w[e]}", level=1)
                     matvec = lambda v, ze=z[e]: self._matvec(sig, ops, ze, v, n1, shapes)
-                    if self.linear_solver.upper() == "RICHARDSON":                 # (the reference's _jacobi, not called by its solve)
+                    # linear_solver: every setting the reference can run goes through self._gcrotmk (:118-119, its default
+                    # "Jacobi" included); its "BICGSTAB" branch (:116-117) calls a method whose body reads names that are not
+                    # in its scope (:377-382, a NameError upstream) and whose last lines are the same gcrotmk call — here it
+                    # runs GCROT(m,k) as well.  "RICHARDSON" (not a value of the reference) selects the damped sweeps of its
+                    # _jacobi method (:252-291), which no reference driver reaches
+                    if self.linear_solver.upper() == "RICHARDSON":
                         solver = lambda b, e=e: (self._jacobi_device(ops, matvec, minv[e], b), 0)
                     else:
                         def psolve(v, e=e):
@@ -302,7 +320,8 @@ class FEAST_EOM_CCSD(EOM_CCSD):
                         ctx.lincomb(Qs[l], [Qs[l], qe.re, qe.im], [1.0, -w[e] / 2 * ph.real, w[e] / 2 * ph.imag])
                 # projected problem (:124-149): H[i,j] = <Q_i, H̄ Q_j>, B[i,j] = <Q_i, Q_j>
                 part = lambda v: (self._part(ctx, v, 0, shapes[0]), self._part(ctx, v, n1, shapes[1]))
-                sigmas = sig.apply_many([part(q)[0] for q in Qs], [part(q)[1] for q in Qs], syms=[False] * m)
+                self.Q_singles, self.Q_doubles = [part(q)[0] for q in Qs], [part(q)[1] for q in Qs]      # (:104-105; device arrays)
+                sigmas = sig.apply_many(self.Q_singles, self.Q_doubles, syms=[False] * m)
                 Ws = []
                 for s1, s2 in sigmas:
                     wv = ctx.empty((n,))
@@ -335,11 +354,17 @@ class FEAST_EOM_CCSD(EOM_CCSD):
                 print_logging_info("Took {:.3f} seconds ".format(time.time() - time_iter_init), level=2)
                 e_norm_prev = e_norm
             self.iterations = it + 1
-            self.u_singles = [self._part(ctx, u, 0, shapes[0]).get() for u in us]
-            self.u_doubles = [self._part(ctx, u, n1, shapes[1]).get() for u in us]
+            self.u_singles = [self._part(ctx, u, 0, shapes[0]) for u in us]
+            self.u_doubles = [self._part(ctx, u, n1, shapes[1]) for u in us]
+            if not device_form:          # (device form: the trial space stays in the caller's context)
+                self.u_singles = [x.get() for x in self.u_singles]
+                self.u_doubles = [x.get() for x in self.u_doubles]
+                self.Q_singles = [x.get() for x in self.Q_singles]
+                self.Q_doubles = [x.get() for x in self.Q_doubles]
         finally:
             collector.__exit__()
-            ctx.close()
+            if not device_form:
+                ctx.close()
         print_logging_info(f"FEAST-EOM-CCSD finished in {time.time() - time_init:.2f} seconds.", level=0)
         self.e_excit = self.eigvals
         return self.eigvals

@@ -105,6 +105,46 @@ def test_linear_solvers_host_forms(hostsim_lib, monkeypatch):
     assert np.abs(j1 - p1).max() < 1e-11 and np.abs(j2 - p2).max() < 1e-11
 
 
+def check_device_form(lib, monkeypatch):
+    """FEAST_EOM_CCSD.solve on the device-resident hand-over of a CCSD solve (DeviceIntegrals -> device amplitudes ->
+    DressedDeviceIntegrals): same Ritz values as the host-dictionary form, diagonals from strided device gathers."""
+    from pymes_amd.integral.device import DeviceIntegrals
+    from pymes_amd.solver.ccsd import CCSD
+    from pymes_amd.solver.feast_eom_ccsd import FEAST_EOM_CCSD
+    monkeypatch.setattr(_lib, "_default", lib)
+    ref = G["LiH.sto6g|seed7"]
+    ne, n, ec, eps, h, V = oio.read_fcidump(os.path.join(GOLD, "fcidump", "FCIDUMP." + ref["tag"]))
+    no = ne // 2
+    f = oio.fock_matrix(no, h, V)
+    ints = DeviceIntegrals.from_V_pqrs(no, V)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            cc = CCSD(no, delta_e=1e-12)
+            res = cc.solve(f, ints, max_iter=200, device_amplitudes=True)
+            fd = cc.get_T1_dressed_fock(f, res["t1"], ints)
+            Vd = cc.get_T1_dressed_V(res["t1"], ints)
+            s = FEAST_EOM_CCSD(no, e_c=ref["e_c"], e_r=ref["e_r"], n_trial=ref["n_trial"], max_iter=ref["max_iter"])
+            host = Vd.to_host()
+            t2h = res["t2"].get()
+            assert np.abs(s.get_diag_singles(fd, Vd, res["t2"]) - s.get_diag_singles(fd, host, t2h)).max() < 1e-13
+            assert np.abs(s.get_diag_doubles(fd, Vd, res["t2"]) - s.get_diag_doubles(fd, host, t2h)).max() < 1e-13
+            np.random.seed(ref["seed"])
+            s.solve(fd, Vd, res["t2"])
+        compare(ref, s.history, 1e-7, 1e-8)
+        assert s.u_doubles[0].ctx is ints.ctx and s.Q_doubles[0].ctx is ints.ctx
+    finally:
+        ints.ctx.close()
+
+
+def test_device_form_host_logic(hostsim_lib, monkeypatch):
+    check_device_form(hostsim_lib, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_device_form_gpu(gpu_lib, monkeypatch):
+    check_device_form(gpu_lib, monkeypatch)
+
+
 def check_real_time_hooks(lib, monkeypatch, tol):
     """get_residual / _gcrotmk / _jacobi with ``is_rt=True, dt, phase`` (feast_eom_ccsd.py:197-214, :276-278, :321-334) against
     the outputs of the reference's own methods on the same seeded inputs (oracle/make_golden_feast.py rt)."""
