@@ -675,6 +675,8 @@ int pymes_diis_mix(pymes_ctx* ctx, double* state_host, int ntypes, int m, int wa
         dev::dots(ntypes * m, x, y, n, ov, e.stream);                      // one launch pair, one synchronisation
         const auto t2 = std::chrono::steady_clock::now();
         diis_small::step(state_host, ov, ntypes, m, was_full);             // (m+1) x (m+1) algebra on this host thread
+        if (state_host[91] == 2.0)      // singular or non-finite subspace matrix: the reference's numpy.linalg raises here too
+            throw pymes::Error("DIIS: the subspace matrix is singular or not finite (numpy.linalg.LinAlgError in pymes/mixer/diis.py:85-95)");
         const auto t3 = std::chrono::steady_clock::now();
         for (int t = 0; t < ntypes; ++t) dev::lincomb(out[t], m, amp_hist + t * m, state_host + 82, sizes[t], e.stream);
         if (trace) {

@@ -58,7 +58,8 @@ PYMES_HD inline void jacobi_eigh(int n, double* A, double* V, double* lam) {
 }
 
 // x = A^-1 b by Gaussian elimination with partial pivoting (A, b overwritten; pitch 9)
-PYMES_HD inline void solve_lu(int n, double* A, double* b, double* x) {
+// Returns false when a pivot vanishes or is not finite (numpy.linalg.inv raises LinAlgError there): x is then not written.
+PYMES_HD inline bool solve_lu(int n, double* A, double* b, double* x) {
     for (int k = 0; k < n; ++k) {
         int piv = k;
         double big = A[k * 9 + k] < 0 ? -A[k * 9 + k] : A[k * 9 + k];
@@ -70,6 +71,7 @@ PYMES_HD inline void solve_lu(int n, double* A, double* b, double* x) {
             for (int j = 0; j < n; ++j) { const double t = A[k * 9 + j]; A[k * 9 + j] = A[piv * 9 + j]; A[piv * 9 + j] = t; }
             const double t = b[k]; b[k] = b[piv]; b[piv] = t;
         }
+        if (!(big > 0.0) || !(big <= 1.7976931348623157e308)) return false;       // zero, NaN or infinite pivot
         for (int i = k + 1; i < n; ++i) {
             const double f = A[i * 9 + k] / A[k * 9 + k];
             for (int j = k; j < n; ++j) A[i * 9 + j] -= f * A[k * 9 + j];
@@ -81,6 +83,7 @@ PYMES_HD inline void solve_lu(int n, double* A, double* b, double* x) {
         for (int j = i + 1; j < n; ++j) s -= A[i * 9 + j] * x[j];
         x[i] = s / A[i * 9 + i];
     }
+    return true;
 }
 
 // One DIIS step on the state S.  overlaps[t * m + i] = <e_i, e_new> of amplitude type t (i < m; the new vector is i = m-1),
@@ -115,8 +118,9 @@ PYMES_HD inline void finish(double* S, const double* L, const double* V, const d
     double* A = work;
     double* c = work + 81;
     double* unit = work + 90;
-    bool dependent = false;
+    bool dependent = false, failed = false;
     for (int i = 0; i < n; ++i) dependent = dependent || (lam[i] < 1e-12 && lam[i] > -1e-12);
+    for (int i = 0; i < n; ++i) failed = failed || !(lam[i] == lam[i]);                       // NaN overlaps
     for (int i = 0; i < n; ++i) unit[i] = (i == n - 1) ? -1.0 : 0.0;
     if (dependent) {
         for (int i = 0; i < n; ++i) c[i] = 0.0;
@@ -128,10 +132,14 @@ PYMES_HD inline void finish(double* S, const double* L, const double* V, const d
         }
     } else {
         for (int i = 0; i < 81; ++i) A[i] = L[i];
-        solve_lu(n, A, unit, c);
+        for (int i = 0; i < n; ++i) c[i] = 0.0;
+        if (!solve_lu(n, A, unit, c)) failed = true;
     }
+    for (int i = 0; i < n; ++i) failed = failed || !(c[i] == c[i]) || c[i] > 1.7976931348623157e308 || c[i] < -1.7976931348623157e308;
     for (int i = 0; i < 9; ++i) S[82 + i] = i < n ? c[i] : 0.0;
-    S[91] = dependent ? 1.0 : 0.0;
+    // S[91]: 0 inverse branch, 1 pseudo-inverse branch, 2 no finite solution (a singular or non-finite L: the reference's
+    // numpy.linalg.inv / eigh raise LinAlgError, diis.py:85-95) — the callers refuse to extrapolate with such coefficients
+    S[91] = failed ? 2.0 : (dependent ? 1.0 : 0.0);
     S[92] += 1.0;
 }
 

@@ -126,7 +126,7 @@ Engine::~Engine() {
         for (auto& p : Vd_) dev::dfree(p);
         for (auto& kv : static_) dev::dfree(kv.second);
         dev::dfree(splitk_ws_);
-        if (side_.stream) {
+        if (side_.ready) {
             dev::stream_sync(side_.stream);
             dev::dfree(side_.splitk);
             side_.arena.release();
@@ -147,12 +147,26 @@ Engine::~Engine() {
 void Engine::side_begin() {
     if (side_.active) throw Error("side_begin: a side section is already open");
     side_join();                                    // one side section in flight at a time
-    if (!side_.stream) {
-        side_.stream = dev::stream_create();
-        side_.arena.init(arena.capacity() / 2);
-        side_.splitk = static_cast<double*>(dev::dmalloc(sizeof(double) * splitk_doubles_));
-        side_.fork = dev::event_create();
-        side_.done = dev::event_create();
+    if (!side_.ready) {
+        // (a flag of its own: the host simulator's stream_create returns null, and a throw half-way must not leave a
+        // section that records on events which do not exist)
+        dev::stream_t s = dev::stream_create();
+        double* sk = nullptr;
+        dev::event_t f = nullptr, d = nullptr;
+        try {
+            side_.arena.init(arena.capacity() / 2);
+            sk = static_cast<double*>(dev::dmalloc(sizeof(double) * splitk_doubles_));
+            f = dev::event_create();
+            d = dev::event_create();
+        } catch (...) {
+            dev::dfree(sk);
+            if (f) dev::event_destroy(f);
+            side_.arena.release();
+            dev::stream_destroy(s);
+            throw;
+        }
+        side_.stream = s; side_.splitk = sk; side_.fork = f; side_.done = d;
+        side_.ready = true;
     }
     dev::event_record(side_.fork, stream);
     dev::stream_wait_event(side_.stream, side_.fork);

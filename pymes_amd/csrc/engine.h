@@ -252,7 +252,7 @@ class Engine {
         Arena arena;
         double* splitk = nullptr;
         dev::event_t fork = nullptr, done = nullptr;
-        bool active = false, pending = false;
+        bool active = false, pending = false, ready = false;      // ready: every resource above exists
     } side_;
     dev::stream_t own_stream_ = nullptr;
     std::set<void*> user_allocs_;

@@ -77,7 +77,7 @@ class DIIS:
             n = int(buf[0])
             self.L = buf[1:82].reshape(9, 9)[:n, :n].copy()
             self.last_coefficients = buf[82:82 + n].copy()
-            self.last_dependent = bool(buf[91])
+            self.last_dependent = bool(buf[91] == 1.0)
         self._stale = False
 
     def _state_closing(self, ctx):
@@ -214,7 +214,7 @@ class DIIS:
             n1 = int(buf[0])
             self.L = buf[1:82].reshape(9, 9)[:n1, :n1].copy()
             self.last_coefficients = buf[82:82 + n1].copy()
-            self.last_dependent = bool(buf[91])
+            self.last_dependent = bool(buf[91] == 1.0)
             if mark is not None:
                 mark("DIIS overlaps + host solve (one call)")
             if defer_log:

@@ -222,8 +222,9 @@ class UEG:
         print_logging_info(__name__, level=0)
         if self.basis_fns is None:
             raise ValueError("Basis functions not initialized!")
-        if np.any(self._k_shift != 0.0):
-            raise NotImplementedError("twist-shifted bases are not on the HIP path")
+        # (a twist k_shift of init_single_basis moves the kinetic energies and the shell order of the basis; every integral
+        # below depends on DIFFERENCES of the integer plane-wave vectors only, so the kernels take the shifted basis as it is
+        # — checked against the reference: tests/golden/ueg_twist.npz)
         if is_only_non_hermi_2b or is_only_hermi_2b or is_exchange_1 or is_exchange_2 or is_exchange_3:
             raise NotImplementedError("test-only switches of the reference are not on the HIP path")
         mode = self._mode(correlator, dict(is_rpa_approx=is_rpa_approx, is_only_2b=is_only_2b, is_effect_2b=is_effect_2b))

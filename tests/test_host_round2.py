@@ -243,6 +243,40 @@ def test_mixer_against_reference_golden(sim):
     check_mixer_against_reference_golden(sim)
 
 
+def test_mixer_near_singular_and_non_finite_subspace(sim):
+    """the native step (csrc/diis_small.h: cyclic Jacobi + LU in place of numpy's eigh / inv) on a linearly
+    dependent history — the same error vector twice, |lambda_min| < 1e-12, the pseudo-inverse branch of diis.py:85-93 — gives
+    numpy's coefficients; a non-finite overlap (a diverged iteration) is refused like numpy.linalg refuses it, instead of
+    writing NaN amplitudes."""
+    from pymes_amd.device import PymesError
+    from pymes_amd.mixer.diis import DIIS
+    rng = np.random.default_rng(3)
+    errs = [rng.standard_normal((3, 2)), rng.standard_normal((3, 3, 2, 2))]
+    amps = [[rng.standard_normal((3, 2)), rng.standard_normal((3, 3, 2, 2))] for _ in range(3)]
+    coeffs = {}
+    for mode in ("numpy", "native"):
+        ctx = Context(2, 3, lib=sim)
+        mixer = DIIS(dim_space=6)
+        try:
+            for it in range(3):          # identical error vectors: L is singular from the second call on
+                quiet(mixer.mix, [ctx.array(e) for e in errs], [ctx.array(a) for a in amps[it]], native=(mode == "native"))
+            assert mode == "numpy" or mixer.last_dependent          # (the pseudo-inverse branch was taken)
+            coeffs[mode] = np.array(mixer.last_coefficients)
+        finally:
+            ctx.close()
+    assert np.allclose(coeffs["native"], coeffs["numpy"], rtol=1e-9, atol=1e-11), coeffs
+    ctx = Context(2, 3, lib=sim)
+    mixer = DIIS(dim_space=6)
+    try:
+        quiet(mixer.mix, [ctx.array(e) for e in errs], [ctx.array(a) for a in amps[0]], native=True)
+        bad = [errs[0].copy(), errs[1].copy()]
+        bad[1][0, 0, 0, 0] = np.nan
+        with pytest.raises(PymesError):
+            quiet(mixer.mix, [ctx.array(e) for e in bad], [ctx.array(a) for a in amps[1]], native=True)
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("solver", ["ccsd", "ccd"])
 def test_device_resident_diis_gives_the_same_solve(sim, monkeypatch, solver):
     """PYMES_DEVICE_DIIS=1: overlaps, subspace solve (pymes_diis_step) and extrapolation without a host round trip — same

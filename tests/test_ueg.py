@@ -237,3 +237,31 @@ def test_config4_size_tc_dcsd_host_logic(hostsim_lib, monkeypatch):
 
 def test_coulomb_57_plane_waves_level_shift_host_logic(hostsim_lib, monkeypatch):
     coulomb_57(hostsim_lib, monkeypatch)
+
+
+def check_twisted_basis(lib, monkeypatch):
+    """init_single_basis(cutoff, k_shift) (ueg.py:128-164): basis order, kinetic energies, the three integral modes and the
+    3-body mean-field pieces against the reference's own output (oracle/make_golden_ueg_twist.py)."""
+    from pymes_amd.model.ueg import UEG
+    monkeypatch.setattr(_lib, "_default", lib)
+    g = np.load(os.path.join(GOLD, "ueg_twist.npz"))
+    m = UEG(int(g["nel"]), int(g["nel"]) // 2, int(g["nel"]) // 2, float(g["rs"]))
+    m.init_single_basis(int(g["cutoff"]), k_shift=list(g["k_shift"]))
+    m.k_cutoff = float(g["k_cutoff"])
+    assert np.array_equal(np.array([b.k for b in m.basis_fns[::2]]), g["k"])
+    assert np.abs(np.array([b.kinetic for b in m.basis_fns[::2]]) - g["kinetic"]).max() == 0.0
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert np.abs(m.eval_2b_integrals() - g["coulomb"]).max() < 1e-14
+        assert np.abs(m.eval_2b_integrals(correlator=m.trunc, is_only_2b=True, sp=0) - g["only_2b"]).max() < 1e-14
+        assert np.abs(m.eval_2b_integrals(correlator=m.trunc, is_effect_2b=True, sp=0) - g["effect_2b"]).max() < 1e-14
+        assert np.abs(np.array(m.double_contractions_in_3_body()) - g["double_contractions"]).max() < 1e-14
+        assert abs(m.triple_contractions_in_3_body() - float(g["triple_contractions"])) < 1e-14
+
+
+def test_twisted_basis_host_logic(hostsim_lib, monkeypatch):
+    check_twisted_basis(hostsim_lib, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_twisted_basis_gpu(gpu_lib, monkeypatch):
+    check_twisted_basis(gpu_lib, monkeypatch)

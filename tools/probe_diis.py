@@ -1,5 +1,6 @@
+import os
 import sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pymes_amd.device import Context
 from pymes_amd.mixer.diis import DIIS

@@ -6,7 +6,9 @@ set -u
 out=gpurun_out/refresh
 mkdir -p $out
 export TMPDIR=/tmp
-step() { echo "== $1" >&2; shift; timeout -k 10 500 "$@"; rc=$?; echo "   rc=$rc" >&2; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "killed: stopping"; exit $rc; fi; }
+# (each step's own limit: profile_bench.sh runs one stats pass and five counter passes of up to 600 s each under its own
+# per-pass timeouts, so the outer limit only has to outlast their sum — an outer kill mid-pass would leave partial profiles)
+step() { local lim=500; case "$1" in *_prof) lim=3700;; esac; echo "== $1" >&2; shift; timeout -k 10 $lim "$@"; rc=$?; echo "   rc=$rc" >&2; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "killed: stopping"; exit $rc; fi; }
 step c3_prof bash tools/profile_bench.sh c3 > $out/prof_c3.txt 2>&1
 step c2_prof bash tools/profile_bench.sh c2 --nocc 20 --nvirt 80 > $out/prof_c2.txt 2>&1
 step c3_cpu python3 bench.py --steps 10 --warmup 3 > $out/bench_c3_with_cpu_baseline.json 2> $out/bench_c3_with_cpu_baseline.err
