@@ -278,6 +278,17 @@ int pymes_cc_update_to(pymes_ctx* ctx, double* t_out_dev, double* dt_dev, const 
  * the T1-free form of the residual: exp(-T1) H exp(T1) = H then, no dressing at all (pymes_amd/solver/ccsd.py). */
 int pymes_energy_norms(pymes_ctx* ctx, const double* f_dev, const double* t1_dev, const double* t2_dev,
                        const double* dt2_dev, double* out_host);
+/* pymes_energy_norms in two halves.  The reference reads the energy back every iteration (ccsd.py:189-197) and its next
+ * residual build waits for that; here _start enqueues the reduction and a copy into a pinned slot (`*slot`), the caller may
+ * enqueue more work — the residual kernels of the NEXT iteration, which need the new amplitudes but not the energy — and
+ * _wait blocks until that one copy has landed (an event, not the stream).  pymes_readback_start / _wait: the same for any
+ * n <= 128 doubles of device memory (the DIIS coefficients for the log lines of pymes/mixer/diis.py:104-111); 16 slots per
+ * device, reused in turn. */
+int pymes_energy_norms_start(pymes_ctx* ctx, const double* f_dev, const double* t1_dev, const double* t2_dev,
+                             const double* dt2_dev, int* slot);
+int pymes_energy_norms_wait(pymes_ctx* ctx, int slot, double* out_host);
+int pymes_readback_start(pymes_ctx* ctx, const double* dev_ptr, int n, int* slot);
+int pymes_readback_wait(pymes_ctx* ctx, int slot, double* out_host, int n);
 /* The same six sums over the virtual pairs of rank `rank` of `world` only, from the compact tiles [pairs][2][o*o] of the
  * pair-sharded tail (tc_dev, dtc_dev: pymes_pairs_pack layout): partial sums that the caller all-reduces — the energy of
  * ccsd.py:458-466 / ccd.py:256-262 then needs no replicated T2, so the all-gather of the new amplitudes can fly while the

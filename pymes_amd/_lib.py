@@ -99,6 +99,10 @@ SIGNATURES = {
     "pymes_cc_update_to": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
                                      C.c_int]),
     "pymes_energy_norms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_double_p]),
+    "pymes_energy_norms_start": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "pymes_energy_norms_wait": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
+    "pymes_readback_start": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "pymes_readback_wait": (C.c_int, [C.c_void_p, C.c_int, c_double_p, C.c_int]),
     "pymes_energy_norms_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                            c_double_p]),
     "pymes_ccsd_energy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_double_p]),

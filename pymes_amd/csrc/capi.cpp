@@ -513,6 +513,32 @@ int pymes_energy_norms(pymes_ctx* ctx, const double* f, const double* t1, const 
         E(ctx).energy_norms(f, t1, t2, dt2, out);
     });
 }
+int pymes_energy_norms_start(pymes_ctx* ctx, const double* f, const double* t1, const double* t2, const double* dt2, int* slot) {
+    return guarded([&] {
+        need(t2, "t2"); need(slot, "slot");
+        if ((f == nullptr) != (t1 == nullptr)) throw pymes::Error("f and t1 must be given together");
+        *slot = E(ctx).energy_norms_start(f, t1, t2, dt2);
+    });
+}
+int pymes_energy_norms_wait(pymes_ctx* ctx, int slot, double* out) {
+    return guarded([&] {
+        need(out, "out");
+        Eq(ctx).energy_norms_wait(slot, out);        // (nothing is enqueued: an open group stays as it is)
+    });
+}
+int pymes_readback_start(pymes_ctx* ctx, const double* dev_ptr, int n, int* slot) {
+    return guarded([&] {
+        need(dev_ptr, "dev_ptr"); need(slot, "slot");
+        *slot = dev::readback_start(dev_ptr, n, E(ctx).stream);
+    });
+}
+int pymes_readback_wait(pymes_ctx* ctx, int slot, double* out, int n) {
+    return guarded([&] {
+        need(out, "out");
+        Eq(ctx);
+        dev::readback_wait(slot, out, n);
+    });
+}
 int pymes_energy_norms_pairs(pymes_ctx* ctx, const double* f, const double* t1, const double* tc, const double* dtc,
                              int rank, int world, double* out) {
     return guarded([&] {

@@ -1512,6 +1512,20 @@ void Engine::cc_update_to(double* t_out, double* dt, const double* t_in, const d
     dev::cc_update_to(t_out, dt, t_in, r, eps_o, eps_v, shift, delta, no, nv, rank, stream);
 }
 
+int Engine::energy_norms_start(const double* f, const double* t1, const double* t2, const double* dt2) {
+    return dev::energy_norms_start(f, t1, t2, get_static("Edir"), get_static("Eex"), dt2, no, nv, stream);
+}
+void Engine::energy_norms_wait(int slot, double out[6]) {
+    double r[6];
+    dev::readback_wait(slot, r, 6);
+    out[0] = 2.0 * r[0];
+    out[1] = 2.0 * r[1];
+    out[2] = -1.0 * r[2];
+    out[3] = r[3];
+    out[4] = r[4];
+    out[5] = r[5];
+}
+
 void Engine::energy_norms(const double* f, const double* t1, const double* t2, const double* dt2, double out[6]) {
     double r[6];
     dev::energy_norms(f, t1, t2, get_static("Edir"), get_static("Eex"), dt2, no, nv, r, stream);

@@ -132,6 +132,13 @@ void dots(int npairs, const double* const* x, const double* const* y, const int6
 // t1 / f may be null (CCD: out[0] = out[5] = 0, tau = t2).  Result on host (synchronises the stream).
 void energy_norms(const double* f, const double* t1, const double* t2, const double* Edir, const double* Eex,
                   const double* dt2, int no, int nv, double out_host[6], stream_t s);
+// the same without draining the stream: the kernels and a copy into a pinned slot are enqueued and the slot id is returned;
+// readback_wait(slot, out, 6) later blocks until THAT copy has landed, while the stream runs what was enqueued behind it
+int energy_norms_start(const double* f, const double* t1, const double* t2, const double* Edir, const double* Eex,
+                       const double* dt2, int no, int nv, stream_t s);
+// generic form: n <= 128 doubles of device memory (a ring of 16 slots per device: wait for a slot before 16 later starts)
+int readback_start(const double* dev_ptr, int n, stream_t s);
+void readback_wait(int slot, double* out_host, int n);
 // the same sums over the virtual pairs P(a,b) in [r0,r1) only, amplitudes given as compact tiles tc / dtc
 // [pair][2][o*o] (tile (a,b), tile (b,a); pairs_pack); the T1 sums out[0], out[5] only when with_t1 (one rank of many)
 void energy_norms_pairs(const double* f, const double* t1, const double* tc, const double* Edir, const double* Eex,

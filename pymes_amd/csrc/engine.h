@@ -212,6 +212,10 @@ class Engine {
     // energies (ccsd.py:458-466 / ccd.py:256-262 when f, t1 are null) and the squared norms of t2 and dt2
     // (ccsd.py:196-197) in one pass: out = {one-body, direct, exchange, |t2|^2, |dt2|^2, |t1|^2}
     void energy_norms(const double* f, const double* t1, const double* t2, const double* dt2, double out[6]);
+    // the same in two halves: enqueue (returns a read-back slot) / wait for that read-back only — the stream goes on with what
+    // was enqueued in between (the next iteration's residual kernels)
+    int energy_norms_start(const double* f, const double* t1, const double* t2, const double* dt2);
+    void energy_norms_wait(int slot, double out[6]);
     void energy_norms_pairs(const double* f, const double* t1, const double* tc, const double* dtc, int rank, int world,
                             double out[6]);
     void invalidate_static();

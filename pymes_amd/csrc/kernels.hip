@@ -1061,15 +1061,108 @@ __global__ void __launch_bounds__(64) diis_step_kernel(double* __restrict__ stat
                                                         int m, int was_full) {
     // one wave; the matrices live in LDS.  Cyclic Jacobi with the lanes over the row / column index of a rotation (a
     // single thread with the matrices in scratch memory takes milliseconds: every element access is a memory round trip)
-    __shared__ double sL[81], sA[81], sV[81], slam[9], swork[99];
+    __shared__ double sL[81], sA[81], sV[81], slam[9], swork[99], sOld[81];
     const int lane = threadIdx.x, n = m + 1;
-    if (lane == 0) diis_small::build_L(state, overlaps, ntypes, m, was_full, sL);
+    // L of this step (diis_small::build_L, diis.py:56-80) with the lanes over its elements: one thread walking the state in
+    // global memory is a chain of ~250 dependent-latency accesses (0.3 ms)
+    for (int e = lane; e < 81; e += 64) sOld[e] = state[1 + e];
+    double snew = 0.0;
+    if (lane < m)
+        for (int t = 0; t < ntypes; ++t) snew += overlaps[t * m + lane];          // (the order of the reference's loop, :65-78)
     __syncthreads();
+    for (int e = lane; e < 81; e += 64) {
+        const int i = e / 9, j = e - 9 * i;
+        double v = 0.0;
+        if ((i == m && j < m) || (j == m && i < m)) v = -1.0;                     // :56-57
+        if (was_full) { if (i < n - 3 && j < n - 3) v = sOld[(i + 1) * 9 + (j + 1)]; }   // :59-60 (quirk included)
+        else if (i < n - 2 && j < n - 2) v = sOld[e];                             // :62
+        sL[e] = v;
+    }
+    __syncthreads();
+    if (lane < m) sL[lane * 9 + (m - 1)] += snew;
+    __syncthreads();
+    if (lane < n) sL[(m - 1) * 9 + lane] = sL[lane * 9 + (m - 1)];
+    __syncthreads();
+    if (lane == 0) state[0] = (double)n;
+    for (int e = lane; e < 81; e += 64) state[1 + e] = sL[e];
+    // Fast path (the usual case): L^-1 by Gauss-Jordan with partial pivoting, the lanes over the elements of [L | 1].  L is
+    // symmetric, so |lambda_min| = 1 / ||L^-1||_2 >= 1 / (n max |L^-1_ij|): if that bound clears the reference's threshold
+    // (|lambda| < 1e-12, diis.py:85) with a factor of two to spare, the pseudo-inverse branch is PROVABLY not taken and the
+    // coefficients are L^-1 (0, ..., 0, -1) (diis.py:95) — a few microseconds.  Anything else (a pivot that vanishes, a
+    // non-finite entry, a bound that does not clear) goes through the eigen-decomposition below, as before: a cyclic Jacobi
+    // on one wave is a chain of LDS and fp64-divide latencies, 0.4 ms per step.
+    {
+        __shared__ double sG[9 * 18];
+        for (int e = lane; e < 9 * 18; e += 64) {
+            const int i = e / 18, j = e - 18 * i;
+            sG[e] = (j < 9) ? sL[i * 9 + j] : ((j - 9 == i) ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        bool ok = true;
+        for (int k = 0; k < n && ok; ++k) {
+            double v = (lane >= k && lane < n) ? fabs(sG[lane * 18 + k]) : -1.0;
+            int idx = lane;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                const double v2 = __shfl_xor(v, o, 64);
+                const int i2 = __shfl_xor(idx, o, 64);
+                if (v2 > v || (v2 == v && i2 < idx)) { v = v2; idx = i2; }
+            }
+            v = __shfl(v, 0, 64);
+            idx = __shfl(idx, 0, 64);
+            if (!(v > 0.0) || !(v <= 1.7976931348623157e308)) { ok = false; break; }       // (wave-uniform)
+            if (idx != k && lane < 18) {
+                const double t = sG[k * 18 + lane];
+                sG[k * 18 + lane] = sG[idx * 18 + lane];
+                sG[idx * 18 + lane] = t;
+            }
+            __syncthreads();
+            const double piv = sG[k * 18 + k];
+            __syncthreads();
+            if (lane < 18) sG[k * 18 + lane] /= piv;
+            __syncthreads();
+            double fac[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int e = lane + 64 * q, i = e / 18;
+                fac[q] = (e < n * 18 && i != k) ? sG[i * 18 + k] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int e = lane + 64 * q, i = e / 18, j = e - 18 * i;
+                if (e < n * 18 && i != k) sG[e] -= fac[q] * sG[k * 18 + j];
+            }
+            __syncthreads();
+        }
+        if (ok) {
+            double big = 0.0;
+            for (int e = lane; e < n * 18; e += 64) {
+                const int i = e / 18, j = e - 18 * i;
+                if (j >= 9 && j - 9 < n) {
+                    const double a = fabs(sG[e]);
+                    big = (a > big || !(a == a)) ? a : big;             // (a NaN wins: the bound below then fails)
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double b2 = __shfl_xor(big, o, 64);
+                big = (b2 > big || !(b2 == b2)) ? b2 : big;
+            }
+            if (big == big && (double)n * big < 0.5e12) {                // |lambda_min| > 2e-12: the inverse branch, for sure
+                if (lane < 9) state[82 + lane] = lane < n ? -sG[lane * 18 + 9 + (n - 1)] : 0.0;
+                if (lane == 0) { state[91] = 0.0; state[92] += 1.0; }
+                return;
+            }
+        }
+        __syncthreads();
+    }
     for (int e = lane; e < 81; e += 64) {
         sA[e] = sL[e];
         sV[e] = (e / 9 == e % 9) ? 1.0 : 0.0;
     }
     __syncthreads();
+
     for (int sweep = 0; sweep < 40; ++sweep) {
         double off = 0.0, tot = 0.0;
         for (int e = lane; e < 81; e += 64) {
@@ -2358,6 +2451,35 @@ long g_live_allocs = 0;
 
 void wait_idle(hipStream_t st) { HIP_CHECK(hipStreamSynchronize(st)); }
 
+// Small read-backs that do not drain the stream: a copy into a pinned slot + an event; the host later waits for THAT event
+// while the stream goes on with whatever was enqueued behind it (the next iteration's residual kernels).
+constexpr int kReadSlots = 16, kReadDoubles = 128;
+double* g_read_host[kMaxDevices] = {nullptr};
+hipEvent_t g_read_ev[kMaxDevices][kReadSlots];
+int g_read_next[kMaxDevices] = {0};
+int readback_start_impl(const double* dev_ptr, int n, hipStream_t st) {
+    if (n < 1 || n > kReadDoubles) throw std::runtime_error("readback: 1..128 doubles");
+    int dv = 0;
+    HIP_CHECK(hipGetDevice(&dv));
+    if (dv < 0 || dv >= kMaxDevices) throw std::runtime_error("device ordinal out of range");
+    if (!g_read_host[dv]) {
+        HIP_CHECK(hipHostMalloc((void**)&g_read_host[dv], sizeof(double) * kReadSlots * kReadDoubles));
+        for (int i = 0; i < kReadSlots; ++i) HIP_CHECK(hipEventCreateWithFlags(&g_read_ev[dv][i], hipEventDisableTiming));
+    }
+    const int slot = g_read_next[dv];
+    g_read_next[dv] = (slot + 1) % kReadSlots;
+    HIP_CHECK(hipMemcpyAsync(g_read_host[dv] + slot * kReadDoubles, dev_ptr, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipEventRecord(g_read_ev[dv][slot], st));
+    return slot;
+}
+void readback_wait_impl(int slot, double* out, int n) {
+    int dv = 0;
+    HIP_CHECK(hipGetDevice(&dv));
+    if (slot < 0 || slot >= kReadSlots || !g_read_host[dv] || n < 1 || n > kReadDoubles) throw std::runtime_error("readback: bad slot");
+    HIP_CHECK(hipEventSynchronize(g_read_ev[dv][slot]));
+    for (int i = 0; i < n; ++i) out[i] = g_read_host[dv][slot * kReadDoubles + i];
+}
+
 int current_device() {
     int d = 0;
     HIP_CHECK(hipGetDevice(&d));
@@ -3240,8 +3362,9 @@ void lincomb_dev(double* out, int nx, const double* const* x, const double* coef
     HIP_CHECK(hipGetLastError());
 }
 
-void energy_norms(const double* f, const double* t1, const double* t2, const double* Edir, const double* Eex,
-                  const double* dt2, int no, int nv, double out_host[6], stream_t s) {
+int energy_norms_start(const double* f, const double* t1, const double* t2, const double* Edir, const double* Eex,
+                       const double* dt2, int no, int nv, stream_t s) {
+    gemm_group_flush();
     hipStream_t st = (hipStream_t)s;
     const int dv = current_device();
     ensure_dot_ws(dv);
@@ -3253,10 +3376,17 @@ void energy_norms(const double* f, const double* t1, const double* t2, const dou
     double* out_dev = g_dot_ws[dv] + 16 * kDotBlocks;
     hipLaunchKernelGGL(dots_stage2_kernel, dim3(6), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipMemcpyAsync(g_dot_host[dv], out_dev, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
-    wait_idle(st);
-    for (int i = 0; i < 6; ++i) out_host[i] = g_dot_host[dv][i];
+    return readback_start_impl(out_dev, 6, st);
 }
+void energy_norms(const double* f, const double* t1, const double* t2, const double* Edir, const double* Eex,
+                  const double* dt2, int no, int nv, double out_host[6], stream_t s) {
+    readback_wait_impl(energy_norms_start(f, t1, t2, Edir, Eex, dt2, no, nv, s), out_host, 6);
+}
+int readback_start(const double* dev_ptr, int n, stream_t s) {
+    gemm_group_flush();
+    return readback_start_impl(dev_ptr, n, (hipStream_t)s);
+}
+void readback_wait(int slot, double* out_host, int n) { readback_wait_impl(slot, out_host, n); }
 
 void exchange_asymmetry(const double* A, const double* B, const int64_t d[4], double out_host[2], stream_t s) {
     hipStream_t st = (hipStream_t)s;

@@ -552,6 +552,32 @@ class Context:
                       C.c_void_p(dt2.ptr if dt2 is not None else 0), out)
         return tuple(out[:])
 
+    def energy_norms_start(self, f, t1, t2, dt2=None):
+        """``energy_norms`` enqueued only: returns a read-back slot for ``energy_norms_wait`` (include/pymes_amd.h)."""
+        slot = C.c_int()
+        self.lib.call("pymes_energy_norms_start", self.handle, C.c_void_p(f.ptr if f is not None else 0),
+                      C.c_void_p(t1.ptr if t1 is not None else 0), C.c_void_p(t2.ptr),
+                      C.c_void_p(dt2.ptr if dt2 is not None else 0), C.byref(slot))
+        return slot.value
+
+    def energy_norms_wait(self, slot):
+        out = (C.c_double * 6)()
+        self.lib.call("pymes_energy_norms_wait", self.handle, int(slot), out)
+        return tuple(out[:])
+
+    def readback_start(self, arr, n=None, offset=0):
+        """Start the read-back of n (<= 128) doubles of ``arr`` from ``offset`` on; ``readback_wait(slot, n)`` returns them
+        as a numpy vector once that copy — not the whole stream — has completed."""
+        n = arr.size - offset if n is None else int(n)
+        slot = C.c_int()
+        self.lib.call("pymes_readback_start", self.handle, C.c_void_p(arr.ptr + 8 * int(offset)), n, C.byref(slot))
+        return slot.value
+
+    def readback_wait(self, slot, n):
+        buf = (C.c_double * int(n))()
+        self.lib.call("pymes_readback_wait", self.handle, int(slot), buf, int(n))
+        return np.frombuffer(buf, dtype=np.float64).copy()
+
     def energy_norms_pairs(self, f, t1, tc, dtc, rank, world):
         """This rank's partial sums of ``energy_norms`` from the compact tiles of its pairs (to be all-reduced)."""
         out = (C.c_double * 6)()

@@ -73,7 +73,10 @@ class DIIS:
         """Bring self.L / self.last_coefficients up to date with the device state (one small download)."""
         st = getattr(self, "_state", None)
         if st is not None and getattr(self, "_stale", False) and st.ctx.handle is not None:
-            buf = st.get()
+            slot, self._log_slot = getattr(self, "_log_slot", None), None
+            # (the copy that mix() started right behind the step kernel: waiting for it does not drain the stream, on which
+            # the caller may already have enqueued its next residual)
+            buf = st.ctx.readback_wait(slot, 96) if slot is not None else st.get()
             n = int(buf[0])
             self.L = buf[1:82].reshape(9, 9)[:n, :n].copy()
             self.last_coefficients = buf[82:82 + n].copy()
@@ -190,6 +193,7 @@ class DIIS:
             ctx.diis_step(state, [self.error_list[i][nt] for nt in range(ntypes) for i in range(m)],
                           [error[nt] for nt in range(ntypes) for _ in range(m)], ntypes, m, was_full)
             self._stale = True
+            self._log_slot = ctx.readback_start(state, 96)       # L and the coefficients for log_last(), read back on the side
             res = []
             for nt in range(ntypes):
                 dst = out[nt] if out is not None else ctx.pool_get(amplitude[nt].shape)

@@ -187,12 +187,23 @@ class CCSD(ccd.CCD):
             ctx.dress_V(t1, LOOP_KEYS)                                                # :165
             ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True, sym_ladder=False)   # :171
 
+    def _launch_residuals(self, st):
+        ccd.run_replayable(st["ctx"], st, lambda: self._residuals(st), key="t1=0" if st["t1_zero"] else "t1")
+
     def _iterate_single(self, st):
+        """One pass of the loop body on one rank, software-pipelined: the reference reads the energy back (ccsd.py:189-197)
+        before it builds the next residual; here the device does not wait for that read-back.  The energy reduction is only
+        ENQUEUED, the residual kernels of the NEXT pass — which need the extrapolated amplitudes, not the energy — are enqueued behind
+        it, and only then does the host wait for the six numbers of this pass (an event, not the stream).  A pass therefore
+        finds its residuals computed already; a solve pays for this with one residual build it does not use (the one
+        enqueued by its last pass), which ``st["speculate"] = False`` switches off when the caller expects the pass to be
+        the last.  At (20,80) that round trip (read-back, interpreter, graph launch) was 85 us of a 2.1-ms iteration."""
         ctx, t1, t2, r1, r2 = st["ctx"], st["t1"], st["t2"], st["r1"], st["r2"]
         shift = st["level_shift"]
         mark = pdist.trace.mark          # device and host time per phase when bench.py asks for it (no-ops otherwise)
         mark("begin")
-        ccd.run_replayable(ctx, st, lambda: self._residuals(st), key="t1=0" if st["t1_zero"] else "t1")
+        if not st.pop("residuals_in_flight", False):
+            self._launch_residuals(st)
         mark("residuals (dressing, R1, R2)")
         if self.is_diis:
             # the DIIS history keeps the updated amplitudes (:176-183); the extrapolation goes back into the fixed buffers
@@ -210,19 +221,35 @@ class CCSD(ccd.CCD):
         st["first"] = False
         mark("update")
         if self.is_diis:
-            # :181-183; the mixer's log lines are printed (log_last) after the energy kernel has been enqueued.
-            # PYMES_DEVICE_DIIS=1: overlaps, subspace solve and extrapolation without a host round trip (pymes_diis_step) —
-            # measured slower than the host solve for now: a one-wave Jacobi sweep is a chain of LDS / fp64-divide
-            # latencies, 0.40 ms per step against 0.15 ms (tools/probe_diis.py), so it is opt-in
+            # :181-183; the mixer's log lines are printed (log_last) after the energy has been read back.  Default: overlaps
+            # reduced on the device, ONE synchronisation, the 7 x 7 algebra in C on this thread, extrapolation enqueued
+            # (pymes_diis_mix).  PYMES_DEVICE_DIIS=1: the whole step on the device (pymes_diis_step) — no round trip, and
+            # a few microseconds while a bound on |lambda_min| proves the inverse branch of diis.py:95; but a converging
+            # solve soon has overlaps below 1e-12, the reference's pseudo-inverse branch (:85-93) is then the one that is
+            # MEANT, and its eigen-decomposition on one wave costs 0.4 ms against 0.13 ms for the round trip (measured at
+            # (20,80), round 4).  PYMES_NUMPY_DIIS=1: numpy.linalg as the reference.
             self.mixer.mix([dt1, dt2], [t1n, t2n], release=ctx.pool_put, out=[t1, t2], mark=mark, defer_log=True,
                            on_device=bool(os.environ.get("PYMES_DEVICE_DIIS")),
                            native=not os.environ.get("PYMES_NUMPY_DIIS"))
         mark("DIIS extrapolation")
-        e1, ed, ex, nt2, nr2, n1 = ctx.energy_norms(st["f"], t1, t2, dt2)             # :189-197, one pass
-        mark("energy + norms (host sync)")
+        slot = ctx.energy_norms_start(st["f"], t1, t2, dt2)                            # :189-197, one pass, enqueued
+        # the next pass's residuals, behind the energy reduction: same variant as this pass's (T1 = 0 only ever changes after
+        # the first pass from MP2, or never: a momentum-conserving system); recorded launch graphs only — the eager first
+        # passes of a variant do their per-solve set-up work and stay where they were
+        key = "t1=0" if st["t1_zero"] else "t1"
+        speculate = (st.get("speculate", True) and not ctx.profiling and st.get("graphs", {}).get(key) is not None
+                     and not os.environ.get("PYMES_NO_PIPELINE"))
+        if speculate:
+            self._launch_residuals(st)
+        e1, ed, ex, nt2, nr2, n1 = ctx.energy_norms_wait(slot)
+        mark("energy + norms (read-back)")
         if self.is_diis:
             self.mixer.log_last()
+        was_zero = st["t1_zero"]
         st["t1_zero"] = bool(n1 == 0.0) and not os.environ.get("PYMES_NO_T1_SHORTCUT")
+        # (a variant switch — T1 became non-zero — invalidates what was enqueued for the old variant: the next pass builds its
+        # residuals itself; the stale kernels only wrote the residual buffers, which are overwritten)
+        st["residuals_in_flight"] = bool(speculate and st["t1_zero"] == was_zero)
         return e1, ed, ex, np.sqrt(nt2), np.sqrt(nr2)
 
     # ---- one process per GPU ----------------------------------------------------------------------------------------
@@ -431,6 +458,9 @@ class CCSD(ccd.CCD):
             e_ccsd = e_1b = e_dir = e_ex = 0.
             while np.abs(dE) > delta_e and iteration <= max_iter:
                 iteration += 1
+                # (single rank: a pass enqueues the residuals of the next one before it reads its energy back — not when
+                # this pass is expected to be the last: |dE| shrinks geometrically, a factor of 30 per pass is generous)
+                st["speculate"] = bool(np.abs(dE) > 30.0 * delta_e and iteration < max_iter + 1)
                 e_1b, e_dir, e_ex, nt, nr = self.iterate(st)
                 e_ccsd = e_1b + e_dir + e_ex
                 dE = e_ccsd - e_last

@@ -222,6 +222,27 @@ void exchange_asymmetry(const double* A, const double* B, const int64_t d[4], do
                 }
 }
 
+// read-backs: the simulator is synchronous — the values are copied at start and handed over at wait
+static double g_read_slots[16][128];
+static int g_read_next = 0;
+int readback_start(const double* dev_ptr, int n, stream_t) {
+    if (n < 1 || n > 128) throw std::runtime_error("readback: 1..128 doubles");
+    const int slot = g_read_next;
+    g_read_next = (slot + 1) % 16;
+    for (int i = 0; i < n; ++i) g_read_slots[slot][i] = dev_ptr[i];
+    return slot;
+}
+void readback_wait(int slot, double* out, int n) {
+    if (slot < 0 || slot >= 16 || n < 1 || n > 128) throw std::runtime_error("readback: bad slot");
+    for (int i = 0; i < n; ++i) out[i] = g_read_slots[slot][i];
+}
+int energy_norms_start(const double* f, const double* t1, const double* t2, const double* Edir, const double* Eex,
+                       const double* dt2, int no, int nv, stream_t s) {
+    double out[6];
+    energy_norms(f, t1, t2, Edir, Eex, dt2, no, nv, out, s);
+    return readback_start(out, 6, s);
+}
+
 void lincomb(double* out, int nx, const double* const* x, const double* c, int64_t n, stream_t) {
     if (nx < 0 || nx > 8) throw std::runtime_error("lincomb: at most 8 terms");
     for (int64_t i = 0; i < n; ++i) {
