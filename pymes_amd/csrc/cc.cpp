@@ -311,6 +311,42 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
     // (numerically identical to the reference's sequence to rounding: tests/test_host_round2.py pins the identity and every
     // golden solve pins the result).  DCSD keeps ccd.py:202-204 only: 2 Wd - Ud^T + Vd Tt_d in the D-term, no build in the
     // C-term.  Column slab [c0,c1): both builds are restricted to the rank's columns n, the applications give rows n.
+    const bool row_form = nc != ov && !getenv("PYMES_SLAB_COLUMN_FORM");
+    const bool traces = !P && nc == ov;      // the small V.T sums as partial traces of the builds (below; one rank only)
+    if (row_form) {
+        // Several ranks: the slab in its TRANSPOSED form from the start.  MT[(b,j),(c,k)] / N1T hold the rank's columns as
+        // ROWS; Tt_d, Tx, Ld, Vx, Vd are symmetric pair matrices, so
+        //     MT += rows(Tt_d) Ld / 2,  N1T += rows(Tx) Vx / 2,  ET_x = N1T Tx,  ET_d = MT Tt_d / 2 + ET_x / 2
+        // are all products with a K-contiguous left and an N-contiguous right operand — the LDS-DMA variant that runs at 93 %
+        // of peak on one rank (the column form needed the <false,true> variant for its applications: 85.5 % at N = 8,
+        // profiles/r03/stub_rank0_of8.json) — and their outputs ARE the contiguous row blocks of ETd / ETx that are exchanged.
+        auto slabT = [&]() { return make_view(arena.alloc(nc * ov), {nc, ov}); };
+        TView MT = slabT(), N1T = slabT();
+        auto load_rows = [&](double alpha, const TView& blk, const char* spec, const TView& dst) {
+            TView src = slice(blk, 1, b0, b1);                       // only the b values the slab touches
+            if (b0 * o == c0 && b1 * o == c1) {
+                permute(alpha, src, spec, 0.0, make_view(dst.p, {b1 - b0, o, v, o}), "bjck");
+            } else {
+                ArenaScope s2(arena);
+                TView tmp = make_view(arena.alloc((b1 - b0) * o * ov), {(b1 - b0) * o, ov});
+                permute(alpha, src, spec, 0.0, make_view(tmp.p, {b1 - b0, o, v, o}), "bjck");
+                copy(slice(tmp, 0, c0 - b0 * o, c1 - b0 * o), dst);
+            }
+        };
+        load_rows(2.0, Viabj, "kbcj", MT);                                                   // MT = (2 Wd)^T
+        load_rows(-1.0, Viajb, "kbjc", N1T);                                                 // N1T = -(UdT)^T
+        axpby(1.0, N1T, 1.0, MT);
+        ring_xd_ = 0.0;
+        auto rowsOf = [&](const TView& m) { return slice(m, 0, c0, c1); };
+        if (quad) {
+            contract(0.5, rowsOf(Ttd), "ny", pairm(get_static("Ld")), "yx", 1.0, MT, "nx");
+            contract(0.5, rowsOf(Tx), "ny", pairm(get_static("Vx")), "yx", 1.0, N1T, "nx");
+        } else {
+            contract(1.0, rowsOf(Ttd), "ny", pairm(get_static("Vd")), "yx", 1.0, MT, "nx");
+        }
+        contract(1.0, N1T, "nk", Tx, "km", 0.0, ETx, "nm");                                  // (Ex_x)^T, rows = this rank's columns
+        contract(0.5, MT, "nk", Ttd, "km", 0.5, ETd, "nm", "", &ETx);                        // (Ex_d)^T
+    } else {
     TView M = slab(), N1 = slab();
     // One rank with all columns: the two builds are independent, and so are the two applications once the D-term no longer
     // carries the half of the C-term (Ex_d = D + Ex_x / 2: the assembly reads Ex_x in both placements, `ring_xd_`) — each pair
@@ -345,7 +381,6 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
     // The small V.T sums S_ac = sum_dkl Tt_adkl V_lkdc, S_ki = sum_cdl Tt_cdil V_lkdc (X_ac, X_ki, ccsd.py:434 / :436) are
     // partial traces of the builds: tr(Vd Tt_d) for DCSD, (3 tr(Vx Tx) + tr(Ld Tt_d)) / 4 for CCSD — read off the
     // accumulators before and after the products (all columns on this rank only)
-    const bool traces = !P && nc == ov;
     const double cz = (quad ? 0.5 : 1.0) * (paired ? 2.0 : 1.0), cu = 1.5;   // (tr after - tr before) x these = the contribution to S
     if (traces) {
         ensure_xs();
@@ -380,6 +415,7 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
     } else {
         contract(1.0, N1, "kn", Tx, "mk", 0.0, ETx, "nm");                                   // (Ex_x)^T, rows = this rank's columns
         contract(0.5, M, "kn", Ttd, "mk", 0.5, ETd, "nm", "", &ETx);                         // (Ex_d)^T
+    }
     }
     {
         // :232  Ex[a,b,i,j] -= X_ki T[a,b,k,j]  ->  ET[(b,j),(a,i)] -= sum_k Td[(b,j),(a,k)] X_ki   (Td symmetric)
@@ -1470,27 +1506,21 @@ void Engine::singles_residual_partial(const double* fd, const double* t1, const 
         permute(-1.0, slice(T, 2, j0, j1), "bcji", 1.0, P1, "jbci");
     }
     contract(1.0, Tq, "bjai", slice(Dov, 0, j0, j1), "jb", 1.0, R, "ai");                    // :432 (Tt' symmetric)
-    // :433 and :435 (and the sums of :434 / :436 when they were not left by the slab) are independent products over the
-    // same amplitudes: each into a buffer of its own, as ONE grouped launch, then one sum — at (20,80) four 15-50 us
-    // k-split launches with their reductions otherwise
-    TView R3 = make_view(arena.alloc(v * o), {v, o}), R5 = make_view(arena.alloc(v * o), {v, o});
-    TView S2 = make_view(arena.alloc(o * o), {o, o}), S4 = make_view(arena.alloc(v * v), {v, v});
-    {
-        GemmGroupScope grp(stream);
-        contract(1.0, slice(block(P_aibc), 1, j0, j1), "ajbc", P1, lp1, 0.0, R3, "ai");                                   // :433
-        contract(-1.0, Tq, "ajbk", slice(block(P_ijka), 0, j0, j1), "jkib", 0.0, R5, "ai");                              // :435
-        if (!have_oo)
-            contract(1.0, slice(make_view(get_static("Vjbck"), {o, v, v, o}), 0, j0, j1), "jbck", P1, lp1, 0.0, S2, "ki");
-        if (!have_vv) contract(1.0, Tq, "ajbk", slice(block(P_ijab), 0, j0, j1), "jkcb", 0.0, S4, "ac");
-        grp.close();
+    // (these products stream 80-MB..3.2-GB blocks into tiny outputs over K = o v^2: each runs alone on the single-buffer
+    // streaming kernel, which keeps 4-6 blocks per CU in flight — as ONE grouped launch on the double-buffered group kernel
+    // they were slower, 178 against 112 us at (20,80), rocprofv3 round 4)
+    contract(1.0, slice(block(P_aibc), 1, j0, j1), "ajbc", P1, lp1, 1.0, R, "ai");           // :433
+    if (!have_oo) {
+        TView S2 = make_view(arena.alloc(o * o), {o, o});
+        contract(1.0, slice(make_view(get_static("Vjbck"), {o, v, v, o}), 0, j0, j1), "jbck", P1, lp1, 0.0, S2, "ki");
+        contract(-1.0, t, "ak", S2, "ki", 1.0, R, "ai");                                     // :434
     }
-    {
-        const double* xs[3] = {R.p, R3.p, R5.p};
-        const double cs[3] = {1.0, 1.0, 1.0};
-        dev::lincomb(R.p, 3, xs, cs, v * o, stream);
+    contract(-1.0, Tq, "ajbk", slice(block(P_ijka), 0, j0, j1), "jkib", 1.0, R, "ai");       // :435
+    if (!have_vv) {
+        TView S4 = make_view(arena.alloc(v * v), {v, v});
+        contract(1.0, Tq, "ajbk", slice(block(P_ijab), 0, j0, j1), "jkcb", 0.0, S4, "ac");
+        contract(-1.0, S4, "ac", t, "ci", 1.0, R, "ai");                                     // :436
     }
-    if (!have_oo) contract(-1.0, t, "ak", S2, "ki", 1.0, R, "ai");                           // :434
-    if (!have_vv) contract(-1.0, S4, "ac", t, "ci", 1.0, R, "ai");                           // :436
 }
 
 // -----------------------------------------------------------------------------------

@@ -2085,7 +2085,8 @@ __global__ void fock_ft_kernel(const double* __restrict__ f, const double* __res
     const int j = e / no, i = e - j * no, n = no + nv;
     const FockW w = fock_w(W, no, nv);
     double acc = 2.0 * w.L1[e] - w.L2[e];
-    for (int b = 0; b < nv; ++b)
+#pragma unroll 8
+    for (int b = 0; b < nv; ++b)       // (independent loads, eight steps in flight: the loop is a latency chain otherwise)
         acc += (f[(long)j * n + no + b] + 2.0 * w.J1[(long)j * nv + b] - w.J2[(long)j * nv + b]) * t1[(long)b * no + i];
     ft[e] = acc;
 }
@@ -2105,13 +2106,16 @@ __global__ void fock_finish_kernel(const double* __restrict__ f, const double* _
     } else if (q >= no) {
         const int a = p - no, b = q - no;
         double acc = 2.0 * w.G1[(long)a * nv + b] - w.G2[(long)a * nv + b];
+#pragma unroll 8
         for (int i = 0; i < no; ++i)
             acc -= t1[(long)a * no + i] * (f[(long)i * n + no + b] + 2.0 * w.J1[(long)i * nv + b] - w.J2[(long)i * nv + b]);
         v += acc;
     } else {
         const int a = p - no, i = q;
         double acc = 2.0 * w.K1[(long)i * nv + a] - w.K2[(long)a * no + i];
+#pragma unroll 8
         for (int j = 0; j < no; ++j) acc -= t1[(long)a * no + j] * (f[(long)j * n + i] + ft[j * no + i]);
+#pragma unroll 8
         for (int b = 0; b < nv; ++b)
             acc += (f[(long)(no + a) * n + no + b] + 2.0 * w.G1[(long)a * nv + b] - w.G2[(long)a * nv + b]) * t1[(long)b * no + i];
         v += acc;
@@ -2974,6 +2978,11 @@ bool gemm_group_take(const Gemm& g, bool a_kcontig, bool b_kcontig, int64_t a_sm
     }
     if (t128 < 256 && g.K / std::max<long>(1, (512 + t128 - 1) / t128) >= dma_min_k() && g.M > 64 && g.N > 64) return false;
     if (t64 * ktiles > 400000 || t64 > 0x3fffffffL / 16) return false;
+    // streaming shapes (short K against a skinny side; tiny outputs over a huge K): one pass over a big operand, bound by the
+    // bytes in flight — the single-buffer kernel of dev::gemm with its 4-6 blocks per CU, not the double-buffered group kernel
+    // (from a few rounds of blocks on: tiny ones lose nothing in a group)
+    if (t64 * ktiles >= 4096 && ((g.K <= 256 && std::min(g.M, g.N) <= 256) || (g.M <= 256 && g.N <= 256 && g.K >= 65536)))
+        return false;
     GemmK k;
     k.A = g.A; k.B = g.B; k.C = g.C;
     k.Cin = g.Cin ? g.Cin : g.C;
