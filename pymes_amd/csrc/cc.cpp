@@ -354,7 +354,11 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
     // At (20,80) a product is 169 tiles of 128 x 128 on 256 CUs, 3-way k-split with its reduction; a pair is 338 tiles:
     // 256 whole ones and an 82-tile tail.  M is kept halved (M_h = Wd - UdT / 2 + Ld Tt_d / 4) so that both products of a
     // pair share alpha.
-    const bool paired = nc == ov && !getenv("PYMES_NO_RING_PAIRS");
+    // Only where a single product under-fills the chip (< 512 tiles of 128 x 128): a big product loses nothing on its own,
+    // and the assembly's two extra reads of Ex_x (1.6 GB at (50,200)) would be paid for nothing.  PYMES_RING_PAIRS=0/1 forces.
+    const int64_t ring_tiles = ((ov + 127) / 128) * ((ov + 127) / 128);
+    const char* pair_env = getenv("PYMES_RING_PAIRS");
+    const bool paired = nc == ov && !getenv("PYMES_NO_RING_PAIRS") && (pair_env ? atoi(pair_env) != 0 : ring_tiles < 512);
     ring_xd_ = paired ? 0.5 : 0.0;
     auto pair_gemm = [&](double alpha, const double* A0, const double* A1, const double* B0, const double* B1, double beta,
                          double* C0, double* C1) {

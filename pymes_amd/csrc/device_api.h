@@ -184,7 +184,7 @@ void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nc, int6
 // ladder_dress: T1 dressing of the bra of pair-packed rows (ccsd.py:414-419 as far as the packed ladder reads it).
 // V, W: [row1 - row0][ld], rows r = P(a,b) in [row0,row1); Pk: [nv*no][ld], rows (x,k) = x*no + k of V_kxcd packed like V:
 //   W[r] = V[r] - sum_k t1[a,k] Pk[(b,k)] + sgn sum_k t1[b,k] Pk[(a,k)]     (sgn = -1: "plus" half, +1: "minus" half, whose
-//   rows a == b stay zero).  ld must be a multiple of 16 doubles (all ld columns are processed); ladder_dress_ok: no <= 64 and
+//   rows a == b stay zero).  ld must be a multiple of 16 doubles (all ld columns are processed); ladder_dress_ok: no <= 80 and
 //   the rows of 16 a of the packed block within 2 GB (nv up to ~320).
 bool ladder_dress_ok(int no, int nv);
 // ws: ladder_dress_ws_doubles(no, nv) doubles of scratch (the t1 fragments in matrix-core operand order).

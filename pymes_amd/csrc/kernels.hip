@@ -3595,14 +3595,14 @@ void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nc, int6
 // below the 2-GB record count of the buffer resources
 bool ladder_dress_ok(int no, int nv) {
     const double ld = (double)((((long)nv * (nv + 1) / 2) + 15) & ~15L);
-    return no >= 1 && no <= 64 && nv >= 1 && 8.0 * ld * (15.0 * nv + 137.0) < 2147483648.0;
+    return no >= 1 && no <= 80 && nv >= 1 && 8.0 * ld * (15.0 * nv + 137.0) < 2147483648.0;
 }
 
 int64_t ladder_dress_ws_doubles(int no, int nv) { return (int64_t)((nv + 15) / 16) * ((no + 3) / 4) * 64; }
 
 void ladder_dress(const double* V, const double* Pk, const double* t1, double* W, int no, int nv, int64_t ld, int64_t row0,
                   int64_t row1, double sgn, double* ws, stream_t s) {
-    if (!ladder_dress_ok(no, nv)) throw std::runtime_error("ladder_dress: nocc outside 1..64 or tile extents beyond 2 GB");
+    if (!ladder_dress_ok(no, nv)) throw std::runtime_error("ladder_dress: nocc outside 1..80 or tile extents beyond 2 GB");
     if (ld <= 0 || (ld & 15)) throw std::runtime_error("ladder_dress: the row pitch must be a multiple of 16 doubles");
     if ((reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(Pk) | reinterpret_cast<uintptr_t>(W)) & 127)
         throw std::runtime_error("ladder_dress: operands must be 128-byte aligned");
@@ -3623,6 +3623,7 @@ void ladder_dress(const double* V, const double* Pk, const double* t1, double* W
     switch (nk) {
         PYMES_DRESS(1) PYMES_DRESS(2) PYMES_DRESS(3) PYMES_DRESS(4) PYMES_DRESS(5) PYMES_DRESS(6) PYMES_DRESS(7) PYMES_DRESS(8)
         PYMES_DRESS(9) PYMES_DRESS(10) PYMES_DRESS(11) PYMES_DRESS(12) PYMES_DRESS(13) PYMES_DRESS(14) PYMES_DRESS(15) PYMES_DRESS(16)
+        PYMES_DRESS(17) PYMES_DRESS(18) PYMES_DRESS(19) PYMES_DRESS(20)
     }
 #undef PYMES_DRESS
     HIP_CHECK(hipGetLastError());

@@ -355,7 +355,7 @@ void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nv, int6
         }
 }
 
-bool ladder_dress_ok(int no, int nv) { return no >= 1 && no <= 64 && nv >= 1; }
+bool ladder_dress_ok(int no, int nv) { return no >= 1 && no <= 80 && nv >= 1; }
 
 int64_t ladder_dress_ws_doubles(int no, int nv) { return (int64_t)((nv + 15) / 16) * ((no + 3) / 4) * 64; }
 

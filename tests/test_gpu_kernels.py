@@ -290,6 +290,7 @@ def check_ladder_dress(lib, no, nv, ld, r0, r1, minus, seed=0):
 DRESS_CASES = [  # no, nv, ld, r0, r1
     (3, 5, 16, 0, 15), (2, 16, 144, 0, 136), (5, 17, 160, 0, 153), (7, 33, 64, 0, 561), (13, 20, 208, 37, 161),
     (50, 21, 80, 0, 231), (64, 18, 32, 5, 171), (1, 4, 16, 0, 10), (20, 40, 832, 100, 777), (4, 35, 48, 629, 630),
+    (70, 19, 48, 3, 190), (80, 17, 32, 0, 153), (77, 33, 64, 200, 561),      # nocc > 64: chains of 18-20 MFMA steps (round 4)
 ]
 
 
