@@ -284,8 +284,47 @@ def c5dav(args):
     return out
 
 
+def c5feast(args):
+    """One FEAST-EOM-CCSD pass (feast_eom_ccsd.py:103-150) at (30,120) on the device-resident chain: 8 quadrature points x
+    the current trial vectors, each a GCROT(m,k) solve of (z - H) Q = u through the general (not exchange-symmetric)
+    multi-vector sigma build, then the projected eigenproblem.  Reported next to the Davidson numbers of c5dav."""
+    from pymes_amd.integral.device import DeviceIntegrals
+    from pymes_amd.model import synthetic
+    from pymes_amd.solver.ccsd import CCSD
+    from pymes_amd.solver.feast_eom_ccsd import FEAST_EOM_CCSD
+    no, nv = args.davidson_size
+    B, _ = synthetic.factors(no, nv, seed=0, scale=args.davidson_scale)
+    rng = np.random.default_rng(5)
+    eps = np.concatenate([np.sort(np.concatenate([[-1.5], -2.7 - 0.8 * rng.random(no - 1)])),
+                          np.sort(np.concatenate([[1.5, 1.9, 2.35], 3.2 + 1.0 * rng.random(nv - 3)]))])
+    f = np.diag(eps)
+    ints = DeviceIntegrals.from_factors(no, B)
+    ctx = ints.ctx
+    cc = CCSD(no, delta_e=1e-10)
+    res = quiet(cc.solve, f, ints, device_amplitudes=True)
+    fd = cc.get_T1_dressed_fock(f, res["t1"], ints)
+    Vd = cc.get_T1_dressed_V(res["t1"], ints)
+    out = {"config": f"C5 FEAST-EOM-CCSD passes, synthetic (nocc={no}, nvirt={nv}), window 3.0 +- 0.25, device-resident chain"}
+    s = FEAST_EOM_CCSD(no, e_c=3.0, e_r=0.25, n_trial=4, max_iter=args.feast_passes)
+    np.random.seed(1)
+    ctx.sync()
+    t0 = time.perf_counter()
+    ev = quiet(s.solve, fd, Vd, res["t2"])
+    ctx.sync()
+    wall = time.perf_counter() - t0
+    mv = [m for _, m in s.linear_solver_info]
+    out["feast"] = {"passes": s.iterations, "wall_s": wall, "s_per_pass": wall / s.iterations, "linear_solves": len(mv),
+                    "matvecs": int(np.sum(mv)), "matvecs_per_solve_mean": float(np.mean(mv)),
+                    "solves_not_converged": int(sum(1 for info, _ in s.linear_solver_info if info != 0)),
+                    "ritz_values_last_pass": [[float(np.real(x)), float(np.imag(x))] for x in s.history[-1]],
+                    "s_per_matvec": wall / max(1, int(np.sum(mv)))}
+    ctx.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--feast-passes", type=int, default=2)
     ap.add_argument("--davidson-passes", type=int, default=40)
     ap.add_argument("--davidson-size", type=lambda t: tuple(int(x) for x in t.split(",")), default=(30, 120))
     ap.add_argument("--davidson-scale", type=float, default=0.12)
@@ -293,7 +332,7 @@ def main():
     ap.add_argument("--only", default="c2,c4,c5")
     args = ap.parse_args()
     for name in args.only.split(","):
-        print(json.dumps({"c2": c2, "c4": c4, "c5": c5, "c5dav": c5dav}[name](args)), flush=True)
+        print(json.dumps({"c2": c2, "c4": c4, "c5": c5, "c5dav": c5dav, "c5feast": c5feast}[name](args)), flush=True)
 
 
 if __name__ == "__main__":

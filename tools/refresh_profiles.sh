@@ -1,6 +1,7 @@
 #!/bin/bash
 # Everything profiles/rNN/ holds for one round, re-measured with the library as built (run on the GPU box through gpurun):
-#     gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh'
+#     gpurun --timeout 1150 -- 'bash tools/refresh_profiles.sh 1'     (counter passes of C3 and C2)
+#     gpurun --timeout 1150 -- 'bash tools/refresh_profiles.sh 2'     (benches, stubs, other configs, traces)
 # Results land in gpurun_out/refresh/; copy what is to be judged into profiles/rNN/.
 set -u
 out=gpurun_out/refresh
@@ -9,8 +10,13 @@ export TMPDIR=/tmp
 # (each step's own limit: profile_bench.sh runs one stats pass and five counter passes of up to 600 s each under its own
 # per-pass timeouts, so the outer limit only has to outlast their sum — an outer kill mid-pass would leave partial profiles)
 step() { local lim=500; case "$1" in *_prof) lim=3700;; esac; echo "== $1" >&2; shift; timeout -k 10 $lim "$@"; rc=$?; echo "   rc=$rc" >&2; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "killed: stopping"; exit $rc; fi; }
+part=${1:-all}
+if [ "$part" = "1" ] || [ "$part" = "all" ]; then
 step c3_prof bash tools/profile_bench.sh c3 > $out/prof_c3.txt 2>&1
 step c2_prof bash tools/profile_bench.sh c2 --nocc 20 --nvirt 80 > $out/prof_c2.txt 2>&1
+rm -rf gpurun_out/prof_c3/stats gpurun_out/prof_c3/pmc_* gpurun_out/prof_c2/stats gpurun_out/prof_c2/pmc_*
+fi
+if [ "$part" = "1" ]; then echo done; exit 0; fi
 step c3_cpu python3 bench.py --steps 10 --warmup 3 > $out/bench_c3_with_cpu_baseline.json 2> $out/bench_c3_with_cpu_baseline.err
 step c3_dcsd python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --dcsd > $out/bench_c3_dcsd.json 2>/dev/null
 step c3_qform env PYMES_LADDER_DRESS=0 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_c3_q_form.json 2>/dev/null
@@ -20,13 +26,16 @@ for n in 2 4 8; do
 done
 step stub8r5 python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline --stub-collectives --as-rank 5 --of 8 > $out/stub_rank5_of8.json 2>/dev/null
 step stub8ot python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline --stub-collectives --as-rank 0 --of 8 --owner-tiles > $out/stub_rank0_of8_owner_tiles.json 2>/dev/null
-step configs python3 tools/measure_configs.py > $out/configs_c2_c4_c5.jsonl 2> $out/configs.err
+step configs python3 tools/measure_configs.py --only c2,c4,c5,c5dav > $out/configs_c2_c4_c5.jsonl 2> $out/configs.err
+step feast python3 tools/measure_configs.py --only c5feast --skip-cpu > $out/config_c5_feast.jsonl 2> $out/feast.err
 step dress python3 tools/probe_dress.py > $out/probe_dress_kernel.txt 2>&1
 step eom_stats rocprofv3 --kernel-trace --stats -d $out/eom -o run --output-format csv -- python3 tools/eom_prof_many.py > $out/eom_many.txt 2>&1
 f=$(find $out/eom -name 'run_kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $out/eom_sigma_30_120_k4_kernel_stats.csv
 rm -rf $out/eom
 step trace rocprofv3 --kernel-trace -d $out/tr -o run --output-format csv -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --events timed > $out/trace.log 2>&1
 python3 tools/trace_order.py $(find $out/tr -name "run_kernel_trace.csv") > $out/bench_c3_dispatch_order.txt; rm -rf $out/tr
+step trace2 rocprofv3 --kernel-trace -d $out/tr2 -o run --output-format csv -- python3 bench.py --nocc 20 --nvirt 80 --steps 6 --warmup 3 --no-cpu-baseline > $out/trace2.log 2>&1
+python3 tools/trace_order.py $(find $out/tr2 -name "run_kernel_trace.csv") 8 > $out/bench_c2_dispatch_order.txt; rm -rf $out/tr2
 step clock rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d $out/pmc -o run --output-format csv -- python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline --events timed > $out/clock.log 2>&1
 python3 tools/dispatch_clock.py $(find $out/pmc -name "run_counter_collection.csv") 400 > $out/bench_c3_dispatch_clock.txt; rm -rf $out/pmc
 rm -rf gpurun_out/prof_c3/stats gpurun_out/prof_c3/pmc_* gpurun_out/prof_c2/stats gpurun_out/prof_c2/pmc_*
