@@ -119,6 +119,11 @@ class _Sigma:
         self.many_ok = bool(self.v_sym and self.hole_sym and self.fused_ok and self.t_sym)
         if self.many_ok:
             self.fovT = c.array(np.ascontiguousarray(f[:no, no:].T))
+            # WA / W3 with the contracted index third: u1[d,i] then meets WA[a,b,d,:] as a batch of (a,b) products whose
+            # o x o results ARE the tiles D[z,a,b,:,:] — no transposed copy of a v^3 o array and no permuted accumulation of
+            # the result per build (0.7 ms each at (30,120), rocprofv3 round 4)
+            self.WAt = c.permute("adbj->abdj", self.WA)
+            self.W3t = c.permute("adbi->abdi", self.W3)
             # The four u1 terms with one free index on u1 (:336-338, :341 region: A_oovo, A4, A6 and V_iajk) as ONE product
             # u1[a,l] A346[l,b,i,j].  Everything added to D is symmetrised by P(ijab,jiba) afterwards (:377), so a term
             # X_abij may be replaced by its partner X_baji: sum_l u1[b,l] A4[l,i,a,j] -> sum_l u1[a,l] A4[l,j,b,i], etc.
@@ -316,7 +321,7 @@ class _Sigma:
         c.contract("zak,ki->zai", U1, self.Goo_s, out=S1, beta=1.0)
         c.contract("zaibj,bj->zai", Tt, self.fovT, out=S1, beta=1.0)
         c.contract("zajbk,jkib->zai", Tt, V["ijka"], out=S1, alpha=-1.0, beta=1.0)
-        c.contract("jabc,zbjci->zai", V["iabc"], Tt, out=S1, beta=1.0)
+        c.contract("jabc,zbjci->zai", V["iabc"], Tt, out=S1, beta=1.0, batch="z")        # (z as a batch: Tt is read in place)
         # ---- (ov)^3 products, transposed: only Dx + Dx^T and Dd + Dd^T enter (:377), X and Tt are symmetric matrices ----------
         DxT = c.contract("zajdl,bidl->zajbi", X, self.MDU)                        # (MDU . u2x)^T per vector
         DdT = c.permute("zajbi->zajbi", DxT, alpha=0.5)                           # same memory layout as "zaibj"
@@ -325,17 +330,17 @@ class _Sigma:
         Xoo = c.contract("klid,zdl->zki", V["ijka"], U1, alpha=-2.0)
         c.contract("kldi,zdl->zki", V["ijak"], U1, out=Xoo, beta=1.0)
         c.contract("kd,zdi->zki", self.fov, U1, out=Xoo, alpha=-1.0, beta=1.0, batch="z")
-        c.contract("kldc,zdlci->zki", V["ijab"], X, out=Xoo, alpha=-2.0, beta=1.0)      # u2[d,c,i,l] = X[(d,l),(c,i)]
-        c.contract("kldc,zdicl->zki", V["ijab"], X, out=Xoo, beta=1.0)                  # u2[d,c,l,i] = X[(d,i),(c,l)]
+        c.contract("kldc,zdlci->zki", V["ijab"], X, out=Xoo, alpha=-2.0, beta=1.0, batch="z")      # u2[d,c,i,l] = X[(d,l),(c,i)]
+        c.contract("kldc,zdicl->zki", V["ijab"], X, out=Xoo, beta=1.0, batch="z")                  # u2[d,c,l,i] = X[(d,i),(c,l)]
         c.contract("zki,akbj->zaibj", Xoo, self.Td, out=DdT, beta=1.0, batch="za")
         Xvv = c.contract("ladc,zdl->zac", V["iabc"], U1, alpha=2.0)
         c.contract("lacd,zdl->zac", V["iabc"], U1, out=Xvv, alpha=-1.0, beta=1.0)
         c.contract("zal,lc->zac", U1, self.fov, out=Xvv, alpha=-1.0, beta=1.0)
-        c.contract("lkcd,zakdl->zac", V["ijab"], X, out=Xvv, alpha=-2.0, beta=1.0)      # u2[a,d,l,k] = X[(a,k),(d,l)]
-        c.contract("lkcd,zdkal->zac", V["ijab"], X, out=Xvv, beta=1.0)                  # u2[d,a,l,k] = X[(d,k),(a,l)]
+        c.contract("lkcd,zakdl->zac", V["ijab"], X, out=Xvv, alpha=-2.0, beta=1.0, batch="z")      # u2[a,d,l,k] = X[(a,k),(d,l)]
+        c.contract("lkcd,zdkal->zac", V["ijab"], X, out=Xvv, beta=1.0, batch="z")                  # u2[d,a,l,k] = X[(d,k),(a,l)]
         D = c.contract("zac,cbij->zabij", Xvv, T)
-        c.contract("adbj,zdi->zabij", self.WA, U1, out=D, beta=1.0)
-        c.contract("adbi,zdj->zabij", self.W3, U1, out=D, alpha=-1.0, beta=1.0)
+        c.contract("abdj,zdi->zabij", self.WAt, U1, out=D, beta=1.0, batch="zab")
+        c.contract("abdi,zdj->zabij", self.W3t, U1, out=D, alpha=-1.0, beta=1.0, batch="zab")
         c.contract("zal,lbij->zabij", U1, self.A346, out=D, beta=1.0)
         c.contract("abic,zcj->zabij", V["abic"], U1, out=D, beta=1.0, batch="z")
         npp = self.L.shape[0]

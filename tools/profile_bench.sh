@@ -35,6 +35,11 @@ if [ "${PMC:-1}" = "1" ]; then
     { echo "# kernels.hip sha256=$hash"; python3 tools/pmc_summary.py "$(cc FETCH_SIZE)" "$(cc WRITE_SIZE)"; } > "$out/summary/bench_${tag}_pmc_hbm_traffic.csv"
     { echo "# kernels.hip sha256=$hash"; python3 tools/mfma_util_summary.py "$(cc SQ_VALU_MFMA_BUSY_CYCLES)" "$(cc GRBM_GUI_ACTIVE)" "$(cc SQ_INSTS_MFMA)"; } > "$out/summary/bench_${tag}_pmc_mfma_util.csv"
 fi
+# bench.py reads the counter summary from profiles/<round>/ (and accepts it only if its kernels.hip hash is the current one):
+# put this run's summary there on the box, so that the bench lines kept below carry `traffic`
+round=${ROUND:-r04}
+mkdir -p "profiles/$round"
+[ -f "$out/summary/bench_${tag}_pmc_hbm_traffic.csv" ] && cp "$out/summary/bench_${tag}_pmc_hbm_traffic.csv" "profiles/$round/"
 # the plain (unprofiled) bench line of the same workload, graph replay allowed
 run bench 600 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" || exit 1
 grep '^{' "$out/bench.log" > "$out/summary/bench_${tag}.json"
