@@ -279,6 +279,10 @@ def main():
     pdist.trace.on = False
     replayed = bool(st.get("graph") is not None and separate)
     if separate:        # the same number of steps again, eagerly, with one event pair per GEMM call
+        # (the last timed step has enqueued the residual segment of the step after it — the pipelined iteration, DESIGN 6d;
+        # the counting pass must build every residual itself, or its first step would count none)
+        ctx.sync()
+        st.pop("residuals_in_flight", None)
         ctx.stats(reset=True)
         ctx.prof_enable(True)
         ctx.prof_reset()

@@ -593,8 +593,9 @@ class EOM_CCSD:
         projected against ``us`` and orthonormalised in itself by rounds of block Gram-Schmidt in its Pythagorean form
         — ONE Gram product [us | ys]^T ys (every vector read once), the Cholesky factor of ys^T ys - P^T P on the host, ONE
         multi-output combination (ys - us P) R^-1 — so a round costs two passes over the subspace instead of a dot product
-        and an update per pair of vectors; a round is repeated only when the check of the result asks for it.  Returns the new orthonormal block; with ``shadows`` (vectors that any linear
-        map of ``ys`` must follow, e.g. their sigma vectors; only for an empty ``us``) returns (block, mapped shadows)."""
+        and an update per pair of vectors; a round is repeated only when the check of the result asks for it.  Returns the
+        new orthonormal block; with ``shadows`` (vectors that any linear map of ``ys`` must follow, e.g. their sigma vectors;
+        only for an empty ``us``) returns (block, mapped shadows)."""
         assert shadows is None or not us
         k, d, nflat = len(ys), len(us), lay[2]
         eye = np.vstack([np.zeros((d, k)), np.eye(k)])
