@@ -329,7 +329,7 @@ def main():
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "events": "separate eager pass after the timed steps" if separate else "inside the timed steps",
-                         "kernel": ("dgemm_glds_kernel" if prof_dma["launches"] else "dgemm_kernel") +
+                         "kernel": ("dgemm_glds_kernel + dgemm_glds_group_kernel" if prof_dma["launches"] else "dgemm_kernel") +
                                    " (v_mfma_f64_16x16x4_f64)",
                          "launches_per_step": dom["kernel_launches"] / args.steps,
                          "avg_launch_ms": dom["ms"] / max(1, dom["kernel_launches"]),
