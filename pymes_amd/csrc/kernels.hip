@@ -3450,6 +3450,7 @@ void gram_tile_n(const double* const* x, int mm, const double* const* y, int nn,
                  double* tile_dev, hipStream_t st, int& NNout) {
     if (nn <= 1) { NNout = 1; gram_tile<MM, 1>(x, mm, y, nn, len, vec, nblk, ws, tile_dev, st); }
     else if (nn <= 2) { NNout = 2; gram_tile<MM, 2>(x, mm, y, nn, len, vec, nblk, ws, tile_dev, st); }
+    else if (nn <= 3) { NNout = 3; gram_tile<MM, 3>(x, mm, y, nn, len, vec, nblk, ws, tile_dev, st); }
     else { NNout = 4; gram_tile<MM, 4>(x, mm, y, nn, len, vec, nblk, ws, tile_dev, st); }
 }
 template <int MM, int NN>
@@ -3472,6 +3473,7 @@ void lincomb_multi_tile_n(const double* const* x, int mm, const double* c, int l
                           long len, bool vec, hipStream_t st) {
     if (nn <= 1) lincomb_multi_tile<MM, 1>(x, mm, c, ldc, beta, y, nn, len, vec, st);
     else if (nn <= 2) lincomb_multi_tile<MM, 2>(x, mm, c, ldc, beta, y, nn, len, vec, st);
+    else if (nn <= 3) lincomb_multi_tile<MM, 3>(x, mm, c, ldc, beta, y, nn, len, vec, st);
     else lincomb_multi_tile<MM, 4>(x, mm, c, ldc, beta, y, nn, len, vec, st);
 }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -3525,7 +3527,8 @@ void gram(int m, int n, const double* const* x, const double* const* y, int64_t 
             double* tile = tiles + 64 * done.size();
             if (mm <= 4) gram_tile_n<4>(X + i0, mm, Y + j0, nn, (long)len, vec, nblk, ws, tile, st, NN);
             else if (mm <= 8) gram_tile_n<8>(X + i0, mm, Y + j0, nn, (long)len, vec, nblk, ws, tile, st, NN);
-            else gram_tile_n<16>(X + i0, mm, Y + j0, nn, (long)len, vec, nblk, ws, tile, st, NN);
+            else if (mm <= 12) gram_tile_n<12>(X + i0, mm, Y + j0, nn, (long)len, vec, nblk, ws, tile, st, NN);    // (the Davidson
+            else gram_tile_n<16>(X + i0, mm, Y + j0, nn, (long)len, vec, nblk, ws, tile, st, NN);    //  subspace: 12 x 3, no padded slots)
             done.push_back({i0, mm, j0, nn, NN});
             if ((int)done.size() == kGramTiles) flush();
         }
@@ -3560,6 +3563,7 @@ void lincomb_multi(int m, int n, const double* const* x, const double* c, const 
             const double* cc = c + (long)i0 * n + j0;
             if (mm <= 4) lincomb_multi_tile_n<4>(x + i0, mm, cc, n, bb, y + j0, nn, (long)len, vec, st);
             else if (mm <= 8) lincomb_multi_tile_n<8>(x + i0, mm, cc, n, bb, y + j0, nn, (long)len, vec, st);
+            else if (mm <= 12) lincomb_multi_tile_n<12>(x + i0, mm, cc, n, bb, y + j0, nn, (long)len, vec, st);
             else lincomb_multi_tile_n<16>(x + i0, mm, cc, n, bb, y + j0, nn, (long)len, vec, st);
         }
     }
