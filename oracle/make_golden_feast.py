@@ -2,7 +2,7 @@
 """Pin oracle/feast_oracle.py against the reference's FEAST-EOM-CCSD driver (pymes/solver/feast_eom_ccsd.py:72-181) and
 write tests/golden/feast.json.  BUILD CONTAINER ONLY:
 
-    PYTHONPATH=/root/reference:/root/repo python oracle/make_golden_feast.py [rt]
+    PYTHONPATH=/root/reference:/root/repo python oracle/make_golden_feast.py [rt | syn [small] [big]]
 
 The reference's driver does not run against the scipy of this image (1.15.3) as it stands: (1) its ``LinearOperator`` is
 created without ``dtype`` (:341), scipy then probes the operator with an int8 zero vector and the in-place ``+=`` of
@@ -115,10 +115,63 @@ def rt_case():
     print(f"feast real-time hooks: GCROT relative residual {rel:.2e}; written feast_rt.npz")
 
 
+SYN_CASES = {  # tag: nocc, nvirt, scale (oracle/cases.py::eom_davidson_case), seed, e_c, e_r, n_trial, max_iter
+    "small": (4, 12, 0.3, 3, 3.25, 0.3, 4, 4),
+    "big": (12, 48, 0.19, 3, 3.2, 0.3, 4, 3),
+}
+
+
+def syn_cases(tags):
+    """FEAST beyond a toy molecule: the reference's chain CCSD.solve -> get_T1_dressed_* -> FEAST_EOM_CCSD.solve on the
+    synthetic problems of the Davidson golden (tests/golden/eom_davidson.json: the window holds its two lowest roots).
+    -> tests/golden/feast_synthetic.json: Ritz values of every pass, the settled ones, wall time of the reference."""
+    from oracle.cases import eom_davidson_case
+    path = os.path.join(GOLD, "feast_synthetic.json")
+    out = json.load(open(path)) if os.path.exists(path) else {}
+    dav = json.load(open(os.path.join(GOLD, "eom_davidson.json")))
+    for tag in tags:
+        no, nv, scale, seed, e_c, e_r, n_trial, max_iter = SYN_CASES[tag]
+        f, V = eom_davidson_case(no, nv, seed=0, scale=scale)
+        t0 = time.time()
+        cc = ref_ccsd.CCSD(no, delta_e=1e-11)
+        res, _ = quiet(cc.solve, f, V, max_iter=100)
+        Vb = part_2_body_int(no, V)
+        fd = cc.get_T1_dressed_fock(f, res["t1"], Vb)
+        Vd = cc.get_T1_dressed_V(res["t1"], Vb)
+        t2 = res["t2"].copy()
+        t_cc = time.time() - t0
+        s = ref_feast.FEAST_EOM_CCSD(no, e_c=e_c, e_r=e_r, n_trial=n_trial, max_iter=max_iter)
+        np.random.seed(seed)
+        t0 = time.time()
+        ev, log = quiet(s.solve, fd, Vd, t2)
+        t_ref = time.time() - t0
+        hist = parse_history(log)
+        if len(hist) < max_iter or not hist or np.abs(np.sort_complex(np.array(hist[-1])) - np.sort_complex(np.asarray(ev))).max() > 0:
+            hist.append(list(ev))                                  # a pass that met the stopping test is returned, not logged
+        final = np.array(hist[-1])
+        settled = [x for x in final if abs(x - e_c) < e_r and len(hist) > 1 and min(abs(x - y) for y in hist[-2]) < 1e-7]
+        # the settled values are excitation energies of the same H-bar: the Davidson golden's roots inside the window
+        roots = [e for e in dav[tag]["ee"] if abs(e - e_c) < e_r]
+        near = [min(abs(x - e) for x in final) for e in roots]
+        cplx = lambda h: [[float(np.real(x)), float(np.imag(x))] for x in h]
+        out[tag] = {"no": no, "nv": nv, "scale": scale, "seed": seed, "e_c": e_c, "e_r": e_r, "n_trial": n_trial,
+                    "max_iter": max_iter, "ccsd_e": float(res["ccsd e"]), "eigvals": cplx(ev), "history": [cplx(h) for h in hist],
+                    "settled_in_window": cplx(settled), "iterations": len(hist), "davidson_roots_in_window": roots,
+                    "distance_to_davidson_roots": [float(x) for x in near],
+                    "reference_seconds": {"ccsd+dressing": round(t_cc, 1), "feast": round(t_ref, 1)}}
+        print(f"feast synthetic {tag} ({no},{nv}): {len(hist)} passes, {t_cc:.0f} s + {t_ref:.0f} s; final {np.real(final)}; "
+              f"settled {np.real(settled)}; Davidson roots in the window {roots}, distance {near}", flush=True)
+        with open(path, "w") as fh:
+            json.dump(out, fh, indent=1)
+
+
 def main():
     np.set_printoptions(precision=17, linewidth=10000)
     if "rt" in sys.argv[1:]:
         rt_case()
+        return
+    if "syn" in sys.argv[1:]:
+        syn_cases([t for t in sys.argv[1:] if t in SYN_CASES] or ["small"])
         return
     out = {}
     for tag, seed, e_c, e_r, n_trial, max_iter in CASES:

@@ -186,3 +186,53 @@ def test_real_time_hooks_gpu(gpu_lib, monkeypatch):
 @pytest.mark.gpu
 def test_product_gpu(gpu_lib, monkeypatch):
     run_product(gpu_lib, monkeypatch, list(G))
+
+
+SYN_PATH = os.path.join(GOLD, "feast_synthetic.json")       # oracle/make_golden_feast.py syn
+SYN = json.load(open(SYN_PATH)) if os.path.exists(SYN_PATH) else {}
+
+
+def check_synthetic_chain(lib, monkeypatch, tag, first_tol, settled_tol):
+    """Beyond a toy molecule: CCSD.solve -> get_T1_dressed_* -> FEAST_EOM_CCSD.solve, device-resident, on the synthetic problems
+    of the Davidson golden, against the reference's own run of the same chain (tests/golden/feast_synthetic.json): Ritz values
+    of the first pass, the settled values of the last, and those against the Davidson roots inside the window."""
+    from oracle.cases import eom_davidson_case
+    from pymes_amd.integral.device import DeviceIntegrals
+    from pymes_amd.solver.ccsd import CCSD
+    from pymes_amd.solver.feast_eom_ccsd import FEAST_EOM_CCSD
+    monkeypatch.setattr(_lib, "_default", lib)
+    ref = SYN[tag]
+    no, nv = ref["no"], ref["nv"]
+    f, V = eom_davidson_case(no, nv, seed=0, scale=ref["scale"])
+    ints = DeviceIntegrals.from_V_pqrs(no, V)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            cc = CCSD(no, delta_e=1e-11)
+            res = cc.solve(f, ints, max_iter=100, device_amplitudes=True)
+            fd = cc.get_T1_dressed_fock(f, res["t1"], ints)
+            Vd = cc.get_T1_dressed_V(res["t1"], ints)
+            s = FEAST_EOM_CCSD(no, e_c=ref["e_c"], e_r=ref["e_r"], n_trial=ref["n_trial"], max_iter=ref["max_iter"])
+            np.random.seed(ref["seed"])
+            s.solve(fd, Vd, res["t2"])
+        assert abs(res["ccsd e"] - ref["ccsd_e"]) < 1e-9
+        assert len(ref["settled_in_window"]) == len(ref["davidson_roots_in_window"]) == 2
+        compare(ref, s.history, first_tol, settled_tol)
+        for e in ref["davidson_roots_in_window"]:
+            assert min(abs(x - e) for x in s.history[-1]) < 2e-7, (e, s.history[-1])
+        assert all(info == 0 for info, _ in s.linear_solver_info)
+    finally:
+        ints.ctx.close()
+    return s
+
+
+def test_synthetic_chain_host_logic(hostsim_lib, monkeypatch):
+    check_synthetic_chain(hostsim_lib, monkeypatch, "small", 1e-7, 1e-7)
+
+
+@pytest.mark.gpu
+def test_synthetic_chain_gpu(gpu_lib, monkeypatch):
+    """(12,48): LDS-DMA GEMMs, batched pair-packed ladders and the stacked complex sigma (24 right-hand sides per quadrature
+    sweep) inside a FEAST solve that is compared with the reference."""
+    check_synthetic_chain(gpu_lib, monkeypatch, "small", 1e-7, 1e-7)
+    if "big" in SYN:
+        check_synthetic_chain(gpu_lib, monkeypatch, "big", 1e-7, 1e-7)

@@ -153,3 +153,35 @@ def test_full_size_properties(gpu_lib):
             assert ctx.norm(d) < 1e-11 * ctx.norm(r2), dcd
     finally:
         ctx.close()
+
+
+def test_pipelined_iteration_is_the_same_iteration(gpu_lib, monkeypatch):
+    """The single-rank pass enqueues the next pass's residual graph before it reads its own energy back (ccsd.py:_iterate_single);
+    PYMES_NO_PIPELINE=1 launches every pass after the previous read-back.  Same kernels on the same data in the same order: the
+    solutions agree bit for bit, with and without DIIS, also when the last passes stop speculating and when the T1 = 0
+    shortcut of the first pass switches graphs."""
+    no, nv = 6, 22
+    f, V, B, eps = synthetic_case(no, nv, seed=4, scale=0.25)
+    from pymes_amd.integral.device import DeviceIntegrals
+    ints = DeviceIntegrals.from_factors(no, B)
+    try:
+        for dcsd in (False, True):
+            for diis in (True, False):
+                runs = []
+                for off in (False, True):
+                    if off:
+                        monkeypatch.setenv("PYMES_NO_PIPELINE", "1")
+                    else:
+                        monkeypatch.delenv("PYMES_NO_PIPELINE", raising=False)
+                    s = ccsd.CCSD(no, delta_e=1e-10, is_dcsd=dcsd, is_diis=diis)
+                    buf = io.StringIO()
+                    with contextlib.redirect_stdout(buf):
+                        res = s.solve(f, ints)
+                    energies = [ln for ln in buf.getvalue().splitlines() if "Correlation Energy" in ln]
+                    runs.append((s.iterations, res["ccsd e"], res["t1"].copy(), res["t2"].copy(), energies))
+                a, b = runs
+                assert a[0] == b[0] and a[0] > 3
+                assert a[1] == b[1] and a[4] == b[4] and len(a[4]) == a[0]
+                assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    finally:
+        ints.ctx.close()
