@@ -1032,18 +1032,40 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
     __syncthreads();
     return r;   // valid on thread 0
 }
-__global__ void __launch_bounds__(256) dots_stage1_kernel(const DotPtrs p, double* __restrict__ partial) {
+// block -> (pair, chunk): the pairs of a DIIS / energy call mostly share one operand (the newest vector against the history), so the
+// blocks that read the same chunk are neighbours in dispatch order AND on the same XCD (ids 8 apart): the shared chunk comes
+// from HBM once and from that XCD's L2 for the other pairs (pair-major order re-reads it from HBM for every pair)
+template <int VEC>
+__global__ void __launch_bounds__(256) dots_stage1_kernel(const DotPtrs p, double* __restrict__ partial, int nb, int npairs) {
     __shared__ double sh[4];
-    const int pair = blockIdx.y;
+    const int lin = blockIdx.x;
+    int pair, b;
+    if ((nb & 7) == 0) { const int q = lin >> 3; pair = q % npairs; b = (q / npairs) * 8 + (lin & 7); }
+    else { pair = lin / nb; b = lin - pair * nb; }
     const double* __restrict__ x = p.x[pair];
     const double* __restrict__ y = p.y[pair];
     const long n = p.n[pair];
     double s = 0.0;
+    if (VEC == 2) {
+        const double2* __restrict__ x2 = reinterpret_cast<const double2*>(x);
+        const double2* __restrict__ y2 = reinterpret_cast<const double2*>(y);
+        const long n2 = n >> 1;
+        double s1 = 0.0;
 #pragma unroll 4
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        s += x[i] * y[i];       // read-only operands: the unrolled loads are issued together
+        for (long i = b * 256L + threadIdx.x; i < n2; i += nb * 256L) {
+            const double2 a = x2[i], c = y2[i];
+            s += a.x * c.x;
+            s1 += a.y * c.y;
+        }
+        s += s1;
+        if ((n & 1) && b == 0 && threadIdx.x == 0) s += x[n - 1] * y[n - 1];
+    } else {
+#pragma unroll 4
+        for (long i = b * 256L + threadIdx.x; i < n; i += nb * 256L)
+            s += x[i] * y[i];       // read-only operands: the unrolled loads are issued together
+    }
     s = block_sum(s, sh);
-    if (threadIdx.x == 0) partial[pair * kDotBlocks + blockIdx.x] = s;
+    if (threadIdx.x == 0) partial[pair * kDotBlocks + b] = s;
 }
 __global__ void __launch_bounds__(256) dots_stage2_kernel(const double* __restrict__ partial, int nblocks,
                                                           double* __restrict__ out) {
@@ -1221,29 +1243,64 @@ __global__ void lincomb_dev_kernel(double* __restrict__ out, const LinPtrsDev p,
     }
 }
 
-// five reductions in one pass over the amplitudes (device_api.h energy_norms); partial[q * kDotBlocks + block]
+// five reductions in one pass over the amplitudes (device_api.h energy_norms); partial[q * kDotBlocks + block].
+// The (a, b, i, j) digits of the element index advance by the digits of the grid stride with carries — four integer
+// divisions per ELEMENT made this kernel VALU-bound (0.75 ms for 3.2 GB at (50,200)); VEC = 2: 16-byte loads over j pairs
+// (nocc even: a pair never leaves its row).
+template <int VEC>
 __global__ void __launch_bounds__(256) energy_norms_kernel(const double* __restrict__ f, const double* __restrict__ t1,
                                                            const double* __restrict__ t2, const double* __restrict__ Edir,
                                                            const double* __restrict__ Eex, const double* __restrict__ dt2,
                                                            int no, int nv, long total, double* __restrict__ partial) {
     __shared__ double sh[4];
     double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s0 = 0.0, s5 = 0.0;
+    const int noV = no / VEC;                       // j digit in units of VEC elements
+    const long nvecs = total / VEC, stride = (long)gridDim.x * blockDim.x;
+    long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    int j, i, b, a, sj, si, sb, sa;
+    {
+        long r = idx;
+        j = (int)(r % noV); r /= noV;
+        i = (int)(r % no); r /= no;
+        b = (int)(r % nv);
+        a = (int)(r / nv);
+        r = stride;
+        sj = (int)(r % noV); r /= noV;
+        si = (int)(r % no); r /= no;
+        sb = (int)(r % nv);
+        sa = (int)(r / nv);
+    }
 #pragma unroll 4
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const double x = t2[idx];
-        double tau = x;
-        if (t1) {
-            long r = idx;
-            const int j = (int)(r % no); r /= no;
-            const int i = (int)(r % no); r /= no;
-            const int b = (int)(r % nv);
-            const int a = (int)(r / nv);
-            tau += t1[a * no + i] * t1[b * no + j];
+    for (; idx < nvecs; idx += stride) {
+        if (VEC == 2) {
+            const double2 x = reinterpret_cast<const double2*>(t2)[idx];
+            const double2 ed = reinterpret_cast<const double2*>(Edir)[idx], ex = reinterpret_cast<const double2*>(Eex)[idx];
+            double tx = x.x, ty = x.y;
+            if (t1) {
+                const double ta = t1[a * no + i];
+                tx += ta * t1[b * no + 2 * j];
+                ty += ta * t1[b * no + 2 * j + 1];
+            }
+            s1 += tx * ed.x + ty * ed.y;
+            s2 += tx * ex.x + ty * ex.y;
+            s3 += x.x * x.x + x.y * x.y;
+            if (dt2) { const double2 d = reinterpret_cast<const double2*>(dt2)[idx]; s4 += d.x * d.x + d.y * d.y; }
+        } else {
+            const double x = t2[idx];
+            double tau = x;
+            if (t1) tau += t1[a * no + i] * t1[b * no + j];
+            s1 += tau * Edir[idx];
+            s2 += tau * Eex[idx];
+            s3 += x * x;
+            if (dt2) { const double d = dt2[idx]; s4 += d * d; }
         }
-        s1 += tau * Edir[idx];
-        s2 += tau * Eex[idx];
-        s3 += x * x;
-        if (dt2) { const double d = dt2[idx]; s4 += d * d; }
+        j += sj;
+        int c = j >= noV; j -= c ? noV : 0;
+        i += si + c;
+        c = i >= no; i -= c ? no : 0;
+        b += sb + c;
+        c = b >= nv; b -= c ? nv : 0;
+        a += sa + c;
     }
     if (t1 && f) {
         const long n = no + nv, ov = (long)no * nv;
@@ -3320,19 +3377,33 @@ void cc_update(double* t, double* dt, const double* r, const double* eo, const d
     cc_update_to(t, dt, t, r, eo, ev, shift, delta, no, nv, rank, s);
 }
 
+// stage 1 of a batch of dot products: 16-byte loads when every operand allows them; returns the number of chunks per pair
+static int launch_dots_stage1(int npairs, const double* const* x, const double* const* y, const int64_t* n, double* ws,
+                              hipStream_t st) {
+    DotPtrs p;
+    long nmax = 0;
+    bool vec = true;
+    for (int i = 0; i < npairs; ++i) {
+        p.x[i] = x[i]; p.y[i] = y[i]; p.n[i] = (long)n[i];
+        nmax = std::max(nmax, p.n[i]);
+        vec = vec && ((reinterpret_cast<uintptr_t>(x[i]) | reinterpret_cast<uintptr_t>(y[i])) & 15) == 0;
+    }
+    for (int i = npairs; i < 16; ++i) { p.x[i] = nullptr; p.y[i] = nullptr; p.n[i] = 0; }
+    const long per = vec ? 512 : 256;
+    const int nb = (int)std::max<long>(1, std::min<long>(kDotBlocks, (nmax + per - 1) / per));
+    if (vec) hipLaunchKernelGGL(dots_stage1_kernel<2>, dim3(nb * npairs), dim3(256), 0, st, p, ws, nb, npairs);
+    else hipLaunchKernelGGL(dots_stage1_kernel<1>, dim3(nb * npairs), dim3(256), 0, st, p, ws, nb, npairs);
+    HIP_CHECK(hipGetLastError());
+    return nb;
+}
+
 void dots(int npairs, const double* const* x, const double* const* y, const int64_t* n, double* out_host, stream_t s) {
     if (npairs <= 0) return;
     if (npairs > 16) throw std::runtime_error("dots: at most 16 pairs per call");
     hipStream_t st = (hipStream_t)s;
     const int dv = current_device();
     ensure_dot_ws(dv);
-    DotPtrs p;
-    long nmax = 0;
-    for (int i = 0; i < npairs; ++i) { p.x[i] = x[i]; p.y[i] = y[i]; p.n[i] = (long)n[i]; nmax = std::max(nmax, p.n[i]); }
-    for (int i = npairs; i < 16; ++i) { p.x[i] = nullptr; p.y[i] = nullptr; p.n[i] = 0; }
-    const int nb = (int)std::max<long>(1, std::min<long>(kDotBlocks, (nmax + 255) / 256));
-    hipLaunchKernelGGL(dots_stage1_kernel, dim3(nb, npairs), dim3(256), 0, st, p, g_dot_ws[dv]);
-    HIP_CHECK(hipGetLastError());
+    const int nb = launch_dots_stage1(npairs, x, y, n, g_dot_ws[dv], st);
     double* out_dev = g_dot_ws[dv] + 16 * kDotBlocks;
     hipLaunchKernelGGL(dots_stage2_kernel, dim3(npairs), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);
     HIP_CHECK(hipGetLastError());
@@ -3348,13 +3419,7 @@ void diis_step(double* state, int npairs, const double* const* x, const double* 
     hipStream_t st = (hipStream_t)s;
     const int dv = current_device();
     ensure_dot_ws(dv);
-    DotPtrs p;
-    long nmax = 0;
-    for (int i = 0; i < npairs; ++i) { p.x[i] = x[i]; p.y[i] = y[i]; p.n[i] = (long)n[i]; nmax = std::max(nmax, p.n[i]); }
-    for (int i = npairs; i < 16; ++i) { p.x[i] = nullptr; p.y[i] = nullptr; p.n[i] = 0; }
-    const int nb = (int)std::max<long>(1, std::min<long>(kDotBlocks, (nmax + 255) / 256));
-    hipLaunchKernelGGL(dots_stage1_kernel, dim3(nb, npairs), dim3(256), 0, st, p, g_dot_ws[dv]);
-    HIP_CHECK(hipGetLastError());
+    const int nb = launch_dots_stage1(npairs, x, y, n, g_dot_ws[dv], st);
     double* out_dev = g_dot_ws[dv] + 16 * kDotBlocks;
     hipLaunchKernelGGL(dots_stage2_kernel, dim3(npairs), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);
     HIP_CHECK(hipGetLastError());
@@ -3379,8 +3444,10 @@ int energy_norms_start(const double* f, const double* t1, const double* t2, cons
     ensure_dot_ws(dv);
     const long total = (long)nv * nv * no * no;
     const int nb = (int)std::max<long>(1, std::min<long>(kDotBlocks, (total + 255) / 256));
-    hipLaunchKernelGGL(energy_norms_kernel, dim3(nb), dim3(256), 0, st, f, t1, t2, Edir, Eex, dt2, no, nv, total,
-                       g_dot_ws[dv]);
+    const bool vec = (no % 2 == 0) && !((reinterpret_cast<uintptr_t>(t2) | reinterpret_cast<uintptr_t>(Edir) |
+                                          reinterpret_cast<uintptr_t>(Eex) | reinterpret_cast<uintptr_t>(dt2)) & 15);
+    if (vec) hipLaunchKernelGGL(energy_norms_kernel<2>, dim3(nb), dim3(256), 0, st, f, t1, t2, Edir, Eex, dt2, no, nv, total, g_dot_ws[dv]);
+    else hipLaunchKernelGGL(energy_norms_kernel<1>, dim3(nb), dim3(256), 0, st, f, t1, t2, Edir, Eex, dt2, no, nv, total, g_dot_ws[dv]);
     HIP_CHECK(hipGetLastError());
     double* out_dev = g_dot_ws[dv] + 16 * kDotBlocks;
     hipLaunchKernelGGL(dots_stage2_kernel, dim3(6), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);

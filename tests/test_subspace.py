@@ -138,3 +138,43 @@ def test_grouped_products_gpu(gpu_lib):
     # an under-filled group of deep products: k-split inside the group, one reduction launch
     check_grouped_products(gpu_lib, [(64, 64, 20000, True, True, 1.0, 0.5), (128, 64, 9999, False, False, 1.0, 0.0),
                                      (60, 60, 7, True, False, 1.0, 0.0)], (3, 1))
+
+
+def check_dots(lib, lengths_sets):
+    """pymes_dots_var: pairs of different lengths in one call, a shared second operand (the DIIS pattern), odd lengths,
+    8-byte-aligned operands, chunk counts on both block mappings (a multiple of 8 and not)."""
+    ctx = Context(2, 3, lib=lib)
+    rng = np.random.default_rng(21)
+    try:
+        for lengths, shared, mis in lengths_sets:
+            xh, xd, yh, yd = [], [], [], []
+            ys_h, ys_d = None, None
+            for n in lengths:
+                h, d = _vectors(ctx, rng, 1, n, mis)
+                xh.append(h[0]); xd.append(d[0])
+                if shared and ys_h is not None and ys_h.size == n:
+                    yh.append(ys_h); yd.append(ys_d)
+                else:
+                    h, d = _vectors(ctx, rng, 1, n, mis)
+                    ys_h, ys_d = h[0], d[0]
+                    yh.append(ys_h); yd.append(ys_d)
+            got = ctx.dots(xd, yd)
+            for g, a, b in zip(got, xh, yh):
+                ref = float(np.dot(a, b))
+                assert abs(g - ref) <= 1e-13 * max(1.0, np.abs(a).max() * np.abs(b).max() * max(1, a.size) ** 0.5 * 8), (lengths, g, ref)
+    finally:
+        ctx.close()
+
+
+DOT_SETS = [((1,), False, False), ((17, 17, 17), True, False), ((1000, 1000, 33, 33), True, False), ((513, 7), False, True),
+            ((4097, 4097, 4097, 4097, 4097, 4097, 65, 65, 65, 65, 65, 65), True, False), ((2049, 2049), True, True)]
+
+
+def test_dots_host_logic(hostsim_lib):
+    check_dots(hostsim_lib, DOT_SETS)
+
+
+@pytest.mark.gpu
+def test_dots_gpu(gpu_lib):
+    check_dots(gpu_lib, DOT_SETS + [((300001,) * 6 + (1201,) * 6, True, False), ((1 << 20,) * 3, True, False),
+                                    (((1 << 20) + 3,) * 5, True, True), ((700000, 11), False, False)])
