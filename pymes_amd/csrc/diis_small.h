@@ -25,15 +25,21 @@ constexpr int kStateDoubles = 96;
 PYMES_HD inline void jacobi_eigh(int n, double* A, double* V, double* lam) {
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) V[i * 9 + j] = (i == j) ? 1.0 : 0.0;
+    // Off-diagonal elements below 1e-17 of the Frobenius norm are left alone (they move an eigenvalue by less than that — the
+    // callers decide at 1e-12 of an O(1) norm); a sweep without a rotation ends the iteration.  (A test on the SUM of the
+    // off-diagonal squares never fires on a DIIS matrix near convergence — eigenvalues of 1e-17 next to +-2.4, the rounding
+    // noise of each rotation keeps the sum above it — and all 60 sweeps ran: 40-100 us on the host with the device idle.)
+    double norm2 = 0.0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) norm2 += A[i * 9 + j] * A[i * 9 + j];
+    const double tiny = 1e-17 * sqrt(norm2);
     for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0.0, diag = 0.0;
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j < n; ++j) (i == j ? diag : off) += A[i * 9 + j] * A[i * 9 + j];
-        if (off <= 1e-34 * (diag + off) || off == 0.0) break;       // off-diagonal elements below 1e-17 of the norm
+        int rotations = 0;
         for (int p = 0; p < n - 1; ++p)
             for (int q = p + 1; q < n; ++q) {
                 const double apq = A[p * 9 + q];
-                if (apq == 0.0) continue;
+                if (!(apq > tiny || apq < -tiny)) { if (apq == apq) continue; }      // (NaN rotates on: the result is NaN)
+                ++rotations;
                 const double theta = (A[q * 9 + q] - A[p * 9 + p]) / (2.0 * apq);
                 const double t = (theta >= 0.0 ? 1.0 : -1.0) / ((theta >= 0.0 ? theta : -theta) + sqrt(theta * theta + 1.0));
                 const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
@@ -53,6 +59,7 @@ PYMES_HD inline void jacobi_eigh(int n, double* A, double* V, double* lam) {
                     V[k * 9 + q] = s * vkp + c * vkq;
                 }
             }
+        if (!rotations) break;
     }
     for (int i = 0; i < n; ++i) lam[i] = A[i * 9 + i];
 }
@@ -143,12 +150,65 @@ PYMES_HD inline void finish(double* S, const double* L, const double* V, const d
     S[92] += 1.0;
 }
 
+// inv = A^-1 by Gauss-Jordan elimination with partial pivoting (A overwritten; pitch 9); false when a pivot vanishes or is
+// not finite
+PYMES_HD inline bool invert(int n, double* A, double* inv) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) inv[i * 9 + j] = (i == j) ? 1.0 : 0.0;
+    for (int k = 0; k < n; ++k) {
+        int piv = k;
+        double big = A[k * 9 + k] < 0 ? -A[k * 9 + k] : A[k * 9 + k];
+        for (int i = k + 1; i < n; ++i) {
+            const double v = A[i * 9 + k] < 0 ? -A[i * 9 + k] : A[i * 9 + k];
+            if (v > big) { big = v; piv = i; }
+        }
+        if (!(big > 0.0) || !(big <= 1.7976931348623157e308)) return false;
+        if (piv != k)
+            for (int j = 0; j < n; ++j) {
+                double t = A[k * 9 + j]; A[k * 9 + j] = A[piv * 9 + j]; A[piv * 9 + j] = t;
+                t = inv[k * 9 + j]; inv[k * 9 + j] = inv[piv * 9 + j]; inv[piv * 9 + j] = t;
+            }
+        const double d = 1.0 / A[k * 9 + k];
+        for (int j = 0; j < n; ++j) { A[k * 9 + j] *= d; inv[k * 9 + j] *= d; }
+        for (int i = 0; i < n; ++i) {
+            if (i == k) continue;
+            const double f = A[i * 9 + k];
+            if (f == 0.0) continue;
+            for (int j = 0; j < n; ++j) { A[i * 9 + j] -= f * A[k * 9 + j]; inv[i * 9 + j] -= f * inv[k * 9 + j]; }
+        }
+    }
+    return true;
+}
+
+// The reference decides between inverse and pseudo-inverse by the eigenvalues of L (any |lambda| < 1e-12, diis.py:85-86).
+// 1 / min|lambda| = ||L^-1||_2 <= n max|L^-1_ij|: when that bound stays below 0.5e12 no eigenvalue is within 2e-12 of zero,
+// the decision is "inverse" without the eigen-decomposition (40 us of cyclic Jacobi on the host for a 7 x 7 matrix — the
+// device is idle while it runs), and c = -L^-1[:, n-1].  Anything else (a large inverse, a vanished pivot, NaN) goes through
+// the eigen-decomposition as before.
 PYMES_HD inline void step(double* S, const double* overlaps, int ntypes, int m, int was_full) {
     double L[81], A[81], V[81], lam[9], work[99];
+    const int n = m + 1;
     build_L(S, overlaps, ntypes, m, was_full, L);
     for (int i = 0; i < 81; ++i) A[i] = L[i];
-    jacobi_eigh(m + 1, A, V, lam);
-    finish(S, L, V, lam, m + 1, work);
+    if (invert(n, A, V)) {
+        double big = 0.0;
+        bool finite = true;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                const double v = V[i * 9 + j] < 0 ? -V[i * 9 + j] : V[i * 9 + j];
+                finite = finite && (v == v);
+                if (v > big) big = v;
+            }
+        if (finite && n * big < 0.5e12) {
+            for (int i = 0; i < 9; ++i) S[82 + i] = i < n ? -V[i * 9 + (n - 1)] : 0.0;
+            S[91] = 0.0;
+            S[92] += 1.0;
+            return;
+        }
+    }
+    for (int i = 0; i < 81; ++i) A[i] = L[i];
+    jacobi_eigh(n, A, V, lam);
+    finish(S, L, V, lam, n, work);
 }
 
 }  // namespace diis_small

@@ -1239,26 +1239,23 @@ __global__ void __launch_bounds__(64) diis_step_kernel(double* __restrict__ stat
     }
     __syncthreads();
 
-    for (int sweep = 0; sweep < 40; ++sweep) {
-        double off = 0.0, tot = 0.0;
-        for (int e = lane; e < 81; e += 64) {
-            const int i = e / 9, j = e - 9 * i;
-            if (i < n && j < n) {
-                const double v = sA[e] * sA[e];
-                tot += v;
-                if (i != j) off += v;
-            }
-        }
+    // (stopping rule of diis_small::jacobi_eigh: elements below 1e-17 of the norm are left alone, a sweep without a
+    // rotation ends the iteration — a test on the sum of the off-diagonal squares never fires near convergence)
+    double tot = 0.0;
+    for (int e = lane; e < 81; e += 64) {
+        const int i = e / 9, j = e - 9 * i;
+        if (i < n && j < n) tot += sA[e] * sA[e];
+    }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            off += __shfl_xor(off, o, 64);
-            tot += __shfl_xor(tot, o, 64);
-        }
-        if (off <= 1e-34 * tot || off == 0.0) break;            // (wave-uniform)
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    const double tiny = 1e-17 * sqrt(tot);
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        int rotations = 0;
         for (int p = 0; p < n - 1; ++p)
             for (int q = p + 1; q < n; ++q) {
                 const double apq = sA[p * 9 + q];
-                if (apq == 0.0) continue;                        // (wave-uniform: every lane reads the same word)
+                if (!(apq > tiny || apq < -tiny) && apq == apq) continue;   // (wave-uniform: every lane reads the same word)
+                ++rotations;
                 const double theta = (sA[q * 9 + q] - sA[p * 9 + p]) / (2.0 * apq);
                 const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                 const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
@@ -1279,6 +1276,7 @@ __global__ void __launch_bounds__(64) diis_step_kernel(double* __restrict__ stat
                 }
                 __syncthreads();
             }
+        if (!rotations) break;
     }
     if (lane < n) slam[lane] = sA[lane * 9 + lane];
     __syncthreads();
