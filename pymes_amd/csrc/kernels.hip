@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -2647,21 +2648,24 @@ inline long dma_min_k() {
     }();
     return v;
 }
-template <bool AKC, bool BKC>
+template <int BM, int BN, bool AKC, bool BKC>
 void launch_stream64(const GemmK& k, int vec, long nblocks, hipStream_t st) {
-    if (vec == 2) launch_gemm<64, 64, AKC, BKC, 2, true>(k, nblocks, st);
-    else launch_gemm<64, 64, AKC, BKC, 1, true>(k, nblocks, st);
+    if (vec == 2) launch_gemm<BM, BN, AKC, BKC, 2, true>(k, nblocks, st);
+    else launch_gemm<BM, BN, AKC, BKC, 1, true>(k, nblocks, st);
 }
 thread_local bool g_stream64 = false;      // set by dev::gemm for the launches of one call
 
 template <int BM, int BN>
 bool dispatch_layout(const GemmK& k, bool akc, bool bkc, int vec, long nblocks, hipStream_t st) {   // true: LDS-DMA kernel
-    if (BM == 64 && BN == 64 && g_stream64) {
-        if (akc && bkc) launch_stream64<true, true>(k, vec, nblocks, st);
-        else if (akc) launch_stream64<true, false>(k, vec, nblocks, st);
-        else if (bkc) launch_stream64<false, true>(k, vec, nblocks, st);
-        else launch_stream64<false, false>(k, vec, nblocks, st);
-        return false;
+    if constexpr (BM <= 64 && BN <= 64) {
+        // (the narrow tiles 64 x 32 / 32 x 64 exist for the streaming shapes only)
+        if (g_stream64 || BM < 64 || BN < 64) {
+            if (akc && bkc) launch_stream64<BM, BN, true, true>(k, vec, nblocks, st);
+            else if (akc) launch_stream64<BM, BN, true, false>(k, vec, nblocks, st);
+            else if (bkc) launch_stream64<BM, BN, false, true>(k, vec, nblocks, st);
+            else launch_stream64<BM, BN, false, false>(k, vec, nblocks, st);
+            return false;
+        }
     }
     // the LDS-DMA kernel addresses a tile as uniform base + 32-bit byte offset per lane
     const bool off32 = (akc ? 128 : 16) * k.a_ld * 8 + 4096 < (1L << 32) && (bkc ? 128 : 16) * k.b_ld * 8 + 4096 < (1L << 32);
@@ -3199,6 +3203,19 @@ void gemm(const Gemm& g, stream_t s) {
     // ... and the tiny outputs contracted over a huge K (singles residual: 200 x 50 over o v^2 = 2e6), k-split over the chip
     if (g.M <= 256 && g.N <= 256 && g.K >= 65536 && BM == 64 && BN == 64) stream = true;
     if (const char* e = getenv("PYMES_GEMM_STREAM")) stream = stream && atoi(e) != 0;
+    // a streaming shape whose skinny side is at most 32 (nocc = 20 against 64-wide tiles: two thirds of the MFMA work on
+    // padding, and these launches are MFMA-issue AND bandwidth co-limited): 64 x 32 / 32 x 64 tiles
+    // (single-buffer kernel for every narrow launch: the only variant instantiated for them — PYMES_NARROW_TILES=stream keeps
+    // them to the streaming shapes)
+    static const int narrow_mode = [] {
+        if (getenv("PYMES_NO_NARROW_TILES")) return 0;
+        const char* e = getenv("PYMES_NARROW_TILES");
+        return (e && !strcmp(e, "stream")) ? 1 : 2;
+    }();
+    if (BM == 64 && BN == 64 && (narrow_mode == 2 || (narrow_mode == 1 && stream))) {
+        if (g.N <= 32) BN = 32;
+        else if (g.M <= 32) BM = 32;
+    }
     if (const char* ov = getenv("PYMES_GEMM_TILE")) {   // tuning experiments only
         int bm = 0, bn = 0;
         if (sscanf(ov, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) { BM = bm; BN = bn; }
@@ -3231,7 +3248,7 @@ void gemm(const Gemm& g, stream_t s) {
     const long ktiles = (g.K + BK - 1) / BK;
     // Blocks that share a CU time-share its MFMA pipes, so what has to balance is the number of tiles per CU:
     // a launch costs about ceil(tiles / 256) tile-times (64x64 tiles need 4 co-resident blocks to fill a CU).
-    const long slots = (BM == 64 && BN == 64) ? 1024 : 256;
+    const long slots = (BM <= 64 && BN <= 64) ? 1024 : 256;
     const long ws_tiles = g.splitk_ws ? g.splitk_ws_doubles / ((long)BM * BN) : 0;
     long main_tiles = tiles, tail_tiles = 0;
     int main_split = 1, tail_split = 1;
@@ -3298,7 +3315,7 @@ void gemm(const Gemm& g, stream_t s) {
     }
     bool used_dma = false;
     int n_kernels = 0;
-    g_stream64 = stream && BM == 64 && BN == 64;
+    g_stream64 = stream && BM <= 64 && BN <= 64;
     auto launch = [&](long tile_begin, long ntiles, int nsplit) {
         const long kt_per = (ktiles + nsplit - 1) / nsplit;
         k.kchunk = (int)std::max<long>(kt_per * BK, BK);
@@ -3315,6 +3332,8 @@ void gemm(const Gemm& g, stream_t s) {
             ++n_kernels;
             if (BM == 128 && BN == 64) dispatch_layout<128, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
             else if (BM == 64 && BN == 128) dispatch_layout<64, 128>(k, a_kcontig, b_kcontig, vec, nblocks, st);
+            else if (BM == 64 && BN == 32) dispatch_layout<64, 32>(k, a_kcontig, b_kcontig, vec, nblocks, st);
+            else if (BM == 32 && BN == 64) dispatch_layout<32, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
             else dispatch_layout<64, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
         }
         if (k.nsplit > 1) {
