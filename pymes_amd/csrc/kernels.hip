@@ -2756,9 +2756,37 @@ void gemm_group_flush_dma() {
     hipStream_t st = q.st;
     long total = 0;
     for (int i = 0; i < q.nd; ++i) total += q.tiles_d[i];
-    // ~4 blocks per CU (two resident at a time: the kernel needs its second block per CU, see dev::gemm), every cut at least
-    // dma_min_k deep
-    const long want = std::max<long>(1, (1024 + total - 1) / total);
+    // How many ways every product is cut along K (each cut at least dma_min_k deep).  Two blocks are resident per CU, so the
+    // launch runs in rounds of 512 blocks; measured on the (20,80) ladders (156 tiles, K = 3240: 284 / 317 / 337 / 304 / 316 /
+    // 290 us for 3 ... 8 cuts) and on the slabs of one rank in eight, a cut s costs, in microseconds,
+    //     full rounds x (0.23 d + 8)  +  last round: the same when it holds more than 256 blocks, half of (0.153 d + 8) when
+    //     fewer (they start as slots free up and run alone)  +  0.04 per block for the partial tiles
+    // with d the depth of the deepest block.  (The old rule — ~1024 blocks — cut those ladders 7 ways: 1092 blocks, two rounds
+    // and 68 blocks of a third.)  A single cut is never chosen when a deeper one is possible: an uncut block applies beta in
+    // its own epilogue, element by element.
+    long want = std::max<long>(1, (1024 + total - 1) / total);
+    // Used where it was measured — fewer tiles than CUs; larger launches keep ~1024 blocks (at (30,120), 684 tiles, the model
+    // cut 3 ways instead of 2 and the CCSD iteration lost 5 %: its partial tiles no longer fit the 256-MB last-level cache).
+    if (total <= 256 && !getenv("PYMES_GROUP_SPLIT_OLD")) {
+        double best = 1e300;
+        for (long sp = 2; sp <= 16; ++sp) {
+            long blocks = 0;
+            double d = 0.0;
+            bool any_cut = false;
+            for (int i = 0; i < q.nd; ++i) {
+                const long si = std::min(sp, std::max<long>(1, q.ktiles_d[i] / (dma_min_k() / BK)));
+                any_cut = any_cut || si > 1;
+                blocks += q.tiles_d[i] * si;
+                d = std::max(d, (double)((q.ktiles_d[i] + si - 1) / si) * BK);
+            }
+            if (!any_cut) break;
+            const long full = blocks / 512, rem = blocks % 512;
+            const double round = 0.23 * d + 8.0;
+            const double cost = full * round + (rem == 0 ? 0.0 : rem <= 256 ? 0.5 * (0.153 * d + 8.0) : round) + 0.04 * (double)blocks;
+            if (cost < best - 1e-9) { best = cost; want = sp; }
+        }
+    }
+    if (const char* e = getenv("PYMES_GROUP_SPLIT")) want = std::max(1, atoi(e));      // experiments
     GroupK grp, red;
     grp.n = q.nd; grp.tile = 128; red.n = 0; red.tile = 128;
     long blocks = 0, ws_used = 0, red_blocks = 0;
