@@ -3313,7 +3313,10 @@ void gemm(const Gemm& g, stream_t s) {
     // runs at ~54 TF instead of 70+ (rocprofv3, round 4) — it needs its second block per CU to hide the barrier phases.  Model:
     // c = ceil(tiles s / 256) blocks per CU, time ~ (c / s) / (c >= 2 ? 1 : 0.75) tile-times; cutting EVERY tile s ways
     // (338 x 3 = 4 blocks per CU, two at a time) gives 1.33 where whole tiles + split tail give 1.33 + 0.44.
-    if (BM == 128 && BN == 128 && tiles >= 256 && tiles < 512 && ktiles >= 2 * dma_min_k() / BK && !getenv("PYMES_NO_FULL_SPLIT")) {
+    // Measured again at the end of round 4 on the whole (20,80) iteration: 1.720 ms with it, 1.698 without (three runs each, one
+    // box) — the 256 whole tiles + 3-way cut of the other 82 win by 11 us per pair (no partial tiles for three quarters of the
+    // output).  Off unless PYMES_FULL_SPLIT is set ("auto": the model below; a number: that cut).
+    if (BM == 128 && BN == 128 && tiles >= 256 && tiles < 512 && ktiles >= 2 * dma_min_k() / BK && getenv("PYMES_FULL_SPLIT")) {
         long best = 1;
         double best_cost = 1e30;
         const long smax = std::min<long>(std::min<long>(8, ktiles / (dma_min_k() / BK)), ws_tiles / tiles);
@@ -3325,6 +3328,7 @@ void gemm(const Gemm& g, stream_t s) {
         const long cm = (main_tiles + 255) / 256;
         const double cur = (double)cm / (cm >= 2 ? 1.0 : 0.75) +
                            (tail_tiles ? ((double)((tail_tiles * tail_split + 255) / 256) / tail_split) / 0.75 : 0.0);
+        if (atoi(getenv("PYMES_FULL_SPLIT")) > 0) { best = atoi(getenv("PYMES_FULL_SPLIT")); best_cost = 0.0; }
         if (best > 1 && best_cost < 0.95 * cur) {
             main_tiles = tiles; main_split = (int)best; tail_tiles = 0; tail_split = 1;
         }
