@@ -379,9 +379,21 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
         stats.gemm_calls++;
         stats.gemm_flops += 4.0 * double(ov) * double(ov) * double(ov);
     };
-    load_cols(paired ? 1.0 : 2.0, Viabj, "kbcj", M);                                          // M = 2 Wd  (paired: Wd)
-    load_cols(-1.0, Viajb, "kbjc", N1);                                                       // N1 = -UdT
-    axpby(paired ? 0.5 : 1.0, N1, 1.0, M);                                                   // M = 2 Wd - UdT  (paired: half of it)
+    auto dense = [](const TView& t) {
+        int64_t st = 1;
+        for (int i = t.rank - 1; i >= 0; --i) { if (t.st[i] != st) return false; st *= t.dim[i]; }
+        return true;
+    };
+    if (nc == ov && dense(Viabj) && dense(Viajb) && (size_t)no * 33 * sizeof(double) <= 64 * 1024 && !getenv("PYMES_NO_RING_OPERANDS")) {
+        // both operands in one pass over the two blocks (two permutations and an axpby before: 5 reads / 3 writes of (ov)^2)
+        dev::ring_operands(Viabj.p, Viajb.p, M.p, N1.p, paired ? 1.0 : 2.0, paired ? 0.5 : 1.0, no, nv, stream);
+        stats.permute_calls++;
+        stats.permute_bytes += 8.0 * 4.0 * double(ov) * double(ov);
+    } else {
+        load_cols(paired ? 1.0 : 2.0, Viabj, "kbcj", M);                                      // M = 2 Wd  (paired: Wd)
+        load_cols(-1.0, Viajb, "kbjc", N1);                                                   // N1 = -UdT
+        axpby(paired ? 0.5 : 1.0, N1, 1.0, M);                                               // M = 2 Wd - UdT  (paired: half of it)
+    }
     // The small V.T sums S_ac = sum_dkl Tt_adkl V_lkdc, S_ki = sum_cdl Tt_cdil V_lkdc (X_ac, X_ki, ccsd.py:434 / :436) are
     // partial traces of the builds: tr(Vd Tt_d) for DCSD, (3 tr(Vx Tx) + tr(Ld Tt_d)) / 4 for CCSD — read off the
     // accumulators before and after the products (all columns on this rank only)

@@ -227,6 +227,12 @@ void residual_assemble_pairs(const double* V, const double* L, const double* Np,
                              double* Rc, int no, int nv, int64_t r0, int64_t r1, int a0, int nbp, stream_t s, double xd = 0.0);
 // plain rows of the same [ S | A ] layout: out[r][i][j] = Q[r][P(i,j)] + sgn(i-j) Q[r][o(o+1)/2 + Q(i,j)]
 void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t s);
+// Right-hand operands of the ring builds in ONE pass over the two (dressed) blocks V_iabj [k][b][c][j] and V_iajb [k][b][j][c]
+// (ccd.py:190-191, :199-204 through the C / D form of cc.cpp): pair matrices on (c,k) = c*no + k, (b,j) = b*no + j,
+//   N1[(c,k)][(b,j)] = -V_iajb[k,b,j,c],   M[(c,k)][(b,j)] = a1 V_iabj[k,b,c,j] - a2 V_iajb[k,b,j,c]
+// — two permutations and an axpby before: 5 reads / 3 writes of (ov)^2 doubles instead of 2 / 2.  Blocks dense.
+void ring_operands(const double* Viabj, const double* Viajb, double* M, double* N1, double a1, double a2, int no, int nv,
+                   stream_t s);
 // partial traces of a pair matrix M[(c,k)][(b,j)] (row pitch ld; (c,k) = c*no + k):
 //   out_vv[a][c] = beta out_vv[a][c] + alpha sum_k M[(c,k)][(a,k)],   out_oo[k][i] = beta out_oo[k][i] + alpha sum_c M[(c,k)][(c,i)]
 void pair_traces(const double* M, int64_t ld, double alpha, double beta, double* out_vv, double* out_oo, int no, int nv,

@@ -669,6 +669,21 @@ void fock_finish(const double* f, const double* t1, const double* W, double* fd,
         }
 }
 
+void ring_operands(const double* Viabj, const double* Viajb, double* M, double* N1, double a1, double a2, int no, int nv,
+                   stream_t) {
+    const int64_t ov = (int64_t)no * nv;
+    for (int k = 0; k < no; ++k)
+        for (int b = 0; b < nv; ++b)
+            for (int c = 0; c < nv; ++c)
+                for (int j = 0; j < no; ++j) {
+                    const double w = Viabj[(((int64_t)k * nv + b) * nv + c) * no + j];
+                    const double u = Viajb[(((int64_t)k * nv + b) * no + j) * nv + c];
+                    const int64_t off = ((int64_t)c * no + k) * ov + (int64_t)b * no + j;
+                    N1[off] = -u;
+                    M[off] = a1 * w - a2 * u;
+                }
+}
+
 void pair_traces(const double* M, int64_t ld, double alpha, double beta, double* out_vv, double* out_oo, int no, int nv,
                  stream_t) {
     for (int a = 0; a < nv; ++a)
