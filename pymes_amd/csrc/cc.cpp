@@ -402,8 +402,7 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
         ensure_xs();
         xs_oo_tag_.clear();
         xs_vv_tag_.clear();
-        dev::pair_traces(M.p, nc, -cz, 0.0, xs_vv_, xs_oo_, no, nv, stream);
-        if (quad) dev::pair_traces(N1.p, nc, -cu, 1.0, xs_vv_, xs_oo_, no, nv, stream);
+        dev::pair_traces(M.p, nc, -cz, 0.0, xs_vv_, xs_oo_, no, nv, stream, quad ? N1.p : nullptr, -cu);
     }
     if (quad && paired) {
         pair_gemm(0.5, get_static("Ldh"), get_static("Vx"), Ttd.p, Tx.p, 1.0, M.p, N1.p);    // M_h += Ld Tt_d / 4, N1 += Vx Tx / 2
@@ -414,8 +413,7 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
         contract(paired ? 0.5 : 1.0, pairm(get_static("Vd")), "xy", cols(Ttd), "yn", 1.0, M, "xn");   // M = 2 Wd - UdT + Vd Tt_d
     }
     if (traces) {
-        dev::pair_traces(M.p, nc, cz, 1.0, xs_vv_, xs_oo_, no, nv, stream);
-        if (quad) dev::pair_traces(N1.p, nc, cu, 1.0, xs_vv_, xs_oo_, no, nv, stream);
+        dev::pair_traces(M.p, nc, cz, 1.0, xs_vv_, xs_oo_, no, nv, stream, quad ? N1.p : nullptr, cu);
         xs_oo_tag_.set(t2, 0, 1);
         xs_vv_tag_.set(t2, 0, 1);
     }

@@ -235,8 +235,9 @@ void ring_operands(const double* Viabj, const double* Viajb, double* M, double* 
                    stream_t s);
 // partial traces of a pair matrix M[(c,k)][(b,j)] (row pitch ld; (c,k) = c*no + k):
 //   out_vv[a][c] = beta out_vv[a][c] + alpha sum_k M[(c,k)][(a,k)],   out_oo[k][i] = beta out_oo[k][i] + alpha sum_c M[(c,k)][(c,i)]
+// With M2 (same shape and pitch): + alpha2 x the same traces of M2, in the same pass.
 void pair_traces(const double* M, int64_t ld, double alpha, double beta, double* out_vv, double* out_oo, int no, int nv,
-                 stream_t s);
+                 stream_t s, const double* M2 = nullptr, double alpha2 = 0.0);
 
 // ---- Hartree-Fock matrix from the packed blocks (pymes/mean_field/hf.py:14-18); dir[tp*2+tq] = block (tp,o,tq,o),
 // exc[tp*2+tq] = block (tp,o,o,tq), tp/tq = 1 for a virtual index; h and f are [n,n] on the device

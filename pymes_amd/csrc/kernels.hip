@@ -2269,20 +2269,27 @@ __global__ void fock_finish_kernel(const double* __restrict__ f, const double* _
 // each — a wave takes four a (their loads in flight together), its lanes the k of sum_k M[(c,k)][(a,k)] (one element per
 // 128-byte line: 1/3 of the lines of M in all), summed by a shuffle tree.  The no blocks behind them: one k each — lanes
 // over i, the four waves over c = w, w+4, ..., added up in wave order through LDS.  Fixed summation orders: deterministic.
+// A second matrix M2 (same shape and pitch) adds alpha2 x its traces in the same pass (the two builds of the ring terms).
 __global__ void __launch_bounds__(256) pair_traces_kernel(const double* __restrict__ M, long ld, double alpha, double beta,
                                                           double* __restrict__ out_vv, double* __restrict__ out_oo,
-                                                          int no, int nv) {
+                                                          int no, int nv, const double* __restrict__ M2, double alpha2) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int agroups = (nv + 15) / 16, nvv = nv * agroups;
     if ((int)blockIdx.x < nvv) {
         const int c = blockIdx.x / agroups, a0 = (blockIdx.x - c * agroups) * 16 + wave;
         const double* __restrict__ base = M + (long)c * no * ld;
+        const double* __restrict__ base2 = M2 ? M2 + (long)c * no * ld : nullptr;
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int a = a0 + 4 * u;
             if (a < nv)
-                for (int k = lane; k < no; k += 64) acc[u] += base[(long)k * ld + (long)a * no + k];
+                for (int k = lane; k < no; k += 64) {
+                    const long e = (long)k * ld + (long)a * no + k;
+                    double v = alpha * base[e];
+                    if (base2) v += alpha2 * base2[e];
+                    acc[u] += v;
+                }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -2291,7 +2298,7 @@ __global__ void __launch_bounds__(256) pair_traces_kernel(const double* __restri
             const int a = a0 + 4 * u;
             if (lane == 0 && a < nv) {
                 double* o = out_vv + (long)a * nv + c;
-                *o = (beta == 0.0 ? 0.0 : beta * *o) + alpha * acc[u];
+                *o = (beta == 0.0 ? 0.0 : beta * *o) + acc[u];
             }
         }
         return;
@@ -2303,14 +2310,19 @@ __global__ void __launch_bounds__(256) pair_traces_kernel(const double* __restri
         double acc = 0.0;
         if (i < no) {
 #pragma unroll 4
-            for (int c = wave; c < nv; c += 4) acc += M[((long)c * no + k) * ld + (long)c * no + i];
+            for (int c = wave; c < nv; c += 4) {
+                const long e = ((long)c * no + k) * ld + (long)c * no + i;
+                double v = alpha * M[e];
+                if (M2) v += alpha2 * M2[e];
+                acc += v;
+            }
         }
         part[wave][lane] = acc;
         __syncthreads();
         if (wave == 0 && i < no) {
             const double sum = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
             double* o = out_oo + (long)k * no + i;
-            *o = (beta == 0.0 ? 0.0 : beta * *o) + alpha * sum;
+            *o = (beta == 0.0 ? 0.0 : beta * *o) + sum;
         }
         __syncthreads();
     }
@@ -4054,11 +4066,11 @@ void fock_finish(const double* f, const double* t1, const double* W, double* fd,
 }
 
 void pair_traces(const double* M, int64_t ld, double alpha, double beta, double* out_vv, double* out_oo, int no, int nv,
-                 stream_t s) {
+                 stream_t s, const double* M2, double alpha2) {
     if (no <= 0 || nv <= 0) return;
     const unsigned blocks = (unsigned)nv * (unsigned)((nv + 15) / 16) + (unsigned)no;
     hipLaunchKernelGGL(pair_traces_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, M, (long)ld, alpha, beta, out_vv, out_oo,
-                       no, nv);
+                       no, nv, M2, alpha2);
     HIP_CHECK(hipGetLastError());
 }
 

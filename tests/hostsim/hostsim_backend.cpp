@@ -685,20 +685,21 @@ void ring_operands(const double* Viabj, const double* Viajb, double* M, double* 
 }
 
 void pair_traces(const double* M, int64_t ld, double alpha, double beta, double* out_vv, double* out_oo, int no, int nv,
-                 stream_t) {
+                 stream_t, const double* M2, double alpha2) {
+    auto at = [&](int64_t e) { return alpha * M[e] + (M2 ? alpha2 * M2[e] : 0.0); };
     for (int a = 0; a < nv; ++a)
         for (int c = 0; c < nv; ++c) {
             double acc = 0.0;
-            for (int k = 0; k < no; ++k) acc += M[((int64_t)c * no + k) * ld + (int64_t)a * no + k];
+            for (int k = 0; k < no; ++k) acc += at(((int64_t)c * no + k) * ld + (int64_t)a * no + k);
             double& o = out_vv[(int64_t)a * nv + c];
-            o = (beta == 0.0 ? 0.0 : beta * o) + alpha * acc;
+            o = (beta == 0.0 ? 0.0 : beta * o) + acc;
         }
     for (int k = 0; k < no; ++k)
         for (int i = 0; i < no; ++i) {
             double acc = 0.0;
-            for (int c = 0; c < nv; ++c) acc += M[((int64_t)c * no + k) * ld + (int64_t)c * no + i];
+            for (int c = 0; c < nv; ++c) acc += at(((int64_t)c * no + k) * ld + (int64_t)c * no + i);
             double& o = out_oo[(int64_t)k * no + i];
-            o = (beta == 0.0 ? 0.0 : beta * o) + alpha * acc;
+            o = (beta == 0.0 ? 0.0 : beta * o) + acc;
         }
 }
 
