@@ -162,6 +162,13 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         return launch_ranks(args.gpus, sys.argv[1:], timeout_s=args.run_timeout_s)   # no launcher around us: be the launcher
 
+    # Native libraries print to the process's stdout on their own (RCCL: a five-line version banner at communicator set-up;
+    # gloo logs there too): file descriptor 1 goes to stderr for the whole run and the ONE JSON line is written to the saved
+    # descriptor at the end, so that stdout of rank 0 holds exactly that line whoever launched the ranks.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -387,7 +394,9 @@ def main():
                 "blas_value": cpu["blas"]["seconds_per_doubles_residual"] * to_iter, "blas_cores": cpu["cores"]["blas"],
                 "blas_all_cores": {"value": cpu["blas"]["seconds_per_doubles_residual"] * to_iter, "unit": "s",
                                    "cores": cpu["cores"]["blas"]}}
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    os.close(json_fd)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
