@@ -372,6 +372,10 @@ int pymes_diis_mix(pymes_ctx* ctx, double* state_host, int ntypes, int m, int wa
                    double* const* out_dev);
 int pymes_diis_step(pymes_ctx* ctx, double* state_dev, int npairs, const double* const* x_dev, const double* const* y_dev,
                     const int64_t* n, int ntypes, int m, int was_full);
+/* Only the small algebra of that step (diis.py:56-103), on the calling host thread and on host arrays: overlaps_host[t * m + i]
+ * = <e_i, e_new> of amplitude type t, already complete (one process per GPU: summed over the ranks by the caller).  L and
+ * the coefficients in state_host as above; state_host[91] = 2 when L is singular or not finite.  No context, no device. */
+int pymes_diis_solve(double* state_host, const double* overlaps_host, int ntypes, int m, int was_full);
 int pymes_lincomb_dev(pymes_ctx* ctx, double* out_dev, int nx, const double* const* x_dev, const double* coeff_dev,
                       int64_t n);
 /* (yr + i yi)[e] = (mr + i mi)[e] (xr + i xi)[e], e < n: a complex diagonal applied to a complex vector held as two real

@@ -132,6 +132,7 @@ SIGNATURES = {
     "pymes_lincomb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_pp, c_double_p, C.c_int64]),
     "pymes_cmul": (C.c_int, [C.c_void_p] * 7 + [C.c_int64]),
     "pymes_diis_mix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, c_pp, c_pp, c_i64_p, c_pp, c_pp]),
+    "pymes_diis_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "pymes_diis_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_pp, c_pp, c_i64_p, C.c_int, C.c_int, C.c_int]),
     "pymes_gemm_group_begin": (C.c_int, [C.c_void_p]),
     "pymes_gemm_group_end": (C.c_int, [C.c_void_p, c_i64_p, c_i64_p]),

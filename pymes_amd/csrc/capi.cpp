@@ -677,6 +677,13 @@ int pymes_diis_step(pymes_ctx* ctx, double* state, int npairs, const double* con
         dev::diis_step(state, npairs, x, y, n, ntypes, m, was_full, E(ctx).stream);
     });
 }
+int pymes_diis_solve(double* state_host, const double* overlaps_host, int ntypes, int m, int was_full) {
+    return guarded([&] {
+        need(state_host, "state"); need(overlaps_host, "overlaps");
+        if (ntypes < 1 || m < 1 || m > 8) throw pymes::Error("diis_solve: need ntypes >= 1, 1 <= m <= 8");
+        diis_small::step(state_host, overlaps_host, ntypes, m, was_full);
+    });
+}
 int pymes_diis_mix(pymes_ctx* ctx, double* state_host, int ntypes, int m, int was_full, const double* const* err_hist,
                    const double* const* err_new, const int64_t* sizes, const double* const* amp_hist, double* const* out) {
     return guarded([&] {

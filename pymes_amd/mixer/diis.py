@@ -6,8 +6,11 @@ full-subspace quirk is reproduced on purpose: once ``dim_space``
 are stored, the shifted copy of the old L (diis.py:59-60) omits the row/column of the
 second-newest vector, which therefore become zeros — iteration histories depend on it.
 """
+import os
+
 import numpy as np
 
+from pymes_amd import _lib
 from pymes_amd.log import print_logging_info
 
 _blas_threads = None
@@ -236,8 +239,27 @@ class DIIS:
             overlaps += allreduce(part) if nt in sharded else part
         if mark is not None:
             mark("DIIS overlaps (reduction + host sync)")
-        self._update_L(overlaps, was_full)
-        c = self._solve()
+        dependent = False
+        if m <= 8 and not os.environ.get("PYMES_NUMPY_DIIS"):
+            # the small algebra in C on this thread (pymes_diis_solve: the code of pymes_diis_mix without its device part) —
+            # numpy.linalg under a one-thread BLAS limit took 0.4 ms here, mostly the limit itself (threadpoolctl)
+            buf = np.zeros(96)
+            n0 = self.L.shape[0]
+            buf[0] = n0
+            pad = np.zeros((9, 9))
+            pad[:n0, :n0] = self.L
+            buf[1:82] = pad.ravel()
+            ctx.lib.call("pymes_diis_solve", _lib.host_ptr(buf), _lib.host_ptr(np.ascontiguousarray(overlaps, dtype=np.float64)),
+                         1, int(m), int(bool(was_full)))
+            if buf[91] == 2.0:
+                raise np.linalg.LinAlgError("DIIS: the subspace matrix is singular or not finite")
+            n1 = int(buf[0])
+            self.L = buf[1:82].reshape(9, 9)[:n1, :n1].copy()
+            c = buf[82:82 + n1].copy()
+            dependent = bool(buf[91] == 1.0)
+        else:
+            self._update_L(overlaps, was_full)
+            c = self._solve()
         self.last_coefficients = c
         if mark is not None:
             mark("DIIS host solve")
@@ -248,8 +270,10 @@ class DIIS:
             res.append(dst)
         out = res
         if defer_log:           # the caller prints these lines (log_last) once its next kernels are on their way
-            self._log_pending, self.last_dependent = True, False
+            self._log_pending, self.last_dependent = True, dependent
         else:
+            if dependent:
+                print_logging_info("Linear dependence found in DIIS subspace.", level=2)
             self._log(c)
         return out
 

@@ -577,3 +577,40 @@ def test_dressed_fock_from_its_six_blocks(hostsim_lib):
     from tests.test_gpu_kernels import check_dressed_fock_from_blocks
     for i, (no, nv) in enumerate(((3, 7), (2, 9), (1, 4))):
         check_dressed_fock_from_blocks(hostsim_lib, no, nv, i)
+
+
+def test_host_diis_solve_matches_numpy(sim):
+    """pymes_diis_solve (the small algebra of a DIIS step in C on host arrays — what the one-process-per-GPU path calls after
+    it has summed the overlaps over the ranks) against the mixer's numpy.linalg route (diis.py:56-103): subspace growing to
+    its full size, the full-subspace quirk, overlaps shrinking into the pseudo-inverse branch."""
+    import ctypes as C
+    from pymes_amd import _lib
+    from pymes_amd.mixer.diis import DIIS
+    rng = np.random.default_rng(17)
+    ref = DIIS(dim_space=6)
+    state = np.zeros(96)
+    state[0] = 1.0
+    scale = 1.0
+    for it in range(14):
+        was_full = it >= 6
+        m = min(it + 1, 6)
+        vecs = rng.standard_normal((m, 40)) * scale
+        overlaps = vecs @ vecs[-1]                      # <e_i, e_new>, the newest vector last
+        if was_full:                                     # the mixer drops the oldest vector before it extends L
+            pass
+        ref._update_L(overlaps, was_full)
+        c_ref = ref._solve_on_this_thread()
+        sim.call("pymes_diis_solve", _lib.host_ptr(state), _lib.host_ptr(np.ascontiguousarray(overlaps)), 1, m, int(was_full))
+        n = int(state[0])
+        assert n == m + 1
+        assert np.abs(state[1:82].reshape(9, 9)[:n, :n] - ref.L).max() == 0.0
+        c = state[82:82 + n]
+        assert np.abs(c - c_ref).max() <= 1e-9 * max(1.0, np.abs(c_ref).max()), (it, c, c_ref)
+        assert state[91] == (1.0 if np.any(np.abs(np.linalg.eigvalsh(ref.L)) < 1e-12) else 0.0)
+        scale *= 0.1                                     # overlaps fall below 1e-12: the pseudo-inverse branch is taken
+    # two types: the overlaps are summed over the types in the reference's order
+    st2 = np.zeros(96); st2[0] = 1.0
+    sim.call("pymes_diis_solve", _lib.host_ptr(st2), _lib.host_ptr(np.array([0.3, 0.2])), 2, 1, 0)
+    assert st2[1] == 0.5 and abs(st2[82] - 1.0) < 1e-15
+    with pytest.raises(Exception):
+        sim.call("pymes_diis_solve", _lib.host_ptr(st2), _lib.host_ptr(np.array([0.3])), 1, 9, 0)
