@@ -125,6 +125,173 @@ def launch_ranks(n, argv, script=None, timeout_s=1500.0):
         raise SystemExit(f"rank exit codes {codes}")
 
 
+
+# ---- the other BASELINE configs, driver-timed -------------------------------------------------------------
+# Golden values are LITERALS recorded from the reference's own runs (tests/golden/*.json / *.npz, written by oracle/make_golden*.py
+# in the build container) — data, not the oracle; nothing under oracle/ is imported here.
+C2_GOLDEN = {"e": -0.40137558021086484, "iterations": 9, "delta_e": 1e-10}            # tests/golden/solves.json["syn_20_80"]["ccsd"]
+C4_GOLDEN = {"dcsd": -0.4181690961120107, "passes": 22, "k_cutoff": 1.436091003782944}   # tests/golden/ueg.json["tc_N14_rs1.0_c5"]
+# (30,120) Davidson: no reference run exists at this size (the reference would take days); the literals are THIS engine's values
+# of round 4 (profiles/r04/configs_c2_c4_c5.jsonl) — a regression check; the driver is reference-pinned at (12,48) and (20,80)
+C5_DAVIDSON = {"ccsd_e": -0.32983974045195175, "ee": [3.0060256332720243, 3.409850418963405, 3.8568464914371234], "passes": 26}
+
+
+def _quiet(fn, *a, **k):
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def _timed(fn, sync, reps, warm=3):
+    for _ in range(warm):       # lazy statics and launch-graph recording
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / reps
+
+
+def other_configs(device=0):
+    """BASELINE configs 2, 4 and 5 behind the headline: per config an iteration / sigma time under this process's clock and a
+    result checked against the reference's recorded value.  Returns the `other_configs` object of the JSON line."""
+    import gc
+    from pymes_amd.integral.device import DeviceIntegrals
+    from pymes_amd.model import synthetic
+    from pymes_amd.solver.ccsd import CCSD
+    out, t_all = {}, time.perf_counter()
+    gc.collect()
+    gc.disable()
+    try:
+        # ---- C2: (20,80) CCSD, the reference's own 9-iteration solve, then the iteration time -------------------------------
+        no, nv = 20, 80
+        B, eps = synthetic.factors(no, nv, seed=0, scale=0.15)
+        t0 = time.perf_counter()
+        ints = DeviceIntegrals.from_factors(no, B, device=device)
+        s2 = CCSD(no, delta_e=C2_GOLDEN["delta_e"], device=device)
+        res = _quiet(s2.solve, np.diag(eps), ints)
+        out["c2_solve_s"] = time.perf_counter() - t0
+        out["c2_energy_minus_reference"] = res["ccsd e"] - C2_GOLDEN["e"]
+        out["c2_ok"] = bool(abs(res["ccsd e"] - C2_GOLDEN["e"]) < 1e-9 and s2.iterations == C2_GOLDEN["iterations"])
+        solver = CCSD(no, device=device)
+        st = _quiet(solver.setup, np.diag(eps), ints)
+        for _ in range(4):
+            _quiet(solver.iterate, st)
+        ints.ctx.sync()
+        ints.ctx.stats(reset=True)
+        dt = _timed(lambda: _quiet(solver.iterate, st), ints.ctx.sync, 20, warm=0)
+        fl = ints.ctx.stats()["gemm_flops"] / 20
+        out["c2_ms"] = 1e3 * dt
+        out["c2_frac"] = fl / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS       # executed GEMM flops over the whole iteration
+        out["c2_executed_gemm_flops"] = fl
+        ints.ctx.close()
+        # ---- C4: UEG N = 14, rs = 1, 57 plane waves, transcorrelated DCSD (test_symmetrised_2body_integral.py:39-222) -------
+        from pymes_amd.mean_field import hf
+        from pymes_amd.model.ueg import UEG
+        nel = 14
+        t0 = time.perf_counter()
+        m = UEG(nel, nel // 2, nel // 2, 1.0)
+        m.init_single_basis(5)
+        m.k_cutoff = C4_GOLDEN["k_cutoff"]
+        no, n_p = nel // 2, len(m.basis_fns) // 2
+        kin = np.array([m.basis_fns[2 * i].kinetic for i in range(n_p)])
+        V = _quiet(m.eval_2b_integrals, correlator=m.trunc, is_only_2b=True, sp=0)
+        f = hf.construct_hf_matrix(no, np.diag(kin), V)
+        Va = _quiet(m.eval_2b_integrals, correlator=m.trunc, is_effect_2b=True, sp=0)
+        V = V + 0.5 * (Va + Va.transpose(1, 0, 3, 2))
+        f = f + np.diag(_quiet(m.double_contractions_in_3_body))
+        out["c4_integrals_s"] = time.perf_counter() - t0
+        ints = DeviceIntegrals.from_V_pqrs(no, V, device=device)
+        s4 = CCSD(no, delta_e=1e-10, is_dcsd=True, device=device)
+        r4 = _quiet(s4.solve, f, ints)
+        out["c4_energy_minus_reference"] = r4["ccsd e"] - C4_GOLDEN["dcsd"]
+        out["c4_ok"] = bool(abs(r4["ccsd e"] - C4_GOLDEN["dcsd"]) < 1e-9 and s4.iterations == C4_GOLDEN["passes"])
+        solver = CCSD(no, is_dcsd=True, device=device)
+        st = _quiet(solver.setup, f, ints)
+        out["c4_ms"] = 1e3 * _timed(lambda: _quiet(solver.iterate, st), ints.ctx.sync, 20, warm=4)
+        ints.ctx.close()
+        # ---- C5: (30,120) EOM-CCSD sigma (the inputs of tests/golden/eom_sigma_30_120.npz, i.e. the reference's own
+        # update_singles / update_doubles output), single and k = 4 stacked; then one Davidson solve ----------------------------
+        from pymes_amd.solver.eom_ccsd import EOM_CCSD, _Sigma
+        no, nv = 30, 120
+        g = np.load(os.path.join(ROOT, "tests", "golden", "eom_sigma_30_120.npz"))
+        B, eps = synthetic.factors(no, nv, seed=0, scale=float(g["scale"]))
+        rng = np.random.default_rng(int(g["seed"]))
+        n = no + nv
+        fd = np.diag(eps) + 0.02 * rng.standard_normal((n, n))
+        t2h = rng.standard_normal((nv, nv, no, no)) * 0.02
+        t2h = 0.5 * (t2h + t2h.transpose(1, 0, 3, 2))
+        u1h = rng.standard_normal((nv, no)) * 0.3
+        u2h = rng.standard_normal((nv, nv, no, no)) * 0.05
+        u2h = 0.5 * (u2h + u2h.transpose(1, 0, 3, 2))
+        ints = DeviceIntegrals.from_factors(no, B, device=device)
+        ctx = ints.ctx
+        sig = _Sigma(ctx, fd, ctx.array(t2h))
+        u1, u2 = ctx.array(u1h), ctx.array(u2h)
+        s1, s2d = sig.apply(u1, u2, u2_sym=True)
+        s1h, s2h = s1.get(), s2d.get()
+        sc1, sc2 = np.abs(g["sigma1"]).max(), np.abs(g["sigma2_val"]).max()
+        err = max(np.abs(s1h - g["sigma1"]).max() / sc1, np.abs(s2h[7:8] - g["sigma2_slab"]).max() / sc2,
+                  np.abs(s2h.reshape(-1)[g["sigma2_idx"]] - g["sigma2_val"]).max() / sc2)
+        sums = np.array([s2h.sum(), np.abs(s2h).sum(), np.linalg.norm(s2h)])
+        out["c5_sigma_rel_err_vs_reference"] = float(err)
+        out["c5_ok"] = bool(err < 1e-10 and np.abs(sums - g["sigma2_sums"]).max() < 1e-9 * g["sigma2_sums"][1])
+        del s1h, s2h, s1, s2d
+        ctx.stats(reset=True)
+        dt = _timed(lambda: sig.apply(u1, u2, u2_sym=True), ctx.sync, 5, warm=0)
+        fl = ctx.stats()["gemm_flops"] / 5
+        out["c5_sigma_ms"] = 1e3 * dt
+        out["c5_frac"] = fl / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS
+        kvec = 4
+        u1s = [u1] + [ctx.array(rng.standard_normal((nv, no))) for _ in range(kvec - 1)]
+        u2s = [u2]
+        for _ in range(kvec - 1):
+            h = rng.standard_normal((nv, nv, no, no))
+            u2s.append(ctx.array(h + h.transpose(1, 0, 3, 2)))
+        ctx.stats(reset=True)
+        dtk = _timed(lambda: sig.apply_many(u1s, u2s, [True] * kvec), ctx.sync, 5, warm=2)
+        flk = ctx.stats()["gemm_flops"] / 7
+        out["c5_sigma_k4_ms_per_vector"] = 1e3 * dtk / kvec
+        out["c5_k4_frac"] = flk / dtk / 1e12 / FP64_MFMA_PEAK_TFLOPS
+        del sig, u1s, u2s, u1, u2
+        ctx.close()
+        # Davidson: CCSD -> T1 dressing -> EOM, device-resident; orbital energies with isolated frontier levels (on the dense
+        # spectrum of the SURVEY 8(d) recipe the reference's driver stalls, DESIGN 2)
+        B, _ = synthetic.factors(no, nv, seed=0, scale=0.12)
+        rng = np.random.default_rng(5)
+        eps = np.concatenate([np.sort(np.concatenate([[-1.5], -2.7 - 0.8 * rng.random(no - 1)])),
+                              np.sort(np.concatenate([[1.5, 1.9, 2.35], 3.2 + 1.0 * rng.random(nv - 3)]))])
+        f = np.diag(eps)
+        ints = DeviceIntegrals.from_factors(no, B, device=device)
+        ctx = ints.ctx
+        cc = CCSD(no, delta_e=1e-10, device=device)
+        res = _quiet(cc.solve, f, ints, device_amplitudes=True)
+        fdd = cc.get_T1_dressed_fock(f, res["t1"], ints)
+        Vd = cc.get_T1_dressed_V(res["t1"], ints)
+        eom = EOM_CCSD(no, n_excit=3, device=device)
+        eom.max_iter = 3
+        _quiet(eom.solve, fdd, Vd, res["t2"])                      # warm-up: lazy statics, cached transposed blocks
+        eom = EOM_CCSD(no, n_excit=3, device=device)
+        eom.max_iter = 60
+        ctx.sync()
+        t0 = time.perf_counter()
+        ee = _quiet(eom.solve, fdd, Vd, res["t2"])
+        ctx.sync()
+        out["c5_davidson_s"] = time.perf_counter() - t0
+        out["c5_davidson_passes"] = eom.iterations
+        out["c5_davidson_ok"] = bool(abs(res["ccsd e"] - C5_DAVIDSON["ccsd_e"]) < 1e-9 and
+                                     np.abs(np.asarray(ee) - np.asarray(C5_DAVIDSON["ee"])).max() < 1e-7 and
+                                     eom.iterations == C5_DAVIDSON["passes"])
+        out["c5_davidson_golden"] = "this engine's round-4 values (no reference run at this size)"
+        ctx.close()
+    finally:
+        gc.enable()
+    out["wall_s"] = time.perf_counter() - t_all
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,6 +318,8 @@ def main():
     ap.add_argument("--stub-collectives", action="store_true",
                     help="ONE GPU: run rank --as-rank of a world of --of ranks with every collective a no-op — that rank's "
                          "compute time (timings valid, energies not); the compute-only leg of the 1/2/4/8 curve")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the C2 / C4 / C5 legs that follow the headline measurement on a single GPU (~10 s)")
     ap.add_argument("--as-rank", type=int, default=0)
     ap.add_argument("--of", type=int, default=8)
     args = ap.parse_args()
@@ -394,6 +563,14 @@ def main():
                 "blas_value": cpu["blas"]["seconds_per_doubles_residual"] * to_iter, "blas_cores": cpu["cores"]["blas"],
                 "blas_all_cores": {"value": cpu["blas"]["seconds_per_doubles_residual"] * to_iter, "unit": "s",
                                    "cores": cpu["cores"]["blas"]}}
+        if (world == 1 and not sharded_run and not args.no_other_configs and (no, nv) == (50, 200) and not args.dcsd):
+            # BASELINE configs 2, 4, 5 under the same clock, AFTER the headline region: the (50,200) context goes first
+            del st, solver
+            ctx.close()
+            try:
+                line["other_configs"] = other_configs(device=local)
+            except Exception as exc:          # the headline line must survive a failure of a side leg
+                line["other_configs"] = {"error": f"{type(exc).__name__}: {exc}"}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     os.close(json_fd)

@@ -11,6 +11,7 @@ Davidson passes, the Ritz values of every pass — to tests/golden/eom_davidson.
 
   small  (nocc, nvirt) = (4, 12),  s = 0.3   (host-logic test through the host simulator, CPU)
   big    (nocc, nvirt) = (12, 48), s = 0.19  (GPU test: LDS-DMA GEMMs, batched pair-packed ladders, multi-vector sigma)
+  mid    (nocc, nvirt) = (20, 80), s = 0.15  (round 5: config 2's size, the nearest to config 5 an hour of CPU reaches)
 
 ``--oracle`` pins oracle/eom_oracle.py::eom_solve on the same inputs (energies 1e-9, pass count equal).
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
@@ -36,7 +37,7 @@ from pymes.solver import ccsd as ref_ccsd, eom_ccsd as ref_eom               # n
 from pymes.integral.partition import part_2_body_int                          # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
-CASES = {"small": (4, 12, 0.3, 3), "big": (12, 48, 0.19, 3)}
+CASES = {"small": (4, 12, 0.3, 3), "big": (12, 48, 0.19, 3), "mid": (20, 80, 0.15, 3)}
 
 
 def quiet(fn, *a, **k):

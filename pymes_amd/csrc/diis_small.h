@@ -143,7 +143,9 @@ PYMES_HD inline void finish(double* S, const double* L, const double* V, const d
         if (!solve_lu(n, A, unit, c)) failed = true;
     }
     for (int i = 0; i < n; ++i) failed = failed || !(c[i] == c[i]) || c[i] > 1.7976931348623157e308 || c[i] < -1.7976931348623157e308;
-    for (int i = 0; i < 9; ++i) S[82 + i] = i < n ? c[i] : 0.0;
+    // no finite solution: the coefficients select the newest amplitudes unchanged, so that an extrapolation that is already
+    // enqueued behind this step (the device-resident form) leaves finite numbers; the host raises when it reads S[91]
+    for (int i = 0; i < 9; ++i) S[82 + i] = failed ? (i == n - 2 ? 1.0 : 0.0) : (i < n ? c[i] : 0.0);
     // S[91]: 0 inverse branch, 1 pseudo-inverse branch, 2 no finite solution (a singular or non-finite L: the reference's
     // numpy.linalg.inv / eigh raise LinAlgError, diis.py:85-95) — the callers refuse to extrapolate with such coefficients
     S[91] = failed ? 2.0 : (dependent ? 1.0 : 0.0);

@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -2615,26 +2616,45 @@ constexpr int kReadSlots = 16, kReadDoubles = 128;
 double* g_read_host[kMaxDevices] = {nullptr};
 hipEvent_t g_read_ev[kMaxDevices][kReadSlots];
 int g_read_next[kMaxDevices] = {0};
+// what a caller holds is a TICKET = slot | generation << 8: a slot that has been handed out again since (16 later starts on
+// the device, whoever made them) or was never started is refused instead of returning somebody else's numbers.  The ring is
+// shared by every context and thread of the process on that device, hence the lock.
+unsigned g_read_gen[kMaxDevices][kReadSlots] = {{0}};
+std::mutex g_read_mu;
 int readback_start_impl(const double* dev_ptr, int n, hipStream_t st) {
     if (n < 1 || n > kReadDoubles) throw std::runtime_error("readback: 1..128 doubles");
     int dv = 0;
     HIP_CHECK(hipGetDevice(&dv));
     if (dv < 0 || dv >= kMaxDevices) throw std::runtime_error("device ordinal out of range");
+    std::lock_guard<std::mutex> lock(g_read_mu);
     if (!g_read_host[dv]) {
         HIP_CHECK(hipHostMalloc((void**)&g_read_host[dv], sizeof(double) * kReadSlots * kReadDoubles));
         for (int i = 0; i < kReadSlots; ++i) HIP_CHECK(hipEventCreateWithFlags(&g_read_ev[dv][i], hipEventDisableTiming));
     }
     const int slot = g_read_next[dv];
     g_read_next[dv] = (slot + 1) % kReadSlots;
+    const unsigned gen = (g_read_gen[dv][slot] = (g_read_gen[dv][slot] + 1) & 0x3fffffu);
     HIP_CHECK(hipMemcpyAsync(g_read_host[dv] + slot * kReadDoubles, dev_ptr, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipEventRecord(g_read_ev[dv][slot], st));
-    return slot;
+    return (int)((gen << 8) | (unsigned)slot);
 }
-void readback_wait_impl(int slot, double* out, int n) {
+void readback_wait_impl(int ticket, double* out, int n) {
     int dv = 0;
     HIP_CHECK(hipGetDevice(&dv));
-    if (slot < 0 || slot >= kReadSlots || !g_read_host[dv] || n < 1 || n > kReadDoubles) throw std::runtime_error("readback: bad slot");
-    HIP_CHECK(hipEventSynchronize(g_read_ev[dv][slot]));
+    const int slot = ticket & 0xff;
+    const unsigned gen = (unsigned)ticket >> 8;
+    if (ticket < 0 || slot >= kReadSlots || dv < 0 || dv >= kMaxDevices || n < 1 || n > kReadDoubles)
+        throw std::runtime_error("readback: bad ticket");
+    hipEvent_t ev;
+    {
+        std::lock_guard<std::mutex> lock(g_read_mu);
+        if (!g_read_host[dv] || gen == 0 || g_read_gen[dv][slot] != gen)
+            throw std::runtime_error("readback: the slot was never started or has been reused since (16 later read-backs)");
+        ev = g_read_ev[dv][slot];
+    }
+    HIP_CHECK(hipEventSynchronize(ev));
+    std::lock_guard<std::mutex> lock(g_read_mu);
+    if (g_read_gen[dv][slot] != gen) throw std::runtime_error("readback: the slot was reused while it was awaited");
     for (int i = 0; i < n; ++i) out[i] = g_read_host[dv][slot * kReadDoubles + i];
 }
 
@@ -2776,7 +2796,10 @@ void gemv_batch_flush() {
 
 // ---- dev::gemm_group_begin / _end: small products issued in between are queued and launched together ----------------
 struct GemmGroup {
+    static constexpr int kMaxDepth = 8;
     bool active = false;
+    int depth = 0;
+    hipStream_t outer[kMaxDepth] = {nullptr};
     hipStream_t st = nullptr;
     int n = 0;
     GemmK k[kGroupMax];
@@ -2978,7 +3001,15 @@ namespace dev {
 
 const char* backend_name() { return "hip-gfx950"; }
 
-void set_device(int ordinal) { HIP_CHECK(hipSetDevice(ordinal)); }
+void set_device(int ordinal) {
+    int cur = -1;
+    HIP_CHECK(hipGetDevice(&cur));
+    if (cur != ordinal) {      // launches queued for the device that is being left (an open group / batch of this thread) go first
+        gemv_batch_flush();
+        gemm_group_flush();
+    }
+    HIP_CHECK(hipSetDevice(ordinal));
+}
 
 void* dmalloc(size_t bytes) {
     void* p = nullptr;
@@ -3207,15 +3238,29 @@ bool gemm_group_take(const Gemm& g, bool a_kcontig, bool b_kcontig, int64_t a_sm
 }
 }  // namespace
 
+// begin / end nest (an engine-internal scope inside a caller's): the group stays open until the outermost end; an inner
+// begin on another stream flushes what is queued and queues on its own stream until its end, then the outer stream is back
 void gemm_group_begin(stream_t s) {
     gemm_group_flush();
-    g_group.active = true;
-    g_group.st = (hipStream_t)s;
-    g_group.launches = g_group.products = 0;
+    GemmGroup& q = g_group;
+    if (q.depth >= GemmGroup::kMaxDepth) throw std::runtime_error("gemm_group_begin: nested too deeply");
+    q.outer[q.depth++] = q.st;
+    if (q.depth == 1) q.launches = q.products = 0;
+    q.active = true;
+    q.st = (hipStream_t)s;
 }
 void gemm_group_end() {
+    GemmGroup& q = g_group;
+    if (q.depth == 0) return;
+    struct Close {          // the group is closed even when the flush throws
+        GemmGroup& q;
+        ~Close() {
+            q.st = q.outer[--q.depth];
+            q.active = q.depth > 0;
+            if (!q.active) { q.n = 0; q.nd = 0; }
+        }
+    } close{q};
     gemm_group_flush();
-    g_group.active = false;
 }
 void gemm_group_sync() { gemm_group_flush(); }
 void gemm_group_stats(long* launches, long* products) {

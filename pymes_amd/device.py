@@ -359,6 +359,8 @@ class Context:
         mask = _lib.PYMES_DRESS_ABIJ_REDUCED if reduced_abij else 0
         for nm in names:
             mask |= 1 << pattern_of(nm)
+        # every dressing overwrites the context's dressed blocks: holders of an earlier set (DressedDeviceIntegrals) compare
+        self.dress_generation = getattr(self, "dress_generation", 0) + 1
         if q_range is not None or p_range is not None:
             p0, p1 = p_range if p_range is not None else (0, 0)
             q0, q1 = q_range if q_range is not None else (0, 0)

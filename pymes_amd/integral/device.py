@@ -50,6 +50,20 @@ class DressedDeviceIntegrals:
         self.ints, self.ctx = ints, ints.ctx
         self.no, self.nv = ints.no, ints.nv
         self._keys = tuple(keys)
+        # The object ALIASES the context's dressed storage: any later dressing on the same context (another
+        # get_T1_dressed_V, a CCSD iteration) overwrites what it stands for.  The generation of the dressing it belongs to:
+        self._generation = getattr(ints.ctx, "dress_generation", 0)
+
+    def require(self, names):
+        """Raise unless every block of ``names`` was dressed for this object and the context's dressed storage still holds
+        that dressing (``get_T1_dressed_V(t1, ints, subset)`` may have dressed fewer blocks; a later dressing on the same
+        ``DeviceIntegrals`` replaces them underneath)."""
+        missing = [nm for nm in names if nm not in self._keys]
+        if missing:
+            raise KeyError("T1-dressed blocks %s were not requested from get_T1_dressed_V" % ", ".join(missing))
+        if getattr(self.ctx, "dress_generation", 0) != self._generation:
+            raise RuntimeError("the dressed integrals are stale: the context's blocks have been dressed again since "
+                               "(another get_T1_dressed_V / CCSD iteration on the same DeviceIntegrals)")
 
     def keys(self):
         from pymes_amd.integral.partition import BLOCK_NAMES

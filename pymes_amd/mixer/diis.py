@@ -84,6 +84,11 @@ class DIIS:
             self.L = buf[1:82].reshape(9, 9)[:n, :n].copy()
             self.last_coefficients = buf[82:82 + n].copy()
             self.last_dependent = bool(buf[91] == 1.0)
+            if buf[91] == 2.0:
+                # the step on the device found no finite solution (its extrapolation kept the newest amplitudes): the
+                # reference's numpy.linalg raises at this point (diis.py:85-95)
+                self._stale = False
+                raise np.linalg.LinAlgError("DIIS: singular or non-finite subspace matrix")
         self._stale = False
 
     def _state_closing(self, ctx):

@@ -35,8 +35,19 @@ class quiet_collector:
 
 
 def destroy_graphs(ctx, st):
-    """Release the launch graphs a solve recorded (a caller-owned context would otherwise keep them until it closes)."""
-    for g in (st or {}).pop("graphs", {}).values():
+    """Release the launch graphs a solve recorded (a caller-owned context would otherwise keep them until it closes).
+    A pipelined pass may have left a replay of one of them in flight (the residual build of a pass that never came, or
+    the one an exception cut short) and ``device_amplitudes=True`` hands results over without a host copy: the stream is
+    drained first — a graph exec owns the kernel arguments of its queued launches."""
+    graphs = (st or {}).pop("graphs", {})
+    if st is not None:
+        st.pop("residuals_in_flight", None)
+    if graphs:
+        try:
+            ctx.sync()
+        except PymesError:
+            pass
+    for g in graphs.values():
         try:
             ctx.graph_destroy(g)
         except PymesError:

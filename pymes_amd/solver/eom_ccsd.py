@@ -29,6 +29,9 @@ class _Sigma:
 
     Pair layouts (ov x ov matrices): Xd[(a,i),(b,j)] = X[a,b,i,j], Xx[(a,j),(b,i)] = X[a,b,i,j]."""
 
+    # the blocks a sigma build reads (eom_ccsd.py:268-385)
+    BLOCKS = ("ijab", "iabj", "iajb", "ijka", "ijak", "iabc", "iajk", "abic", "klij", "abcd")
+
     def __init__(self, ctx, f, t2, dressed=False):
         """``dressed``: read the context's T1-DRESSED blocks (the context of a CCSD solve whose integrals were dressed in
         place, ``CCSD.get_T1_dressed_V`` on a ``DeviceIntegrals``) instead of blocks uploaded as they are."""
@@ -38,8 +41,7 @@ class _Sigma:
         self.dressed = bool(dressed)
         f = np.asarray(f, dtype=np.float64)
         self.foo, self.fov, self.fvv = c.array(f[:no, :no]), c.array(f[:no, no:]), c.array(f[no:, no:])
-        V = {nm: c.V_block(nm, self.dressed) for nm in ("ijab", "iabj", "iajb", "ijka", "ijak", "iabc", "iajk", "abic",
-                                                          "klij", "abcd")}
+        V = {nm: c.V_block(nm, self.dressed) for nm in self.BLOCKS}
         self.V = V
         T = t2
         self.T = T
@@ -426,6 +428,7 @@ class EOM_CCSD:
             t2 = t_T_abij if isinstance(t_T_abij, DeviceArray) else ctx.array(t_T_abij)
             if isinstance(t_T_abij, DeviceArray) and t_T_abij.ctx is not ctx:
                 raise ValueError("t_T_abij lives in another context than the dressed integrals")
+            dict_t_V_dressed.require(_Sigma.BLOCKS)      # a subset dressing / a later dressing on the same context: refuse
         else:
             ctx = self._context(dict_t_V_dressed, nv)
             t2 = ctx.array(t_T_abij)

@@ -241,6 +241,9 @@ class FEAST_EOM_CCSD(EOM_CCSD):
         time_init = time.time()
         no = self.no
         device_form = isinstance(dict_t_V_dressed, DressedDeviceIntegrals)      # the hand-over of EOM_CCSD.solve: everything in HBM
+        if device_form:
+            from pymes_amd.solver.eom_ccsd import _Sigma as _S
+            dict_t_V_dressed.require(_S.BLOCKS)       # a subset dressing / a later dressing on the same context: refuse
         if isinstance(t_fock_dressed_pq, DeviceArray):
             t_fock_dressed_pq = t_fock_dressed_pq.get()
         f = np.asarray(t_fock_dressed_pq, dtype=np.float64)

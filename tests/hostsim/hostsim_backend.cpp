@@ -224,16 +224,23 @@ void exchange_asymmetry(const double* A, const double* B, const int64_t d[4], do
 
 // read-backs: the simulator is synchronous — the values are copied at start and handed over at wait
 static double g_read_slots[16][128];
+static unsigned g_read_gen[16] = {0};
 static int g_read_next = 0;
+// (ticket = slot | generation << 8, as the HIP backend: a reused or never-started slot is refused)
 int readback_start(const double* dev_ptr, int n, stream_t) {
     if (n < 1 || n > 128) throw std::runtime_error("readback: 1..128 doubles");
     const int slot = g_read_next;
     g_read_next = (slot + 1) % 16;
+    const unsigned gen = (g_read_gen[slot] = (g_read_gen[slot] + 1) & 0x3fffffu);
     for (int i = 0; i < n; ++i) g_read_slots[slot][i] = dev_ptr[i];
-    return slot;
+    return (int)((gen << 8) | (unsigned)slot);
 }
-void readback_wait(int slot, double* out, int n) {
-    if (slot < 0 || slot >= 16 || n < 1 || n > 128) throw std::runtime_error("readback: bad slot");
+void readback_wait(int ticket, double* out, int n) {
+    const int slot = ticket & 0xff;
+    const unsigned gen = (unsigned)ticket >> 8;
+    if (ticket < 0 || slot >= 16 || n < 1 || n > 128) throw std::runtime_error("readback: bad ticket");
+    if (gen == 0 || g_read_gen[slot] != gen)
+        throw std::runtime_error("readback: the slot was never started or has been reused since (16 later read-backs)");
     for (int i = 0; i < n; ++i) out[i] = g_read_slots[slot][i];
 }
 int energy_norms_start(const double* f, const double* t1, const double* t2, const double* Edir, const double* Eex,
