@@ -60,6 +60,13 @@ struct GemmK {
     long nb2;
     long a_b1, a_b2, b_b1, b_b2, c_b1, c_b2;
     double* ws;   // split-K partials, tile-local: [tile - tile_begin][ks][BM][BN]
+    // Mixed launch of the LDS-DMA kernel (mixed != 0): the first `whole` tiles of the launch run as whole tiles (one block
+    // each, written straight to C), the remaining `tail` tiles are cut nsplit ways along K with their blocks in ks-major
+    // order (block whole + ks * tail + i is cut ks of tile whole + i: co-resident blocks work on the SAME k range of
+    // neighbouring tiles and share their A / B panels through the L2, as the blocks of an uncut launch do); partials
+    // ws[i][ks], reduced by splitk_reduce_kernel over the tail tiles.  `whole` is a multiple of 8 (XCD remap per part).
+    long whole = 0, tail = 0;
+    int mixed = 0;
 };
 
 // blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2): give each
@@ -434,8 +441,13 @@ __device__ __forceinline__ unsigned lds_addr_of(const double* p) {
     return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
 }
 
+// One output tile over the k range [kbeg, kend) (kbeg a multiple of BK): `gt` = tile id in the batch-major, grouped order of
+// the whole product; `Wpart` = destination of a partial tile [128][128] (k-split / stream-K), or null: alpha / beta epilogue
+// into C.  May be called several times by one block (persistent kernels): every wave has passed the barrier behind its last
+// LDS read when the function returns, so the next call may overwrite the buffers at once.
 template <bool AKC, bool BKC>
-__device__ __forceinline__ void dgemm_glds_body(const GemmK& g, const long bid) {
+__device__ __forceinline__ void dgemm_glds_tile(const GemmK& g, const long gt, const int kbeg, const int kend,
+                                                double* __restrict__ Wpart) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int BM = 128, BN = 128, WM = 64, WN = 64, FM = 4, FN = 4;
     constexpr int A_PITCH = AKC ? BK : (BM + 16);
@@ -451,9 +463,6 @@ __device__ __forceinline__ void dgemm_glds_body(const GemmK& g, const long bid) 
     const int l15 = lane & 15, l4 = lane >> 4;
 
     const int tiles = g.tiles_m * g.tiles_n;
-    const long lt = bid / g.nsplit;
-    const int ks = uni((int)(bid - lt * g.nsplit));
-    const long gt = g.tile_begin + lt;
     const long z = gt / tiles;
     const int t = (int)(gt - z * tiles);
     constexpr int GROUP = 8;
@@ -466,8 +475,6 @@ __device__ __forceinline__ void dgemm_glds_body(const GemmK& g, const long bid) 
     const int tn = uni(tin / gm);
     const long z1 = z / g.nb2, z2 = z - z1 * g.nb2;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = ks * g.kchunk;
-    const int kend = min(g.K, kbeg + g.kchunk);
     const int nkt = (kend - kbeg + BK - 1) / BK;
     const int nfull = (kend - kbeg) / BK;
 
@@ -625,8 +632,8 @@ __device__ __forceinline__ void dgemm_glds_body(const GemmK& g, const long bid) 
     }
 
     // ---- epilogue (as dgemm_kernel) -----------------------------------------------------------------
-    if (g.nsplit > 1) {
-        double* __restrict__ W = g.ws + (lt * g.nsplit + ks) * (long)(BM * BN);
+    if (Wpart) {
+        double* __restrict__ W = Wpart;
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -661,9 +668,121 @@ __device__ __forceinline__ void dgemm_glds_body(const GemmK& g, const long bid) 
     }
 }
 
+// block -> (tile, k cut) of the tile-per-block launches
+template <bool AKC, bool BKC>
+__device__ __forceinline__ void dgemm_glds_body(const GemmK& g, const long bid) {
+    long lt;             // launch-local tile
+    int ks;              // its k cut handled here
+    bool cut;            // this block writes a partial tile
+    if (g.mixed) {
+        if (bid < g.whole) { lt = bid; ks = 0; cut = false; }
+        else {
+            const long r = bid - g.whole;
+            ks = uni((int)(r / g.tail));
+            lt = g.whole + (r - (long)ks * g.tail);
+            cut = true;
+        }
+    } else {
+        lt = bid / g.nsplit;
+        ks = uni((int)(bid - lt * g.nsplit));
+        cut = g.nsplit > 1;
+    }
+    const int kbeg = cut ? ks * g.kchunk : 0;
+    const int kend = cut ? min(g.K, kbeg + g.kchunk) : g.K;
+    dgemm_glds_tile<AKC, BKC>(g, g.tile_begin + lt, kbeg, kend,
+                              cut ? g.ws + ((lt - (g.mixed ? g.whole : 0)) * g.nsplit + ks) * 16384L : nullptr);
+}
+
+// ---- hybrid stream-K launch (g.mixed == 2): gridDim.x persistent blocks, two per CU, all resident from the start ----------
+// Each block first computes its whole tiles (tile j * G + id, j < g.whole / G: the data-parallel part), then an EQUAL share
+// of the remaining g.tail tiles measured in k-tiles: units [id U / G, (id + 1) U / G) of the U = tail * ktiles units in
+// tile-major order — contiguous in k within a tile, at most two tiles touched when the share is below one tile.  A tile that
+// lies inside one share is finished by its block; of a shared tile every block writes its partial sum to a slot of its own
+// (slot 2 id: the share starts inside the tile; 2 id + 1: the tile starts inside the share) and streamk_fixup_kernel adds
+// the pieces in block order.  Every block does the same amount of work, whatever tiles mod 512 is: no last round with idle
+// CUs, and no dependence on the order in which the hardware hands blocks to CUs.
+// (b U < 2^63: the host keeps U = tail * ktiles below 2^40 and G <= 2048.  No 128-bit arithmetic: its division is a
+// 2000-instruction software loop per lane — the first version of the fix-up kernel spent 30 us per wave in it)
+__device__ __forceinline__ long sk_unit_begin(long b, long U, long G) {
+    return (long)(((unsigned long)b * (unsigned long)U) / (unsigned long)G);
+}
+template <bool AKC, bool BKC>
+__global__ void __launch_bounds__(kThreads, 2) dgemm_glds_sk_kernel(const GemmK g) {
+    const long G = gridDim.x;
+    const long id = xcd_remap(blockIdx.x, G);
+    const long per = g.whole / G;
+    for (long j = 0; j < per; ++j) dgemm_glds_tile<AKC, BKC>(g, g.tile_begin + j * G + id, 0, g.K, nullptr);
+    const long KT = (g.K + BK - 1) / BK;
+    const long U = g.tail * KT;
+    long u = sk_unit_begin(id, U, G);
+    const long u1 = sk_unit_begin(id + 1, U, G);
+    while (u < u1) {
+        const long i = u / KT;
+        const long kt0 = u - i * KT;
+        const long kt1 = min(KT, kt0 + (u1 - u));
+        const bool whole = kt0 == 0 && kt1 == KT;
+        double* W = whole ? nullptr : g.ws + (2 * id + (kt0 == 0 ? 1 : 0)) * 16384L;
+        dgemm_glds_tile<AKC, BKC>(g, g.tile_begin + g.whole + i, uni((int)(kt0 * BK)), uni((int)min((long)g.K, kt1 * BK)), W);
+        u += kt1 - kt0;
+    }
+}
+// C tile = alpha * (pieces of the tile in block order) + beta * C tile for the tiles of the stream-K part that more than one
+// block worked on; grid (g.tail, 64 pieces of 256 elements), G = the block count of the GEMM launch
+__global__ void __launch_bounds__(256) streamk_fixup_kernel(const GemmK g, const long G) {
+    const long i = blockIdx.x;
+    const long KT = (g.K + BK - 1) / BK;
+    const long U = g.tail * KT;
+    const long ua = i * KT, ue = ua + KT;                  // the tile's units
+    // first / last block whose share meets the tile: the largest b with begin(b) <= unit
+    auto owner = [&](long unit) {
+        long b = (long)(((unsigned long)unit * (unsigned long)G) / (unsigned long)U);
+        b = min(max(b, 0L), G - 1);
+        while (b + 1 < G && sk_unit_begin(b + 1, U, G) <= unit) ++b;
+        while (b > 0 && sk_unit_begin(b, U, G) > unit) --b;
+        return b;
+    };
+    __shared__ long own[2];
+    if (threadIdx.x == 0) { own[0] = owner(ua); own[1] = owner(ue - 1); }
+    __syncthreads();
+    const long bf = own[0], bl = own[1];
+    if (bf == bl) return;                                  // finished by its block
+    const int tiles = g.tiles_m * g.tiles_n;
+    const long gt = g.tile_begin + g.whole + i;
+    const long z = gt / tiles;
+    const int t = (int)(gt - z * tiles);
+    constexpr int GROUP = 8;
+    const int group_sz = GROUP * g.tiles_n;
+    const int grp = t / group_sz;
+    const int first_m = grp * GROUP;
+    const int gm = min(g.tiles_m - first_m, GROUP);
+    const int tin = t - grp * group_sz;
+    const int tm = first_m + tin % gm;
+    const int tn = tin / gm;
+    const long z1 = z / g.nb2, z2 = z - z1 * g.nb2;
+    const int e = blockIdx.y * 256 + threadIdx.x;
+    const int r = e >> 7, c = e & 127;
+    const int m = tm * 128 + r, n = tn * 128 + c;
+    if (m >= g.M || n >= g.N) return;
+    // only the first piece can be of the kind "the tile starts inside the share" (slot 2 b + 1): every later block
+    // begins inside the tile
+    double sum = g.ws[(2 * bf + (sk_unit_begin(bf, U, G) > ua ? 0 : 1)) * 16384L + e];
+    for (long b = bf + 1; b <= bl; ++b) sum += g.ws[(2 * b) * 16384L + e];
+    double* C = g.C + z1 * g.c_b1 + z2 * g.c_b2;
+    const double* Cin = g.Cin + z1 * g.c_b1 + z2 * g.c_b2;
+    const long off = (long)m * g.ldc + n;
+    double v = g.alpha * sum;
+    if (g.beta != 0.0) v += g.beta * Cin[off];
+    C[off] = v;
+}
+
 template <bool AKC, bool BKC>
 __global__ void __launch_bounds__(kThreads, 2) dgemm_glds_kernel(const GemmK g) {
-    dgemm_glds_body<AKC, BKC>(g, xcd_remap(blockIdx.x, gridDim.x));
+    // mixed launch: whole tiles and cut blocks are dealt to the XCDs separately (each XCD its share of both: an XCD has no
+    // way to take over work of another one), whole % 8 == 0 keeps hardware block b on XCD b % 8 in both parts
+    const long b = blockIdx.x;
+    const long id = !g.mixed ? xcd_remap(b, gridDim.x)
+                             : (b < g.whole ? xcd_remap(b, g.whole) : g.whole + xcd_remap(b - g.whole, (long)gridDim.x - g.whole));
+    dgemm_glds_body<AKC, BKC>(g, id);
 }
 // Grouped launch of mid-size products on the LDS-DMA kernel (A K-contiguous, B N-contiguous — the layout of the pair-packed
 // ladders and of every product with a symmetric pair matrix on the left): the four halves of the particle ladder and of
@@ -2704,6 +2823,23 @@ void launch_gemm_glds(const GemmK& k, long nblocks, hipStream_t st) {
     HIP_CHECK(hipGetLastError());
 }
 
+template <bool AKC, bool BKC>
+void launch_gemm_glds_sk(const GemmK& k, long nblocks, hipStream_t st) {
+    constexpr int A_T = AKC ? 128 * BK : BK * (128 + 16);
+    constexpr int B_T = BKC ? 128 * BK : BK * (128 + 16);
+    constexpr size_t lds = (size_t)2 * (A_T + B_T) * sizeof(double);
+    static bool attr_set[kMaxDevices] = {false};
+    auto fn = dgemm_glds_sk_kernel<AKC, BKC>;
+    const int dv = current_device();
+    if (!attr_set[dv]) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+        attr_set[dv] = true;
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)nblocks), dim3(kThreads), lds, st, k);
+    HIP_CHECK(hipGetLastError());
+}
+
 // tuning knob (experiments): smallest K range per block that still goes to the LDS-DMA kernel
 inline long dma_min_k() {
     static const long v = [] {
@@ -2712,6 +2848,72 @@ inline long dma_min_k() {
     }();
     return v;
 }
+// ---- launch plan of the LDS-DMA kernel -------------------------------------------------------------------------------
+// Two blocks are resident per CU (LDS, registers), so the chip has 512 slots and a CU's MFMA pipes are shared by its two
+// blocks: a round of 512 blocks of depth d (in K) costs ~0.23 d + 8 us, and a round that leaves a CU with ONE block runs
+// that block at 3/4 of the speed (0.153 d + 8 us: a lone block cannot hide its barrier phases — rocprofv3, round 4: 54 TF
+// against 70+).  So whole tiles are dealt in rounds of 512 and never as a round of <= 256; what is left after the whole
+// rounds is cut s ways along K so that its blocks fill rounds of 512 again (s chosen by the model below, partial tiles and
+// their reduction priced at 3 TB/s), all in ONE grid — the cut blocks start as the whole tiles drain, no launch boundary in
+// between.  790 tiles (one rank's slab of a ring product on eight): 512 whole + 278 cut 7 ways instead of 768 whole
+// (the third round with one block per CU) + 22 cut 8 ways.
+struct DmaPlan { long whole, tail; int s; long sk_blocks = 0; };      // sk_blocks > 0: hybrid stream-K with that many blocks
+inline double dma_plan_cost(long whole, long tail, long s, long ktiles) {
+    const double Kd = (double)ktiles * BK;
+    auto round_full = [](double d) { return 0.23 * d + 8.0; };
+    auto round_lone = [](double d) { return 0.153 * d + 8.0; };
+    double cost = (double)(whole / 512) * round_full(Kd);
+    if (tail > 0) {
+        const long kt_per = (ktiles + s - 1) / s, ns = (ktiles + kt_per - 1) / kt_per;
+        const double d = (double)kt_per * BK;
+        const long blocks = tail * ns, full = blocks / 512, rem = blocks % 512;
+        cost += (double)full * round_full(d);
+        if (rem > 256) cost += round_full(d);
+        else if (rem > 0) cost += ((full > 0 || whole > 0) ? 0.6 : 1.0) * round_lone(d);     // (starts while the round before drains)
+        if (ns > 1) cost += 6.0 + (double)tail * (double)(ns + 1) * 131072.0 / 3.0e6;
+    }
+    return cost;
+}
+inline DmaPlan plan_dma(long tiles, long ktiles, long ws_tiles) {
+    DmaPlan best{tiles, 0, 1};
+    double best_cost = 1e300;
+    const long max_cuts = std::max<long>(1, ktiles / (dma_min_k() / BK));
+    const long top = (tiles / 512) * 512;
+    for (long whole = top; whole >= std::max<long>(0, top - 512); whole -= 512) {
+        const long tail = tiles - whole;
+        const long smax = tail > 0 ? std::max<long>(1, std::min<long>(std::min<long>(16, max_cuts), ws_tiles / tail)) : 1;
+        for (long sp = 1; sp <= smax; ++sp) {
+            const double c = dma_plan_cost(whole, tail, sp, ktiles);
+            if (c < best_cost - 1e-9) { best_cost = c; best = DmaPlan{whole, tail, (int)sp}; }
+        }
+        if (whole == 0) break;
+    }
+    // Hybrid stream-K for launches of fewer than four rounds: G persistent blocks (two per CU), whole / G whole tiles each,
+    // the remaining tiles shared out in k-tiles.  The stream-K part covers between half a round and one and a half (a
+    // block's share is then 0.5 ... 1.5 tiles: at most two partial tiles per block, few pieces per shared tile).
+    {
+        long G = 512;
+        const long units = tiles * ktiles;
+        while (G > 8 && units / G < dma_min_k() / BK) G /= 2;          // every share at least dma_min_k deep
+        if (tiles < 2048 && units / G >= dma_min_k() / BK && 2 * G <= ws_tiles && units < (1L << 40)) {
+            long whole = (tiles / G) * G;
+            if (tiles - whole < G / 2 && whole >= G) whole -= G;
+            best = DmaPlan{whole, tiles - whole, 1, G};
+        }
+    }
+    if (const char* e = getenv("PYMES_GEMM_PLAN")) {          // tuning experiments: "whole,cuts" / "sk,whole,blocks"
+        long w = 0, sp = 1, G = 0;
+        if (sscanf(e, "sk,%ld,%ld", &w, &G) == 2) {
+            if (G >= 8 && G <= 2048 && G % 8 == 0 && w >= 0 && w <= tiles && w % G == 0 && 2 * G <= ws_tiles &&
+                (tiles - w) * ktiles >= G && tiles * ktiles < (1L << 40))
+                best = DmaPlan{w, tiles - w, 1, G};
+        } else if (sscanf(e, "%ld,%ld", &w, &sp) == 2 && w >= 0 && w <= tiles && w % 8 == 0 && sp >= 1 && sp <= max_cuts &&
+                   (tiles - w) * sp <= ws_tiles)
+            best = DmaPlan{w, tiles - w, (int)sp};
+    }
+    return best;
+}
+
 template <int BM, int BN, bool AKC, bool BKC>
 void launch_stream64(const GemmK& k, int vec, long nblocks, hipStream_t st) {
     if (vec == 2) launch_gemm<BM, BN, AKC, BKC, 2, true>(k, nblocks, st);
@@ -2720,7 +2922,7 @@ void launch_stream64(const GemmK& k, int vec, long nblocks, hipStream_t st) {
 thread_local bool g_stream64 = false;      // set by dev::gemm for the launches of one call
 
 template <int BM, int BN>
-bool dispatch_layout(const GemmK& k, bool akc, bool bkc, int vec, long nblocks, hipStream_t st) {   // true: LDS-DMA kernel
+bool dispatch_layout(const GemmK& k, bool akc, bool bkc, int vec, long nblocks, hipStream_t st) {   // (register-staged kernels)
     if constexpr (BM <= 64 && BN <= 64) {
         // (the narrow tiles 64 x 32 / 32 x 64 exist for the streaming shapes only)
         if (g_stream64 || BM < 64 || BN < 64) {
@@ -2730,16 +2932,6 @@ bool dispatch_layout(const GemmK& k, bool akc, bool bkc, int vec, long nblocks, 
             else launch_stream64<BM, BN, false, false>(k, vec, nblocks, st);
             return false;
         }
-    }
-    // the LDS-DMA kernel addresses a tile as uniform base + 32-bit byte offset per lane
-    const bool off32 = (akc ? 128 : 16) * k.a_ld * 8 + 4096 < (1L << 32) && (bkc ? 128 : 16) * k.b_ld * 8 + 4096 < (1L << 32);
-    // ... and pays off from about 64 k-tiles per block on (measured: below that the register-staged kernel wins)
-    if (BM == 128 && BN == 128 && vec == 2 && off32 && k.kchunk >= dma_min_k() && !getenv("PYMES_GEMM_NO_LDSDMA")) {
-        if (akc && bkc) launch_gemm_glds<true, true>(k, nblocks, st);
-        else if (akc) launch_gemm_glds<true, false>(k, nblocks, st);
-        else if (bkc) launch_gemm_glds<false, true>(k, nblocks, st);
-        else launch_gemm_glds<false, false>(k, nblocks, st);
-        return true;
     }
     if (vec == 2) {
         if (akc && bkc) launch_gemm<BM, BN, true, true, 2>(k, nblocks, st);
@@ -3369,7 +3561,14 @@ void gemm(const Gemm& g, stream_t s) {
     const long ws_tiles = g.splitk_ws ? g.splitk_ws_doubles / ((long)BM * BN) : 0;
     long main_tiles = tiles, tail_tiles = 0;
     int main_split = 1, tail_split = 1;
-    if (ktiles >= 16) {
+    // the LDS-DMA kernel (128 x 128, 16-byte loads, 32-bit lane offsets, K range per block >= dma_min_k) plans its own
+    // launch: whole tiles + a cut tail in ONE grid (plan_dma)
+    const bool dma_ok = BM == 128 && BN == 128 && vec == 2 && g.K >= dma_min_k() &&
+                        (a_kcontig ? 128 : 16) * k.a_ld * 8 + 4096 < (1L << 32) &&
+                        (b_kcontig ? 128 : 16) * k.b_ld * 8 + 4096 < (1L << 32) && !getenv("PYMES_GEMM_NO_LDSDMA");
+    DmaPlan plan{tiles, 0, 1};
+    if (dma_ok) plan = plan_dma(tiles, ktiles, ws_tiles);
+    else if (ktiles >= 16) {
         // The last, partially filled round of tiles (all of them for a small output) is split s ways along K:
         // ceil(rem s / slots) rounds of 1/s tile-time each.  Few remainder tiles may be split finer (huge K, tiny output).
         const long rem = tiles % slots;
@@ -3377,49 +3576,18 @@ void gemm(const Gemm& g, stream_t s) {
             long best = 1;
             double best_cost = 1.0;
             long smax = std::min<long>(512, std::max<long>(8, 2048 / rem));
-            // per split: >= 1024 deep when the launch is deep enough for the LDS-DMA kernel (the split blocks then run on
-            // it too), else >= 256 (128x128) / 128 (smaller tiles)
-            const long min_kt = (BM == 128 && BN == 128) ? (ktiles >= 2 * dma_min_k() / BK ? dma_min_k() / BK : 16) : 8;
+            const long min_kt = (BM == 128 && BN == 128) ? 16 : 8;       // per split: >= 256 (128x128) / 128 (smaller tiles) deep
             smax = std::min<long>(smax, ktiles / min_kt);
             smax = std::min<long>(smax, ws_tiles / rem);
             for (long sp = 2; sp <= smax; ++sp) {
                 const double cost = (double)((rem * sp + slots - 1) / slots) / (double)sp + 1e-5 * sp;
                 if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
             }
-            // worth it below 0.8 of a tile-time; below 0.9 when every split is still >= 2048 deep (the partial-tile
-            // traffic and the reduction are then small against the product: a 200-tile ladder slab of one rank in eight)
-            const bool deep_split = best >= 2 && (ktiles / best) * BK >= 2048;
-            if (best >= 2 && best_cost < (deep_split ? 0.9 : 0.8)) {
+            if (best >= 2 && best_cost < 0.8) {        // worth it below 0.8 of a tile-time
                 tail_tiles = rem;
                 main_tiles = tiles - rem;
                 tail_split = (int)best;
             }
-        }
-    }
-
-    // 128 x 128 tiles, between one and two blocks per CU (256 <= tiles < 512; the two ring builds of a (20,80) iteration as
-    // one batched launch: 338): a round of 256 WHOLE tiles leaves every SIMD with a single wave, and the LDS-DMA kernel then
-    // runs at ~54 TF instead of 70+ (rocprofv3, round 4) — it needs its second block per CU to hide the barrier phases.  Model:
-    // c = ceil(tiles s / 256) blocks per CU, time ~ (c / s) / (c >= 2 ? 1 : 0.75) tile-times; cutting EVERY tile s ways
-    // (338 x 3 = 4 blocks per CU, two at a time) gives 1.33 where whole tiles + split tail give 1.33 + 0.44.
-    // Measured again at the end of round 4 on the whole (20,80) iteration: 1.720 ms with it, 1.698 without (three runs each, one
-    // box) — the 256 whole tiles + 3-way cut of the other 82 win by 11 us per pair (no partial tiles for three quarters of the
-    // output).  Off unless PYMES_FULL_SPLIT is set ("auto": the model below; a number: that cut).
-    if (BM == 128 && BN == 128 && tiles >= 256 && tiles < 512 && ktiles >= 2 * dma_min_k() / BK && getenv("PYMES_FULL_SPLIT")) {
-        long best = 1;
-        double best_cost = 1e30;
-        const long smax = std::min<long>(std::min<long>(8, ktiles / (dma_min_k() / BK)), ws_tiles / tiles);
-        for (long sp = 1; sp <= smax; ++sp) {
-            const long c = (tiles * sp + 255) / 256;
-            const double cost = ((double)c / (double)sp) / (c >= 2 ? 1.0 : 0.75) + 0.02 * (sp - 1);
-            if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
-        }
-        const long cm = (main_tiles + 255) / 256;
-        const double cur = (double)cm / (cm >= 2 ? 1.0 : 0.75) +
-                           (tail_tiles ? ((double)((tail_tiles * tail_split + 255) / 256) / tail_split) / 0.75 : 0.0);
-        if (atoi(getenv("PYMES_FULL_SPLIT")) > 0) { best = atoi(getenv("PYMES_FULL_SPLIT")); best_cost = 0.0; }
-        if (best > 1 && best_cost < 0.95 * cur) {
-            main_tiles = tiles; main_split = (int)best; tail_tiles = 0; tail_split = 1;
         }
     }
 
@@ -3444,27 +3612,69 @@ void gemm(const Gemm& g, stream_t s) {
         k.tile_begin = tile_begin;
         k.ws = k.nsplit > 1 ? g.splitk_ws : nullptr;
         const long nblocks = ntiles * k.nsplit;
-        if (BM == 128 && BN == 128) {
-            const bool dma = dispatch_layout<128, 128>(k, a_kcontig, b_kcontig, vec, nblocks, st);
-            used_dma |= dma;
-            n_kernels += used_dma ? (dma ? 1 : 0) : 1;      // a DMA call reports its DMA launches only
-        }
-        else {
-            ++n_kernels;
-            if (BM == 128 && BN == 64) dispatch_layout<128, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
-            else if (BM == 64 && BN == 128) dispatch_layout<64, 128>(k, a_kcontig, b_kcontig, vec, nblocks, st);
-            else if (BM == 64 && BN == 32) dispatch_layout<64, 32>(k, a_kcontig, b_kcontig, vec, nblocks, st);
-            else if (BM == 32 && BN == 64) dispatch_layout<32, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
-            else dispatch_layout<64, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
-        }
+        ++n_kernels;
+        if (BM == 128 && BN == 128) dispatch_layout<128, 128>(k, a_kcontig, b_kcontig, vec, nblocks, st);
+        else if (BM == 128 && BN == 64) dispatch_layout<128, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
+        else if (BM == 64 && BN == 128) dispatch_layout<64, 128>(k, a_kcontig, b_kcontig, vec, nblocks, st);
+        else if (BM == 64 && BN == 32) dispatch_layout<64, 32>(k, a_kcontig, b_kcontig, vec, nblocks, st);
+        else if (BM == 32 && BN == 64) dispatch_layout<32, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
+        else dispatch_layout<64, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
         if (k.nsplit > 1) {
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ntiles, (unsigned)(BM * BN / 256)), dim3(256), 0, st, k, BM, BN);
             HIP_CHECK(hipGetLastError());
         }
         return k.nsplit;
     };
-    int nsplit = main_tiles > 0 ? launch(0, main_tiles, main_split) : 1;
-    if (tail_tiles > 0) nsplit = -launch(main_tiles, tail_tiles, tail_split);   // logged as a negative split
+    int nsplit = 1;
+    if (dma_ok && plan.sk_blocks > 0) {
+        k.kchunk = (int)(ktiles * BK);
+        k.nsplit = 1;
+        k.tile_begin = 0;
+        k.mixed = 2;
+        k.whole = plan.whole;
+        k.tail = plan.tail;
+        k.ws = g.splitk_ws;
+        if (a_kcontig && b_kcontig) launch_gemm_glds_sk<true, true>(k, plan.sk_blocks, st);
+        else if (a_kcontig) launch_gemm_glds_sk<true, false>(k, plan.sk_blocks, st);
+        else if (b_kcontig) launch_gemm_glds_sk<false, true>(k, plan.sk_blocks, st);
+        else launch_gemm_glds_sk<false, false>(k, plan.sk_blocks, st);
+        used_dma = true;
+        n_kernels = 1;
+        if (plan.tail > 0) {
+            hipLaunchKernelGGL(streamk_fixup_kernel, dim3((unsigned)plan.tail, 64u), dim3(256), 0, st, k, plan.sk_blocks);
+            HIP_CHECK(hipGetLastError());
+        }
+    } else if (dma_ok) {
+        // one grid: plan.whole whole tiles, then plan.tail tiles cut plan.s ways (ks-major); one reduction over the tail tiles
+        const long kt_per = (ktiles + plan.s - 1) / plan.s;
+        k.kchunk = (int)std::max<long>(kt_per * BK, BK);
+        k.nsplit = (int)std::max<long>(1, (ktiles + kt_per - 1) / std::max<long>(kt_per, 1));
+        if (k.nsplit == 1) { plan.whole = tiles; plan.tail = 0; }
+        k.tile_begin = 0;
+        k.mixed = 1;
+        k.whole = plan.whole;
+        k.tail = plan.tail;
+        k.ws = plan.tail > 0 ? g.splitk_ws : nullptr;
+        const long nblocks = plan.whole + plan.tail * k.nsplit;
+        if (nblocks > 0x7fffffffL) throw std::runtime_error("gemm: grid too large");
+        if (a_kcontig && b_kcontig) launch_gemm_glds<true, true>(k, nblocks, st);
+        else if (a_kcontig) launch_gemm_glds<true, false>(k, nblocks, st);
+        else if (b_kcontig) launch_gemm_glds<false, true>(k, nblocks, st);
+        else launch_gemm_glds<false, false>(k, nblocks, st);
+        used_dma = true;
+        n_kernels = 1;
+        if (plan.tail > 0) {
+            GemmK r = k;                   // the reduction sees the tail tiles as a launch of its own: ws[i][ks], i from 0
+            r.tile_begin = plan.whole;
+            r.mixed = 0;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)plan.tail, 64u), dim3(256), 0, st, r, 128, 128);
+            HIP_CHECK(hipGetLastError());
+            nsplit = -k.nsplit;            // logged as a negative split
+        }
+    } else {
+        nsplit = main_tiles > 0 ? launch(0, main_tiles, main_split) : 1;
+        if (tail_tiles > 0) nsplit = -launch(main_tiles, tail_tiles, tail_split);   // logged as a negative split
+    }
     if (g_prof.on) {
         HIP_CHECK(hipEventRecord(ev.second, st));
         g_prof.ev.push_back(ev);
@@ -3474,9 +3684,12 @@ void gemm(const Gemm& g, stream_t s) {
         g_prof.klass.push_back(used_dma ? 1 : 0);
         g_prof.nk.push_back(n_kernels);
         char buf[256];
-        snprintf(buf, sizeof buf, "M=%ld N=%ld K=%ld batch=%ld tile=%dx%d%s akc=%d bkc=%d vec=%d dma=%d split=%d flops=%.4e",
-                 (long)g.M, (long)g.N, (long)g.K, (long)nbatch, BM, BN, g_stream64 ? "s" : "", (int)a_kcontig, (int)b_kcontig, vec,
-                 (int)used_dma, nsplit, fl);
+        int len = snprintf(buf, sizeof buf, "M=%ld N=%ld K=%ld batch=%ld tile=%dx%d%s akc=%d bkc=%d vec=%d dma=%d split=%d flops=%.4e",
+                           (long)g.M, (long)g.N, (long)g.K, (long)nbatch, BM, BN, g_stream64 ? "s" : "", (int)a_kcontig,
+                           (int)b_kcontig, vec, (int)used_dma, nsplit, fl);
+        if (used_dma && len > 0 && len < (int)sizeof buf)
+            snprintf(buf + len, sizeof buf - len, plan.sk_blocks ? " plan=%ld+%ld/sk%ld" : " plan=%ld+%ld/%ld", plan.whole, plan.tail,
+                     plan.sk_blocks ? plan.sk_blocks : (long)(plan.tail ? k.nsplit : 1));
         g_prof.what.push_back(buf);
     }
 }
