@@ -39,16 +39,6 @@ int pymes_ctx_destroy(pymes_ctx* ctx);
 int pymes_ctx_set_stream(pymes_ctx* ctx, void* hip_stream);
 int pymes_ctx_sync(pymes_ctx* ctx);
 int pymes_ctx_workspace(pymes_ctx* ctx, uint64_t* capacity_bytes, uint64_t* high_water_bytes);
-/* Side sections: every entry point called between pymes_side_begin and pymes_side_end is enqueued on a second stream of
- * the context (own temporaries and split-K workspace), ordered behind what the main stream held at _begin; the main stream
- * goes on without waiting.  pymes_side_join (idempotent; also implied by pymes_ctx_sync, by a stream change and by every
- * read of a T1-dressed integral block) makes the main stream wait for the section.  Inputs of a section must not be
- * written, nor its outputs read, by main-stream calls before the join.  Used to stream the T1 dressing (ccsd.py:226-421,
- * HBM-bound) next to the particle ladders (ccd.py:187, MFMA-bound), which need none of it.  The reference has no
- * counterpart: numpy runs its einsum calls one after the other. */
-int pymes_side_begin(pymes_ctx* ctx);
-int pymes_side_end(pymes_ctx* ctx);
-int pymes_side_join(pymes_ctx* ctx);
 
 /* ---- device memory ------------------------------------------------------------ */
 /* buffers belong to the context: pymes_ctx_destroy releases whatever has not been passed to pymes_free */

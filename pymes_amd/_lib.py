@@ -25,9 +25,6 @@ SIGNATURES = {
     "pymes_ctx_destroy": (C.c_int, [C.c_void_p]),
     "pymes_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pymes_ctx_sync": (C.c_int, [C.c_void_p]),
-    "pymes_side_begin": (C.c_int, [C.c_void_p]),
-    "pymes_side_end": (C.c_int, [C.c_void_p]),
-    "pymes_side_join": (C.c_int, [C.c_void_p]),
     "pymes_ctx_workspace": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "pymes_malloc": (C.c_int, [C.c_void_p, C.c_uint64, c_pp]),
     "pymes_free": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -80,7 +80,6 @@ int pymes_ctx_set_stream(pymes_ctx* ctx, void* s) {
     return guarded([&] {
         Engine& e = E(ctx);
         if (e.capturing()) throw pymes::Error("set_stream while a launch graph is being recorded");
-        e.side_join();
         dev::stream_sync(e.stream);       // work already enqueued on the old stream is complete before the switch
         e.set_stream(s);
     });
@@ -88,18 +87,8 @@ int pymes_ctx_set_stream(pymes_ctx* ctx, void* s) {
 int pymes_ctx_sync(pymes_ctx* ctx) {
     return guarded([&] {
         Engine& e = E(ctx);
-        e.side_join();
         dev::stream_sync(e.stream);
     });
-}
-int pymes_side_begin(pymes_ctx* ctx) {
-    return guarded([&] { E(ctx).side_begin(); });
-}
-int pymes_side_end(pymes_ctx* ctx) {
-    return guarded([&] { E(ctx).side_end(); });
-}
-int pymes_side_join(pymes_ctx* ctx) {
-    return guarded([&] { E(ctx).side_join(); });
 }
 int pymes_ctx_workspace(pymes_ctx* ctx, uint64_t* cap, uint64_t* high) {
     return guarded([&] {
@@ -701,25 +690,11 @@ int pymes_diis_mix(pymes_ctx* ctx, double* state_host, int ntypes, int m, int wa
                 n[t * m + i] = sizes[t];
             }
         double ov[16];
-        static const bool trace = getenv("PYMES_DIIS_TRACE") != nullptr;
-        const auto t0 = std::chrono::steady_clock::now();
-        if (trace) dev::stream_sync(e.stream);                             // (what was enqueued before: residual, update)
-        const auto t1 = std::chrono::steady_clock::now();
         dev::dots(ntypes * m, x, y, n, ov, e.stream);                      // one launch pair, one synchronisation
-        const auto t2 = std::chrono::steady_clock::now();
         diis_small::step(state_host, ov, ntypes, m, was_full);             // (m+1) x (m+1) algebra on this host thread
         if (state_host[91] == 2.0)      // singular or non-finite subspace matrix: the reference's numpy.linalg raises here too
             throw pymes::Error("DIIS: the subspace matrix is singular or not finite (numpy.linalg.LinAlgError in pymes/mixer/diis.py:85-95)");
-        const auto t3 = std::chrono::steady_clock::now();
         for (int t = 0; t < ntypes; ++t) dev::lincomb(out[t], m, amp_hist + t * m, state_host + 82, sizes[t], e.stream);
-        if (trace) {
-            const auto t4 = std::chrono::steady_clock::now();
-            dev::stream_sync(e.stream);
-            const auto t5 = std::chrono::steady_clock::now();
-            auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-            fprintf(stderr, "diis_mix: wait-for-earlier %.0f us, dots+copy+sync %.0f us, solve %.0f us, lincomb enqueue %.0f us, lincomb run %.0f us\n",
-                    us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4), us(t4, t5));
-        }
     });
 }
 int pymes_lincomb_dev(pymes_ctx* ctx, double* out, int nx, const double* const* x, const double* coeff_dev, int64_t n) {

@@ -311,7 +311,7 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
     // (numerically identical to the reference's sequence to rounding: tests/test_host_round2.py pins the identity and every
     // golden solve pins the result).  DCSD keeps ccd.py:202-204 only: 2 Wd - Ud^T + Vd Tt_d in the D-term, no build in the
     // C-term.  Column slab [c0,c1): both builds are restricted to the rank's columns n, the applications give rows n.
-    const bool row_form = nc != ov && !getenv("PYMES_SLAB_COLUMN_FORM");
+    const bool row_form = nc != ov;
     const bool traces = !P && nc == ov;      // the small V.T sums as partial traces of the builds (below; one rank only)
     if (row_form) {
         // Several ranks: the slab in its TRANSPOSED form from the start.  MT[(b,j),(c,k)] / N1T hold the rank's columns as
@@ -355,10 +355,9 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
     // 256 whole ones and an 82-tile tail.  M is kept halved (M_h = Wd - UdT / 2 + Ld Tt_d / 4) so that both products of a
     // pair share alpha.
     // Only where a single product under-fills the chip (< 512 tiles of 128 x 128): a big product loses nothing on its own,
-    // and the assembly's two extra reads of Ex_x (1.6 GB at (50,200)) would be paid for nothing.  PYMES_RING_PAIRS=0/1 forces.
+    // and the assembly's two extra reads of Ex_x (1.6 GB at (50,200)) would be paid for nothing.
     const int64_t ring_tiles = ((ov + 127) / 128) * ((ov + 127) / 128);
-    const char* pair_env = getenv("PYMES_RING_PAIRS");
-    const bool paired = nc == ov && !getenv("PYMES_NO_RING_PAIRS") && (pair_env ? atoi(pair_env) != 0 : ring_tiles < 512);
+    const bool paired = nc == ov && ring_tiles < 512;
     ring_xd_ = paired ? 0.5 : 0.0;
     auto pair_gemm = [&](double alpha, const double* A0, const double* A1, const double* B0, const double* B1, double beta,
                          double* C0, double* C1) {
@@ -384,7 +383,7 @@ void Engine::residual_slab(const double* f, const double* t2, double* ETd_p, dou
         for (int i = t.rank - 1; i >= 0; --i) { if (t.st[i] != st) return false; st *= t.dim[i]; }
         return true;
     };
-    if (nc == ov && dense(Viabj) && dense(Viajb) && (size_t)no * 33 * sizeof(double) <= 64 * 1024 && !getenv("PYMES_NO_RING_OPERANDS")) {
+    if (nc == ov && dense(Viabj) && dense(Viajb) && (size_t)no * 33 * sizeof(double) <= 64 * 1024) {
         // both operands in one pass over the two blocks (two permutations and an axpby before: 5 reads / 3 writes of (ov)^2)
         dev::ring_operands(Viabj.p, Viajb.p, M.p, N1.p, paired ? 1.0 : 2.0, paired ? 0.5 : 1.0, no, nv, stream);
         stats.permute_calls++;
@@ -1264,7 +1263,7 @@ void Engine::dress_fock_partial(const double* t1, double* W, int rank, int world
     const bool all = (j0 == 0 && j1 == o);       // whole blocks: the planner may reuse its cached transposed copies
     auto js = [&](int pat) { return all ? block(pat) : slice(block(pat), 0, j0, j1); };
     // the two sums over the o v^3 block in one pass over it as stored (no transposed static copies of the block)
-    const bool fused_g12 = dev::fock_g12_ok(nv) && !getenv("PYMES_NO_FUSED_FOCK");
+    const bool fused_g12 = dev::fock_g12_ok(nv);
     if (fused_g12) {
         ArenaScope s2(arena);
         const int ja = static_cast<int>(j0), jb = static_cast<int>(j1);

@@ -126,14 +126,6 @@ Engine::~Engine() {
         for (auto& p : Vd_) dev::dfree(p);
         for (auto& kv : static_) dev::dfree(kv.second);
         dev::dfree(splitk_ws_);
-        if (side_.ready) {
-            dev::stream_sync(side_.stream);
-            dev::dfree(side_.splitk);
-            side_.arena.release();
-            dev::event_destroy(side_.fork);
-            dev::event_destroy(side_.done);
-            dev::stream_destroy(side_.stream);
-        }
         dev::dfree(lpack_.Vp);
         dev::dfree(lpack_.Vm);
         dev::dfree(eps_o);
@@ -144,52 +136,6 @@ Engine::~Engine() {
     }
 }
 
-void Engine::side_begin() {
-    if (side_.active) throw Error("side_begin: a side section is already open");
-    side_join();                                    // one side section in flight at a time
-    if (!side_.ready) {
-        // (a flag of its own: the host simulator's stream_create returns null, and a throw half-way must not leave a
-        // section that records on events which do not exist)
-        dev::stream_t s = dev::stream_create();
-        double* sk = nullptr;
-        dev::event_t f = nullptr, d = nullptr;
-        try {
-            side_.arena.init(arena.capacity() / 2);
-            sk = static_cast<double*>(dev::dmalloc(sizeof(double) * splitk_doubles_));
-            f = dev::event_create();
-            d = dev::event_create();
-        } catch (...) {
-            dev::dfree(sk);
-            if (f) dev::event_destroy(f);
-            side_.arena.release();
-            dev::stream_destroy(s);
-            throw;
-        }
-        side_.stream = s; side_.splitk = sk; side_.fork = f; side_.done = d;
-        side_.ready = true;
-    }
-    dev::event_record(side_.fork, stream);
-    dev::stream_wait_event(side_.stream, side_.fork);
-    std::swap(stream, side_.stream);
-    std::swap(arena, side_.arena);
-    std::swap(splitk_ws_, side_.splitk);
-    side_.active = true;
-}
-void Engine::side_end() {
-    if (!side_.active) throw Error("side_end: no side section is open");
-    dev::event_record(side_.done, stream);          // (stream is the side stream here)
-    std::swap(stream, side_.stream);
-    std::swap(arena, side_.arena);
-    std::swap(splitk_ws_, side_.splitk);
-    side_.active = false;
-    side_.pending = true;
-}
-void Engine::side_join() {
-    if (side_.active) throw Error("side_join inside a side section");
-    if (!side_.pending) return;
-    dev::stream_wait_event(stream, side_.done);
-    side_.pending = false;
-}
 
 void* Engine::user_malloc(size_t bytes) {
     void* p = dev::dmalloc(bytes);
@@ -282,7 +228,6 @@ bool Engine::has_block(int pattern, bool dressed) const {
     return (dressed ? Vd_[pattern & 15] : V_[pattern & 15]) != nullptr;
 }
 TView Engine::block(int pattern, bool dressed) {
-    if (dressed && side_.pending && !side_.active) side_join();      // the dressing may have run on the side stream
     double* p = dressed ? Vd_[pattern & 15] : V_[pattern & 15];
     if (!p)
         throw Error(std::string(dressed ? "dressed" : "undressed") + " integral block '" + canonical_name(pattern) +

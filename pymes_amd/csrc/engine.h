@@ -109,18 +109,6 @@ class Engine {
     void graph_launch(dev::graph_t g);
     void graph_destroy(dev::graph_t g);
     bool capturing() const { return capturing_; }
-    // ---- side stream: HBM-bound work next to the MFMA-bound GEMMs -------------------------------------------------------
-    // Between side_begin() and side_end() every engine call is enqueued on a second stream (own temporaries arena and
-    // split-K workspace), ordered behind what the main stream held at side_begin().  The main stream goes on without
-    // waiting; side_join() (idempotent) makes it wait for the side section — called explicitly by whoever reads its
-    // results from Python-held buffers, and implicitly by block(pattern, dressed = true).  The T1 dressing of the Fock
-    // matrix and of the V blocks (streaming 3.2-GB blocks against the 200 x 50 T1) runs there while the main stream
-    // computes the particle ladders, which need none of it.  Inputs of the side section must not be written, and its
-    // outputs not be read, on the main stream before side_join().
-    void side_begin();
-    void side_end();
-    void side_join();
-    bool side_pending() const { return side_.pending; }
     // max |V_pqrs - V_qpsr| over all blocks that are set (infinity if a block's exchange partner is missing) and max |V|
     void exchange_asymmetry_V(double out[2]);
 
@@ -251,13 +239,6 @@ class Engine {
     double* xs_vv_ = nullptr;
     SumTag xs_oo_tag_, xs_vv_tag_;
     void ensure_xs();
-    struct Side {
-        dev::stream_t stream = nullptr;
-        Arena arena;
-        double* splitk = nullptr;
-        dev::event_t fork = nullptr, done = nullptr;
-        bool active = false, pending = false, ready = false;      // ready: every resource above exists
-    } side_;
     dev::stream_t own_stream_ = nullptr;
     std::set<void*> user_allocs_;
     std::set<dev::graph_t> graphs_;

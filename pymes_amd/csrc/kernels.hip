@@ -442,9 +442,9 @@ __device__ __forceinline__ unsigned lds_addr_of(const double* p) {
 }
 
 // One output tile over the k range [kbeg, kend) (kbeg a multiple of BK): `gt` = tile id in the batch-major, grouped order of
-// the whole product; `Wpart` = destination of a partial tile [128][128] (k-split / stream-K), or null: alpha / beta epilogue
-// into C.  May be called several times by one block (persistent kernels): every wave has passed the barrier behind its last
-// LDS read when the function returns, so the next call may overwrite the buffers at once.
+// the whole product; `Wpart` = destination of a partial tile [128][128] (k-split), or null: alpha / beta epilogue into C.
+// (Every wave has passed the barrier behind its last LDS read when the function returns: a persistent kernel may call it
+// again at once — the hybrid stream-K launch of round 5 did)
 template <bool AKC, bool BKC>
 __device__ __forceinline__ void dgemm_glds_tile(const GemmK& g, const long gt, const int kbeg, const int kend,
                                                 double* __restrict__ Wpart) {
@@ -691,88 +691,6 @@ __device__ __forceinline__ void dgemm_glds_body(const GemmK& g, const long bid) 
     const int kend = cut ? min(g.K, kbeg + g.kchunk) : g.K;
     dgemm_glds_tile<AKC, BKC>(g, g.tile_begin + lt, kbeg, kend,
                               cut ? g.ws + ((lt - (g.mixed ? g.whole : 0)) * g.nsplit + ks) * 16384L : nullptr);
-}
-
-// ---- hybrid stream-K launch (g.mixed == 2): gridDim.x persistent blocks, two per CU, all resident from the start ----------
-// Each block first computes its whole tiles (tile j * G + id, j < g.whole / G: the data-parallel part), then an EQUAL share
-// of the remaining g.tail tiles measured in k-tiles: units [id U / G, (id + 1) U / G) of the U = tail * ktiles units in
-// tile-major order — contiguous in k within a tile, at most two tiles touched when the share is below one tile.  A tile that
-// lies inside one share is finished by its block; of a shared tile every block writes its partial sum to a slot of its own
-// (slot 2 id: the share starts inside the tile; 2 id + 1: the tile starts inside the share) and streamk_fixup_kernel adds
-// the pieces in block order.  Every block does the same amount of work, whatever tiles mod 512 is: no last round with idle
-// CUs, and no dependence on the order in which the hardware hands blocks to CUs.
-// (b U < 2^63: the host keeps U = tail * ktiles below 2^40 and G <= 2048.  No 128-bit arithmetic: its division is a
-// 2000-instruction software loop per lane — the first version of the fix-up kernel spent 30 us per wave in it)
-__device__ __forceinline__ long sk_unit_begin(long b, long U, long G) {
-    return (long)(((unsigned long)b * (unsigned long)U) / (unsigned long)G);
-}
-template <bool AKC, bool BKC>
-__global__ void __launch_bounds__(kThreads, 2) dgemm_glds_sk_kernel(const GemmK g) {
-    const long G = gridDim.x;
-    const long id = xcd_remap(blockIdx.x, G);
-    const long per = g.whole / G;
-    for (long j = 0; j < per; ++j) dgemm_glds_tile<AKC, BKC>(g, g.tile_begin + j * G + id, 0, g.K, nullptr);
-    const long KT = (g.K + BK - 1) / BK;
-    const long U = g.tail * KT;
-    long u = sk_unit_begin(id, U, G);
-    const long u1 = sk_unit_begin(id + 1, U, G);
-    while (u < u1) {
-        const long i = u / KT;
-        const long kt0 = u - i * KT;
-        const long kt1 = min(KT, kt0 + (u1 - u));
-        const bool whole = kt0 == 0 && kt1 == KT;
-        double* W = whole ? nullptr : g.ws + (2 * id + (kt0 == 0 ? 1 : 0)) * 16384L;
-        dgemm_glds_tile<AKC, BKC>(g, g.tile_begin + g.whole + i, uni((int)(kt0 * BK)), uni((int)min((long)g.K, kt1 * BK)), W);
-        u += kt1 - kt0;
-    }
-}
-// C tile = alpha * (pieces of the tile in block order) + beta * C tile for the tiles of the stream-K part that more than one
-// block worked on; grid (g.tail, 64 pieces of 256 elements), G = the block count of the GEMM launch
-__global__ void __launch_bounds__(256) streamk_fixup_kernel(const GemmK g, const long G) {
-    const long i = blockIdx.x;
-    const long KT = (g.K + BK - 1) / BK;
-    const long U = g.tail * KT;
-    const long ua = i * KT, ue = ua + KT;                  // the tile's units
-    // first / last block whose share meets the tile: the largest b with begin(b) <= unit
-    auto owner = [&](long unit) {
-        long b = (long)(((unsigned long)unit * (unsigned long)G) / (unsigned long)U);
-        b = min(max(b, 0L), G - 1);
-        while (b + 1 < G && sk_unit_begin(b + 1, U, G) <= unit) ++b;
-        while (b > 0 && sk_unit_begin(b, U, G) > unit) --b;
-        return b;
-    };
-    __shared__ long own[2];
-    if (threadIdx.x == 0) { own[0] = owner(ua); own[1] = owner(ue - 1); }
-    __syncthreads();
-    const long bf = own[0], bl = own[1];
-    if (bf == bl) return;                                  // finished by its block
-    const int tiles = g.tiles_m * g.tiles_n;
-    const long gt = g.tile_begin + g.whole + i;
-    const long z = gt / tiles;
-    const int t = (int)(gt - z * tiles);
-    constexpr int GROUP = 8;
-    const int group_sz = GROUP * g.tiles_n;
-    const int grp = t / group_sz;
-    const int first_m = grp * GROUP;
-    const int gm = min(g.tiles_m - first_m, GROUP);
-    const int tin = t - grp * group_sz;
-    const int tm = first_m + tin % gm;
-    const int tn = tin / gm;
-    const long z1 = z / g.nb2, z2 = z - z1 * g.nb2;
-    const int e = blockIdx.y * 256 + threadIdx.x;
-    const int r = e >> 7, c = e & 127;
-    const int m = tm * 128 + r, n = tn * 128 + c;
-    if (m >= g.M || n >= g.N) return;
-    // only the first piece can be of the kind "the tile starts inside the share" (slot 2 b + 1): every later block
-    // begins inside the tile
-    double sum = g.ws[(2 * bf + (sk_unit_begin(bf, U, G) > ua ? 0 : 1)) * 16384L + e];
-    for (long b = bf + 1; b <= bl; ++b) sum += g.ws[(2 * b) * 16384L + e];
-    double* C = g.C + z1 * g.c_b1 + z2 * g.c_b2;
-    const double* Cin = g.Cin + z1 * g.c_b1 + z2 * g.c_b2;
-    const long off = (long)m * g.ldc + n;
-    double v = g.alpha * sum;
-    if (g.beta != 0.0) v += g.beta * Cin[off];
-    C[off] = v;
 }
 
 template <bool AKC, bool BKC>
@@ -2823,92 +2741,45 @@ void launch_gemm_glds(const GemmK& k, long nblocks, hipStream_t st) {
     HIP_CHECK(hipGetLastError());
 }
 
-template <bool AKC, bool BKC>
-void launch_gemm_glds_sk(const GemmK& k, long nblocks, hipStream_t st) {
-    constexpr int A_T = AKC ? 128 * BK : BK * (128 + 16);
-    constexpr int B_T = BKC ? 128 * BK : BK * (128 + 16);
-    constexpr size_t lds = (size_t)2 * (A_T + B_T) * sizeof(double);
-    static bool attr_set[kMaxDevices] = {false};
-    auto fn = dgemm_glds_sk_kernel<AKC, BKC>;
-    const int dv = current_device();
-    if (!attr_set[dv]) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds));
-        attr_set[dv] = true;
-    }
-    hipLaunchKernelGGL(fn, dim3((unsigned)nblocks), dim3(kThreads), lds, st, k);
-    HIP_CHECK(hipGetLastError());
-}
+// smallest K range per block that still goes to the LDS-DMA kernel (measured at (20,80), DESIGN 5: below it the
+// register-staged kernel wins)
+inline long dma_min_k() { return 384L; }
 
-// tuning knob (experiments): smallest K range per block that still goes to the LDS-DMA kernel
-inline long dma_min_k() {
-    static const long v = [] {
-        const char* e = getenv("PYMES_DMA_MIN_K");
-        return e ? std::max<long>(64, atol(e)) : 384L;
-    }();
-    return v;
-}
 // ---- launch plan of the LDS-DMA kernel -------------------------------------------------------------------------------
-// Two blocks are resident per CU (LDS, registers), so the chip has 512 slots and a CU's MFMA pipes are shared by its two
-// blocks: a round of 512 blocks of depth d (in K) costs ~0.23 d + 8 us, and a round that leaves a CU with ONE block runs
-// that block at 3/4 of the speed (0.153 d + 8 us: a lone block cannot hide its barrier phases — rocprofv3, round 4: 54 TF
-// against 70+).  So whole tiles are dealt in rounds of 512 and never as a round of <= 256; what is left after the whole
-// rounds is cut s ways along K so that its blocks fill rounds of 512 again (s chosen by the model below, partial tiles and
-// their reduction priced at 3 TB/s), all in ONE grid — the cut blocks start as the whole tiles drain, no launch boundary in
-// between.  790 tiles (one rank's slab of a ring product on eight): 512 whole + 278 cut 7 ways instead of 768 whole
-// (the third round with one block per CU) + 22 cut 8 ways.
-struct DmaPlan { long whole, tail; int s; long sk_blocks = 0; };      // sk_blocks > 0: hybrid stream-K with that many blocks
-inline double dma_plan_cost(long whole, long tail, long s, long ktiles) {
-    const double Kd = (double)ktiles * BK;
-    auto round_full = [](double d) { return 0.23 * d + 8.0; };
-    auto round_lone = [](double d) { return 0.153 * d + 8.0; };
-    double cost = (double)(whole / 512) * round_full(Kd);
-    if (tail > 0) {
-        const long kt_per = (ktiles + s - 1) / s, ns = (ktiles + kt_per - 1) / kt_per;
-        const double d = (double)kt_per * BK;
-        const long blocks = tail * ns, full = blocks / 512, rem = blocks % 512;
-        cost += (double)full * round_full(d);
-        if (rem > 256) cost += round_full(d);
-        else if (rem > 0) cost += ((full > 0 || whole > 0) ? 0.6 : 1.0) * round_lone(d);     // (starts while the round before drains)
-        if (ns > 1) cost += 6.0 + (double)tail * (double)(ns + 1) * 131072.0 / 3.0e6;
-    }
-    return cost;
-}
+// A CU turns out one tile per tile-time tau whether it holds one block or two (two resident blocks share its MFMA pipes),
+// and the hardware hands the next block of the grid to whichever CU frees a slot: a launch costs about (work of the
+// busiest CU) x tau.  Whole tiles therefore go in rounds of 256 — whole = floor(tiles / 256) * 256 — and the remaining
+// `tail` tiles are cut s ways along K so that their tail * s blocks fill rounds of 256 again:
+//     cost(s) / tau = ceil(tail s / 256) / s  +  s * 3 us / tau  +  (5 us + 44 ns * tail (s + 1)) / tau      (the last: reduction)
+// minimised over s <= 16 with every cut >= dma_min_k deep.  All of it is ONE grid (the cut blocks take the second slot of
+// the CUs that run the last whole tiles; no launch boundary), cut blocks in ks-major order.  Fitted to, and checked
+// against, profiles/r05/probe_gemm_plan_grid.txt (19 tile counts x 5 depths x 3 choices of `whole` x 7 cut counts): the
+// formula's ranking of s is the measured one, whole = floor(tiles / 256) * 256 beats floor(tiles / 512) * 512 and 0 wherever
+// they differ, e.g. 338 tiles x 100 k-tiles (the two ring builds of a (20,80) iteration): 256 + 82/3 280 us, 0 + 338/3 301,
+// 338 whole 394; 790 x 625 (a rank's slab of a (50,200) ring product on eight): 768 + 22/10 3411 us, 512 + 278/6 3567,
+// 790 whole 4695.
+struct DmaPlan { long whole, tail; int s; };
 inline DmaPlan plan_dma(long tiles, long ktiles, long ws_tiles) {
+    const long whole = (tiles / 256) * 256, tail = tiles - whole;
     DmaPlan best{tiles, 0, 1};
-    double best_cost = 1e300;
     const long max_cuts = std::max<long>(1, ktiles / (dma_min_k() / BK));
-    const long top = (tiles / 512) * 512;
-    for (long whole = top; whole >= std::max<long>(0, top - 512); whole -= 512) {
-        const long tail = tiles - whole;
-        const long smax = tail > 0 ? std::max<long>(1, std::min<long>(std::min<long>(16, max_cuts), ws_tiles / tail)) : 1;
+    if (tail > 0) {
+        const double tau = 1.75 * (double)ktiles;                      // us per tile
+        const long smax = std::max<long>(1, std::min<long>(std::min<long>(16, max_cuts), ws_tiles / tail));
+        double best_cost = 1e300;
         for (long sp = 1; sp <= smax; ++sp) {
-            const double c = dma_plan_cost(whole, tail, sp, ktiles);
+            const long kt_per = (ktiles + sp - 1) / sp, ns = (ktiles + kt_per - 1) / kt_per;       // the cuts that result
+            if (ns != sp) continue;
+            double c = (double)((tail * sp + 255) / 256) / (double)sp + (double)sp * 3.0 / tau;
+            if (sp > 1) c += (5.0 + 0.0437 * (double)tail * (double)(sp + 1)) / tau;
             if (c < best_cost - 1e-9) { best_cost = c; best = DmaPlan{whole, tail, (int)sp}; }
         }
-        if (whole == 0) break;
+        if (best.s == 1) best = DmaPlan{tiles, 0, 1};
     }
-    // Hybrid stream-K for launches of fewer than four rounds: G persistent blocks (two per CU), whole / G whole tiles each,
-    // the remaining tiles shared out in k-tiles.  The stream-K part covers between half a round and one and a half (a
-    // block's share is then 0.5 ... 1.5 tiles: at most two partial tiles per block, few pieces per shared tile).
-    {
-        long G = 512;
-        const long units = tiles * ktiles;
-        while (G > 8 && units / G < dma_min_k() / BK) G /= 2;          // every share at least dma_min_k deep
-        if (tiles < 2048 && units / G >= dma_min_k() / BK && 2 * G <= ws_tiles && units < (1L << 40)) {
-            long whole = (tiles / G) * G;
-            if (tiles - whole < G / 2 && whole >= G) whole -= G;
-            best = DmaPlan{whole, tiles - whole, 1, G};
-        }
-    }
-    if (const char* e = getenv("PYMES_GEMM_PLAN")) {          // tuning experiments: "whole,cuts" / "sk,whole,blocks"
-        long w = 0, sp = 1, G = 0;
-        if (sscanf(e, "sk,%ld,%ld", &w, &G) == 2) {
-            if (G >= 8 && G <= 2048 && G % 8 == 0 && w >= 0 && w <= tiles && w % G == 0 && 2 * G <= ws_tiles &&
-                (tiles - w) * ktiles >= G && tiles * ktiles < (1L << 40))
-                best = DmaPlan{w, tiles - w, 1, G};
-        } else if (sscanf(e, "%ld,%ld", &w, &sp) == 2 && w >= 0 && w <= tiles && w % 8 == 0 && sp >= 1 && sp <= max_cuts &&
-                   (tiles - w) * sp <= ws_tiles)
+    if (const char* e = getenv("PYMES_GEMM_PLAN")) {          // tuning experiments: "whole,cuts"
+        long w = 0, sp = 1;
+        if (sscanf(e, "%ld,%ld", &w, &sp) == 2 && w >= 0 && w <= tiles && (w % 8 == 0 || w == tiles) && sp >= 1 &&
+            sp <= max_cuts && (tiles - w) * sp <= ws_tiles)
             best = DmaPlan{w, tiles - w, (int)sp};
     }
     return best;
@@ -3015,37 +2886,32 @@ void gemm_group_flush_dma() {
     hipStream_t st = q.st;
     long total = 0;
     for (int i = 0; i < q.nd; ++i) total += q.tiles_d[i];
-    // How many ways every product is cut along K (each cut at least dma_min_k deep).  Two blocks are resident per CU, so the
-    // launch runs in rounds of 512 blocks; measured on the (20,80) ladders (156 tiles, K = 3240: 284 / 317 / 337 / 304 / 316 /
-    // 290 us for 3 ... 8 cuts) and on the slabs of one rank in eight, a cut s costs, in microseconds,
-    //     full rounds x (0.23 d + 8)  +  last round: the same when it holds more than 256 blocks, half of (0.153 d + 8) when
-    //     fewer (they start as slots free up and run alone)  +  0.04 per block for the partial tiles
-    // with d the depth of the deepest block.  (The old rule — ~1024 blocks — cut those ladders 7 ways: 1092 blocks, two rounds
-    // and 68 blocks of a third.)  A single cut is never chosen when a deeper one is possible: an uncut block applies beta in
-    // its own epilogue, element by element.
-    long want = std::max<long>(1, (1024 + total - 1) / total);
-    // Used where it was measured — fewer tiles than CUs; larger launches keep ~1024 blocks (at (30,120), 684 tiles, the model
-    // cut 3 ways instead of 2 and the CCSD iteration lost 5 %: its partial tiles no longer fit the 256-MB last-level cache).
-    if (total <= 256 && !getenv("PYMES_GROUP_SPLIT_OLD")) {
+    // How many ways every product is cut along K (each cut at least dma_min_k deep): the rule of plan_dma for the tiles of the
+    // whole group — a CU turns out one tile per tile-time however many blocks it holds, so s cuts cost about
+    // ceil(total s / 256) / s tile-times, + 3 us per cut and the reduction of the partial tiles (profiles/r05/
+    // probe_gemm_plan_grid.txt).  A single cut is never chosen when a deeper one is possible: an uncut block applies beta
+    // in its own epilogue, element by element.
+    long want = 1;
+    {
+        long ktmax = 0;
+        for (int i = 0; i < q.nd; ++i) ktmax = std::max(ktmax, q.ktiles_d[i]);
+        const double tau = 1.75 * (double)ktmax;
         double best = 1e300;
         for (long sp = 2; sp <= 16; ++sp) {
             long blocks = 0;
-            double d = 0.0;
             bool any_cut = false;
             for (int i = 0; i < q.nd; ++i) {
                 const long si = std::min(sp, std::max<long>(1, q.ktiles_d[i] / (dma_min_k() / BK)));
                 any_cut = any_cut || si > 1;
                 blocks += q.tiles_d[i] * si;
-                d = std::max(d, (double)((q.ktiles_d[i] + si - 1) / si) * BK);
             }
             if (!any_cut) break;
-            const long full = blocks / 512, rem = blocks % 512;
-            const double round = 0.23 * d + 8.0;
-            const double cost = full * round + (rem == 0 ? 0.0 : rem <= 256 ? 0.5 * (0.153 * d + 8.0) : round) + 0.04 * (double)blocks;
+            if (blocks * 16384 > q.ws_doubles) break;
+            const double cost = (double)((blocks + 255) / 256) / (double)sp + (double)sp * 3.0 / tau +
+                                (5.0 + 0.0437 * (double)(blocks + total)) / tau;
             if (cost < best - 1e-9) { best = cost; want = sp; }
         }
     }
-    if (const char* e = getenv("PYMES_GROUP_SPLIT")) want = std::max(1, atoi(e));      // experiments
     GroupK grp, red;
     grp.n = q.nd; grp.tile = 128; red.n = 0; red.tile = 128;
     long blocks = 0, ws_used = 0, red_blocks = 0;
@@ -3358,7 +3224,7 @@ bool gemm_group_take(const Gemm& g, bool a_kcontig, bool b_kcontig, int64_t a_sm
         // (enough blocks of >= dma_min_k depth for half the chip, else the 64 x 64 group fills it better)
         const bool fills = t128 * std::min<long>(16, g.K / dma_min_k()) >= 128;
         if (a_kcontig && !b_kcontig && vec2 && off32 && g.M > 64 && g.N > 64 && g.K >= 2 * dma_min_k() && g.splitk_ws && fills &&
-            !getenv("PYMES_GEMM_NO_LDSDMA") && !getenv("PYMES_NO_DMA_GROUP") && t128 <= 0x3fffffffL / 64) {
+            t128 <= 0x3fffffffL / 64) {
             if (q.nd == kGroupMax) gemm_group_flush_dma();
             GemmK k;
             k.A = g.A; k.B = g.B; k.C = g.C;
@@ -3511,23 +3377,12 @@ void gemm(const Gemm& g, stream_t s) {
     if (g.K <= 256 && std::min(g.M, g.N) <= 256) { BM = 64; BN = 64; stream = true; }
     // ... and the tiny outputs contracted over a huge K (singles residual: 200 x 50 over o v^2 = 2e6), k-split over the chip
     if (g.M <= 256 && g.N <= 256 && g.K >= 65536 && BM == 64 && BN == 64) stream = true;
-    if (const char* e = getenv("PYMES_GEMM_STREAM")) stream = stream && atoi(e) != 0;
     // a streaming shape whose skinny side is at most 32 (nocc = 20 against 64-wide tiles: two thirds of the MFMA work on
     // padding, and these launches are MFMA-issue AND bandwidth co-limited): 64 x 32 / 32 x 64 tiles
-    // (single-buffer kernel for every narrow launch: the only variant instantiated for them — PYMES_NARROW_TILES=stream keeps
-    // them to the streaming shapes)
-    static const int narrow_mode = [] {
-        if (getenv("PYMES_NO_NARROW_TILES")) return 0;
-        const char* e = getenv("PYMES_NARROW_TILES");
-        return (e && !strcmp(e, "stream")) ? 1 : 2;
-    }();
-    if (BM == 64 && BN == 64 && (narrow_mode == 2 || (narrow_mode == 1 && stream))) {
+    // (single-buffer kernel for every narrow launch: the only variant instantiated for them)
+    if (BM == 64 && BN == 64) {
         if (g.N <= 32) BN = 32;
         else if (g.M <= 32) BM = 32;
-    }
-    if (const char* ov = getenv("PYMES_GEMM_TILE")) {   // tuning experiments only
-        int bm = 0, bn = 0;
-        if (sscanf(ov, "%dx%d", &bm, &bn) == 2 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128)) { BM = bm; BN = bn; }
     }
     k.tiles_m = (int)((g.M + BM - 1) / BM);
     k.tiles_n = (int)((g.N + BN - 1) / BN);
@@ -3565,7 +3420,7 @@ void gemm(const Gemm& g, stream_t s) {
     // launch: whole tiles + a cut tail in ONE grid (plan_dma)
     const bool dma_ok = BM == 128 && BN == 128 && vec == 2 && g.K >= dma_min_k() &&
                         (a_kcontig ? 128 : 16) * k.a_ld * 8 + 4096 < (1L << 32) &&
-                        (b_kcontig ? 128 : 16) * k.b_ld * 8 + 4096 < (1L << 32) && !getenv("PYMES_GEMM_NO_LDSDMA");
+                        (b_kcontig ? 128 : 16) * k.b_ld * 8 + 4096 < (1L << 32);
     DmaPlan plan{tiles, 0, 1};
     if (dma_ok) plan = plan_dma(tiles, ktiles, ws_tiles);
     else if (ktiles >= 16) {
@@ -3626,25 +3481,7 @@ void gemm(const Gemm& g, stream_t s) {
         return k.nsplit;
     };
     int nsplit = 1;
-    if (dma_ok && plan.sk_blocks > 0) {
-        k.kchunk = (int)(ktiles * BK);
-        k.nsplit = 1;
-        k.tile_begin = 0;
-        k.mixed = 2;
-        k.whole = plan.whole;
-        k.tail = plan.tail;
-        k.ws = g.splitk_ws;
-        if (a_kcontig && b_kcontig) launch_gemm_glds_sk<true, true>(k, plan.sk_blocks, st);
-        else if (a_kcontig) launch_gemm_glds_sk<true, false>(k, plan.sk_blocks, st);
-        else if (b_kcontig) launch_gemm_glds_sk<false, true>(k, plan.sk_blocks, st);
-        else launch_gemm_glds_sk<false, false>(k, plan.sk_blocks, st);
-        used_dma = true;
-        n_kernels = 1;
-        if (plan.tail > 0) {
-            hipLaunchKernelGGL(streamk_fixup_kernel, dim3((unsigned)plan.tail, 64u), dim3(256), 0, st, k, plan.sk_blocks);
-            HIP_CHECK(hipGetLastError());
-        }
-    } else if (dma_ok) {
+    if (dma_ok) {
         // one grid: plan.whole whole tiles, then plan.tail tiles cut plan.s ways (ks-major); one reduction over the tail tiles
         const long kt_per = (ktiles + plan.s - 1) / plan.s;
         k.kchunk = (int)std::max<long>(kt_per * BK, BK);
@@ -3688,8 +3525,7 @@ void gemm(const Gemm& g, stream_t s) {
                            (long)g.M, (long)g.N, (long)g.K, (long)nbatch, BM, BN, g_stream64 ? "s" : "", (int)a_kcontig,
                            (int)b_kcontig, vec, (int)used_dma, nsplit, fl);
         if (used_dma && len > 0 && len < (int)sizeof buf)
-            snprintf(buf + len, sizeof buf - len, plan.sk_blocks ? " plan=%ld+%ld/sk%ld" : " plan=%ld+%ld/%ld", plan.whole, plan.tail,
-                     plan.sk_blocks ? plan.sk_blocks : (long)(plan.tail ? k.nsplit : 1));
+            snprintf(buf + len, sizeof buf - len, " plan=%ld+%ld/%d", plan.whole, plan.tail, plan.tail ? k.nsplit : 1);
         g_prof.what.push_back(buf);
     }
 }
@@ -4412,7 +4248,6 @@ void ueg_two_body(const UegParams& prm, const int* k_int_dev, const int* index_m
 namespace {
 
 bool gemv_dispatch(const dev::Gemm& g, long a_sm, long a_sk, long b_sk, long b_sn, hipStream_t st) {
-    if (getenv("PYMES_NO_GEMV")) return false;
     if (g.nb1 != 1 || g.nb2 != 1 || g.K < 256) return false;
     const double* W; const double* x; long ld, xs, R, C, ys; bool cols;
     if (g.M == 1 && g.N >= 64) {                 // y[n] = sum_k A(0,k) B(k,n)

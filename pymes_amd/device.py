@@ -130,23 +130,6 @@ class Context:
     def sync(self):
         self.lib.call("pymes_ctx_sync", self.handle)
 
-    def side(self):
-        """``with ctx.side(): ...``: the calls inside run on the context's second stream, next to what the main stream does
-        afterwards; ``side_join()`` (or any read of a dressed block, ``sync()``) makes the main stream wait for them."""
-        ctx = self
-
-        class _Side:
-            def __enter__(self):
-                ctx.lib.call("pymes_side_begin", ctx.handle)
-
-            def __exit__(self, *exc):
-                ctx.lib.call("pymes_side_end", ctx.handle)
-                return False
-        return _Side()
-
-    def side_join(self):
-        self.lib.call("pymes_side_join", self.handle)
-
     def workspace(self):
         cap, high = C.c_uint64(), C.c_uint64()
         self.lib.call("pymes_ctx_workspace", self.handle, C.byref(cap), C.byref(high))

@@ -128,10 +128,6 @@ class CCSD(ccd.CCD):
                 st["dt1"], st["dt2"] = ctx.pool_get(t1.shape), ctx.pool_get(t2.shape)
             st["graph"], st["eager_passes"] = None, 0
             st["eager_passes_of"] = {}
-            # side-stream overlap of the T1 dressing with the ladders: opt-in (PYMES_OVERLAP=1).  Measured at (50,200): the
-            # streaming kernels take CU slots and LDS from the ladder GEMMs (92 -> 88.5 % of peak) and the iteration gets
-            # 2.5 ms slower, not faster (profiles/r03)
-            st["overlap"] = os.environ.get("PYMES_OVERLAP") == "1"
             # T1 starts at zero (MP2) unless the caller brought amplitudes
             st["t1_zero"] = amps is None and not os.environ.get("PYMES_NO_T1_SHORTCUT")
             st["graph_ok"] = ctx.graphs_supported() and not os.environ.get("PYMES_NO_GRAPH")
@@ -152,22 +148,6 @@ class CCSD(ccd.CCD):
             ctx.residual_slab(st["f"], t2, st["ETd"], st["ETx"], st["L"], 0, 1, is_dcd=self.is_dcd)          # :171
             ctx.singles_residual_partial(st["f"], t1, t2, r1, 0, 1, reuse_layouts=True)                      # :167
             ctx.residual_finish(st["f"], t2, st["ETd"], st["ETx"], st["L"], r2, is_dcd=self.is_dcd, reuse_layouts=True)
-            return
-        if st["sym"] and st.get("overlap") and st["eager_passes_of"].get("t1", 0) >= 1:
-            # The T1 dressing (:163, :165: streaming passes over the o v^3 blocks, HBM-bound) on the context's side stream,
-            # next to the particle ladders and Q_kb (MFMA-bound, from undressed integrals and tau = T2 + T1 T1): the main
-            # stream waits for the dressed blocks only where the hole ladder reads V~_klij (implicit join) and before the
-            # ring products.  Not in the first pass of a solve, which still builds its per-solve statics on the main stream.
-            with ctx.side():
-                ctx.dress_fock(st["f"], t1, st["fd"])                                 # :163
-                ctx.dress_V(t1, ("klij", "iajb", "iabj"))                             # :165
-            slab = dict(is_dcd=self.is_dcd, dressed=True, t1=t1, QK=st["QK"])
-            ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], 0, 1, part="ladders", **slab)   # :171, ladders
-            ctx.side_join()
-            ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], 0, 1, part="rings", **slab)     # :171, rings
-            ctx.singles_residual_partial(st["fd"], t1, t2, r1, 0, 1, reuse_layouts=True)      # :167
-            ctx.residual_finish(st["fd"], t2, st["ETd"], st["ETx"], st["L"], r2, is_dcd=self.is_dcd, dressed=True,
-                                t1=t1, QK=st["QK"], reuse_layouts=True)
             return
         ctx.dress_fock(st["f"], t1, st["fd"])                                         # :163
         if st["sym"]:

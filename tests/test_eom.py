@@ -241,3 +241,12 @@ def test_davidson_golden_gpu(gpu_lib, monkeypatch, device_form):
     compared with the reference (38 passes with collapses)."""
     check_davidson_golden(gpu_lib, monkeypatch, "small", device_form)
     check_davidson_golden(gpu_lib, monkeypatch, "big", device_form)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_form", [False, True])
+def test_davidson_golden_config2_size_gpu(gpu_lib, monkeypatch, device_form):
+    """(20,80), the size of BASELINE config 2 and the nearest to config 5 a reference run reaches in an hour of CPU (round 5:
+    792 s of CCSD + 1128 s of Davidson in the build container, oracle/make_golden_eom_davidson.py mid): CCSD energy,
+    excitation energies, the 29 passes and the Ritz values of every one of them, through both call forms."""
+    check_davidson_golden(gpu_lib, monkeypatch, "mid", device_form)

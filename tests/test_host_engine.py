@@ -303,36 +303,6 @@ def test_bra_dressed_ladder_reproduces_reference_energies(sim, monkeypatch, tag,
     assert abs(np.linalg.norm(res["t2"]) - ref["t2_norm"]) < 1e-7
 
 
-@pytest.mark.parametrize("tag,kind", [("LiH.sto6g", "ccsd"), ("H2.321g", "dcsd")])
-def test_unpaired_ring_products_reproduce_reference_energies(sim, monkeypatch, tag, kind):
-    """PYMES_RING_PAIRS=0: the ring builds / applications as four separate products with the half of the C-term inside the
-    D-term product (the form big problems keep; small ones pair the products and let the assembly read Ex_x twice)."""
-    from pymes_amd.solver import ccsd
-    monkeypatch.setenv("PYMES_RING_PAIRS", "0")
-    ref = SOLVES[tag][kind]
-    no, f, V = _problem(tag)
-    s = ccsd.CCSD(no, delta_e=ref["delta_e"], is_dcsd=(kind == "dcsd"))
-    with contextlib.redirect_stdout(io.StringIO()):
-        res = s.solve(f, V)
-    assert s.iterations == ref["iterations"]
-    assert abs(res["ccsd e"] - ref["e"]) < 1e-9
-
-
-@pytest.mark.parametrize("tag,kind", [("LiH.sto6g", "ccsd"), ("H2.321g", "dcsd")])
-def test_ring_operands_by_permutations_reproduce_reference_energies(sim, monkeypatch, tag, kind):
-    """PYMES_NO_RING_OPERANDS=1: the right-hand operands of the ring builds as two permutations and an axpby (what slabs of
-    several ranks keep) instead of the one-pass kernel over V_iabj / V_iajb."""
-    from pymes_amd.solver import ccsd
-    monkeypatch.setenv("PYMES_NO_RING_OPERANDS", "1")
-    ref = SOLVES[tag][kind]
-    no, f, V = _problem(tag)
-    s = ccsd.CCSD(no, delta_e=ref["delta_e"], is_dcsd=(kind == "dcsd"))
-    with contextlib.redirect_stdout(io.StringIO()):
-        res = s.solve(f, V)
-    assert s.iterations == ref["iterations"]
-    assert abs(res["ccsd e"] - ref["e"]) < 1e-9
-
-
 def test_bra_dressing_falls_back_when_its_buffers_do_not_fit(sim, monkeypatch):
     """Out of device memory for the dressed copy of the packed V_abcd (injected in the host simulator): one rank goes on in
     the Q_kb form — same history, nothing leaked."""

@@ -292,35 +292,6 @@ def test_device_resident_diis_gives_the_same_solve(sim, monkeypatch, solver):
     assert s.mixer._state is None and s.mixer.L.shape == (7, 7)          # the state came back to the host when the context closed
 
 
-def test_side_stream_sections_give_the_same_solve(sim, monkeypatch):
-    """The T1 dressing on the context's side stream (own arena / split-K workspace, joined before the hole ladder and the
-    ring products): same iteration history as the one-stream order; the side section may not be nested, and a join
-    without a pending section is a no-op."""
-    no, nv = 3, 7
-    f, V, _, _ = synthetic_case(no, nv, seed=2, scale=0.3)
-    ref = oc.ccsd_solve(no, f, V, delta_e=1e-11)
-    res = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("PYMES_OVERLAP", flag)
-        s = CCSD(no, delta_e=1e-11)
-        r = quiet(s.solve, f, V)
-        res[flag] = (r["ccsd e"], s.iterations, r["t2"])
-    assert res["0"][1] == res["1"][1] == ref["iterations"]
-    assert abs(res["1"][0] - ref["e"]) < 1e-11 and np.abs(res["1"][2] - res["0"][2]).max() < 1e-13
-    ctx = Context(no, nv)
-    ctx.side_join()
-    with ctx.side():
-        with pytest.raises(_lib.PymesError, match="already open"):
-            ctx.lib.call("pymes_side_begin", ctx.handle)
-        x = ctx.array(np.arange(6.0).reshape(2, 3))
-        y = ctx.permute("ab->ba", x)
-    ctx.side_join()
-    assert np.array_equal(y.get(), np.arange(6.0).reshape(2, 3).T)
-    with pytest.raises(_lib.PymesError, match="no side section"):
-        ctx.lib.call("pymes_side_end", ctx.handle)
-    ctx.close()
-
-
 def test_mixer_history_follows_caller_owned_contexts(sim):
     """with caller-owned DeviceIntegrals the DIIS history stays on that context after solve().  A second solve()
     on another context must neither read vectors of a closed context nor pool foreign pointers: the history is parked on
