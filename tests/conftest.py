@@ -28,6 +28,9 @@ def hostsim_lib():
     """Host engine linked against the CPU stand-in for the kernels (tests/hostsim): checks HOST logic only."""
     from pymes_amd import _lib
     d = os.path.join(ROOT, "tests", "hostsim")
+    san = os.environ.get("PYMES_HOSTSIM_LIBRARY")      # a sanitizer build (tests/hostsim/run_sanitized.sh)
+    if san:
+        return hostsim_library(san)
     subprocess.run(["make", "-s", "-C", d], check=True)
     return hostsim_library(os.path.join(d, "_build", "libpymes_hostsim.so"))
 
