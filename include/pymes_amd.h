@@ -409,6 +409,33 @@ int pymes_packed_write(pymes_ctx* ctx, const char* path, int n_elec, double e_co
 int pymes_packed_write_factors(const char* path, int n_elec, int n_orb, int naux, double e_core, const double* eps_host,
                                const double* h_host, const double* B_host);
 
+/* ---- EOM-CCSD sigma build as ONE entry per step: pymes/solver/eom_ccsd.py:268-385 (update_singles + update_doubles) --------
+ * The reference builds sigma = H-bar u term by term from 62 einsums per trial vector.  pymes_eom_sigma_prepare hoists every V.T
+ * product that does not depend on the trial vector (once per solve: the (ov)^2 pair matrices, the o v^3 / o^3 v blocks,
+ * the one-index dressings; ~10 amplitude-sized arrays held by the handle), pymes_eom_sigma_apply builds sigma for k trial
+ * vectors — k >= 2 exchange-symmetric vectors stacked so that every shared operand is read once (the Davidson driver,
+ * eom_ccsd.py:95-101), anything else vector by vector, complex trial vectors as two real ones (the operator is real).
+ *   f_host      T1-dressed Fock matrix [n,n] (host; eom_ccsd.py:46: t_fock_dressed_pq)
+ *   t2_dev      CCSD doubles [v,v,o,o] on the device; must stay alive and unchanged until pymes_eom_sigma_destroy
+ *   dressed     != 0: read the context's T1-dressed blocks (pymes_ccsd_dress_V, all of eom_ccsd.py's ten), else the blocks as set
+ *   u1_dev[z] [v,o], u2_dev[z] [v,v,o,o] in; s1_dev[z], s2_dev[z] out (device; may not alias the inputs)
+ *   sym[z]      != 0: u2[z]_abij = u2[z]_baji is known to hold; sym == NULL: tested (one reduction + synchronisation per vector)
+ *   flags       bit 0 V_abcd = V_badc, 1 T_abij = T_baji, 2 pair-packed hole-ladder terms, 3 fused pair kernels, 4 stacked build
+ * pymes_eom_diagonals: eom_ccsd.py:169-198 (get_diag_singles) and :200-266 (get_diag_doubles) on the device, d1 [v,o],
+ * d2 [v,v,o,o] (needs no handle).  A handle belongs to its context: destroy it before pymes_ctx_destroy. */
+typedef struct pymes_eom pymes_eom;
+int pymes_eom_sigma_prepare(pymes_ctx* ctx, const double* f_host, const double* t2_dev, int dressed, pymes_eom** out);
+int pymes_eom_sigma_flags(pymes_eom* h, int* flags);
+int pymes_eom_sigma_apply(pymes_eom* h, int k, const double* const* u1_dev, const double* const* u2_dev, const int* sym,
+                          double* const* s1_dev, double* const* s2_dev);
+int pymes_eom_diagonals(pymes_ctx* ctx, const double* f_host, const double* t2_dev, int dressed, double* d1_dev, double* d2_dev);
+int pymes_eom_sigma_trim(pymes_eom* h);
+int pymes_eom_sigma_destroy(pymes_eom* h);
+/* (mr + i mi)[e] = 1 / ((zr + i zi) - (hr + i hi) d[e] + shift), e < n: the FEAST preconditioner 1 / (z - diag + 0.01)
+ * (feast_eom_ccsd.py:342; hs = 1j dt for the real-time form :276-278) from the device-resident diagonal */
+int pymes_cshift_inv(pymes_ctx* ctx, const double* d_dev, double zr, double zi, double hr, double hi, double shift,
+                     double* mr_dev, double* mi_dev, int64_t n);
+
 /* ---- explicit 3-body (transcorrelated) operator ---------------------------------------
  * pymes/util/tcdump.py:52-56: dense fill of L[nb]^6 from (flat index, value) pairs — the host parser hands over
  * unique targets (the last of duplicate entries, as the reference's sequential assignment keeps). */

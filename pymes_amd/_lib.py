@@ -128,6 +128,13 @@ SIGNATURES = {
     "pymes_dots_var": (C.c_int, [C.c_void_p, C.c_int, c_pp, c_pp, c_i64_p, c_double_p]),
     "pymes_lincomb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_pp, c_double_p, C.c_int64]),
     "pymes_cmul": (C.c_int, [C.c_void_p] * 7 + [C.c_int64]),
+    "pymes_cshift_inv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_double] * 5 + [C.c_void_p, C.c_void_p, C.c_int64]),
+    "pymes_eom_sigma_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "pymes_eom_sigma_flags": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pymes_eom_sigma_apply": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5),
+    "pymes_eom_diagonals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "pymes_eom_sigma_trim": (C.c_int, [C.c_void_p]),
+    "pymes_eom_sigma_destroy": (C.c_int, [C.c_void_p]),
     "pymes_diis_mix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, c_pp, c_pp, c_i64_p, c_pp, c_pp]),
     "pymes_diis_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "pymes_diis_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_pp, c_pp, c_i64_p, C.c_int, C.c_int, C.c_int]),

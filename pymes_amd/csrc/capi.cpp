@@ -10,6 +10,7 @@
 #include "../../include/pymes_amd.h"
 #include "diis_small.h"
 #include "engine.h"
+#include "eom.h"
 #include "fcidump.h"
 #include "packed.h"
 
@@ -18,6 +19,10 @@ using pymes::TView;
 
 struct pymes_ctx {
     Engine* e;
+};
+struct pymes_eom {
+    pymes::EomSigma* s;
+    pymes_ctx* ctx;
 };
 
 namespace {
@@ -47,6 +52,11 @@ Engine& E(pymes_ctx* c) {               // every other entry point: what is queu
 }
 void need(const void* p, const char* what) {
     if (!p) throw pymes::Error(std::string("null pointer: ") + what);
+}
+pymes::EomSigma& S(pymes_eom* h) {
+    if (!h || !h->s || !h->ctx) throw pymes::Error("null EOM handle");
+    E(h->ctx);                           // the context's device; queued grouped products first
+    return *h->s;
 }
 TView view_of(const double* p, const char* labels, const int64_t* dim, const int64_t* stride) {
     need(p, "tensor data");
@@ -708,6 +718,60 @@ int pymes_cmul(pymes_ctx* ctx, const double* mr, const double* mi, const double*
     return guarded([&] {
         need(mr, "mr"); need(mi, "mi"); need(xr, "xr"); need(xi, "xi"); need(yr, "yr"); need(yi, "yi");
         dev::cmul(mr, mi, xr, xi, yr, yi, n, E(ctx).stream);
+    });
+}
+
+int pymes_cshift_inv(pymes_ctx* ctx, const double* d, double zr, double zi, double hr, double hi, double shift, double* mr,
+                     double* mi, int64_t n) {
+    return guarded([&] {
+        need(d, "d"); need(mr, "mr"); need(mi, "mi");
+        dev::cshift_inv(d, zr, zi, hr, hi, shift, mr, mi, n, E(ctx).stream);
+    });
+}
+
+// ---- EOM-CCSD sigma (eom.cpp) ---------------------------------------------------------------------------------------------------
+int pymes_eom_sigma_prepare(pymes_ctx* ctx, const double* f_host, const double* t2, int dressed, pymes_eom** out) {
+    return guarded([&] {
+        need(out, "out");
+        *out = nullptr;
+        need(f_host, "f_host"); need(t2, "t2");
+        Engine& e = E(ctx);
+        if (e.capturing()) throw pymes::Error("eom_sigma_prepare while a launch graph is being recorded");
+        pymes::EomSigma* s = new pymes::EomSigma(e, f_host, t2, dressed != 0);
+        *out = new pymes_eom{s, ctx};
+    });
+}
+int pymes_eom_sigma_flags(pymes_eom* h, int* flags) {
+    return guarded([&] {
+        need(flags, "flags");
+        *flags = S(h).flags();
+    });
+}
+int pymes_eom_sigma_apply(pymes_eom* h, int k, const double* const* u1, const double* const* u2, const int* sym,
+                          double* const* s1, double* const* s2) {
+    return guarded([&] {
+        need(u1, "u1"); need(u2, "u2"); need(s1, "s1"); need(s2, "s2");
+        if (k < 0 || k > 4096) throw pymes::Error("eom_sigma_apply: 0 <= k <= 4096");
+        for (int z = 0; z < k; ++z)
+            if (u2[z] == s2[z] || u1[z] == s1[z]) throw pymes::Error("eom_sigma_apply: output aliases input");
+        S(h).apply(k, u1, u2, sym, s1, s2);
+    });
+}
+int pymes_eom_diagonals(pymes_ctx* ctx, const double* f_host, const double* t2, int dressed, double* d1, double* d2) {
+    return guarded([&] {
+        need(f_host, "f_host"); need(t2, "t2"); need(d1, "d1"); need(d2, "d2");
+        pymes::eom_diagonals(E(ctx), f_host, t2, dressed != 0, d1, d2);
+    });
+}
+int pymes_eom_sigma_trim(pymes_eom* h) {
+    return guarded([&] { S(h).trim(); });
+}
+int pymes_eom_sigma_destroy(pymes_eom* h) {
+    return guarded([&] {
+        if (!h) return;
+        if (h->ctx && h->ctx->e) dev::set_device(h->ctx->e->device);
+        delete h->s;
+        delete h;
     });
 }
 

@@ -170,6 +170,15 @@ void lincomb_dev(double* out, int nx, const double* const* x, const double* coef
 // (yr + i yi)[e] = (mr + i mi)[e] * (xr + i xi)[e]: a complex diagonal applied to a complex vector held as two real arrays
 // (y may alias x)
 void cmul(const double* mr, const double* mi, const double* xr, const double* xi, double* yr, double* yi, int64_t n, stream_t s);
+// (mr + i mi)[e] = 1 / ((zr + i zi) - (hr + i hi) d[e] + shift): that preconditioner from the device-resident diagonal
+void cshift_inv(const double* d, double zr, double zi, double hr, double hi, double shift, double* mr, double* mi, int64_t n,
+                stream_t s);
+// EOM-CCSD diagonals (eom_ccsd.py:169-198 singles, :200-266 doubles): V = V_ijab [o,o,v,v], T [v,v,o,o], dai[a,i] = f_aa - f_ii,
+// the four diagonal slices iaai[a,i] = V_iabj[i,a,a,i], iaia[a,i] = V_iajb[i,a,i,a], ijij[i,j] = V_klij[i,j,i,j],
+// abab[a,b] = V_abcd[a,b,a,b] (all device); d1 [v,o], d2 [v,v,o,o]; ws: eom_diag_ws_doubles(no, nv) doubles
+int64_t eom_diag_ws_doubles(int no, int nv);
+void eom_diagonals(const double* V, const double* T, const double* dai, const double* iaai, const double* iaia, const double* ijij,
+                   const double* abab, double* d1, double* d2, int no, int nv, double* ws, stream_t s);
 // tau[a,b,i,j] = t2[a,b,i,j] + t1[a,i]*t1[b,j]                        (ccsd.py:462)
 void tau_build(double* tau, const double* t2, const double* t1, int no, int nv, stream_t s);
 

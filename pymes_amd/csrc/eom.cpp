@@ -1,0 +1,516 @@
+// EOM-CCSD sigma build and diagonals on the engine (see eom.h).  Term by term this is pymes/solver/eom_ccsd.py:268-385 with
+// every V.T product that does not depend on the trial vector hoisted into per-solve intermediates; the comments name the
+// reference lines.  Pair layouts (ov x ov matrices): Xd[(a,i),(b,j)] = X[a,b,i,j], Xx[(a,j),(b,i)] = X[a,b,i,j].
+#include "eom.h"
+
+#include <algorithm>
+#include <cmath>
+#include <initializer_list>
+#include <string>
+
+namespace pymes {
+
+// ---- pooled temporaries -------------------------------------------------------------------------------------------------
+double* EomSigma::get(int64_t doubles) {
+    auto it = free_.find(doubles);
+    double* p;
+    if (it != free_.end()) {
+        p = it->second;
+        free_.erase(it);
+    } else {
+        p = static_cast<double*>(dev::try_dmalloc(sizeof(double) * static_cast<size_t>(std::max<int64_t>(doubles, 1))));
+        if (!p) {
+            trim();
+            p = static_cast<double*>(dev::try_dmalloc(sizeof(double) * static_cast<size_t>(std::max<int64_t>(doubles, 1))));
+        }
+        if (!p) throw Error("eom sigma: out of device memory (" + std::to_string((doubles * 8) >> 20) + " MiB temporary)");
+    }
+    live_[p] = doubles;
+    return p;
+}
+void EomSigma::put(double* p) {
+    auto it = live_.find(p);
+    if (it == live_.end()) return;
+    free_.emplace(it->second, p);
+    live_.erase(it);
+}
+void EomSigma::trim() {
+    if (free_.empty()) return;
+    dev::stream_sync(e.stream);
+    for (auto& kv : free_) dev::dfree(kv.second);
+    free_.clear();
+}
+double* EomSigma::keep(int64_t doubles) {
+    double* p = static_cast<double*>(dev::dmalloc(sizeof(double) * static_cast<size_t>(std::max<int64_t>(doubles, 1))));
+    owned_.push_back(p);
+    return p;
+}
+struct EomSigma::Tmp {
+    EomSigma& s;
+    double* p;
+    Tmp(EomSigma& s_, int64_t n) : s(s_), p(s_.get(n)) {}
+    ~Tmp() { s.put(p); }
+    Tmp(const Tmp&) = delete;
+    Tmp& operator=(const Tmp&) = delete;
+    operator double*() const { return p; }
+};
+
+namespace {
+struct Ops {       // the three engine calls every term is made of, with the output allocated by the caller
+    Engine& e;
+    void C(double al, const TView& A, const char* sa, const TView& B, const char* sb, double be, const TView& Cv, const char* sc,
+           const char* batch = "") const {
+        e.contract(al, A, sa, B, sb, be, Cv, sc, batch);
+    }
+    void P(double al, const TView& in, const char* si, double be, const TView& out, const char* so) const {
+        e.permute(al, in, si, be, out, so);
+    }
+    void L(double* out, std::initializer_list<const double*> xs, std::initializer_list<double> cs, int64_t n) const {
+        const double* x[8];
+        double c[8];
+        int m = 0;
+        auto ci = cs.begin();
+        for (auto xp : xs) { x[m] = xp; c[m] = *ci++; ++m; }
+        dev::lincomb(out, m, x, c, n, e.stream);
+    }
+};
+inline TView mv(const double* p, std::initializer_list<int64_t> d) { return make_view(p, d); }
+}  // namespace
+
+TView EomSigma::V(const char* name) const { return e.block(pattern_of_name(name), dressed); }
+
+bool EomSigma::exchange_symmetric(const double* x, int64_t d0, int64_t d2) const {
+    const int64_t d[4] = {d0, d0, d2, d2};
+    double out[2] = {0.0, 0.0};
+    dev::exchange_asymmetry(x, x, d, out, e.stream);
+    return std::isfinite(out[1]) && out[0] <= 1e-13 * std::max(1.0, out[1]);      // inf / NaN entries: never "symmetric"
+}
+
+int EomSigma::flags() const {
+    return (v_sym ? 1 : 0) | (t_sym ? 2 : 0) | (hole_sym ? 4 : 0) | (fused_ok ? 8 : 0) | (many_ok ? 16 : 0);
+}
+
+EomSigma::~EomSigma() {
+    try {
+        dev::set_device(e.device);
+        dev::stream_sync(e.stream);
+        for (auto& kv : free_) dev::dfree(kv.second);
+        for (auto& kv : live_) dev::dfree(kv.first);
+        for (double* p : owned_) dev::dfree(p);
+    } catch (...) {
+    }
+}
+
+// ---- hoisting: everything of eom_ccsd.py:288-373 that does not depend on (u1, u2) -----------------------------------------
+EomSigma::EomSigma(Engine& eng, const double* f_host, const double* t2, bool dressed_)
+    : e(eng), no(eng.no), nv(eng.nv), dressed(dressed_), T(t2) {
+    if (!f_host || !t2) throw Error("eom sigma: null Fock matrix / amplitudes");
+    const int64_t o = no, v = nv, n = o + v, ov = o * v, ov2 = ov * ov;
+    const Ops q{e};
+    try {
+        std::vector<double> h(static_cast<size_t>(std::max(v * v, o * v)));
+        auto upload = [&](int64_t r0, int64_t nr, int64_t c0, int64_t nc, double sign, bool transposed = false) {
+            for (int64_t r = 0; r < nr; ++r)
+                for (int64_t c = 0; c < nc; ++c)
+                    h[transposed ? c * nr + r : r * nc + c] = sign * f_host[(r0 + r) * n + c0 + c];
+            double* d = keep(nr * nc);
+            dev::memcpy_h2d(d, h.data(), sizeof(double) * nr * nc, e.stream);
+            dev::stream_sync(e.stream);            // (h is reused)
+            return d;
+        };
+        foo = upload(0, o, 0, o, 1.0);
+        fov = upload(0, o, o, v, 1.0);
+        fvv = upload(o, v, o, v, 1.0);
+        const TView Vijab = V("ijab"), Viabj = V("iabj"), Viajb = V("iajb"), Vijka = V("ijka"), Vijak = V("ijak"),
+                    Viabc = V("iabc"), Viajk = V("iajk"), Vklij = V("klij"), Vabcd = V("abcd");
+        V("abic");
+        const TView T4 = mv(T, {v, v, o, o});
+        Td = keep(ov2);
+        Tx = keep(ov2);
+        q.P(1.0, T4, "abij", 0.0, mv(Td, {v, o, v, o}), "aibj");
+        q.P(1.0, T4, "abij", 0.0, mv(Tx, {v, o, v, o}), "ajbi");
+        {
+            Tmp Vd(*this, ov2), Vx(*this, ov2);
+            q.P(1.0, Vijab, "klcd", 0.0, mv(Vd, {v, o, v, o}), "ckdl");          // [(c,k),(d,l)]
+            q.P(1.0, Vijab, "klcd", 0.0, mv(Vx, {v, o, v, o}), "cldk");          // [(c,l),(d,k)]
+            // ---- singles (eom_ccsd.py:288-308) ---------------------------------------------------------------------------
+            // W1[(c,k),(a,i)] = sum_jb (2V[j,k,b,c]-V[j,k,c,b]) (2T[b,a,j,i]-T[a,b,j,i]) + 2V_iabj[k,a,c,i] - V_iajb[k,a,i,c]
+            W1 = keep(ov2);
+            {
+                Tmp Vq(*this, ov2), Tq(*this, ov2);
+                q.P(2.0, Vijab, "jkbc", 0.0, mv(Vq, {v, o, v, o}), "ckbj");
+                q.P(-1.0, Vijab, "jkcb", 1.0, mv(Vq, {v, o, v, o}), "ckbj");
+                q.P(2.0, T4, "baji", 0.0, mv(Tq, {v, o, v, o}), "bjai");
+                q.P(-1.0, T4, "abji", 1.0, mv(Tq, {v, o, v, o}), "bjai");
+                q.C(1.0, mv(Vq, {v, o, v, o}), "ckbj", mv(Tq, {v, o, v, o}), "bjai", 0.0, mv(W1, {v, o, v, o}), "ckai");
+            }
+            q.P(2.0, Viabj, "kaci", 1.0, mv(W1, {v, o, v, o}), "ckai");
+            q.P(-1.0, Viajb, "kaic", 1.0, mv(W1, {v, o, v, o}), "ckai");
+            // Gvv_s[a,c] = fvv + sum V[j,k,b,c] (-2T[b,a,j,k] + T[a,b,j,k]);  Goo_s[k,i] = -foo + sum (-2V[j,k,b,c]+V[j,k,c,b]) T[b,c,j,i]
+            Gvv_s = keep(v * v);
+            q.L(Gvv_s, {fvv}, {1.0}, v * v);
+            q.C(-2.0, Vijab, "jkbc", T4, "bajk", 1.0, mv(Gvv_s, {v, v}), "ac");
+            q.C(1.0, Vijab, "jkbc", T4, "abjk", 1.0, mv(Gvv_s, {v, v}), "ac");
+            Goo_s = keep(o * o);
+            q.L(Goo_s, {foo}, {-1.0}, o * o);
+            q.C(-2.0, Vijab, "jkbc", T4, "bcji", 1.0, mv(Goo_s, {o, o}), "ki");
+            q.C(1.0, Vijab, "jkcb", T4, "bcji", 1.0, mv(Goo_s, {o, o}), "ki");
+            // ---- doubles: (V.T) pair matrices (eom_ccsd.py:352-372) --------------------------------------------------------
+            M_C = keep(ov2);
+            M_D = keep(ov2);
+            M1 = keep(ov2);
+            Ud = keep(ov2);
+            M2 = keep(ov2);
+            M12 = keep(ov2);
+            MDU = keep(ov2);
+            const TView Tdv = mv(Td, {v, o, v, o}), Txv = mv(Tx, {v, o, v, o});
+            {
+                Tmp M_A(*this, ov2), M_B(*this, ov2);
+                q.C(1.0, Tdv, "ckai", mv(Vd, {v, o, v, o}), "ckdl", 0.0, mv(M_A, {v, o, v, o}), "aidl");   // sum_kc V[k,l,c,d] T[c,a,k,i]
+                q.C(1.0, Txv, "aick", mv(Vd, {v, o, v, o}), "ckdl", 0.0, mv(M_B, {v, o, v, o}), "aidl");   // sum_kc V[k,l,c,d] T[a,c,k,i]
+                q.C(1.0, Tdv, "ckai", mv(Vx, {v, o, v, o}), "dlck", 0.0, mv(M_C, {v, o, v, o}), "aidl");   // sum_kc V[k,l,d,c] T[c,a,k,i]
+                q.C(1.0, Txv, "aick", mv(Vx, {v, o, v, o}), "dlck", 0.0, mv(M_D, {v, o, v, o}), "aidl");   // sum_kc V[k,l,d,c] T[a,c,k,i]
+                q.P(1.0, Viabj, "kaci", 0.0, mv(M1, {v, o, v, o}), "aick");      // Wd'[(a,i),(c,k)] = V_iabj[k,a,c,i]
+                q.L(M1, {M1, M_A, M_B}, {1.0, 2.0, -1.0}, ov2);
+            }
+            q.P(1.0, Viajb, "kaic", 0.0, mv(Ud, {v, o, v, o}), "aick");          // Ud[(a,i),(c,k)] = V_iajb[k,a,i,c]
+            q.L(M2, {M_D, M_C, Ud}, {1.0, -2.0, -1.0}, ov2);
+            // exchange-symmetric trial doubles: M1.utd + M2.u2d + M_C.u2x = (2 M1 + M2).utd / 2 + (M_D - Ud).u2x / 2
+            q.L(M12, {M1, M2}, {2.0, 1.0}, ov2);
+            q.L(MDU, {M_D, Ud}, {1.0, -1.0}, ov2);
+        }
+        // V_kacd.T products of the u1 terms (eom_ccsd.py:334, :343, :345, :346), u-independent like the pair matrices above:
+        //   WA[a,d,b,j] = sum_ck (2 V[k,a,c,d] - V[k,a,d,c]) T[c,b,k,j] - V[k,a,c,d] T[b,c,k,j],   W3[a,d,b,i] = sum_ck V[k,a,d,c] T[b,c,k,i]
+        WA = keep(v * v * v * o);
+        W3 = keep(v * v * v * o);
+        q.C(2.0, Viabc, "kacd", T4, "cbkj", 0.0, mv(WA, {v, v, v, o}), "adbj");
+        q.C(-1.0, Viabc, "kadc", T4, "cbkj", 1.0, mv(WA, {v, v, v, o}), "adbj");
+        q.C(-1.0, Viabc, "kacd", T4, "bckj", 1.0, mv(WA, {v, v, v, o}), "adbj");
+        q.C(1.0, Viabc, "kadc", T4, "bcki", 0.0, mv(W3, {v, v, v, o}), "adbi");
+        // small hoisted V.T blocks
+        A3 = keep(o * o * v * o);
+        q.C(-2.0, Vijak, "klci", T4, "cbkj", 0.0, mv(A3, {o, o, v, o}), "libj");      // A_oovo
+        q.C(1.0, Vijka, "klic", T4, "cbkj", 1.0, mv(A3, {o, o, v, o}), "libj");
+        q.C(1.0, Vijak, "kldi", T4, "bdkj", 1.0, mv(A3, {o, o, v, o}), "libj");
+        A4 = keep(o * o * v * o);
+        q.C(1.0, Vijka, "klid", T4, "adkj", 0.0, mv(A4, {o, o, v, o}), "liaj");
+        A6 = keep(o * v * o * o);
+        q.C(1.0, Viabc, "lacd", T4, "cdji", 0.0, mv(A6, {o, v, o, o}), "laji");
+        Gvv = keep(v * v);
+        q.L(Gvv, {fvv}, {1.0}, v * v);
+        q.C(-2.0, Vijab, "klcd", T4, "cakl", 1.0, mv(Gvv, {v, v}), "ad");
+        q.C(1.0, Vijab, "klcd", T4, "ackl", 1.0, mv(Gvv, {v, v}), "ad");
+        Goo = keep(o * o);
+        q.L(Goo, {foo}, {-1.0}, o * o);
+        q.C(-2.0, Vijab, "klcd", T4, "cdki", 1.0, mv(Goo, {o, o}), "li");
+        q.C(1.0, Vijab, "kldc", T4, "cdki", 1.0, mv(Goo, {o, o}), "li");
+        B2 = keep(o * o * o * o);
+        q.P(1.0, Vklij, "klij", 0.0, mv(B2, {o, o, o, o}), "klij");
+        q.C(1.0, Vijab, "klcd", T4, "cdij", 1.0, mv(B2, {o, o, o, o}), "klij");
+        // particle ladder (:383): pair-packed form (1/4 of the flops) whenever V_abcd = V_badc and the trial doubles are
+        // exchange-symmetric — true for every vector the Davidson driver generates
+        v_sym = exchange_symmetric(Vabcd.p, v, v);
+        // T_abij = T_baji (every CCSD solution): P(ijab,jiba)[T B5] = T (B5 + B5^(lkji)), so that term rides in the product
+        // with B' of eom_ccsd.py:381 — one v^2 o^4 product less per sigma
+        fused_ok = dev::fused_pair_kernels_ok(no);
+        t_sym = exchange_symmetric(T, v, o);
+        // eom_ccsd.py:380-382 in pair-packed rows needs B2_klij = B2_lkji and V_klcd = V_lkdc
+        hole_sym = t_sym && exchange_symmetric(B2, o, o) && exchange_symmetric(Vijab.p, o, v);
+        if (v_sym) L = keep(v * (v + 1) / 2 * o * o);
+        many_ok = v_sym && hole_sym && fused_ok && t_sym;
+        if (many_ok) {
+            fovT = upload(0, o, o, v, 1.0, true);
+            // WA / W3 with the contracted index third: u1[d,i] then meets WA[a,b,d,:] as a batch of (a,b) products whose
+            // o x o results ARE the tiles D[z,a,b,:,:]
+            WAt = keep(v * v * v * o);
+            W3t = keep(v * v * v * o);
+            q.P(1.0, mv(WA, {v, v, v, o}), "adbj", 0.0, mv(WAt, {v, v, v, o}), "abdj");
+            q.P(1.0, mv(W3, {v, v, v, o}), "adbi", 0.0, mv(W3t, {v, v, v, o}), "abdi");
+            // the four u1 terms with one free index on u1 (A_oovo, A4, A6, V_iajk) as ONE product u1[a,l] A346[l,b,i,j]:
+            // everything added to D is symmetrised by P(ijab,jiba) afterwards (:377), so a term X_abij may be replaced by its
+            // partner X_baji
+            A346 = keep(o * v * o * o);
+            q.P(1.0, mv(A3, {o, o, v, o}), "libj", 0.0, mv(A346, {o, v, o, o}), "lbij");
+            q.P(1.0, mv(A4, {o, o, v, o}), "ljbi", 1.0, mv(A346, {o, v, o, o}), "lbij");
+            q.L(A346, {A346, A6, Viajk.p}, {1.0, -1.0, -1.0}, o * v * o * o);
+        }
+        trim();
+    } catch (...) {
+        try {
+            dev::stream_sync(e.stream);
+        } catch (...) {
+        }
+        for (auto& kv : free_) dev::dfree(kv.second);
+        for (auto& kv : live_) dev::dfree(kv.first);
+        for (double* p : owned_) dev::dfree(p);
+        free_.clear(); live_.clear(); owned_.clear();
+        throw;
+    }
+}
+
+// ---- eom_ccsd.py:268-310 -------------------------------------------------------------------------------------------------------
+void EomSigma::singles(const double* u1, const double* u2, double* s1) {
+    const int64_t o = no, v = nv;
+    const Ops q{e};
+    const TView U1 = mv(u1, {v, o}), U2 = mv(u2, {v, v, o, o}), S = mv(s1, {v, o});
+    Tmp ut(*this, v * v * o * o);                                      // 2 u2[a,b,i,j] - u2[b,a,i,j]
+    const TView Ut = mv(ut, {v, v, o, o});
+    q.P(2.0, U2, "abij", 0.0, Ut, "abij");
+    q.P(-1.0, U2, "baij", 1.0, Ut, "abij");
+    q.C(1.0, U1, "ck", mv(W1, {v, o, v, o}), "ckai", 0.0, S, "ai");
+    q.C(1.0, mv(Gvv_s, {v, v}), "ac", U1, "ci", 1.0, S, "ai");
+    q.C(1.0, U1, "ak", mv(Goo_s, {o, o}), "ki", 1.0, S, "ai");
+    q.C(1.0, mv(fov, {o, v}), "jb", Ut, "baji", 1.0, S, "ai");
+    q.C(-1.0, V("ijka"), "jkib", Ut, "abjk", 1.0, S, "ai");
+    q.C(1.0, V("iabc"), "jabc", Ut, "bcji", 1.0, S, "ai");
+}
+
+// ---- eom_ccsd.py:312-385 -------------------------------------------------------------------------------------------------------
+void EomSigma::doubles(const double* u1, const double* u2, bool u2_sym, double* s2) {
+    const int64_t o = no, v = nv, ov = o * v, ov2 = ov * ov, npp = v * (v + 1) / 2;
+    const Ops q{e};
+    const TView U1 = mv(u1, {v, o}), U2 = mv(u2, {v, v, o, o}), T4 = mv(T, {v, v, o, o});
+    const TView Vijab = V("ijab"), Vijka = V("ijka"), Vijak = V("ijak"), Viabc = V("iabc");
+    auto P4 = [&](double* p) { return mv(p, {v, o, v, o}); };
+    Tmp u2x(*this, ov2), utd(*this, ov2), Dx(*this, ov2), Dd(*this, ov2);
+    q.P(1.0, U2, "abij", 0.0, P4(u2x), "ajbi");
+    // ---- (ov)^3 products ---------------------------------------------------------------------------------------------------
+    q.P(2.0, U2, "abij", 0.0, P4(utd), "aibj");                         // ut[d,b,l,j] = 2u2[d,b,l,j] - u2[b,d,l,j]
+    q.P(-1.0, U2, "baij", 1.0, P4(utd), "aibj");
+    if (u2_sym) {
+        // exchange-symmetric u2: utd = 2 u2d - u2x as matrices, hence M1.utd + M2.u2d + M_C.u2x = (2 M1 + M2).utd / 2 +
+        // (M_D - Ud).u2x / 2, and the second product IS Dx (the C / D form of the ring terms): TWO (ov)^3 products per sigma
+        q.C(1.0, P4(MDU), "ajdl", P4(u2x), "dlbi", 0.0, P4(Dx), "ajbi");                       // :372 and :364 (transposed)
+        q.P(0.5, P4(Dx), "ajbi", 0.0, P4(Dd), "ajbi");                                         // same memory layout as "aibj"
+        q.C(0.5, P4(M12), "aidl", P4(utd), "dlbj", 1.0, P4(Dd), "aibj");
+    } else {
+        Tmp u2d(*this, ov2);
+        q.P(1.0, U2, "abij", 0.0, P4(u2d), "aibj");
+        q.C(1.0, P4(M1), "aidl", P4(utd), "dlbj", 0.0, P4(Dd), "aibj");
+        q.C(1.0, P4(M2), "aidl", P4(u2d), "dlbj", 1.0, P4(Dd), "aibj");
+        q.C(1.0, P4(M_C), "aidl", P4(u2x), "dlbj", 1.0, P4(Dd), "aibj");                      // u2x[(d,l),(b,j)] = u2[d,b,j,l]
+        q.C(1.0, P4(M_D), "ajdl", P4(u2x), "dlbi", 0.0, P4(Dx), "ajbi");                      // :372  u2[d,b,i,l]
+        q.C(-1.0, P4(u2x), "ajck", P4(Ud), "bick", 1.0, P4(Dx), "ajbi");                      // :364
+    }
+    // ---- one-index dressings ---------------------------------------------------------------------------------------------------
+    Tmp Xoo(*this, o * o), Xvv(*this, v * v), B5(*this, o * o * o * o);
+    const TView XooV = mv(Xoo, {o, o}), XvvV = mv(Xvv, {v, v}), FOV = mv(fov, {o, v});
+    q.C(-2.0, Vijka, "klid", U1, "dl", 0.0, XooV, "ki");
+    q.C(1.0, Vijak, "kldi", U1, "dl", 1.0, XooV, "ki");
+    q.C(-1.0, FOV, "kd", U1, "di", 1.0, XooV, "ki");
+    q.C(-2.0, Vijab, "kldc", U2, "dcil", 1.0, XooV, "ki");
+    q.C(1.0, Vijab, "kldc", U2, "dcli", 1.0, XooV, "ki");
+    q.C(1.0, XooV, "ki", P4(Td), "akbj", 1.0, P4(Dd), "aibj", "a");
+    q.C(2.0, Viabc, "ladc", U1, "dl", 0.0, XvvV, "ac");
+    q.C(-1.0, Viabc, "lacd", U1, "dl", 1.0, XvvV, "ac");
+    q.C(-1.0, U1, "al", FOV, "lc", 1.0, XvvV, "ac");
+    q.C(-2.0, Vijab, "lkcd", U2, "adlk", 1.0, XvvV, "ac");
+    q.C(1.0, Vijab, "lkcd", U2, "dalk", 1.0, XvvV, "ac");
+    const bool packed = v_sym && u2_sym && hole_sym;
+    const bool fused = packed && fused_ok;
+    // D goes straight into the caller's array unless the fused assembly needs it as an input
+    Tmp Dtmp(*this, fused ? v * v * o * o : 1);
+    double* Dp = fused ? Dtmp.p : s2;
+    const TView D = mv(Dp, {v, v, o, o});
+    q.C(1.0, XvvV, "ac", T4, "cbij", 0.0, D, "abij");
+    // V_kacd.T.u1 terms (:334, :343, :345, :346) through the hoisted V.T intermediates: o^2 v^3 instead of (ov)^3 each
+    q.C(1.0, mv(WA, {v, v, v, o}), "adbj", U1, "di", 1.0, D, "abij");
+    q.C(-1.0, mv(W3, {v, v, v, o}), "adbi", U1, "dj", 1.0, D, "abij");
+    q.C(1.0, mv(Gvv, {v, v}), "ad", U2, "dbij", 1.0, D, "abij");
+    q.C(1.0, mv(Goo, {o, o}), "li", U2, "ablj", 1.0, D, "abij", "ab");
+    q.C(1.0, U1, "al", mv(A3, {o, o, v, o}), "libj", 1.0, D, "abij");
+    q.C(1.0, U1, "bl", mv(A4, {o, o, v, o}), "liaj", 1.0, D, "abij");
+    q.C(-1.0, U1, "bl", mv(A6, {o, v, o, o}), "laji", 1.0, D, "abij");
+    const TView B5v = mv(B5, {o, o, o, o});
+    q.C(1.0, Vijka, "klid", U1, "dj", 0.0, B5v, "klij");
+    if (!t_sym) q.C(1.0, T4, "abkl", B5v, "klij", 1.0, D, "abij");
+    q.C(-1.0, U1, "ak", V("iajk"), "kbij", 1.0, D, "abij");
+    q.C(1.0, V("abic"), "abic", U1, "cj", 1.0, D, "abij");
+    auto packed_terms = [&]() {       // the terms (:380-383) that stay outside P(ijab,jiba), in the pair-packed rows L
+        Tmp B5s(*this, o * o * o * o);
+        q.P(1.0, B5v, "klij", 0.0, mv(B5s, {o, o, o, o}), "klij");
+        q.P(1.0, B5v, "lkji", 1.0, mv(B5s, {o, o, o, o}), "klij");
+        e.ladder_sym(u2, L, 0, npp, dressed, 0);
+        e.hole_ladder_packed(u2, B2, L, 0, npp, nullptr);
+        e.hole_ladder_packed(T, B5s, L, 0, npp, u2);
+    };
+    if (fused) {
+        // symmetrisation (:377) of D and of the two pair matrices and the unpacking of L in ONE pass (the assembly kernel of
+        // the CCSD residual)
+        packed_terms();
+        dev::residual_assemble(nullptr, L, Dp, Dd, Dx, s2, no, nv, e.stream);
+        return;
+    }
+    q.P(1.0, P4(Dd), "aibj", 1.0, D, "abij");
+    q.P(1.0, P4(Dx), "ajbi", 1.0, D, "abij");
+    // ---- P(ijab, jiba) (:377), then the unpermuted terms (:380-383) ------------------------------------------------------------
+    {
+        Tmp S(*this, v * v * o * o);
+        q.P(1.0, D, "baji", 0.0, mv(S, {v, v, o, o}), "abij");
+        q.L(Dp, {Dp, S}, {1.0, 1.0}, v * v * o * o);
+    }
+    if (packed) {
+        packed_terms();
+        e.ladder_sym_unpack(L, Dp, 1.0);
+        return;
+    }
+    Tmp Bn(*this, o * o * o * o);
+    const TView BnV = mv(Bn, {o, o, o, o});
+    q.C(1.0, Vijab, "kldc", U2, "dcij", 0.0, BnV, "klij");
+    if (t_sym) {                       // + the symmetrised u1 term that was held back above
+        q.P(1.0, B5v, "klij", 1.0, BnV, "klij");
+        q.P(1.0, B5v, "lkji", 1.0, BnV, "klij");
+    }
+    q.C(1.0, U2, "abkl", mv(B2, {o, o, o, o}), "klij", 1.0, D, "abij");               // :380, :382
+    q.C(1.0, T4, "abkl", BnV, "klij", 1.0, D, "abij");                                  // :381
+    if (v_sym && u2_sym) {                                                              // :383
+        e.ladder_sym(u2, L, 0, npp, dressed, 0);
+        e.ladder_sym_unpack(L, Dp, 1.0);
+    } else {
+        q.C(1.0, V("abcd"), "abcd", U2, "cdij", 1.0, D, "abij");
+    }
+}
+
+int EomSigma::stack_limit() const {
+    // nine (ov)^2-sized temporaries per vector (X, Tt, DxT, DdT, D, the packed ladder rows and their operands) must fit in
+    // half of what the device has free right now (pooled buffers count as free)
+    int64_t pooled = 0;
+    for (auto& kv : free_) pooled += kv.first * 8;
+    const double free_b = static_cast<double>(dev::mem_free_bytes()) + static_cast<double>(pooled);
+    const double per_vector = 9.0 * 8.0 * static_cast<double>(no) * nv * static_cast<double>(no) * nv;
+    return static_cast<int>(std::max(1.0, std::min(16.0, std::floor(free_b / 2.0 / std::max(per_vector, 1.0)))));
+}
+
+// ---- sigma for k exchange-symmetric trial vectors at once: every operand that does not depend on the vector is read ONCE ----
+void EomSigma::stack(int k, const double* const* u1, const double* const* u2, double* const* s1, double* const* s2) {
+    const int64_t o = no, v = nv, ov = o * v, ov2 = ov * ov, npp = v * (v + 1) / 2, K = k;
+    const Ops q{e};
+    const TView Vijab = V("ijab"), Vijka = V("ijka"), Vijak = V("ijak"), Viabc = V("iabc"), T4 = mv(T, {v, v, o, o});
+    Tmp U1(*this, K * v * o), X(*this, K * ov2), Tt(*this, K * ov2);
+    for (int z = 0; z < k; ++z) {
+        dev::memcpy_d2d(U1.p + z * v * o, u1[z], sizeof(double) * v * o, e.stream);
+        // X[z,(a,j),(b,i)] = u2_z[a,b,i,j], Tt[z,(a,i),(b,j)] = 2 u2_z[a,b,i,j] - u2_z[b,a,i,j]        (symmetric matrices)
+        dev::t2_layouts(u2[z], nullptr, X.p + z * ov2, Tt.p + z * ov2, no, nv, e.stream);
+    }
+    const TView U1v = mv(U1, {K, v, o}), Xv = mv(X, {K, v, o, v, o}), Ttv = mv(Tt, {K, v, o, v, o});
+    // ---- singles (eom_ccsd.py:268-310), ut[a,b,i,j] = Tt[(a,i),(b,j)] -----------------------------------------------------------
+    Tmp S1(*this, K * v * o);
+    const TView S1v = mv(S1, {K, v, o});
+    q.C(1.0, U1v, "zck", mv(W1, {v, o, v, o}), "ckai", 0.0, S1v, "zai");
+    q.C(1.0, mv(Gvv_s, {v, v}), "ac", U1v, "zci", 1.0, S1v, "zai", "z");
+    q.C(1.0, U1v, "zak", mv(Goo_s, {o, o}), "ki", 1.0, S1v, "zai");
+    q.C(1.0, Ttv, "zaibj", mv(fovT, {v, o}), "bj", 1.0, S1v, "zai");
+    q.C(-1.0, Ttv, "zajbk", Vijka, "jkib", 1.0, S1v, "zai");
+    q.C(1.0, Viabc, "jabc", Ttv, "zbjci", 1.0, S1v, "zai", "z");                       // (z as a batch: Tt is read in place)
+    // ---- (ov)^3 products, transposed: only Dx + Dx^T and Dd + Dd^T enter (:377), X and Tt are symmetric matrices ---------------
+    Tmp DxT(*this, K * ov2), DdT(*this, K * ov2);
+    const TView DxTv = mv(DxT, {K, v, o, v, o}), DdTv = mv(DdT, {K, v, o, v, o});
+    q.C(1.0, Xv, "zajdl", mv(MDU, {v, o, v, o}), "bidl", 0.0, DxTv, "zajbi");          // (MDU . u2x)^T per vector
+    q.P(0.5, DxTv, "zajbi", 0.0, DdTv, "zajbi");                                        // same memory layout as "zaibj"
+    q.C(0.5, Ttv, "zaidl", mv(M12, {v, o, v, o}), "bjdl", 1.0, DdTv, "zaibj");
+    // ---- one-index dressings -------------------------------------------------------------------------------------------------------
+    Tmp Xoo(*this, K * o * o), Xvv(*this, K * v * v);
+    const TView XooV = mv(Xoo, {K, o, o}), XvvV = mv(Xvv, {K, v, v}), FOV = mv(fov, {o, v});
+    q.C(-2.0, Vijka, "klid", U1v, "zdl", 0.0, XooV, "zki");
+    q.C(1.0, Vijak, "kldi", U1v, "zdl", 1.0, XooV, "zki");
+    q.C(-1.0, FOV, "kd", U1v, "zdi", 1.0, XooV, "zki", "z");
+    q.C(-2.0, Vijab, "kldc", Xv, "zdlci", 1.0, XooV, "zki", "z");                      // u2[d,c,i,l] = X[(d,l),(c,i)]
+    q.C(1.0, Vijab, "kldc", Xv, "zdicl", 1.0, XooV, "zki", "z");                       // u2[d,c,l,i] = X[(d,i),(c,l)]
+    q.C(1.0, XooV, "zki", mv(Td, {v, o, v, o}), "akbj", 1.0, DdTv, "zaibj", "za");
+    q.C(2.0, Viabc, "ladc", U1v, "zdl", 0.0, XvvV, "zac");
+    q.C(-1.0, Viabc, "lacd", U1v, "zdl", 1.0, XvvV, "zac");
+    q.C(-1.0, U1v, "zal", FOV, "lc", 1.0, XvvV, "zac");
+    q.C(-2.0, Vijab, "lkcd", Xv, "zakdl", 1.0, XvvV, "zac", "z");                      // u2[a,d,l,k] = X[(a,k),(d,l)]
+    q.C(1.0, Vijab, "lkcd", Xv, "zdkal", 1.0, XvvV, "zac", "z");                       // u2[d,a,l,k] = X[(d,k),(a,l)]
+    Tmp D(*this, K * v * v * o * o);
+    const TView Dv = mv(D, {K, v, v, o, o});
+    q.C(1.0, XvvV, "zac", T4, "cbij", 0.0, Dv, "zabij");
+    q.C(1.0, mv(WAt, {v, v, v, o}), "abdj", U1v, "zdi", 1.0, Dv, "zabij", "zab");
+    q.C(-1.0, mv(W3t, {v, v, v, o}), "abdi", U1v, "zdj", 1.0, Dv, "zabij", "zab");
+    q.C(1.0, U1v, "zal", mv(A346, {o, v, o, o}), "lbij", 1.0, Dv, "zabij");
+    q.C(1.0, V("abic"), "abic", U1v, "zcj", 1.0, Dv, "zabij", "z");
+    Tmp Lall(*this, K * npp * o * o);
+    e.ladder_sym_multi(u2, k, Lall, dressed);                                           // :383, all vectors
+    Tmp B5(*this, K * o * o * o * o), B5s(*this, K * o * o * o * o);
+    std::vector<const double*> b2s(k, B2), ts(k, T), b5p(k);
+    for (int z = 0; z < k; ++z) {
+        const TView Dz = mv(D.p + z * v * v * o * o, {v, v, o, o}), U2z = mv(u2[z], {v, v, o, o});
+        q.C(1.0, mv(Gvv, {v, v}), "ad", U2z, "dbij", 1.0, Dz, "abij");
+        q.C(1.0, mv(Goo, {o, o}), "li", U2z, "ablj", 1.0, Dz, "abij", "ab");
+        const TView B5z = mv(B5.p + z * o * o * o * o, {o, o, o, o}), B5sz = mv(B5s.p + z * o * o * o * o, {o, o, o, o});
+        q.C(1.0, Vijka, "klid", mv(U1.p + z * v * o, {v, o}), "dj", 0.0, B5z, "klij");
+        q.P(1.0, B5z, "klij", 0.0, B5sz, "klij");
+        q.P(1.0, B5z, "lkji", 1.0, B5sz, "klij");
+        b5p[z] = B5sz.p;
+    }
+    // the hole-ladder-shaped terms of all vectors in batched launches (the shared side — V_klij + V_klcd T_cdij, then T —
+    // packed once)
+    e.hole_ladder_packed_multi(u2, b2s.data(), nullptr, k, Lall);                      // :380, :382
+    e.hole_ladder_packed_multi(ts.data(), b5p.data(), u2, k, Lall);                    // :381 (+ the symmetrised u1 term)
+    for (int z = 0; z < k; ++z) {
+        dev::residual_assemble(nullptr, Lall.p + z * npp * o * o, D.p + z * v * v * o * o, DdT.p + z * ov2, DxT.p + z * ov2, s2[z],
+                               no, nv, e.stream);                                       // :377 + unpacking
+        dev::memcpy_d2d(s1[z], S1.p + z * v * o, sizeof(double) * v * o, e.stream);
+    }
+}
+
+void EomSigma::apply(int k, const double* const* u1, const double* const* u2, const int* sym, double* const* s1,
+                     double* const* s2) {
+    if (k < 1) return;
+    const int64_t o = no, v = nv;
+    std::vector<int> sy(k);
+    bool all = true;
+    for (int z = 0; z < k; ++z) {
+        if (!u1[z] || !u2[z] || !s1[z] || !s2[z]) throw Error("eom sigma: null vector");
+        sy[z] = sym ? (sym[z] != 0) : exchange_symmetric(u2[z], v, o);
+        all = all && sy[z];
+    }
+    auto one = [&](int z) {
+        singles(u1[z], u2[z], s1[z]);
+        doubles(u1[z], u2[z], sy[z] != 0, s2[z]);
+    };
+    if (k < 2 || !many_ok || !all) {
+        for (int z = 0; z < k; ++z) one(z);
+        return;
+    }
+    const int step = stack_limit();
+    for (int lo = 0; lo < k; lo += step) {
+        const int hi = std::min(k, lo + step);
+        if (hi - lo < 2) { one(lo); continue; }
+        try {
+            stack(hi - lo, u1 + lo, u2 + lo, s1 + lo, s2 + lo);
+        } catch (const Error& err) {
+            if (std::string(err.what()).find("memory") == std::string::npos) throw;
+            trim();                    // out of device memory in the middle of a stacked build: one vector at a time
+            for (int z = lo; z < hi; ++z) one(z);
+        }
+    }
+}
+
+// ---- eom_ccsd.py:169-198 (singles) and :200-266 (doubles) on the device ---------------------------------------------------------
+void eom_diagonals(Engine& e, const double* f_host, const double* t2, bool dressed, double* d1, double* d2) {
+    if (!f_host || !t2 || !d1 || !d2) throw Error("eom diagonals: null argument");
+    const int64_t o = e.no, v = e.nv, n = o + v;
+    std::vector<double> h(static_cast<size_t>(v * o));
+    for (int64_t a = 0; a < v; ++a)
+        for (int64_t i = 0; i < o; ++i) h[a * o + i] = f_host[(o + a) * n + o + a] - f_host[i * n + i];
+    ArenaScope scope(e.arena);
+    double *dai = e.arena.alloc(v * o), *iaai = e.arena.alloc(v * o), *iaia = e.arena.alloc(v * o), *ijij = e.arena.alloc(o * o),
+           *abab = e.arena.alloc(v * v), *ws = e.arena.alloc(dev::eom_diag_ws_doubles(e.no, e.nv));
+    dev::memcpy_h2d(dai, h.data(), sizeof(double) * v * o, e.stream);
+    dev::stream_sync(e.stream);
+    // the four diagonal slices of other blocks, gathered through strided views (o v / o^2 / v^2 numbers)
+    auto gather = [&](const char* name, int64_t d0, int64_t d1_, int64_t s0, int64_t s1_, double* out) {
+        const TView blk = e.block(pattern_of_name(name), dressed);
+        const int64_t dims[2] = {d0, d1_}, st[2] = {s0, s1_};
+        e.permute(1.0, make_view(blk.p, 2, dims, st), "xy", 0.0, mv(out, {d0, d1_}), "xy");
+    };
+    gather("iabj", v, o, v * o + o, v * v * o + 1, iaai);          // [a,i] <- V[i,a,a,i]
+    gather("iajb", v, o, o * v + 1, v * o * v + v, iaia);          // [a,i] <- V[i,a,i,a]
+    gather("klij", o, o, o * o * o + o, o * o + 1, ijij);          // [i,j] <- V[i,j,i,j]
+    gather("abcd", v, v, v * v * v + v, v * v + 1, abab);          // [a,b] <- V[a,b,a,b]
+    dev::eom_diagonals(e.block(pattern_of_name("ijab"), dressed).p, t2, dai, iaai, iaia, ijij, abab, d1, d2, e.no, e.nv, ws,
+                       e.stream);
+}
+
+}  // namespace pymes

@@ -1627,6 +1627,153 @@ __global__ void cmul_kernel(const double* __restrict__ mr, const double* __restr
     }
 }
 
+// ---- EOM-CCSD diagonals (eom_ccsd.py:169-266), once per solve ------------------------------------------------------------------
+// V = V_ijab [o,o,v,v], T [v,v,o,o].  Stage 1: the V.T sums with one to three free indices, one block per output element
+// (strided loop over the summed indices + block reduction).  Layout of ws (offsets in doubles, EomDiagWs below):
+//   S1[a,i]  = sum_jb (2V[j,i,b,a] - V[j,i,a,b]) (2T[b,a,j,i] - T[a,b,j,i])                      (:181-190)
+//   Sa[a]    = sum_jkb (2V[j,k,b,a] - V[j,k,a,b]) T[a,b,j,k],    Si[i] = sum_jcb V[j,i,c,b] T[b,c,j,i]   (:192-196)
+//   A2[a,i]  = sum_kc (2V[k,i,c,a] - 2V[k,i,a,c]) T[c,a,k,i] + (V[k,i,a,c] - 2V[k,i,c,a]) T[a,c,k,i] + sum_kcb V[k,i,c,b] T[a,c,k,i]
+//   a_[a]    = sum_klc V[k,l,c,a] (T[a,c,k,l] - 2T[c,a,k,l]),    i_[i] = sum_kcd (V[k,i,d,c] - 2V[k,i,c,d]) T[c,d,k,i]
+//   IJ[i,j]  = sum_cd V[i,j,c,d] T[c,d,i,j],   AJ[a,j] = sum_kc V[k,j,a,c] T[a,c,k,j],   AB[a,b] = sum_kl V[k,l,a,b] T[a,b,k,l]
+//   Z1[a,i,j] = sum_kc V[k,j,a,c] T[c,a,k,i],  X1[a,b,j] = sum_k V[k,j,a,b] T[a,b,k,j]
+struct EomDiagWs {
+    long S1, Sa, Si, A2, a_, i_, IJ, AJ, AB, Z1, X1, total;
+    __host__ __device__ EomDiagWs(long o, long v) {
+        long p = 0;
+        S1 = p; p += v * o;  Sa = p; p += v;  Si = p; p += o;  A2 = p; p += v * o;  a_ = p; p += v;  i_ = p; p += o;
+        IJ = p; p += o * o;  AJ = p; p += v * o;  AB = p; p += v * v;  Z1 = p; p += v * o * o;  X1 = p; p += v * v * o;
+        total = p;
+    }
+};
+__global__ void __launch_bounds__(256) eom_diag_sums_kernel(const double* __restrict__ V, const double* __restrict__ T,
+                                                            double* __restrict__ ws, int no, int nv) {
+    __shared__ double sh[4];
+    const long o = no, v = nv;
+    const EomDiagWs w(o, v);
+    auto Vx = [&](long k, long l, long c, long d) { return V[((k * o + l) * v + c) * v + d]; };
+    auto Tx = [&](long a, long b, long i, long j) { return T[((a * v + b) * o + i) * o + j]; };
+    const long e = blockIdx.x;
+    const int t = threadIdx.x;
+    double s = 0.0;
+    if (e < w.Sa) {                                     // S1[a,i]
+        const long a = e / o, i = e % o;
+        for (long x = t; x < o * v; x += 256) {
+            const long j = x / v, b = x % v;
+            s += (2.0 * Vx(j, i, b, a) - Vx(j, i, a, b)) * (2.0 * Tx(b, a, j, i) - Tx(a, b, j, i));
+        }
+    } else if (e < w.Si) {                              // Sa[a]
+        const long a = e - w.Sa;
+        for (long x = t; x < o * o * v; x += 256) {
+            const long j = x / (o * v), k = (x / v) % o, b = x % v;
+            s += (2.0 * Vx(j, k, b, a) - Vx(j, k, a, b)) * Tx(a, b, j, k);
+        }
+    } else if (e < w.A2) {                              // Si[i]
+        const long i = e - w.Si;
+        for (long x = t; x < o * v * v; x += 256) {
+            const long j = x / (v * v), c = (x / v) % v, b = x % v;
+            s += Vx(j, i, c, b) * Tx(b, c, j, i);
+        }
+    } else if (e < w.a_) {                              // A2[a,i]
+        const long a = (e - w.A2) / o, i = (e - w.A2) % o;
+        for (long x = t; x < o * v; x += 256) {
+            const long k = x / v, c = x % v;
+            const double tca = Tx(c, a, k, i), tac = Tx(a, c, k, i);
+            s += (2.0 * Vx(k, i, c, a) - 2.0 * Vx(k, i, a, c)) * tca + (Vx(k, i, a, c) - 2.0 * Vx(k, i, c, a)) * tac;
+            double vb = 0.0;
+            for (long b = 0; b < v; ++b) vb += Vx(k, i, c, b);
+            s += vb * tac;
+        }
+    } else if (e < w.i_) {                              // a_[a]
+        const long a = e - w.a_;
+        for (long x = t; x < o * o * v; x += 256) {
+            const long k = x / (o * v), l = (x / v) % o, c = x % v;
+            s += Vx(k, l, c, a) * (Tx(a, c, k, l) - 2.0 * Tx(c, a, k, l));
+        }
+    } else if (e < w.IJ) {                              // i_[i]
+        const long i = e - w.i_;
+        for (long x = t; x < o * v * v; x += 256) {
+            const long k = x / (v * v), c = (x / v) % v, d = x % v;
+            s += (Vx(k, i, d, c) - 2.0 * Vx(k, i, c, d)) * Tx(c, d, k, i);
+        }
+    } else if (e < w.AJ) {                              // IJ[i,j]
+        const long i = (e - w.IJ) / o, j = (e - w.IJ) % o;
+        for (long x = t; x < v * v; x += 256) {
+            const long c = x / v, d = x % v;
+            s += Vx(i, j, c, d) * Tx(c, d, i, j);
+        }
+    } else if (e < w.AB) {                              // AJ[a,j]
+        const long a = (e - w.AJ) / o, j = (e - w.AJ) % o;
+        for (long x = t; x < o * v; x += 256) {
+            const long k = x / v, c = x % v;
+            s += Vx(k, j, a, c) * Tx(a, c, k, j);
+        }
+    } else if (e < w.Z1) {                              // AB[a,b]
+        const long a = (e - w.AB) / v, b = (e - w.AB) % v;
+        for (long x = t; x < o * o; x += 256) {
+            const long k = x / o, l = x % o;
+            s += Vx(k, l, a, b) * Tx(a, b, k, l);
+        }
+    } else if (e < w.X1) {                              // Z1[a,i,j]
+        const long r = e - w.Z1, a = r / (o * o), i = (r / o) % o, j = r % o;
+        for (long x = t; x < o * v; x += 256) {
+            const long k = x / v, c = x % v;
+            s += Vx(k, j, a, c) * Tx(c, a, k, i);
+        }
+    } else {                                            // X1[a,b,j]
+        const long r = e - w.X1, a = r / (v * o), b = (r / o) % v, j = r % o;
+        for (long k = t; k < o; k += 256) s += Vx(k, j, a, b) * Tx(a, b, k, j);
+    }
+    s = block_sum(s, sh);
+    if (t == 0) ws[e] = s;
+}
+// Stage 2: d1[a,i] (:169-198) and, one thread per (a,b,i,j), d2 = e(a,b,i,j) + e(b,a,j,i) + ijij + IJ + AB + abab (:200-266) with
+//   e(a,b,i,j) = ai[a,i] + a_[a] + i_[i] - 2 X1[a,b,j] - 2 IJ[i,j] + sum_k V[k,i,a,b] T[a,b,k,j] + sum_c V[i,j,c,a] T[c,b,i,j]
+//                + Z1[a,i,j] + AJ[a,j],     ai = dai + iaai - 2 iaia + A2
+__global__ void eom_diag_singles_kernel(const double* __restrict__ ws, const double* __restrict__ dai, const double* __restrict__ iaai,
+                                        const double* __restrict__ iaia, double* __restrict__ d1, int no, int nv) {
+    const long o = no, v = nv;
+    const EomDiagWs w(o, v);
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= v * o) return;
+    const long a = e / o, i = e % o;
+    d1[e] = dai[e] + 2.0 * iaai[e] - iaia[e] + ws[w.S1 + e] - ws[w.Sa + a] - ws[w.Si + i];
+}
+__global__ void __launch_bounds__(256) eom_diag_doubles_kernel(const double* __restrict__ V, const double* __restrict__ T,
+                                                               const double* __restrict__ ws, const double* __restrict__ dai,
+                                                               const double* __restrict__ iaai, const double* __restrict__ iaia,
+                                                               const double* __restrict__ ijij, const double* __restrict__ abab,
+                                                               double* __restrict__ d2, int no, int nv, long total) {
+    const long o = no, v = nv;
+    const EomDiagWs w(o, v);
+    auto Vx = [&](long k, long l, long c, long d) { return V[((k * o + l) * v + c) * v + d]; };
+    auto Tx = [&](long a, long b, long i, long j) { return T[((a * v + b) * o + i) * o + j]; };
+    auto half = [&](long a, long b, long i, long j) {
+        const long ai = a * o + i;
+        double r = dai[ai] + iaai[ai] - 2.0 * iaia[ai] + ws[w.A2 + ai] + ws[w.a_ + a] + ws[w.i_ + i] -
+                   2.0 * ws[w.X1 + (a * v + b) * o + j] - 2.0 * ws[w.IJ + i * o + j] + ws[w.Z1 + (a * o + i) * o + j] +
+                   ws[w.AJ + a * o + j];
+        double y = 0.0;
+        for (long k = 0; k < o; ++k) y += Vx(k, i, a, b) * Tx(a, b, k, j);
+        for (long c = 0; c < v; ++c) y += Vx(i, j, c, a) * Tx(c, b, i, j);
+        return r + y;
+    };
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long j = e % o, i = (e / o) % o, b = (e / (o * o)) % v, a = e / (o * o * v);
+        d2[e] = half(a, b, i, j) + half(b, a, j, i) + ijij[i * o + j] + ws[w.IJ + i * o + j] + ws[w.AB + a * v + b] + abab[a * v + b];
+    }
+}
+// (mr + i mi)[e] = 1 / (z - hs d[e] + shift): the diagonal preconditioner of the FEAST linear solves from the device-resident
+// diagonal (feast_eom_ccsd.py:276-278, :342)
+__global__ void cshift_inv_kernel(const double* __restrict__ d, double zr, double zi, double hr, double hi, double shift,
+                                  double* __restrict__ mr, double* __restrict__ mi, long n) {
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const double x = zr - hr * d[e] + shift, y = zi - hi * d[e];
+        const double q = x * x + y * y;
+        mr[e] = x / q;
+        mi[e] = -y / q;
+    }
+}
+
 __global__ void tau_kernel(double* __restrict__ tau, const double* __restrict__ t2, const double* __restrict__ t1,
                            int no, int nv, long total) {
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
@@ -3880,6 +4027,29 @@ void lincomb_multi(int m, int n, const double* const* x, const double* c, const 
 void cmul(const double* mr, const double* mi, const double* xr, const double* xi, double* yr, double* yi, int64_t n, stream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(cmul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, mr, mi, xr, xi, yr, yi, (long)n);
+    HIP_CHECK(hipGetLastError());
+}
+
+int64_t eom_diag_ws_doubles(int no, int nv) { return EomDiagWs(no, nv).total; }
+void eom_diagonals(const double* V, const double* T, const double* dai, const double* iaai, const double* iaia, const double* ijij,
+                   const double* abab, double* d1, double* d2, int no, int nv, double* ws, stream_t s) {
+    hipStream_t st = (hipStream_t)s;
+    const EomDiagWs w(no, nv);
+    const long total = (long)nv * nv * no * no;
+    if (w.total > 0x7fffffffL) throw std::runtime_error("eom_diagonals: problem too large for one grid");
+    hipLaunchKernelGGL(eom_diag_sums_kernel, dim3((unsigned)w.total), dim3(256), 0, st, V, T, ws, no, nv);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(eom_diag_singles_kernel, dim3((unsigned)(((long)nv * no + 255) / 256)), dim3(256), 0, st, ws, dai, iaai, iaia,
+                       d1, no, nv);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(eom_diag_doubles_kernel, dim3(grid_for(total, 256, 256 * 64)), dim3(256), 0, st, V, T, ws, dai, iaai, iaia, ijij,
+                       abab, d2, no, nv, total);
+    HIP_CHECK(hipGetLastError());
+}
+void cshift_inv(const double* d, double zr, double zi, double hr, double hi, double shift, double* mr, double* mi, int64_t n,
+                stream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(cshift_inv_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, d, zr, zi, hr, hi, shift, mr, mi, (long)n);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -718,6 +718,12 @@ class Context:
         self.lib.call("pymes_cmul", self.handle, C.c_void_p(mr.ptr), C.c_void_p(mi.ptr), C.c_void_p(xr.ptr), C.c_void_p(xi.ptr),
                       C.c_void_p(yr.ptr), C.c_void_p(yi.ptr), xr.size)
 
+    def cshift_inv(self, d, z, hs, shift, mr, mi):
+        """(mr + i mi) = 1 / (z - hs d + shift) element by element: the FEAST preconditioner from a device-resident diagonal."""
+        z, hs = complex(z), complex(hs)
+        self.lib.call("pymes_cshift_inv", self.handle, C.c_void_p(d.ptr), z.real, z.imag, hs.real, hs.imag, float(shift),
+                      C.c_void_p(mr.ptr), C.c_void_p(mi.ptr), d.size)
+
     # ---- measurement --------------------------------------------------------------------
     def stats(self, reset=False):
         gc, pc, gf, pb = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()

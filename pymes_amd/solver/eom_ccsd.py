@@ -12,11 +12,13 @@ three-operand einsums.  The subspace algebra (QR, B = Uᵀσ, eig, collapse/expa
 eom_ccsd.py:46-167 and stays on the host: the trial vectors live on the device, the host sees
 only overlaps and coefficients.
 """
+import ctypes as C
 import os
 import time
 
 import numpy as np
 
+from pymes_amd import _lib
 from pymes_amd.device import Context, DeviceArray, PymesError
 from pymes_amd.integral.device import DressedDeviceIntegrals
 from pymes_amd.integral.partition import BLOCK_NAMES
@@ -25,9 +27,10 @@ from pymes_amd.mixer.diis import _single_threaded_blas
 
 
 class _Sigma:
-    """Device-resident H̄·u with hoisted u-independent intermediates.
-
-    Pair layouts (ov x ov matrices): Xd[(a,i),(b,j)] = X[a,b,i,j], Xx[(a,j),(b,i)] = X[a,b,i,j]."""
+    """Device-resident H-bar . u (eom_ccsd.py:268-385): a handle of the engine's EOM sigma build (csrc/eom.cpp,
+    ``pymes_eom_sigma_prepare / _apply``).  Every V.T product that does not depend on the trial vector is hoisted once per solve;
+    one ``apply_many`` call builds sigma for any number of trial vectors — exchange-symmetric ones stacked, so that every shared
+    operand is read once — in ONE library call (round 4 issued the ~130 contractions of a build one ctypes call at a time)."""
 
     # the blocks a sigma build reads (eom_ccsd.py:268-385)
     BLOCKS = ("ijab", "iabj", "iajb", "ijka", "ijak", "iabc", "iajk", "abic", "klij", "abcd")
@@ -35,339 +38,73 @@ class _Sigma:
     def __init__(self, ctx, f, t2, dressed=False):
         """``dressed``: read the context's T1-DRESSED blocks (the context of a CCSD solve whose integrals were dressed in
         place, ``CCSD.get_T1_dressed_V`` on a ``DeviceIntegrals``) instead of blocks uploaded as they are."""
-        self.ctx, c = ctx, ctx
-        no, nv = ctx.no, ctx.nv
-        self.no, self.nv = no, nv
+        self.ctx = ctx
+        self.no, self.nv = ctx.no, ctx.nv
         self.dressed = bool(dressed)
-        f = np.asarray(f, dtype=np.float64)
-        self.foo, self.fov, self.fvv = c.array(f[:no, :no]), c.array(f[:no, no:]), c.array(f[no:, no:])
-        V = {nm: c.V_block(nm, self.dressed) for nm in self.BLOCKS}
-        self.V = V
-        T = t2
-        self.T = T
-        self.Td = c.permute("abij->aibj", T)
-        self.Tx = c.permute("abij->ajbi", T)
-        Vd = c.permute("klcd->ckdl", V["ijab"])          # [(c,k),(d,l)]
-        Vx = c.permute("klcd->cldk", V["ijab"])          # [(c,l),(d,k)]
-        # ---- singles (eom_ccsd.py:288-308) ----------------------------------------------------
-        # W1[(c,k),(a,i)] = sum_jb (2V[j,k,b,c]-V[j,k,c,b]) (2T[b,a,j,i]-T[a,b,j,i]) + 2V_iabj[k,a,c,i] - V_iajb[k,a,i,c]
-        Vq = c.permute("jkbc->ckbj", V["ijab"], alpha=2.0)
-        c.permute("jkcb->ckbj", V["ijab"], out=Vq, alpha=-1.0, beta=1.0)
-        Tq = c.permute("baji->bjai", T, alpha=2.0)
-        c.permute("abji->bjai", T, out=Tq, alpha=-1.0, beta=1.0)
-        self.W1 = c.contract("ckbj,bjai->ckai", Vq, Tq)
-        c.permute("kaci->ckai", V["iabj"], out=self.W1, alpha=2.0, beta=1.0)
-        c.permute("kaic->ckai", V["iajb"], out=self.W1, alpha=-1.0, beta=1.0)
-        # Gvv_s[a,c] = fvv + sum V[j,k,b,c] (-2T[b,a,j,k] + T[a,b,j,k]);  Goo_s[k,i] = -foo + sum (-2V[j,k,b,c]+V[j,k,c,b]) T[b,c,j,i]
-        self.Gvv_s = c.array(f[no:, no:])
-        c.contract("jkbc,bajk->ac", V["ijab"], T, out=self.Gvv_s, alpha=-2.0, beta=1.0)
-        c.contract("jkbc,abjk->ac", V["ijab"], T, out=self.Gvv_s, alpha=1.0, beta=1.0)
-        self.Goo_s = c.array(-f[:no, :no])
-        c.contract("jkbc,bcji->ki", V["ijab"], T, out=self.Goo_s, alpha=-2.0, beta=1.0)
-        c.contract("jkcb,bcji->ki", V["ijab"], T, out=self.Goo_s, alpha=1.0, beta=1.0)
-        # ---- doubles: (V.T) pair matrices (eom_ccsd.py:352-372) ------------------------------------
-        M_A = c.contract("ckai,ckdl->aidl", self.Td, Vd)       # sum_kc V[k,l,c,d] T[c,a,k,i]
-        M_B = c.contract("aick,ckdl->aidl", self.Tx, Vd)       # sum_kc V[k,l,c,d] T[a,c,k,i]
-        self.M_C = c.contract("ckai,dlck->aidl", self.Td, Vx)  # sum_kc V[k,l,d,c] T[c,a,k,i]
-        self.M_D = c.contract("aick,dlck->aidl", self.Tx, Vx)  # sum_kc V[k,l,d,c] T[a,c,k,i]
-        self.M1 = c.permute("kaci->aick", V["iabj"])           # Wd'[(a,i),(c,k)] = V_iabj[k,a,c,i]
-        c.lincomb(self.M1, [self.M1, M_A, M_B], [1.0, 2.0, -1.0])
-        self.Ud = c.permute("kaic->aick", V["iajb"])           # Ud[(a,i),(c,k)] = V_iajb[k,a,i,c]
-        self.M2 = c.empty(self.M1.shape)
-        c.lincomb(self.M2, [self.M_D, self.M_C, self.Ud], [1.0, -2.0, -1.0])
-        # for exchange-symmetric trial doubles ut = 2 u2 - u2^(ab) is 2 u2d - u2x in the pair layout, so
-        # M1.utd + M2.u2d + M_C.u2x = (2 M1 + M2).utd / 2 + (M_D - Ud).u2x / 2 (see doubles()): one product + half of Dx
-        self.M12 = c.empty(self.M1.shape)
-        c.lincomb(self.M12, [self.M1, self.M2], [2.0, 1.0])
-        # crossed layout: the result is symmetrised by P(ijab, jiba) (:377), i.e. only Dx + Dx^T counts, and u2x is a
-        # symmetric matrix for exchange-symmetric u2, so -u2x.Ud^T (:364) may be replaced by its transpose -Ud.u2x:
-        # M_D.u2x - Ud.u2x = (M_D - Ud).u2x, one product instead of two
-        self.MDU = c.empty(self.M1.shape)
-        c.lincomb(self.MDU, [self.M_D, self.Ud], [1.0, -1.0])
-        del M_A, M_B, Vd, Vx, Vq, Tq
-        # V_kacd.T products of the u1 terms (eom_ccsd.py:334, :343, :345, :346), u-independent like the pair matrices above:
-        #   WA[a,d,b,j] = sum_ck (2 V[k,a,c,d] - V[k,a,d,c]) T[c,b,k,j] - V[k,a,c,d] T[b,c,k,j],   W3[a,d,b,i] = sum_ck V[k,a,d,c] T[b,c,k,i]
-        # so that a sigma build contracts them with u1 over d (o^2 v^3, HBM-bound) instead of forming V.u1 first and paying
-        # three (ov)^3 products per trial vector.  Two v^3 o arrays (0.4 GB each at (30,120)).
-        self.WA = c.contract("kacd,cbkj->adbj", V["iabc"], T, alpha=2.0)
-        c.contract("kadc,cbkj->adbj", V["iabc"], T, out=self.WA, alpha=-1.0, beta=1.0)
-        c.contract("kacd,bckj->adbj", V["iabc"], T, out=self.WA, alpha=-1.0, beta=1.0)
-        self.W3 = c.contract("kadc,bcki->adbi", V["iabc"], T)
-        # small hoisted V.T blocks
-        self.A3 = c.contract("klci,cbkj->libj", V["ijak"], T, alpha=-2.0)                 # A_oovo
-        c.contract("klic,cbkj->libj", V["ijka"], T, out=self.A3, alpha=1.0, beta=1.0)
-        c.contract("kldi,bdkj->libj", V["ijak"], T, out=self.A3, alpha=1.0, beta=1.0)
-        self.A4 = c.contract("klid,adkj->liaj", V["ijka"], T)
-        self.A6 = c.contract("lacd,cdji->laji", V["iabc"], T)
-        self.Gvv = c.array(f[no:, no:])
-        c.contract("klcd,cakl->ad", V["ijab"], T, out=self.Gvv, alpha=-2.0, beta=1.0)
-        c.contract("klcd,ackl->ad", V["ijab"], T, out=self.Gvv, alpha=1.0, beta=1.0)
-        self.Goo = c.array(-f[:no, :no])
-        c.contract("klcd,cdki->li", V["ijab"], T, out=self.Goo, alpha=-2.0, beta=1.0)
-        c.contract("kldc,cdki->li", V["ijab"], T, out=self.Goo, alpha=1.0, beta=1.0)
-        self.B2 = c.permute("klij->klij", V["klij"])
-        c.contract("klcd,cdij->klij", V["ijab"], T, out=self.B2, alpha=1.0, beta=1.0)
-        # particle ladder (:383): pair-packed form (1/4 of the flops) whenever V_abcd = V_badc and the trial doubles
-        # are exchange-symmetric, u2_abij = u2_baji — true for every vector the Davidson driver generates
-        self.v_sym = c.exchange_symmetric(V["abcd"])
-        # T_abij = T_baji (every CCSD solution): P(ijab,jiba)[T B5] = T (B5 + B5^(lkji)), so that term rides in the
-        # product with B' of eom_ccsd.py:381 — one v^2 o^4 product less per sigma
-        self.fused_ok = c.pairs_supported()
-        self.t_sym = c.exchange_symmetric(T)
-        # eom_ccsd.py:380-382 in pair-packed rows needs B2_klij = B2_lkji and V_klcd = V_lkdc (then B' has it for symmetric u2)
-        self.hole_sym = self.t_sym and c.exchange_symmetric(self.B2) and c.exchange_symmetric(V["ijab"])
-        self.L = c.empty((nv * (nv + 1) // 2, no * no)) if self.v_sym else None
-        # ---- multi-vector sigma (apply_many): what the stacked products read --------------------------------------------
-        self.many_ok = bool(self.v_sym and self.hole_sym and self.fused_ok and self.t_sym)
-        if self.many_ok:
-            self.fovT = c.array(np.ascontiguousarray(f[:no, no:].T))
-            # WA / W3 with the contracted index third: u1[d,i] then meets WA[a,b,d,:] as a batch of (a,b) products whose
-            # o x o results ARE the tiles D[z,a,b,:,:] — no transposed copy of a v^3 o array and no permuted accumulation of
-            # the result per build (0.7 ms each at (30,120), rocprofv3 round 4)
-            self.WAt = c.permute("adbj->abdj", self.WA)
-            self.W3t = c.permute("adbi->abdi", self.W3)
-            # The four u1 terms with one free index on u1 (:336-338, :341 region: A_oovo, A4, A6 and V_iajk) as ONE product
-            # u1[a,l] A346[l,b,i,j].  Everything added to D is symmetrised by P(ijab,jiba) afterwards (:377), so a term
-            # X_abij may be replaced by its partner X_baji: sum_l u1[b,l] A4[l,i,a,j] -> sum_l u1[a,l] A4[l,j,b,i], etc.
-            self.A346 = c.permute("libj->lbij", self.A3)
-            c.permute("ljbi->lbij", self.A4, out=self.A346, beta=1.0)
-            c.lincomb(self.A346, [self.A346, self.A6, V["iajk"]], [1.0, -1.0, -1.0])
+        self.T = t2                                   # (kept alive: the handle reads it in every build)
+        self._f = np.ascontiguousarray(f, dtype=np.float64)
+        if self._f.shape != (ctx.n, ctx.n):
+            raise ValueError("the dressed Fock matrix must be [n, n]")
+        h = C.c_void_p()
+        ctx.lib.call("pymes_eom_sigma_prepare", ctx.handle, _lib.host_ptr(self._f), C.c_void_p(t2.ptr), int(self.dressed),
+                     C.byref(h))
+        self._h = h
+        ctx.on_close(self._ctx_closing)               # the handle dies before its context
+        flags = C.c_int()
+        ctx.lib.call("pymes_eom_sigma_flags", self._h, C.byref(flags))
+        fl = flags.value
+        self.v_sym, self.t_sym, self.hole_sym = bool(fl & 1), bool(fl & 2), bool(fl & 4)
+        self.fused_ok, self.many_ok = bool(fl & 8), bool(fl & 16)
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and self.ctx.handle is not None:
+            self.ctx.lib.call("pymes_eom_sigma_destroy", h)
+
+    def _ctx_closing(self, ctx):
+        try:
+            self.close()
+        except Exception:
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def exchange_symmetric(self, u2):
         return self.ctx.exchange_symmetric(u2)      # one reduction kernel, no temporary
 
-    # ------------------------------------------------------------------------------------------
-    def singles(self, u1, u2):
-        """eom_ccsd.py:268-310."""
-        c, V = self.ctx, self.V
-        ut = c.permute("abij->abij", u2, alpha=2.0)                   # 2 u2[a,b,i,j] - u2[b,a,i,j]
-        c.permute("baij->abij", u2, out=ut, alpha=-1.0, beta=1.0)
-        s = c.contract("ck,ckai->ai", u1, self.W1)
-        c.contract("ac,ci->ai", self.Gvv_s, u1, out=s, beta=1.0)
-        c.contract("ak,ki->ai", u1, self.Goo_s, out=s, beta=1.0)
-        c.contract("jb,baji->ai", self.fov, ut, out=s, beta=1.0)
-        c.contract("jkib,abjk->ai", V["ijka"], ut, out=s, alpha=-1.0, beta=1.0)
-        c.contract("jabc,bcji->ai", V["iabc"], ut, out=s, beta=1.0)
-        return s
-
-    def doubles(self, u1, u2, u2_sym=None):
-        """eom_ccsd.py:312-385.  ``u2_sym``: the caller's knowledge that u2_abij = u2_baji (checked here, with a
-        device-to-host synchronisation, when None)."""
-        c, V, T = self.ctx, self.V, self.T
-        u2x = c.permute("abij->ajbi", u2)
-        if u2_sym is None:
-            u2_sym = self.exchange_symmetric(u2)
-        # ---- (ov)^3 products -----------------------------------------------------------------------
-        utd = c.permute("abij->aibj", u2, alpha=2.0)                  # ut[d,b,l,j] = 2u2[d,b,l,j] - u2[b,d,l,j]
-        c.permute("baij->aibj", u2, out=utd, alpha=-1.0, beta=1.0)
-        if u2_sym:
-            # exchange-symmetric u2: utd = 2 u2d - u2x as matrices, hence M1.utd + M2.u2d + M_C.u2x =
-            # (2 M1 + M2).utd / 2 + (M_D - Ud).u2x / 2, and the second product IS Dx (the C / D form of the ring terms, as
-            # in the CCSD residual): TWO (ov)^3 products per sigma, Dd = M12.utd / 2 + Dx / 2
-            Dx = c.contract("ajdl,dlbi->ajbi", self.MDU, u2x)                     # :372 and :364 (transposed)
-            Dd = c.permute("ajbi->ajbi", Dx, alpha=0.5)                           # same memory layout as "aibj"
-            c.contract("aidl,dlbj->aibj", self.M12, utd, out=Dd, alpha=0.5, beta=1.0)
-        else:
-            u2d = c.permute("abij->aibj", u2)
-            Dd = c.contract("aidl,dlbj->aibj", self.M1, utd)
-            c.contract("aidl,dlbj->aibj", self.M2, u2d, out=Dd, beta=1.0)
-            c.contract("aidl,dlbj->aibj", self.M_C, u2x, out=Dd, beta=1.0)      # u2x[(d,l),(b,j)] = u2[d,b,j,l]
-            Dx = c.contract("ajdl,dlbi->ajbi", self.M_D, u2x)                     # :372  u2[d,b,i,l]
-            c.contract("ajck,bick->ajbi", u2x, self.Ud, out=Dx, alpha=-1.0, beta=1.0)  # :364
-        # ---- one-index dressings -----------------------------------------------------------------------
-        Xoo = c.contract("klid,dl->ki", V["ijka"], u1, alpha=-2.0)
-        c.contract("kldi,dl->ki", V["ijak"], u1, out=Xoo, beta=1.0)
-        c.contract("kd,di->ki", self.fov, u1, out=Xoo, alpha=-1.0, beta=1.0)
-        c.contract("kldc,dcil->ki", V["ijab"], u2, out=Xoo, alpha=-2.0, beta=1.0)
-        c.contract("kldc,dcli->ki", V["ijab"], u2, out=Xoo, beta=1.0)
-        c.contract("ki,akbj->aibj", Xoo, self.Td, out=Dd, beta=1.0, batch="a")
-        Xvv = c.contract("ladc,dl->ac", V["iabc"], u1, alpha=2.0)
-        c.contract("lacd,dl->ac", V["iabc"], u1, out=Xvv, alpha=-1.0, beta=1.0)
-        c.contract("al,lc->ac", u1, self.fov, out=Xvv, alpha=-1.0, beta=1.0)
-        c.contract("lkcd,adlk->ac", V["ijab"], u2, out=Xvv, alpha=-2.0, beta=1.0)
-        c.contract("lkcd,dalk->ac", V["ijab"], u2, out=Xvv, beta=1.0)
-        D = c.contract("ac,cbij->abij", Xvv, T)
-        # V_kacd.T.u1 terms (:334, :343, :345, :346) through the hoisted V.T intermediates: o^2 v^3 instead of (ov)^3 each
-        c.contract("adbj,di->abij", self.WA, u1, out=D, beta=1.0)
-        c.contract("adbi,dj->abij", self.W3, u1, out=D, alpha=-1.0, beta=1.0)
-        c.contract("ad,dbij->abij", self.Gvv, u2, out=D, beta=1.0)
-        c.contract("li,ablj->abij", self.Goo, u2, out=D, beta=1.0, batch="ab")
-        c.contract("al,libj->abij", u1, self.A3, out=D, beta=1.0)
-        c.contract("bl,liaj->abij", u1, self.A4, out=D, beta=1.0)
-        c.contract("bl,laji->abij", u1, self.A6, out=D, alpha=-1.0, beta=1.0)
-        B5 = c.contract("klid,dj->klij", V["ijka"], u1)
-        if not self.t_sym:
-            c.contract("abkl,klij->abij", T, B5, out=D, beta=1.0)
-        c.contract("ak,kbij->abij", u1, V["iajk"], out=D, alpha=-1.0, beta=1.0)
-        c.contract("abic,cj->abij", V["abic"], u1, out=D, beta=1.0)
-        packed = self.v_sym and u2_sym and self.hole_sym
-        if packed and self.fused_ok:
-            # the terms (:380-383) that stay outside P(ijab,jiba) all live in the pair-packed rows L here, so the
-            # symmetrisation (:377) of D and of the two pair matrices and the unpacking of L are ONE pass (the assembly
-            # kernel of the CCSD residual) instead of two transposed accumulations, a transposition, a sum and an unpack
-            npp = self.L.shape[0]
-            B5s = c.permute("klij->klij", B5)
-            c.permute("lkji->klij", B5, out=B5s, beta=1.0)
-            c.ladder_sym(u2, self.L, 0, npp, dressed=self.dressed)
-            c.hole_ladder_packed(u2, self.B2, self.L, 0, npp)
-            c.hole_ladder_packed(T, B5s, self.L, 0, npp, y=u2)
-            return c.symmetrised_assemble(D, Dd, Dx, c.empty(D.shape), L=self.L)
-        c.permute("aibj->abij", Dd, out=D, beta=1.0)
-        c.permute("ajbi->abij", Dx, out=D, beta=1.0)
-        # ---- P(ijab, jiba) (:377), then the unpermuted terms (:380-383) ----------------------------------
-        S = c.permute("baji->abij", D)
-        c.lincomb(D, [D, S], [1.0, 1.0])
-        if packed:
-            # all three remaining terms in the pair-packed rows (a >= b, i >= j): the particle ladder (:383) and the two
-            # hole-ladder-shaped products (:380-382; B2 and B' are symmetric under (kl)(ij) -> (lk)(ji)) — 1/4 of their
-            # flops; B' = V_kldc u2_dcij itself is formed pair-packed inside the second call, on top of the symmetrised
-            # u1 term that was held back above
-            npp = self.L.shape[0]
-            B5s = c.permute("klij->klij", B5)
-            c.permute("lkji->klij", B5, out=B5s, beta=1.0)
-            c.ladder_sym(u2, self.L, 0, npp, dressed=self.dressed)
-            c.hole_ladder_packed(u2, self.B2, self.L, 0, npp)
-            c.hole_ladder_packed(T, B5s, self.L, 0, npp, y=u2)
-            c.ladder_sym_unpack(self.L, D, beta=1.0)
-            return D
-        Bn = c.contract("kldc,dcij->klij", V["ijab"], u2)
-        if self.t_sym:           # + the symmetrised u1 term that was held back above
-            c.permute("klij->klij", B5, out=Bn, beta=1.0)
-            c.permute("lkji->klij", B5, out=Bn, beta=1.0)
-        c.contract("abkl,klij->abij", u2, self.B2, out=D, beta=1.0)               # :380, :382
-        c.contract("abkl,klij->abij", T, Bn, out=D, beta=1.0)                     # :381
-        if self.v_sym and u2_sym:                                                 # :383
-            c.ladder_sym(u2, self.L, 0, self.L.shape[0], dressed=self.dressed)
-            c.ladder_sym_unpack(self.L, D, beta=1.0)
-        else:
-            c.contract("abcd,cdij->abij", V["abcd"], u2, out=D, beta=1.0)
-        return D
+    def apply_many(self, u1s, u2s, syms=None, out1=None, out2=None):
+        """[(sigma1_z, sigma2_z)] for the trial vectors (u1s[z], u2s[z]).  ``syms[z]``: the caller's knowledge that u2_z has
+        the exchange symmetry u2_abij = u2_baji (tested on the device when ``syms`` is None); ``out1`` / ``out2``: device
+        arrays that receive sigma1_z / sigma2_z (e.g. the two parts of a flat subspace vector) instead of fresh ones."""
+        if self._h is None:
+            raise PymesError("the EOM sigma handle has been destroyed (its context was closed)")
+        k = len(u1s)
+        c, no, nv = self.ctx, self.no, self.nv
+        s1 = [out1[z] if out1 is not None else c.empty((nv, no)) for z in range(k)]
+        s2 = [out2[z] if out2 is not None else c.empty((nv, nv, no, no)) for z in range(k)]
+        sym = None if syms is None else (C.c_int * max(k, 1))(*[int(bool(x)) for x in syms])
+        c.lib.call("pymes_eom_sigma_apply", self._h, k, _lib.ptr_array([u.ptr for u in u1s]), _lib.ptr_array([u.ptr for u in u2s]),
+                   sym, _lib.ptr_array([x.ptr for x in s1]), _lib.ptr_array([x.ptr for x in s2]))
+        return list(zip(s1, s2))
 
     def apply(self, u1, u2, u2_sym=None):
-        return self.singles(u1, u2), self.doubles(u1, u2, u2_sym)
+        return self.apply_many([u1], [u2], None if u2_sym is None else [u2_sym])[0]
 
-    # ------------------------------------------------------------------------------------------
-    MAX_STACK = 16          # vectors per stacked build (the batched ladder launches take at most 64)
+    def singles(self, u1, u2):
+        """eom_ccsd.py:268-310."""
+        return self.apply(u1, u2)[0]
 
-    def stack_limit(self):
-        """How many trial vectors one stacked build may take: nine (ov)^2-sized temporaries per vector (X, Tt, DxT, DdT, D,
-        S2, the packed ladder rows and their operands) must fit in half of what the device has free right now."""
-        free = self.ctx.mem_info()[0] + self.ctx._spare_bytes
-        per_vector = 9 * 8 * (self.no * self.nv) ** 2
-        return int(max(1, min(self.MAX_STACK, (free // 2) // max(per_vector, 1))))
+    def doubles(self, u1, u2, u2_sym=None):
+        """eom_ccsd.py:312-385."""
+        return self.apply(u1, u2, u2_sym)[1]
 
-    def apply_many(self, u1s, u2s, syms=None, out1=None, out2=None):
-        """sigma for any number of trial vectors: stacked builds (``_apply_stack``) over chunks of at most ``stack_limit()``
-        vectors — every batched kernel and every temporary is sized by the chunk, not by the subspace; a chunk whose
-        temporaries cannot be allocated after all is built vector by vector.  ``out1`` / ``out2``: device arrays that receive
-        sigma1_z / sigma2_z (e.g. the two parts of a flat subspace vector) instead of fresh ones."""
-        k = len(u1s)
-        if syms is None:
-            syms = [self.exchange_symmetric(u2) for u2 in u2s]
-        res = []
-        step = self.stack_limit()
-        for lo in range(0, k, step):
-            hi = min(k, lo + step)
-            o1 = out1[lo:hi] if out1 is not None else None
-            o2 = out2[lo:hi] if out2 is not None else None
-            try:
-                res += self._apply_stack(u1s[lo:hi], u2s[lo:hi], syms[lo:hi], o1, o2)
-            except PymesError as err:
-                if hi - lo < 2 or "memory" not in str(err).lower():
-                    raise
-                self.ctx.trim()          # out of device memory in the middle of a stacked build: one vector at a time
-                for z in range(lo, hi):
-                    res += self._apply_stack(u1s[z:z + 1], u2s[z:z + 1], syms[z:z + 1],
-                                             o1[z - lo:z - lo + 1] if o1 is not None else None,
-                                             o2[z - lo:z - lo + 1] if o2 is not None else None)
-        return res
-
-    def _into(self, pairs, out1, out2):
-        """Results of the vector-by-vector build copied into the caller's output arrays, if any."""
-        if out1 is None and out2 is None:
-            return pairs
-        res = []
-        for z, (s1, s2) in enumerate(pairs):
-            if out1 is not None:
-                s1 = out1[z].copy_from(s1)
-            if out2 is not None:
-                s2 = out2[z].copy_from(s2)
-            res.append((s1, s2))
-        return res
-
-    def _apply_stack(self, u1s, u2s, syms, out1=None, out2=None):
-        """sigma for k trial vectors at once: [(sigma1_z, sigma2_z)].  The reference builds sigma vector by vector for
-        the whole Davidson subspace (eom_ccsd.py:95-101); here the k vectors are stacked, so that every operand that does not
-        depend on the trial vector — the hoisted (ov)^2 pair matrices, V_abcd (pair-packed), T, the V.T intermediates — is
-        read ONCE for all of them: the (ov)^3 products become [k ov x ov x ov] GEMMs, the particle ladders one batched
-        launch, the one-index terms GEMMs with M = k v.  Needs exchange-symmetric vectors and the pair-packed forms
-        (``many_ok``); anything else goes vector by vector through ``apply``."""
-        k = len(u1s)
-        if k < 2 or not self.many_ok or not all(syms):
-            return self._into([self.apply(u1, u2, u2_sym=sy) for u1, u2, sy in zip(u1s, u2s, syms)], out1, out2)
-        c, V, T = self.ctx, self.V, self.T
-        no, nv = self.no, self.nv
-
-        def part(stack, z):
-            n = stack.size // k
-            return DeviceArray(c, stack.ptr + 8 * z * n, stack.shape[1:], owned=False, keepalive=stack)
-        U1 = c.empty((k, nv, no))
-        X = c.empty((k, nv, no, nv, no))        # X[z,(a,j),(b,i)] = u2_z[a,b,i,j]                   (symmetric matrices)
-        Tt = c.empty((k, nv, no, nv, no))       # Tt[z,(a,i),(b,j)] = 2 u2_z[a,b,i,j] - u2_z[b,a,i,j]  (symmetric matrices)
-        for z in range(k):
-            part(U1, z).copy_from(u1s[z])
-            c.pair_layouts(u2s[z], part(X, z), part(Tt, z))
-        # ---- singles (eom_ccsd.py:268-310), ut[a,b,i,j] = Tt[(a,i),(b,j)] --------------------------------------------------
-        S1 = c.contract("zck,ckai->zai", U1, self.W1)
-        c.contract("ac,zci->zai", self.Gvv_s, U1, out=S1, beta=1.0, batch="z")
-        c.contract("zak,ki->zai", U1, self.Goo_s, out=S1, beta=1.0)
-        c.contract("zaibj,bj->zai", Tt, self.fovT, out=S1, beta=1.0)
-        c.contract("zajbk,jkib->zai", Tt, V["ijka"], out=S1, alpha=-1.0, beta=1.0)
-        c.contract("jabc,zbjci->zai", V["iabc"], Tt, out=S1, beta=1.0, batch="z")        # (z as a batch: Tt is read in place)
-        # ---- (ov)^3 products, transposed: only Dx + Dx^T and Dd + Dd^T enter (:377), X and Tt are symmetric matrices ----------
-        DxT = c.contract("zajdl,bidl->zajbi", X, self.MDU)                        # (MDU . u2x)^T per vector
-        DdT = c.permute("zajbi->zajbi", DxT, alpha=0.5)                           # same memory layout as "zaibj"
-        c.contract("zaidl,bjdl->zaibj", Tt, self.M12, out=DdT, alpha=0.5, beta=1.0)
-        # ---- one-index dressings ---------------------------------------------------------------------------------------------
-        Xoo = c.contract("klid,zdl->zki", V["ijka"], U1, alpha=-2.0)
-        c.contract("kldi,zdl->zki", V["ijak"], U1, out=Xoo, beta=1.0)
-        c.contract("kd,zdi->zki", self.fov, U1, out=Xoo, alpha=-1.0, beta=1.0, batch="z")
-        c.contract("kldc,zdlci->zki", V["ijab"], X, out=Xoo, alpha=-2.0, beta=1.0, batch="z")      # u2[d,c,i,l] = X[(d,l),(c,i)]
-        c.contract("kldc,zdicl->zki", V["ijab"], X, out=Xoo, beta=1.0, batch="z")                  # u2[d,c,l,i] = X[(d,i),(c,l)]
-        c.contract("zki,akbj->zaibj", Xoo, self.Td, out=DdT, beta=1.0, batch="za")
-        Xvv = c.contract("ladc,zdl->zac", V["iabc"], U1, alpha=2.0)
-        c.contract("lacd,zdl->zac", V["iabc"], U1, out=Xvv, alpha=-1.0, beta=1.0)
-        c.contract("zal,lc->zac", U1, self.fov, out=Xvv, alpha=-1.0, beta=1.0)
-        c.contract("lkcd,zakdl->zac", V["ijab"], X, out=Xvv, alpha=-2.0, beta=1.0, batch="z")      # u2[a,d,l,k] = X[(a,k),(d,l)]
-        c.contract("lkcd,zdkal->zac", V["ijab"], X, out=Xvv, beta=1.0, batch="z")                  # u2[d,a,l,k] = X[(d,k),(a,l)]
-        D = c.contract("zac,cbij->zabij", Xvv, T)
-        c.contract("abdj,zdi->zabij", self.WAt, U1, out=D, beta=1.0, batch="zab")
-        c.contract("abdi,zdj->zabij", self.W3t, U1, out=D, alpha=-1.0, beta=1.0, batch="zab")
-        c.contract("zal,lbij->zabij", U1, self.A346, out=D, beta=1.0)
-        c.contract("abic,zcj->zabij", V["abic"], U1, out=D, beta=1.0, batch="z")
-        npp = self.L.shape[0]
-        Lall = c.empty((k, npp, no * no))
-        c.ladder_sym_multi(u2s, Lall, dressed=self.dressed)                                                   # :383, all vectors
-        out = []
-        S2 = c.empty(D.shape) if out2 is None else None
-        B5s = []
-        for z in range(k):
-            Dz, u2, u1 = part(D, z), u2s[z], part(U1, z)
-            c.contract("ad,dbij->abij", self.Gvv, u2, out=Dz, beta=1.0)
-            c.contract("li,ablj->abij", self.Goo, u2, out=Dz, beta=1.0, batch="ab")
-            B5 = c.contract("klid,dj->klij", V["ijka"], u1)
-            B5s.append(c.permute("klij->klij", B5))
-            c.permute("lkji->klij", B5, out=B5s[z], beta=1.0)
-        # the hole-ladder-shaped terms of all vectors in batched launches (the shared side — V_klij + V_klcd T_cdij, then T —
-        # packed once)
-        c.hole_ladder_packed_multi(u2s, [self.B2] * k, Lall)                            # :380, :382
-        c.hole_ladder_packed_multi([T] * k, B5s, Lall, ys=u2s)                          # :381 (+ the symmetrised u1 term)
-        for z in range(k):
-            s2 = part(S2, z) if out2 is None else out2[z]
-            c.symmetrised_assemble(part(D, z), part(DdT, z), part(DxT, z), s2, L=part(Lall, z))            # :377 + unpacking
-            s1 = part(S1, z) if out1 is None else out1[z].copy_from(part(S1, z))
-            out.append((s1, s2))
-        return out
+    def trim(self):
+        if self._h is not None:
+            self.ctx.lib.call("pymes_eom_sigma_trim", self._h)
 
 
 class EOM_CCSD:
@@ -715,10 +452,26 @@ class EOM_CCSD:
                 "iaai": np.einsum("iaai->ai", dict_t_V["iabj"]), "iaia": np.einsum("iaia->ai", dict_t_V["iajb"]),
                 "ijij": np.einsum("ijij->ij", dict_t_V["klij"]), "abab": np.einsum("abab->ab", dict_t_V["abcd"])}
 
+    def _device_diagonals(self, t_fock_pq, dict_t_V, t_T_abij):
+        """Both diagonals (eom_ccsd.py:169-198, :200-266) on the device for the device-resident hand-over: (d1 [v,o], d2
+        [v,v,o,o]) as DeviceArrays of the integrals' context (``pymes_eom_diagonals``: the V.T sums, the four diagonal
+        slices and the assembly in three kernels; nothing of size o^2 v^2 crosses PCIe)."""
+        c = dict_t_V.ctx
+        dict_t_V.require(("ijab", "iabj", "iajb", "klij", "abcd"))
+        f = t_fock_pq.get() if isinstance(t_fock_pq, DeviceArray) else np.asarray(t_fock_pq)
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        t2 = t_T_abij if isinstance(t_T_abij, DeviceArray) else c.array(t_T_abij)
+        d1, d2 = c.empty((c.nv, c.no)), c.empty((c.nv, c.nv, c.no, c.no))
+        c.lib.call("pymes_eom_diagonals", c.handle, _lib.host_ptr(f), C.c_void_p(t2.ptr), 1, C.c_void_p(d1.ptr),
+                   C.c_void_p(d2.ptr))
+        return d1, d2
+
     def get_diag_singles(self, t_fock_pq, dict_t_V, t_T_abij, _inputs=None):
         """eom_ccsd.py:169-198, terms grouped: with V~ = 2V - V^(ab), T~ = 2T - T^(ab) the four (a,i)-resolved
         V.T terms are one Hadamard sum.  O(o^2 v^2) work on host arrays (preconditioner data, once per solve)."""
         no = self.no
+        if _inputs is None and isinstance(dict_t_V, DressedDeviceIntegrals):
+            return self._device_diagonals(t_fock_pq, dict_t_V, t_T_abij)[0].get()
         g = _inputs or self._diag_inputs(dict_t_V, t_T_abij)
         V, T = g["V"], g["T"]
         f = t_fock_pq.get() if isinstance(t_fock_pq, DeviceArray) else np.asarray(t_fock_pq)
@@ -734,6 +487,8 @@ class EOM_CCSD:
     def get_diag_doubles(self, t_fock_pq, dict_t_V, t_T_abij, _inputs=None):
         """eom_ccsd.py:200-266 (same grouping; the reference's placement of the `ibib` term on the (a,i) axes is kept)."""
         no = self.no
+        if _inputs is None and isinstance(dict_t_V, DressedDeviceIntegrals):
+            return self._device_diagonals(t_fock_pq, dict_t_V, t_T_abij)[1].get()
         g = _inputs or self._diag_inputs(dict_t_V, t_T_abij)
         V, T = g["V"], g["T"]
         f = t_fock_pq.get() if isinstance(t_fock_pq, DeviceArray) else np.asarray(t_fock_pq)

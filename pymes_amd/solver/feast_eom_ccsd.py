@@ -248,10 +248,14 @@ class FEAST_EOM_CCSD(EOM_CCSD):
             t_fock_dressed_pq = t_fock_dressed_pq.get()
         f = np.asarray(t_fock_dressed_pq, dtype=np.float64)
         nv = f.shape[0] - no
-        dg = self._diag_inputs(dict_t_V_dressed, t_T_abij)
-        diag_ai = self.get_diag_singles(f, dict_t_V_dressed, t_T_abij, _inputs=dg)
-        diag_abij = self.get_diag_doubles(f, dict_t_V_dressed, t_T_abij, _inputs=dg)
-        del dg
+        if device_form:
+            # both diagonals on the device (pymes_eom_diagonals): the preconditioners below are formed from them in HBM
+            diag_ai, diag_abij = self._device_diagonals(f, dict_t_V_dressed, t_T_abij)
+        else:
+            dg = self._diag_inputs(dict_t_V_dressed, t_T_abij)
+            diag_ai = self.get_diag_singles(f, dict_t_V_dressed, t_T_abij, _inputs=dg)
+            diag_abij = self.get_diag_doubles(f, dict_t_V_dressed, t_T_abij, _inputs=dg)
+            del dg
         print_logging_info("Initialising u tensors...", level=1)
         # the reference APPENDS its two random vectors to whatever self.u_singles / u_doubles hold (:89-91): a second solve()
         # on the same object continues from the trial space of the first
@@ -270,8 +274,13 @@ class FEAST_EOM_CCSD(EOM_CCSD):
         n1, n2 = nv * no, nv * nv * no * no
         n = n1 + n2
         shapes = ((nv, no), (nv, nv, no, no))
-        diag = np.concatenate((diag_ai.ravel(), diag_abij.ravel()))
         ctx = dict_t_V_dressed.ctx if device_form else self._context(dict_t_V_dressed, nv)
+        if device_form:
+            diag = ctx.empty((n,))                     # [d1 | d2], flat, on the device
+            self._part(ctx, diag, 0, shapes[0]).copy_from(diag_ai)
+            self._part(ctx, diag, n1, shapes[1]).copy_from(diag_abij)
+        else:
+            diag = np.concatenate((diag_ai.ravel(), diag_abij.ravel()))
         self.history, self.linear_solver_info = [], []
         from pymes_amd.solver.ccd import quiet_collector
         collector = quiet_collector().__enter__()
@@ -288,6 +297,11 @@ class FEAST_EOM_CCSD(EOM_CCSD):
                 normalise(u)
             minv = []                                                              # 1 / (z_e - diag + 0.01) per node (:342)
             for ze in z:
+                if device_form:
+                    mv = _CVec(ctx.empty((n,)), ctx.empty((n,)))
+                    ctx.cshift_inv(diag, ze, 1.0, 0.01, mv.re, mv.im)
+                    minv.append(mv)
+                    continue
                 mv = 1.0 / (ze - diag + 0.01)
                 minv.append(_CVec(ctx.array(np.ascontiguousarray(mv.real)), ctx.array(np.ascontiguousarray(mv.imag))))
             e_norm_prev = 1e10

@@ -320,6 +320,79 @@ void lincomb_dev(double* out, int nx, const double* const* x, const double* coef
     }
 }
 
+void cshift_inv(const double* d, double zr, double zi, double hr, double hi, double shift, double* mr, double* mi, int64_t n,
+                stream_t) {
+    for (int64_t e = 0; e < n; ++e) {
+        const double x = zr - hr * d[e] + shift, y = zi - hi * d[e], q = x * x + y * y;
+        mr[e] = x / q;
+        mi[e] = -y / q;
+    }
+}
+int64_t eom_diag_ws_doubles(int, int) { return 1; }
+// eom_ccsd.py:169-266 as plain loops over the reference's einsum index lists (independent of the kernels' staging)
+void eom_diagonals(const double* V, const double* T, const double* dai, const double* iaai, const double* iaia, const double* ijij,
+                   const double* abab, double* d1, double* d2, int no, int nv, double*, stream_t) {
+    const long o = no, v = nv;
+    auto Vx = [&](long k, long l, long c, long d) { return V[((k * o + l) * v + c) * v + d]; };
+    auto Tx = [&](long a, long b, long i, long j) { return T[((a * v + b) * o + i) * o + j]; };
+    std::vector<double> sa(v, 0.0), si(o, 0.0), a_(v, 0.0), i_(o, 0.0), ij(o * o, 0.0), ab(v * v, 0.0), ai(v * o, 0.0),
+        aj(v * o, 0.0), z1(v * o * o, 0.0), x1(v * v * o, 0.0);
+    for (long a = 0; a < v; ++a)
+        for (long j = 0; j < o; ++j)
+            for (long k = 0; k < o; ++k)
+                for (long b = 0; b < v; ++b) {
+                    sa[a] += (2.0 * Vx(j, k, b, a) - Vx(j, k, a, b)) * Tx(a, b, j, k);
+                    a_[a] += Vx(j, k, b, a) * (Tx(a, b, j, k) - 2.0 * Tx(b, a, j, k));
+                }
+    for (long i = 0; i < o; ++i)
+        for (long j = 0; j < o; ++j)
+            for (long c = 0; c < v; ++c)
+                for (long b = 0; b < v; ++b) {
+                    si[i] += Vx(j, i, c, b) * Tx(b, c, j, i);
+                    i_[i] += (Vx(j, i, b, c) - 2.0 * Vx(j, i, c, b)) * Tx(c, b, j, i);
+                    ij[i * o + j] += Vx(i, j, c, b) * Tx(c, b, i, j);
+                }
+    for (long a = 0; a < v; ++a)
+        for (long b = 0; b < v; ++b)
+            for (long k = 0; k < o; ++k)
+                for (long l = 0; l < o; ++l) ab[a * v + b] += Vx(k, l, a, b) * Tx(a, b, k, l);
+    for (long a = 0; a < v; ++a)
+        for (long i = 0; i < o; ++i) {
+            double s1 = 0.0, s2 = 0.0;
+            for (long k = 0; k < o; ++k)
+                for (long c = 0; c < v; ++c) {
+                    s1 += (2.0 * Vx(k, i, c, a) - Vx(k, i, a, c)) * (2.0 * Tx(c, a, k, i) - Tx(a, c, k, i));
+                    s2 += (2.0 * Vx(k, i, c, a) - 2.0 * Vx(k, i, a, c)) * Tx(c, a, k, i) +
+                          (Vx(k, i, a, c) - 2.0 * Vx(k, i, c, a)) * Tx(a, c, k, i);
+                    for (long b = 0; b < v; ++b) s2 += Vx(k, i, c, b) * Tx(a, c, k, i);
+                    aj[a * o + i] += Vx(k, i, a, c) * Tx(a, c, k, i);
+                }
+            d1[a * o + i] = dai[a * o + i] + 2.0 * iaai[a * o + i] - iaia[a * o + i] + s1 - sa[a] - si[i];
+            ai[a * o + i] = dai[a * o + i] + iaai[a * o + i] - 2.0 * iaia[a * o + i] + s2;
+        }
+    for (long a = 0; a < v; ++a)
+        for (long i = 0; i < o; ++i)
+            for (long j = 0; j < o; ++j)
+                for (long k = 0; k < o; ++k)
+                    for (long c = 0; c < v; ++c) z1[(a * o + i) * o + j] += Vx(k, j, a, c) * Tx(c, a, k, i);
+    for (long a = 0; a < v; ++a)
+        for (long b = 0; b < v; ++b)
+            for (long j = 0; j < o; ++j)
+                for (long k = 0; k < o; ++k) x1[(a * v + b) * o + j] += Vx(k, j, a, b) * Tx(a, b, k, j);
+    auto half = [&](long a, long b, long i, long j) {
+        double r = ai[a * o + i] + a_[a] + i_[i] - 2.0 * x1[(a * v + b) * o + j] - 2.0 * ij[i * o + j] + z1[(a * o + i) * o + j] +
+                   aj[a * o + j];
+        for (long k = 0; k < o; ++k) r += Vx(k, i, a, b) * Tx(a, b, k, j);
+        for (long c = 0; c < v; ++c) r += Vx(i, j, c, a) * Tx(c, b, i, j);
+        return r;
+    };
+    for (long a = 0; a < v; ++a)
+        for (long b = 0; b < v; ++b)
+            for (long i = 0; i < o; ++i)
+                for (long j = 0; j < o; ++j)
+                    d2[((a * v + b) * o + i) * o + j] = half(a, b, i, j) + half(b, a, j, i) + ijij[i * o + j] + ij[i * o + j] +
+                                                        ab[a * v + b] + abab[a * v + b];
+}
 void cmul(const double* mr, const double* mi, const double* xr, const double* xi, double* yr, double* yi, int64_t n, stream_t) {
     for (int64_t e = 0; e < n; ++e) {
         const double a = xr[e], b = xi[e];

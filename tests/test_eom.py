@@ -75,6 +75,24 @@ def run_product(lib, monkeypatch):
         assert np.abs(e.update_doubles(f, Vb, u1 + 1j * w1, u2 + 1j * w2, t2) - g["c2"]).max() < 1e-12
         assert np.abs(e.get_diag_singles(f, Vb, t2) - g["d1"]).max() < 1e-12
         assert np.abs(e.get_diag_doubles(f, Vb, t2) - g["d2"]).max() < 1e-12
+        # the same two diagonals on the device (pymes_eom_diagonals: what the device-resident FEAST chain uses) against the
+        # reference's output, on integrals without any symmetry
+        import ctypes as C
+        ctx = e._context(Vb, nv)
+        try:
+            d1, d2 = ctx.empty((nv, no)), ctx.empty((nv, nv, no, no))
+            fc = np.ascontiguousarray(f, dtype=np.float64)
+            ctx.lib.call("pymes_eom_diagonals", ctx.handle, _lib.host_ptr(fc), C.c_void_p(ctx.array(t2).ptr), 0,
+                         C.c_void_p(d1.ptr), C.c_void_p(d2.ptr))
+            assert np.abs(d1.get() - g["d1"]).max() < 1e-12
+            assert np.abs(d2.get() - g["d2"]).max() < 1e-12
+            zr = ctx.empty((d2.size,))
+            zi = ctx.empty((d2.size,))
+            ctx.cshift_inv(d2.reshape(d2.size), 0.3 + 0.2j, 1.0 - 0.5j, 0.01, zr, zi)
+            want = 1.0 / (0.3 + 0.2j - (1.0 - 0.5j) * g["d2"].ravel() + 0.01)
+            assert np.abs(zr.get() + 1j * zi.get() - want).max() < 1e-12 * np.abs(want).max()
+        finally:
+            ctx.close()
         with pytest.raises(TypeError):
             e.update_singles(f.astype(complex), Vb, u1, u2, t2)
     # exchange-symmetric integrals and trial doubles: the pair-packed particle ladder must give the same sigma
