@@ -429,7 +429,8 @@ int pymes_eom_sigma_flags(pymes_eom* h, int* flags);
 int pymes_eom_sigma_apply(pymes_eom* h, int k, const double* const* u1_dev, const double* const* u2_dev, const int* sym,
                           double* const* s1_dev, double* const* s2_dev);
 int pymes_eom_diagonals(pymes_ctx* ctx, const double* f_host, const double* t2_dev, int dressed, double* d1_dev, double* d2_dev);
-int pymes_eom_sigma_trim(pymes_eom* h);
+/* releases the engine's pooled scratch that is not in use (the temporaries / hoisted arrays of destroyed EOM handles) */
+int pymes_scratch_trim(pymes_ctx* ctx);
 int pymes_eom_sigma_destroy(pymes_eom* h);
 /* (mr + i mi)[e] = 1 / ((zr + i zi) - (hr + i hi) d[e] + shift), e < n: the FEAST preconditioner 1 / (z - diag + 0.01)
  * (feast_eom_ccsd.py:342; hs = 1j dt for the real-time form :276-278) from the device-resident diagonal */

@@ -133,7 +133,7 @@ SIGNATURES = {
     "pymes_eom_sigma_flags": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pymes_eom_sigma_apply": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5),
     "pymes_eom_diagonals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
-    "pymes_eom_sigma_trim": (C.c_int, [C.c_void_p]),
+    "pymes_scratch_trim": (C.c_int, [C.c_void_p]),
     "pymes_eom_sigma_destroy": (C.c_int, [C.c_void_p]),
     "pymes_diis_mix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, c_pp, c_pp, c_i64_p, c_pp, c_pp]),
     "pymes_diis_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),

@@ -763,8 +763,8 @@ int pymes_eom_diagonals(pymes_ctx* ctx, const double* f_host, const double* t2, 
         pymes::eom_diagonals(E(ctx), f_host, t2, dressed != 0, d1, d2);
     });
 }
-int pymes_eom_sigma_trim(pymes_eom* h) {
-    return guarded([&] { S(h).trim(); });
+int pymes_scratch_trim(pymes_ctx* ctx) {
+    return guarded([&] { E(ctx).scratch_trim(); });
 }
 int pymes_eom_sigma_destroy(pymes_eom* h) {
     return guarded([&] {

@@ -119,6 +119,8 @@ Engine::~Engine() {
         dev::stream_sync(stream);
         for (auto g : graphs_) dev::graph_destroy(g);
         for (void* p : user_allocs_) dev::dfree(p);
+        for (auto& kv : scratch_free_) dev::dfree(kv.second);
+        for (auto& kv : scratch_live_) dev::dfree(kv.first);
         for (auto& p : lay_) dev::dfree(p);
         dev::dfree(xs_oo_);
         dev::dfree(xs_vv_);
@@ -136,6 +138,42 @@ Engine::~Engine() {
     }
 }
 
+
+double* Engine::scratch_get(int64_t doubles) {
+    doubles = std::max<int64_t>(doubles, 1);
+    auto it = scratch_free_.find(doubles);
+    double* p;
+    if (it != scratch_free_.end()) {
+        p = it->second;
+        scratch_free_.erase(it);
+    } else {
+        p = static_cast<double*>(dev::try_dmalloc(sizeof(double) * static_cast<size_t>(doubles)));
+        if (!p) {
+            scratch_trim();
+            p = static_cast<double*>(dev::try_dmalloc(sizeof(double) * static_cast<size_t>(doubles)));
+        }
+        if (!p) throw Error("out of device memory (" + std::to_string((doubles * 8) >> 20) + " MiB of scratch)");
+    }
+    scratch_live_[p] = doubles;
+    return p;
+}
+void Engine::scratch_put(double* p) {
+    auto it = scratch_live_.find(p);
+    if (it == scratch_live_.end()) return;
+    scratch_free_.emplace(it->second, p);
+    scratch_live_.erase(it);
+}
+void Engine::scratch_trim() {
+    if (scratch_free_.empty()) return;
+    dev::stream_sync(stream);
+    for (auto& kv : scratch_free_) dev::dfree(kv.second);
+    scratch_free_.clear();
+}
+int64_t Engine::scratch_free_bytes() const {
+    int64_t b = 0;
+    for (auto& kv : scratch_free_) b += kv.first * 8;
+    return b;
+}
 
 void* Engine::user_malloc(size_t bytes) {
     void* p = dev::dmalloc(bytes);

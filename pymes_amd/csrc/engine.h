@@ -102,6 +102,13 @@ class Engine {
     // side still holds
     void* user_malloc(size_t bytes);
     void user_free(void* p);
+    // Pooled device scratch for multi-call objects (the EOM sigma handle, eom.cpp): buffers are handed out by exact size and
+    // kept when returned — a second solve on the same context finds the buffers of the first (stream-ordered reuse: all
+    // work is on `stream`).  scratch_trim() frees what is not in use (also tried by scratch_get before it gives up).
+    double* scratch_get(int64_t doubles);
+    void scratch_put(double* p);
+    void scratch_trim();
+    int64_t scratch_free_bytes() const;
     // launch graphs recorded on this engine's stream (see device_api.h)
     void graph_begin();
     dev::graph_t graph_end();
@@ -241,6 +248,8 @@ class Engine {
     void ensure_xs();
     dev::stream_t own_stream_ = nullptr;
     std::set<void*> user_allocs_;
+    std::multimap<int64_t, double*> scratch_free_;
+    std::map<double*, int64_t> scratch_live_;
     std::set<dev::graph_t> graphs_;
     bool capturing_ = false;
     double* V_[16] = {nullptr};      // undressed blocks (owned)

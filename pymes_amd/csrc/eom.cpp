@@ -10,38 +10,13 @@
 
 namespace pymes {
 
-// ---- pooled temporaries -------------------------------------------------------------------------------------------------
-double* EomSigma::get(int64_t doubles) {
-    auto it = free_.find(doubles);
-    double* p;
-    if (it != free_.end()) {
-        p = it->second;
-        free_.erase(it);
-    } else {
-        p = static_cast<double*>(dev::try_dmalloc(sizeof(double) * static_cast<size_t>(std::max<int64_t>(doubles, 1))));
-        if (!p) {
-            trim();
-            p = static_cast<double*>(dev::try_dmalloc(sizeof(double) * static_cast<size_t>(std::max<int64_t>(doubles, 1))));
-        }
-        if (!p) throw Error("eom sigma: out of device memory (" + std::to_string((doubles * 8) >> 20) + " MiB temporary)");
-    }
-    live_[p] = doubles;
-    return p;
-}
-void EomSigma::put(double* p) {
-    auto it = live_.find(p);
-    if (it == live_.end()) return;
-    free_.emplace(it->second, p);
-    live_.erase(it);
-}
-void EomSigma::trim() {
-    if (free_.empty()) return;
-    dev::stream_sync(e.stream);
-    for (auto& kv : free_) dev::dfree(kv.second);
-    free_.clear();
-}
+// ---- temporaries and hoisted arrays come from the engine's scratch pool: a second solve on the same context (the warm
+// start of a Davidson run, the next FEAST solve) finds the buffers of the first instead of paying hipMalloc again ----------
+double* EomSigma::get(int64_t doubles) { return e.scratch_get(doubles); }
+void EomSigma::put(double* p) { e.scratch_put(p); }
+void EomSigma::trim() { e.scratch_trim(); }
 double* EomSigma::keep(int64_t doubles) {
-    double* p = static_cast<double*>(dev::dmalloc(sizeof(double) * static_cast<size_t>(std::max<int64_t>(doubles, 1))));
+    double* p = e.scratch_get(doubles);
     owned_.push_back(p);
     return p;
 }
@@ -91,14 +66,7 @@ int EomSigma::flags() const {
 }
 
 EomSigma::~EomSigma() {
-    try {
-        dev::set_device(e.device);
-        dev::stream_sync(e.stream);
-        for (auto& kv : free_) dev::dfree(kv.second);
-        for (auto& kv : live_) dev::dfree(kv.first);
-        for (double* p : owned_) dev::dfree(p);
-    } catch (...) {
-    }
+    for (double* p : owned_) e.scratch_put(p);        // (stream-ordered: whoever gets them next enqueues behind our last kernel)
 }
 
 // ---- hoisting: everything of eom_ccsd.py:288-373 that does not depend on (u1, u2) -----------------------------------------
@@ -123,7 +91,6 @@ EomSigma::EomSigma(Engine& eng, const double* f_host, const double* t2, bool dre
         fvv = upload(o, v, o, v, 1.0);
         const TView Vijab = V("ijab"), Viabj = V("iabj"), Viajb = V("iajb"), Vijka = V("ijka"), Vijak = V("ijak"),
                     Viabc = V("iabc"), Viajk = V("iajk"), Vklij = V("klij"), Vabcd = V("abcd");
-        V("abic");
         const TView T4 = mv(T, {v, v, o, o});
         Td = keep(ov2);
         Tx = keep(ov2);
@@ -187,6 +154,39 @@ EomSigma::EomSigma(Engine& eng, const double* f_host, const double* t2, bool dre
         q.C(-1.0, Viabc, "kadc", T4, "cbkj", 1.0, mv(WA, {v, v, v, o}), "adbj");
         q.C(-1.0, Viabc, "kacd", T4, "bckj", 1.0, mv(WA, {v, v, v, o}), "adbj");
         q.C(1.0, Viabc, "kadc", T4, "bcki", 0.0, mv(W3, {v, v, v, o}), "adbi");
+        // ... merged: everything added to D is symmetrised by P(ijab,jiba) afterwards (:377), so a term X_abij may be replaced by
+        // its partner X_baji — sum_d WA[a,d,b,j] u1[d,i] by sum_d WA[b,d,a,i] u1[d,j] — and the two terms become ONE product with
+        // the free index of u1 innermost, WW[a,b,i,d] = WA[b,d,a,i] - W3[a,d,b,i]: [(a,b,i) x d] . u1[d,j] writes D in place, one
+        // pass over one v^3 o array per build instead of two
+        WW = keep(v * v * v * o);
+        q.P(1.0, mv(WA, {v, v, v, o}), "bdai", 0.0, mv(WW, {v, v, o, v}), "abid");
+        q.P(-1.0, mv(W3, {v, v, v, o}), "adbi", 1.0, mv(WW, {v, v, o, v}), "abid");
+        // ... and the plain V_abic . u1 term (:349) has the same shape, [(a,b,i) x c] . u1[c,j]: it rides in the same product
+        q.P(1.0, V("abic"), "abic", 1.0, mv(WW, {v, v, o, v}), "abic");
+        for (double** w : {&WA, &W3}) {           // only WW is read by the builds
+            owned_.erase(std::find(owned_.begin(), owned_.end(), *w));
+            put(*w);
+            *w = nullptr;
+        }
+        // The u2 parts of the one-index dressings (:353-354, :359-360) for an exchange-symmetric u2, whose crossed pair matrix
+        // X[(a,j),(b,i)] = u2[a,b,i,j] is symmetric: both index placements of u2 are rows / columns of X itself,
+        //   X_vv[a,c] = sum_kdl X[(a,k),(d,l)] (-2 V[l,k,c,d] + V[k,l,c,d]),   X_oo[k,i] = sum_dlc (-2 V[k,l,d,c] + V[k,l,c,d]) X[(d,l),(c,i)]
+        // — ONE product each, X read in place, against two products over transposed copies before (2.2 ms of a 26-ms build of
+        // four vectors at (30,120), rocprofv3 round 5)
+        // (Bvv = columns [0, v) of BB[(k,d,l), v + o]; columns [v, v + o) hold the singles term :297 in the same form: with
+        // Tt[(a,j),(b,k)] = 2 X[(a,k),(b,j)] - X[(a,j),(b,k)],  -sum_jbk Tt[(a,j),(b,k)] V[j,k,i,b] = sum_kbj X[(a,k),(b,j)] Bs[k,b,j,i],
+        // Bs = -2 V[j,k,i,b] + V[k,j,i,b] — the stacked build gets X_vv AND that singles term from ONE pass over X)
+        BB = keep(o * v * o * (v + o));
+        {
+            const TView BBv = mv(BB, {o, v, o, v + o});
+            q.P(-2.0, Vijab, "lkcd", 0.0, slice(BBv, 3, 0, v), "kdlc");
+            q.P(1.0, Vijab, "klcd", 1.0, slice(BBv, 3, 0, v), "kdlc");
+            q.P(-2.0, Vijka, "jkib", 0.0, slice(BBv, 3, v, v + o), "kbji");
+            q.P(1.0, Vijka, "kjib", 1.0, slice(BBv, 3, v, v + o), "kbji");
+        }
+        Aoo = keep(o * v * o * v);
+        q.P(-2.0, Vijab, "kldc", 0.0, mv(Aoo, {o, v, o, v}), "kdlc");
+        q.P(1.0, Vijab, "klcd", 1.0, mv(Aoo, {o, v, o, v}), "kdlc");
         // small hoisted V.T blocks
         A3 = keep(o * o * v * o);
         q.C(-2.0, Vijak, "klci", T4, "cbkj", 0.0, mv(A3, {o, o, v, o}), "libj");      // A_oovo
@@ -220,12 +220,6 @@ EomSigma::EomSigma(Engine& eng, const double* f_host, const double* t2, bool dre
         many_ok = v_sym && hole_sym && fused_ok && t_sym;
         if (many_ok) {
             fovT = upload(0, o, o, v, 1.0, true);
-            // WA / W3 with the contracted index third: u1[d,i] then meets WA[a,b,d,:] as a batch of (a,b) products whose
-            // o x o results ARE the tiles D[z,a,b,:,:]
-            WAt = keep(v * v * v * o);
-            W3t = keep(v * v * v * o);
-            q.P(1.0, mv(WA, {v, v, v, o}), "adbj", 0.0, mv(WAt, {v, v, v, o}), "abdj");
-            q.P(1.0, mv(W3, {v, v, v, o}), "adbi", 0.0, mv(W3t, {v, v, v, o}), "abdi");
             // the four u1 terms with one free index on u1 (A_oovo, A4, A6, V_iajk) as ONE product u1[a,l] A346[l,b,i,j]:
             // everything added to D is symmetrised by P(ijab,jiba) afterwards (:377), so a term X_abij may be replaced by its
             // partner X_baji
@@ -234,16 +228,9 @@ EomSigma::EomSigma(Engine& eng, const double* f_host, const double* t2, bool dre
             q.P(1.0, mv(A4, {o, o, v, o}), "ljbi", 1.0, mv(A346, {o, v, o, o}), "lbij");
             q.L(A346, {A346, A6, Viajk.p}, {1.0, -1.0, -1.0}, o * v * o * o);
         }
-        trim();
     } catch (...) {
-        try {
-            dev::stream_sync(e.stream);
-        } catch (...) {
-        }
-        for (auto& kv : free_) dev::dfree(kv.second);
-        for (auto& kv : live_) dev::dfree(kv.first);
-        for (double* p : owned_) dev::dfree(p);
-        free_.clear(); live_.clear(); owned_.clear();
+        for (double* p : owned_) e.scratch_put(p);
+        owned_.clear();
         throw;
     }
 }
@@ -298,14 +285,22 @@ void EomSigma::doubles(const double* u1, const double* u2, bool u2_sym, double* 
     q.C(-2.0, Vijka, "klid", U1, "dl", 0.0, XooV, "ki");
     q.C(1.0, Vijak, "kldi", U1, "dl", 1.0, XooV, "ki");
     q.C(-1.0, FOV, "kd", U1, "di", 1.0, XooV, "ki");
-    q.C(-2.0, Vijab, "kldc", U2, "dcil", 1.0, XooV, "ki");
-    q.C(1.0, Vijab, "kldc", U2, "dcli", 1.0, XooV, "ki");
+    if (u2_sym) {
+        q.C(1.0, mv(Aoo, {o, v, o, v}), "kdlc", P4(u2x), "dlci", 1.0, XooV, "ki");
+    } else {
+        q.C(-2.0, Vijab, "kldc", U2, "dcil", 1.0, XooV, "ki");
+        q.C(1.0, Vijab, "kldc", U2, "dcli", 1.0, XooV, "ki");
+    }
     q.C(1.0, XooV, "ki", P4(Td), "akbj", 1.0, P4(Dd), "aibj", "a");
     q.C(2.0, Viabc, "ladc", U1, "dl", 0.0, XvvV, "ac");
     q.C(-1.0, Viabc, "lacd", U1, "dl", 1.0, XvvV, "ac");
     q.C(-1.0, U1, "al", FOV, "lc", 1.0, XvvV, "ac");
-    q.C(-2.0, Vijab, "lkcd", U2, "adlk", 1.0, XvvV, "ac");
-    q.C(1.0, Vijab, "lkcd", U2, "dalk", 1.0, XvvV, "ac");
+    if (u2_sym) {
+        q.C(1.0, P4(u2x), "akdl", slice(mv(BB, {o, v, o, v + o}), 3, 0, v), "kdlc", 1.0, XvvV, "ac");
+    } else {
+        q.C(-2.0, Vijab, "lkcd", U2, "adlk", 1.0, XvvV, "ac");
+        q.C(1.0, Vijab, "lkcd", U2, "dalk", 1.0, XvvV, "ac");
+    }
     const bool packed = v_sym && u2_sym && hole_sym;
     const bool fused = packed && fused_ok;
     // D goes straight into the caller's array unless the fused assembly needs it as an input
@@ -314,8 +309,7 @@ void EomSigma::doubles(const double* u1, const double* u2, bool u2_sym, double* 
     const TView D = mv(Dp, {v, v, o, o});
     q.C(1.0, XvvV, "ac", T4, "cbij", 0.0, D, "abij");
     // V_kacd.T.u1 terms (:334, :343, :345, :346) through the hoisted V.T intermediates: o^2 v^3 instead of (ov)^3 each
-    q.C(1.0, mv(WA, {v, v, v, o}), "adbj", U1, "di", 1.0, D, "abij");
-    q.C(-1.0, mv(W3, {v, v, v, o}), "adbi", U1, "dj", 1.0, D, "abij");
+    q.C(1.0, mv(WW, {v, v, o, v}), "abid", U1, "dj", 1.0, D, "abij");
     q.C(1.0, mv(Gvv, {v, v}), "ad", U2, "dbij", 1.0, D, "abij");
     q.C(1.0, mv(Goo, {o, o}), "li", U2, "ablj", 1.0, D, "abij", "ab");
     q.C(1.0, U1, "al", mv(A3, {o, o, v, o}), "libj", 1.0, D, "abij");
@@ -325,7 +319,6 @@ void EomSigma::doubles(const double* u1, const double* u2, bool u2_sym, double* 
     q.C(1.0, Vijka, "klid", U1, "dj", 0.0, B5v, "klij");
     if (!t_sym) q.C(1.0, T4, "abkl", B5v, "klij", 1.0, D, "abij");
     q.C(-1.0, U1, "ak", V("iajk"), "kbij", 1.0, D, "abij");
-    q.C(1.0, V("abic"), "abic", U1, "cj", 1.0, D, "abij");
     auto packed_terms = [&]() {       // the terms (:380-383) that stay outside P(ijab,jiba), in the pair-packed rows L
         Tmp B5s(*this, o * o * o * o);
         q.P(1.0, B5v, "klij", 0.0, mv(B5s, {o, o, o, o}), "klij");
@@ -374,9 +367,7 @@ void EomSigma::doubles(const double* u1, const double* u2, bool u2_sym, double* 
 int EomSigma::stack_limit() const {
     // nine (ov)^2-sized temporaries per vector (X, Tt, DxT, DdT, D, the packed ladder rows and their operands) must fit in
     // half of what the device has free right now (pooled buffers count as free)
-    int64_t pooled = 0;
-    for (auto& kv : free_) pooled += kv.first * 8;
-    const double free_b = static_cast<double>(dev::mem_free_bytes()) + static_cast<double>(pooled);
+    const double free_b = static_cast<double>(dev::mem_free_bytes()) + static_cast<double>(e.scratch_free_bytes());
     const double per_vector = 9.0 * 8.0 * static_cast<double>(no) * nv * static_cast<double>(no) * nv;
     return static_cast<int>(std::max(1.0, std::min(16.0, std::floor(free_b / 2.0 / std::max(per_vector, 1.0)))));
 }
@@ -385,7 +376,7 @@ int EomSigma::stack_limit() const {
 void EomSigma::stack(int k, const double* const* u1, const double* const* u2, double* const* s1, double* const* s2) {
     const int64_t o = no, v = nv, ov = o * v, ov2 = ov * ov, npp = v * (v + 1) / 2, K = k;
     const Ops q{e};
-    const TView Vijab = V("ijab"), Vijka = V("ijka"), Vijak = V("ijak"), Viabc = V("iabc"), T4 = mv(T, {v, v, o, o});
+    const TView Vijka = V("ijka"), Vijak = V("ijak"), Viabc = V("iabc"), T4 = mv(T, {v, v, o, o});
     Tmp U1(*this, K * v * o), X(*this, K * ov2), Tt(*this, K * ov2);
     for (int z = 0; z < k; ++z) {
         dev::memcpy_d2d(U1.p + z * v * o, u1[z], sizeof(double) * v * o, e.stream);
@@ -400,7 +391,11 @@ void EomSigma::stack(int k, const double* const* u1, const double* const* u2, do
     q.C(1.0, mv(Gvv_s, {v, v}), "ac", U1v, "zci", 1.0, S1v, "zai", "z");
     q.C(1.0, U1v, "zak", mv(Goo_s, {o, o}), "ki", 1.0, S1v, "zai");
     q.C(1.0, Ttv, "zaibj", mv(fovT, {v, o}), "bj", 1.0, S1v, "zai");
-    q.C(-1.0, Ttv, "zajbk", Vijka, "jkib", 1.0, S1v, "zai");
+    // X_vv's u2 part (:359-360) and the singles term :297 from one pass over X: XS[z,a,:] = X[z,(a,k),(d,l)] BB[(k,d,l),:]
+    Tmp XS(*this, K * v * (v + o));
+    const TView XSv = mv(XS, {K, v, v + o});
+    q.C(1.0, Xv, "zakdl", mv(BB, {o, v, o, v + o}), "kdln", 0.0, XSv, "zan");
+    e.axpby(1.0, slice(XSv, 2, v, v + o), 1.0, S1v);
     q.C(1.0, Viabc, "jabc", Ttv, "zbjci", 1.0, S1v, "zai", "z");                       // (z as a batch: Tt is read in place)
     // ---- (ov)^3 products, transposed: only Dx + Dx^T and Dd + Dd^T enter (:377), X and Tt are symmetric matrices ---------------
     Tmp DxT(*this, K * ov2), DdT(*this, K * ov2);
@@ -414,21 +409,17 @@ void EomSigma::stack(int k, const double* const* u1, const double* const* u2, do
     q.C(-2.0, Vijka, "klid", U1v, "zdl", 0.0, XooV, "zki");
     q.C(1.0, Vijak, "kldi", U1v, "zdl", 1.0, XooV, "zki");
     q.C(-1.0, FOV, "kd", U1v, "zdi", 1.0, XooV, "zki", "z");
-    q.C(-2.0, Vijab, "kldc", Xv, "zdlci", 1.0, XooV, "zki", "z");                      // u2[d,c,i,l] = X[(d,l),(c,i)]
-    q.C(1.0, Vijab, "kldc", Xv, "zdicl", 1.0, XooV, "zki", "z");                       // u2[d,c,l,i] = X[(d,i),(c,l)]
+    q.C(1.0, mv(Aoo, {o, v, o, v}), "kdlc", Xv, "zdlci", 1.0, XooV, "zki", "z");       // u2[d,c,i,l] = X[(d,l),(c,i)], both placements
     q.C(1.0, XooV, "zki", mv(Td, {v, o, v, o}), "akbj", 1.0, DdTv, "zaibj", "za");
     q.C(2.0, Viabc, "ladc", U1v, "zdl", 0.0, XvvV, "zac");
     q.C(-1.0, Viabc, "lacd", U1v, "zdl", 1.0, XvvV, "zac");
     q.C(-1.0, U1v, "zal", FOV, "lc", 1.0, XvvV, "zac");
-    q.C(-2.0, Vijab, "lkcd", Xv, "zakdl", 1.0, XvvV, "zac", "z");                      // u2[a,d,l,k] = X[(a,k),(d,l)]
-    q.C(1.0, Vijab, "lkcd", Xv, "zdkal", 1.0, XvvV, "zac", "z");                       // u2[d,a,l,k] = X[(d,k),(a,l)]
+    e.axpby(1.0, slice(XSv, 2, 0, v), 1.0, XvvV);                                       // u2[a,d,l,k] = X[(a,k),(d,l)], both placements
     Tmp D(*this, K * v * v * o * o);
     const TView Dv = mv(D, {K, v, v, o, o});
     q.C(1.0, XvvV, "zac", T4, "cbij", 0.0, Dv, "zabij");
-    q.C(1.0, mv(WAt, {v, v, v, o}), "abdj", U1v, "zdi", 1.0, Dv, "zabij", "zab");
-    q.C(-1.0, mv(W3t, {v, v, v, o}), "abdi", U1v, "zdj", 1.0, Dv, "zabij", "zab");
+    q.C(1.0, mv(WW, {v, v, o, v}), "abid", U1v, "zdj", 1.0, Dv, "zabij", "z");
     q.C(1.0, U1v, "zal", mv(A346, {o, v, o, o}), "lbij", 1.0, Dv, "zabij");
-    q.C(1.0, V("abic"), "abic", U1v, "zcj", 1.0, Dv, "zabij", "z");
     Tmp Lall(*this, K * npp * o * o);
     e.ladder_sym_multi(u2, k, Lall, dressed);                                           // :383, all vectors
     Tmp B5(*this, K * o * o * o * o), B5s(*this, K * o * o * o * o);

@@ -34,10 +34,7 @@ class EomSigma {
     const int no, nv;
     const bool dressed;
     const double* T;
-    // pooled device buffers (stream-ordered reuse: everything runs on the engine's stream)
-    std::multimap<int64_t, double*> free_;
-    std::map<double*, int64_t> live_;
-    std::vector<double*> owned_;      // hoisted intermediates, freed by the destructor
+    std::vector<double*> owned_;      // hoisted intermediates (engine scratch), returned by the destructor
     double* get(int64_t doubles);
     void put(double* p);
     double* keep(int64_t doubles);
@@ -46,8 +43,8 @@ class EomSigma {
     double *foo = nullptr, *fov = nullptr, *fvv = nullptr, *fovT = nullptr;
     double *Td = nullptr, *Tx = nullptr, *W1 = nullptr, *Gvv_s = nullptr, *Goo_s = nullptr, *M_C = nullptr, *M_D = nullptr,
            *M1 = nullptr, *Ud = nullptr, *M2 = nullptr, *M12 = nullptr, *MDU = nullptr, *WA = nullptr, *W3 = nullptr, *A3 = nullptr,
-           *A4 = nullptr, *A6 = nullptr, *Gvv = nullptr, *Goo = nullptr, *B2 = nullptr, *L = nullptr, *WAt = nullptr, *W3t = nullptr,
-           *A346 = nullptr;
+           *A4 = nullptr, *A6 = nullptr, *Gvv = nullptr, *Goo = nullptr, *B2 = nullptr, *L = nullptr, *WW = nullptr, *BB = nullptr,
+           *Aoo = nullptr, *A346 = nullptr;
     bool v_sym = false, t_sym = false, hole_sym = false, fused_ok = false, many_ok = false;
     TView V(const char* name) const;
     void singles(const double* u1, const double* u2, double* s1);

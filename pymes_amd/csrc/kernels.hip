@@ -2898,7 +2898,7 @@ inline long dma_min_k() { return 384L; }
 // busiest CU) x tau.  Whole tiles therefore go in rounds of 256 — whole = floor(tiles / 256) * 256 — and the remaining
 // `tail` tiles are cut s ways along K so that their tail * s blocks fill rounds of 256 again:
 //     cost(s) / tau = ceil(tail s / 256) / s  +  s * 3 us / tau  +  (5 us + 44 ns * tail (s + 1)) / tau      (the last: reduction)
-// minimised over s <= 16 with every cut >= dma_min_k deep.  All of it is ONE grid (the cut blocks take the second slot of
+// minimised over s <= 16 (64 for a handful of tiles) with every cut >= dma_min_k deep.  All of it is ONE grid (the cut blocks take the second slot of
 // the CUs that run the last whole tiles; no launch boundary), cut blocks in ks-major order.  Fitted to, and checked
 // against, profiles/r05/probe_gemm_plan_grid.txt (19 tile counts x 5 depths x 3 choices of `whole` x 7 cut counts): the
 // formula's ranking of s is the measured one, whole = floor(tiles / 256) * 256 beats floor(tiles / 512) * 512 and 0 wherever
@@ -2912,7 +2912,10 @@ inline DmaPlan plan_dma(long tiles, long ktiles, long ws_tiles) {
     const long max_cuts = std::max<long>(1, ktiles / (dma_min_k() / BK));
     if (tail > 0) {
         const double tau = 1.75 * (double)ktiles;                      // us per tile
-        const long smax = std::max<long>(1, std::min<long>(std::min<long>(16, max_cuts), ws_tiles / tail));
+        // (up to 16 cuts; a handful of tiles over a huge K — tiny outputs contracted over o v^2 or o^2 v — up to 64: 4 tiles x
+        // 6750 k-tiles ran as 64 blocks on 256 CUs with the cap at 16, 767 us of a sigma build)
+        const long cap = tail * 16 >= 256 ? 16 : std::min<long>(64, (512 + tail - 1) / tail);
+        const long smax = std::max<long>(1, std::min<long>(std::min<long>(cap, max_cuts), ws_tiles / tail));
         double best_cost = 1e300;
         for (long sp = 1; sp <= smax; ++sp) {
             const long kt_per = (ktiles + sp - 1) / sp, ns = (ktiles + kt_per - 1) / kt_per;       // the cuts that result

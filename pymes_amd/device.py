@@ -189,6 +189,7 @@ class Context:
             for ptr in ptrs:
                 self.lib.call("pymes_free", self.handle, C.c_void_p(ptr))
         self._spare, self._spare_bytes = {}, 0
+        self.lib.call("pymes_scratch_trim", self.handle)       # ... and the engine's pooled scratch (EOM sigma temporaries)
 
     def zeros(self, shape):
         return self.empty(shape).zero_()

@@ -103,8 +103,7 @@ class _Sigma:
         return self.apply(u1, u2, u2_sym)[1]
 
     def trim(self):
-        if self._h is not None:
-            self.ctx.lib.call("pymes_eom_sigma_trim", self._h)
+        self.ctx.trim()
 
 
 class EOM_CCSD:

@@ -24,3 +24,6 @@ ctx.sync()
 ctx.prof_enable(True); ctx.prof_reset(); ctx.stats(reset=True)
 t0 = time.perf_counter(); sig.apply(u1, u2, u2_sym=flag); ctx.sync(); dt = time.perf_counter() - t0
 print("sigma s", dt, ctx.prof_query(), ctx.stats())
+ctx.prof_enable(False)
+for _ in range(3):
+    ctx.sync(); t0 = time.perf_counter(); sig.apply(u1, u2, u2_sym=flag); ctx.sync(); print("plain apply s", time.perf_counter() - t0)
