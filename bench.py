@@ -247,8 +247,11 @@ def other_configs(device=0):
         out["c5_ok"] = bool(err < 1e-10 and np.abs(sums - g["sigma2_sums"]).max() < 1e-9 * g["sigma2_sums"][1])
         del s1h, s2h, s1, s2d
         ctx.stats(reset=True)
-        dt = _timed(lambda: sig.apply(u1, u2, u2_sym=True), ctx.sync, 5, warm=2)     # (the first build allocates its temporaries)
-        fl = ctx.stats()["gemm_flops"] / 7
+        # (warm-up: the first build allocates its temporaries — and the host-side comparison above left the GPU idle for a
+        # few hundred ms: the first builds run at idle clocks and ONE of the next few stalls ~70 ms while the power state
+        # changes — measured, tools/probe_other_configs.py; a solve never has that gap)
+        dt = _timed(lambda: sig.apply(u1, u2, u2_sym=True), ctx.sync, 10, warm=30)
+        fl = ctx.stats()["gemm_flops"] / 40
         out["c5_sigma_ms"] = 1e3 * dt
         out["c5_frac"] = fl / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS
         kvec = 4

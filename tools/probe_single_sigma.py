@@ -27,3 +27,16 @@ for i in range(8):
     ctx.sync(); t0 = time.perf_counter(); r = sig.apply(u1, u2, u2_sym=True); t1 = time.perf_counter(); ctx.sync(); t2_ = time.perf_counter()
     print(i, "enqueue ms", 1e3 * (t1 - t0), "total ms", 1e3 * (t2_ - t0), flush=True)
     del r
+import gc
+gc.collect(); gc.disable()
+ts = []
+for i in range(60):
+    t0 = time.perf_counter(); r = sig.apply(u1, u2, u2_sym=True); del r; ts.append(time.perf_counter() - t0)
+ctx.sync()
+print("enqueue-only times ms, max:", 1e3 * max(ts), "mean:", 1e3 * sum(ts) / len(ts), "argmax", ts.index(max(ts)))
+print([round(1e3 * t, 2) for t in ts])
+t0 = time.perf_counter(); ctx.mem_info(); print("mem_info ms", 1e3 * (time.perf_counter() - t0))
+t0 = time.perf_counter()
+for i in range(60):
+    r = sig.apply(u1, u2, u2_sym=True); del r
+ctx.sync(); print("60 builds, ms each", 1e3 * (time.perf_counter() - t0) / 60)
