@@ -142,6 +142,8 @@ int pymes_ccsd_singles_residual_partial(pymes_ctx* ctx, const double* fd_dev, co
 #define PYMES_REUSE_LAYOUTS 32u /* the caller's promise that t2 has not changed since the preceding pymes_residual_slab call
                                  on it: its pair layouts (Td, Tx, 2T - T^(ab)) are read again instead of being rebuilt
                                  (pymes_residual_finish, pymes_ccsd_singles_residual_partial) */
+#define PYMES_T1_ZERO (1u << 20) /* pymes_ccsd_residuals / _iterate: the caller knows that t1 == 0 exactly (the MP2 start; every
+                                  * pass of a momentum-conserving system): the residuals come from the undressed f and V */
 #define PYMES_SYM_RINGS 16u   /* same precondition: merge the o^3v^3 ring/exchange products through the symmetry of
                                  the pair matrices (C / D form: 4 products instead of 10; 3 instead of 5 for DCSD) */
 int pymes_doubles_residual(pymes_ctx* ctx, const double* f_dev, const double* t2_dev, double* r2_dev,
@@ -193,6 +195,22 @@ int pymes_hole_ladder_packed(pymes_ctx* ctx, const double* x_dev, const double* 
  * eom_ccsd.py:380-382 over the vectors of a Davidson pass.  y_dev may be NULL. */
 int pymes_hole_ladder_packed_multi(pymes_ctx* ctx, const double* const* x_dev, const double* const* I_dev,
                                    const double* const* y_dev, int k, double* L_all_dev);
+/* ---- whole steps of the CCSD / DCSD loop body (ccsd_residuals, ccsd_iterate) ---------------------------------------
+ * pymes_ccsd_residuals: ccsd.py:161-171 in ONE call — T1-dressed Fock matrix (:163), the dressed blocks the loop reads (:165),
+ * R1 [v,o] (:167) and R2 [v,v,o,o] (:171) from f [n,n], t1 [v,o], t2 [v,v,o,o] (all on the device).  The symmetry-reduced
+ * form on one rank: needs V_pqrs = V_qpsr (pymes_V_exchange_asymmetry) and T_abij = T_baji (pymes_exchange_asymmetry) — the
+ * caller's promise; anything else goes through pymes_ccsd_doubles_residual.  Only enqueues kernels, on buffers the context
+ * holds from the first call to pymes_ccsd_release (replayable as a launch graph between those two).
+ * pymes_ccsd_iterate: one fixed-point pass without a mixer (ccsd.py:159-197 with is_diis = False): residuals, dT = R / (D +
+ * level_shift) (pymes_set_orbital_energies first), T += delta dT in place, energies and norms of the updated amplitudes:
+ * out6 = {one-body, direct, exchange, |t2|^2, |dt2|^2, |t1|^2} (host).  With a mixer: pymes_ccsd_residuals,
+ * pymes_cc_update_to, pymes_diis_mix, pymes_energy_norms — the sequence of pymes_amd/solver/ccsd.py. */
+int pymes_ccsd_residuals(pymes_ctx* ctx, const double* f_dev, const double* t1_dev, const double* t2_dev, uint32_t flags,
+                         double* r1_dev, double* r2_dev);
+int pymes_ccsd_iterate(pymes_ctx* ctx, const double* f_dev, double* t1_dev, double* t2_dev, uint32_t flags, double level_shift,
+                       double delta, double* dt1_dev, double* dt2_dev, double* out6_host);
+int pymes_ccsd_release(pymes_ctx* ctx);
+
 /* The symmetry-reduced residual (PYMES_SYM_LADDER | PYMES_SYM_RINGS) in its shardable form, one process per
  * GPU.  pymes_residual_slab computes what rank `rank` of `world` owns: the rows [c0,c1) of ETd and ETx (both
  * [o*v][o*v] on the device; ET[(b,j),(a,i)] = Ex[(a,i),(b,j)], rows cut into `world` chunks of ceil(ov/world))

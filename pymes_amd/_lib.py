@@ -128,6 +128,10 @@ SIGNATURES = {
     "pymes_dots_var": (C.c_int, [C.c_void_p, C.c_int, c_pp, c_pp, c_i64_p, c_double_p]),
     "pymes_lincomb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_pp, c_double_p, C.c_int64]),
     "pymes_cmul": (C.c_int, [C.c_void_p] * 7 + [C.c_int64]),
+    "pymes_ccsd_residuals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "pymes_ccsd_iterate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_double,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pymes_ccsd_release": (C.c_int, [C.c_void_p]),
     "pymes_cshift_inv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_double] * 5 + [C.c_void_p, C.c_void_p, C.c_int64]),
     "pymes_eom_sigma_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pymes_eom_sigma_flags": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -151,6 +155,7 @@ SIGNATURES = {
 
 PYMES_DCD, PYMES_USE_DRESSED, PYMES_SKIP_LADDER, PYMES_SYM_LADDER, PYMES_SYM_RINGS = 1, 2, 4, 8, 16
 PYMES_REUSE_LAYOUTS = 32
+PYMES_T1_ZERO = 1 << 20
 PYMES_SLAB_RINGS_ONLY, PYMES_SLAB_LADDERS_ONLY = 64, 128
 PYMES_DRESS_ABIJ_REDUCED = 1 << 16
 

@@ -284,6 +284,32 @@ int pymes_ccsd_dress_fock(pymes_ctx* ctx, const double* f, const double* t1, dou
         E(ctx).dress_fock(f, t1, fd);
     });
 }
+int pymes_ccsd_residuals(pymes_ctx* ctx, const double* f, const double* t1, const double* t2, uint32_t flags, double* r1,
+                         double* r2) {
+    return guarded([&] {
+        need(f, "f"); need(t1, "t1"); need(t2, "t2"); need(r1, "r1"); need(r2, "r2");
+        if (flags & ~(PYMES_DCD | PYMES_T1_ZERO)) throw pymes::Error("ccsd_residuals: flags are PYMES_DCD | PYMES_T1_ZERO");
+        E(ctx).ccsd_residuals(f, t1, t2, (flags & PYMES_DCD) | ((flags & PYMES_T1_ZERO) ? Engine::kT1Zero : 0u), r1, r2);
+    });
+}
+int pymes_ccsd_iterate(pymes_ctx* ctx, const double* f, double* t1, double* t2, uint32_t flags, double level_shift, double delta,
+                       double* dt1, double* dt2, double* out6) {
+    return guarded([&] {
+        need(f, "f"); need(t1, "t1"); need(t2, "t2"); need(dt1, "dt1"); need(dt2, "dt2"); need(out6, "out");
+        if (flags & ~(PYMES_DCD | PYMES_T1_ZERO)) throw pymes::Error("ccsd_iterate: flags are PYMES_DCD | PYMES_T1_ZERO");
+        Engine& e = E(ctx);
+        if (e.capturing()) throw pymes::Error("ccsd_iterate reads the energy back: not inside a launch graph");
+        e.ccsd_iterate(f, t1, t2, (flags & PYMES_DCD) | ((flags & PYMES_T1_ZERO) ? Engine::kT1Zero : 0u), level_shift, delta, dt1,
+                       dt2, out6);
+    });
+}
+int pymes_ccsd_release(pymes_ctx* ctx) {
+    return guarded([&] {
+        Engine& e = E(ctx);
+        if (e.capturing()) throw pymes::Error("ccsd_release while a launch graph is being recorded");
+        e.release_residual_buffers();
+    });
+}
 int pymes_ccsd_dress_V(pymes_ctx* ctx, const double* t1, uint32_t mask) {
     return guarded([&] {
         need(t1, "t1");

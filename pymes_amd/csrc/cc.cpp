@@ -1548,6 +1548,53 @@ void Engine::cc_update(double* t, double* dt, const double* r, double shift, dou
 // -----------------------------------------------------------------------------------
 // ccsd.py:458-466 and ccd.py:256-262
 // -----------------------------------------------------------------------------------
+// ---- whole steps ------------------------------------------------------------------------------------------------------------
+void Engine::ccsd_residuals(const double* f, const double* t1, const double* t2, unsigned flags, double* r1, double* r2) {
+    const int64_t o = no, v = nv, ov = o * v, npp = v * (v + 1) / 2;
+    if (!res_ETd_) {
+        res_fd_ = scratch_get((o + v) * (o + v));
+        res_ETd_ = scratch_get(ov * ov);
+        res_ETx_ = scratch_get(ov * ov);
+        res_L_ = scratch_get(npp * o * o);
+        res_QK_ = scratch_get(ov * o * o);
+    }
+    const unsigned dcd = flags & 1u;                  // PYMES_DCD
+    const unsigned sym = 8u | 16u;                    // PYMES_SYM_LADDER | PYMES_SYM_RINGS
+    if (flags & kT1Zero) {
+        residual_slab(f, t2, res_ETd_, res_ETx_, res_L_, 0, 1, dcd | sym);                                     // :171
+        singles_residual_partial(f, t1, t2, r1, 0, 1, true);                                                   // :167
+        residual_finish(f, t2, res_ETd_, res_ETx_, res_L_, r2, dcd | sym | 32u);                              // (PYMES_REUSE_LAYOUTS)
+        return;
+    }
+    dress_fock(f, t1, res_fd_);                                                                                // :163
+    // V_abcd is never dressed: its T1 dressing (:165, ccsd.py:414-419) is carried by tau = T2 + T1 T1 inside the ladders,
+    // that of V_abij by Q_kb and two small products inside the finish; only V~_klij, V~_iajb, V~_iabj are formed
+    dress_V(t1, (1u << pattern_of_name("klij")) | (1u << pattern_of_name("iajb")) | (1u << pattern_of_name("iabj")));
+    residual_slab(res_fd_, t2, res_ETd_, res_ETx_, res_L_, 0, 1, dcd | sym | 2u, t1, res_QK_);                // :171 (PYMES_USE_DRESSED)
+    singles_residual_partial(res_fd_, t1, t2, r1, 0, 1, true);                                                 // :167
+    residual_finish(res_fd_, t2, res_ETd_, res_ETx_, res_L_, r2, dcd | sym | 2u | 32u, t1, res_QK_);
+}
+
+void Engine::ccsd_iterate(const double* f, double* t1, double* t2, unsigned flags, double shift, double delta, double* dt1,
+                          double* dt2, double out[6]) {
+    const int64_t o = no, v = nv;
+    if (!res_r1_) {
+        res_r1_ = scratch_get(v * o);
+        res_r2_ = scratch_get(v * v * o * o);
+    }
+    ccsd_residuals(f, t1, t2, flags, res_r1_, res_r2_);                       // ccsd.py:161-171
+    cc_update_to(t1, dt1, t1, res_r1_, shift, delta, 2);                      // :176-179
+    cc_update_to(t2, dt2, t2, res_r2_, shift, delta, 4);
+    energy_norms(f, t1, t2, dt2, out);                                        // :189-197
+}
+
+void Engine::release_residual_buffers() {
+    for (double** p : {&res_fd_, &res_ETd_, &res_ETx_, &res_L_, &res_QK_, &res_r1_, &res_r2_}) {
+        if (*p) scratch_put(*p);
+        *p = nullptr;
+    }
+}
+
 void Engine::cc_update_to(double* t_out, double* dt, const double* t_in, const double* r, double shift, double delta,
                           int rank) {
     if (rank != 2 && rank != 4) throw Error("cc_update: rank must be 2 (T1) or 4 (T2)");

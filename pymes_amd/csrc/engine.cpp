@@ -150,9 +150,12 @@ double* Engine::scratch_get(int64_t doubles) {
         p = static_cast<double*>(dev::try_dmalloc(sizeof(double) * static_cast<size_t>(doubles)));
         if (!p) {
             scratch_trim();
-            p = static_cast<double*>(dev::try_dmalloc(sizeof(double) * static_cast<size_t>(doubles)));
+            try {
+                p = static_cast<double*>(dev::dmalloc(sizeof(double) * static_cast<size_t>(doubles)));
+            } catch (const std::exception&) {
+                throw Error("out of device memory (" + std::to_string((doubles * 8) >> 20) + " MiB of scratch)");
+            }
         }
-        if (!p) throw Error("out of device memory (" + std::to_string((doubles * 8) >> 20) + " MiB of scratch)");
     }
     scratch_live_[p] = doubles;
     return p;

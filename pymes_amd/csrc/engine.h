@@ -200,6 +200,21 @@ class Engine {
     void ladder_t1(const double* t1, const double* t2, double* L, int64_t row0, int64_t row1, double* QK, int64_t q0,
                    int64_t q1, bool dcd, const double* J = nullptr);
     void dress_abcd_rows(const double* t1, int a0, int a1, bool lower_only);
+    // ---- whole steps (ccsd_residuals / ccsd_iterate) ----------------------------------------------------------
+    // ccsd.py:161-171 in one call: dressed Fock matrix, the dressed blocks the loop needs, R1 [v,o] and R2 [v,v,o,o] from
+    // (f, t1, t2) — the symmetry-reduced form (V_pqrs = V_qpsr and T_abij = T_baji: the caller's promise, tested by
+    // exchange_asymmetry_V / dev::exchange_asymmetry), one rank.  flags: PYMES_DCD; bit `kT1Zero`: the caller knows that
+    // t1 == 0 exactly (the MP2 start, a momentum-conserving system): exp(-T1) H exp(T1) = H, residuals from the undressed f, V.
+    // Only enqueues kernels on buffers the engine holds (replayable as a launch graph).
+    static constexpr unsigned kT1Zero = 1u << 20;
+    void ccsd_residuals(const double* f, const double* t1, const double* t2, unsigned flags, double* r1, double* r2);
+    // ... and one fixed-point pass without a mixer (ccsd.py:159-197 with is_diis = False): residuals, dT = R / (D + shift),
+    // T += delta dT in place, then the energies and norms of the updated amplitudes: out = {one-body, direct, exchange,
+    // |t2|^2, |dt2|^2, |t1|^2}.  A caller with a mixer calls ccsd_residuals, pymes_cc_update_to, pymes_diis_mix,
+    // pymes_energy_norms instead (what pymes_amd/solver/ccsd.py does).
+    void ccsd_iterate(const double* f, double* t1, double* t2, unsigned flags, double shift, double delta, double* dt1,
+                      double* dt2, double out[6]);
+    void release_residual_buffers();
     void cc_update(double* t, double* dt, const double* r, double shift, double delta, int rank);  // ccsd.py:176-179
     void cc_update_to(double* t_out, double* dt, const double* t_in, const double* r, double shift, double delta, int rank);
     void ccsd_energy(const double* f, const double* t1, const double* t2, double out[3]);     // ccsd.py:458-466
@@ -248,6 +263,9 @@ class Engine {
     void ensure_xs();
     dev::stream_t own_stream_ = nullptr;
     std::set<void*> user_allocs_;
+    // exchange / staging buffers of ccsd_residuals (engine scratch, held from the first call to release_residual_buffers)
+    double *res_fd_ = nullptr, *res_ETd_ = nullptr, *res_ETx_ = nullptr, *res_L_ = nullptr, *res_QK_ = nullptr, *res_r1_ = nullptr,
+           *res_r2_ = nullptr;
     std::multimap<int64_t, double*> scratch_free_;
     std::map<double*, int64_t> scratch_live_;
     std::set<dev::graph_t> graphs_;

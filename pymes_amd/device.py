@@ -352,6 +352,24 @@ class Context:
         else:
             self.lib.call("pymes_ccsd_dress_V", self.handle, C.c_void_p(t1.ptr), mask)
 
+    def ccsd_residuals(self, f, t1, t2, r1, r2, is_dcd=False, t1_zero=False):
+        """ccsd.py:161-171 in one call (symmetry-reduced form, one rank; include/pymes_amd.h): R1, R2 from (f, t1, t2)."""
+        self.lib.call("pymes_ccsd_residuals", self.handle, C.c_void_p(f.ptr), C.c_void_p(t1.ptr), C.c_void_p(t2.ptr),
+                      (_lib.PYMES_DCD if is_dcd else 0) | (_lib.PYMES_T1_ZERO if t1_zero else 0), C.c_void_p(r1.ptr),
+                      C.c_void_p(r2.ptr))
+
+    def ccsd_iterate(self, f, t1, t2, dt1, dt2, level_shift=0.0, delta=1.0, is_dcd=False, t1_zero=False):
+        """One fixed-point pass without a mixer (ccsd.py:159-197, is_diis = False): (e_1b, e_dir, e_ex, |t2|^2, |dt2|^2, |t1|^2)."""
+        out = (C.c_double * 6)()
+        self.lib.call("pymes_ccsd_iterate", self.handle, C.c_void_p(f.ptr), C.c_void_p(t1.ptr), C.c_void_p(t2.ptr),
+                      (_lib.PYMES_DCD if is_dcd else 0) | (_lib.PYMES_T1_ZERO if t1_zero else 0), float(level_shift), float(delta),
+                      C.c_void_p(dt1.ptr), C.c_void_p(dt2.ptr), out)
+        return tuple(out)
+
+    def ccsd_release(self):
+        """Give back the staging buffers pymes_ccsd_residuals holds (recorded launch graphs that replay it must be gone)."""
+        self.lib.call("pymes_ccsd_release", self.handle)
+
     def singles_residual(self, fd, t1, t2, out):
         self.lib.call("pymes_ccsd_singles_residual", self.handle, C.c_void_p(fd.ptr), C.c_void_p(t1.ptr),
                       C.c_void_p(t2.ptr), C.c_void_p(out.ptr))

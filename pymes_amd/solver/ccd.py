@@ -54,6 +54,10 @@ def destroy_graphs(ctx, st):
             pass
     if st is not None:
         st["graph"] = None
+    try:
+        ctx.ccsd_release()           # the staging buffers of pymes_ccsd_residuals go back to the engine's scratch pool
+    except PymesError:
+        pass
 
 
 def run_replayable(ctx, st, body, key="residual"):

@@ -116,9 +116,6 @@ class CCSD(ccd.CCD):
             else:
                 st["lad_rows"] = nv * nv
                 st["lad_t"], st["lad"] = shared(nv * nv, no * no)
-        elif st["sym"]:
-            st["ETd"], st["ETx"] = ctx.empty((no * nv, no * nv)), ctx.empty((no * nv, no * nv))
-            st["L"], st["QK"] = ctx.empty((st["npp"], no * no)), ctx.empty((no * nv, no * no))
         if not dist_on:
             # single rank: T1, T2 and the residuals live in fixed buffers, so the residual part of the loop body (about
             # 130 kernel launches) can be recorded once as a launch graph and replayed (frees the host; measured: the device
@@ -142,27 +139,17 @@ class CCSD(ccd.CCD):
         """ccsd.py:161-171: dressed Fock, dressed V blocks, R1, R2 from the fixed T1/T2 buffers into the fixed residual
         buffers.  Only enqueues kernels (no host read-back), hence replayable as a launch graph."""
         ctx, t1, t2, r1, r2 = st["ctx"], st["t1"], st["t2"], st["r1"], st["r2"]
-        if st["sym"] and st["t1_zero"]:
-            # T1 = 0 exactly (the MP2 start; every iteration of a momentum-conserving system such as the UEG):
-            # exp(-T1) H exp(T1) = H, so :163 and :165 are identities — the residuals straight from the undressed f and V
-            ctx.residual_slab(st["f"], t2, st["ETd"], st["ETx"], st["L"], 0, 1, is_dcd=self.is_dcd)          # :171
-            ctx.singles_residual_partial(st["f"], t1, t2, r1, 0, 1, reuse_layouts=True)                      # :167
-            ctx.residual_finish(st["f"], t2, st["ETd"], st["ETx"], st["L"], r2, is_dcd=self.is_dcd, reuse_layouts=True)
-            return
-        ctx.dress_fock(st["f"], t1, st["fd"])                                         # :163
         if st["sym"]:
-            # Symmetry-reduced form = the one-rank case of the sharded form: V_abcd is never dressed, its T1 dressing
-            # (:165, ccsd.py:414-419) is carried by tau = T2 + T1 T1 inside the ladders, that of V_abij by Q_kb and two
-            # small products inside the finish (include/pymes_amd.h, pymes_residual_slab)
-            ctx.dress_V(t1, ("klij", "iajb", "iabj"))                                 # :165
-            ctx.residual_slab(st["fd"], t2, st["ETd"], st["ETx"], st["L"], 0, 1, is_dcd=self.is_dcd, dressed=True, t1=t1,
-                              QK=st["QK"])                                            # :171
-            # both read the pair layouts residual_slab has just built from this t2 (no transpositions of their own)
-            ctx.singles_residual_partial(st["fd"], t1, t2, r1, 0, 1, reuse_layouts=True)      # :167
-            ctx.residual_finish(st["fd"], t2, st["ETd"], st["ETx"], st["L"], r2, is_dcd=self.is_dcd, dressed=True,
-                                t1=t1, QK=st["QK"], reuse_layouts=True)
+            # Symmetry-reduced form = the one-rank case of the sharded form, ONE library call (pymes_ccsd_residuals: dressed
+            # Fock :163, the dressed blocks the loop reads :165, R1 :167, R2 :171).  V_abcd is never dressed, its T1 dressing
+            # (ccsd.py:414-419) is carried by tau = T2 + T1 T1 inside the ladders, that of V_abij by Q_kb and two small
+            # products inside the finish (include/pymes_amd.h, pymes_residual_slab).  T1 = 0 exactly (the MP2 start; every
+            # iteration of a momentum-conserving system such as the UEG): exp(-T1) H exp(T1) = H, :163 and :165 are
+            # identities — the residuals straight from the undressed f and V
+            ctx.ccsd_residuals(st["f"], t1, t2, r1, r2, is_dcd=self.is_dcd, t1_zero=st["t1_zero"])
         else:
             # general path (amplitudes or integrals without the exchange symmetry): explicitly dressed blocks
+            ctx.dress_fock(st["f"], t1, st["fd"])                                     # :163
             ctx.singles_residual(st["fd"], t1, t2, r1)                                # :167
             ctx.dress_V(t1, LOOP_KEYS)                                                # :165
             ctx.doubles_residual(st["fd"], t2, r2, is_dcd=self.is_dcd, dressed=True, sym_ladder=False)   # :171

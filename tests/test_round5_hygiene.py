@@ -178,3 +178,54 @@ def test_solve_ends_with_residuals_in_flight(gpu_lib, monkeypatch):
         assert np.array_equal(t2a, r2["t2"].get())
     finally:
         ints.ctx.close()
+
+
+# ---- whole-step entry points of the C-ABI (ccsd_residuals / ccsd_iterate) ---------------------------------------
+def check_ccsd_iterate_entry(lib, dcsd):
+    """pymes_ccsd_iterate — one fixed-point pass without a mixer (ccsd.py:159-197, is_diis = False) per call — three passes
+    from the MP2 start against the oracle's loop (= the reference's algebra), and pymes_ccsd_residuals against the residuals
+    the engine's separate entry points give."""
+    from oracle import cc_oracle as oc
+    no, nv = 3, 6
+    f, V, _, _ = synthetic_case(no, nv, seed=4, scale=0.3)
+    ref = oc.ccsd_solve(no, f, V, is_dcsd=dcsd, is_diis=False, delta_e=1e-30, max_iter=2)
+    ctx = Context(no, nv, lib=lib)
+    try:
+        ctx.set_V_pqrs(V)
+        assert ctx.V_exchange_symmetric()
+        ctx.set_orbital_energies(f.diagonal()[:no].copy(), f.diagonal()[no:].copy())
+        fdev = ctx.array(f)
+        t1, t2 = ctx.zeros((nv, no)), ctx.empty((nv, nv, no, no))
+        ctx.mp2(t2, 0.0)
+        dt1, dt2 = ctx.empty(t1.shape), ctx.empty(t2.shape)
+        e = None
+        for it in range(3):
+            out = ctx.ccsd_iterate(fdev, t1, t2, dt1, dt2, is_dcd=dcsd, t1_zero=(it == 0))
+            e = out[0] + out[1] + out[2]
+            assert abs(out[3] - np.vdot(t2.get(), t2.get())) < 1e-12
+        assert abs(e - ref["e"]) < 1e-12
+        assert np.abs(t2.get() - ref["t2"]).max() < 1e-12 and np.abs(t1.get() - ref["t1"]).max() < 1e-12
+        # the residuals alone, against the general (no symmetry assumed) entry points on explicitly dressed blocks
+        r1, r2 = ctx.empty(t1.shape), ctx.empty(t2.shape)
+        ctx.ccsd_residuals(fdev, t1, t2, r1, r2, is_dcd=dcsd)
+        fd = ctx.empty(f.shape)
+        ctx.dress_fock(fdev, t1, fd)
+        g1, g2 = ctx.empty(t1.shape), ctx.empty(t2.shape)
+        ctx.singles_residual(fd, t1, t2, g1)
+        ctx.dress_V(t1, ("abij", "klij", "iajb", "iabj", "abcd"))
+        ctx.doubles_residual(fd, t2, g2, is_dcd=dcsd, dressed=True, sym_ladder=False)
+        assert np.abs(r1.get() - g1.get()).max() < 1e-12 and np.abs(r2.get() - g2.get()).max() < 1e-12
+        ctx.ccsd_release()
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("dcsd", [False, True])
+def test_ccsd_iterate_entry_host_logic(hostsim_lib, dcsd):
+    check_ccsd_iterate_entry(hostsim_lib, dcsd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dcsd", [False, True])
+def test_ccsd_iterate_entry_gpu(gpu_lib, dcsd):
+    check_ccsd_iterate_entry(gpu_lib, dcsd)
