@@ -227,6 +227,11 @@ EomSigma::EomSigma(Engine& eng, const double* f_host, const double* t2, bool dre
             q.P(1.0, mv(A3, {o, o, v, o}), "libj", 0.0, mv(A346, {o, v, o, o}), "lbij");
             q.P(1.0, mv(A4, {o, o, v, o}), "ljbi", 1.0, mv(A346, {o, v, o, o}), "lbij");
             q.L(A346, {A346, A6, Viajk.p}, {1.0, -1.0, -1.0}, o * v * o * o);
+            // ... and that product shares its shape with X_vv . T (:360-361): [z a] x (c | l) against the rows of T and of A346
+            // stacked, TA[(c | l), (b,i,j)] — ONE product writes D (two passes over the k amplitude-sized accumulators before)
+            TA = keep((v + o) * v * o * o);
+            dev::memcpy_d2d(TA, T, sizeof(double) * v * v * o * o, e.stream);
+            dev::memcpy_d2d(TA + v * v * o * o, A346, sizeof(double) * o * v * o * o, e.stream);
         }
     } catch (...) {
         for (double* p : owned_) e.scratch_put(p);
@@ -376,7 +381,7 @@ int EomSigma::stack_limit() const {
 void EomSigma::stack(int k, const double* const* u1, const double* const* u2, double* const* s1, double* const* s2) {
     const int64_t o = no, v = nv, ov = o * v, ov2 = ov * ov, npp = v * (v + 1) / 2, K = k;
     const Ops q{e};
-    const TView Vijka = V("ijka"), Vijak = V("ijak"), Viabc = V("iabc"), T4 = mv(T, {v, v, o, o});
+    const TView Vijka = V("ijka"), Vijak = V("ijak"), Viabc = V("iabc");
     Tmp U1(*this, K * v * o), X(*this, K * ov2), Tt(*this, K * ov2);
     for (int z = 0; z < k; ++z) {
         dev::memcpy_d2d(U1.p + z * v * o, u1[z], sizeof(double) * v * o, e.stream);
@@ -417,14 +422,21 @@ void EomSigma::stack(int k, const double* const* u1, const double* const* u2, do
     e.axpby(1.0, slice(XSv, 2, 0, v), 1.0, XvvV);                                       // u2[a,d,l,k] = X[(a,k),(d,l)], both placements
     Tmp D(*this, K * v * v * o * o);
     const TView Dv = mv(D, {K, v, v, o, o});
-    q.C(1.0, XvvV, "zac", T4, "cbij", 0.0, Dv, "zabij");
+    {
+        // D = [X_vv | u1] . [T ; A346]   (:360-361 and the four u1 terms with a free index on u1, see the hoist)
+        Tmp XU(*this, K * v * (v + o));
+        const TView XUv = mv(XU, {K, v, v + o});
+        e.copy(XvvV, slice(XUv, 2, 0, v));
+        e.copy(U1v, slice(XUv, 2, v, v + o));
+        q.C(1.0, XUv, "zan", mv(TA, {v + o, v, o, o}), "nbij", 0.0, Dv, "zabij");
+    }
     q.C(1.0, mv(WW, {v, v, o, v}), "abid", U1v, "zdj", 1.0, Dv, "zabij", "z");
-    q.C(1.0, U1v, "zal", mv(A346, {o, v, o, o}), "lbij", 1.0, Dv, "zabij");
     Tmp Lall(*this, K * npp * o * o);
     e.ladder_sym_multi(u2, k, Lall, dressed);                                           // :383, all vectors
     Tmp B5(*this, K * o * o * o * o), B5s(*this, K * o * o * o * o);
     std::vector<const double*> b2s(k, B2), ts(k, T), b5p(k);
     for (int z = 0; z < k; ++z) {
+        // (G_vv . u2, G_oo . u2 per vector: a batched launch over a stacked direct layout moves the same bytes — measured)
         const TView Dz = mv(D.p + z * v * v * o * o, {v, v, o, o}), U2z = mv(u2[z], {v, v, o, o});
         q.C(1.0, mv(Gvv, {v, v}), "ad", U2z, "dbij", 1.0, Dz, "abij");
         q.C(1.0, mv(Goo, {o, o}), "li", U2z, "ablj", 1.0, Dz, "abij", "ab");

@@ -44,7 +44,7 @@ class EomSigma {
     double *Td = nullptr, *Tx = nullptr, *W1 = nullptr, *Gvv_s = nullptr, *Goo_s = nullptr, *M_C = nullptr, *M_D = nullptr,
            *M1 = nullptr, *Ud = nullptr, *M2 = nullptr, *M12 = nullptr, *MDU = nullptr, *WA = nullptr, *W3 = nullptr, *A3 = nullptr,
            *A4 = nullptr, *A6 = nullptr, *Gvv = nullptr, *Goo = nullptr, *B2 = nullptr, *L = nullptr, *WW = nullptr, *BB = nullptr,
-           *Aoo = nullptr, *A346 = nullptr;
+           *Aoo = nullptr, *A346 = nullptr, *TA = nullptr;
     bool v_sym = false, t_sym = false, hole_sym = false, fused_ok = false, many_ok = false;
     TView V(const char* name) const;
     void singles(const double* u1, const double* u2, double* s1);
