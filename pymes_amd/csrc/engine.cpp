@@ -343,14 +343,6 @@ void Engine::permute(double alpha, const TView& in, const char* si, double beta,
     dev::permute(p, stream);
     stats.permute_calls++;
     stats.permute_bytes += 8.0 * static_cast<double>(out.size()) * (beta != 0.0 ? 3.0 : 2.0);
-    if (const char* logp = getenv("PYMES_PERMUTE_LOG")) {       // tuning aid: one line per explicit permutation
-        if (FILE* lf = fopen(logp, "a")) {
-            fprintf(lf, "%s->%s alpha=%g beta=%g MB=%.1f dims", si, so, alpha, beta, 8e-6 * static_cast<double>(out.size()));
-            for (int i = 0; i < out.rank; ++i) fprintf(lf, " %ld", static_cast<long>(out.dim[i]));
-            fprintf(lf, "\n");
-            fclose(lf);
-        }
-    }
 }
 
 void Engine::axpby(double alpha, const TView& in, double beta, const TView& out) {

@@ -250,10 +250,6 @@ def allreduce_tensor_start(t, ctx=None, label="allreduce"):
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return _Done()
-    if os.environ.get("PYMES_SYNC_EXCHANGE"):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        _fence_after(t)
-        return _Done()
     return _Pending(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True), t, label)
 
 
@@ -282,14 +278,14 @@ class _Pending:
 def exchange_rows_start(full, rank, world_size, ctx=None, label="allgather"):
     """Asynchronous form of ``exchange_rows``: returns a handle whose ``wait()`` makes the current stream wait for
     the all-gather (RCCL runs it on its own stream, so kernels enqueued in between overlap with the transfer).
-    The staged test rigs and PYMES_SYNC_EXCHANGE=1 fall back to the blocking exchange."""
+    The staged test rigs fall back to the blocking exchange."""
     import torch.distributed as dist
     if not sharded():
         return _Done()
     trace.sent(label, _ring_bytes(full, world_size, 1))
     if _STUB is not None:
         return _Done()
-    if _staged(full) or os.environ.get("PYMES_SYNC_EXCHANGE"):
+    if _staged(full):
         exchange_rows(full, rank, world_size, ctx)
         _fence_after(full)
         return _Done()
@@ -342,7 +338,7 @@ def exchange_pair_tiles_start(mats, no, nv, rank, world_size, ctx=None, label="o
     trace.sent(label, 8 * sum(send_n))
     if _STUB is not None:
         return _Done()
-    staged = _staged(mats[0]) or bool(os.environ.get("PYMES_SYNC_EXCHANGE"))
+    staged = _staged(mats[0])
     if staged:
         _fence_before(mats[0], ctx)
     src = [m.cpu() if (staged and m.is_cuda) else m for m in mats]

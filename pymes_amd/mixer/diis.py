@@ -48,7 +48,7 @@ class DIIS:
     # (``Context.on_close``); when such a context closes, its stored vectors are parked on the host — up to PARK_LIMIT
     # bytes; a larger history (12 amplitude sets, 9.6 GB at (50,200)) is dropped instead: a second solve() on the same
     # solver instance then starts from an empty subspace, the only place where this drop-in knowingly leaves the
-    # reference's never-reset semantics (PYMES_DIIS_PARK_LIMIT=<bytes> moves the limit).
+    # reference's never-reset semantics (``DIIS.PARK_LIMIT`` moves the limit).
     PARK_LIMIT = 2 << 30
 
     def _reset(self):
@@ -111,7 +111,7 @@ class DIIS:
             mine = [a for a in self._stored() if not isinstance(a, np.ndarray) and a.ctx is ctx]
             if not mine:
                 return
-            limit = int(os.environ.get("PYMES_DIIS_PARK_LIMIT", self.PARK_LIMIT))
+            limit = int(self.PARK_LIMIT)
             if ctx.handle is None or sum(a.nbytes for a in mine) > limit:
                 self._reset()
                 return

@@ -23,3 +23,18 @@ def test_missing_library_fails_loudly(tmp_path):
     import pytest
     with pytest.raises(_lib.PymesError, match="no CPU fallback"):
         _lib.Library(str(tmp_path / "nope.so"))
+
+
+def test_library_override(tmp_path, monkeypatch):
+    """PYMES_AMD_LIBRARY=<path>: the loader takes that build (a missing one fails loudly; the backend check still applies)."""
+    import importlib
+    import pytest
+    monkeypatch.setenv("PYMES_AMD_LIBRARY", str(tmp_path / "other_build.so"))
+    mod = importlib.reload(_lib)
+    try:
+        assert mod.DEFAULT_PATH.endswith("other_build.so")
+        with pytest.raises(mod.PymesError, match="no CPU fallback"):
+            mod.Library()
+    finally:
+        monkeypatch.delenv("PYMES_AMD_LIBRARY")
+        importlib.reload(_lib)

@@ -113,3 +113,21 @@ def test_read_to_device_host_logic(hostsim_lib, monkeypatch, tmp_path):
         fh.write(" 1.0 60 61 62 63\n 2.0 61 60 62 63\n")
     with pytest.raises(_lib.PymesError):
         fcidump.read_to_device(p)
+
+
+def test_parser_thread_counts_agree(tmp_path, monkeypatch):
+    """PYMES_PARSE_THREADS: the threaded body parser (fcidump.cpp) cuts the text at line boundaries and joins the records in
+    file order — 1, 3 and 7 threads give the same arrays on a file large enough to be cut (> 4 MB of text)."""
+    p = str(tmp_path / "big")
+    sparse_fcidump(p, 40, 8, 160000, seed=3)
+    assert os.path.getsize(p) > (4 << 20)
+    ref = None
+    for nt in ("1", "3", "7"):
+        monkeypatch.setenv("PYMES_PARSE_THREADS", nt)
+        got = fcidump.read(p)
+        if ref is None:
+            ref = got
+        else:
+            assert got[:3] == ref[:3]
+            for a, b in zip(got[3:], ref[3:]):
+                assert np.array_equal(a, b)

@@ -23,13 +23,13 @@ run() {   # name, timeout, command...
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "killed: stopping"; exit $rc; fi
     return $rc
 }
-run stats 600 rocprofv3 --kernel-trace --stats -d "$out/stats" -o run --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --events timed "$@" || exit 1
+run stats 600 rocprofv3 --kernel-trace --stats -d "$out/stats" -o run --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --events timed "$@" || exit 1
 grep '^{' "$out/stats.log" > "$out/summary/bench_${tag}_under_rocprof.json"
 f=$(find "$out/stats" -name 'run_kernel_stats.csv' | head -1)
 [ -n "$f" ] && cp "$f" "$out/summary/bench_${tag}_kernel_stats.csv"
 if [ "${PMC:-1}" = "1" ]; then
     for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA; do
-        run "pmc_$c" 600 rocprofv3 --kernel-trace --pmc "$c" -d "$out/pmc_$c" -o run --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --events timed "$@" || exit 1
+        run "pmc_$c" 600 rocprofv3 --kernel-trace --pmc "$c" -d "$out/pmc_$c" -o run --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs --events timed "$@" || exit 1
     done
     cc() { find "$out/pmc_$1" -name 'run_counter_collection.csv' | head -1; }
     { echo "# kernels.hip sha256=$hash"; python3 tools/pmc_summary.py "$(cc FETCH_SIZE)" "$(cc WRITE_SIZE)"; } > "$out/summary/bench_${tag}_pmc_hbm_traffic.csv"
@@ -41,6 +41,6 @@ round=${ROUND:-r05}
 mkdir -p "profiles/$round"
 [ -f "$out/summary/bench_${tag}_pmc_hbm_traffic.csv" ] && cp "$out/summary/bench_${tag}_pmc_hbm_traffic.csv" "profiles/$round/"
 # the plain (unprofiled) bench line of the same workload, graph replay allowed
-run bench 600 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" || exit 1
+run bench 600 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs "$@" || exit 1
 grep '^{' "$out/bench.log" > "$out/summary/bench_${tag}.json"
 ls -la "$out/summary"

@@ -32,11 +32,11 @@ step dress python3 tools/probe_dress.py > $out/probe_dress_kernel.txt 2>&1
 step eom_stats rocprofv3 --kernel-trace --stats -d $out/eom -o run --output-format csv -- python3 tools/eom_prof_many.py > $out/eom_many.txt 2>&1
 f=$(find $out/eom -name 'run_kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $out/eom_sigma_30_120_k4_kernel_stats.csv
 rm -rf $out/eom
-step trace rocprofv3 --kernel-trace -d $out/tr -o run --output-format csv -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --events timed > $out/trace.log 2>&1
+step trace rocprofv3 --kernel-trace -d $out/tr -o run --output-format csv -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-other-configs --events timed > $out/trace.log 2>&1
 python3 tools/trace_order.py $(find $out/tr -name "run_kernel_trace.csv") > $out/bench_c3_dispatch_order.txt; rm -rf $out/tr
 step trace2 rocprofv3 --kernel-trace -d $out/tr2 -o run --output-format csv -- python3 bench.py --nocc 20 --nvirt 80 --steps 6 --warmup 3 --no-cpu-baseline > $out/trace2.log 2>&1
 python3 tools/trace_order.py $(find $out/tr2 -name "run_kernel_trace.csv") 8 > $out/bench_c2_dispatch_order.txt; rm -rf $out/tr2
-step clock rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d $out/pmc -o run --output-format csv -- python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline --events timed > $out/clock.log 2>&1
+step clock rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d $out/pmc -o run --output-format csv -- python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-other-configs --events timed > $out/clock.log 2>&1
 python3 tools/dispatch_clock.py $(find $out/pmc -name "run_counter_collection.csv") 400 > $out/bench_c3_dispatch_clock.txt; rm -rf $out/pmc
 rm -rf gpurun_out/prof_c3/stats gpurun_out/prof_c3/pmc_* gpurun_out/prof_c2/stats gpurun_out/prof_c2/pmc_*
 echo done
