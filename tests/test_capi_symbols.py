@@ -25,16 +25,14 @@ def test_missing_library_fails_loudly(tmp_path):
         _lib.Library(str(tmp_path / "nope.so"))
 
 
-def test_library_override(tmp_path, monkeypatch):
-    """PYMES_AMD_LIBRARY=<path>: the loader takes that build (a missing one fails loudly; the backend check still applies)."""
-    import importlib
-    import pytest
-    monkeypatch.setenv("PYMES_AMD_LIBRARY", str(tmp_path / "other_build.so"))
-    mod = importlib.reload(_lib)
-    try:
-        assert mod.DEFAULT_PATH.endswith("other_build.so")
-        with pytest.raises(mod.PymesError, match="no CPU fallback"):
-            mod.Library()
-    finally:
-        monkeypatch.delenv("PYMES_AMD_LIBRARY")
-        importlib.reload(_lib)
+def test_library_override(tmp_path):
+    """PYMES_AMD_LIBRARY=<path>: the loader takes that build (a missing one fails loudly; the backend check still applies).
+    In a process of its own: the variable is read when the module is imported."""
+    import subprocess
+    import sys
+    code = ("from pymes_amd import _lib\n"
+            "assert _lib.DEFAULT_PATH.endswith('other_build.so'), _lib.DEFAULT_PATH\n"
+            "try:\n    _lib.Library()\nexcept _lib.PymesError as e:\n    assert 'no CPU fallback' in str(e); print('refused')\n")
+    env = dict(os.environ, PYMES_AMD_LIBRARY=str(tmp_path / "other_build.so"), PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "refused" in out.stdout, out.stderr
