@@ -3047,7 +3047,9 @@ void gemm_group_flush_dma() {
         for (int i = 0; i < q.nd; ++i) ktmax = std::max(ktmax, q.ktiles_d[i]);
         const double tau = 1.75 * (double)ktmax;
         double best = 1e300;
-        for (long sp = 2; sp <= 16; ++sp) {
+        long smax = 1;                 // (beyond the deepest product's limit a larger s changes nothing but the divisor below)
+        for (int i = 0; i < q.nd; ++i) smax = std::max(smax, q.ktiles_d[i] / (dma_min_k() / BK));
+        for (long sp = 2; sp <= std::min<long>(16, smax); ++sp) {
             long blocks = 0;
             bool any_cut = false;
             for (int i = 0; i < q.nd; ++i) {
