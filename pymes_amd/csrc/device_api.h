@@ -170,6 +170,10 @@ void lincomb_dev(double* out, int nx, const double* const* x, const double* coef
 // (yr + i yi)[e] = (mr + i mi)[e] * (xr + i xi)[e]: a complex diagonal applied to a complex vector held as two real arrays
 // (y may alias x)
 void cmul(const double* mr, const double* mi, const double* xr, const double* xi, double* yr, double* yi, int64_t n, stream_t s);
+// u [v,v,o,o] without the exchange symmetry split for two pair-packed ladders: us = (u + P u) / 2, (P u)_abij = u_baji;
+// w_abij = sgn(i - j) (u - P u)_abij / 2 (exchange-symmetric, zero for i == j); dg[a,b,i] = (u - P u)_abii / 2 [v,v,o]
+void exchange_split(const double* u, double* us, double* w, double* dg, int no, int nv, stream_t s);
+void sgn_ij_add(double* D, const double* R, int no, int nv, stream_t s);          // D_abij += sgn(i - j) R_abij
 // (mr + i mi)[e] = 1 / ((zr + i zi) - (hr + i hi) d[e] + shift): that preconditioner from the device-resident diagonal
 void cshift_inv(const double* d, double zr, double zi, double hr, double hi, double shift, double* mr, double* mi, int64_t n,
                 stream_t s);

@@ -1627,6 +1627,31 @@ __global__ void cmul_kernel(const double* __restrict__ mr, const double* __restr
     }
 }
 
+// ---- particle ladder of a trial vector WITHOUT the exchange symmetry through two pair-packed ladders (eom.cpp) ------------------
+// u = us + ua, us = (u + P u) / 2 (P u)_abij = u_baji; w_abij = sgn(i - j) ua_abij is exchange-symmetric again (zero for
+// i == j), dg[a,b,i] = ua_abii is what w leaves out.  One thread per element; the partner read is a transposed access (once
+// per build, 0.1 ms at (30,120)).
+__global__ void exchange_split_kernel(const double* __restrict__ u, double* __restrict__ us, double* __restrict__ w,
+                                      double* __restrict__ dg, int no, int nv, long total) {
+    const long o = no, v = nv;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long j = e % o, i = (e / o) % o, b = (e / (o * o)) % v, a = e / (o * o * v);
+        const double x = u[e], y = u[((b * v + a) * o + j) * o + i];
+        const double ua = 0.5 * (x - y);
+        us[e] = 0.5 * (x + y);
+        w[e] = i > j ? ua : (i < j ? -ua : 0.0);
+        if (i == j) dg[(a * v + b) * o + i] = ua;
+    }
+}
+// D_abij += sgn(i - j) R_abij
+__global__ void sgn_ij_add_kernel(double* __restrict__ D, const double* __restrict__ R, int no, long total) {
+    const long o = no;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long j = e % o, i = (e / o) % o;
+        if (i != j) D[e] += (i > j ? R[e] : -R[e]);
+    }
+}
+
 // ---- EOM-CCSD diagonals (eom_ccsd.py:169-266), once per solve ------------------------------------------------------------------
 // V = V_ijab [o,o,v,v], T [v,v,o,o].  Stage 1: the V.T sums with one to three free indices, one block per output element
 // (strided loop over the summed indices + block reduction).  Layout of ws (offsets in doubles, EomDiagWs below):
@@ -4035,6 +4060,19 @@ void cmul(const double* mr, const double* mi, const double* xr, const double* xi
     HIP_CHECK(hipGetLastError());
 }
 
+void exchange_split(const double* u, double* us, double* w, double* dg, int no, int nv, stream_t s) {
+    const long total = (long)nv * nv * no * no;
+    if (!total) return;
+    hipLaunchKernelGGL(exchange_split_kernel, dim3(grid_for(total, 256, 256 * 64)), dim3(256), 0, (hipStream_t)s, u, us, w, dg, no, nv,
+                       total);
+    HIP_CHECK(hipGetLastError());
+}
+void sgn_ij_add(double* D, const double* R, int no, int nv, stream_t s) {
+    const long total = (long)nv * nv * no * no;
+    if (!total) return;
+    hipLaunchKernelGGL(sgn_ij_add_kernel, dim3(grid_for(total, 256, 256 * 64)), dim3(256), 0, (hipStream_t)s, D, R, no, total);
+    HIP_CHECK(hipGetLastError());
+}
 int64_t eom_diag_ws_doubles(int no, int nv) { return EomDiagWs(no, nv).total; }
 void eom_diagonals(const double* V, const double* T, const double* dai, const double* iaai, const double* iaia, const double* ijij,
                    const double* abab, double* d1, double* d2, int no, int nv, double* ws, stream_t s) {

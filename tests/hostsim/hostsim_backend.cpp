@@ -320,6 +320,26 @@ void lincomb_dev(double* out, int nx, const double* const* x, const double* coef
     }
 }
 
+void exchange_split(const double* u, double* us, double* w, double* dg, int no, int nv, stream_t) {
+    const long o = no, v = nv;
+    for (long a = 0; a < v; ++a)
+        for (long b = 0; b < v; ++b)
+            for (long i = 0; i < o; ++i)
+                for (long j = 0; j < o; ++j) {
+                    const long e = ((a * v + b) * o + i) * o + j, p = ((b * v + a) * o + j) * o + i;
+                    const double ua = 0.5 * (u[e] - u[p]);
+                    us[e] = 0.5 * (u[e] + u[p]);
+                    w[e] = i > j ? ua : (i < j ? -ua : 0.0);
+                    if (i == j) dg[(a * v + b) * o + i] = ua;
+                }
+}
+void sgn_ij_add(double* D, const double* R, int no, int nv, stream_t) {
+    const long o = no, total = (long)nv * nv * o * o;
+    for (long e = 0; e < total; ++e) {
+        const long j = e % o, i = (e / o) % o;
+        if (i != j) D[e] += (i > j ? R[e] : -R[e]);
+    }
+}
 void cshift_inv(const double* d, double zr, double zi, double hr, double hi, double shift, double* mr, double* mi, int64_t n,
                 stream_t) {
     for (int64_t e = 0; e < n; ++e) {
