@@ -219,9 +219,11 @@ void ladder_pack_T(const double* X, const double* t1, double* Sp, double* Am, in
 // R[a,b,i,j] = beta R + LS[P(ab)][P(ij)] + sgn(a-b) sgn(i-j) LA[P(ab)][Q(ij)]
 void ladder_unpack(const double* L, double* R, double beta, int no, int nv, stream_t s);
 // The pair layouts of T[a,b,i,j] in one pass: Td[(a,i),(b,j)] = Tx[(a,j),(b,i)] = T_abij, Ttd = 2 Td - (T_baij in
-// the Td layout).  fused_pair_kernels_ok(no): the o x o staging tile fits the LDS (else use permutes).
+// the Td layout) — in general Ttd = ca Td + cb (T_baij in the Td layout).  fused_pair_kernels_ok(no): the o x o staging tile
+// fits the LDS (else use permutes).
 bool fused_pair_kernels_ok(int no);
-void t2_layouts(const double* T, double* Td, double* Tx, double* Ttd, int no, int nv, stream_t s);
+void t2_layouts(const double* T, double* Td, double* Tx, double* Ttd, int no, int nv, stream_t s, double ca = 2.0,
+                double cb = -1.0);
 // Assembly of the symmetry-reduced residual (ccd.py:249-252) in one pass:
 //   R_abij = V_abij + unpack(L)_abij + N_abij + N_baji + D[(a,i),(b,j)] + D[(b,j),(a,i)] + X[(a,j),(b,i)] + X[(b,i),(a,j)]
 // L (pair-packed ladder rows, may be null), V (may be null: 0), N [v,v,o,o], D and X [ov,ov]

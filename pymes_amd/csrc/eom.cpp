@@ -258,16 +258,28 @@ void EomSigma::singles(const double* u1, const double* u2, double* s1) {
 }
 
 // ---- eom_ccsd.py:312-385 -------------------------------------------------------------------------------------------------------
-void EomSigma::doubles(const double* u1, const double* u2, bool u2_sym, double* s2) {
+void EomSigma::doubles(const double* u1, const double* u2, bool u2_sym, double* s2, bool defer_ladder) {
     const int64_t o = no, v = nv, ov = o * v, ov2 = ov * ov, npp = v * (v + 1) / 2;
     const Ops q{e};
     const TView U1 = mv(u1, {v, o}), U2 = mv(u2, {v, v, o, o}), T4 = mv(T, {v, v, o, o});
     const TView Vijab = V("ijab"), Vijka = V("ijka"), Vijak = V("ijak"), Viabc = V("iabc");
     auto P4 = [&](double* p) { return mv(p, {v, o, v, o}); };
-    Tmp u2x(*this, ov2), utd(*this, ov2), Dx(*this, ov2), Dd(*this, ov2);
-    Tmp u2d(*this, u2_sym ? 1 : ov2);
+    // a trial vector without exchange symmetry: the five (ov)^3 products as TWO, stacked along the summed pair index
+    const bool kstack = !u2_sym && fused_ok;
+    Tmp u2x(*this, kstack ? 1 : ov2), utd(*this, kstack ? 1 : ov2), Dx(*this, ov2), Dd(*this, ov2);
+    Tmp u2d(*this, u2_sym || kstack ? 1 : ov2), R3(*this, kstack ? 3 * ov2 : 1);
     // the pair layouts u2x[(a,j),(b,i)] = u2[a,b,i,j], utd = 2 u2d - (u2[b,a,i,j] in the u2d layout), u2d[(a,i),(b,j)] = u2[a,b,i,j]
-    if (fused_ok) {                    // ... in ONE pass over u2 (the kernel of the CCSD residual's layouts)
+    if (kstack) {
+        // R3 = [u2d ; u2x^T ; u2x] from one pass over u2 (u2x^T[(d,l),(b,j)] = u2[b,d,l,j] is "u2[b,a,i,j] in the u2d layout"):
+        //   Dd = M1.(2 u2d - u2x^T) + M2.u2d + M_C.u2x = [2 M1 + M2 | -M1 | M_C] . R3                       (K = 3 ov)
+        //   Dx = M_D.u2x - u2x.Ud^T, and since only Dx + Dx^T enters (:377, the assembly below) the second term may be
+        //   transposed: Dx' = [-Ud | M_D] . [u2x^T ; u2x]                                                      (K = 2 ov)
+        // same flops, but 841 tiles x 5 launches with their cut tails become two long launches (8.0 -> 6.9 ms at (30,120))
+        general_operands();
+        dev::t2_layouts(u2, R3.p, R3.p + 2 * ov2, R3.p + ov2, no, nv, e.stream, 0.0, 1.0);
+        q.C(1.0, mv(LK3, {v, o, 3, v, o}), "aisdl", mv(R3.p, {3, v, o, v, o}), "sdlbj", 0.0, P4(Dd), "aibj");
+        q.C(1.0, mv(LK2, {v, o, 2, v, o}), "ajsdl", mv(R3.p + ov2, {2, v, o, v, o}), "sdlbi", 0.0, P4(Dx), "ajbi");
+    } else if (fused_ok) {             // ... in ONE pass over u2 (the kernel of the CCSD residual's layouts)
         dev::t2_layouts(u2, u2_sym ? nullptr : u2d.p, u2x, utd, no, nv, e.stream);
     } else {
         q.P(1.0, U2, "abij", 0.0, P4(u2x), "ajbi");
@@ -282,7 +294,7 @@ void EomSigma::doubles(const double* u1, const double* u2, bool u2_sym, double* 
         q.C(1.0, P4(MDU), "ajdl", P4(u2x), "dlbi", 0.0, P4(Dx), "ajbi");                       // :372 and :364 (transposed)
         q.P(0.5, P4(Dx), "ajbi", 0.0, P4(Dd), "ajbi");                                         // same memory layout as "aibj"
         q.C(0.5, P4(M12), "aidl", P4(utd), "dlbj", 1.0, P4(Dd), "aibj");
-    } else {
+    } else if (!kstack) {
         q.C(1.0, P4(M1), "aidl", P4(utd), "dlbj", 0.0, P4(Dd), "aibj");
         q.C(1.0, P4(M2), "aidl", P4(u2d), "dlbj", 1.0, P4(Dd), "aibj");
         q.C(1.0, P4(M_C), "aidl", P4(u2x), "dlbj", 1.0, P4(Dd), "aibj");                      // u2x[(d,l),(b,j)] = u2[d,b,j,l]
@@ -374,25 +386,63 @@ void EomSigma::doubles(const double* u1, const double* u2, bool u2_sym, double* 
         e.ladder_sym(u2, L, 0, npp, dressed, 0);
         e.ladder_sym_unpack(L, Dp, 1.0);
     } else if (v_sym) {
-        // The particle ladder acts on (i,j) as spectators and commutes with the exchange P (V_abcd = V_badc): for a trial
-        // vector without the symmetry, u = us + ua (us = (u + P u) / 2), the symmetric part runs pair-packed as it stands, and
-        // so does the antisymmetric one after w_abij = sgn(i - j) ua_abij (exchange-symmetric, zero for i == j):
-        // Lad(ua)_abij = sgn(i - j) Lad(w)_abij; the o columns i == j that w leaves out are a skinny plain product.  Two
-        // quarter-flop ladders + v^4 o flops instead of the full v^4 o^2 product (5.3 -> 2.6 ms at (30,120)).  (Nothing else of
-        // the general build can be split this way: the reference's symmetrised part is not P-covariant)
-        const int64_t n2 = v * v * o * o;
-        Tmp us(*this, n2), w(*this, n2), dg(*this, v * v * o), R2(*this, n2), Rd(*this, v * v * o);
-        dev::exchange_split(u2, us, w, dg, no, nv, e.stream);
-        e.ladder_sym(us, L, 0, npp, dressed, 0);
-        e.ladder_sym_unpack(L, Dp, 1.0);
-        e.ladder_sym(w, L, 0, npp, dressed, 0);
-        e.ladder_sym_unpack(L, R2, 0.0);
-        dev::sgn_ij_add(Dp, R2, no, nv, e.stream);
-        q.C(1.0, V("abcd"), "abcd", mv(dg, {v, v, o}), "cdi", 0.0, mv(Rd, {v, v, o}), "abi");
-        const int64_t dims[3] = {v, v, o}, st[3] = {v * o * o, o * o, o + 1};
-        q.P(1.0, mv(Rd, {v, v, o}), "abi", 1.0, make_view(Dp, 3, dims, st), "abi");      // D[a,b,i,i] += Rd[a,b,i]
+        if (!defer_ladder) {
+            const double* us[1] = {u2};
+            double* ss[1] = {Dp};
+            general_ladders(1, us, ss);
+        }
     } else {
         q.C(1.0, V("abcd"), "abcd", U2, "cdij", 1.0, D, "abij");
+    }
+}
+
+// The u-independent left operands of the two stacked (ov)^3 products of doubles() for a trial vector without exchange symmetry
+void EomSigma::general_operands() {
+    if (LK3) return;
+    const int64_t ov = static_cast<int64_t>(no) * nv;
+    const Ops q{e};
+    LK3 = keep(3 * ov * ov);
+    LK2 = keep(2 * ov * ov);
+    auto columns = [&](double* dst, int64_t width, int64_t s, double c0, const double* m0, double c1, const double* m1) {
+        const int64_t dims[2] = {ov, ov}, st[2] = {width * ov, 1};
+        const TView out = make_view(dst + s * ov, 2, dims, st);
+        q.P(c0, mv(m0, {ov, ov}), "xy", 0.0, out, "xy");
+        if (m1) q.P(c1, mv(m1, {ov, ov}), "xy", 1.0, out, "xy");
+    };
+    columns(LK3, 3, 0, 2.0, M1, 1.0, M2);
+    columns(LK3, 3, 1, -1.0, M1, 0.0, nullptr);
+    columns(LK3, 3, 2, 1.0, M_C, 0.0, nullptr);
+    columns(LK2, 2, 0, -1.0, Ud, 0.0, nullptr);
+    columns(LK2, 2, 1, 1.0, M_D, 0.0, nullptr);
+}
+
+// The particle ladder (:383) of g trial vectors WITHOUT exchange symmetry, added to s2[z].  It acts on (i,j) as spectators and
+// commutes with the exchange P (V_abcd = V_badc): with u = us + ua (us = (u + P u) / 2) the symmetric part runs pair-packed as
+// it stands, and so does the antisymmetric one after w_abij = sgn(i - j) ua_abij (exchange-symmetric, zero for i == j):
+// Lad(ua)_abij = sgn(i - j) Lad(w)_abij; the o columns i == j that w leaves out are a skinny plain product.  2 g quarter-flop
+// ladders in ONE batched launch per half (the packed integrals read once) + v^4 o flops per vector instead of g full v^4 o^2
+// products.  (Nothing else of the general build can be split this way: the reference's symmetrised part is not P-covariant,
+// DESIGN 6e.)
+void EomSigma::general_ladders(int g, const double* const* u2, double* const* s2) {
+    const int64_t o = no, v = nv, n2 = v * v * o * o, npp = v * (v + 1) / 2, G = g;
+    const Ops q{e};
+    Tmp usw(*this, 2 * G * n2), dg(*this, G * v * v * o), Lall(*this, 2 * G * npp * o * o), R2(*this, n2), Rd(*this, G * v * v * o);
+    std::vector<const double*> xs(2 * g);
+    for (int z = 0; z < g; ++z) {
+        double *us = usw.p + 2 * z * n2, *w = us + n2;
+        dev::exchange_split(u2[z], us, w, dg.p + z * v * v * o, no, nv, e.stream);
+        xs[2 * z] = us;
+        xs[2 * z + 1] = w;
+    }
+    e.ladder_sym_multi(xs.data(), 2 * g, Lall, dressed);
+    // the diagonal columns of all vectors from one pass over V_abcd
+    q.C(1.0, V("abcd"), "abcd", mv(dg, {G, v, v, o}), "zcdi", 0.0, mv(Rd, {G, v, v, o}), "zabi");
+    for (int z = 0; z < g; ++z) {
+        e.ladder_sym_unpack(Lall.p + 2 * z * npp * o * o, s2[z], 1.0);
+        e.ladder_sym_unpack(Lall.p + (2 * z + 1) * npp * o * o, R2, 0.0);
+        dev::sgn_ij_add(s2[z], R2, no, nv, e.stream);
+        const int64_t dims[3] = {v, v, o}, st[3] = {v * o * o, o * o, o + 1};
+        q.P(1.0, mv(Rd.p + z * v * v * o, {v, v, o}), "abi", 1.0, make_view(s2[z], 3, dims, st), "abi");      // s2[a,b,i,i] += Rd[a,b,i]
     }
 }
 
@@ -495,12 +545,27 @@ void EomSigma::apply(int k, const double* const* u1, const double* const* u2, co
         sy[z] = sym ? (sym[z] != 0) : exchange_symmetric(u2[z], v, o);
         all = all && sy[z];
     }
-    auto one = [&](int z) {
+    auto one = [&](int z, bool defer = false) {
         singles(u1[z], u2[z], s1[z]);
-        doubles(u1[z], u2[z], sy[z] != 0, s2[z]);
+        doubles(u1[z], u2[z], sy[z] != 0, s2[z], defer);
     };
     if (k < 2 || !many_ok || !all) {
-        for (int z = 0; z < k; ++z) one(z);
+        // vectors without exchange symmetry: their particle ladders are held back and run together, eight vectors at a time
+        std::vector<const double*> gu;
+        std::vector<double*> gs;
+        for (int z = 0; z < k; ++z) {
+            const bool defer = k > 1 && v_sym && !sy[z];
+            one(z, defer);
+            if (defer) {
+                gu.push_back(u2[z]);
+                gs.push_back(s2[z]);
+            }
+            if (gu.size() == 8 || (z == k - 1 && !gu.empty())) {
+                general_ladders(static_cast<int>(gu.size()), gu.data(), gs.data());
+                gu.clear();
+                gs.clear();
+            }
+        }
         return;
     }
     const int step = stack_limit();

@@ -44,11 +44,13 @@ class EomSigma {
     double *Td = nullptr, *Tx = nullptr, *W1 = nullptr, *Gvv_s = nullptr, *Goo_s = nullptr, *M_C = nullptr, *M_D = nullptr,
            *M1 = nullptr, *Ud = nullptr, *M2 = nullptr, *M12 = nullptr, *MDU = nullptr, *WA = nullptr, *W3 = nullptr, *A3 = nullptr,
            *A4 = nullptr, *A6 = nullptr, *Gvv = nullptr, *Goo = nullptr, *B2 = nullptr, *L = nullptr, *WW = nullptr, *BB = nullptr,
-           *Aoo = nullptr, *A346 = nullptr, *TA = nullptr;
+           *Aoo = nullptr, *A346 = nullptr, *TA = nullptr, *LK3 = nullptr, *LK2 = nullptr;
+    void general_operands();          // LK3, LK2 (trial vectors without exchange symmetry), on first use
     bool v_sym = false, t_sym = false, hole_sym = false, fused_ok = false, many_ok = false;
     TView V(const char* name) const;
     void singles(const double* u1, const double* u2, double* s1);
-    void doubles(const double* u1, const double* u2, bool u2_sym, double* s2);
+    void doubles(const double* u1, const double* u2, bool u2_sym, double* s2, bool defer_ladder = false);
+    void general_ladders(int g, const double* const* u2, double* const* s2);
     void stack(int k, const double* const* u1, const double* const* u2, double* const* s1, double* const* s2);
     int stack_limit() const;
 };

@@ -522,7 +522,7 @@ void ladder_pack_T(const double* T, const double* t1, double* Sp, double* Am, in
 
 bool fused_pair_kernels_ok(int no) { return no <= 3; }   // small, so that the tests reach both code paths
 
-void t2_layouts(const double* T, double* Td, double* Tx, double* Ttd, int no, int nv, stream_t) {
+void t2_layouts(const double* T, double* Td, double* Tx, double* Ttd, int no, int nv, stream_t, double ca, double cb) {
     const int64_t o2 = (int64_t)no * no, ov = (int64_t)no * nv;
     for (int a = 0; a < nv; ++a)
         for (int b = 0; b < nv; ++b)
@@ -532,7 +532,7 @@ void t2_layouts(const double* T, double* Td, double* Tx, double* Ttd, int no, in
                     const double y = T[((int64_t)b * nv + a) * o2 + i * no + j];
                     if (Td) Td[((int64_t)a * no + i) * ov + b * no + j] = x;
                     Tx[((int64_t)a * no + j) * ov + b * no + i] = x;
-                    Ttd[((int64_t)a * no + i) * ov + b * no + j] = 2.0 * x - y;
+                    Ttd[((int64_t)a * no + i) * ov + b * no + j] = ca * x + cb * y;
                 }
 }
 

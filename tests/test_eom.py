@@ -161,6 +161,18 @@ def check_apply_many(lib, monkeypatch, no, nv, k, tol):
         mixed = sig.apply_many(d1, d2)
         r2 = eo.sigma_doubles(no, f, Vb, u1s[1], u2s[1], t2)
         assert np.abs(mixed[1][1].get() - r2).max() < tol * max(1.0, np.abs(r2).max())
+        # NO vector with the symmetry (FEAST's random trial vectors): the particle ladders of all of them run as one batch of
+        # 2k pair-packed ladders, the (ov)^3 products stacked along the summed index — declared by the caller, then detected
+        g2s = [rng.standard_normal((nv, nv, no, no)) for _ in range(k)]
+        dg2 = [ctx.array(u) for u in g2s]
+        for syms in ([False] * k, None):
+            gen = sig.apply_many(d1, dg2, syms=syms)
+            for z in range(k):
+                r1, r2 = eo.sigma_singles(no, f, Vb, u1s[z], g2s[z], t2), eo.sigma_doubles(no, f, Vb, u1s[z], g2s[z], t2)
+                sc = max(1.0, np.abs(r2).max())
+                assert np.abs(gen[z][0].get() - r1).max() < tol * sc and np.abs(gen[z][1].get() - r2).max() < tol * sc, z
+        s1, s2 = sig.apply(d1[0], dg2[0], u2_sym=False)                     # one vector: its two ladders as a batch of two
+        assert np.abs(s2.get() - gen[0][1].get()).max() < tol * sc
     finally:
         ctx.close()
 
