@@ -303,6 +303,67 @@ int pymes_readback_wait(pymes_ctx* ctx, int slot, double* out_host, int n);
  * next iteration's T1-only work runs.  The T1 sums out[0], out[5] are non-zero on rank 0 only. */
 int pymes_energy_norms_pairs(pymes_ctx* ctx, const double* f_dev, const double* t1_dev, const double* tc_dev,
                              const double* dtc_dev, int rank, int world, double* out_host);
+
+/* ---- one process per GPU as WHOLE STEPS, with the collectives of the host program -----------------------------------------
+ * The call sequence above (slab, exchange, finish) leaves the collectives to the caller; here the caller hands the library a
+ * table of them once and the loop body of ccsd.py:159-197 for one rank becomes three calls — the N > 1 form is expressible
+ * from any host language, no Python and no torch involved (the Python host of this repository fills the table with
+ * torch.distributed calls, pymes_amd/dist.py:Collectives; an RCCL host with ncclAllReduce / ncclAllGather on a communicator
+ * and a stream of its own).
+ *
+ * Contract of the table.  All buffers are DEVICE memory; `stream` is the stream the library runs on (hipStream_t).
+ *   allreduce_start(user, buf, n, stream, &ticket)      in-place sum over the ranks of n doubles at buf
+ *   allgather_start(user, buf, chunk, stream, &ticket)  buf = world consecutive chunks of `chunk` doubles, chunk `rank` is
+ *                                                       filled in: on completion every rank holds every chunk
+ *   wait(user, ticket, stream)                          orders `stream` behind the completion of that collective
+ * Each *_start orders its collective behind the work ALREADY enqueued on `stream` and returns without waiting (the usual
+ * RCCL pattern: record an event on `stream`, make the communication stream wait for it, enqueue the collective there, record
+ * its completion event; wait = hipStreamWaitEvent(stream, that event)).  Tickets are the host program's.  A blocking
+ * implementation (synchronise, exchange through host memory, return) is equally valid — the test rigs do that over gloo.
+ * Collectives are issued in the same order on every rank.  Return 0 for success; anything else fails the library call.
+ *   mark(user, phase)   optional (may be NULL): called at the phase boundaries of a step, for profiling. */
+typedef struct pymes_collectives {
+    void* user;
+    int rank, world;
+    int (*allreduce_start)(void* user, double* buf_dev, int64_t n, void* stream, int64_t* ticket);
+    int (*allgather_start)(void* user, double* buf_dev, int64_t chunk, void* stream, int64_t* ticket);
+    int (*wait)(void* user, int64_t ticket, void* stream);
+    void (*mark)(void* user, const char* phase);
+} pymes_collectives;
+/* the table is copied; NULL removes it.  One table per context (= per GPU = per process). */
+int pymes_set_collectives(pymes_ctx* ctx, const pymes_collectives* table);
+/* Buffers that take part in a collective belong to the caller (a host that registers memory with its communicator does so
+ * once).  With chunk(n) = ceil(n / world), doubles each (pymes_shard_buffer_sizes fills sizes[10] in this order):
+ *   ETd, ETx  world chunk(o v) x o v      rows of the ring products (pymes_residual_slab), all-gathered
+ *   L         world chunk(v(v+1)/2) x o^2 pair-packed ladder rows (stay on the rank)
+ *   QK        world chunk(o v) x o^2      Q_kb rows, all-gathered
+ *   Tall      world chunk(v(v+1)/2) x 2 o^2   compact tiles of the new T2, all-gathered
+ *   W         pymes_ccsd_dress_fock_ws,  Xvv  v^2,  P  pymes_slab_prepare_ws,  R1  v o   partial sums, all-reduced
+ *   S         8                           the six energy / norm sums, all-reduced */
+typedef struct pymes_shard_buffers {
+    double *ETd, *ETx, *L, *QK, *Tall, *W, *Xvv, *P, *R1, *S;
+} pymes_shard_buffers;
+int pymes_shard_buffer_sizes(pymes_ctx* ctx, int world, int64_t* sizes_out);
+/* ccsd.py:161-171 for this rank (symmetry-reduced form: V_pqrs = V_qpsr, T_abij = T_baji; pymes_pairs_supported): dressed
+ * Fock matrix into fd_dev [n,n] + the dressed blocks of the rank's slab, ring products (their rows exchanged while the ladders
+ * run), ladders, Q_kb, X_ac, the singles residual (all-reduced: complete in buffers->R1 [v,o] on every rank) and the doubles
+ * residual of the rank's virtual pairs as compact tiles rc_dev [max(pairs,1)][2][o*o] (pymes_pairs_pack layout; zero on a rank
+ * without pairs).  t2_dev [v,v,o,o] is the replicated array: an exchange left in flight by pymes_ccsd_sharded_finish is
+ * completed into it before it is read.  Writes nothing but fd_dev, rc_dev and the buffers, and reads nothing from the host:
+ * the caller may enqueue it BEFORE it reads the previous pass's energy (pymes_ccsd_sharded_energy).  The update follows with
+ * pymes_cc_update (t1, R1) and pymes_cc_update_pairs (tc, rc), a mixer with pymes_dots / pymes_diis_solve / pymes_lincomb over
+ * the compact tiles (overlaps summed over the ranks by the caller), as in the single-rank sequence.  flags: PYMES_DCD. */
+int pymes_ccsd_sharded_residuals(pymes_ctx* ctx, const double* f_dev, double* fd_dev, const double* t1_dev, double* t2_dev,
+                                 const pymes_shard_buffers* buffers, uint32_t flags, double* rc_dev);
+/* ccsd.py:189-197 and the hand-over of the new amplitudes (after the caller's mixer, if any, has replaced t1 / tc): the six
+ * sums of pymes_energy_norms_pairs all-reduced ON THE DEVICE and copied to the host on the side (`*slot`, read with
+ * pymes_ccsd_sharded_energy — after the caller has enqueued the next pymes_ccsd_sharded_residuals if it wishes: nothing on the
+ * stream waits for the host), tc into the exchange buffer, the all-gather of the new T2 started.  It is completed by the next
+ * pymes_ccsd_sharded_residuals, or by pymes_ccsd_sharded_await (end of the solve: t2_dev then holds the amplitudes). */
+int pymes_ccsd_sharded_finish(pymes_ctx* ctx, const double* f_dev, const double* t1_dev, const double* tc_dev,
+                              const double* dtc_dev, const pymes_shard_buffers* buffers, int* slot);
+int pymes_ccsd_sharded_energy(pymes_ctx* ctx, int slot, double* out_host /* [6], as pymes_energy_norms */);
+int pymes_ccsd_sharded_await(pymes_ctx* ctx, double* t2_dev, const pymes_shard_buffers* buffers);
 /* CCSD.get_energy, ccsd.py:458-466: e_out = {one-body, direct, exchange}; f is the UNDRESSED Fock */
 int pymes_ccsd_energy(pymes_ctx* ctx, const double* f_dev, const double* t1_dev, const double* t2_dev,
                       double* e_out_host);

@@ -15,6 +15,12 @@ DEFAULT_PATH = os.environ.get("PYMES_AMD_LIBRARY") or os.path.join(_HERE, "lib",
 
 c_double_p = C.POINTER(C.c_double)
 c_i64_p = C.POINTER(C.c_int64)
+
+
+class ShardBuffers(C.Structure):
+    """pymes_shard_buffers of include/pymes_amd.h (device pointers, in this order)."""
+    _fields_ = [(k, C.c_void_p) for k in ("ETd", "ETx", "L", "QK", "Tall", "W", "Xvv", "P", "R1", "S")]
+
 c_pp = C.POINTER(C.c_void_p)
 
 # name -> (restype, argtypes); exactly the declarations of include/pymes_amd.h
@@ -132,6 +138,12 @@ SIGNATURES = {
     "pymes_ccsd_iterate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_double,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "pymes_ccsd_release": (C.c_int, [C.c_void_p]),
+    "pymes_set_collectives": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pymes_shard_buffer_sizes": (C.c_int, [C.c_void_p, C.c_int, c_i64_p]),
+    "pymes_ccsd_sharded_residuals": (C.c_int, [C.c_void_p] * 6 + [C.c_uint32, C.c_void_p]),
+    "pymes_ccsd_sharded_finish": (C.c_int, [C.c_void_p] * 6 + [C.POINTER(C.c_int)]),
+    "pymes_ccsd_sharded_energy": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "pymes_ccsd_sharded_await": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pymes_cshift_inv": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_double] * 5 + [C.c_void_p, C.c_void_p, C.c_int64]),
     "pymes_eom_sigma_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pymes_eom_sigma_flags": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -572,6 +572,77 @@ int pymes_energy_norms_pairs(pymes_ctx* ctx, const double* f, const double* t1, 
         E(ctx).energy_norms_pairs(f, t1, tc, dtc, rank, world, out);
     });
 }
+int pymes_set_collectives(pymes_ctx* ctx, const pymes_collectives* table) {
+    return guarded([&] {
+        if (!table) {
+            E(ctx).set_collectives(nullptr);
+            return;
+        }
+        pymes::Engine::Collectives c;
+        c.user = table->user;
+        c.rank = table->rank;
+        c.world = table->world;
+        c.allreduce_start = table->allreduce_start;
+        c.allgather_start = table->allgather_start;
+        c.wait = table->wait;
+        c.mark = table->mark;
+        E(ctx).set_collectives(&c);
+    });
+}
+int pymes_shard_buffer_sizes(pymes_ctx* ctx, int world, int64_t* sizes) {
+    return guarded([&] {
+        if (!sizes) throw pymes::Error("null output");
+        if (world < 1) throw pymes::Error("world must be >= 1");
+        pymes::Engine& e = E(ctx);
+        const int64_t o = e.no, v = e.nv, ov = o * v, npp = v * (v + 1) / 2;
+        auto padded = [&](int64_t n) { return (n + world - 1) / world * world; };
+        sizes[0] = sizes[1] = padded(ov) * ov;
+        sizes[2] = padded(npp) * o * o;
+        sizes[3] = padded(ov) * o * o;
+        sizes[4] = padded(npp) * 2 * o * o;
+        sizes[5] = e.dress_fock_ws_doubles();
+        sizes[6] = v * v;
+        sizes[7] = e.slab_prepare_ws_doubles();
+        sizes[8] = v * o;
+        sizes[9] = 8;
+    });
+}
+namespace {
+pymes::Engine::ShardBuffers shard_buffers(const pymes_shard_buffers* b) {
+    if (!b) throw pymes::Error("null buffers");
+    for (const double* p : {b->ETd, b->ETx, b->L, b->QK, b->Tall, b->W, b->Xvv, b->P, b->R1, b->S})
+        if (!p) throw pymes::Error("null exchange buffer");
+    return pymes::Engine::ShardBuffers{b->ETd, b->ETx, b->L, b->QK, b->Tall, b->W, b->Xvv, b->P, b->R1, b->S};
+}
+}  // namespace
+int pymes_ccsd_sharded_residuals(pymes_ctx* ctx, const double* f, double* fd, const double* t1, double* t2,
+                                 const pymes_shard_buffers* buffers, uint32_t flags, double* rc) {
+    return guarded([&] {
+        need(f, "f"); need(fd, "fd"); need(t1, "t1"); need(t2, "t2"); need(rc, "rc");
+        if (flags & ~PYMES_DCD) throw pymes::Error("sharded step: flags is PYMES_DCD or 0");
+        E(ctx).ccsd_sharded_residuals(f, fd, t1, t2, shard_buffers(buffers), flags, rc);
+    });
+}
+int pymes_ccsd_sharded_finish(pymes_ctx* ctx, const double* f, const double* t1, const double* tc, const double* dtc,
+                              const pymes_shard_buffers* buffers, int* slot) {
+    return guarded([&] {
+        need(f, "f"); need(t1, "t1"); need(tc, "tc");
+        if (!slot) throw pymes::Error("null output");
+        *slot = E(ctx).ccsd_sharded_finish(f, t1, tc, dtc, shard_buffers(buffers));
+    });
+}
+int pymes_ccsd_sharded_energy(pymes_ctx* ctx, int slot, double* out) {
+    return guarded([&] {
+        need(out, "out");
+        E(ctx).ccsd_sharded_energy(slot, out);
+    });
+}
+int pymes_ccsd_sharded_await(pymes_ctx* ctx, double* t2, const pymes_shard_buffers* buffers) {
+    return guarded([&] {
+        need(t2, "t2");
+        E(ctx).ccsd_sharded_await(t2, shard_buffers(buffers));
+    });
+}
 int pymes_ccsd_energy(pymes_ctx* ctx, const double* f, const double* t1, const double* t2, double* e_out) {
     return guarded([&] {
         need(f, "f"); need(t1, "t1"); need(t2, "t2"); need(e_out, "e_out");

@@ -1588,6 +1588,159 @@ void Engine::ccsd_iterate(const double* f, double* t1, double* t2, unsigned flag
     energy_norms(f, t1, t2, dt2, out);                                        // :189-197
 }
 
+// ---- one process per GPU with the host program's collectives (engine.h; include/pymes_amd.h, pymes_collectives) -----------------
+void Engine::set_collectives(const Collectives* c) {
+    if (t2_in_flight_) throw Error("set_collectives: an exchange of the amplitudes is in flight (pymes_ccsd_sharded_await first)");
+    if (!c) {
+        coll_ = Collectives();
+        coll_set_ = false;
+        return;
+    }
+    if (!c->allreduce_start || !c->allgather_start || !c->wait) throw Error("set_collectives: allreduce_start, allgather_start and wait are required");
+    if (c->world < 1 || c->rank < 0 || c->rank >= c->world) throw Error("set_collectives: need 0 <= rank < world");
+    coll_ = *c;
+    coll_set_ = true;
+}
+
+namespace {
+// the calls into the host program: a failure there (non-zero return) becomes an Error of this library
+struct Hooks {
+    const Engine::Collectives& c;
+    void* stream;
+    // (nothing of the library's own may still be queued when the host program orders a collective behind the stream)
+    int64_t allreduce(double* buf, int64_t n) const {
+        dev::gemm_group_sync();
+        int64_t t = 0;
+        if (c.allreduce_start(c.user, buf, n, stream, &t) != 0) throw Error("collective hook: allreduce_start failed");
+        return t;
+    }
+    int64_t allgather(double* buf, int64_t chunk) const {
+        dev::gemm_group_sync();
+        int64_t t = 0;
+        if (c.allgather_start(c.user, buf, chunk, stream, &t) != 0) throw Error("collective hook: allgather_start failed");
+        return t;
+    }
+    void wait(int64_t ticket) const {
+        if (c.wait(c.user, ticket, stream) != 0) throw Error("collective hook: wait failed");
+    }
+    void mark(const char* phase) const {
+        if (c.mark) c.mark(c.user, phase);
+    }
+};
+int64_t chunk_of(int64_t n, int world) { return (n + world - 1) / world; }
+}  // namespace
+
+void Engine::ccsd_sharded_await(double* t2, const ShardBuffers& b) {
+    if (!t2_in_flight_) return;
+    if (!coll_set_) throw Error("sharded step: no collectives set (pymes_set_collectives)");
+    const Hooks h{coll_, stream};
+    h.wait(t2_ticket_);
+    t2_in_flight_ = false;
+    const int64_t o2 = static_cast<int64_t>(no) * no, c = chunk_of(static_cast<int64_t>(nv) * (nv + 1) / 2, coll_.world);
+    for (int r = 0; r < coll_.world; ++r) {          // chunk r of the exchanged buffer: the compact tiles of rank r's pairs
+        int64_t r0, r1;
+        pair_chunk(r, coll_.world, r0, r1);
+        dev::pairs_unpack(b.Tall + static_cast<int64_t>(r) * c * 2 * o2, t2, no, nv, r0, r1, stream);
+    }
+}
+
+void Engine::ccsd_sharded_residuals(const double* f, double* fd, const double* t1, double* t2, const ShardBuffers& b,
+                                    unsigned flags, double* rc) {
+    if (!coll_set_) throw Error("sharded step: no collectives set (pymes_set_collectives)");
+    if (!dev::fused_pair_kernels_ok(no)) throw Error("sharded step: nocc too large for the pair-sharded tail");
+    const Hooks h{coll_, stream};
+    const int rank = coll_.rank, world = coll_.world;
+    const int64_t o = no, v = nv, ov = o * v, o2 = o * o;
+    // flag bits of include/pymes_amd.h: PYMES_DCD 1, PYMES_USE_DRESSED 2, PYMES_SYM_LADDER 8, PYMES_SYM_RINGS 16,
+    // PYMES_SLAB_RINGS_ONLY 64, PYMES_SLAB_LADDERS_ONLY 128
+    const unsigned dcd = flags & 1u, kSlabRingsOnly = 64u, kSlabLaddersOnly = 128u;
+    const unsigned slab = dcd | 2u | 8u | 16u;
+    h.mark("begin");
+    // K-sharded partial sums, all-reduced: the T1.V intermediates of the dressed Fock matrix (ccsd.py:163, this rank's chunk of
+    // j).  What needs T1 only comes first: the all-gather of the new T2 that the previous pass left in flight is awaited — and
+    // unpacked into the replicated array — right before the first kernel that reads T2.
+    dress_fock_partial(t1, b.W, rank, world);
+    const int64_t tW = h.allreduce(b.W, dress_fock_ws_doubles());
+    {
+        // V~_iajb / V~_iabj only for the second-index range that this rank's column slab reads (:165); V~_klij rides in the
+        // same call and shares its V_klcd t_dj intermediate with V~_iabj
+        const int64_t cc = chunk_of(ov, world), c0 = std::min<int64_t>(rank * cc, ov), c1 = std::min<int64_t>(c0 + cc, ov);
+        if (c1 > c0) {
+            const int64_t cut[4] = {0, 0, c0 / o, (c1 + o - 1) / o};
+            dress_V(t1, (1u << P_klij) | (1u << P_iajb) | (1u << P_iabj), cut);
+        } else {
+            dress_V(t1, 1u << P_klij);
+        }
+    }
+    h.mark("T1-only: fock partial, dress V slab");
+    ccsd_sharded_await(t2, b);
+    slab_prepare(t2, b.P, rank, world, dcd);
+    // P = [ X'_ki (o^2 doubles: read by the ring half) | pair-packed 2 V_klcd T_cdij (read by the ladder half) ]: two
+    // all-reduces, the big one is awaited only in front of the ladders — behind the ring products
+    const int64_t tX = h.allreduce(b.P, o2);
+    const int64_t tJ = h.allreduce(b.P + o2, slab_prepare_ws_doubles() - o2);
+    h.wait(tW);
+    h.wait(tX);
+    dress_fock_finish(f, t1, b.W, fd);
+    h.mark("await T2, slab prepare, fock finish");
+    // :171 in two halves: the ring products first, so that the all-gathers of their rows fly while the ladders — whose rows
+    // of L never leave the rank — and the singles residual are computed
+    residual_slab(fd, t2, b.ETd, b.ETx, b.L, rank, world, slab | kSlabRingsOnly, t1, b.QK, b.P);
+    h.mark("ring products");
+    const int64_t tD = h.allgather(b.ETd, chunk_of(ov, world) * ov);
+    const int64_t tE = h.allgather(b.ETx, chunk_of(ov, world) * ov);
+    h.wait(tJ);
+    residual_slab(fd, t2, b.ETd, b.ETx, b.L, rank, world, slab | kSlabLaddersOnly, t1, b.QK, b.P);
+    h.mark("ladders, Q_kb");
+    const int64_t tQ = h.allgather(b.QK, chunk_of(ov, world) * o2);
+    xvv_partial(fd, t2, b.Xvv, rank, world, dcd);                     // X_ac (ccd.py:206-221) over this rank's chunk of k
+    const int64_t tV = h.allreduce(b.Xvv, v * v);
+    singles_residual_partial(fd, t1, t2, b.R1, rank, world, true);    // :167 over this rank's chunk of the occupied index
+    const int64_t tR = h.allreduce(b.R1, v * o);
+    for (int64_t t : {tD, tE, tQ, tV, tR}) h.wait(t);
+    h.mark("X_ac, singles residual, waits");
+    int64_t r0, r1;
+    pair_chunk(rank, world, r0, r1);
+    if (r1 <= r0) dev::memset_zero(rc, sizeof(double) * 2 * o2, stream);       // a rank without pairs: one zero tile pair
+    residual_finish_pairs(fd, t2, b.ETd, b.ETx, b.L, rc, slab, t1, b.QK, rank, world, b.Xvv);     // :171, this rank's pairs
+    h.mark("finish + assembly (pairs)");
+}
+
+int Engine::ccsd_sharded_finish(const double* f, const double* t1, const double* tc, const double* dtc, const ShardBuffers& b) {
+    if (!coll_set_) throw Error("sharded step: no collectives set (pymes_set_collectives)");
+    if (t2_in_flight_) throw Error("sharded step: the previous exchange of the amplitudes was never awaited");
+    const Hooks h{coll_, stream};
+    const int rank = coll_.rank, world = coll_.world;
+    const int64_t o2 = static_cast<int64_t>(no) * no;
+    int64_t r0, r1;
+    pair_chunk(rank, world, r0, r1);
+    const int64_t c = chunk_of(static_cast<int64_t>(nv) * (nv + 1) / 2, world);
+    if (r1 > r0)
+        dev::memcpy_d2d(b.Tall + static_cast<int64_t>(rank) * c * 2 * o2, tc, sizeof(double) * (r1 - r0) * 2 * o2, stream);
+    // the energy and the norms (:189-197) come from the compact tiles: six partial sums, all-reduced where they are and copied
+    // to the host on the side — nothing on this stream waits for the host.  The all-gather of the new T2 is only STARTED, after
+    // that small all-reduce (a communicator runs its collectives in order: behind the 0.8-GB transfer the six numbers would
+    // wait for it)
+    dev::energy_norms_pairs_dev(f, t1, tc, get_static("Edir"), get_static("Eex"), dtc, no, nv, r0, r1, rank == 0, b.S, stream);
+    h.wait(h.allreduce(b.S, 6));
+    const int slot = dev::readback_start(b.S, 6, stream);
+    t2_ticket_ = h.allgather(b.Tall, c * 2 * o2);
+    t2_in_flight_ = true;
+    h.mark("energy + norms (pairs)");
+    return slot;
+}
+
+void Engine::ccsd_sharded_energy(int slot, double out[6]) {
+    double r[6];
+    dev::readback_wait(slot, r, 6);
+    out[0] = 2.0 * r[0];
+    out[1] = 2.0 * r[1];
+    out[2] = -1.0 * r[2];
+    out[3] = r[3];
+    out[4] = r[4];
+    out[5] = r[5];
+}
+
 void Engine::release_residual_buffers() {
     for (double** p : {&res_fd_, &res_ETd_, &res_ETx_, &res_L_, &res_QK_, &res_r1_, &res_r2_}) {
         if (*p) scratch_put(*p);

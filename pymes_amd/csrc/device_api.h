@@ -144,6 +144,11 @@ void readback_wait(int slot, double* out_host, int n);
 void energy_norms_pairs(const double* f, const double* t1, const double* tc, const double* Edir, const double* Eex,
                         const double* dtc, int no, int nv, int64_t r0, int64_t r1, bool with_t1, double out_host[6],
                         stream_t s);
+// ... the six sums left in device memory (out_dev[6]; nothing is copied, nothing waits): one rank's share, all-reduced by
+// the host program's collective before anybody reads it
+void energy_norms_pairs_dev(const double* f, const double* t1, const double* tc, const double* Edir, const double* Eex,
+                            const double* dtc, int no, int nv, int64_t r0, int64_t r1, bool with_t1, double* out_dev,
+                            stream_t s);
 // max |A[p,q,r,s] - B[q,p,s,r]| and max |A| for A [d0,d1,d2,d3], B [d1,d0,d3,d2] (electron-exchange partner; B may be
 // A itself when d0 == d1 and d2 == d3).  Result on host (synchronises the stream).
 void exchange_asymmetry(const double* A, const double* B, const int64_t d[4], double out_host[2], stream_t s);

@@ -228,6 +228,37 @@ class Engine {
     void energy_norms_wait(int slot, double out[6]);
     void energy_norms_pairs(const double* f, const double* t1, const double* tc, const double* dtc, int rank, int world,
                             double out[6]);
+    // ---- one process per GPU: the loop body with the collectives of the HOST PROGRAM (include/pymes_amd.h, pymes_collectives:
+    // RCCL calls on a communicator of the host's own; this repository's Python host wraps torch.distributed).  Every
+    // collective is asynchronous: `*_start` orders it behind the work already enqueued on the engine's stream and returns a
+    // ticket, `wait` orders the stream behind its completion — the host never blocks, the exchange of the ring products flies
+    // while the ladders are computed.  Buffers that take part in a collective are the caller's (ShardBuffers, sizes in the
+    // header): a host that registers memory with its communicator does so once.
+    struct Collectives {
+        void* user = nullptr;
+        int rank = 0, world = 1;
+        int (*allreduce_start)(void* user, double* buf, int64_t n, void* stream, int64_t* ticket) = nullptr;
+        int (*allgather_start)(void* user, double* buf, int64_t chunk, void* stream, int64_t* ticket) = nullptr;
+        int (*wait)(void* user, int64_t ticket, void* stream) = nullptr;
+        void (*mark)(void* user, const char* phase) = nullptr;      // optional: phase boundaries (profiling)
+    };
+    struct ShardBuffers {
+        double *ETd, *ETx, *L, *QK, *Tall, *W, *Xvv, *P, *R1, *S;
+    };
+    void set_collectives(const Collectives* c);          // nullptr: none (single rank)
+    bool has_collectives() const { return coll_set_; }
+    // ccsd.py:161-171 for this rank: dressed Fock + the dressed blocks of its slab, ring products (rows exchanged), ladders,
+    // Q_kb, X_ac, R1 (all-reduced, left in b.R1), R2 of its virtual pairs as compact tiles rc [max(pairs,1)][2][o*o]; t2
+    // [v,v,o,o] is the replicated array (completed from the exchange the previous ccsd_sharded_finish left in flight before
+    // it is read).  Writes only b.* , fd and rc: a caller may enqueue it ahead of reading the previous energy.  flags: PYMES_DCD
+    void ccsd_sharded_residuals(const double* f, double* fd, const double* t1, double* t2, const ShardBuffers& b,
+                                unsigned flags, double* rc);
+    // ccsd.py:189-197 + the hand-over of the new amplitudes: partial energies / norms of (t1, tc, dtc) all-reduced on the
+    // device and copied to the host on the side (returns the read-back slot for ccsd_sharded_energy), tc into the exchange
+    // buffer, all-gather of the new T2 started (awaited by the next ccsd_sharded_residuals or by ccsd_sharded_await)
+    int ccsd_sharded_finish(const double* f, const double* t1, const double* tc, const double* dtc, const ShardBuffers& b);
+    void ccsd_sharded_energy(int slot, double out[6]);
+    void ccsd_sharded_await(double* t2, const ShardBuffers& b);
     void invalidate_static();
 
     double* eps_o = nullptr;
@@ -264,6 +295,9 @@ class Engine {
     dev::stream_t own_stream_ = nullptr;
     std::set<void*> user_allocs_;
     // exchange / staging buffers of ccsd_residuals (engine scratch, held from the first call to release_residual_buffers)
+    Collectives coll_;
+    bool coll_set_ = false, t2_in_flight_ = false;
+    int64_t t2_ticket_ = 0;
     double *res_fd_ = nullptr, *res_ETd_ = nullptr, *res_ETx_ = nullptr, *res_L_ = nullptr, *res_QK_ = nullptr, *res_r1_ = nullptr,
            *res_r2_ = nullptr;
     std::multimap<int64_t, double*> scratch_free_;

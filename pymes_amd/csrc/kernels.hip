@@ -4308,6 +4308,20 @@ void energy_norms_pairs(const double* f, const double* t1, const double* tc, con
     wait_idle(st);
     for (int i = 0; i < 6; ++i) out_host[i] = g_dot_host[dv][i];
 }
+void energy_norms_pairs_dev(const double* f, const double* t1, const double* tc, const double* Edir, const double* Eex,
+                            const double* dtc, int no, int nv, int64_t r0, int64_t r1, bool with_t1, double* out_dev,
+                            stream_t s) {
+    hipStream_t st = (hipStream_t)s;
+    const int dv = current_device();
+    ensure_dot_ws(dv);
+    const long npairs = std::max<long>(0, (long)(r1 - r0));
+    const int nb = (int)std::max<long>(1, std::min<long>(kDotBlocks, 2 * npairs));
+    hipLaunchKernelGGL(energy_norms_pairs_kernel, dim3(nb), dim3(256), 0, st, f, t1, tc, Edir, Eex, dtc, no, nv, (long)r0,
+                       npairs, with_t1 ? 1 : 0, g_dot_ws[dv]);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(dots_stage2_kernel, dim3(6), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);
+    HIP_CHECK(hipGetLastError());
+}
 void pairs_unpack(const double* Xc, double* full, int no, int nv, int64_t r0, int64_t r1, stream_t s) {
     if (r1 <= r0) return;
     hipLaunchKernelGGL(pairs_unpack_kernel, dim3((unsigned)(r1 - r0)), dim3(256), 0, (hipStream_t)s, Xc, full, no, nv, (long)r0);

@@ -294,6 +294,92 @@ def exchange_rows_start(full, rank, world_size, ctx=None, label="allgather"):
     return _Pending(dist.all_gather_into_tensor(full.view(-1), mine.view(-1), async_op=True), mine, label)
 
 
+# ---- the collective table of include/pymes_amd.h (pymes_collectives), filled with torch.distributed ------------------------------
+class Collectives:
+    """What a host program hands to ``pymes_set_collectives``: the library's one-process-per-GPU step
+    (``pymes_ccsd_sharded_residuals`` / ``_finish``) calls back for every all-reduce / all-gather, naming device memory by
+    pointer.  Here the exchange buffers are torch tensors (``buffers``: name -> tensor, the memory the solver allocated
+    for them), the pointer is mapped back to a view of its tensor and the collective is the same ``torch.distributed`` call
+    the Python-sequenced path makes (RCCL on the GPUs, gloo staged through the host in the test rigs, a no-op under
+    ``stub``).  An RCCL host in another language fills the same table with ncclAllReduce / ncclAllGather."""
+
+    LABELS = {"W": "fock intermediates", "Xvv": "X_ac", "R1": "R1", "S": "scalars", "ETd": "ETd", "ETx": "ETx", "QK": "QK",
+              "Tall": "new T2", "L": "L"}
+
+    def __init__(self, ctx, buffers, rank, world_size):
+        import ctypes as C
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world_size)
+        self._buffers = sorted(((t.data_ptr(), t.numel(), name, t) for name, t in buffers.items()), key=lambda x: x[0])
+        self._tickets, self._next, self.error = {}, 1, None
+        start_t = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64))
+        wait_t = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p)
+        mark_t = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p)
+
+        class Table(C.Structure):
+            _fields_ = [("user", C.c_void_p), ("rank", C.c_int), ("world", C.c_int), ("allreduce_start", start_t),
+                        ("allgather_start", start_t), ("wait", wait_t), ("mark", mark_t)]
+        self._callbacks = (start_t(self._allreduce), start_t(self._allgather), wait_t(self._wait), mark_t(self._mark))
+        self.table = Table(None, self.rank, self.world, *self._callbacks)
+        ctx.lib.call("pymes_set_collectives", ctx.handle, C.byref(self.table))
+        ctx._collectives = self              # the callbacks must outlive the context's use of them
+
+    def _view(self, ptr, n):
+        for base, numel, name, t in self._buffers:
+            if base <= ptr < base + 8 * numel:
+                off = (ptr - base) // 8
+                if off + n > numel:
+                    raise ValueError("collective hook: %d doubles at offset %d run past buffer %s" % (n, off, name))
+                return t.view(-1)[off:off + n], name, off
+        raise ValueError("collective hook: pointer %#x is none of the exchange buffers" % ptr)
+
+    def _ticket(self, work, ticket_p):
+        k = self._next
+        self._next += 1
+        self._tickets[k] = work
+        ticket_p[0] = k
+        return 0
+
+    def _allreduce(self, user, buf, n, stream, ticket_p):
+        try:
+            t, name, off = self._view(int(buf), int(n))
+            label = ("X_ki" if off == 0 else "hole-ladder J") if name == "P" else self.LABELS.get(name, name)
+            return self._ticket(allreduce_tensor_start(t, self.ctx, label=label), ticket_p)
+        except BaseException as exc:         # nothing may propagate through the C frames: the library reports the failure
+            self.error = exc
+            return 1
+
+    def _allgather(self, user, buf, chunk, stream, ticket_p):
+        try:
+            t, name, _ = self._view(int(buf), int(chunk) * self.world)
+            full = t.view(self.world, int(chunk))
+            return self._ticket(exchange_rows_start(full, self.rank, self.world, self.ctx, label=self.LABELS.get(name, name)),
+                                ticket_p)
+        except BaseException as exc:
+            self.error = exc
+            return 1
+
+    def _wait(self, user, ticket, stream):
+        try:
+            self._tickets.pop(int(ticket)).wait()
+            return 0
+        except BaseException as exc:
+            self.error = exc
+            return 1
+
+    def _mark(self, user, phase):
+        trace.mark(phase.decode())
+
+    def call(self, name, *args):
+        """``ctx.lib.call`` for an entry that may call back: a failure inside a callback is re-raised as what it was."""
+        self.error = None
+        try:
+            return self.ctx.lib.call(name, *args)
+        except Exception as exc:
+            if self.error is not None:
+                raise self.error from exc
+            raise
+
+
 # ---- owner-tile exchange of the ring-product rows ------------------------------------------------------------------------
 # In the pair-sharded tail rank q assembles R only for its virtual pairs P(a,b), a >= b, a in [a0_q, a1_q): of the pair
 # matrices ETd / ETx (rows = this rank's column slab, see Engine::residual_slab) it reads the tiles [(a,.),(b,.)] and

@@ -6,11 +6,13 @@ signature, return dictionary and public helper methods.  Inside ``solve`` everyt
 scalars only.  With ``torch.distributed`` initialised (one process per GPU) the
 particle-particle ladder is sharded over the ranks on the virtual index ``a``
 (pymes_amd/dist.py)."""
+import ctypes as C
 import os
 import time
 
 import numpy as np
 
+from pymes_amd import _lib
 from pymes_amd import dist as pdist
 from pymes_amd.device import Context, DeviceArray
 from pymes_amd.integral.device import DeviceIntegrals, DressedDeviceIntegrals
@@ -113,6 +115,17 @@ class CCSD(ccd.CCD):
                 st["P_t"], st["P"] = reduced(ctx.slab_prepare_ws())
                 st["R1_t"], st["R1"] = reduced(nv * no)
                 st["R1"] = st["R1"].reshape(nv, no)
+                if st["pairs"] and not st["owner_tiles"]:
+                    # the loop body as whole library steps (pymes_ccsd_sharded_residuals / _finish) that call back for their
+                    # collectives (include/pymes_amd.h, pymes_collectives; pymes_amd/dist.py:Collectives fills the table with
+                    # torch.distributed): the sequence a host in any language would run.  (The owner-tile all-to-all and the
+                    # replicated tail of user amplitudes keep the Python-sequenced form below.)
+                    st["S_t"], st["S"] = reduced(8)
+                    names = ("ETd", "ETx", "L", "QK", "Tall", "W", "Xvv", "P", "R1", "S")
+                    st["coll"] = pdist.Collectives(ctx, {k: st[k + "_t"] for k in names}, rank, wsize)
+                    st["bufs"] = _lib.ShardBuffers(*[st[k + "_t"].data_ptr() for k in names])
+                    st["rc"] = self._compact(ctx, st)
+                    st["flags"] = _lib.PYMES_DCD if self.is_dcd else 0
             else:
                 st["lad_rows"] = nv * nv
                 st["lad_t"], st["lad"] = shared(nv * nv, no * no)
@@ -220,7 +233,49 @@ class CCSD(ccd.CCD):
         return e1, ed, ex, np.sqrt(nt2), np.sqrt(nr2)
 
     # ---- one process per GPU ----------------------------------------------------------------------------------------
+    def _hooked_residuals(self, st):
+        ctx = st["ctx"]
+        st["coll"].call("pymes_ccsd_sharded_residuals", ctx.handle, C.c_void_p(st["f"].ptr), C.c_void_p(st["fd"].ptr),
+                        C.c_void_p(st["t1"].ptr), C.c_void_p(st["t2"].ptr), C.byref(st["bufs"]), st["flags"],
+                        C.c_void_p(st["rc"].ptr))
+
+    def _iterate_hooked(self, st):
+        """One pass on one rank of many, as whole library steps with the collective table (setup): residuals — enqueued by the
+        PREVIOUS pass behind its energy reduction whenever that pass did not expect to be the last, as on a single rank —
+        update, mixer (its overlaps are the one host round trip of a pass), then energies all-reduced on the device and
+        copied to the host on the side, the next residuals enqueued, and only then the six numbers are waited for."""
+        ctx, t1, tc = st["ctx"], st["t1"], st["Tc"]
+        rank, world, shift = st["rank"], st["world"], st["level_shift"]
+        coll, mark = st["coll"], pdist.trace.mark
+        if not st.pop("residuals_in_flight", False):
+            self._hooked_residuals(st)
+        dt1, dtc = ctx.pool_get(t1.shape), self._compact(ctx, st)
+        ctx.cc_update(t1, dt1, st["R1"], shift, self.delta)                             # :176-179
+        ctx.cc_update_pairs(tc, dtc, st["rc"], shift, self.delta, rank, world)
+        st["first"] = False
+        mark("update")
+        if self.is_diis:
+            t1, tc = self.mixer.mix([dt1, dtc], [t1, tc], release=ctx.pool_put, sharded=(1,),
+                                    allreduce=pdist.allreduce_sum, mark=mark)            # :181-183
+        mark("DIIS extrapolation")
+        st["t1"], st["Tc"] = t1, tc
+        slot = C.c_int()
+        coll.call("pymes_ccsd_sharded_finish", ctx.handle, C.c_void_p(st["f"].ptr), C.c_void_p(t1.ptr), C.c_void_p(tc.ptr),
+                  C.c_void_p(dtc.ptr), C.byref(st["bufs"]), C.byref(slot))
+        if not self.is_diis:
+            ctx.pool_put(dt1)
+            ctx.pool_put(dtc)
+        if st.get("speculate", True):
+            self._hooked_residuals(st)
+            st["residuals_in_flight"] = True
+        out = (C.c_double * 6)()
+        coll.call("pymes_ccsd_sharded_energy", ctx.handle, slot.value, out)
+        mark("energy + norms (read-back)")
+        return out[0], out[1], out[2], np.sqrt(out[3]), np.sqrt(out[4])
+
     def _iterate_sharded(self, st):
+        if "coll" in st:
+            return self._iterate_hooked(st)
         ctx, t1, t2 = st["ctx"], st["t1"], st["t2"]
         shift = st["level_shift"]
         world, rank, dist_on = st["world"], st["rank"], st["dist"]
@@ -385,6 +440,8 @@ class CCSD(ccd.CCD):
     def _await_t2(st):
         """Complete the exchange of the new amplitudes that the pair-sharded tail left in flight: wait for the all-gather
         of the compact tiles and unpack them into the replicated T2."""
+        if "coll" in st:
+            st["coll"].call("pymes_ccsd_sharded_await", st["ctx"].handle, C.c_void_p(st["t2"].ptr), C.byref(st["bufs"]))
         work = st.pop("t2_pending", None)
         if work is not None:
             work.wait()

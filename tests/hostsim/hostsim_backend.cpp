@@ -209,6 +209,12 @@ void energy_norms_pairs(const double* f, const double* t1, const double* tc, con
             }
 }
 
+void energy_norms_pairs_dev(const double* f, const double* t1, const double* tc, const double* Edir, const double* Eex,
+                            const double* dtc, int no, int nv, int64_t r0, int64_t r1, bool with_t1, double* out_dev,
+                            stream_t s) {
+    energy_norms_pairs(f, t1, tc, Edir, Eex, dtc, no, nv, r0, r1, with_t1, out_dev, s);       // "device" memory is host memory here
+}
+
 void exchange_asymmetry(const double* A, const double* B, const int64_t d[4], double out[2], stream_t) {
     out[0] = out[1] = 0.0;
     for (int64_t p = 0; p < d[0]; ++p)
