@@ -475,6 +475,7 @@ class CCSD(ccd.CCD):
             print_logging_info("Iteration = 0", level=1)
             st = self.setup(t_fock_pq, ints, level_shift, amps)
             self.pair_sharded = st["pairs"]          # which tail the iterations use (world > 1 only)
+            self.hooked = "coll" in st               # ... and whether they run as whole library steps with the collective table
             e_mp2 = st["e_mp2"]
             dE = np.abs(e_mp2)
             iteration = 0
@@ -503,6 +504,7 @@ class CCSD(ccd.CCD):
             print_logging_info("CCSD correlation energy = {:.12f}".format(e_ccsd), level=1)
             print_logging_info("{:.3f} seconds spent on ccsd".format((time.time() - time_ccsd)), level=1)
             self._await_t2(st)
+            self.collective_calls = st["coll"]._next - 1 if self.hooked else 0
             if kwargs.get("device_amplitudes"):
                 # device-resident hand-over to the callers of the solution (EOM-CCSD / FEAST: get_T1_dressed_V on the same
                 # DeviceIntegrals, EOM_CCSD.solve on the result): "t1" / "t2" are DeviceArrays of the integrals' context —

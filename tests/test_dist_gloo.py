@@ -126,7 +126,7 @@ def _solver_worker(rank, world, port, libpath, out):
             s = CCSD(no, delta_e=1e-10, is_dcsd=dcsd, is_diis=diis)
             with contextlib.redirect_stdout(io.StringIO()):
                 r = s.solve(f, V)
-            assert s.pair_sharded
+            assert s.pair_sharded and s.hooked and s.collective_calls >= 10 * s.iterations
             res[(no, nv, dcsd, diis)] = (float(r["ccsd e"]), int(s.iterations), float(np.abs(r["t2"]).sum()),
                                          float(np.abs(r["t2"] - r["t2"].transpose(1, 0, 3, 2)).max()))
         # symmetric user amplitudes: sharded residual with the replicated tail (the caller's arrays are updated in place)

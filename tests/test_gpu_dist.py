@@ -32,7 +32,7 @@ def _worker(rank, world, port, out):
             s = CCSD(no, delta_e=1e-10, is_dcsd=dcsd, device=0)
             with contextlib.redirect_stdout(io.StringIO()):
                 r = s.solve(f, ints)
-            assert s.pair_sharded
+            assert s.pair_sharded and s.hooked       # whole library steps, collectives through the table (pymes_collectives)
             ints.ctx.close()
             res[f"syn_{no}_{nv}_{'dcsd' if dcsd else 'ccsd'}"] = (float(r["ccsd e"]), int(s.iterations))
         from pymes_amd.solver.ccd import CCD
@@ -77,3 +77,46 @@ def test_two_ranks_one_gpu(gpu_lib):
     amps = [rng.standard_normal((12, 4)) * 1e-3, rng.standard_normal((12, 12, 4, 4)) * 1e-3]
     ref = oc.ccsd_solve(4, f, V, delta_e=1e-10, amps=amps)
     assert abs(out[0]["syn_4_12_unsym_start"][0] - ref["e"]) < 1e-9
+
+
+def _worker_rccl(rank, port, out):
+    """A world of ONE rank on an RCCL communicator (PYMES_FORCE_SHARDED=1): every collective entry point of the table is
+    entered with device tensors, asynchronously, ordered on the stream the engine is bound to."""
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0", PYMES_FORCE_SHARDED="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        from oracle.cases import synthetic_case
+        from pymes_amd import dist as pdist
+        from pymes_amd.integral.device import DeviceIntegrals
+        from pymes_amd.solver.ccsd import CCSD
+        assert pdist.sharded()
+        res = {}
+        for no, nv, dcsd in ((6, 20, False), (4, 12, True)):
+            f, V, B, eps = synthetic_case(no, nv, seed=0, scale=0.3)
+            ints = DeviceIntegrals.from_V_pqrs(no, V, device=0)
+            s = CCSD(no, delta_e=1e-10, is_dcsd=dcsd, device=0)
+            with contextlib.redirect_stdout(io.StringIO()):
+                r = s.solve(f, ints)
+            assert s.pair_sharded and s.hooked
+            res[f"syn_{no}_{nv}_{'dcsd' if dcsd else 'ccsd'}"] = (float(r["ccsd e"]), int(s.iterations), int(s.collective_calls))
+            ints.ctx.close()
+        out[0] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_forced_one_rank_rccl(gpu_lib):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_rccl, args=(port, out), nprocs=1, join=True)
+    gold = json.load(open(os.path.join(GOLD, "solves.json")))
+    e, it, calls = out[0]["syn_6_20_ccsd"]
+    assert abs(e - gold["syn_6_20"]["ccsd"]["e"]) < 1e-9 and it == gold["syn_6_20"]["ccsd"]["iterations"]
+    assert calls >= 10 * it                  # ten collectives per residual build + finish
+    e, it, calls = out[0]["syn_4_12_dcsd"]
+    assert abs(e - gold["syn_4_12"]["dcsd"]["e"]) < 1e-9 and it == gold["syn_4_12"]["dcsd"]["iterations"]
