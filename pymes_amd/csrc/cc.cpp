@@ -1590,7 +1590,12 @@ void Engine::ccsd_iterate(const double* f, double* t1, double* t2, unsigned flag
 
 // ---- one process per GPU with the host program's collectives (engine.h; include/pymes_amd.h, pymes_collectives) -----------------
 void Engine::set_collectives(const Collectives* c) {
-    if (t2_in_flight_) throw Error("set_collectives: an exchange of the amplitudes is in flight (pymes_ccsd_sharded_await first)");
+    if (t2_in_flight_) {
+        // a loop that was abandoned between finish and the next residuals: its last exchange is completed through the table
+        // that started it (nobody reads the result) before that table goes
+        t2_in_flight_ = false;
+        if (coll_.wait(coll_.user, t2_ticket_, stream) != 0) throw Error("collective hook: wait failed");
+    }
     if (!c) {
         coll_ = Collectives();
         coll_set_ = false;

@@ -253,6 +253,39 @@ def check_failures(lib):
         rk.close()
 
 
+def check_abandoned_loop(lib):
+    """A loop left between finish and the next residuals: the exchange of the amplitudes it started is completed through the
+    table that started it when that table is replaced or removed (nobody reads the result)."""
+    no, nv = 2, 4
+    f, V, _, _ = synthetic_case(no, nv, seed=2, scale=0.3)
+    t1, t2, dt2 = amplitudes(no, nv, 3)
+    rk = Rank(lib, no, nv, f, V, 0, 1)
+    try:
+        ctx = rk.ctx
+        fdev, a1, a2 = ctx.array(f), ctx.array(t1), ctx.array(t2)
+        shape = (nv * (nv + 1) // 2, 2, no * no)
+        tc, dtc = ctx.zeros(shape), ctx.zeros(shape)
+        ctx.pairs_pack(a2, tc, 0, 1)
+        slot = C.c_int()
+        rk.call("pymes_ccsd_sharded_finish", C.c_void_p(fdev.ptr), C.c_void_p(a1.ptr), C.c_void_p(tc.ptr), C.c_void_p(dtc.ptr),
+                C.byref(rk.bufs), C.byref(slot))
+        with pytest.raises(PymesError, match="never awaited"):                   # a second finish without residuals / await
+            rk.call("pymes_ccsd_sharded_finish", C.c_void_p(fdev.ptr), C.c_void_p(a1.ptr), C.c_void_p(tc.ptr),
+                    C.c_void_p(dtc.ptr), C.byref(rk.bufs), C.byref(slot))
+        gather = [i + 1 for i, e in enumerate(rk.log) if e[:2] == ("allgather", "Tall")][-1]      # its ticket (Rank._allgather)
+        waits = len([e for e in rk.log if e[0] == "wait"])
+        ctx.lib.call("pymes_set_collectives", ctx.handle, C.byref(rk.table))     # the same table again: old exchange completed
+        assert [e for e in rk.log if e[0] == "wait"][waits:] == [("wait", gather)]
+        ctx.lib.call("pymes_set_collectives", ctx.handle, None)                  # nothing in flight any more
+        assert len([e for e in rk.log if e[0] == "wait"]) == waits + 1
+    finally:
+        rk.close()
+
+
+def test_abandoned_loop_host_logic(hostsim_lib):
+    check_abandoned_loop(hostsim_lib)
+
+
 def test_failures_host_logic(hostsim_lib):
     check_failures(hostsim_lib)
 
