@@ -2098,6 +2098,7 @@ __global__ void __launch_bounds__(256) ring_operands_kernel(const double* __rest
 
 // Pair layouts of exchange-symmetric-or-not amplitudes in one pass over T[a,b,i,j]; one block per (a,b):
 //   Td[(a,i),(b,j)] = T_abij,  Tx[(a,j),(b,i)] = T_abij,  Ttd[(a,i),(b,j)] = ca T_abij + cb T_baij   (2, -1 in the residual)
+template <bool RESIDUAL>     // RESIDUAL: (ca, cb) = (2, -1) as compile-time constants (the form every CCSD iteration runs)
 __global__ void __launch_bounds__(256) t2_layouts_kernel(const double* __restrict__ T, double* __restrict__ Td,
                                                          double* __restrict__ Tx, double* __restrict__ Ttd, int no,
                                                          int nv, double ca, double cb) {
@@ -2113,7 +2114,7 @@ __global__ void __launch_bounds__(256) t2_layouts_kernel(const double* __restric
         tile[i * (no + 1) + j] = x;
         const long off = base + (long)i * ov + j;
         if (Td) Td[off] = x;
-        Ttd[off] = ca * x + cb * Tba[e];
+        Ttd[off] = RESIDUAL ? 2.0 * x - Tba[e] : ca * x + cb * Tba[e];
     }
     __syncthreads();
     for (int e = threadIdx.x; e < o2; e += blockDim.x) {
@@ -4191,7 +4192,10 @@ void ring_operands(const double* Viabj, const double* Viajb, double* M, double* 
 void t2_layouts(const double* T, double* Td, double* Tx, double* Ttd, int no, int nv, stream_t s, double ca, double cb) {
     if (!fused_pair_kernels_ok(no)) throw std::runtime_error("t2_layouts: nocc too large for the LDS tile");
     const size_t lds = sizeof(double) * no * (no + 1);
-    hipLaunchKernelGGL(t2_layouts_kernel, dim3((unsigned)(nv * nv)), dim3(256), lds, (hipStream_t)s, T, Td, Tx, Ttd, no, nv, ca, cb);
+    if (ca == 2.0 && cb == -1.0)
+        hipLaunchKernelGGL(t2_layouts_kernel<true>, dim3((unsigned)(nv * nv)), dim3(256), lds, (hipStream_t)s, T, Td, Tx, Ttd, no, nv, ca, cb);
+    else
+        hipLaunchKernelGGL(t2_layouts_kernel<false>, dim3((unsigned)(nv * nv)), dim3(256), lds, (hipStream_t)s, T, Td, Tx, Ttd, no, nv, ca, cb);
     HIP_CHECK(hipGetLastError());
 }
 
