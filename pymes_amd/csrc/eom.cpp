@@ -292,8 +292,9 @@ void EomSigma::doubles(const double* u1, const double* u2, bool u2_sym, double* 
         // exchange-symmetric u2: utd = 2 u2d - u2x as matrices, hence M1.utd + M2.u2d + M_C.u2x = (2 M1 + M2).utd / 2 +
         // (M_D - Ud).u2x / 2, and the second product IS Dx (the C / D form of the ring terms): TWO (ov)^3 products per sigma
         q.C(1.0, P4(MDU), "ajdl", P4(u2x), "dlbi", 0.0, P4(Dx), "ajbi");                       // :372 and :364 (transposed)
-        q.P(0.5, P4(Dx), "ajbi", 0.0, P4(Dd), "ajbi");                                         // same memory layout as "aibj"
-        q.C(0.5, P4(M12), "aidl", P4(utd), "dlbj", 1.0, P4(Dd), "aibj");
+        // Dd also carries Dx / 2 in the direct placement: the fused assembly reads Dx there itself (xd), else a scaled copy
+        if (!fused_ok) q.P(0.5, P4(Dx), "ajbi", 0.0, P4(Dd), "ajbi");                          // same memory layout as "aibj"
+        q.C(0.5, P4(M12), "aidl", P4(utd), "dlbj", fused_ok ? 0.0 : 1.0, P4(Dd), "aibj");
     } else if (!kstack) {
         q.C(1.0, P4(M1), "aidl", P4(utd), "dlbj", 0.0, P4(Dd), "aibj");
         q.C(1.0, P4(M2), "aidl", P4(u2d), "dlbj", 1.0, P4(Dd), "aibj");
@@ -353,12 +354,12 @@ void EomSigma::doubles(const double* u1, const double* u2, bool u2_sym, double* 
         // symmetrisation (:377) of D and of the two pair matrices and the unpacking of L in ONE pass (the assembly kernel of
         // the CCSD residual)
         packed_terms();
-        dev::residual_assemble(nullptr, L, Dp, Dd, Dx, s2, no, nv, e.stream);
+        dev::residual_assemble(nullptr, L, Dp, Dd, Dx, s2, no, nv, e.stream, 0.5);
         return;
     }
     // ---- P(ijab, jiba) (:377), then the unpermuted terms (:380-383) ------------------------------------------------------------
     if (fused_ok) {                    // D + P D and the two pair matrices with their transposes in one pass, into the result
-        dev::residual_assemble(nullptr, nullptr, Dp, Dd, Dx, s2, no, nv, e.stream);
+        dev::residual_assemble(nullptr, nullptr, Dp, Dd, Dx, s2, no, nv, e.stream, u2_sym ? 0.5 : 0.0);
         Dp = s2;
         D = mv(Dp, {v, v, o, o});
     } else {
@@ -483,8 +484,8 @@ void EomSigma::stack(int k, const double* const* u1, const double* const* u2, do
     Tmp DxT(*this, K * ov2), DdT(*this, K * ov2);
     const TView DxTv = mv(DxT, {K, v, o, v, o}), DdTv = mv(DdT, {K, v, o, v, o});
     q.C(1.0, Xv, "zajdl", mv(MDU, {v, o, v, o}), "bidl", 0.0, DxTv, "zajbi");          // (MDU . u2x)^T per vector
-    q.P(0.5, DxTv, "zajbi", 0.0, DdTv, "zajbi");                                        // same memory layout as "zaibj"
-    q.C(0.5, Ttv, "zaidl", mv(M12, {v, o, v, o}), "bjdl", 1.0, DdTv, "zaibj");
+    // (DdT also carries DxT / 2 in the direct placement: the assembly below reads DxT there itself, xd = 0.5 — no scaled copy)
+    q.C(0.5, Ttv, "zaidl", mv(M12, {v, o, v, o}), "bjdl", 0.0, DdTv, "zaibj");
     // ---- one-index dressings -------------------------------------------------------------------------------------------------------
     Tmp Xoo(*this, K * o * o), Xvv(*this, K * v * v);
     const TView XooV = mv(Xoo, {K, o, o}), XvvV = mv(Xvv, {K, v, v}), FOV = mv(fov, {o, v});
@@ -529,7 +530,7 @@ void EomSigma::stack(int k, const double* const* u1, const double* const* u2, do
     e.hole_ladder_packed_multi(ts.data(), b5p.data(), u2, k, Lall);                    // :381 (+ the symmetrised u1 term)
     for (int z = 0; z < k; ++z) {
         dev::residual_assemble(nullptr, Lall.p + z * npp * o * o, D.p + z * v * v * o * o, DdT.p + z * ov2, DxT.p + z * ov2, s2[z],
-                               no, nv, e.stream);                                       // :377 + unpacking
+                               no, nv, e.stream, 0.5);                                  // :377 + unpacking
         dev::memcpy_d2d(s1[z], S1.p + z * v * o, sizeof(double) * v * o, e.stream);
     }
 }

@@ -3552,7 +3552,9 @@ void gemm(const Gemm& g, stream_t s) {
     // once from HBM and nothing is reused across tiles — 64x64 blocks (more of them resident, more loads in flight) move
     // 13-18 % more bytes per second than the wider tiles (tools/probe_stream.py)
     bool stream = false;
-    if (g.K <= 256 && std::min(g.M, g.N) <= 256) { BM = 64; BN = 64; stream = true; }
+    // (min side up to 512: the stacked EOM build's [X_vv | u1] . [T ; A346] — M = k nv = 480, K = nv + nocc = 150, 0.4 GB written — ran
+    // 128 x 128 tiles with ten k-steps each at a quarter of the HBM rate)
+    if (g.K <= 256 && std::min(g.M, g.N) <= 512) { BM = 64; BN = 64; stream = true; }
     // ... and the tiny outputs contracted over a huge K (singles residual: 200 x 50 over o v^2 = 2e6), k-split over the chip
     if (g.M <= 256 && g.N <= 256 && g.K >= 65536 && BM == 64 && BN == 64) stream = true;
     // a streaming shape whose skinny side is at most 32 (nocc = 20 against 64-wide tiles: two thirds of the MFMA work on

@@ -25,16 +25,17 @@ for z in range(k):
     u2s.append(ctx.array(h + h.transpose(1, 0, 3, 2)))
 syms = [True] * k
 gc.disable()
-for _ in range(2):
+reps = int(os.environ.get("REPS", 3))
+for _ in range(max(2, reps // 2)):
     out = sig.apply_many(u1s, u2s, syms)
     del out
 ctx.sync()
 t0 = time.perf_counter()
-for _ in range(3):
+for _ in range(reps):
     out = sig.apply_many(u1s, u2s, syms)
     del out
 ctx.sync()
-print("ms per vector", 1e3 * (time.perf_counter() - t0) / 3 / k)
+print("ms per vector", 1e3 * (time.perf_counter() - t0) / reps / k)
 ctx.prof_enable(True); ctx.prof_reset(); ctx.stats(reset=True)
 t0 = time.perf_counter(); out = sig.apply_many(u1s, u2s, syms); ctx.sync(); dt = time.perf_counter() - t0
 print("build s (events on)", dt, ctx.prof_query(), ctx.stats())
