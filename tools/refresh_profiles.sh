@@ -38,5 +38,10 @@ step trace2 rocprofv3 --kernel-trace -d $out/tr2 -o run --output-format csv -- p
 python3 tools/trace_order.py $(find $out/tr2 -name "run_kernel_trace.csv") 8 > $out/bench_c2_dispatch_order.txt; rm -rf $out/tr2
 step clock rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d $out/pmc -o run --output-format csv -- python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-other-configs --events timed > $out/clock.log 2>&1
 python3 tools/dispatch_clock.py $(find $out/pmc -name "run_counter_collection.csv") 400 > $out/bench_c3_dispatch_clock.txt; rm -rf $out/pmc
+# forced one-rank RCCL runs (the collective table on a real communicator) and the EOM traces
+PYMES_FORCE_SHARDED=1 step forced_c2 python3 bench.py --gpus 1 --nocc 20 --nvirt 80 --steps 5 --warmup 3 --no-cpu-baseline --no-other-configs > $out/forced_one_rank_rccl_c2.json 2>/dev/null
+PYMES_FORCE_SHARDED=1 step forced_c3 python3 bench.py --gpus 1 --steps 5 --warmup 3 --no-cpu-baseline --no-other-configs > $out/forced_one_rank_rccl.json 2>/dev/null
+step eom_trace bash tools/trace_eom_many.sh > $out/trace_eom_many.log 2>&1
+step gsig_trace bash tools/trace_general_sigma.sh > $out/trace_general_sigma.log 2>&1
 rm -rf gpurun_out/prof_c3/stats gpurun_out/prof_c3/pmc_* gpurun_out/prof_c2/stats gpurun_out/prof_c2/pmc_*
 echo done
