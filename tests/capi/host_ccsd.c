@@ -4,20 +4,28 @@
  * integral file, load it, run the CCSD / DCSD fixed point of pymes/solver/ccsd.py:159-209 (is_diis = False) pass by pass and
  * print the energies.  Two forms, same numbers:
  *   mode 0  one rank: pymes_ccsd_iterate (residuals, update, energies: one call per pass)
- *   mode 1  the one-process-per-GPU steps with a collective table (pymes_set_collectives) in a world of ONE rank — the
- *           callbacks a real host fills with ncclAllReduce / ncclAllGather have nothing to exchange here:
+ *   mode 1  the one-process-per-GPU steps with a collective table (pymes_set_collectives) in a world of ONE rank whose
+ *           callbacks have nothing to exchange:
  *           pymes_ccsd_sharded_residuals -> pymes_cc_update / pymes_cc_update_pairs -> pymes_ccsd_sharded_finish ->
  *           pymes_ccsd_sharded_energy, the replicated T2 completed by the next residuals call / pymes_ccsd_sharded_await
+ *   mode 2  (built with -DWITH_RCCL) the same steps with the table of INTEGRATION.md 2b: ncclAllReduce / ncclAllGather on an
+ *           RCCL communicator and a communication stream of the host's own, ordered against the library's stream through
+ *           events — the code a multi-GPU host runs unchanged with its rank and world (here: a communicator of one rank,
+ *           all a one-GPU test box can hold)
  * tests/test_capi_host.py compiles it with gcc (CPU: compiles and links against the library's symbols; GPU: runs it on
  * tests/golden-sized synthetic factors and compares every pass with the Python host and the oracle).
  *
- *   host_ccsd <packed file (kind 2: factors)> <passes> <dcsd 0|1> <mode 0|1>
+ *   host_ccsd <packed file (kind 2: factors)> <passes> <dcsd 0|1> <mode 0|1|2>
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include "pymes_amd.h"
+#ifdef WITH_RCCL
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#endif
 
 #define CHECK(call)                                                                      \
     do {                                                                                 \
@@ -45,6 +53,68 @@ static int one_rank_wait(void* user, int64_t ticket, void* stream) {
     return 0;
 }
 
+#ifdef WITH_RCCL
+/* The table over RCCL.  A collective is ordered behind the work already enqueued on the library's stream by an event that the
+ * communication stream waits for; its completion is another event that `wait` makes the library's stream wait for.  Tickets
+ * index a ring of event pairs (at most a dozen tickets are alive at a time). */
+#define RING 64
+typedef struct {
+    ncclComm_t comm;
+    hipStream_t cs;
+    hipEvent_t before[RING], done[RING];
+    int64_t next;
+    int rank;
+} rccl_host;
+static int rccl_order(rccl_host* h, void* stream, int64_t* ticket) {
+    const int64_t t = h->next++;
+    if (hipEventRecord(h->before[t % RING], (hipStream_t)stream) != hipSuccess) return 1;
+    if (hipStreamWaitEvent(h->cs, h->before[t % RING], 0) != hipSuccess) return 1;
+    *ticket = t;
+    return 0;
+}
+static int rccl_allreduce(void* user, double* buf, int64_t n, void* stream, int64_t* ticket) {
+    rccl_host* h = (rccl_host*)user;
+    if (rccl_order(h, stream, ticket)) return 1;
+    if (ncclAllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, h->comm, h->cs) != ncclSuccess) return 2;
+    ++calls[0];
+    return hipEventRecord(h->done[*ticket % RING], h->cs) != hipSuccess;
+}
+static int rccl_allgather(void* user, double* buf, int64_t chunk, void* stream, int64_t* ticket) {
+    rccl_host* h = (rccl_host*)user;
+    if (rccl_order(h, stream, ticket)) return 1;
+    /* in place: this rank's chunk already sits at its position in the receive buffer */
+    if (ncclAllGather(buf + (int64_t)h->rank * chunk, buf, (size_t)chunk, ncclDouble, h->comm, h->cs) != ncclSuccess) return 2;
+    ++calls[1];
+    return hipEventRecord(h->done[*ticket % RING], h->cs) != hipSuccess;
+}
+static int rccl_wait(void* user, int64_t ticket, void* stream) {
+    rccl_host* h = (rccl_host*)user;
+    ++calls[2];
+    return hipStreamWaitEvent((hipStream_t)stream, h->done[ticket % RING], 0) != hipSuccess;
+}
+static int rccl_open(rccl_host* h) {
+    int dev = 0;
+    memset(h, 0, sizeof *h);
+    if (hipSetDevice(0) != hipSuccess) return 1;
+    if (ncclCommInitAll(&h->comm, 1, &dev) != ncclSuccess) return 2;       /* a multi-GPU host: ncclCommInitRank(rank, world, id) */
+    if (hipStreamCreateWithFlags(&h->cs, hipStreamNonBlocking) != hipSuccess) return 3;
+    for (int i = 0; i < RING; ++i)
+        if (hipEventCreateWithFlags(&h->before[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->done[i], hipEventDisableTiming) != hipSuccess)
+            return 4;
+    return 0;
+}
+static void rccl_close(rccl_host* h) {
+    (void)hipStreamSynchronize(h->cs);
+    for (int i = 0; i < RING; ++i) {
+        (void)hipEventDestroy(h->before[i]);
+        (void)hipEventDestroy(h->done[i]);
+    }
+    (void)hipStreamDestroy(h->cs);
+    (void)ncclCommDestroy(h->comm);
+}
+#endif
+
 static double* dev_doubles(pymes_ctx* ctx, int64_t n) {
     void* p = NULL;
     if (pymes_malloc(ctx, (uint64_t)n * sizeof(double), &p) != 0 || pymes_memset_zero(ctx, p, (uint64_t)n * sizeof(double)) != 0) {
@@ -56,7 +126,7 @@ static double* dev_doubles(pymes_ctx* ctx, int64_t n) {
 
 int main(int argc, char** argv) {
     if (argc != 5) {
-        fprintf(stderr, "usage: %s <packed factors file> <passes> <dcsd 0|1> <mode 0|1>\n", argv[0]);
+        fprintf(stderr, "usage: %s <packed factors file> <passes> <dcsd 0|1> <mode 0|1|2>\n", argv[0]);
         return 2;
     }
     const char* path = argv[1];
@@ -102,6 +172,25 @@ int main(int argc, char** argv) {
         table.allreduce_start = one_rank_allreduce;
         table.allgather_start = one_rank_allgather;
         table.wait = one_rank_wait;
+#ifdef WITH_RCCL
+        rccl_host rh;
+        if (mode == 2) {
+            const int rc = rccl_open(&rh);
+            if (rc != 0) {
+                fprintf(stderr, "RCCL set-up failed at step %d\n", rc);
+                return 1;
+            }
+            table.user = &rh;
+            table.allreduce_start = rccl_allreduce;
+            table.allgather_start = rccl_allgather;
+            table.wait = rccl_wait;
+        }
+#else
+        if (mode == 2) {
+            fprintf(stderr, "mode 2 needs a build with -DWITH_RCCL\n");
+            return 2;
+        }
+#endif
         CHECK(pymes_set_collectives(ctx, &table));
         int64_t sz[10];
         CHECK(pymes_shard_buffer_sizes(ctx, 1, sz));
@@ -124,6 +213,12 @@ int main(int argc, char** argv) {
         CHECK(pymes_ccsd_sharded_await(ctx, t2, &bufs));
         printf("collectives allreduce %d allgather %d wait %d\n", calls[0], calls[1], calls[2]);
         CHECK(pymes_set_collectives(ctx, NULL));
+#ifdef WITH_RCCL
+        if (mode == 2) {
+            CHECK(pymes_ctx_sync(ctx));
+            rccl_close(&rh);
+        }
+#endif
     }
     /* a checksum of the amplitudes, from the host copy */
     double* t2h = (double*)malloc(sizeof(double) * (size_t)nt2);

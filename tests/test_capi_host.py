@@ -18,11 +18,18 @@ SRC = os.path.join(ROOT, "tests", "capi", "host_ccsd.c")
 LIBDIR = os.path.join(ROOT, "pymes_amd", "lib")
 
 
-def build(out):
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+
+
+def build(out, rccl=False):
     # (-rpath: the program finds the in-tree library; the HIP runtime it needs is found through the library's own RUNPATH /
     # the system's ROCm installation; unresolved symbols of that runtime do not concern the host program)
     cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"), SRC,
            "-L", LIBDIR, "-lpymes_amd", "-Wl,-rpath," + LIBDIR, "-Wl,--allow-shlib-undefined", "-o", out]
+    if rccl:     # the RCCL table of INTEGRATION.md 2b: HIP runtime API + RCCL from the host program itself
+        # (HIP's and RCCL's own headers are not pedantic C99: system headers, not ours)
+        cmd += ["-DWITH_RCCL", "-D__HIP_PLATFORM_AMD__", "-isystem", os.path.join(ROCM, "include"), "-L", os.path.join(ROCM, "lib"),
+                "-lrccl", "-lamdhip64", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return out
@@ -35,6 +42,8 @@ def test_header_is_c99_and_host_program_links(tmp_path):
                         os.path.join(ROOT, "include", "pymes_amd.h")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     exe = build(str(tmp_path / "host_ccsd"))
+    if os.path.exists(os.path.join(ROCM, "include", "rccl", "rccl.h")):
+        build(str(tmp_path / "host_ccsd_rccl"), rccl=True)              # the RCCL table compiles and links too
     # every pymes_* symbol the program uses is one the header declares and the library exports (no GPU here: not run)
     used = subprocess.run(["nm", "-u", exe], capture_output=True, text=True).stdout
     used = {ln.split()[-1].split("@")[0] for ln in used.splitlines() if " pymes_" in ln or ln.strip().startswith("U pymes_")}
@@ -68,13 +77,16 @@ def test_c_host_runs_the_fixed_point(gpu_lib, tmp_path, dcsd):
     f, V, B, eps = synthetic_case(no, nv, seed=0, scale=0.3)
     path = str(tmp_path / "factors.pk")
     packed.write_factors(path, 2 * no, 0.0, eps, np.diag(eps), B)
-    exe = build(str(tmp_path / "host_ccsd"))
+    exe = build(str(tmp_path / "host_ccsd_rccl"), rccl=True)
     runs = []
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         r = subprocess.run([exe, path, str(passes), str(int(dcsd)), str(mode)], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr + r.stdout
         runs.append(lines_of(r.stdout))
-    plain, hooked = runs
+    plain, hooked, rccl = runs
+    # the RCCL table (real ncclAllReduce / ncclAllGather on a communicator of one rank, event-ordered against the library's
+    # stream) gives the numbers of the table that exchanges nothing, bit for bit
+    assert rccl == hooked
     # the Python host on the same library, same sequence
     ctx = Context(no, nv, lib=gpu_lib)
     try:
