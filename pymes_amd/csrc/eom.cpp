@@ -132,13 +132,15 @@ EomSigma::EomSigma(Engine& eng, const double* f_host, const double* t2, bool dre
             MDU = keep(ov2);
             const TView Tdv = mv(Td, {v, o, v, o}), Txv = mv(Tx, {v, o, v, o});
             {
-                Tmp M_A(*this, ov2), M_B(*this, ov2);
-                q.C(1.0, Tdv, "ckai", mv(Vd, {v, o, v, o}), "ckdl", 0.0, mv(M_A, {v, o, v, o}), "aidl");   // sum_kc V[k,l,c,d] T[c,a,k,i]
-                q.C(1.0, Txv, "aick", mv(Vd, {v, o, v, o}), "ckdl", 0.0, mv(M_B, {v, o, v, o}), "aidl");   // sum_kc V[k,l,c,d] T[a,c,k,i]
+                // M1 = Wd' + 2 M_A - M_B with M_A = sum_kc V[k,l,c,d] T[c,a,k,i], M_B = sum_kc V[k,l,c,d] T[a,c,k,i]: the two share
+                // their right operand, so the left ones are combined first — ONE (ov)^3 product instead of two
+                Tmp TAB(*this, ov2);
+                q.P(2.0, Tdv, "ckai", 0.0, mv(TAB, {v, o, v, o}), "aick");       // 2 T[c,a,k,i] - T[a,c,k,i] as [(a,i),(c,k)]
+                q.P(-1.0, Txv, "aick", 1.0, mv(TAB, {v, o, v, o}), "aick");
+                q.P(1.0, Viabj, "kaci", 0.0, mv(M1, {v, o, v, o}), "aick");      // Wd'[(a,i),(c,k)] = V_iabj[k,a,c,i]
+                q.C(1.0, mv(TAB, {v, o, v, o}), "aick", mv(Vd, {v, o, v, o}), "ckdl", 1.0, mv(M1, {v, o, v, o}), "aidl");
                 q.C(1.0, Tdv, "ckai", mv(Vx, {v, o, v, o}), "dlck", 0.0, mv(M_C, {v, o, v, o}), "aidl");   // sum_kc V[k,l,d,c] T[c,a,k,i]
                 q.C(1.0, Txv, "aick", mv(Vx, {v, o, v, o}), "dlck", 0.0, mv(M_D, {v, o, v, o}), "aidl");   // sum_kc V[k,l,d,c] T[a,c,k,i]
-                q.P(1.0, Viabj, "kaci", 0.0, mv(M1, {v, o, v, o}), "aick");      // Wd'[(a,i),(c,k)] = V_iabj[k,a,c,i]
-                q.L(M1, {M1, M_A, M_B}, {1.0, 2.0, -1.0}, ov2);
             }
             q.P(1.0, Viajb, "kaic", 0.0, mv(Ud, {v, o, v, o}), "aick");          // Ud[(a,i),(c,k)] = V_iajb[k,a,i,c]
             q.L(M2, {M_D, M_C, Ud}, {1.0, -2.0, -1.0}, ov2);
@@ -150,8 +152,14 @@ EomSigma::EomSigma(Engine& eng, const double* f_host, const double* t2, bool dre
         //   WA[a,d,b,j] = sum_ck (2 V[k,a,c,d] - V[k,a,d,c]) T[c,b,k,j] - V[k,a,c,d] T[b,c,k,j],   W3[a,d,b,i] = sum_ck V[k,a,d,c] T[b,c,k,i]
         WA = keep(v * v * v * o);
         W3 = keep(v * v * v * o);
-        q.C(2.0, Viabc, "kacd", T4, "cbkj", 0.0, mv(WA, {v, v, v, o}), "adbj");
-        q.C(-1.0, Viabc, "kadc", T4, "cbkj", 1.0, mv(WA, {v, v, v, o}), "adbj");
+        {
+            // (the first two terms share T[c,b,k,j]: 2 V[k,a,c,d] - V[k,a,d,c] is formed once — one o v^3 (ov) product less)
+            Tmp Vt(*this, o * v * v * v);
+            const TView VtV = mv(Vt, {o, v, v, v});
+            q.P(2.0, Viabc, "kacd", 0.0, VtV, "kacd");
+            q.P(-1.0, Viabc, "kadc", 1.0, VtV, "kacd");
+            q.C(1.0, VtV, "kacd", T4, "cbkj", 0.0, mv(WA, {v, v, v, o}), "adbj");
+        }
         q.C(-1.0, Viabc, "kacd", T4, "bckj", 1.0, mv(WA, {v, v, v, o}), "adbj");
         q.C(1.0, Viabc, "kadc", T4, "bcki", 0.0, mv(W3, {v, v, v, o}), "adbi");
         // ... merged: everything added to D is symmetrised by P(ijab,jiba) afterwards (:377), so a term X_abij may be replaced by
