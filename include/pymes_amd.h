@@ -46,6 +46,11 @@ int pymes_malloc(pymes_ctx* ctx, uint64_t bytes, void** dev_ptr);
 int pymes_free(pymes_ctx* ctx, void* dev_ptr);
 int pymes_live_allocations(int64_t* n);          /* device allocations of this library not yet released (leak tests) */
 int pymes_mem_info(pymes_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);   /* hipMemGetInfo of the context's device */
+/* Number of T1 dressings the context's dressed blocks have seen: every get_T1_dressed_V-shaped call (pymes_ccsd_dress_V,
+ * _slab), every pymes_ccsd_residuals / _iterate / _sharded_residuals with T1 != 0 and every replay of a recorded graph that
+ * contains one.  A holder of dressed blocks (ccsd.py:290-421 hands out a dictionary; here the blocks stay in the context)
+ * remembers the value and refuses to read blocks that have been dressed again since. */
+int pymes_dress_generation(pymes_ctx* ctx, uint64_t* n);
 
 /* ---- launch graphs (hipGraph): the loop body of a small, launch-bound solve is recorded once and replayed.
  * Between begin and end the context's entry points only RECORD their kernels (nothing executes, nothing may

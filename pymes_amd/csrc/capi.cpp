@@ -129,6 +129,12 @@ int pymes_mem_info(pymes_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes) 
         if (total_bytes) *total_bytes = dev::mem_total_bytes();
     });
 }
+int pymes_dress_generation(pymes_ctx* ctx, uint64_t* n) {
+    return guarded([&] {
+        if (!n) throw pymes::Error("null output");
+        *n = E(ctx).dress_generation();
+    });
+}
 int pymes_graph_begin(pymes_ctx* ctx) {
     return guarded([&] { E(ctx).graph_begin(); });
 }

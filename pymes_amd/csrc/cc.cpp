@@ -1407,6 +1407,7 @@ void Engine::dressed_into(int pattern, const std::vector<int>& pos, int k, const
 }
 
 void Engine::dress_V(const double* t1, uint32_t mask, const int64_t* cut) {
+    ++dress_generation_;
     TView t = make_view(const_cast<double*>(t1), {(int64_t)nv, (int64_t)no});
     for (int axis = 0; axis < 2 && cut; ++axis)
         if (cut[2 * axis] < 0 || cut[2 * axis + 1] > nv || cut[2 * axis] > cut[2 * axis + 1]) throw Error("dress_V: bad index range");

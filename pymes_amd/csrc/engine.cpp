@@ -198,6 +198,7 @@ void Engine::graph_begin() {
     if (!dev::graphs_supported()) throw Error("launch graphs are not supported by this backend");
     dev::graph_begin(stream);
     capturing_ = true;
+    capture_generation_ = dress_generation_;
 }
 dev::graph_t Engine::graph_end() {
     if (!capturing_) throw Error("graph_end: not recording");
@@ -210,6 +211,7 @@ dev::graph_t Engine::graph_end() {
         throw;
     }
     graphs_.insert(g);
+    if (dress_generation_ != capture_generation_) graphs_dressing_.insert(g);
     return g;
 }
 void Engine::graph_abort() {
@@ -219,6 +221,7 @@ void Engine::graph_abort() {
 }
 void Engine::graph_launch(dev::graph_t g) {
     if (!graphs_.count(g)) throw Error("graph_launch: unknown graph");
+    if (graphs_dressing_.count(g)) ++dress_generation_;
     dev::graph_launch(g, stream);
 }
 void Engine::graph_destroy(dev::graph_t g) {
@@ -227,6 +230,7 @@ void Engine::graph_destroy(dev::graph_t g) {
     dev::stream_sync(stream);
     dev::graph_destroy(g);
     graphs_.erase(it);
+    graphs_dressing_.erase(g);
 }
 
 void Engine::exchange_asymmetry_V(double out[2]) {

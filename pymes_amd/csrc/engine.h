@@ -116,6 +116,10 @@ class Engine {
     void graph_launch(dev::graph_t g);
     void graph_destroy(dev::graph_t g);
     bool capturing() const { return capturing_; }
+    // Counts the dressings of the context's dressed blocks (every Engine::dress_V, wherever it is called from — also inside
+    // ccsd_residuals / ccsd_sharded_residuals — and every replay of a recorded graph that contains one): holders of an
+    // earlier dressing (the host's DressedDeviceIntegrals) compare (pymes_dress_generation).
+    uint64_t dress_generation() const { return dress_generation_; }
     // max |V_pqrs - V_qpsr| over all blocks that are set (infinity if a block's exchange partner is missing) and max |V|
     void exchange_asymmetry_V(double out[2]);
 
@@ -303,7 +307,9 @@ class Engine {
     std::multimap<int64_t, double*> scratch_free_;
     std::map<double*, int64_t> scratch_live_;
     std::set<dev::graph_t> graphs_;
+    std::set<dev::graph_t> graphs_dressing_;     // recorded graphs whose replay dresses V again
     bool capturing_ = false;
+    uint64_t dress_generation_ = 0, capture_generation_ = 0;
     double* V_[16] = {nullptr};      // undressed blocks (owned)
     double* Vd_[16] = {nullptr};     // dressed blocks (owned, allocated on demand)
     std::map<std::string, double*> static_;   // cached permutations of static blocks (owned)

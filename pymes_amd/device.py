@@ -326,6 +326,15 @@ class Context:
         assert eo.shape == (self.no,) and ev.shape == (self.nv,)
         self.lib.call("pymes_set_orbital_energies", self.handle, _lib.host_ptr(eo), _lib.host_ptr(ev))
 
+    @property
+    def dress_generation(self):
+        """How often the context's dressed blocks have been (re)written — counted by the engine itself, so that the
+        dressings inside ``pymes_ccsd_residuals`` / ``_iterate`` / ``_sharded_residuals`` and replayed launch graphs are
+        seen too; ``DressedDeviceIntegrals.require`` compares."""
+        n = C.c_uint64()
+        self.lib.call("pymes_dress_generation", self.handle, C.byref(n))
+        return int(n.value)
+
     # ---- CC hot path ----------------------------------------------------------------
     def mp2(self, t2, level_shift=0.0):
         e = (C.c_double * 2)()
@@ -343,8 +352,6 @@ class Context:
         mask = _lib.PYMES_DRESS_ABIJ_REDUCED if reduced_abij else 0
         for nm in names:
             mask |= 1 << pattern_of(nm)
-        # every dressing overwrites the context's dressed blocks: holders of an earlier set (DressedDeviceIntegrals) compare
-        self.dress_generation = getattr(self, "dress_generation", 0) + 1
         if q_range is not None or p_range is not None:
             p0, p1 = p_range if p_range is not None else (0, 0)
             q0, q1 = q_range if q_range is not None else (0, 0)

@@ -142,6 +142,14 @@ def check_dressed_handover(lib, monkeypatch):
         cc.get_T1_dressed_V(res["t1"], ints, {"klij": None})            # a later dressing on the same context ...
         with pytest.raises(RuntimeError, match="stale"):
             quiet(eom.solve, fd, full, res["t2"])                       # ... invalidates the earlier hand-over
+        # ... and so does a CCSD solve on the same DeviceIntegrals: its loop body dresses V_klij / V_iajb / V_iabj INSIDE the
+        # library (pymes_ccsd_residuals, recorded and replayed as a launch graph) — the engine counts those too
+        full = cc.get_T1_dressed_V(res["t1"], ints)
+        quiet(eom.solve, fd, full, res["t2"])
+        f2 = f + np.diag(np.linspace(0.0, 0.05, no + nv))
+        quiet(CCSD(no, delta_e=1e-9).solve, f2, ints, device_amplitudes=True)
+        with pytest.raises(RuntimeError, match="stale"):
+            quiet(eom.solve, fd, full, res["t2"])
     finally:
         ints.ctx.close()
 
