@@ -133,6 +133,7 @@ C2_GOLDEN = {"e": -0.40137558021086484, "iterations": 9, "delta_e": 1e-10}      
 C4_GOLDEN = {"dcsd": -0.4181690961120107, "passes": 22, "k_cutoff": 1.436091003782944}   # tests/golden/ueg.json["tc_N14_rs1.0_c5"]
 # (30,120) Davidson: no reference run exists at this size (the reference would take days); the literals are THIS engine's values
 # of round 4 (profiles/r04/configs_c2_c4_c5.jsonl) — a regression check; the driver is reference-pinned at (12,48) and (20,80)
+C5_RITZ_TOL = 2e-4        # relative residual of a converged root at the driver's stopping test (measured: profiles/r06)
 C5_DAVIDSON = {"ccsd_e": -0.32983974045195175, "ee": [3.0060256332720243, 3.409850418963405, 3.8568464914371234], "passes": 26}
 
 
@@ -294,7 +295,14 @@ def other_configs(device=0):
         out["c5_davidson_ok"] = bool(abs(res["ccsd e"] - C5_DAVIDSON["ccsd_e"]) < 1e-9 and
                                      np.abs(np.asarray(ee) - np.asarray(C5_DAVIDSON["ee"])).max() < 1e-7 and
                                      eom.iterations == C5_DAVIDSON["passes"])
-        out["c5_davidson_golden"] = "this engine's round-4 values (no reference run at this size)"
+        out["c5_davidson_golden"] = "regression check: this engine's round-4 values (no reference run at this size)"
+        # PARITY at this size: the sigma build is pinned to the reference's own output (c5_ok above), so the converged roots
+        # are certified by it — Ritz vectors rebuilt, a fresh sigma applied once, |sigma r - e r| / |r| per root (outside the
+        # timed region; EOM_CCSD.ritz_residuals).  The driver stops at |dE| < 1e-8 (eom_ccsd.py:150), which leaves residuals
+        # of this size; a wrong root would give O(1).
+        rr = eom.ritz_residuals(fdd, Vd, res["t2"])
+        out["c5_davidson_ritz_residuals"] = rr
+        out["c5_davidson_certified"] = bool(max(rr) < C5_RITZ_TOL)
         ctx.close()
     finally:
         gc.enable()

@@ -52,6 +52,16 @@ int pymes_mem_info(pymes_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
  * remembers the value and refuses to read blocks that have been dressed again since. */
 int pymes_dress_generation(pymes_ctx* ctx, uint64_t* n);
 
+/* ---- phase launches.  The small kernels between two big products (a (20,80) iteration has ~60 of 5-35 us) are not launched
+ * one by one: inside the library they are recorded with the address ranges they read and write and launched level by level of
+ * their dependency graph, ONE grid per level carrying the blocks of all its tasks (a dependent launch costs 1.9 us on
+ * this chip, so the seams stay kernel boundaries and what goes is the serialisation of INDEPENDENT kernels).  Every entry point
+ * of this header leaves nothing recorded behind when it returns; results are the same as with immediate launches.
+ * pymes_phase_enable: 1 on, 0 off, -1 as the environment says (PYMES_PHASE=0 off, =serial one task per level; default on) — per
+ * calling thread.  pymes_phase_stats: tasks recorded / grids launched / levels / flushes by the calling thread so far. */
+int pymes_phase_enable(int mode);
+int pymes_phase_stats(int64_t* tasks, int64_t* launches, int64_t* levels, int64_t* flushes);
+
 /* ---- launch graphs (hipGraph): the loop body of a small, launch-bound solve is recorded once and replayed.
  * Between begin and end the context's entry points only RECORD their kernels (nothing executes, nothing may
  * synchronise: no pymes_dots / pymes_download / pymes_free); every pointer passed in is baked into the graph, so the

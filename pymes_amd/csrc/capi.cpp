@@ -30,13 +30,20 @@ thread_local std::string g_err;
 
 template <class F>
 int guarded(F&& f) {
+    // (what an entry point has recorded for the open phase — device_api.h, phase launches — is on the stream when it returns:
+    // the host program may order work of its own behind it)
     try {
         f();
+        dev::phase_sync();
         return 0;
     } catch (const std::exception& ex) {
         g_err = ex.what();
     } catch (...) {
         g_err = "unknown error";
+    }
+    try {
+        dev::phase_sync();
+    } catch (...) {
     }
     return 1;
 }
@@ -133,6 +140,19 @@ int pymes_dress_generation(pymes_ctx* ctx, uint64_t* n) {
     return guarded([&] {
         if (!n) throw pymes::Error("null output");
         *n = E(ctx).dress_generation();
+    });
+}
+int pymes_phase_enable(int mode) {
+    return guarded([&] { dev::phase_enable(mode); });
+}
+int pymes_phase_stats(int64_t* tasks, int64_t* launches, int64_t* levels, int64_t* flushes) {
+    return guarded([&] {
+        long t = 0, l = 0, v = 0, f = 0;
+        dev::phase_stats(&t, &l, &v, &f);
+        if (tasks) *tasks = t;
+        if (launches) *launches = l;
+        if (levels) *levels = v;
+        if (flushes) *flushes = f;
     });
 }
 int pymes_graph_begin(pymes_ctx* ctx) {

@@ -1595,6 +1595,7 @@ void Engine::set_collectives(const Collectives* c) {
         // a loop that was abandoned between finish and the next residuals: its last exchange is completed through the table
         // that started it (nobody reads the result) before that table goes
         t2_in_flight_ = false;
+        dev::phase_sync();
         if (coll_.wait(coll_.user, t2_ticket_, stream) != 0) throw Error("collective hook: wait failed");
     }
     if (!c) {
@@ -1615,22 +1616,26 @@ struct Hooks {
     void* stream;
     // (nothing of the library's own may still be queued when the host program orders a collective behind the stream)
     int64_t allreduce(double* buf, int64_t n) const {
-        dev::gemm_group_sync();
+        dev::phase_sync();
         int64_t t = 0;
         if (c.allreduce_start(c.user, buf, n, stream, &t) != 0) throw Error("collective hook: allreduce_start failed");
         return t;
     }
     int64_t allgather(double* buf, int64_t chunk) const {
-        dev::gemm_group_sync();
+        dev::phase_sync();
         int64_t t = 0;
         if (c.allgather_start(c.user, buf, chunk, stream, &t) != 0) throw Error("collective hook: allgather_start failed");
         return t;
     }
     void wait(int64_t ticket) const {
+        dev::phase_sync();
         if (c.wait(c.user, ticket, stream) != 0) throw Error("collective hook: wait failed");
     }
     void mark(const char* phase) const {
-        if (c.mark) c.mark(c.user, phase);
+        if (c.mark) {
+            dev::phase_sync();
+            c.mark(c.user, phase);
+        }
     }
 };
 int64_t chunk_of(int64_t n, int world) { return (n + world - 1) / world; }

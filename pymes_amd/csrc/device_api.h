@@ -103,6 +103,17 @@ void gemm_group_end();
 void gemm_group_sync();
 void gemm_group_stats(long* launches, long* products);    // grouped launches / queued products since the last begin
 
+// ---- phase launches (kernels.hip, phase_kernel).  Small operations of this interface — products, permutations,
+// the element-wise and reduction helpers below — are not launched one by one: they are recorded with the address ranges they
+// read and write, and launched level by level of their dependency graph, one grid per level carrying the blocks of all its
+// tasks.  Anything that is not recorded (a big product, a copy, a synchronisation, a graph boundary) launches the recorded
+// tasks first, so the order of effects is that of immediate execution.  phase_sync(): launch what is recorded now (the end of
+// every entry point of the C interface; before a collective of the host program).  phase_enable: 1 on, 0 off, -1 as the
+// environment says (PYMES_PHASE=0 off, =serial one task per level; default on).  No-ops in the host simulator.
+void phase_sync();
+void phase_enable(int mode);
+void phase_stats(long* tasks, long* launches, long* levels, long* flushes);     // counted per thread since its start
+
 // ---- strided copy / permutation:  out = alpha * in + beta * out ----------------
 // rank <= 6, both tensors described by the same extents and their own strides.
 struct Permute {

@@ -849,11 +849,8 @@ struct GemvTable {
     GemvItem it[kGemvBatchMax];
 };
 
-__global__ void __launch_bounds__(256) gemv_multi_cols_kernel(const GemvTable tab, double* __restrict__ ws) {
-    int i = 0;
-    while (i + 1 < tab.n && (int)blockIdx.x >= tab.it[i + 1].blk0) ++i;
-    const GemvItem& g = tab.it[i];
-    const int local = blockIdx.x - g.blk0, cb = local % g.cblocks, chunk = local / g.cblocks;
+__device__ __forceinline__ void gemv_cols_item(const GemvItem& g, const int local, double* __restrict__ ws) {
+    const int cb = local % g.cblocks, chunk = local / g.cblocks;
     const long c = ((long)cb * 256 + threadIdx.x) * g.vec;
     if (c >= g.C) return;
     const long r0 = (long)chunk * g.rchunk, r1 = min(g.R, r0 + g.rchunk);
@@ -886,12 +883,16 @@ __global__ void __launch_bounds__(256) gemv_multi_cols_kernel(const GemvTable ta
     p[0] = a0 + b0;
     if (g.vec == 2) p[1] = a1 + b1;
 }
-
-__global__ void __launch_bounds__(256) gemv_multi_finish_kernel(const GemvTable tab, const double* __restrict__ ws) {
+__global__ void __launch_bounds__(256) gemv_multi_cols_kernel(const GemvTable tab, double* __restrict__ ws) {
     int i = 0;
-    while (i + 1 < tab.n && (int)blockIdx.x >= tab.it[i + 1].out0) ++i;
-    const GemvItem& g = tab.it[i];
-    const long c = (long)(blockIdx.x - g.out0) * 256 + threadIdx.x;
+    while (i + 1 < tab.n && (int)blockIdx.x >= tab.it[i + 1].blk0) ++i;
+    gemv_cols_item(tab.it[i], blockIdx.x - tab.it[i].blk0, ws);
+}
+
+// (beta / yin: the phase tasks finish accumulating products too; the batch kernel passes beta = 0)
+__device__ __forceinline__ void gemv_finish_item(const GemvItem& g, const int local, const double* __restrict__ ws, const double beta,
+                                                 const double* yin) {
+    const long c = (long)local * 256 + threadIdx.x;
     if (c >= g.C) return;
     const double* __restrict__ part = ws + g.ws_off + c;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -903,13 +904,29 @@ __global__ void __launch_bounds__(256) gemv_multi_finish_kernel(const GemvTable 
         s3 += part[(long)(k + 3) * g.C];
     }
     for (; k < g.nchunk; ++k) s0 += part[(long)k * g.C];
-    g.y[c * g.ys] = g.alpha * ((s0 + s1) + (s2 + s3));
+    double v = g.alpha * ((s0 + s1) + (s2 + s3));
+    if (beta != 0.0) v += beta * yin[c * g.ys];
+    g.y[c * g.ys] = v;
 }
+__global__ void __launch_bounds__(256) gemv_multi_finish_kernel(const GemvTable tab, const double* __restrict__ ws) {
+    int i = 0;
+    while (i + 1 < tab.n && (int)blockIdx.x >= tab.it[i + 1].out0) ++i;
+    gemv_finish_item(tab.it[i], blockIdx.x - tab.it[i].out0, ws, 0.0, nullptr);
+}
+struct GemvRowsK {
+    const double* W; const double* x; const double* yin; double* y;
+    long ld, xs, R, C, ys;
+    double alpha, beta;
+};
 template <int VEC>
-__global__ void __launch_bounds__(256) gemv_rows_kernel(const double* __restrict__ W, long ld, const double* __restrict__ x,
-                                                        long xs, long R, long C, double alpha, double beta, const double* yin,
-                                                        double* y, long ys) {
-    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void gemv_rows_body(const GemvRowsK& k, const unsigned vb) {
+    const double* __restrict__ W = k.W;
+    const double* __restrict__ x = k.x;
+    const double* yin = k.yin;
+    double* y = k.y;
+    const long ld = k.ld, xs = k.xs, R = k.R, C = k.C, ys = k.ys;
+    const double alpha = k.alpha, beta = k.beta;
+    const long r = (long)vb * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
     const int lane = threadIdx.x & 63;
     const double* __restrict__ w = W + r * ld;
@@ -930,6 +947,8 @@ __global__ void __launch_bounds__(256) gemv_rows_kernel(const double* __restrict
         y[r * ys] = v;
     }
 }
+template <int VEC>
+__global__ void __launch_bounds__(256) gemv_rows_kernel(const GemvRowsK k) { gemv_rows_body<VEC>(k, blockIdx.x); }
 
 // ------------------------------------------------------------------------------------
 // permutation / strided copy
@@ -946,9 +965,11 @@ struct PermK {
 // generic: one element per thread and pass of the grid-stride loop, last (canonical) dim fastest.  The digits of the element
 // index advance by the digits of the grid stride with carries (a per-element decomposition is up to six 64-bit divisions:
 // the 0.8-GB permutations of (50,200) ran at 3.2-4 TB/s, VALU-bound)
-__global__ void permute_direct_kernel(const PermK p, long total) {
-    const long stride = (long)gridDim.x * blockDim.x;
-    long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+// (bodies take the block's id and the size of their grid as arguments: a block of a phase launch — phase_kernel below — runs
+// them for its task with ids of that task's own)
+__device__ __forceinline__ void permute_direct_body(const PermK& p, const long total, const unsigned vb, const unsigned vgrid) {
+    const long stride = (long)vgrid * blockDim.x;
+    long idx = vb * (long)blockDim.x + threadIdx.x;
     if (idx >= total) return;
     long c[6], sd[6];          // (64-bit: a merged dimension may exceed 2^31 elements)
     {
@@ -989,13 +1010,16 @@ __global__ void permute_direct_kernel(const PermK p, long total) {
         c[0] += sd[0] + carry;
     }
 }
+__global__ void permute_direct_kernel(const PermK p, long total) { permute_direct_body(p, total, blockIdx.x, gridDim.x); }
 
 // tiled transpose: canonical dims [rest..., Q, L] where in is unit-stride along Q
 // (dim index rank-2) and out is unit-stride along L (dim index rank-1).
-__global__ void __launch_bounds__(256) permute_tiled_kernel(const PermK p, int tiles_q, int tiles_l) {
-    __shared__ double tile[32][33];
+constexpr int kPermTileDoubles = 32 * 33;
+__device__ __forceinline__ void permute_tiled_body(const PermK& p, const int tiles_q, const int tiles_l, const unsigned vb,
+                                                   double* __restrict__ smem) {
+    double (*tile)[33] = reinterpret_cast<double (*)[33]>(smem);
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    long b = blockIdx.x;
+    long b = vb;
     const int tq = (int)(b % tiles_q);
     b /= tiles_q;
     const int tl = (int)(b % tiles_l);
@@ -1030,6 +1054,10 @@ __global__ void __launch_bounds__(256) permute_tiled_kernel(const PermK p, int t
             *o = v;
         }
     }
+}
+__global__ void __launch_bounds__(256) permute_tiled_kernel(const PermK p, int tiles_q, int tiles_l) {
+    __shared__ double tile[kPermTileDoubles];
+    permute_tiled_body(p, tiles_q, tiles_l, blockIdx.x, tile);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1077,11 +1105,24 @@ struct Walk4 {
     }
 };
 
-__global__ void cc_update_kernel(double* t, double* __restrict__ dt, const double* t_in, const double* __restrict__ r_,
-                                 const double* __restrict__ eo, const double* __restrict__ ev, double shift,
-                                 double delta, int no, int nv, int rank, long total) {
-    const long stride = (long)gridDim.x * blockDim.x;
-    long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+struct CcUpdateK {
+    double* t; double* dt; const double* t_in; const double* r; const double* eo; const double* ev;
+    double shift, delta;
+    int no, nv, rank;
+    long total;
+};
+__device__ __forceinline__ void cc_update_body(const CcUpdateK& k, const unsigned vb, const unsigned vgrid) {
+    double* t = k.t;
+    double* __restrict__ dt = k.dt;
+    const double* t_in = k.t_in;
+    const double* __restrict__ r_ = k.r;
+    const double* __restrict__ eo = k.eo;
+    const double* __restrict__ ev = k.ev;
+    const double shift = k.shift, delta = k.delta;
+    const int no = k.no, nv = k.nv, rank = k.rank;
+    const long total = k.total;
+    const long stride = (long)vgrid * blockDim.x;
+    long idx = vb * (long)blockDim.x + threadIdx.x;
     if (rank == 4) {
         Walk4 w(idx, stride, no, nv);
         for (; idx < total; idx += stride, w.step()) {
@@ -1102,6 +1143,7 @@ __global__ void cc_update_kernel(double* t, double* __restrict__ dt, const doubl
         }
     }
 }
+__global__ void cc_update_kernel(const CcUpdateK k) { cc_update_body(k, blockIdx.x, gridDim.x); }
 
 constexpr int kDotBlocks = 1024;
 struct DotPtrs {
@@ -1128,10 +1170,17 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
 // block -> (pair, chunk): the pairs of a DIIS / energy call mostly share one operand (the newest vector against the history), so the
 // blocks that read the same chunk are neighbours in dispatch order AND on the same XCD (ids 8 apart): the shared chunk comes
 // from HBM once and from that XCD's L2 for the other pairs (pair-major order re-reads it from HBM for every pair)
+struct DotsK {
+    DotPtrs p;
+    double* partial;
+    int nb, npairs;
+};
 template <int VEC>
-__global__ void __launch_bounds__(256) dots_stage1_kernel(const DotPtrs p, double* __restrict__ partial, int nb, int npairs) {
-    __shared__ double sh[4];
-    const int lin = blockIdx.x;
+__device__ __forceinline__ void dots_stage1_body(const DotsK& k, const unsigned vb, double* sh) {
+    const DotPtrs& p = k.p;
+    double* __restrict__ partial = k.partial;
+    const int nb = k.nb, npairs = k.npairs;
+    const int lin = vb;
     int pair, b;
     if ((nb & 7) == 0) { const int q = lin >> 3; pair = q % npairs; b = (q / npairs) * 8 + (lin & 7); }
     else { pair = lin / nb; b = lin - pair * nb; }
@@ -1160,14 +1209,27 @@ __global__ void __launch_bounds__(256) dots_stage1_kernel(const DotPtrs p, doubl
     s = block_sum(s, sh);
     if (threadIdx.x == 0) partial[pair * kDotBlocks + b] = s;
 }
+template <int VEC>
+__global__ void __launch_bounds__(256) dots_stage1_kernel(const DotsK k) {
+    __shared__ double sh[4];
+    dots_stage1_body<VEC>(k, blockIdx.x, sh);
+}
+struct Dots2K {
+    const double* partial;
+    double* out;
+    int nblocks;
+};
+__device__ __forceinline__ void dots_stage2_body(const Dots2K& k, const unsigned vb, double* sh) {
+    const int pair = vb;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < k.nblocks; i += blockDim.x) s += k.partial[pair * kDotBlocks + i];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) k.out[pair] = s;
+}
 __global__ void __launch_bounds__(256) dots_stage2_kernel(const double* __restrict__ partial, int nblocks,
                                                           double* __restrict__ out) {
     __shared__ double sh[4];
-    const int pair = blockIdx.x;
-    double s = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += partial[pair * kDotBlocks + i];
-    s = block_sum(s, sh);
-    if (threadIdx.x == 0) out[pair] = s;
+    dots_stage2_body(Dots2K{partial, out, nblocks}, blockIdx.x, sh);
 }
 
 // the small algebra of a DIIS step on the device: one thread (the matrices are at most 9 x 9), overlaps straight from
@@ -1338,16 +1400,27 @@ __global__ void lincomb_dev_kernel(double* __restrict__ out, const LinPtrsDev p,
 // The (a, b, i, j) digits of the element index advance by the digits of the grid stride with carries — four integer
 // divisions per ELEMENT made this kernel VALU-bound (0.75 ms for 3.2 GB at (50,200)); VEC = 2: 16-byte loads over j pairs
 // (nocc even: a pair never leaves its row).
+struct EnergyK {
+    const double *f, *t1, *t2, *Edir, *Eex, *dt2;
+    double* partial;
+    long total;
+    int no, nv;
+};
 template <int VEC>
-__global__ void __launch_bounds__(256) energy_norms_kernel(const double* __restrict__ f, const double* __restrict__ t1,
-                                                           const double* __restrict__ t2, const double* __restrict__ Edir,
-                                                           const double* __restrict__ Eex, const double* __restrict__ dt2,
-                                                           int no, int nv, long total, double* __restrict__ partial) {
-    __shared__ double sh[4];
+__device__ __forceinline__ void energy_norms_body(const EnergyK& k, const unsigned vb, const unsigned vgrid, double* sh) {
+    const double* __restrict__ f = k.f;
+    const double* __restrict__ t1 = k.t1;
+    const double* __restrict__ t2 = k.t2;
+    const double* __restrict__ Edir = k.Edir;
+    const double* __restrict__ Eex = k.Eex;
+    const double* __restrict__ dt2 = k.dt2;
+    double* __restrict__ partial = k.partial;
+    const int no = k.no, nv = k.nv;
+    const long total = k.total;
     double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s0 = 0.0, s5 = 0.0;
     const int noV = no / VEC;                       // j digit in units of VEC elements
-    const long nvecs = total / VEC, stride = (long)gridDim.x * blockDim.x;
-    long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const long nvecs = total / VEC, stride = (long)vgrid * blockDim.x;
+    long idx = vb * (long)blockDim.x + threadIdx.x;
     int j, i, b, a, sj, si, sb, sa;
     {
         long r = idx;
@@ -1395,7 +1468,7 @@ __global__ void __launch_bounds__(256) energy_norms_kernel(const double* __restr
     }
     if (t1 && f) {
         const long n = no + nv, ov = (long)no * nv;
-        for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < ov; e += (long)gridDim.x * blockDim.x) {
+        for (long e = vb * (long)blockDim.x + threadIdx.x; e < ov; e += (long)vgrid * blockDim.x) {
             const long a = e / no, i = e - a * no;
             const double y = t1[e];
             s0 += f[i * n + no + a] * y;
@@ -1405,13 +1478,18 @@ __global__ void __launch_bounds__(256) energy_norms_kernel(const double* __restr
     const double r0 = block_sum(s0, sh), r1 = block_sum(s1, sh), r2 = block_sum(s2, sh), r3 = block_sum(s3, sh),
                  r4 = block_sum(s4, sh), r5 = block_sum(s5, sh);
     if (threadIdx.x == 0) {
-        partial[5 * kDotBlocks + blockIdx.x] = r5;
-        partial[0 * kDotBlocks + blockIdx.x] = r0;
-        partial[1 * kDotBlocks + blockIdx.x] = r1;
-        partial[2 * kDotBlocks + blockIdx.x] = r2;
-        partial[3 * kDotBlocks + blockIdx.x] = r3;
-        partial[4 * kDotBlocks + blockIdx.x] = r4;
+        partial[5 * kDotBlocks + vb] = r5;
+        partial[0 * kDotBlocks + vb] = r0;
+        partial[1 * kDotBlocks + vb] = r1;
+        partial[2 * kDotBlocks + vb] = r2;
+        partial[3 * kDotBlocks + vb] = r3;
+        partial[4 * kDotBlocks + vb] = r4;
     }
+}
+template <int VEC>
+__global__ void __launch_bounds__(256) energy_norms_kernel(const EnergyK k) {
+    __shared__ double sh[4];
+    energy_norms_body<VEC>(k, blockIdx.x, gridDim.x, sh);
 }
 
 // out[0] = max |A[p,q,r,s] - B[q,p,s,r]|, out[1] = max(|A|, |B|) as bit patterns (non-negative doubles order like integers).
@@ -1497,13 +1575,22 @@ struct LinPtrs {
     const double* x[8];
     double c[8];
 };
-__global__ void lincomb_kernel(double* __restrict__ out, const LinPtrs p, int nx, long n) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+struct LinK {
+    double* out;
+    LinPtrs p;
+    long n;
+    int nx;
+};
+__device__ __forceinline__ void lincomb_body(const LinK& k, const unsigned vb, const unsigned vgrid) {
+    double* __restrict__ out = k.out;
+    const int nx = k.nx;
+    for (long i = vb * (long)blockDim.x + threadIdx.x; i < k.n; i += (long)vgrid * blockDim.x) {
         double s = 0.0;
-        for (int k = 0; k < nx; ++k) s += p.x[k][i] * p.c[k];
+        for (int q = 0; q < nx; ++q) s += k.p.x[q][i] * k.p.c[q];
         out[i] = s;
     }
 }
+__global__ void lincomb_kernel(const LinK k) { lincomb_body(k, blockIdx.x, gridDim.x); }
 
 // ---- tall-skinny subspace algebra of the Davidson / FEAST drivers (eom_ccsd.py:91-147, :512-541) -------------------------
 // The vectors are 13 M doubles at (30,120) and a pass needs their Gram blocks and a handful of linear combinations: one
@@ -1799,10 +1886,18 @@ __global__ void cshift_inv_kernel(const double* __restrict__ d, double zr, doubl
     }
 }
 
-__global__ void tau_kernel(double* __restrict__ tau, const double* __restrict__ t2, const double* __restrict__ t1,
-                           int no, int nv, long total) {
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long)gridDim.x * blockDim.x) {
+struct TauK {
+    double* tau; const double* t2; const double* t1;
+    long total;
+    int no, nv;
+};
+__device__ __forceinline__ void tau_body(const TauK& k, const unsigned vb, const unsigned vgrid) {
+    double* __restrict__ tau = k.tau;
+    const double* __restrict__ t2 = k.t2;
+    const double* __restrict__ t1 = k.t1;
+    const int no = k.no, nv = k.nv;
+    const long total = k.total;
+    for (long idx = vb * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)vgrid * blockDim.x) {
         long r = idx;
         const int j = (int)(r % no); r /= no;
         const int i = (int)(r % no); r /= no;
@@ -1811,6 +1906,7 @@ __global__ void tau_kernel(double* __restrict__ tau, const double* __restrict__ 
         tau[idx] = t2[idx] + t1[a * no + i] * t1[b * no + j];
     }
 }
+__global__ void tau_kernel(const TauK k) { tau_body(k, blockIdx.x, gridDim.x); }
 
 // ------------------------------------------------------------------------------------
 // symmetry-packed ladder helpers
@@ -2006,10 +2102,19 @@ __global__ void __launch_bounds__(64) ladder_dress_kernel(const double* __restri
     }
 }
 
-__global__ void ladder_pack_T_kernel(const double* __restrict__ T, const double* __restrict__ t1,
-                                     double* __restrict__ Sp, double* __restrict__ Am, int no, int nv, int flags,
-                                     long ldp, long ldm, long rp0) {
-    const long row = rp0 + blockIdx.x;   // P(c,d)
+struct PackTK {
+    const double* T; const double* t1; double* Sp; double* Am;
+    long ldp, ldm, rp0;
+    int no, nv, flags;
+};
+__device__ __forceinline__ void ladder_pack_T_body(const PackTK& k, const unsigned vb) {
+    const double* __restrict__ T = k.T;
+    const double* __restrict__ t1 = k.t1;
+    double* __restrict__ Sp = k.Sp;
+    double* __restrict__ Am = k.Am;
+    const int no = k.no, nv = k.nv, flags = k.flags;
+    const long ldp = k.ldp, ldm = k.ldm;
+    const long row = k.rp0 + vb;   // P(c,d)
     int c, d;
     unrank_pair(row, c, d);
     const bool row_half = flags & dev::PACK_ROW_HALF, prow = flags & dev::PACK_AM_PROWS,
@@ -2041,13 +2146,23 @@ __global__ void ladder_pack_T_kernel(const double* __restrict__ T, const double*
         }
     }
 }
+__global__ void ladder_pack_T_kernel(const PackTK k) { ladder_pack_T_body(k, blockIdx.x); }
 
 // L[P(a,b)][0:opp] = LS, L[P(a,b)][opp:opp+opm] = LA (rows of diagonal pairs carry zeros there)
-__global__ void ladder_unpack_kernel(const double* __restrict__ L, double* __restrict__ R, double beta, int no,
-                                     int nv, long total) {
+struct UnpackK {
+    const double* L; double* R;
+    double beta;
+    long total;
+    int no, nv;
+};
+__device__ __forceinline__ void ladder_unpack_body(const UnpackK& k, const unsigned vb, const unsigned vgrid) {
+    const double* __restrict__ L = k.L;
+    double* __restrict__ R = k.R;
+    const double beta = k.beta;
+    const int no = k.no, nv = k.nv;
+    const long total = k.total;
     const long opp = (long)no * (no + 1) / 2, ld = (long)no * no;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long)gridDim.x * blockDim.x) {
+    for (long idx = vb * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)vgrid * blockDim.x) {
         long r = idx;
         const int j = (int)(r % no); r /= no;
         const int i = (int)(r % no); r /= no;
@@ -2063,16 +2178,26 @@ __global__ void ladder_unpack_kernel(const double* __restrict__ L, double* __res
         R[idx] = (beta != 0.0) ? beta * R[idx] + v : v;
     }
 }
+__global__ void ladder_unpack_kernel(const UnpackK k) { ladder_unpack_body(k, blockIdx.x, gridDim.x); }
 
 // Right-hand operands of the ring builds (device_api.h ring_operands); one block per (k,b), chunks of CT c: the V_iajb tile
 // [j][c] goes through LDS (read with c fastest, used with j fastest), the V_iabj tile [c][j] and both outputs move in the order
 // of the threads (runs of nocc doubles per c)
-__global__ void __launch_bounds__(256) ring_operands_kernel(const double* __restrict__ Wd, const double* __restrict__ Ud,
-                                                            double* __restrict__ M, double* __restrict__ N1, double a1, double a2,
-                                                            int no, int nv) {
+struct RingOpK {
+    const double* Wd; const double* Ud; double* M; double* N1;
+    double a1, a2;
+    int no, nv;
+};
+__device__ __forceinline__ void ring_operands_body(const RingOpK& q, const unsigned vb) {
+    const double* __restrict__ Wd = q.Wd;
+    const double* __restrict__ Ud = q.Ud;
+    double* __restrict__ M = q.M;
+    double* __restrict__ N1 = q.N1;
+    const double a1 = q.a1, a2 = q.a2;
+    const int no = q.no, nv = q.nv;
     extern __shared__ double tile[];          // [no][CT + 1]
     constexpr int CT = 32;                    // (16 / 32 / 64 measure the same: 0.88 ms for 3.2 GB at (50,200))
-    const int k = blockIdx.x / nv, b = blockIdx.x - k * nv;
+    const int k = vb / nv, b = vb - k * nv;
     const long ov = (long)no * nv;
     const double* __restrict__ wd = Wd + ((long)k * nv + b) * ((long)nv * no);       // [c][j]
     const double* __restrict__ ud = Ud + ((long)k * nv + b) * ((long)no * nv);       // [j][c]
@@ -2095,15 +2220,25 @@ __global__ void __launch_bounds__(256) ring_operands_kernel(const double* __rest
         __syncthreads();
     }
 }
+__global__ void __launch_bounds__(256) ring_operands_kernel(const RingOpK q) { ring_operands_body(q, blockIdx.x); }
 
 // Pair layouts of exchange-symmetric-or-not amplitudes in one pass over T[a,b,i,j]; one block per (a,b):
 //   Td[(a,i),(b,j)] = T_abij,  Tx[(a,j),(b,i)] = T_abij,  Ttd[(a,i),(b,j)] = ca T_abij + cb T_baij   (2, -1 in the residual)
+struct LayoutsK {
+    const double* T; double* Td; double* Tx; double* Ttd;
+    double ca, cb;
+    int no, nv;
+};
 template <bool RESIDUAL>     // RESIDUAL: (ca, cb) = (2, -1) as compile-time constants (the form every CCSD iteration runs)
-__global__ void __launch_bounds__(256) t2_layouts_kernel(const double* __restrict__ T, double* __restrict__ Td,
-                                                         double* __restrict__ Tx, double* __restrict__ Ttd, int no,
-                                                         int nv, double ca, double cb) {
+__device__ __forceinline__ void t2_layouts_body(const LayoutsK& k, const unsigned vb) {
+    const double* __restrict__ T = k.T;
+    double* __restrict__ Td = k.Td;
+    double* __restrict__ Tx = k.Tx;
+    double* __restrict__ Ttd = k.Ttd;
+    const int no = k.no, nv = k.nv;
+    const double ca = k.ca, cb = k.cb;
     extern __shared__ double tile[];          // [no][no + 1]
-    const int a = blockIdx.x / nv, b = blockIdx.x - a * nv;
+    const int a = vb / nv, b = vb - a * nv;
     const long o2 = (long)no * no, ov = (long)no * nv;
     const double* __restrict__ Tab = T + ((long)a * nv + b) * o2;
     const double* __restrict__ Tba = T + ((long)b * nv + a) * o2;
@@ -2122,17 +2257,29 @@ __global__ void __launch_bounds__(256) t2_layouts_kernel(const double* __restric
         Tx[base + (long)j * ov + i] = tile[i * (no + 1) + j];
     }
 }
+template <bool RESIDUAL>
+__global__ void __launch_bounds__(256) t2_layouts_kernel(const LayoutsK k) { t2_layouts_body<RESIDUAL>(k, blockIdx.x); }
 
 // R[a,b,:,:] and R[b,a,:,:] of the symmetry-reduced residual in one pass (one block per pair a >= b):
 //   S[i][j] = N_ab[i][j] + N_ba[j][i] + D[(a,i),(b,j)] + D[(b,j),(a,i)] + X[(a,j),(b,i)] + X[(b,i),(a,j)]
 //   R_ab = V_ab + unpack(L)_ab + S,   R_ba = V_ba + unpack(L)_ba + S^T
-__global__ void __launch_bounds__(256) residual_assemble_kernel(const double* V, const double* __restrict__ L,
-                                                                const double* __restrict__ N, const double* __restrict__ D,
-                                                                const double* __restrict__ X, double* R,   // V may be R
-                                                                int no, int nv, double xd) {
+struct AssembleK {
+    const double* V; const double* L; const double* N; const double* D; const double* X; double* R;   // V may be R
+    double xd;
+    int no, nv;
+};
+__device__ __forceinline__ void residual_assemble_body(const AssembleK& k, const unsigned vb) {
+    const double* V = k.V;
+    const double* __restrict__ L = k.L;
+    const double* __restrict__ N = k.N;
+    const double* __restrict__ D = k.D;
+    const double* __restrict__ X = k.X;
+    double* R = k.R;
+    const int no = k.no, nv = k.nv;
+    const double xd = k.xd;
     extern __shared__ double S[];             // [no][no + 1]
     int a, b;
-    unrank_pair(blockIdx.x, a, b);
+    unrank_pair(vb, a, b);
     const int p = no + 1;
     const long o2 = (long)no * no, ov = (long)no * nv, opp = (long)no * (no + 1) / 2;
     const long ab = ((long)a * nv + b) * o2, ba = ((long)b * nv + a) * o2;
@@ -2165,6 +2312,7 @@ __global__ void __launch_bounds__(256) residual_assemble_kernel(const double* V,
         if (a != b) R[ba + e] = (V ? V[ba + e] : 0.0) + ls - sgn * la + S[j * p + i];
     }
 }
+__global__ void __launch_bounds__(256) residual_assemble_kernel(const AssembleK k) { residual_assemble_body(k, blockIdx.x); }
 
 // ---- pair-sharded tail of the iteration (one process per GPU): a rank owns the virtual pairs P(a,b) in [r0,r1), a >= b,
 // and keeps the tiles X[a,b,:,:] and X[b,a,:,:] of every amplitude-sized quantity in the compact layout
@@ -2311,10 +2459,18 @@ __global__ void __launch_bounds__(256) residual_assemble_pairs_kernel(const doub
 }
 
 // out[r][i][j] = Q[r][P(i,j)] + sgn(i-j) Q[r][opp + Q(i,j)]   (rows are plain, not pair-packed)
-__global__ void rows_unpack_kernel(const double* __restrict__ Q, double* __restrict__ out, int no, long total) {
+struct RowsUnpackK {
+    const double* Q; double* out;
+    long total;
+    int no;
+};
+__device__ __forceinline__ void rows_unpack_body(const RowsUnpackK& k, const unsigned vb, const unsigned vgrid) {
+    const double* __restrict__ Q = k.Q;
+    double* __restrict__ out = k.out;
+    const int no = k.no;
+    const long total = k.total;
     const long opp = (long)no * (no + 1) / 2, ld = (long)no * no;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long)gridDim.x * blockDim.x) {
+    for (long idx = vb * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)vgrid * blockDim.x) {
         const long r = idx / ld;
         const int e = (int)(idx - r * ld);
         const int i = e / no, j = e - i * no;
@@ -2328,6 +2484,7 @@ __global__ void rows_unpack_kernel(const double* __restrict__ Q, double* __restr
         out[idx] = v;
     }
 }
+__global__ void rows_unpack_kernel(const RowsUnpackK k) { rows_unpack_body(k, blockIdx.x, gridDim.x); }
 
 // dev::fock_finish (device_api.h): two launches instead of twenty for matrices of n^2 <= 62500 elements
 struct FockW {
@@ -2348,14 +2505,21 @@ __device__ __forceinline__ FockW fock_w(const double* W, int no, int nv) {
 // columns each (16-byte loads), the row dots go through a wave reduction; partial results per chunk land in ws
 // [chunk][2][v][v] and are summed by fock_g12_finish_kernel in a fixed order (bit-reproducible).  Replaces two
 // matrix-vector passes over two transposed static copies of the block (2 x 3.2 GB at (50,200)).
+struct FockG12K {
+    const double* V; const double* t1; double* ws;
+    int no, nv, na, j0, j1, jper;
+};
 template <int VEC>
-__global__ void __launch_bounds__(256) fock_g12_kernel(const double* __restrict__ V, const double* __restrict__ t1,
-                                                       double* __restrict__ ws, int no, int nv, int na, int j0, int j1, int jper) {
+__device__ __forceinline__ void fock_g12_body(const FockG12K& k, const unsigned vb) {
+    const double* __restrict__ V = k.V;
+    const double* __restrict__ t1 = k.t1;
+    double* __restrict__ ws = k.ws;
+    const int no = k.no, nv = k.nv, na = k.na, j0 = k.j0, j1 = k.j1, jper = k.jper;
     extern __shared__ double sm[];
     double* tj = sm;                 // [nv]     t[:, j]
     double* y2 = sm + nv;            // [nv]     row dots, summed over the chunk's j
     double* y1s = sm + 2 * nv;       // [4][nv]  per-wave column sums
-    const int a = blockIdx.x % na, chunk = blockIdx.x / na;
+    const int a = vb % na, chunk = vb / na;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int jb = j0 + chunk * jper, je = min(j1, jb + jper);
     constexpr int QMAX = 8;          // columns per lane: VEC * QMAX * 64 >= nv (host checks)
@@ -2417,23 +2581,40 @@ __global__ void __launch_bounds__(256) fock_g12_kernel(const double* __restrict_
         o2[i] = y2[i];
     }
 }
+template <int VEC>
+__global__ void __launch_bounds__(256) fock_g12_kernel(const FockG12K k) { fock_g12_body<VEC>(k, blockIdx.x); }
 
-__global__ void fock_g12_finish_kernel(const double* __restrict__ ws, int nchunk, long vv, double* __restrict__ G1,
-                                       double* __restrict__ G2) {
-    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+struct FockG12FinK {
+    const double* ws; double* G1; double* G2;
+    long vv;
+    int nchunk;
+};
+__device__ __forceinline__ void fock_g12_finish_body(const FockG12FinK& k, const unsigned vb) {
+    const double* __restrict__ ws = k.ws;
+    const long vv = k.vv;
+    const long i = vb * (long)blockDim.x + threadIdx.x;
     if (i >= vv) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int c = 0; c < nchunk; ++c) {
+    for (int c = 0; c < k.nchunk; ++c) {
         s1 += ws[(long)c * 2 * vv + i];
         s2 += ws[(long)c * 2 * vv + vv + i];
     }
-    G1[i] = s1;
-    G2[i] = s2;
+    k.G1[i] = s1;
+    k.G2[i] = s2;
 }
+__global__ void fock_g12_finish_kernel(const FockG12FinK k) { fock_g12_finish_body(k, blockIdx.x); }
 
-__global__ void fock_ft_kernel(const double* __restrict__ f, const double* __restrict__ t1, const double* __restrict__ W,
-                               double* __restrict__ ft, int no, int nv) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+struct FockFinK {
+    const double* f; const double* t1; const double* W; double* ft; double* fd;
+    int no, nv;
+};
+__device__ __forceinline__ void fock_ft_body(const FockFinK& k, const unsigned vb) {
+    const double* __restrict__ f = k.f;
+    const double* __restrict__ t1 = k.t1;
+    const double* __restrict__ W = k.W;
+    double* __restrict__ ft = k.ft;
+    const int no = k.no, nv = k.nv;
+    const int e = vb * blockDim.x + threadIdx.x;
     if (e >= no * no) return;
     const int j = e / no, i = e - j * no, n = no + nv;
     const FockW w = fock_w(W, no, nv);
@@ -2443,10 +2624,16 @@ __global__ void fock_ft_kernel(const double* __restrict__ f, const double* __res
         acc += (f[(long)j * n + no + b] + 2.0 * w.J1[(long)j * nv + b] - w.J2[(long)j * nv + b]) * t1[(long)b * no + i];
     ft[e] = acc;
 }
-__global__ void fock_finish_kernel(const double* __restrict__ f, const double* __restrict__ t1, const double* __restrict__ W,
-                                   const double* __restrict__ ft, double* __restrict__ fd, int no, int nv) {
+__global__ void fock_ft_kernel(const FockFinK k) { fock_ft_body(k, blockIdx.x); }
+__device__ __forceinline__ void fock_finish_body(const FockFinK& k, const unsigned vb) {
+    const double* __restrict__ f = k.f;
+    const double* __restrict__ t1 = k.t1;
+    const double* __restrict__ W = k.W;
+    const double* __restrict__ ft = k.ft;
+    double* __restrict__ fd = k.fd;
+    const int no = k.no, nv = k.nv;
     const int n = no + nv;
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long e = (long)vb * blockDim.x + threadIdx.x;
     if (e >= (long)n * n) return;
     const int p = (int)(e / n), q = (int)(e - (long)p * n);
     const FockW w = fock_w(W, no, nv);
@@ -2475,19 +2662,32 @@ __global__ void fock_finish_kernel(const double* __restrict__ f, const double* _
     }
     fd[e] = v;
 }
+__global__ void fock_finish_kernel(const FockFinK k) { fock_finish_body(k, blockIdx.x); }
 
 // partial traces of a pair matrix M[(c,k)][(b,j)] (device_api.h).  Blocks [0, nv * ceil(nv/16)): one c and sixteen a
 // each — a wave takes four a (their loads in flight together), its lanes the k of sum_k M[(c,k)][(a,k)] (one element per
 // 128-byte line: 1/3 of the lines of M in all), summed by a shuffle tree.  The no blocks behind them: one k each — lanes
 // over i, the four waves over c = w, w+4, ..., added up in wave order through LDS.  Fixed summation orders: deterministic.
 // A second matrix M2 (same shape and pitch) adds alpha2 x its traces in the same pass (the two builds of the ring terms).
-__global__ void __launch_bounds__(256) pair_traces_kernel(const double* __restrict__ M, long ld, double alpha, double beta,
-                                                          double* __restrict__ out_vv, double* __restrict__ out_oo,
-                                                          int no, int nv, const double* __restrict__ M2, double alpha2) {
+struct TracesK {
+    const double* M; const double* M2; double* out_vv; double* out_oo;
+    long ld;
+    double alpha, beta, alpha2;
+    int no, nv;
+};
+constexpr int kTracesLdsDoubles = 4 * 64;
+__device__ __forceinline__ void pair_traces_body(const TracesK& q, const unsigned vb, double* __restrict__ smem) {
+    const double* __restrict__ M = q.M;
+    const double* __restrict__ M2 = q.M2;
+    double* __restrict__ out_vv = q.out_vv;
+    double* __restrict__ out_oo = q.out_oo;
+    const long ld = q.ld;
+    const double alpha = q.alpha, beta = q.beta, alpha2 = q.alpha2;
+    const int no = q.no, nv = q.nv;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int agroups = (nv + 15) / 16, nvv = nv * agroups;
-    if ((int)blockIdx.x < nvv) {
-        const int c = blockIdx.x / agroups, a0 = (blockIdx.x - c * agroups) * 16 + wave;
+    if ((int)vb < nvv) {
+        const int c = vb / agroups, a0 = (vb - c * agroups) * 16 + wave;
         const double* __restrict__ base = M + (long)c * no * ld;
         const double* __restrict__ base2 = M2 ? M2 + (long)c * no * ld : nullptr;
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -2514,8 +2714,8 @@ __global__ void __launch_bounds__(256) pair_traces_kernel(const double* __restri
         }
         return;
     }
-    __shared__ double part[4][64];
-    const int k = blockIdx.x - nvv;
+    double (*part)[64] = reinterpret_cast<double (*)[64]>(smem);
+    const int k = vb - nvv;
     for (int i0 = 0; i0 < no; i0 += 64) {
         const int i = i0 + lane;
         double acc = 0.0;
@@ -2537,6 +2737,10 @@ __global__ void __launch_bounds__(256) pair_traces_kernel(const double* __restri
         }
         __syncthreads();
     }
+}
+__global__ void __launch_bounds__(256) pair_traces_kernel(const TracesK q) {
+    __shared__ double part[kTracesLdsDoubles];
+    pair_traces_body(q, blockIdx.x, part);
 }
 
 // ------------------------------------------------------------------------------------
@@ -2790,6 +2994,141 @@ __global__ void ueg_scatter_kernel(const UegK u, const int* __restrict__ kint, c
     V[((long)(p * n + q) * n + r) * n + s] = w;
 }
 
+// =====================================================================================================================
+// Phase launches (round 6): the small kernels between two big products form a dependency graph that is mostly
+// WIDE, not deep — the dressed Fock matrix, the T1 dressing of three V blocks, the pair layouts and the ladder operands of
+// a (20,80) iteration are seventeen launches of 5-35 us, each on a fraction of the chip, none reading what another writes.
+// A dependent launch costs 1.9 us on this chip and a dependency counter inside a persistent kernel more than that at
+// every task size (profiles/r06/probe_phase_boundary_vs_counters.txt), so the seam between dependent tasks stays a kernel
+// boundary and what is removed is the serialisation of INDEPENDENT ones: while a phase is open the device functions below
+// do not launch, they append a task (kind, argument block, blocks, LDS, the address ranges it reads and writes); a flush
+// assigns every task the earliest level its hazards allow (read-after-write, write-after-read and write-after-write on
+// overlapping address ranges order two tasks, nothing else does — also across reused arena temporaries) and launches ONE
+// grid per level that carries the blocks of all its tasks (phase_kernel).  A task's blocks are dealt round-robin over
+// the eight XCDs (its range of hardware blocks starts at a multiple of 8), tasks in order of decreasing cost.
+// Anything that is not recorded (a big product, a copy, a synchronisation, a graph boundary) flushes first: the order of
+// effects is that of immediate execution.
+// =====================================================================================================================
+enum : unsigned short {
+    PK_GEMM = 0, PK_SPLITK, PK_PERM_DIRECT, PK_PERM_TILED, PK_GEMV_COLS, PK_GEMV_FINISH, PK_GEMV_ROWS, PK_CC_UPDATE, PK_LINCOMB,
+    PK_DOTS1, PK_DOTS2, PK_ENERGY, PK_TAU, PK_PACK_T, PK_LADDER_UNPACK, PK_RING_OPERANDS, PK_T2_LAYOUTS, PK_ASSEMBLE,
+    PK_ROWS_UNPACK, PK_FOCK_G12, PK_FOCK_G12_FIN, PK_FOCK_FT, PK_FOCK_FIN, PK_TRACES, PK_KINDS
+};
+struct SplitkTaskK { GemmK g; int BM, BN; };
+struct PermTaskK { PermK p; long total; int tiles_q, tiles_l; };
+struct GemvTaskK { GemvItem it; double* ws; const double* yin; double beta; };
+
+constexpr int kPhaseMaxTasks = 24;
+constexpr int kPhaseBlobWords = 440;
+struct PhaseK {
+    int n;
+    int blk_end[kPhaseMaxTasks];       // running block count, every task's range padded to a multiple of 8
+    int nblk[kPhaseMaxTasks];          // blocks the task really has
+    unsigned short kind[kPhaseMaxTasks], sub[kPhaseMaxTasks], off[kPhaseMaxTasks];     // off: 8-byte words into blob
+    long blob[kPhaseBlobWords];
+};
+static_assert(sizeof(PhaseK) <= 4096, "kernel arguments are limited to 4 KB");
+
+// (the argument block of a task is addressed ONCE, before the switch over the kinds: a pointer into the by-value kernel
+// argument formed inside every case makes the compiler merge them into a phi, lose track of the argument's constness and copy
+// all 3.9 KB of it to scratch at the start of every block)
+template <typename T>
+__device__ __forceinline__ const T& phase_args(const long* args) { return *reinterpret_cast<const T*>(args); }
+// GEMM variants of a phase: sub = shape * 8 + (A K-contiguous) * 4 + (B K-contiguous) * 2 + (16-byte loads); shape 0 = 64 x 64,
+// 1 = 64 x 32, 2 = 32 x 64 (double-buffered register-staged tiles: the block count per CU is the launch's, not the variant's)
+template <int BM, int BN>
+__device__ __forceinline__ void phase_gemm_layouts(const GemmK& g, const int lay, const long bid) {
+    switch (lay) {
+        case 0: dgemm_body<BM, BN, false, false, 1>(g, bid); break;
+        case 1: dgemm_body<BM, BN, false, false, 2>(g, bid); break;
+        case 2: dgemm_body<BM, BN, false, true, 1>(g, bid); break;
+        case 3: dgemm_body<BM, BN, false, true, 2>(g, bid); break;
+        case 4: dgemm_body<BM, BN, true, false, 1>(g, bid); break;
+        case 5: dgemm_body<BM, BN, true, false, 2>(g, bid); break;
+        case 6: dgemm_body<BM, BN, true, true, 1>(g, bid); break;
+        default: dgemm_body<BM, BN, true, true, 2>(g, bid); break;
+    }
+}
+__global__ void __launch_bounds__(kThreads, 2) phase_kernel(const PhaseK ph) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double sh[4];
+    const int b = blockIdx.x;
+    int it = 0;
+    while (it + 1 < ph.n && b >= ph.blk_end[it]) ++it;
+    const int start = it ? ph.blk_end[it - 1] : 0;
+    const int span = ph.blk_end[it] - start;
+    const int nblk = ph.nblk[it];
+    const int kind = ph.kind[it], sub = ph.sub[it];
+    const long* const args = ph.blob + ph.off[it];      // (ONE address into the kernel arguments, formed here: see phase_args)
+    int vb = b - start;                          // start % 8 == 0: vb % 8 is the block's XCD
+    if (kind == PK_GEMM) vb = (int)xcd_remap(vb, span);     // neighbouring tiles of a product on one XCD
+    if (vb >= nblk) return;
+    switch (kind) {
+        case PK_GEMM: {
+            const GemmK& g = phase_args<GemmK>(args);
+            const int shape = sub >> 3, lay = sub & 7;
+            if (shape == 0) phase_gemm_layouts<64, 64>(g, lay, vb);
+            else if (shape == 1) phase_gemm_layouts<64, 32>(g, lay, vb);
+            else phase_gemm_layouts<32, 64>(g, lay, vb);
+        } break;
+        case PK_SPLITK: {
+            const SplitkTaskK& k = phase_args<SplitkTaskK>(args);
+            const int pieces = k.BM * k.BN / 256;
+            splitk_reduce_body(k.g, k.BM, k.BN, vb / pieces, vb % pieces);
+        } break;
+        case PK_PERM_DIRECT: {
+            const PermTaskK& k = phase_args<PermTaskK>(args);
+            permute_direct_body(k.p, k.total, vb, nblk);
+        } break;
+        case PK_PERM_TILED: {
+            const PermTaskK& k = phase_args<PermTaskK>(args);
+            permute_tiled_body(k.p, k.tiles_q, k.tiles_l, vb, smem);
+        } break;
+        case PK_GEMV_COLS: {
+            const GemvTaskK& k = phase_args<GemvTaskK>(args);
+            gemv_cols_item(k.it, vb, k.ws);
+        } break;
+        case PK_GEMV_FINISH: {
+            const GemvTaskK& k = phase_args<GemvTaskK>(args);
+            gemv_finish_item(k.it, vb, k.ws, k.beta, k.yin);
+        } break;
+        case PK_GEMV_ROWS:
+            if (sub) gemv_rows_body<2>(phase_args<GemvRowsK>(args), vb);
+            else gemv_rows_body<1>(phase_args<GemvRowsK>(args), vb);
+            break;
+        case PK_CC_UPDATE: cc_update_body(phase_args<CcUpdateK>(args), vb, nblk); break;
+        case PK_LINCOMB: lincomb_body(phase_args<LinK>(args), vb, nblk); break;
+        case PK_DOTS1:
+            if (sub) dots_stage1_body<2>(phase_args<DotsK>(args), vb, sh);
+            else dots_stage1_body<1>(phase_args<DotsK>(args), vb, sh);
+            break;
+        case PK_DOTS2: dots_stage2_body(phase_args<Dots2K>(args), vb, sh); break;
+        case PK_ENERGY:
+            if (sub) energy_norms_body<2>(phase_args<EnergyK>(args), vb, nblk, sh);
+            else energy_norms_body<1>(phase_args<EnergyK>(args), vb, nblk, sh);
+            break;
+        case PK_TAU: tau_body(phase_args<TauK>(args), vb, nblk); break;
+        case PK_PACK_T: ladder_pack_T_body(phase_args<PackTK>(args), vb); break;
+        case PK_LADDER_UNPACK: ladder_unpack_body(phase_args<UnpackK>(args), vb, nblk); break;
+        case PK_RING_OPERANDS: ring_operands_body(phase_args<RingOpK>(args), vb); break;
+        case PK_T2_LAYOUTS:
+            if (sub) t2_layouts_body<true>(phase_args<LayoutsK>(args), vb);
+            else t2_layouts_body<false>(phase_args<LayoutsK>(args), vb);
+            break;
+        case PK_ASSEMBLE: residual_assemble_body(phase_args<AssembleK>(args), vb); break;
+        case PK_ROWS_UNPACK: rows_unpack_body(phase_args<RowsUnpackK>(args), vb, nblk); break;
+        case PK_FOCK_G12:
+            if (sub) fock_g12_body<2>(phase_args<FockG12K>(args), vb);
+            else fock_g12_body<1>(phase_args<FockG12K>(args), vb);
+            break;
+        case PK_FOCK_G12_FIN: fock_g12_finish_body(phase_args<FockG12FinK>(args), vb); break;
+        case PK_FOCK_FT: fock_ft_body(phase_args<FockFinK>(args), vb); break;
+        case PK_FOCK_FIN: fock_finish_body(phase_args<FockFinK>(args), vb); break;
+        case PK_TRACES: pair_traces_body(phase_args<TracesK>(args), vb, smem); break;
+        default: break;
+    }
+}
+
 inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
     long g = (total + block - 1) / block;
     return (int)std::max<long>(1, std::min<long>(g, cap));
@@ -2817,6 +3156,204 @@ constexpr int kGramTiles = 64;
 double* g_gram_ws[kMaxDevices] = {nullptr};
 double* g_gram_host[kMaxDevices] = {nullptr};
 long g_live_allocs = 0;
+
+// ---- phase queue (host side of phase_kernel) ----------------------------------------------------------------------------
+struct PhaseRange { uintptr_t lo, hi; };
+inline PhaseRange prange(const void* p, long doubles) {
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(p);
+    return PhaseRange{lo, p && doubles > 0 ? lo + 8 * (uintptr_t)doubles : lo};
+}
+// bounding interval of a strided box: extents n[i] with strides st[i] (in doubles, any sign), + `slack` doubles at the top
+inline PhaseRange pbox(const void* base, std::initializer_list<std::pair<long, long>> dims, long slack = 0) {
+    long lo = 0, hi = 0;
+    for (const auto& d : dims) {
+        if (d.first <= 0) return PhaseRange{0, 0};
+        const long span = (d.first - 1) * d.second;
+        if (span < 0) lo += span; else hi += span;
+    }
+    const uintptr_t b = reinterpret_cast<uintptr_t>(base);
+    return PhaseRange{b + 8 * lo, b + 8 * (hi + 1 + slack)};
+}
+struct PhaseRec {
+    unsigned short kind = 0, sub = 0;
+    int nblk = 0, lds = 0, level = 0, words = 0;
+    double cost = 0.0;                 // estimated microseconds (order of the tasks inside a level: longest first)
+    int nr = 0, nw = 0;
+    PhaseRange r[10], w[4];
+    long blob[56];
+};
+struct PhaseQueue {
+    int enabled = -1;                  // -1: PYMES_PHASE decides at first use (default on)
+    bool flushing = false;
+    double max_us = 60.0;              // tasks estimated above this run as launches of their own (PYMES_PHASE_MAX_US)
+    bool serial = false;               // PYMES_PHASE=serial: one task per level (hazard-analysis bisection)
+    hipStream_t st = nullptr;
+    std::vector<PhaseRec> q;
+    long ws_cursor = 0;                // rolling sub-allocation of the split-K workspace among the tasks of a phase
+    long tasks = 0, launches = 0, levels = 0, flushes = 0;      // statistics (dev::phase_stats)
+};
+thread_local PhaseQueue g_phase;
+void phase_flush();
+void gemm_group_flush();
+bool gemm_group_pending();
+
+inline bool phase_open(hipStream_t st) {
+    PhaseQueue& P = g_phase;
+    if (P.enabled < 0) {
+        const char* e = getenv("PYMES_PHASE");
+        P.enabled = (e && e[0] == '0') ? 0 : 1;
+        P.serial = e && !strcmp(e, "serial");
+        if (const char* m = getenv("PYMES_PHASE_MAX_US")) P.max_us = atof(m);
+    }
+    if (!P.enabled || P.flushing || g_prof.on) return false;
+    if (!P.q.empty() && P.st != st) phase_flush();
+    P.st = st;
+    return true;
+}
+inline bool phase_small(double cost_us) { return cost_us <= g_phase.max_us; }
+
+template <typename T>
+PhaseRec& phase_push(unsigned short kind, unsigned short sub, long nblk, int lds, double cost, const T& args) {
+    static_assert(sizeof(T) % 8 == 0 && sizeof(T) <= sizeof(PhaseRec::blob), "task arguments: 8-byte words, at most 448 bytes");
+    static_assert(std::is_trivially_copyable<T>::value, "task arguments are copied as bytes");
+    PhaseQueue& P = g_phase;
+    // a product waiting in an open group (dev::gemm_group_*) keeps its place in the order of effects: it goes first
+    if (gemm_group_pending()) gemm_group_flush();
+    if (P.q.size() >= 160) phase_flush();
+    if (nblk <= 0 || nblk > 0x3fffffffL) throw std::runtime_error("phase: bad block count");
+    P.q.emplace_back();
+    PhaseRec& t = P.q.back();
+    t.kind = kind; t.sub = sub; t.nblk = (int)nblk; t.lds = lds; t.cost = cost;
+    t.words = (int)(sizeof(T) / 8);
+    memcpy(t.blob, &args, sizeof(T));
+    ++P.tasks;
+    return t;
+}
+inline void phase_reads(PhaseRec& t, std::initializer_list<PhaseRange> rs) {
+    for (const auto& x : rs)
+        if (x.hi > x.lo) {
+            if (t.nr >= 10) throw std::runtime_error("phase: too many read ranges");
+            t.r[t.nr++] = x;
+        }
+}
+inline void phase_writes(PhaseRec& t, std::initializer_list<PhaseRange> ws) {
+    for (const auto& x : ws)
+        if (x.hi > x.lo) {
+            if (t.nw >= 4) throw std::runtime_error("phase: too many write ranges");
+            t.w[t.nw++] = x;
+        }
+}
+inline bool phase_overlap(const PhaseRange& a, const PhaseRange& b) { return a.lo < b.hi && b.lo < a.hi; }
+inline bool phase_conflict(const PhaseRec& a, const PhaseRec& b) {       // a earlier, b later
+    for (int i = 0; i < a.nw; ++i) {
+        for (int j = 0; j < b.nw; ++j) if (phase_overlap(a.w[i], b.w[j])) return true;
+        for (int j = 0; j < b.nr; ++j) if (phase_overlap(a.w[i], b.r[j])) return true;
+    }
+    for (int i = 0; i < a.nr; ++i)
+        for (int j = 0; j < b.nw; ++j) if (phase_overlap(a.r[i], b.w[j])) return true;
+    return false;
+}
+// a slice of the split-K / matrix-vector workspace for one task of the open phase (rolling: a wrap-around is ordered by the
+// hazard analysis like any other reuse)
+inline double* phase_ws(double* ws, long ws_doubles, long need) {
+    PhaseQueue& P = g_phase;
+    if (!ws || need > ws_doubles) return nullptr;
+    need = (need + 15) & ~15L;
+    if (P.ws_cursor + need > ws_doubles) P.ws_cursor = 0;
+    double* p = ws + P.ws_cursor;
+    P.ws_cursor += need;
+    return p;
+}
+
+void phase_flush() {
+    PhaseQueue& P = g_phase;
+    if (P.q.empty() || P.flushing) return;
+    struct Guard {
+        PhaseQueue& P;
+        ~Guard() { P.flushing = false; P.q.clear(); P.ws_cursor = 0; }
+    } guard{P};
+    P.flushing = true;
+    ++P.flushes;
+    std::vector<PhaseRec>& q = P.q;
+    const int n = (int)q.size();
+    int nlev = 0;
+    for (int i = 0; i < n; ++i) {
+        int lev = 0;
+        if (P.serial) lev = i;
+        else
+            for (int j = i - 1; j >= 0; --j)
+                if (q[j].level >= lev && phase_conflict(q[j], q[i])) lev = q[j].level + 1;
+        q[i].level = lev;
+        nlev = std::max(nlev, lev + 1);
+    }
+    static const bool log = getenv("PYMES_PHASE_LOG") != nullptr;      // one line per level: kind:blocks:cost of its tasks
+    if (log) {
+        static const char* names[] = {"gemm", "splitk", "perm", "permT", "gemvC", "gemvF", "gemvR", "update", "lincomb", "dots1", "dots2",
+                                      "energy", "tau", "packT", "unpackL", "ringops", "layouts", "assemble", "unpackR", "fockG", "fockGf",
+                                      "fockFt", "fockFin", "traces"};
+        fprintf(stderr, "[phase] flush %ld: %d tasks, %d levels\n", P.flushes, n, nlev);
+        for (int lev = 0; lev < nlev; ++lev) {
+            fprintf(stderr, "[phase]   L%-2d", lev);
+            for (int i = 0; i < n; ++i)
+                if (q[i].level == lev) fprintf(stderr, " %s:%d:%.1f", q[i].kind < PK_KINDS ? names[q[i].kind] : "?", q[i].nblk, q[i].cost);
+            fprintf(stderr, "\n");
+        }
+    }
+    static bool attr_set[kMaxDevices] = {false};
+    int dv = 0;
+    HIP_CHECK(hipGetDevice(&dv));
+    if (dv >= 0 && dv < kMaxDevices && !attr_set[dv]) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(phase_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr_set[dv] = true;
+    }
+    std::vector<int> idx;
+    for (int lev = 0; lev < nlev; ++lev) {
+        idx.clear();
+        for (int i = 0; i < n; ++i)
+            if (q[i].level == lev) idx.push_back(i);
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return q[a].cost > q[b].cost; });
+        ++P.levels;
+        size_t pos = 0;
+        while (pos < idx.size()) {
+            PhaseK ph;
+            ph.n = 0;
+            int words = 0, lds = 0;
+            long blocks = 0;
+            while (pos < idx.size() && ph.n < kPhaseMaxTasks) {
+                const PhaseRec& t = q[idx[pos]];
+                const long padded = ((long)t.nblk + 7) & ~7L;
+                if (words + t.words > kPhaseBlobWords || blocks + padded > 0x7ffffff0L) break;
+                const int i = ph.n++;
+                ph.kind[i] = t.kind; ph.sub[i] = t.sub; ph.off[i] = (unsigned short)words;
+                ph.nblk[i] = t.nblk;
+                memcpy(ph.blob + words, t.blob, 8 * (size_t)t.words);
+                words += t.words;
+                blocks += padded;
+                ph.blk_end[i] = (int)blocks;
+                lds = std::max(lds, t.lds);
+                ++pos;
+            }
+            if (ph.n == 0) throw std::runtime_error("phase: a task does not fit a launch");
+            for (int i = ph.n; i < kPhaseMaxTasks; ++i) { ph.blk_end[i] = (int)blocks; ph.nblk[i] = 0; ph.kind[i] = PK_KINDS; ph.sub[i] = 0; ph.off[i] = 0; }
+            hipLaunchKernelGGL(phase_kernel, dim3((unsigned)blocks), dim3(kThreads), (size_t)lds, P.st, ph);
+            HIP_CHECK(hipGetLastError());
+            ++P.launches;
+        }
+    }
+}
+// Every launch or stream operation below that is NOT recorded as a task goes through these: the open phase is launched
+// first, so that the order of effects on the stream is that of immediate execution.
+#define PYMES_LAUNCH(...) do { phase_flush(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+#define hipMemcpyAsync(...) (phase_flush(), hipMemcpyAsync(__VA_ARGS__))
+#define hipMemsetAsync(...) (phase_flush(), hipMemsetAsync(__VA_ARGS__))
+#define hipMemcpy(...) (phase_flush(), hipMemcpy(__VA_ARGS__))
+#define hipStreamSynchronize(...) (phase_flush(), hipStreamSynchronize(__VA_ARGS__))
+#define hipEventRecord(...) (phase_flush(), hipEventRecord(__VA_ARGS__))
+#define hipStreamWaitEvent(...) (phase_flush(), hipStreamWaitEvent(__VA_ARGS__))
+#define hipGraphLaunch(...) (phase_flush(), hipGraphLaunch(__VA_ARGS__))
+#define hipStreamBeginCapture(...) (phase_flush(), hipStreamBeginCapture(__VA_ARGS__))
+#define hipStreamEndCapture(...) (phase_flush(), hipStreamEndCapture(__VA_ARGS__))
+#define hipFree(...) (phase_flush(), hipFree(__VA_ARGS__))
 
 void wait_idle(hipStream_t st) { HIP_CHECK(hipStreamSynchronize(st)); }
 
@@ -2893,7 +3430,7 @@ void launch_gemm(const GemmK& k, long nblocks, hipStream_t st) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dv] = true;
     }
-    hipLaunchKernelGGL(fn, dim3((unsigned)nblocks), dim3(kThreads), lds, st, k);
+    PYMES_LAUNCH(fn, dim3((unsigned)nblocks), dim3(kThreads), lds, st, k);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -2910,7 +3447,7 @@ void launch_gemm_glds(const GemmK& k, long nblocks, hipStream_t st) {
                                       (int)lds));
         attr_set[dv] = true;
     }
-    hipLaunchKernelGGL(fn, dim3((unsigned)nblocks), dim3(kThreads), lds, st, k);
+    PYMES_LAUNCH(fn, dim3((unsigned)nblocks), dim3(kThreads), lds, st, k);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -3025,9 +3562,9 @@ void gemv_batch_flush() {
         blocks += it.cblocks * it.nchunk;
         outs += (int)((it.C + 255) / 256);
     }
-    hipLaunchKernelGGL(gemv_multi_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, b.st, b.tab, b.ws);
+    PYMES_LAUNCH(gemv_multi_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, b.st, b.tab, b.ws);
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(gemv_multi_finish_kernel, dim3((unsigned)outs), dim3(256), 0, b.st, b.tab, b.ws);
+    PYMES_LAUNCH(gemv_multi_finish_kernel, dim3((unsigned)outs), dim3(256), 0, b.st, b.tab, b.ws);
     HIP_CHECK(hipGetLastError());
     b.tab.n = 0;
     b.ws_used = 0;
@@ -3055,6 +3592,7 @@ struct GemmGroup {
     double flops_d[kGroupMax];
 };
 thread_local GemmGroup g_group;
+bool gemm_group_pending() { return g_group.n > 0 || g_group.nd > 0; }
 
 void gemm_group_flush_dma() {
     GemmGroup& q = g_group;
@@ -3136,10 +3674,10 @@ void gemm_group_flush_dma() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dv] = true;
     }
-    hipLaunchKernelGGL(dgemm_glds_group_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, st, grp);
+    PYMES_LAUNCH(dgemm_glds_group_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, st, grp);
     HIP_CHECK(hipGetLastError());
     if (red.n > 0) {
-        hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3((unsigned)red_blocks), dim3(256), 0, st, red);
+        PYMES_LAUNCH(splitk_reduce_group_kernel, dim3((unsigned)red_blocks), dim3(256), 0, st, red);
         HIP_CHECK(hipGetLastError());
     }
     ++q.launches;
@@ -3212,10 +3750,10 @@ void gemm_group_flush() {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dv] = true;
     }
-    hipLaunchKernelGGL(dgemm_group_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, st, grp);
+    PYMES_LAUNCH(dgemm_group_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, st, grp);
     HIP_CHECK(hipGetLastError());
     if (red.n > 0) {
-        hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3((unsigned)red_blocks), dim3(256), 0, st, red);
+        PYMES_LAUNCH(splitk_reduce_group_kernel, dim3((unsigned)red_blocks), dim3(256), 0, st, red);
         HIP_CHECK(hipGetLastError());
     }
     ++q.launches;
@@ -3474,6 +4012,104 @@ bool gemm_group_take(const Gemm& g, bool a_kcontig, bool b_kcontig, int64_t a_sm
 }
 }  // namespace
 
+namespace {
+// A small product as tasks of the open phase: 64 x 64 tiles (64 x 32 / 32 x 64 when a side is at most 32), the k-split rule of
+// the register-staged launches of dev::gemm, its partial tiles in a slice of the workspace and their reduction as a task
+// of the next level.  false: not small (or no phase open) — the caller goes on with the launches of its own.
+bool phase_gemm(const Gemm& g, bool akc, bool bkc, int64_t a_sm, int64_t a_sk, int64_t b_sk, int64_t b_sn, hipStream_t st) {
+    if (!phase_open(st)) return false;
+    const long nbatch = g.nb1 * g.nb2;
+    const double dM = (double)g.M, dN = (double)g.N, dK = (double)g.K, dB = (double)nbatch;
+    const double cost = 2.0 * dM * dN * dK * dB / 4.0e7 + 8.0 * (dM * dK + dK * dN + (g.beta != 0.0 ? 2.0 : 1.0) * dM * dN) * dB / 4.0e6;
+    if (!phase_small(cost)) return false;
+    int BM = 64, BN = 64;
+    if (g.N <= 32) BN = 32;
+    else if (g.M <= 32) BM = 32;
+    GemmK k;
+    k.A = g.A; k.B = g.B; k.C = g.C;
+    k.Cin = g.Cin ? g.Cin : g.C;
+    k.a_ld = akc ? a_sm : a_sk;
+    k.b_ld = bkc ? b_sn : b_sk;
+    k.ldc = g.ldc;
+    k.M = (int)g.M; k.N = (int)g.N; k.K = (int)g.K;
+    k.alpha = g.alpha; k.beta = g.beta;
+    k.nb2 = g.nb2;
+    k.a_b1 = g.a_b1; k.a_b2 = g.a_b2; k.b_b1 = g.b_b1; k.b_b2 = g.b_b2; k.c_b1 = g.c_b1; k.c_b2 = g.c_b2;
+    k.ws = nullptr;
+    k.tiles_m = (int)((g.M + BM - 1) / BM);
+    k.tiles_n = (int)((g.N + BN - 1) / BN);
+    const long tiles = (long)k.tiles_m * k.tiles_n * nbatch;
+    if (tiles > 0x3fffffffL / 16) return false;
+    int vec = 2;
+    k.Mc = k.M; k.Nc = k.N;
+    if (!akc && (g.M & 1) && k.a_ld > g.M) k.Mc = k.M + 1;
+    if (!bkc && (g.N & 1) && k.b_ld > g.N) k.Nc = k.N + 1;
+    {
+        const long ace = akc ? g.K : k.Mc, bce = bkc ? g.K : k.Nc;
+        if (!even(k.a_ld) || !even(k.b_ld) || !even(ace) || !even(bce) || !aligned16(g.A) || !aligned16(g.B) || !even(g.a_b1) ||
+            !even(g.a_b2) || !even(g.b_b1) || !even(g.b_b2))
+            vec = 1;
+    }
+    const long ktiles = (g.K + BK - 1) / BK;
+    // k-split of the last, partially filled round of blocks (all of them for a small output), as dev::gemm does it
+    const long slots = 1024;
+    const long ws_cap = g.splitk_ws ? g.splitk_ws_doubles / ((long)BM * BN) : 0;
+    long main_tiles = tiles, tail_tiles = 0;
+    int tail_split = 1;
+    if (ktiles >= 16) {
+        const long rem = tiles % slots;
+        if (rem > 0) {
+            long best = 1;
+            double best_cost = 1.0;
+            long smax = std::min<long>(512, std::max<long>(8, 2048 / rem));
+            smax = std::min<long>(smax, ktiles / 8);
+            smax = std::min<long>(smax, ws_cap / rem);
+            for (long sp = 2; sp <= smax; ++sp) {
+                const double c = (double)((rem * sp + slots - 1) / slots) / (double)sp + 1e-5 * sp;
+                if (c < best_cost - 1e-9) { best_cost = c; best = sp; }
+            }
+            if (best >= 2 && best_cost < 0.8) { tail_tiles = rem; main_tiles = tiles - rem; tail_split = (int)best; }
+        }
+    }
+    const unsigned short sub = (unsigned short)((BM == 64 && BN == 64 ? 0 : (BN == 32 ? 1 : 2)) * 8 + (akc ? 4 : 0) + (bkc ? 2 : 0) + (vec == 2 ? 1 : 0));
+    const int a_t = akc ? (BK + 2) * BM : (BM + 16) * BK, b_t = bkc ? (BK + 2) * BN : (BN + 16) * BK;
+    const int lds = 2 * (a_t + b_t) * (int)sizeof(double);
+    const PhaseRange rA = pbox(g.A, {{g.M, a_sm}, {g.K, a_sk}, {g.nb1, g.a_b1}, {g.nb2, g.a_b2}}, 1);
+    const PhaseRange rB = pbox(g.B, {{g.K, b_sk}, {g.N, b_sn}, {g.nb1, g.b_b1}, {g.nb2, g.b_b2}}, 1);
+    const PhaseRange rC = pbox(g.C, {{g.M, g.ldc}, {g.N, 1}, {g.nb1, g.c_b1}, {g.nb2, g.c_b2}});
+    const PhaseRange rCin = (g.beta != 0.0 && k.Cin != g.C) ? pbox(k.Cin, {{g.M, g.ldc}, {g.N, 1}, {g.nb1, g.c_b1}, {g.nb2, g.c_b2}})
+                                                           : PhaseRange{0, 0};
+    auto add = [&](long tile_begin, long ntiles, int nsplit, double share) {
+        const long kt_per = (ktiles + nsplit - 1) / nsplit;
+        k.kchunk = (int)std::max<long>(kt_per * BK, BK);
+        k.nsplit = (int)std::max<long>(1, (ktiles + kt_per - 1) / std::max<long>(kt_per, 1));
+        k.tile_begin = tile_begin;
+        k.ws = nullptr;
+        if (k.nsplit > 1) {
+            k.ws = phase_ws(g.splitk_ws, g.splitk_ws_doubles, ntiles * k.nsplit * (long)BM * BN);
+            if (!k.ws) { k.nsplit = 1; k.kchunk = (int)(ktiles * BK); }
+        }
+        PhaseRec& t = phase_push(PK_GEMM, sub, ntiles * k.nsplit, lds, cost * share, k);
+        phase_reads(t, {rA, rB});
+        if (k.nsplit > 1) {
+            const PhaseRange rW = prange(k.ws, ntiles * k.nsplit * (long)BM * BN);
+            phase_writes(t, {rW});
+            SplitkTaskK r{k, BM, BN};
+            PhaseRec& u = phase_push(PK_SPLITK, 0, ntiles * (BM * BN / 256), 0, 2.0, r);
+            phase_reads(u, {rW, rCin});
+            phase_writes(u, {rC});
+        } else {
+            phase_reads(t, {rCin});
+            phase_writes(t, {rC});
+        }
+    };
+    const double fmain = tiles > 0 ? (double)main_tiles / (double)tiles : 1.0;
+    if (main_tiles > 0) add(0, main_tiles, 1, fmain);
+    if (tail_tiles > 0) add(main_tiles, tail_tiles, tail_split, 1.0 - fmain);
+    return true;
+}
+}  // namespace
+
 // begin / end nest (an engine-internal scope inside a caller's): the group stays open until the outermost end; an inner
 // begin on another stream flushes what is queued and queues on its own stream until its end, then the outer stream is back
 void gemm_group_begin(stream_t s) {
@@ -3499,6 +4135,22 @@ void gemm_group_end() {
     gemm_group_flush();
 }
 void gemm_group_sync() { gemm_group_flush(); }
+void phase_sync() {
+    gemv_batch_flush();
+    gemm_group_flush();
+    phase_flush();
+}
+void phase_enable(int mode) {
+    phase_sync();
+    g_phase.enabled = mode < 0 ? -1 : (mode ? 1 : 0);
+    if (mode == 1) g_phase.serial = false;
+}
+void phase_stats(long* tasks, long* launches, long* levels, long* flushes) {
+    if (tasks) *tasks = g_phase.tasks;
+    if (launches) *launches = g_phase.launches;
+    if (levels) *levels = g_phase.levels;
+    if (flushes) *flushes = g_phase.flushes;
+}
 void gemm_group_stats(long* launches, long* products) {
     if (launches) *launches = g_group.launches;
     if (products) *products = g_group.products;
@@ -3519,6 +4171,7 @@ void gemm(const Gemm& g, stream_t s) {
     const bool b_kcontig = (b_sk == 1);
     if (gemv_dispatch(g, a_sm, a_sk, b_sk, b_sn, st)) return;
     gemv_batch_flush();
+    if (phase_gemm(g, a_kcontig, b_kcontig, a_sm, a_sk, b_sk, b_sn, st)) return;
     if (g_group.active && gemm_group_take(g, a_kcontig, b_kcontig, a_sm, a_sk, b_sk, b_sn, st)) return;
     gemm_group_flush();          // (a product that is launched on its own keeps its place in the order of effects)
     GemmK k;
@@ -3655,7 +4308,7 @@ void gemm(const Gemm& g, stream_t s) {
         else if (BM == 32 && BN == 64) dispatch_layout<32, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
         else dispatch_layout<64, 64>(k, a_kcontig, b_kcontig, vec, nblocks, st);
         if (k.nsplit > 1) {
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ntiles, (unsigned)(BM * BN / 256)), dim3(256), 0, st, k, BM, BN);
+            PYMES_LAUNCH(splitk_reduce_kernel, dim3((unsigned)ntiles, (unsigned)(BM * BN / 256)), dim3(256), 0, st, k, BM, BN);
             HIP_CHECK(hipGetLastError());
         }
         return k.nsplit;
@@ -3684,7 +4337,7 @@ void gemm(const Gemm& g, stream_t s) {
             GemmK r = k;                   // the reduction sees the tail tiles as a launch of its own: ws[i][ks], i from 0
             r.tile_begin = plan.whole;
             r.mixed = 0;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)plan.tail, 64u), dim3(256), 0, st, r, 128, 128);
+            PYMES_LAUNCH(splitk_reduce_kernel, dim3((unsigned)plan.tail, 64u), dim3(256), 0, st, r, 128, 128);
             HIP_CHECK(hipGetLastError());
             nsplit = -k.nsplit;            // logged as a negative split
         }
@@ -3747,6 +4400,20 @@ void permute(const Permute& p, stream_t s) {
     if (m.empty()) m.push_back({1, 1, 1});
     PermK k;
     k.alpha = p.alpha; k.beta = p.beta; k.in = p.in; k.out = p.out;
+    // as a task of the open phase when it is small (16 bytes per element, 24 with an accumulating output)
+    const double cost = (p.beta != 0.0 ? 24.0 : 16.0) * (double)total / 4.0e6;
+    const bool phase = phase_open(st) && phase_small(cost);
+    auto record = [&](unsigned short kind, long nblk, int lds, const PermTaskK& t) {
+        PhaseRange ri{reinterpret_cast<uintptr_t>(p.in), reinterpret_cast<uintptr_t>(p.in) + 8}, ro{reinterpret_cast<uintptr_t>(p.out), reinterpret_cast<uintptr_t>(p.out) + 8};
+        for (const auto& x : m) {
+            const long si = (x.n - 1) * x.si * 8, so = (x.n - 1) * x.so * 8;
+            if (si < 0) ri.lo += si; else ri.hi += si;
+            if (so < 0) ro.lo += so; else ro.hi += so;
+        }
+        PhaseRec& r = phase_push(kind, 0, nblk, lds, cost, t);
+        phase_reads(r, {ri});
+        phase_writes(r, {ro});
+    };
     // tiled path: out unit-stride on the last dim, in unit-stride on another dim
     int q = -1;
     const int r = (int)m.size();
@@ -3766,12 +4433,14 @@ void permute(const Permute& p, stream_t s) {
         for (int i = 0; i < r - 2; ++i) rest *= m[i].n;
         const long nblk = rest * tq * tl;
         if (nblk > 0x7fffffffL) throw std::runtime_error("permute: grid too large");
-        hipLaunchKernelGGL(permute_tiled_kernel, dim3((unsigned)nblk), dim3(256), 0, st, k, tq, tl);
+        if (phase && nblk < 0x3fffffffL) { record(PK_PERM_TILED, nblk, kPermTileDoubles * (int)sizeof(double), PermTaskK{k, total, tq, tl}); return; }
+        PYMES_LAUNCH(permute_tiled_kernel, dim3((unsigned)nblk), dim3(256), 0, st, k, tq, tl);
     } else {
         k.rank = r;
         for (int i = 0; i < r; ++i) { k.dim[i] = m[i].n; k.s_in[i] = m[i].si; k.s_out[i] = m[i].so; }
         for (int i = r; i < 6; ++i) { k.dim[i] = 1; k.s_in[i] = 0; k.s_out[i] = 0; }
-        hipLaunchKernelGGL(permute_direct_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, st, k, total);
+        if (phase) { record(PK_PERM_DIRECT, grid_for(total, 256, 256 * 32), 0, PermTaskK{k, total, 0, 0}); return; }
+        PYMES_LAUNCH(permute_direct_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, st, k, total);
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -3780,7 +4449,7 @@ void mp2_amplitudes(double* t, const double* w, const double* eo, const double* 
                     stream_t s) {
     const long total = (long)nv * nv * no * no;
     if (!total) return;
-    hipLaunchKernelGGL(mp2_amplitudes_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, t, w, eo, ev,
+    PYMES_LAUNCH(mp2_amplitudes_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, t, w, eo, ev,
                        shift, no, nv, total);
     HIP_CHECK(hipGetLastError());
 }
@@ -3789,8 +4458,15 @@ void cc_update_to(double* t_out, double* dt, const double* t_in, const double* r
                   double shift, double delta, int no, int nv, int rank, stream_t s) {
     const long total = rank == 4 ? (long)nv * nv * no * no : (long)nv * no;
     if (!total) return;
-    hipLaunchKernelGGL(cc_update_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, t_out, dt, t_in, r, eo, ev,
-                       shift, delta, no, nv, rank, total);
+    const CcUpdateK k{t_out, dt, t_in, r, eo, ev, shift, delta, no, nv, rank, total};
+    const double cost = 32.0 * (double)total / 4.0e6;
+    if (phase_open((hipStream_t)s) && phase_small(cost)) {
+        PhaseRec& t = phase_push(PK_CC_UPDATE, 0, grid_for(total), 0, cost, k);
+        phase_reads(t, {prange(t_in, total), prange(r, total), prange(eo, no), prange(ev, nv)});
+        phase_writes(t, {prange(t_out, total), prange(dt, total)});
+        return;
+    }
+    PYMES_LAUNCH(cc_update_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, k);
     HIP_CHECK(hipGetLastError());
 }
 void cc_update(double* t, double* dt, const double* r, const double* eo, const double* ev, double shift,
@@ -3812,10 +4488,37 @@ static int launch_dots_stage1(int npairs, const double* const* x, const double* 
     for (int i = npairs; i < 16; ++i) { p.x[i] = nullptr; p.y[i] = nullptr; p.n[i] = 0; }
     const long per = vec ? 512 : 256;
     const int nb = (int)std::max<long>(1, std::min<long>(kDotBlocks, (nmax + per - 1) / per));
-    if (vec) hipLaunchKernelGGL(dots_stage1_kernel<2>, dim3(nb * npairs), dim3(256), 0, st, p, ws, nb, npairs);
-    else hipLaunchKernelGGL(dots_stage1_kernel<1>, dim3(nb * npairs), dim3(256), 0, st, p, ws, nb, npairs);
+    const DotsK k{p, ws, nb, npairs};
+    double bytes = 0.0;
+    for (int i = 0; i < npairs; ++i) bytes += 16.0 * (double)p.n[i];
+    if (phase_open(st) && phase_small(bytes / 4.0e6)) {
+        PhaseRec& t = phase_push(PK_DOTS1, vec ? 1 : 0, (long)nb * npairs, 0, bytes / 4.0e6, k);
+        // (the operands: one bounding range per distinct pointer would overflow the list — the pairs of a call share operands)
+        uintptr_t lo = ~(uintptr_t)0, hi = 0;
+        for (int i = 0; i < npairs; ++i)
+            for (const double* q : {p.x[i], p.y[i]}) {
+                lo = std::min(lo, reinterpret_cast<uintptr_t>(q));
+                hi = std::max(hi, reinterpret_cast<uintptr_t>(q) + 8 * (uintptr_t)p.n[i]);
+            }
+        phase_reads(t, {PhaseRange{lo, hi}});
+        phase_writes(t, {prange(ws, 16L * kDotBlocks)});
+        return nb;
+    }
+    if (vec) PYMES_LAUNCH(dots_stage1_kernel<2>, dim3(nb * npairs), dim3(256), 0, st, k);
+    else PYMES_LAUNCH(dots_stage1_kernel<1>, dim3(nb * npairs), dim3(256), 0, st, k);
     HIP_CHECK(hipGetLastError());
     return nb;
+}
+// stage 2 (partial sums of `npairs` reductions -> out_dev[npairs]) as a task of the open phase or a launch
+static void launch_dots_stage2(int npairs, double* ws, int nb, double* out_dev, hipStream_t st) {
+    if (phase_open(st)) {
+        PhaseRec& t = phase_push(PK_DOTS2, 0, npairs, 0, 1.0, Dots2K{ws, out_dev, nb});
+        phase_reads(t, {prange(ws, 16L * kDotBlocks)});
+        phase_writes(t, {prange(out_dev, npairs)});
+        return;
+    }
+    PYMES_LAUNCH(dots_stage2_kernel, dim3(npairs), dim3(256), 0, st, ws, nb, out_dev);
+    HIP_CHECK(hipGetLastError());
 }
 
 void dots(int npairs, const double* const* x, const double* const* y, const int64_t* n, double* out_host, stream_t s) {
@@ -3826,8 +4529,7 @@ void dots(int npairs, const double* const* x, const double* const* y, const int6
     ensure_dot_ws(dv);
     const int nb = launch_dots_stage1(npairs, x, y, n, g_dot_ws[dv], st);
     double* out_dev = g_dot_ws[dv] + 16 * kDotBlocks;
-    hipLaunchKernelGGL(dots_stage2_kernel, dim3(npairs), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);
-    HIP_CHECK(hipGetLastError());
+    launch_dots_stage2(npairs, g_dot_ws[dv], nb, out_dev, st);
     HIP_CHECK(hipMemcpyAsync(g_dot_host[dv], out_dev, sizeof(double) * npairs, hipMemcpyDeviceToHost, st));
     wait_idle(st);
     for (int i = 0; i < npairs; ++i) out_host[i] = g_dot_host[dv][i];
@@ -3842,9 +4544,8 @@ void diis_step(double* state, int npairs, const double* const* x, const double* 
     ensure_dot_ws(dv);
     const int nb = launch_dots_stage1(npairs, x, y, n, g_dot_ws[dv], st);
     double* out_dev = g_dot_ws[dv] + 16 * kDotBlocks;
-    hipLaunchKernelGGL(dots_stage2_kernel, dim3(npairs), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);
-    HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(diis_step_kernel, dim3(1), dim3(64), 0, st, state, out_dev, ntypes, m, was_full);
+    launch_dots_stage2(npairs, g_dot_ws[dv], nb, out_dev, st);
+    PYMES_LAUNCH(diis_step_kernel, dim3(1), dim3(64), 0, st, state, out_dev, ntypes, m, was_full);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -3853,7 +4554,7 @@ void lincomb_dev(double* out, int nx, const double* const* x, const double* coef
     if (n <= 0) return;
     LinPtrsDev p;
     for (int i = 0; i < 8; ++i) p.x[i] = i < nx ? x[i] : nullptr;
-    hipLaunchKernelGGL(lincomb_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, out, p, coeff_dev, nx, (long)n);
+    PYMES_LAUNCH(lincomb_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, out, p, coeff_dev, nx, (long)n);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -3867,12 +4568,21 @@ int energy_norms_start(const double* f, const double* t1, const double* t2, cons
     const int nb = (int)std::max<long>(1, std::min<long>(kDotBlocks, (total + 255) / 256));
     const bool vec = (no % 2 == 0) && !((reinterpret_cast<uintptr_t>(t2) | reinterpret_cast<uintptr_t>(Edir) |
                                           reinterpret_cast<uintptr_t>(Eex) | reinterpret_cast<uintptr_t>(dt2)) & 15);
-    if (vec) hipLaunchKernelGGL(energy_norms_kernel<2>, dim3(nb), dim3(256), 0, st, f, t1, t2, Edir, Eex, dt2, no, nv, total, g_dot_ws[dv]);
-    else hipLaunchKernelGGL(energy_norms_kernel<1>, dim3(nb), dim3(256), 0, st, f, t1, t2, Edir, Eex, dt2, no, nv, total, g_dot_ws[dv]);
-    HIP_CHECK(hipGetLastError());
+    const EnergyK k{f, t1, t2, Edir, Eex, dt2, g_dot_ws[dv], total, no, nv};
+    const double cost = (dt2 ? 32.0 : 24.0) * (double)total / 4.0e6;
+    if (phase_open(st) && phase_small(cost)) {
+        PhaseRec& t = phase_push(PK_ENERGY, vec ? 1 : 0, nb, 0, cost, k);
+        const long n = no + nv;
+        phase_reads(t, {prange(t2, total), prange(Edir, total), prange(Eex, total), prange(dt2, dt2 ? total : 0),
+                        prange(t1, t1 ? (long)no * nv : 0), prange(f, (t1 && f) ? n * n : 0)});
+        phase_writes(t, {prange(g_dot_ws[dv], 16L * kDotBlocks)});
+    } else {
+        if (vec) PYMES_LAUNCH(energy_norms_kernel<2>, dim3(nb), dim3(256), 0, st, k);
+        else PYMES_LAUNCH(energy_norms_kernel<1>, dim3(nb), dim3(256), 0, st, k);
+        HIP_CHECK(hipGetLastError());
+    }
     double* out_dev = g_dot_ws[dv] + 16 * kDotBlocks;
-    hipLaunchKernelGGL(dots_stage2_kernel, dim3(6), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);
-    HIP_CHECK(hipGetLastError());
+    launch_dots_stage2(6, g_dot_ws[dv], nb, out_dev, st);
     return readback_start_impl(out_dev, 6, st);
 }
 void energy_norms(const double* f, const double* t1, const double* t2, const double* Edir, const double* Eex,
@@ -3899,10 +4609,10 @@ void exchange_asymmetry(const double* A, const double* B, const int64_t d[4], do
     const unsigned grid = (unsigned)std::min<long>(ntiles, 256L * 8);
     const bool vec = even(d[2]) && even(d[3]) && aligned16(A) && aligned16(B);
     if (vec)
-        hipLaunchKernelGGL(exchange_asym_kernel<true>, dim3(grid), dim3(256), 0, st, A, B, (long)d[0], (long)d[1], (long)d[2],
+        PYMES_LAUNCH(exchange_asym_kernel<true>, dim3(grid), dim3(256), 0, st, A, B, (long)d[0], (long)d[1], (long)d[2],
                            (long)d[3], (int)tr, (int)ts, ntiles, self, out_dev);
     else
-        hipLaunchKernelGGL(exchange_asym_kernel<false>, dim3(grid), dim3(256), 0, st, A, B, (long)d[0], (long)d[1], (long)d[2],
+        PYMES_LAUNCH(exchange_asym_kernel<false>, dim3(grid), dim3(256), 0, st, A, B, (long)d[0], (long)d[1], (long)d[2],
                            (long)d[3], (int)tr, (int)ts, ntiles, self, out_dev);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(g_dot_host[dv], out_dev, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
@@ -3916,7 +4626,15 @@ void lincomb(double* out, int nx, const double* const* x, const double* c, int64
     if (n <= 0) return;
     LinPtrs p;
     for (int i = 0; i < 8; ++i) { p.x[i] = i < nx ? x[i] : nullptr; p.c[i] = i < nx ? c[i] : 0.0; }
-    hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, out, p, nx, (long)n);
+    const LinK k{out, p, (long)n, nx};
+    const double cost = 8.0 * (double)(nx + 1) * (double)n / 4.0e6;
+    if (phase_open((hipStream_t)s) && phase_small(cost)) {
+        PhaseRec& t = phase_push(PK_LINCOMB, 0, grid_for(n), 0, cost, k);
+        for (int i = 0; i < nx; ++i) phase_reads(t, {prange(x[i], n)});
+        phase_writes(t, {prange(out, n)});
+        return;
+    }
+    PYMES_LAUNCH(lincomb_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, k);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -3927,10 +4645,10 @@ void gram_tile(const double* const* x, int mm, const double* const* y, int nn, l
     GramPtrs<MM, NN> p;
     for (int i = 0; i < MM; ++i) p.x[i] = x[i < mm ? i : 0];
     for (int j = 0; j < NN; ++j) p.y[j] = y[j < nn ? j : 0];
-    if (vec) hipLaunchKernelGGL((gram_stage1_kernel<MM, NN, 2>), dim3(nblk), dim3(256), 0, st, p, len, ws);
-    else hipLaunchKernelGGL((gram_stage1_kernel<MM, NN, 1>), dim3(nblk), dim3(256), 0, st, p, len, ws);
+    if (vec) PYMES_LAUNCH((gram_stage1_kernel<MM, NN, 2>), dim3(nblk), dim3(256), 0, st, p, len, ws);
+    else PYMES_LAUNCH((gram_stage1_kernel<MM, NN, 1>), dim3(nblk), dim3(256), 0, st, p, len, ws);
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(gram_stage2_kernel, dim3(MM * NN), dim3(256), 0, st, ws, nblk, MM * NN, tile_dev);
+    PYMES_LAUNCH(gram_stage2_kernel, dim3(MM * NN), dim3(256), 0, st, ws, nblk, MM * NN, tile_dev);
     HIP_CHECK(hipGetLastError());
 }
 template <int MM>
@@ -3952,8 +4670,8 @@ void lincomb_multi_tile(const double* const* x, int mm, const double* c, int ldc
     for (int j = 0; j < NN; ++j) { p.y[j] = y[j < nn ? j : 0]; p.beta[j] = j < nn ? beta[j] : 0.0; }
     const long nvec = vec ? len / 2 : len;
     const int nblk = (int)std::max<long>(1, std::min<long>(8192, (nvec + 255) / 256));
-    if (vec) hipLaunchKernelGGL((lincomb_multi_kernel<MM, NN, 2>), dim3(nblk), dim3(256), 0, st, p, nn, len);
-    else hipLaunchKernelGGL((lincomb_multi_kernel<MM, NN, 1>), dim3(nblk), dim3(256), 0, st, p, nn, len);
+    if (vec) PYMES_LAUNCH((lincomb_multi_kernel<MM, NN, 2>), dim3(nblk), dim3(256), 0, st, p, nn, len);
+    else PYMES_LAUNCH((lincomb_multi_kernel<MM, NN, 1>), dim3(nblk), dim3(256), 0, st, p, nn, len);
     HIP_CHECK(hipGetLastError());
 }
 template <int MM>
@@ -4059,21 +4777,21 @@ void lincomb_multi(int m, int n, const double* const* x, const double* c, const 
 
 void cmul(const double* mr, const double* mi, const double* xr, const double* xi, double* yr, double* yi, int64_t n, stream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(cmul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, mr, mi, xr, xi, yr, yi, (long)n);
+    PYMES_LAUNCH(cmul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, mr, mi, xr, xi, yr, yi, (long)n);
     HIP_CHECK(hipGetLastError());
 }
 
 void exchange_split(const double* u, double* us, double* w, double* dg, int no, int nv, stream_t s) {
     const long total = (long)nv * nv * no * no;
     if (!total) return;
-    hipLaunchKernelGGL(exchange_split_kernel, dim3(grid_for(total, 256, 256 * 64)), dim3(256), 0, (hipStream_t)s, u, us, w, dg, no, nv,
+    PYMES_LAUNCH(exchange_split_kernel, dim3(grid_for(total, 256, 256 * 64)), dim3(256), 0, (hipStream_t)s, u, us, w, dg, no, nv,
                        total);
     HIP_CHECK(hipGetLastError());
 }
 void sgn_ij_add(double* D, const double* R, int no, int nv, stream_t s) {
     const long total = (long)nv * nv * no * no;
     if (!total) return;
-    hipLaunchKernelGGL(sgn_ij_add_kernel, dim3(grid_for(total, 256, 256 * 64)), dim3(256), 0, (hipStream_t)s, D, R, no, total);
+    PYMES_LAUNCH(sgn_ij_add_kernel, dim3(grid_for(total, 256, 256 * 64)), dim3(256), 0, (hipStream_t)s, D, R, no, total);
     HIP_CHECK(hipGetLastError());
 }
 int64_t eom_diag_ws_doubles(int no, int nv) { return EomDiagWs(no, nv).total; }
@@ -4083,26 +4801,34 @@ void eom_diagonals(const double* V, const double* T, const double* dai, const do
     const EomDiagWs w(no, nv);
     const long total = (long)nv * nv * no * no;
     if (w.total > 0x7fffffffL) throw std::runtime_error("eom_diagonals: problem too large for one grid");
-    hipLaunchKernelGGL(eom_diag_sums_kernel, dim3((unsigned)w.total), dim3(256), 0, st, V, T, ws, no, nv);
+    PYMES_LAUNCH(eom_diag_sums_kernel, dim3((unsigned)w.total), dim3(256), 0, st, V, T, ws, no, nv);
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(eom_diag_singles_kernel, dim3((unsigned)(((long)nv * no + 255) / 256)), dim3(256), 0, st, ws, dai, iaai, iaia,
+    PYMES_LAUNCH(eom_diag_singles_kernel, dim3((unsigned)(((long)nv * no + 255) / 256)), dim3(256), 0, st, ws, dai, iaai, iaia,
                        d1, no, nv);
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(eom_diag_doubles_kernel, dim3(grid_for(total, 256, 256 * 64)), dim3(256), 0, st, V, T, ws, dai, iaai, iaia, ijij,
+    PYMES_LAUNCH(eom_diag_doubles_kernel, dim3(grid_for(total, 256, 256 * 64)), dim3(256), 0, st, V, T, ws, dai, iaai, iaia, ijij,
                        abab, d2, no, nv, total);
     HIP_CHECK(hipGetLastError());
 }
 void cshift_inv(const double* d, double zr, double zi, double hr, double hi, double shift, double* mr, double* mi, int64_t n,
                 stream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(cshift_inv_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, d, zr, zi, hr, hi, shift, mr, mi, (long)n);
+    PYMES_LAUNCH(cshift_inv_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, d, zr, zi, hr, hi, shift, mr, mi, (long)n);
     HIP_CHECK(hipGetLastError());
 }
 
 void tau_build(double* tau, const double* t2, const double* t1, int no, int nv, stream_t s) {
     const long total = (long)nv * nv * no * no;
     if (!total) return;
-    hipLaunchKernelGGL(tau_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, tau, t2, t1, no, nv, total);
+    const TauK k{tau, t2, t1, total, no, nv};
+    const double cost = 16.0 * (double)total / 4.0e6;
+    if (phase_open((hipStream_t)s) && phase_small(cost)) {
+        PhaseRec& t = phase_push(PK_TAU, 0, grid_for(total), 0, cost, k);
+        phase_reads(t, {prange(t2, total), prange(t1, (long)no * nv)});
+        phase_writes(t, {prange(tau, total)});
+        return;
+    }
+    PYMES_LAUNCH(tau_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, k);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -4114,7 +4840,7 @@ void ladder_pack_V(const double* V, double* Vp, double* Vm, int nr, int nc, int6
     const long ntp = (long)nt * (nt + 1) / 2;
     const long nblk = (rp1 - rp0) * ntp;
     if (nblk > 0x7fffffffL) throw std::runtime_error("ladder_pack_V: grid too large");
-    hipLaunchKernelGGL(ladder_pack_V_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)s, V, Vp, Vm, nr, nc,
+    PYMES_LAUNCH(ladder_pack_V_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)s, V, Vp, Vm, nr, nc,
                        (long)rp0, nt, ntp, npp, npm);
     HIP_CHECK(hipGetLastError());
 }
@@ -4146,8 +4872,8 @@ void ladder_dress(const double* V, const double* Pk, const double* t1, double* W
     hipStream_t st = (hipStream_t)s;
     const int nk = (no + 3) / 4;
     const long nfrag = ladder_dress_ws_doubles(no, nv);
-    hipLaunchKernelGGL(ladder_dress_tfrag_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, t1, ws, no, nv, nk, nfrag);
-#define PYMES_DRESS(NK) case NK: hipLaunchKernelGGL(ladder_dress_kernel<NK>, grid, block, 0, st, V, Pk, (const double*)ws, W, no, nv, (long)ld, (long)row0, (long)row1, sgn, ntp); break;
+    PYMES_LAUNCH(ladder_dress_tfrag_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, t1, ws, no, nv, nk, nfrag);
+#define PYMES_DRESS(NK) case NK: PYMES_LAUNCH(ladder_dress_kernel<NK>, grid, block, 0, st, V, Pk, (const double*)ws, W, no, nv, (long)ld, (long)row0, (long)row1, sgn, ntp); break;
     switch (nk) {
         PYMES_DRESS(1) PYMES_DRESS(2) PYMES_DRESS(3) PYMES_DRESS(4) PYMES_DRESS(5) PYMES_DRESS(6) PYMES_DRESS(7) PYMES_DRESS(8)
         PYMES_DRESS(9) PYMES_DRESS(10) PYMES_DRESS(11) PYMES_DRESS(12) PYMES_DRESS(13) PYMES_DRESS(14) PYMES_DRESS(15) PYMES_DRESS(16)
@@ -4167,15 +4893,33 @@ void ladder_pack_T(const double* X, const double* t1, double* Sp, double* Am, in
     if (rp0 < 0 || rp1 > npp || rp0 > rp1) throw std::runtime_error("ladder_pack_T: bad row range");
     if ((rp0 != 0 || rp1 != npp) && !(flags & PACK_AM_PROWS)) throw std::runtime_error("ladder_pack_T: a row range needs PACK_AM_PROWS");
     if (rp1 == rp0) return;
-    hipLaunchKernelGGL(ladder_pack_T_kernel, dim3((unsigned)(rp1 - rp0)), dim3(256), 0, (hipStream_t)s, X, t1, Sp, Am, nc, nr,
-                       flags, (long)ldp, (long)ldm, (long)rp0);
+    const PackTK k{X, t1, Sp, Am, (long)ldp, (long)ldm, (long)rp0, nc, nr, flags};
+    const double cost = 24.0 * (double)(rp1 - rp0) * (double)nc * (double)nc / 4.0e6;
+    if (phase_open((hipStream_t)s) && phase_small(cost)) {
+        PhaseRec& t = phase_push(PK_PACK_T, 0, rp1 - rp0, 0, cost, k);
+        phase_reads(t, {prange(X, X ? (long)nr * nr * nc * nc : 0), prange(t1, t1 ? (long)nr * nc : 0)});
+        // Sp rows [rp0, rp1); Am rows: the same pairs (PACK_AM_PROWS) or the strictly-lower pairs (all rows when the range is full)
+        const long am_rows = (flags & PACK_AM_PROWS) ? npp : (long)nr * (nr - 1) / 2;
+        phase_writes(t, {pbox(Sp + rp0 * ldp, {{rp1 - rp0, ldp}, {ldp, 1}}),
+                         (flags & PACK_AM_PROWS) ? pbox(Am + rp0 * ldm, {{rp1 - rp0, ldm}, {ldm, 1}}) : prange(Am, am_rows * ldm)});
+        return;
+    }
+    PYMES_LAUNCH(ladder_pack_T_kernel, dim3((unsigned)(rp1 - rp0)), dim3(256), 0, (hipStream_t)s, k);
     HIP_CHECK(hipGetLastError());
 }
 
 void ladder_unpack(const double* L, double* R, double beta, int no, int nv, stream_t s) {
     const long total = (long)nv * nv * no * no;
-    hipLaunchKernelGGL(ladder_unpack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, L, R, beta, no, nv,
-                       total);
+    if (!total) return;
+    const UnpackK k{L, R, beta, total, no, nv};
+    const double cost = 20.0 * (double)total / 4.0e6;
+    if (phase_open((hipStream_t)s) && phase_small(cost)) {
+        PhaseRec& t = phase_push(PK_LADDER_UNPACK, 0, grid_for(total), 0, cost, k);
+        phase_reads(t, {prange(L, (long)nv * (nv + 1) / 2 * no * no)});
+        phase_writes(t, {prange(R, total)});
+        return;
+    }
+    PYMES_LAUNCH(ladder_unpack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, k);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -4186,18 +4930,34 @@ void ring_operands(const double* Viabj, const double* Viajb, double* M, double* 
     if (no < 1 || nv < 1) return;
     const size_t lds = sizeof(double) * (size_t)no * 33;
     if (lds > 64 * 1024) throw std::runtime_error("ring_operands: nocc too large for the LDS tile");
-    hipLaunchKernelGGL(ring_operands_kernel, dim3((unsigned)((long)no * nv)), dim3(256), lds, (hipStream_t)s, Viabj, Viajb, M, N1,
-                       a1, a2, no, nv);
+    const RingOpK k{Viabj, Viajb, M, N1, a1, a2, no, nv};
+    const long ov2 = (long)no * nv * no * nv;
+    const double cost = 32.0 * (double)ov2 / 4.0e6;
+    if (phase_open((hipStream_t)s) && phase_small(cost)) {
+        PhaseRec& t = phase_push(PK_RING_OPERANDS, 0, (long)no * nv, (int)lds, cost, k);
+        phase_reads(t, {prange(Viabj, ov2), prange(Viajb, ov2)});
+        phase_writes(t, {prange(M, ov2), prange(N1, ov2)});
+        return;
+    }
+    PYMES_LAUNCH(ring_operands_kernel, dim3((unsigned)((long)no * nv)), dim3(256), lds, (hipStream_t)s, k);
     HIP_CHECK(hipGetLastError());
 }
 
 void t2_layouts(const double* T, double* Td, double* Tx, double* Ttd, int no, int nv, stream_t s, double ca, double cb) {
     if (!fused_pair_kernels_ok(no)) throw std::runtime_error("t2_layouts: nocc too large for the LDS tile");
     const size_t lds = sizeof(double) * no * (no + 1);
-    if (ca == 2.0 && cb == -1.0)
-        hipLaunchKernelGGL(t2_layouts_kernel<true>, dim3((unsigned)(nv * nv)), dim3(256), lds, (hipStream_t)s, T, Td, Tx, Ttd, no, nv, ca, cb);
-    else
-        hipLaunchKernelGGL(t2_layouts_kernel<false>, dim3((unsigned)(nv * nv)), dim3(256), lds, (hipStream_t)s, T, Td, Tx, Ttd, no, nv, ca, cb);
+    const LayoutsK k{T, Td, Tx, Ttd, ca, cb, no, nv};
+    const bool res = ca == 2.0 && cb == -1.0;
+    const long n4 = (long)nv * nv * no * no;
+    const double cost = 40.0 * (double)n4 / 4.0e6;
+    if (phase_open((hipStream_t)s) && phase_small(cost)) {
+        PhaseRec& t = phase_push(PK_T2_LAYOUTS, res ? 1 : 0, (long)nv * nv, (int)lds, cost, k);
+        phase_reads(t, {prange(T, n4)});
+        phase_writes(t, {prange(Td, Td ? n4 : 0), prange(Tx, n4), prange(Ttd, n4)});
+        return;
+    }
+    if (res) PYMES_LAUNCH(t2_layouts_kernel<true>, dim3((unsigned)(nv * nv)), dim3(256), lds, (hipStream_t)s, k);
+    else PYMES_LAUNCH(t2_layouts_kernel<false>, dim3((unsigned)(nv * nv)), dim3(256), lds, (hipStream_t)s, k);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -4205,8 +4965,16 @@ void residual_assemble(const double* V, const double* L, const double* N, const 
                        int no, int nv, stream_t s, double xd) {
     if (!fused_pair_kernels_ok(no)) throw std::runtime_error("residual_assemble: nocc too large for the LDS tile");
     const size_t lds = sizeof(double) * no * (no + 1);
-    hipLaunchKernelGGL(residual_assemble_kernel, dim3((unsigned)((long)nv * (nv + 1) / 2)), dim3(256), lds, (hipStream_t)s,
-                       V, L, N, D, X, R, no, nv, xd);
+    const AssembleK k{V, L, N, D, X, R, xd, no, nv};
+    const long n4 = (long)nv * nv * no * no;
+    const double cost = 48.0 * (double)n4 / 4.0e6;
+    if (phase_open((hipStream_t)s) && phase_small(cost)) {
+        PhaseRec& t = phase_push(PK_ASSEMBLE, 0, (long)nv * (nv + 1) / 2, (int)lds, cost, k);
+        phase_reads(t, {prange(V, V ? n4 : 0), prange(L, L ? (long)nv * (nv + 1) / 2 * no * no : 0), prange(N, n4), prange(D, n4), prange(X, n4)});
+        phase_writes(t, {prange(R, n4)});
+        return;
+    }
+    PYMES_LAUNCH(residual_assemble_kernel, dim3((unsigned)((long)nv * (nv + 1) / 2)), dim3(256), lds, (hipStream_t)s, k);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -4219,7 +4987,7 @@ void scatter(double* dst, const int64_t* idx_host, const double* val_host, int64
     hipStream_t st = (hipStream_t)s;
     HIP_CHECK(hipMemcpyAsync(idx, idx_host, sizeof(long) * n, hipMemcpyHostToDevice, st));
     HIP_CHECK(hipMemcpyAsync(val, val_host, sizeof(double) * n, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(scatter_kernel, dim3(grid_for(n)), dim3(256), 0, st, dst, idx, val, (long)n);
+    PYMES_LAUNCH(scatter_kernel, dim3(grid_for(n)), dim3(256), 0, st, dst, idx, val, (long)n);
     const hipError_t e = hipGetLastError();
     (void)hipStreamSynchronize(st);
     (void)hipFree(idx);
@@ -4232,7 +5000,7 @@ void hf_fock(const double* const dir[4], const double* const exc[4], const doubl
     HfBlocks B;
     for (int i = 0; i < 4; ++i) { B.dir[i] = dir[i]; B.exc[i] = exc[i]; }
     const int n = no + nv;
-    hipLaunchKernelGGL(hf_fock_kernel, dim3((n * n + 255) / 256), dim3(256), 0, (hipStream_t)s, B, h_dev, f_dev, no, nv);
+    PYMES_LAUNCH(hf_fock_kernel, dim3((n * n + 255) / 256), dim3(256), 0, (hipStream_t)s, B, h_dev, f_dev, no, nv);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -4257,7 +5025,7 @@ int64_t fcidump_fill(double* V, const double* val_host, const int32_t* pqrs_host
             err = hipMemcpyAsync(dval, val_host + b0, sizeof(double) * nb, hipMemcpyHostToDevice, st);
             if (err == hipSuccess) err = hipMemcpyAsync(didx, pqrs_host + 4 * b0, sizeof(int) * 4 * nb, hipMemcpyHostToDevice, st);
             if (err != hipSuccess) break;
-            hipLaunchKernelGGL(fcidump_fill_kernel, dim3(grid_for(nb)), dim3(256), 0, st, V, dval, didx, (long)nb, (long)n,
+            PYMES_LAUNCH(fcidump_fill_kernel, dim3(grid_for(nb)), dim3(256), 0, st, V, dval, didx, (long)nb, (long)n,
                                is_tc ? 1 : 0, pass, dbad);
             err = hipGetLastError();
             if (err == hipSuccess) err = hipStreamSynchronize(st);      // the staging buffers are reused
@@ -4270,17 +5038,17 @@ int64_t fcidump_fill(double* V, const double* val_host, const int32_t* pqrs_host
 
 void tc_single_contraction(const double* L, double* D, int nb, int no, stream_t s) {
     const long total = (long)nb * nb * nb * nb;
-    hipLaunchKernelGGL(tc_single_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, L, D, nb, no, total);
+    PYMES_LAUNCH(tc_single_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, L, D, nb, no, total);
     HIP_CHECK(hipGetLastError());
 }
 void tc_double_contraction(const double* L, double* S, int nb, int no, stream_t s) {
-    hipLaunchKernelGGL(tc_double_kernel, dim3((nb * nb + 255) / 256), dim3(256), 0, (hipStream_t)s, L, S, nb, no);
+    PYMES_LAUNCH(tc_double_kernel, dim3((nb * nb + 255) / 256), dim3(256), 0, (hipStream_t)s, L, S, nb, no);
     HIP_CHECK(hipGetLastError());
 }
 double tc_triple_contraction(const double* L, int nb, int no, stream_t s) {
     double* out = nullptr;
     HIP_CHECK(hipMalloc(&out, sizeof(double)));
-    hipLaunchKernelGGL(tc_triple_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, L, out, nb, no);
+    PYMES_LAUNCH(tc_triple_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, L, out, nb, no);
     double h = 0.0;
     const hipError_t e1 = hipGetLastError();
     const hipError_t e2 = hipMemcpyAsync(&h, out, sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)s);
@@ -4293,7 +5061,7 @@ double tc_triple_contraction(const double* L, int nb, int no, stream_t s) {
 
 void pairs_pack(const double* full, double* Xc, int no, int nv, int64_t r0, int64_t r1, stream_t s) {
     if (r1 <= r0) return;
-    hipLaunchKernelGGL(pairs_pack_kernel, dim3((unsigned)(r1 - r0)), dim3(256), 0, (hipStream_t)s, full, Xc, no, nv, (long)r0);
+    PYMES_LAUNCH(pairs_pack_kernel, dim3((unsigned)(r1 - r0)), dim3(256), 0, (hipStream_t)s, full, Xc, no, nv, (long)r0);
     HIP_CHECK(hipGetLastError());
 }
 void energy_norms_pairs(const double* f, const double* t1, const double* tc, const double* Edir, const double* Eex,
@@ -4304,11 +5072,11 @@ void energy_norms_pairs(const double* f, const double* t1, const double* tc, con
     ensure_dot_ws(dv);
     const long npairs = std::max<long>(0, (long)(r1 - r0));
     const int nb = (int)std::max<long>(1, std::min<long>(kDotBlocks, 2 * npairs));
-    hipLaunchKernelGGL(energy_norms_pairs_kernel, dim3(nb), dim3(256), 0, st, f, t1, tc, Edir, Eex, dtc, no, nv, (long)r0,
+    PYMES_LAUNCH(energy_norms_pairs_kernel, dim3(nb), dim3(256), 0, st, f, t1, tc, Edir, Eex, dtc, no, nv, (long)r0,
                        npairs, with_t1 ? 1 : 0, g_dot_ws[dv]);
     HIP_CHECK(hipGetLastError());
     double* out_dev = g_dot_ws[dv] + 16 * kDotBlocks;
-    hipLaunchKernelGGL(dots_stage2_kernel, dim3(6), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);
+    PYMES_LAUNCH(dots_stage2_kernel, dim3(6), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(g_dot_host[dv], out_dev, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
     wait_idle(st);
@@ -4322,21 +5090,21 @@ void energy_norms_pairs_dev(const double* f, const double* t1, const double* tc,
     ensure_dot_ws(dv);
     const long npairs = std::max<long>(0, (long)(r1 - r0));
     const int nb = (int)std::max<long>(1, std::min<long>(kDotBlocks, 2 * npairs));
-    hipLaunchKernelGGL(energy_norms_pairs_kernel, dim3(nb), dim3(256), 0, st, f, t1, tc, Edir, Eex, dtc, no, nv, (long)r0,
+    PYMES_LAUNCH(energy_norms_pairs_kernel, dim3(nb), dim3(256), 0, st, f, t1, tc, Edir, Eex, dtc, no, nv, (long)r0,
                        npairs, with_t1 ? 1 : 0, g_dot_ws[dv]);
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(dots_stage2_kernel, dim3(6), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);
+    PYMES_LAUNCH(dots_stage2_kernel, dim3(6), dim3(256), 0, st, g_dot_ws[dv], nb, out_dev);
     HIP_CHECK(hipGetLastError());
 }
 void pairs_unpack(const double* Xc, double* full, int no, int nv, int64_t r0, int64_t r1, stream_t s) {
     if (r1 <= r0) return;
-    hipLaunchKernelGGL(pairs_unpack_kernel, dim3((unsigned)(r1 - r0)), dim3(256), 0, (hipStream_t)s, Xc, full, no, nv, (long)r0);
+    PYMES_LAUNCH(pairs_unpack_kernel, dim3((unsigned)(r1 - r0)), dim3(256), 0, (hipStream_t)s, Xc, full, no, nv, (long)r0);
     HIP_CHECK(hipGetLastError());
 }
 void cc_update_pairs(double* tc, double* dtc, const double* rc, const double* eo, const double* ev, double shift,
                      double delta, int no, int nv, int64_t r0, int64_t r1, stream_t s) {
     if (r1 <= r0) return;
-    hipLaunchKernelGGL(cc_update_pairs_kernel, dim3((unsigned)(r1 - r0)), dim3(256), 0, (hipStream_t)s, tc, dtc, rc, eo, ev,
+    PYMES_LAUNCH(cc_update_pairs_kernel, dim3((unsigned)(r1 - r0)), dim3(256), 0, (hipStream_t)s, tc, dtc, rc, eo, ev,
                        shift, delta, no, (long)r0);
     HIP_CHECK(hipGetLastError());
 }
@@ -4345,7 +5113,7 @@ void residual_assemble_pairs(const double* V, const double* L, const double* Np,
     if (r1 <= r0) return;
     if (!fused_pair_kernels_ok(no)) throw std::runtime_error("residual_assemble_pairs: nocc too large for the LDS tile");
     const size_t lds = sizeof(double) * no * (no + 1);
-    hipLaunchKernelGGL(residual_assemble_pairs_kernel, dim3((unsigned)(r1 - r0)), dim3(256), lds, (hipStream_t)s, V, L, Np,
+    PYMES_LAUNCH(residual_assemble_pairs_kernel, dim3((unsigned)(r1 - r0)), dim3(256), lds, (hipStream_t)s, V, L, Np,
                        D, X, Rc, no, nv, (long)r0, a0, nbp, xd);
     HIP_CHECK(hipGetLastError());
 }
@@ -4353,7 +5121,15 @@ void residual_assemble_pairs(const double* V, const double* L, const double* Np,
 void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t s) {
     const long total = (long)rows * no * no;
     if (!total) return;
-    hipLaunchKernelGGL(rows_unpack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, Q, out, no, total);
+    const RowsUnpackK k{Q, out, total, no};
+    const double cost = 16.0 * (double)total / 4.0e6;
+    if (phase_open((hipStream_t)s) && phase_small(cost)) {
+        PhaseRec& t = phase_push(PK_ROWS_UNPACK, 0, grid_for(total), 0, cost, k);
+        phase_reads(t, {prange(Q, total)});
+        phase_writes(t, {prange(out, total)});
+        return;
+    }
+    PYMES_LAUNCH(rows_unpack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, k);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -4374,21 +5150,43 @@ void fock_g12(const double* V, const double* t1, double* G1, double* G2, int no,
     const size_t lds = sizeof(double) * 6 * (size_t)nv;
     const dim3 grid((unsigned)(na * used)), block(256);
     const bool vec2 = !(nv & 1) && !(reinterpret_cast<uintptr_t>(V) & 15);
-    if (vec2) hipLaunchKernelGGL(fock_g12_kernel<2>, grid, block, lds, st, V, t1, ws, no, nv, na, j0, j1, jper);
-    else if (nv <= 512) hipLaunchKernelGGL(fock_g12_kernel<1>, grid, block, lds, st, V, t1, ws, no, nv, na, j0, j1, jper);
-    else throw std::runtime_error("fock_g12: unaligned block with nvirt above 512");
-    HIP_CHECK(hipGetLastError());
+    if (!vec2 && nv > 512) throw std::runtime_error("fock_g12: unaligned block with nvirt above 512");
     const long av = (long)na * nv;
-    hipLaunchKernelGGL(fock_g12_finish_kernel, dim3((unsigned)((av + 255) / 256)), dim3(256), 0, st, ws, used, av, G1, G2);
+    const FockG12K k{V, t1, ws, no, nv, na, j0, j1, jper};
+    const FockG12FinK kf{ws, G1, G2, av, used};
+    const double cost = 8.0 * (double)nj * (double)av * (double)nv / 4.0e6;
+    if (phase_open(st) && phase_small(cost)) {
+        PhaseRec& t = phase_push(PK_FOCK_G12, vec2 ? 1 : 0, (long)na * used, (int)lds, cost, k);
+        phase_reads(t, {prange(V + (long)j0 * av * nv, (long)nj * av * nv), prange(t1, (long)no * nv)});
+        phase_writes(t, {prange(ws, (long)used * 2 * av)});
+        PhaseRec& u = phase_push(PK_FOCK_G12_FIN, 0, (av + 255) / 256, 0, 1.0, kf);
+        phase_reads(u, {prange(ws, (long)used * 2 * av)});
+        phase_writes(u, {prange(G1, av), prange(G2, av)});
+        return;
+    }
+    if (vec2) PYMES_LAUNCH(fock_g12_kernel<2>, grid, block, lds, st, k);
+    else PYMES_LAUNCH(fock_g12_kernel<1>, grid, block, lds, st, k);
+    HIP_CHECK(hipGetLastError());
+    PYMES_LAUNCH(fock_g12_finish_kernel, dim3((unsigned)((av + 255) / 256)), dim3(256), 0, st, kf);
     HIP_CHECK(hipGetLastError());
 }
 
 void fock_finish(const double* f, const double* t1, const double* W, double* fd, double* ft, int no, int nv, stream_t s) {
     const long n = no + nv;
-    hipLaunchKernelGGL(fock_ft_kernel, dim3((unsigned)((no * no + 255) / 256)), dim3(256), 0, (hipStream_t)s, f, t1, W, ft, no, nv);
+    const FockFinK k{f, t1, W, ft, fd, no, nv};
+    if (phase_open((hipStream_t)s)) {
+        const long wlen = 2L * nv * nv + 4L * no * nv + 2L * no * no;        // G1 G2 J1 J2 L1 L2 K1 K2
+        PhaseRec& t = phase_push(PK_FOCK_FT, 0, (no * no + 255) / 256, 0, 2.0, k);
+        phase_reads(t, {prange(f, n * n), prange(t1, (long)no * nv), prange(W, wlen)});
+        phase_writes(t, {prange(ft, (long)no * no)});
+        PhaseRec& u = phase_push(PK_FOCK_FIN, 0, (n * n + 255) / 256, 0, 3.0, k);
+        phase_reads(u, {prange(f, n * n), prange(t1, (long)no * nv), prange(W, wlen), prange(ft, (long)no * no)});
+        phase_writes(u, {prange(fd, n * n)});
+        return;
+    }
+    PYMES_LAUNCH(fock_ft_kernel, dim3((unsigned)((no * no + 255) / 256)), dim3(256), 0, (hipStream_t)s, k);
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(fock_finish_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, (hipStream_t)s, f, t1, W, ft, fd,
-                       no, nv);
+    PYMES_LAUNCH(fock_finish_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, (hipStream_t)s, k);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -4396,8 +5194,16 @@ void pair_traces(const double* M, int64_t ld, double alpha, double beta, double*
                  stream_t s, const double* M2, double alpha2) {
     if (no <= 0 || nv <= 0) return;
     const unsigned blocks = (unsigned)nv * (unsigned)((nv + 15) / 16) + (unsigned)no;
-    hipLaunchKernelGGL(pair_traces_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, M, (long)ld, alpha, beta, out_vv, out_oo,
-                       no, nv, M2, alpha2);
+    const TracesK k{M, M2, out_vv, out_oo, (long)ld, alpha, beta, alpha2, no, nv};
+    const long ov = (long)no * nv;
+    const double cost = 128.0 / 3.0 * (double)ov * (double)ov / 8.0 / 4.0e6 * (M2 ? 2.0 : 1.0) + 3.0;
+    if (phase_open((hipStream_t)s) && phase_small(cost)) {
+        PhaseRec& t = phase_push(PK_TRACES, 0, blocks, kTracesLdsDoubles * (int)sizeof(double), cost, k);
+        phase_reads(t, {pbox(M, {{ov, ld}, {ov, 1}}), M2 ? pbox(M2, {{ov, ld}, {ov, 1}}) : PhaseRange{0, 0}});
+        phase_writes(t, {prange(out_vv, (long)nv * nv), prange(out_oo, (long)no * no)});
+        return;
+    }
+    PYMES_LAUNCH(pair_traces_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, k);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -4457,15 +5263,15 @@ void ueg_two_body(const UegParams& prm, const int* k_int_dev, const int* index_m
             HIP_CHECK(hipMemcpyAsync(dint_dev, dints.data(), sizeof(int) * 3 * nd, hipMemcpyHostToDevice, st));
             HIP_CHECK(hipMemcpyAsync(dk_dev, dks.data(), sizeof(double) * 3 * nd, hipMemcpyHostToDevice, st));
             HIP_CHECK(hipMemcpyAsync(uidx, index.data(), sizeof(int) * index.size(), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(ueg_nabla_kernel, dim3(nd), dim3(256), 0, st, u, dk_dev, dint_dev, umat);
+            PYMES_LAUNCH(ueg_nabla_kernel, dim3(nd), dim3(256), 0, st, u, dk_dev, dint_dev, umat);
             HIP_CHECK(hipGetLastError());
         } else if (prm.mode == 2) {
             E = (double*)dmalloc(sizeof(double) * n * n);
-            hipLaunchKernelGGL(ueg_effective_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, st, u, k_int_dev, E);
+            PYMES_LAUNCH(ueg_effective_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, st, u, k_int_dev, E);
             HIP_CHECK(hipGetLastError());
         }
         const long total = n * n * n;
-        hipLaunchKernelGGL(ueg_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, u, k_int_dev,
+        PYMES_LAUNCH(ueg_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, u, k_int_dev,
                            index_map_dev, umat, uidx, E, V_dev);
         HIP_CHECK(hipGetLastError());
         wait_idle(st);
@@ -4506,6 +5312,36 @@ bool gemv_dispatch(const dev::Gemm& g, long a_sm, long a_sk, long b_sk, long b_s
         rchunk = (R + nchunk - 1) / nchunk;
         nchunk = (R + rchunk - 1) / rchunk;
     }
+    if (phase_open(st)) {
+        const double cost = 8.0 * (double)R * (double)C / 4.0e6;
+        if (phase_small(cost)) {
+            const PhaseRange rW = pbox(W, {{R, ld}, {C, 1}}, 1);
+            if (cols) {
+                double* part = phase_ws(g.splitk_ws, g.splitk_ws_doubles, nchunk * C);
+                if (part) {
+                    GemvTaskK t;
+                    t.it.W = W; t.it.x = x; t.it.y = g.C; t.it.ld = ld; t.it.xs = xs; t.it.R = R; t.it.C = C; t.it.rchunk = rchunk;
+                    t.it.ys = ys; t.it.ws_off = 0; t.it.alpha = g.alpha; t.it.nchunk = (int)nchunk; t.it.cblocks = (int)cblocks;
+                    t.it.vec = vec; t.it.blk0 = t.it.out0 = 0;
+                    t.ws = part; t.yin = yin; t.beta = g.beta;
+                    const PhaseRange rP = prange(part, nchunk * C);
+                    PhaseRec& a = phase_push(PK_GEMV_COLS, 0, cblocks * nchunk, 0, cost, t);
+                    phase_reads(a, {rW, pbox(x, {{R, xs}})});
+                    phase_writes(a, {rP});
+                    PhaseRec& f = phase_push(PK_GEMV_FINISH, 0, (C + 255) / 256, 0, 1.0, t);
+                    phase_reads(f, {rP, g.beta != 0.0 ? pbox(yin, {{C, ys}}) : PhaseRange{0, 0}});
+                    phase_writes(f, {pbox(g.C, {{C, ys}})});
+                    return true;
+                }
+            } else {
+                GemvRowsK t{W, x, yin, g.C, ld, xs, R, C, ys, g.alpha, g.beta};
+                PhaseRec& a = phase_push(PK_GEMV_ROWS, vec == 2 ? 1 : 0, (R + 3) / 4, 0, cost, t);
+                phase_reads(a, {rW, pbox(x, {{C, xs}}), g.beta != 0.0 ? pbox(yin, {{R, ys}}) : PhaseRange{0, 0}});
+                phase_writes(a, {pbox(g.C, {{R, ys}})});
+                return true;
+            }
+        }
+    }
     {
         GemvBatch& b = g_gemv_batch;
         if (b.active && !g_prof.on) {        // (per-call event timing wants every product on its own)
@@ -4530,14 +5366,15 @@ bool gemv_dispatch(const dev::Gemm& g, long a_sm, long a_sk, long b_sk, long b_s
         HIP_CHECK(hipEventRecord(ev.first, st));
     }
     if (cols) {
-        if (vec == 2) hipLaunchKernelGGL(gemv_cols_kernel<2>, dim3((unsigned)cblocks, (unsigned)nchunk), dim3(256), 0, st, W, ld, x, xs, R, C, rchunk, g.splitk_ws);
-        else hipLaunchKernelGGL(gemv_cols_kernel<1>, dim3((unsigned)cblocks, (unsigned)nchunk), dim3(256), 0, st, W, ld, x, xs, R, C, rchunk, g.splitk_ws);
+        if (vec == 2) PYMES_LAUNCH(gemv_cols_kernel<2>, dim3((unsigned)cblocks, (unsigned)nchunk), dim3(256), 0, st, W, ld, x, xs, R, C, rchunk, g.splitk_ws);
+        else PYMES_LAUNCH(gemv_cols_kernel<1>, dim3((unsigned)cblocks, (unsigned)nchunk), dim3(256), 0, st, W, ld, x, xs, R, C, rchunk, g.splitk_ws);
         HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(gemv_finish_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, g.splitk_ws, (int)nchunk, C,
+        PYMES_LAUNCH(gemv_finish_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, g.splitk_ws, (int)nchunk, C,
                            g.alpha, g.beta, yin, g.C, ys);
     } else {
-        if (vec == 2) hipLaunchKernelGGL(gemv_rows_kernel<2>, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, W, ld, x, xs, R, C, g.alpha, g.beta, yin, g.C, ys);
-        else hipLaunchKernelGGL(gemv_rows_kernel<1>, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, W, ld, x, xs, R, C, g.alpha, g.beta, yin, g.C, ys);
+        const GemvRowsK rk{W, x, yin, g.C, ld, xs, R, C, ys, g.alpha, g.beta};
+        if (vec == 2) PYMES_LAUNCH(gemv_rows_kernel<2>, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, rk);
+        else PYMES_LAUNCH(gemv_rows_kernel<1>, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, rk);
     }
     HIP_CHECK(hipGetLastError());
     if (g_prof.on) {

@@ -326,6 +326,16 @@ class Context:
         assert eo.shape == (self.no,) and ev.shape == (self.nv,)
         self.lib.call("pymes_set_orbital_energies", self.handle, _lib.host_ptr(eo), _lib.host_ptr(ev))
 
+    def phase_enable(self, mode):
+        """Phase launches of the calling thread (include/pymes_amd.h): 1 on, 0 off, -1 as PYMES_PHASE says."""
+        self.lib.call("pymes_phase_enable", int(mode))
+
+    def phase_stats(self):
+        """(tasks recorded, grids launched, levels, flushes) by the calling thread so far."""
+        v = [C.c_int64() for _ in range(4)]
+        self.lib.call("pymes_phase_stats", *[C.byref(x) for x in v])
+        return dict(zip(("tasks", "launches", "levels", "flushes"), (int(x.value) for x in v)))
+
     @property
     def dress_generation(self):
         """How often the context's dressed blocks have been (re)written — counted by the engine itself, so that the

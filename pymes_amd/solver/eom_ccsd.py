@@ -122,6 +122,35 @@ class EOM_CCSD:
     def write_logging_info(self):
         return
 
+    def ritz_residuals(self, t_fock_dressed_pq, dict_t_V_dressed, t_T_abij):
+        """Certificate of the last device-resident ``solve``: for every returned root e_n the Ritz vector r_n = U v_n is
+        rebuilt from the basis of the last pass, the sigma build (eom_ccsd.py:268-385; pinned to the reference's own output at
+        this size) is applied to it ONCE MORE — a fresh ``_Sigma``, not the W = sigma(U) the driver carried along — and
+        ``|sigma(r_n) - e_n r_n| / |r_n|`` is returned.  Independent of the driver's bookkeeping: a wrong projection,
+        orthonormalisation, collapse or root choice shows up here as an O(1) number.  Not part of the reference's interface."""
+        if not isinstance(dict_t_V_dressed, DressedDeviceIntegrals) or getattr(self, "_ritz", None) is None:
+            raise RuntimeError("ritz_residuals: needs a finished device-resident solve() on these integrals")
+        ctx = dict_t_V_dressed.ctx
+        dict_t_V_dressed.require(_Sigma.BLOCKS)
+        f = t_fock_dressed_pq.get() if isinstance(t_fock_dressed_pq, DeviceArray) else np.asarray(t_fock_dressed_pq, dtype=np.float64)
+        t2 = t_T_abij if isinstance(t_T_abij, DeviceArray) else ctx.array(t_T_abij)
+        us, v, e = self._ritz
+        lay = self._layout(self.no, ctx.nv)
+        nflat = lay[2]
+        sig = _Sigma(ctx, f, t2, dressed=True)
+        rz = [ctx.empty((nflat,)) for _ in range(self.n_excit)]
+        ctx.lincomb_multi(rz, us, v)
+        wz = [self._zero_pad(ctx, ctx.empty((nflat,)), lay) for _ in rz]
+        u2s = [self._u2(ctx, r, lay) for r in rz]
+        sig.apply_many([self._u1(ctx, r, lay) for r in rz], u2s, [sig.exchange_symmetric(u2) for u2 in u2s],
+                       out1=[self._u1(ctx, w, lay) for w in wz], out2=[self._u2(ctx, w, lay) for w in wz])
+        out = []
+        for n in range(self.n_excit):        # the residual vector itself (its norm from the three inner products cancels at 1e-8)
+            z = ctx.empty((nflat,))
+            ctx.lincomb_multi([z], [wz[n], rz[n]], np.array([[1.0], [-e[n]]]))
+            out.append(float(np.sqrt(ctx.gram([z], [z])[0, 0] / ctx.gram([rz[n]], [rz[n]])[0, 0])))
+        return out
+
     # ---- device plumbing ------------------------------------------------------------------
     def _context(self, dict_t_V, nv):
         ctx = Context(self.no, nv, device=self.device)
@@ -243,6 +272,7 @@ class EOM_CCSD:
                 e = np.real(lam[pick])
                 v = np.real(vec[:, pick])
                 self.history.append(np.array(e))      # (the Ritz values of the pass; the reference only logs them)
+                self._ritz = (list(us), v, np.array(e)) if device_form else None     # for ritz_residuals()
                 if dim >= self.max_dim:                                              # collapse :122-133
                     # The next pass of the reference orthonormalises the Ritz vectors U v (:91) and builds their sigma vectors
                     # again.  U is orthonormal, so the Gram matrix of U v is v^T v: its Cholesky factor R is known without

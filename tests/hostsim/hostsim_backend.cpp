@@ -271,6 +271,14 @@ static bool g_group_open = false;
 void gemm_group_begin(stream_t) { g_group_open = true; g_group_launches = g_group_products = 0; }
 void gemm_group_end() { g_group_open = false; }
 void gemm_group_sync() {}
+void phase_sync() {}
+void phase_enable(int) {}
+void phase_stats(long* tasks, long* launches, long* levels, long* flushes) {
+    if (tasks) *tasks = 0;
+    if (launches) *launches = 0;
+    if (levels) *levels = 0;
+    if (flushes) *flushes = 0;
+}
 void gemm_group_stats(long* launches, long* products) {
     if (launches) *launches = g_group_launches;
     if (products) *products = g_group_products;

@@ -234,6 +234,14 @@ def check_davidson_golden(lib, monkeypatch, tag, device_form, reuse=True):
                 assert isinstance(Vd, DressedDeviceIntegrals) and Vd["aibj"] is None and Vd["abcd"].shape == (nv,) * 4
                 ee = eom.solve(fd, Vd, res["t2"])
                 assert eom.u_doubles[0].ctx is ints.ctx          # the trial space stays in HBM
+                # the certificate bench.py reports at (30,120), where no reference run exists: a FRESH sigma build applied to
+                # the rebuilt Ritz vectors — here, where the roots ARE the reference's, it shows the size a converged root has
+                # at the driver's stopping test (|dE| < 1e-8, eom_ccsd.py:150), and that a wrong pairing is O(1)
+                rr = eom.ritz_residuals(fd, Vd, res["t2"])
+                assert len(rr) == g["n_excit"] and max(rr) < 2e-4, rr
+                us, v, e = eom._ritz
+                eom._ritz = (us, v, e[::-1].copy())
+                assert min(eom.ritz_residuals(fd, Vd, res["t2"])[:1]) > 1e-2      # root 0's vector with the last root's energy
             finally:
                 ints.ctx.close()
         else:

@@ -27,6 +27,66 @@ def test_reader_matches_reference_values(capsys):
     assert np.count_nonzero(Vtc) == g["H2.321g"]["V_nnz_is_tc"] and abs(Vtc.sum() - g["H2.321g"]["V_sum_is_tc"]) < 1e-12
 
 
+def h2o_shape_file(tmp_path):
+    """The data file of BASELINE config 1's stand-in (oracle/make_golden_h2o_shape.py): gunzipped to a temporary path."""
+    import gzip
+    g = json.load(open(os.path.join(GOLD, "h2o_shape.json")))
+    path = str(tmp_path / "FCIDUMP.syn_5_19")
+    with gzip.open(os.path.join(GOLD, g["file"]["name"]), "rb") as src, open(path, "wb") as dst:
+        data = src.read()
+        dst.write(data)
+    assert len(data) == g["file"]["bytes"] and data.count(b"\n") == g["file"]["lines"]
+    return path, g
+
+
+def check_h2o_shape_chain(lib, monkeypatch, tmp_path, device_path):
+    """Config 1's plumbing on a file of H2O/cc-pVDZ's shape — 24 orbitals, 10 electrons, (5,19): text FCIDUMP -> native parser ->
+    HF matrix -> CCSD.solve / DCSD against what the REFERENCE's fcidump.read -> construct_hf_matrix -> CCSD.solve made of the
+    same file (pymes/test/test_ccsd/test_ccsd.py:11-27, pymes/util/fcidump.py:59-163)."""
+    import contextlib
+    import io
+    from pymes_amd import _lib
+    from pymes_amd.solver.ccsd import CCSD
+    monkeypatch.setattr(_lib, "_default", lib)
+    path, g = h2o_shape_file(tmp_path)
+    ctx = None
+    if device_path:
+        ne, n, ec, eps, h, V = fcidump.read_to_device(path)
+        ctx = V.ctx
+    else:
+        ne, n, ec, eps, h, V = fcidump.read(path)
+        assert abs(V.sum() - g["V_sum"]) < 1e-10 and np.count_nonzero(V) == g["V_nnz"]
+        assert abs(np.abs(V).sum() - g["V_abs_sum"]) < 1e-9
+    try:
+        assert (ne, n, ec) == (g["n_elec"], g["n_orb"], g["e_core"]) and (ne // 2, n - ne // 2) == (5, 19)
+        assert abs(h.sum() - g["h_sum"]) < 1e-11 and abs(np.abs(h).sum() - g["h_abs_sum"]) < 1e-11
+        no = ne // 2
+        f = hf.construct_hf_matrix(no, h, V)
+        assert np.abs(f.diagonal() - np.array(g["fock_diag"])).max() < 1e-12
+        assert np.abs(f - np.diag(f.diagonal())).max() < 1e-11
+        if not device_path:
+            assert abs(hf.calc_hf_e(no, ec, h, V) - g["e_hf"]) < 1e-11
+        for kind in ("ccsd", "dcsd"):
+            ref = g[kind]
+            s = CCSD(no, delta_e=ref["delta_e"], is_dcsd=(kind == "dcsd"))
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                res = s.solve(f, V)
+            assert abs(res["ccsd e"] - ref["e"]) < 1e-9, (kind, res["ccsd e"], ref["e"])
+            assert s.iterations == ref["iterations"]
+            assert abs(np.linalg.norm(res["t2"]) - ref["t2_norm"]) < 1e-8 and abs(np.linalg.norm(res["t1"]) - ref["t1_norm"]) < 1e-8
+            import re
+            hist = [float(x) for x in re.findall(r"Correlation Energy = (-?[0-9.eE+-]+)", buf.getvalue())]
+            assert len(hist) == len(ref["history"]) and np.abs(np.array(hist) - np.array(ref["history"])).max() < 1e-9
+    finally:
+        if ctx is not None:
+            ctx.close()
+
+
+def test_h2o_shape_chain_host_logic(hostsim_lib, monkeypatch, tmp_path):
+    check_h2o_shape_chain(hostsim_lib, monkeypatch, tmp_path, device_path=False)
+
+
 def test_write_read_round_trip(tmp_path, capsys):
     ne, n, ec, eps, h, V = fcidump.read(os.path.join(GOLD, "fcidump", "FCIDUMP.LiH.sto6g"))
     out = str(tmp_path / "FCIDUMP.rt")

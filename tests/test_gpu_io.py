@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.test_fcidump_hf import check_read_to_device
+from tests.test_fcidump_hf import check_h2o_shape_chain, check_read_to_device
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -17,6 +17,13 @@ def test_read_to_device(gpu_lib, monkeypatch, tmp_path):
     check_read_to_device(gpu_lib, monkeypatch, tmp_path, 12, 6, 3000)       # NORB <= 64: host fill + upload
     check_read_to_device(gpu_lib, monkeypatch, tmp_path, 66, 8, 30000)      # NORB > 64: fcidump_fill_kernel
     check_read_to_device(gpu_lib, monkeypatch, tmp_path, 70, 10, 5_000)
+
+
+@pytest.mark.parametrize("device_path", [False, True])
+def test_h2o_shape_chain_gpu(gpu_lib, monkeypatch, tmp_path, device_path):
+    """BASELINE config 1 as far as it exists here (README): a (5,19) FCIDUMP through the native parser, the HF
+    matrix and CCSD / DCSD on the HIP path — host arrays and device-resident blocks — against the reference's run on that file."""
+    check_h2o_shape_chain(gpu_lib, monkeypatch, tmp_path, device_path)
 
 
 def test_ccsd_from_device_fcidump(gpu_lib, monkeypatch):

@@ -1,6 +1,8 @@
 """Tall-skinny subspace algebra of the Davidson / FEAST drivers (pymes_gram, pymes_lincomb_multi: the device side of
 pymes/solver/eom_ccsd.py:91-147, :512-541) against numpy — through the host simulator on the CPU (C-ABI plumbing, chunking),
 on the GPU for the kernels."""
+import os
+
 import numpy as np
 import pytest
 
@@ -85,6 +87,11 @@ def check_grouped_products(lib, shapes, expect_grouped):
     ctx = Context(2, 3, lib=lib, workspace_bytes=1 << 28)
     rng = np.random.default_rng(11)
     try:
+        # the launch counts asked for are those of the GROUP machinery: with phase launches on (the default) the small
+        # products of a group are tasks of the open phase instead (include/pymes_amd.h; expect_grouped None: whatever is on)
+        if expect_grouped is not None:
+            ctx.phase_enable(0)
+        tasks0 = ctx.phase_stats()["tasks"]
         jobs = []
         for (M, N, K, a_kc, b_kc, alpha, beta) in shapes:
             A = rng.standard_normal((M, K) if a_kc else (K, M))
@@ -102,6 +109,7 @@ def check_grouped_products(lib, shapes, expect_grouped):
             assert err < 1e-13 * max(1, K) ** 0.5 + 1e-14, (M, N, K, a_kc, b_kc, alpha, beta, err)
         if expect_grouped is not None:
             assert grp.products == expect_grouped[0] and grp.launches == expect_grouped[1], (grp.products, grp.launches)
+            assert ctx.phase_stats()["tasks"] == tasks0
         # an einsum-style contraction that needs a transposed temporary inside a group: it must not wait in the queue
         A, B = rng.standard_normal((5, 6, 7)), rng.standard_normal((7, 5, 4))
         dA, dB = ctx.array(A), ctx.array(B)
@@ -111,6 +119,7 @@ def check_grouped_products(lib, shapes, expect_grouped):
         assert np.abs(o1.get() - np.einsum("abc,cad->bd", A, B)).max() < 1e-12
         assert np.abs(o2.get() - np.einsum("abc,cad->db", A, B)).max() < 1e-12
     finally:
+        ctx.phase_enable(-1)
         ctx.close()
 
 
@@ -125,6 +134,16 @@ def test_grouped_products_host_logic(hostsim_lib):
 
 @pytest.mark.gpu
 def test_grouped_products_gpu(gpu_lib):
+    # the same products as tasks of a phase (the default): numerics only, and that they were recorded, not launched
+    ctx = Context(2, 3, lib=gpu_lib)
+    t0 = ctx.phase_stats()
+    ctx.close()
+    check_grouped_products(gpu_lib, GROUP_SHAPES, None)
+    if os.environ.get("PYMES_PHASE", "1") != "0":
+        ctx = Context(2, 3, lib=gpu_lib)
+        t1 = ctx.phase_stats()
+        ctx.close()
+        assert t1["tasks"] - t0["tasks"] >= len(GROUP_SHAPES) and t1["launches"] > t0["launches"]
     check_grouped_products(gpu_lib, GROUP_SHAPES, (23, 2))
     # a big product between small ones keeps its own (LDS-DMA) launch; the small ones on either side are grouped
     check_grouped_products(gpu_lib, [(100, 90, 80, True, False, 1.0, 0.0), (2048, 2048, 2048, True, False, 1.0, 0.0),

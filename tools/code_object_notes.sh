@@ -3,7 +3,7 @@
 #   bash tools/code_object_notes.sh > profiles/rNN/kernels_code_object_notes.txt
 set -e
 tmp=$(mktemp -d)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC --cuda-device-only -c pymes_amd/csrc/kernels.hip -Ipymes_amd/csrc -o "$tmp/k.co" 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -instcombine-max-copied-from-constant-users=100000 --cuda-device-only -c pymes_amd/csrc/kernels.hip -Ipymes_amd/csrc -o "$tmp/k.co" 2>/dev/null
 /opt/rocm/lib/llvm/bin/clang-offload-bundler --unbundle --type=o --input="$tmp/k.co" --targets=hip-amdgcn-amd-amdhsa--gfx950 --output="$tmp/k.elf"
 echo "# kernels.hip sha256=$(sha256sum pymes_amd/csrc/kernels.hip | cut -d' ' -f1)"
 echo "# llvm-readelf --notes of the gfx950 code object: kernel, vgpr_count, agpr_count, vgpr_spill_count, private_segment_fixed_size (scratch bytes)"
