@@ -1616,12 +1616,14 @@ struct Hooks {
     void* stream;
     // (nothing of the library's own may still be queued when the host program orders a collective behind the stream)
     int64_t allreduce(double* buf, int64_t n) const {
+        dev::gemm_group_sync();
         dev::phase_sync();
         int64_t t = 0;
         if (c.allreduce_start(c.user, buf, n, stream, &t) != 0) throw Error("collective hook: allreduce_start failed");
         return t;
     }
     int64_t allgather(double* buf, int64_t chunk) const {
+        dev::gemm_group_sync();
         dev::phase_sync();
         int64_t t = 0;
         if (c.allgather_start(c.user, buf, chunk, stream, &t) != 0) throw Error("collective hook: allgather_start failed");

@@ -111,6 +111,8 @@ void gemm_group_stats(long* launches, long* products);    // grouped launches / 
 // every entry point of the C interface; before a collective of the host program).  phase_enable: 1 on, 0 off, -1 as the
 // environment says (PYMES_PHASE=0 off, =serial one task per level; default on).  No-ops in the host simulator.
 void phase_sync();
+bool phase_pending();              // tasks are recorded and not yet launched (this thread)
+long phase_generation();           // number of non-empty phases launched so far (this thread)
 void phase_enable(int mode);
 void phase_stats(long* tasks, long* launches, long* levels, long* flushes);     // counted per thread since its start
 

@@ -58,9 +58,32 @@ void Arena::release() {
     if (base_) dev::dfree(base_);
     base_ = nullptr;
     cap_ = top_ = 0;
+    deferred_ = false;
+}
+void Arena::reset(size_t m) {
+    if (m >= top_) return;
+    // (only while the arena is at most half full: a hole under live allocations comes back when an enclosing scope ends, and
+    // the engine's own high-water mark is a quarter of the capacity it asks for — above that the release is immediate, as ever)
+    if (dev::phase_pending() && top_ <= cap_ / 2) {
+        want_ = deferred_ ? std::min(want_, m) : m;
+        deferred_ = true;
+        gen_ = dev::phase_generation();
+        return;
+    }
+    top_ = m;
+    deferred_ = false;
 }
 double* Arena::alloc(int64_t doubles) {
     size_t bytes = (static_cast<size_t>(std::max<int64_t>(doubles, 1)) * sizeof(double) + 255) & ~size_t(255);
+    if (deferred_) {
+        if (!dev::phase_pending() || dev::phase_generation() != gen_) {
+            top_ = want_;                          // the tasks recorded when the release was made have been launched
+        } else if (top_ + bytes > cap_) {          // out of room: launch the phase, take the release
+            dev::phase_sync();
+            top_ = want_;
+        }
+        deferred_ = false;                         // (else: above the hole; an enclosing scope's release takes it back)
+    }
     if (top_ + bytes > cap_)
         throw Error("workspace exhausted: need " + std::to_string((top_ + bytes) >> 20) + " MiB, have " +
                     std::to_string(cap_ >> 20) + " MiB (pass a larger workspace_bytes to pymes_ctx_create)");

@@ -47,13 +47,23 @@ class Arena {
     void release();
     double* alloc(int64_t doubles);
     size_t mark() const { return top_; }
-    void reset(size_t m) { top_ = m; }
+    // While tasks of an open phase are recorded but not launched (device_api.h, phase launches) a released region is NOT
+    // handed out again: a later temporary at the same address would be ordered behind every recorded reader of the old one
+    // (a write-after-read hazard that exists only because of the reuse) and the phase would lose the concurrency it is there
+    // for.  The release is remembered and takes effect once those tasks have been launched — or at once when the arena runs
+    // out of room (the phase is launched first).
+    void reset(size_t m);
     size_t capacity() const { return cap_; }
     size_t high_water() const { return high_; }
 
   private:
     char* base_ = nullptr;
     size_t cap_ = 0, top_ = 0, high_ = 0;
+    // a release that waits for the open phase: valid while nothing has been allocated since (stack discipline: the
+    // allocations made after a release are the highest live ones; with none, everything above `want_` is dead)
+    bool deferred_ = false;
+    size_t want_ = 0;
+    long gen_ = 0;
 };
 
 struct ArenaScope {

@@ -2608,21 +2608,24 @@ struct FockFinK {
     const double* f; const double* t1; const double* W; double* ft; double* fd;
     int no, nv;
 };
+// One WAVE per output element, the lanes over the summation index (one thread per element ran its 20-80 dependent steps as a
+// latency chain: 10 + 17 us for the two kernels at (20,80) on 2 and 40 blocks): grids of ceil(no^2 / 4) and ceil(n^2 / 4) blocks.
 __device__ __forceinline__ void fock_ft_body(const FockFinK& k, const unsigned vb) {
     const double* __restrict__ f = k.f;
     const double* __restrict__ t1 = k.t1;
     const double* __restrict__ W = k.W;
     double* __restrict__ ft = k.ft;
     const int no = k.no, nv = k.nv;
-    const int e = vb * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int e = vb * 4 + (threadIdx.x >> 6);
     if (e >= no * no) return;
     const int j = e / no, i = e - j * no, n = no + nv;
     const FockW w = fock_w(W, no, nv);
-    double acc = 2.0 * w.L1[e] - w.L2[e];
-#pragma unroll 8
-    for (int b = 0; b < nv; ++b)       // (independent loads, eight steps in flight: the loop is a latency chain otherwise)
+    double acc = 0.0;
+    for (int b = lane; b < nv; b += 64)
         acc += (f[(long)j * n + no + b] + 2.0 * w.J1[(long)j * nv + b] - w.J2[(long)j * nv + b]) * t1[(long)b * no + i];
-    ft[e] = acc;
+    acc = wave_sum(acc);
+    if (lane == 0) ft[e] = acc + 2.0 * w.L1[e] - w.L2[e];
 }
 __global__ void fock_ft_kernel(const FockFinK k) { fock_ft_body(k, blockIdx.x); }
 __device__ __forceinline__ void fock_finish_body(const FockFinK& k, const unsigned vb) {
@@ -2633,34 +2636,31 @@ __device__ __forceinline__ void fock_finish_body(const FockFinK& k, const unsign
     double* __restrict__ fd = k.fd;
     const int no = k.no, nv = k.nv;
     const int n = no + nv;
-    const long e = (long)vb * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const long e = (long)vb * 4 + (threadIdx.x >> 6);
     if (e >= (long)n * n) return;
     const int p = (int)(e / n), q = (int)(e - (long)p * n);
     const FockW w = fock_w(W, no, nv);
-    double v = f[e];
+    double v = 0.0, acc = 0.0;          // v: the terms without a sum (lane 0), acc: this lane's share of the sums
     if (p < no && q < no) {
-        v += ft[p * no + q];
+        v = ft[p * no + q];
     } else if (p < no) {
         const int a = q - no;
-        v += 2.0 * w.K1[(long)p * nv + a] - w.J2[(long)p * nv + a];
+        v = 2.0 * w.K1[(long)p * nv + a] - w.J2[(long)p * nv + a];
     } else if (q >= no) {
         const int a = p - no, b = q - no;
-        double acc = 2.0 * w.G1[(long)a * nv + b] - w.G2[(long)a * nv + b];
-#pragma unroll 8
-        for (int i = 0; i < no; ++i)
+        v = 2.0 * w.G1[(long)a * nv + b] - w.G2[(long)a * nv + b];
+        for (int i = lane; i < no; i += 64)
             acc -= t1[(long)a * no + i] * (f[(long)i * n + no + b] + 2.0 * w.J1[(long)i * nv + b] - w.J2[(long)i * nv + b]);
-        v += acc;
     } else {
         const int a = p - no, i = q;
-        double acc = 2.0 * w.K1[(long)i * nv + a] - w.K2[(long)a * no + i];
-#pragma unroll 8
-        for (int j = 0; j < no; ++j) acc -= t1[(long)a * no + j] * (f[(long)j * n + i] + ft[j * no + i]);
-#pragma unroll 8
-        for (int b = 0; b < nv; ++b)
+        v = 2.0 * w.K1[(long)i * nv + a] - w.K2[(long)a * no + i];
+        for (int j = lane; j < no; j += 64) acc -= t1[(long)a * no + j] * (f[(long)j * n + i] + ft[j * no + i]);
+        for (int b = lane; b < nv; b += 64)
             acc += (f[(long)(no + a) * n + no + b] + 2.0 * w.G1[(long)a * nv + b] - w.G2[(long)a * nv + b]) * t1[(long)b * no + i];
-        v += acc;
     }
-    fd[e] = v;
+    acc = wave_sum(acc);
+    if (lane == 0) fd[e] = f[e] + (v + acc);
 }
 __global__ void fock_finish_kernel(const FockFinK k) { fock_finish_body(k, blockIdx.x); }
 
@@ -3049,7 +3049,11 @@ __device__ __forceinline__ void phase_gemm_layouts(const GemmK& g, const int lay
         default: dgemm_body<BM, BN, true, true, 2>(g, bid); break;
     }
 }
-__global__ void __launch_bounds__(kThreads, 2) phase_kernel(const PhaseK ph) {
+// HEAVY: with the register-hungry tasks — matrix-core products, the dressed-Fock kernels, the energy reduction (120
+// registers: four blocks per CU); the launches of a level without any of them — layouts, packs, permutations, updates, dot
+// products: bound by the loads they keep in flight — use the light variant (at most 64 registers: eight blocks per CU)
+template <bool HEAVY>
+__device__ __forceinline__ void phase_body(const PhaseK& ph) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double sh[4];
     const int b = blockIdx.x;
@@ -3064,13 +3068,15 @@ __global__ void __launch_bounds__(kThreads, 2) phase_kernel(const PhaseK ph) {
     if (kind == PK_GEMM) vb = (int)xcd_remap(vb, span);     // neighbouring tiles of a product on one XCD
     if (vb >= nblk) return;
     switch (kind) {
-        case PK_GEMM: {
-            const GemmK& g = phase_args<GemmK>(args);
-            const int shape = sub >> 3, lay = sub & 7;
-            if (shape == 0) phase_gemm_layouts<64, 64>(g, lay, vb);
-            else if (shape == 1) phase_gemm_layouts<64, 32>(g, lay, vb);
-            else phase_gemm_layouts<32, 64>(g, lay, vb);
-        } break;
+        case PK_GEMM:
+            if constexpr (HEAVY) {
+                const GemmK& g = phase_args<GemmK>(args);
+                const int shape = sub >> 3, lay = sub & 7;
+                if (shape == 0) phase_gemm_layouts<64, 64>(g, lay, vb);
+                else if (shape == 1) phase_gemm_layouts<64, 32>(g, lay, vb);
+                else phase_gemm_layouts<32, 64>(g, lay, vb);
+            }
+            break;
         case PK_SPLITK: {
             const SplitkTaskK& k = phase_args<SplitkTaskK>(args);
             const int pieces = k.BM * k.BN / 256;
@@ -3104,8 +3110,10 @@ __global__ void __launch_bounds__(kThreads, 2) phase_kernel(const PhaseK ph) {
             break;
         case PK_DOTS2: dots_stage2_body(phase_args<Dots2K>(args), vb, sh); break;
         case PK_ENERGY:
-            if (sub) energy_norms_body<2>(phase_args<EnergyK>(args), vb, nblk, sh);
-            else energy_norms_body<1>(phase_args<EnergyK>(args), vb, nblk, sh);
+            if constexpr (HEAVY) {
+                if (sub) energy_norms_body<2>(phase_args<EnergyK>(args), vb, nblk, sh);
+                else energy_norms_body<1>(phase_args<EnergyK>(args), vb, nblk, sh);
+            }
             break;
         case PK_TAU: tau_body(phase_args<TauK>(args), vb, nblk); break;
         case PK_PACK_T: ladder_pack_T_body(phase_args<PackTK>(args), vb); break;
@@ -3118,15 +3126,26 @@ __global__ void __launch_bounds__(kThreads, 2) phase_kernel(const PhaseK ph) {
         case PK_ASSEMBLE: residual_assemble_body(phase_args<AssembleK>(args), vb); break;
         case PK_ROWS_UNPACK: rows_unpack_body(phase_args<RowsUnpackK>(args), vb, nblk); break;
         case PK_FOCK_G12:
-            if (sub) fock_g12_body<2>(phase_args<FockG12K>(args), vb);
-            else fock_g12_body<1>(phase_args<FockG12K>(args), vb);
+            if constexpr (HEAVY) {
+                if (sub) fock_g12_body<2>(phase_args<FockG12K>(args), vb);
+                else fock_g12_body<1>(phase_args<FockG12K>(args), vb);
+            }
             break;
         case PK_FOCK_G12_FIN: fock_g12_finish_body(phase_args<FockG12FinK>(args), vb); break;
-        case PK_FOCK_FT: fock_ft_body(phase_args<FockFinK>(args), vb); break;
-        case PK_FOCK_FIN: fock_finish_body(phase_args<FockFinK>(args), vb); break;
+        case PK_FOCK_FT:
+            if constexpr (HEAVY) fock_ft_body(phase_args<FockFinK>(args), vb);
+            break;
+        case PK_FOCK_FIN:
+            if constexpr (HEAVY) fock_finish_body(phase_args<FockFinK>(args), vb);
+            break;
         case PK_TRACES: pair_traces_body(phase_args<TracesK>(args), vb, smem); break;
         default: break;
     }
+}
+__global__ void __launch_bounds__(kThreads, 2) phase_kernel(const PhaseK ph) { phase_body<true>(ph); }
+__global__ void __launch_bounds__(kThreads, 8) phase_light_kernel(const PhaseK ph) { phase_body<false>(ph); }
+__host__ __device__ constexpr bool phase_kind_heavy(int kind) {
+    return kind == PK_GEMM || kind == PK_ENERGY || kind == PK_FOCK_G12 || kind == PK_FOCK_FT || kind == PK_FOCK_FIN;
 }
 
 inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
@@ -3304,6 +3323,7 @@ void phase_flush() {
     HIP_CHECK(hipGetDevice(&dv));
     if (dv >= 0 && dv < kMaxDevices && !attr_set[dv]) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(phase_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(phase_light_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         attr_set[dv] = true;
     }
     std::vector<int> idx;
@@ -3319,6 +3339,7 @@ void phase_flush() {
             ph.n = 0;
             int words = 0, lds = 0;
             long blocks = 0;
+            bool heavy = false;
             while (pos < idx.size() && ph.n < kPhaseMaxTasks) {
                 const PhaseRec& t = q[idx[pos]];
                 const long padded = ((long)t.nblk + 7) & ~7L;
@@ -3331,11 +3352,13 @@ void phase_flush() {
                 blocks += padded;
                 ph.blk_end[i] = (int)blocks;
                 lds = std::max(lds, t.lds);
+                heavy = heavy || phase_kind_heavy(t.kind);
                 ++pos;
             }
             if (ph.n == 0) throw std::runtime_error("phase: a task does not fit a launch");
             for (int i = ph.n; i < kPhaseMaxTasks; ++i) { ph.blk_end[i] = (int)blocks; ph.nblk[i] = 0; ph.kind[i] = PK_KINDS; ph.sub[i] = 0; ph.off[i] = 0; }
-            hipLaunchKernelGGL(phase_kernel, dim3((unsigned)blocks), dim3(kThreads), (size_t)lds, P.st, ph);
+            if (heavy) hipLaunchKernelGGL(phase_kernel, dim3((unsigned)blocks), dim3(kThreads), (size_t)lds, P.st, ph);
+            else hipLaunchKernelGGL(phase_light_kernel, dim3((unsigned)blocks), dim3(kThreads), (size_t)lds, P.st, ph);
             HIP_CHECK(hipGetLastError());
             ++P.launches;
         }
@@ -3920,18 +3943,16 @@ void prof_query(int kernel_class, long* calls, long* kernel_launches, double* ms
 }
 
 namespace {
-// Queue a product for the open group.  false: not a small product (it runs as its own launch, after the queue).
-bool gemm_group_take(const Gemm& g, bool a_kcontig, bool b_kcontig, int64_t a_sm, int64_t a_sk, int64_t b_sk, int64_t b_sn,
-                     hipStream_t st) {
+// Queue a mid-size product in the LDS-DMA layout for the grouped 128 x 128 launch of the open group (tried before the open
+// phase gets the product: deep products belong on the LDS-DMA kernel, not on the 64 x 64 tiles of a phase).
+bool gemm_group_take_dma(const Gemm& g, bool a_kcontig, bool b_kcontig, int64_t a_sm, int64_t a_sk, int64_t b_sk, int64_t b_sn,
+                         hipStream_t st) {
     GemmGroup& q = g_group;
     if (q.st != st) return false;
     const long nbatch = g.nb1 * g.nb2;
-    const long t64 = ((g.M + 63) / 64) * ((g.N + 63) / 64) * nbatch, t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128) * nbatch;
+    const long t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128) * nbatch;
     const long ktiles = (g.K + BK - 1) / BK;
-    // big products keep their own launches: enough 128 x 128 tiles for the chip, or deep enough for the LDS-DMA kernel's
-    // k-split; and so do the long streaming products (one pass over a multi-GB block: the single-buffer kernel moves more)
     if (t128 >= 256 && ktiles * BK >= 256) return false;
-    // mid-size products in the LDS-DMA layout: queued for the grouped 128 x 128 launch
     {
         const long a_ld = a_kcontig ? a_sm : a_sk, b_ld = b_kcontig ? b_sn : b_sk;
         const bool vec2 = even(a_ld) && even(b_ld) && even(g.K) && (even(g.N) || b_ld > g.N) && aligned16(g.A) && aligned16(g.B) &&
@@ -3966,6 +3987,20 @@ bool gemm_group_take(const Gemm& g, bool a_kcontig, bool b_kcontig, int64_t a_sm
             return true;
         }
     }
+    return false;
+}
+// Queue a product for the open group.  false: not a small product (it runs as its own launch, after the queue).
+bool gemm_group_take(const Gemm& g, bool a_kcontig, bool b_kcontig, int64_t a_sm, int64_t a_sk, int64_t b_sk, int64_t b_sn,
+                     hipStream_t st) {
+    GemmGroup& q = g_group;
+    if (q.st != st) return false;
+    const long nbatch = g.nb1 * g.nb2;
+    const long t64 = ((g.M + 63) / 64) * ((g.N + 63) / 64) * nbatch, t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128) * nbatch;
+    const long ktiles = (g.K + BK - 1) / BK;
+    // big products keep their own launches: enough 128 x 128 tiles for the chip, or deep enough for the LDS-DMA kernel's
+    // k-split; and so do the long streaming products (one pass over a multi-GB block: the single-buffer kernel moves more)
+    if (t128 >= 256 && ktiles * BK >= 256) return false;
+    if (gemm_group_take_dma(g, a_kcontig, b_kcontig, a_sm, a_sk, b_sk, b_sn, st)) return true;
     if (t128 < 256 && g.K / std::max<long>(1, (512 + t128 - 1) / t128) >= dma_min_k() && g.M > 64 && g.N > 64) return false;
     if (t64 * ktiles > 400000 || t64 > 0x3fffffffL / 16) return false;
     // streaming shapes (short K against a skinny side; tiny outputs over a huge K): one pass over a big operand, bound by the
@@ -4022,6 +4057,11 @@ bool phase_gemm(const Gemm& g, bool akc, bool bkc, int64_t a_sm, int64_t a_sk, i
     const double dM = (double)g.M, dN = (double)g.N, dK = (double)g.K, dB = (double)nbatch;
     const double cost = 2.0 * dM * dN * dK * dB / 4.0e7 + 8.0 * (dM * dK + dK * dN + (g.beta != 0.0 ? 2.0 : 1.0) * dM * dN) * dB / 4.0e6;
     if (!phase_small(cost)) return false;
+    // deep products with enough 128 x 128 tiles for the LDS-DMA kernel (k-split over the chip) belong there, small as they may be
+    {
+        const long t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128) * nbatch;
+        if (g.M > 64 && g.N > 64 && g.K >= 2 * dma_min_k() && t128 * std::min<long>(16, g.K / dma_min_k()) >= 128) return false;
+    }
     int BM = 64, BN = 64;
     if (g.N <= 32) BN = 32;
     else if (g.M <= 32) BM = 32;
@@ -4135,11 +4175,14 @@ void gemm_group_end() {
     gemm_group_flush();
 }
 void gemm_group_sync() { gemm_group_flush(); }
+// (products queued in an open group — dev::gemm_group_begin / _end, which may span several calls of the C interface — stay
+// queued: a task is never recorded while one is waiting, phase_push, so what is recorded precedes them in the order of effects)
 void phase_sync() {
     gemv_batch_flush();
-    gemm_group_flush();
     phase_flush();
 }
+bool phase_pending() { return !g_phase.q.empty(); }
+long phase_generation() { return g_phase.flushes; }
 void phase_enable(int mode) {
     phase_sync();
     g_phase.enabled = mode < 0 ? -1 : (mode ? 1 : 0);
@@ -4171,6 +4214,7 @@ void gemm(const Gemm& g, stream_t s) {
     const bool b_kcontig = (b_sk == 1);
     if (gemv_dispatch(g, a_sm, a_sk, b_sk, b_sn, st)) return;
     gemv_batch_flush();
+    if (g_group.active && gemm_group_take_dma(g, a_kcontig, b_kcontig, a_sm, a_sk, b_sk, b_sn, st)) return;
     if (phase_gemm(g, a_kcontig, b_kcontig, a_sm, a_sk, b_sk, b_sn, st)) return;
     if (g_group.active && gemm_group_take(g, a_kcontig, b_kcontig, a_sm, a_sk, b_sk, b_sn, st)) return;
     gemm_group_flush();          // (a product that is launched on its own keeps its place in the order of effects)
@@ -5176,17 +5220,17 @@ void fock_finish(const double* f, const double* t1, const double* W, double* fd,
     const FockFinK k{f, t1, W, ft, fd, no, nv};
     if (phase_open((hipStream_t)s)) {
         const long wlen = 2L * nv * nv + 4L * no * nv + 2L * no * no;        // G1 G2 J1 J2 L1 L2 K1 K2
-        PhaseRec& t = phase_push(PK_FOCK_FT, 0, (no * no + 255) / 256, 0, 2.0, k);
+        PhaseRec& t = phase_push(PK_FOCK_FT, 0, (no * no + 3) / 4, 0, 2.0, k);
         phase_reads(t, {prange(f, n * n), prange(t1, (long)no * nv), prange(W, wlen)});
         phase_writes(t, {prange(ft, (long)no * no)});
-        PhaseRec& u = phase_push(PK_FOCK_FIN, 0, (n * n + 255) / 256, 0, 3.0, k);
+        PhaseRec& u = phase_push(PK_FOCK_FIN, 0, (n * n + 3) / 4, 0, 3.0, k);
         phase_reads(u, {prange(f, n * n), prange(t1, (long)no * nv), prange(W, wlen), prange(ft, (long)no * no)});
         phase_writes(u, {prange(fd, n * n)});
         return;
     }
-    PYMES_LAUNCH(fock_ft_kernel, dim3((unsigned)((no * no + 255) / 256)), dim3(256), 0, (hipStream_t)s, k);
+    PYMES_LAUNCH(fock_ft_kernel, dim3((unsigned)((no * no + 3) / 4)), dim3(256), 0, (hipStream_t)s, k);
     HIP_CHECK(hipGetLastError());
-    PYMES_LAUNCH(fock_finish_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, (hipStream_t)s, k);
+    PYMES_LAUNCH(fock_finish_kernel, dim3((unsigned)((n * n + 3) / 4)), dim3(256), 0, (hipStream_t)s, k);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -272,6 +272,8 @@ void gemm_group_begin(stream_t) { g_group_open = true; g_group_launches = g_grou
 void gemm_group_end() { g_group_open = false; }
 void gemm_group_sync() {}
 void phase_sync() {}
+bool phase_pending() { return false; }
+long phase_generation() { return 0; }
 void phase_enable(int) {}
 void phase_stats(long* tasks, long* launches, long* levels, long* flushes) {
     if (tasks) *tasks = 0;

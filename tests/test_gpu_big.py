@@ -122,9 +122,9 @@ def test_c2_functions_vs_oracle(gpu_lib, symmetric):
 
 
 def test_c3_slab_vs_oracle(gpu_lib):
-    """Config 3 (50,200): after three real CCSD iterations (T2 of realistic size; T1 perturbed to 0.02) the dressed Fock, R1 and the rows
-    a in [37,39) and [199,200) of R2 (CCSD and DCSD) of the path bench.py times, against the slab oracle; R2 again from
-    three simulated ranks (slab + finish, and the pair-sharded tail)."""
+    """Config 3 (50,200): after three real CCSD iterations (T2 of realistic size; T1 perturbed to 0.02) the dressed Fock, R1 and
+    rows of R2 (CCSD and DCSD) of the path bench.py times — a = 0, 24 | 25, 70, one seeded-random a, 199 — against the slab
+    oracle; R2 again from three and from EIGHT simulated ranks (slab + finish, and the pair-sharded tail)."""
     from pymes_amd.model import synthetic
     no, nv = 50, 200
     B, eps = synthetic.factors(no, nv, seed=0)
@@ -154,37 +154,48 @@ def test_c3_slab_vs_oracle(gpu_lib):
         ctx.singles_residual(fd, dT1, dT2, r1)
         r1_ref = oc.singles_residual(no, fd_ref, t1, t2, so.singles_blocks(no, B))
         assert np.abs(r1.get() - r1_ref).max() < 1e-10
-        # doubles residual on slabs
+        # doubles residual on slabs: one rank, then 3 and 8 SIMULATED ranks (8 is the world north_star names: ring slabs of
+        # 1250 columns = 25 rows of a, 790 tiles with a k-cut tail; pair chunks of 2513 rows P(a,b): the first boundary falls
+        # inside a = 70) through both tails — replicated finish and pair-sharded finish
         npp, ov, o2 = nv * (nv + 1) // 2, no * nv, no * no
-        world = 3
-        pad = lambda n: -(-n // world) * world
+        worlds = (3, 8)
+        padw = lambda n, w: -(-n // w) * w
+        pad = lambda n: max(padw(n, w) for w in worlds)
         ETd, ETx = ctx.zeros((pad(ov), ov)), ctx.zeros((pad(ov), ov))
         L, QK = ctx.zeros((pad(npp), o2)), ctx.zeros((pad(ov), o2))
-        r2, r2b = ctx.empty(t2.shape), ctx.empty(t2.shape)
-        chunk = pad(npp) // world
-        Rall = ctx.zeros((world * chunk, 2, o2))
+        r2 = ctx.empty(t2.shape)
+        Rall = ctx.zeros((pad(npp), 2, o2))
+        # rows of R2 that are compared: the first and last a, both sides of a ring-slab boundary of the 8-rank split (a = 24 | 25),
+        # the a in which its first pair-chunk boundary falls (70), and one drawn from a seeded generator (a fixed list has blind
+        # spots; a fresh seed per run would not be reproducible)
+        a_rand = int(np.random.default_rng(20261004).integers(1, nv - 1))
+        slabs = [(0, 1), (24, 26), (70, 71), (a_rand, a_rand + 1), (199, 200)]
 
         def rows(arr, a0, a1):
             return DeviceArray(ctx, arr.ptr + 8 * a0 * nv * o2, (a1 - a0, nv, no, no), owned=False, keepalive=arr).get()
         for dcd in (False, True):
+            refs = [so.residual_slab(no, fd_ref, t1, t2, B, a0, a1, is_dcsd=dcd) for a0, a1 in slabs]
             ctx.dress_V(dT1, ("klij", "iajb", "iabj"))
             ctx.residual_slab(fd, dT2, ETd, ETx, L, 0, 1, is_dcd=dcd, dressed=True, t1=dT1, QK=QK)
             ctx.residual_finish(fd, dT2, ETd, ETx, L, r2, is_dcd=dcd, dressed=True, t1=dT1, QK=QK)
-            for rank in range(world):
-                ctx.residual_slab(fd, dT2, ETd, ETx, L, rank, world, is_dcd=dcd, dressed=True, t1=dT1, QK=QK)
-            ctx.residual_finish(fd, dT2, ETd, ETx, L, r2b, is_dcd=dcd, dressed=True, t1=dT1, QK=QK)
-            for rank in range(world):
-                piece = DeviceArray(ctx, Rall.ptr + 8 * rank * chunk * 2 * o2, (chunk, 2, o2), owned=False, keepalive=Rall)
-                ctx.residual_finish_pairs(fd, dT2, ETd, ETx, L, piece, rank, world, dT1, QK, is_dcd=dcd, dressed=True)
-            r2c = ctx.empty(t2.shape)
-            ctx.pairs_unpack(Rall, r2c, world)
-            for a0, a1 in ((37, 39), (199, 200)):
-                ref = so.residual_slab(no, fd_ref, t1, t2, B, a0, a1, is_dcsd=dcd)
-                tol = 1e-11 * max(1.0, np.abs(ref).max())
-                assert np.abs(rows(r2, a0, a1) - ref).max() < tol, (dcd, a0)
-                assert np.abs(rows(r2b, a0, a1) - ref).max() < tol, (dcd, a0, "3 simulated ranks")
-                assert np.abs(rows(r2c, a0, a1) - ref).max() < tol, (dcd, a0, "pair-sharded tail")
-            r2c.free()
+            for (a0, a1), ref in zip(slabs, refs):
+                assert np.abs(rows(r2, a0, a1) - ref).max() < 1e-11 * max(1.0, np.abs(ref).max()), (dcd, a0)
+            for world in worlds:
+                chunk = padw(npp, world) // world
+                r2b, r2c = ctx.empty(t2.shape), ctx.empty(t2.shape)
+                for rank in range(world):
+                    ctx.residual_slab(fd, dT2, ETd, ETx, L, rank, world, is_dcd=dcd, dressed=True, t1=dT1, QK=QK)
+                ctx.residual_finish(fd, dT2, ETd, ETx, L, r2b, is_dcd=dcd, dressed=True, t1=dT1, QK=QK)
+                for rank in range(world):
+                    piece = DeviceArray(ctx, Rall.ptr + 8 * rank * chunk * 2 * o2, (chunk, 2, o2), owned=False, keepalive=Rall)
+                    ctx.residual_finish_pairs(fd, dT2, ETd, ETx, L, piece, rank, world, dT1, QK, is_dcd=dcd, dressed=True)
+                ctx.pairs_unpack(DeviceArray(ctx, Rall.ptr, (world * chunk, 2, o2), owned=False, keepalive=Rall), r2c, world)
+                for (a0, a1), ref in zip(slabs, refs):
+                    tol = 1e-11 * max(1.0, np.abs(ref).max())
+                    assert np.abs(rows(r2b, a0, a1) - ref).max() < tol, (dcd, a0, world, "simulated ranks")
+                    assert np.abs(rows(r2c, a0, a1) - ref).max() < tol, (dcd, a0, world, "pair-sharded tail")
+                r2b.free()
+                r2c.free()
         # ---- the HBM-bound remainder of the iteration at FULL size against numpy on the downloaded arrays: amplitude
         # update (ccsd.py:149-156, :176-179), energies + norms in one pass (:189-197, :458-466), the DIIS overlaps of
         # unequal lengths in one launch (diis.py:65-78) and the extrapolation (diis.py:97-103)
