@@ -17,6 +17,7 @@
 #include <type_traits>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1225,6 +1226,33 @@ __device__ __forceinline__ void dots_stage2_body(const Dots2K& k, const unsigned
     for (int i = threadIdx.x; i < k.nblocks; i += blockDim.x) s += k.partial[pair * kDotBlocks + i];
     s = block_sum(s, sh);
     if (threadIdx.x == 0) k.out[pair] = s;
+}
+// The last stage of a reduction whose result the HOST waits for: ONE block sums the partial sums of all `npairs` reductions
+// (same order as dots_stage2: bit-identical), writes them straight into pinned host memory and then, behind a system-scope
+// fence, a sequence number the host polls for — no copy kernel, no event, no stream synchronisation between the device's last
+// store and the host's next launch (the DIIS round trip of an iteration: 40 us of idle device with hipStreamSynchronize).
+struct DotsFinalK {
+    const double* partial;
+    double* out;             // device address of the pinned result slot
+    long* flag;              // ... and of its sequence word
+    long seq;
+    int nblocks, npairs;
+};
+__device__ __forceinline__ void dots_final_body(const DotsFinalK& k, double* sh) {
+    for (int pair = 0; pair < k.npairs; ++pair) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < k.nblocks; i += blockDim.x) s += k.partial[pair * kDotBlocks + i];
+        s = block_sum(s, sh);
+        if (threadIdx.x == 0) k.out[pair] = s;
+    }
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(k.flag, k.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+__global__ void __launch_bounds__(256) dots_final_kernel(const DotsFinalK k) {
+    __shared__ double sh[4];
+    dots_final_body(k, sh);
 }
 __global__ void __launch_bounds__(256) dots_stage2_kernel(const double* __restrict__ partial, int nblocks,
                                                           double* __restrict__ out) {
@@ -3012,7 +3040,7 @@ __global__ void ueg_scatter_kernel(const UegK u, const int* __restrict__ kint, c
 enum : unsigned short {
     PK_GEMM = 0, PK_SPLITK, PK_PERM_DIRECT, PK_PERM_TILED, PK_GEMV_COLS, PK_GEMV_FINISH, PK_GEMV_ROWS, PK_CC_UPDATE, PK_LINCOMB,
     PK_DOTS1, PK_DOTS2, PK_ENERGY, PK_TAU, PK_PACK_T, PK_LADDER_UNPACK, PK_RING_OPERANDS, PK_T2_LAYOUTS, PK_ASSEMBLE,
-    PK_ROWS_UNPACK, PK_FOCK_G12, PK_FOCK_G12_FIN, PK_FOCK_FT, PK_FOCK_FIN, PK_TRACES, PK_KINDS
+    PK_ROWS_UNPACK, PK_FOCK_G12, PK_FOCK_G12_FIN, PK_FOCK_FT, PK_FOCK_FIN, PK_TRACES, PK_DOTS_FINAL, PK_KINDS
 };
 struct SplitkTaskK { GemmK g; int BM, BN; };
 struct PermTaskK { PermK p; long total; int tiles_q, tiles_l; };
@@ -3109,6 +3137,7 @@ __device__ __forceinline__ void phase_body(const PhaseK& ph) {
             else dots_stage1_body<1>(phase_args<DotsK>(args), vb, sh);
             break;
         case PK_DOTS2: dots_stage2_body(phase_args<Dots2K>(args), vb, sh); break;
+        case PK_DOTS_FINAL: dots_final_body(phase_args<DotsFinalK>(args), sh); break;
         case PK_ENERGY:
             if constexpr (HEAVY) {
                 if (sub) energy_norms_body<2>(phase_args<EnergyK>(args), vb, nblk, sh);
@@ -3199,6 +3228,11 @@ struct PhaseRec {
     double cost = 0.0;                 // estimated microseconds (order of the tasks inside a level: longest first)
     int nr = 0, nw = 0;
     PhaseRange r[10], w[4];
+    // accumulation fusion (phase_fuse_accumulations): `box` is set when the task's only output is ONE contiguous array;
+    // acc = 1: it ACCUMULATES into it (out = alpha X + out: a product with beta = 1, an accumulating permutation) and can be
+    // redirected to a private buffer; acc = 0: it overwrites all of it
+    PhaseRange box{0, 0};
+    signed char acc = -1;
     long blob[56];
 };
 struct PhaseQueue {
@@ -3209,7 +3243,10 @@ struct PhaseQueue {
     hipStream_t st = nullptr;
     std::vector<PhaseRec> q;
     long ws_cursor = 0;                // rolling sub-allocation of the split-K workspace among the tasks of a phase
+    double* ws = nullptr;              // that workspace (the engine's; remembered from the products of the phase)
+    long ws_doubles = 0;
     long tasks = 0, launches = 0, levels = 0, flushes = 0;      // statistics (dev::phase_stats)
+    long fused = 0;                    // accumulation chains fused (phase_fuse_accumulations)
 };
 thread_local PhaseQueue g_phase;
 void phase_flush();
@@ -3277,6 +3314,8 @@ inline bool phase_conflict(const PhaseRec& a, const PhaseRec& b) {       // a ea
 inline double* phase_ws(double* ws, long ws_doubles, long need) {
     PhaseQueue& P = g_phase;
     if (!ws || need > ws_doubles) return nullptr;
+    P.ws = ws;
+    P.ws_doubles = ws_doubles;
     need = (need + 15) & ~15L;
     if (P.ws_cursor + need > ws_doubles) P.ws_cursor = 0;
     double* p = ws + P.ws_cursor;
@@ -3284,16 +3323,121 @@ inline double* phase_ws(double* ws, long ws_doubles, long need) {
     return p;
 }
 
+// Accumulation fusion.  A term sequence accumulates its products into one array, C = W; C += X1; C += X2; ... — a chain in the
+// hazard graph (every member reads and writes C) although the X_i are independent of each other.  Where the array is
+// contiguous and no other task touches it in between, the members after the first toucher write alpha X_i into private
+// buffers (slices of the split-K workspace) instead, all in the level their operands allow, and ONE element-wise task
+// C = C + P_1 + P_2 + ... (fixed order: deterministic) follows the last of them: a chain of n becomes two levels.  The
+// singles residual (six products into a v x o array), Q_kb + W_kb, the X_ac T / t Q_kb / V_abic t sum of the finish and the
+// one-index terms of a sigma build are such chains.  Costs one write and one read of the array per redirected member, so
+// only small arrays take part.
+void phase_fuse_accumulations(std::vector<PhaseRec>& q) {
+    PhaseQueue& P = g_phase;
+    static const bool off = getenv("PYMES_PHASE_NO_FUSE") != nullptr;
+    // (arrays up to 2 MB: a redirected member costs one write and one read of the array more.  Measured at (20,80), same box:
+    // 1.486 ms without fusion, 1.478 with the cap at 2 MB — the six-term singles residual and its kin —, 1.512 at 8 MB (the
+    // 5-MB Q_kb + W_kb sum), 1.525 at 32 MB (the amplitude-sized sums of the finish); PYMES_PHASE_FUSE_MB overrides)
+    static const uintptr_t fuse_bytes = (uintptr_t)((getenv("PYMES_PHASE_FUSE_MB") ? atof(getenv("PYMES_PHASE_FUSE_MB")) : 2.0) * 1048576.0);
+    if (off || P.serial || !P.ws) return;
+    struct Group { PhaseRange box; int first; std::vector<int> members; bool open; };
+    std::vector<Group> groups;
+    auto touches = [](const PhaseRec& t, const PhaseRange& b) {
+        for (int i = 0; i < t.nr; ++i) if (phase_overlap(t.r[i], b)) return true;
+        for (int i = 0; i < t.nw; ++i) if (phase_overlap(t.w[i], b)) return true;
+        return false;
+    };
+    auto reads = [](const PhaseRec& t, const PhaseRange& b) {
+        for (int i = 0; i < t.nr; ++i) if (phase_overlap(t.r[i], b)) return true;
+        return false;
+    };
+    const int n = (int)q.size();
+    for (int i = 0; i < n; ++i) {
+        const PhaseRec& t = q[i];
+        bool joined = false;
+        for (auto& G : groups) {
+            if (!G.open || !touches(t, G.box)) continue;
+            if (t.acc == 1 && t.box.lo == G.box.lo && t.box.hi == G.box.hi && !reads(t, G.box) && G.members.size() < 7) {
+                G.members.push_back(i);
+                joined = true;
+            } else {
+                G.open = false;
+            }
+        }
+        if (!joined && t.acc >= 0 && t.box.hi > t.box.lo && t.box.hi - t.box.lo <= fuse_bytes)
+            groups.push_back(Group{t.box, i, {}, true});
+    }
+    struct Insert { int after; PhaseRec rec; };
+    std::vector<Insert> ins;
+    for (auto& G : groups) {
+        if (G.members.empty()) continue;
+        const long len = (long)((G.box.hi - G.box.lo) / 8);
+        LinK lk;
+        lk.out = reinterpret_cast<double*>(G.box.lo);
+        lk.n = len;
+        for (int k = 0; k < 8; ++k) { lk.p.x[k] = nullptr; lk.p.c[k] = 0.0; }
+        lk.p.x[0] = lk.out;
+        lk.p.c[0] = 1.0;
+        int nx = 1, last = -1;
+        PhaseRec comb;
+        for (int m : G.members) {
+            double* buf = phase_ws(P.ws, P.ws_doubles, len);
+            if (!buf) break;
+            PhaseRec& t = q[m];
+            if (t.kind == PK_GEMM) {
+                GemmK k;
+                memcpy(&k, t.blob, sizeof k);
+                k.C = buf; k.Cin = buf; k.beta = 0.0;
+                memcpy(t.blob, &k, sizeof k);
+            } else if (t.kind == PK_SPLITK) {
+                SplitkTaskK k;
+                memcpy(&k, t.blob, sizeof k);
+                k.g.C = buf; k.g.Cin = buf; k.g.beta = 0.0;
+                memcpy(t.blob, &k, sizeof k);
+            } else {
+                PermTaskK k;
+                memcpy(&k, t.blob, sizeof k);
+                k.p.out = buf; k.p.beta = 0.0;
+                memcpy(t.blob, &k, sizeof k);
+            }
+            const PhaseRange rb = prange(buf, len);
+            for (int w = 0; w < t.nw; ++w)
+                if (t.w[w].lo == G.box.lo && t.w[w].hi == G.box.hi) t.w[w] = rb;
+            t.box = PhaseRange{0, 0};
+            t.acc = -1;
+            lk.p.x[nx] = buf;
+            lk.p.c[nx] = 1.0;
+            if (comb.nr < 10) comb.r[comb.nr++] = rb;
+            ++nx;
+            last = m;
+        }
+        if (nx == 1) continue;
+        lk.nx = nx;
+        comb.kind = PK_LINCOMB; comb.sub = 0;
+        comb.nblk = grid_for(len);
+        comb.lds = 0;
+        comb.cost = 8.0 * (double)(nx + 1) * (double)len / 4.0e6;
+        comb.words = (int)(sizeof(LinK) / 8);
+        memcpy(comb.blob, &lk, sizeof lk);
+        comb.w[comb.nw++] = G.box;
+        ins.push_back(Insert{last, comb});
+        ++P.fused;
+    }
+    if (ins.empty()) return;
+    std::stable_sort(ins.begin(), ins.end(), [](const Insert& a, const Insert& b) { return a.after > b.after; });
+    for (const auto& x : ins) q.insert(q.begin() + x.after + 1, x.rec);
+}
+
 void phase_flush() {
     PhaseQueue& P = g_phase;
     if (P.q.empty() || P.flushing) return;
     struct Guard {
         PhaseQueue& P;
-        ~Guard() { P.flushing = false; P.q.clear(); P.ws_cursor = 0; }
+        ~Guard() { P.flushing = false; P.q.clear(); P.ws_cursor = 0; P.ws = nullptr; P.ws_doubles = 0; }
     } guard{P};
     P.flushing = true;
     ++P.flushes;
     std::vector<PhaseRec>& q = P.q;
+    phase_fuse_accumulations(q);
     const int n = (int)q.size();
     int nlev = 0;
     for (int i = 0; i < n; ++i) {
@@ -3309,7 +3453,7 @@ void phase_flush() {
     if (log) {
         static const char* names[] = {"gemm", "splitk", "perm", "permT", "gemvC", "gemvF", "gemvR", "update", "lincomb", "dots1", "dots2",
                                       "energy", "tau", "packT", "unpackL", "ringops", "layouts", "assemble", "unpackR", "fockG", "fockGf",
-                                      "fockFt", "fockFin", "traces"};
+                                      "fockFt", "fockFin", "traces", "dotsF"};
         fprintf(stderr, "[phase] flush %ld: %d tasks, %d levels\n", P.flushes, n, nlev);
         for (int lev = 0; lev < nlev; ++lev) {
             fprintf(stderr, "[phase]   L%-2d", lev);
@@ -3391,21 +3535,65 @@ int g_read_next[kMaxDevices] = {0};
 // shared by every context and thread of the process on that device, hence the lock.
 unsigned g_read_gen[kMaxDevices][kReadSlots] = {{0}};
 std::mutex g_read_mu;
+// slots written by the device itself (dots_final_kernel: results + a sequence word straight into the pinned ring, no copy
+// and no event): the wait polls the word.  g_read_flag: pinned, one word per slot; g_read_flagged: the slot's current
+// read-back is of that kind
+long* g_read_flag[kMaxDevices] = {nullptr};
+bool g_read_flagged[kMaxDevices][kReadSlots] = {{false}};
+// The host side of dots_final_kernel: wait for `seq` to appear in the pinned word.  A device that never delivers it (a fault
+// in an earlier kernel) is found by the stream synchronisation this falls back to after two seconds.
+bool poll_flag(const long* flag, long seq, hipStream_t st) {
+    const auto t0 = std::chrono::steady_clock::now();
+    long spins = 0;
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            if (st) HIP_CHECK(hipStreamSynchronize(st));
+            else HIP_CHECK(hipDeviceSynchronize());
+            return __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq;
+        }
+        __builtin_ia32_pause();
+    }
+    return true;
+}
+void ensure_read_ring(int dv) {
+    if (g_read_host[dv]) return;
+    HIP_CHECK(hipHostMalloc((void**)&g_read_host[dv], sizeof(double) * kReadSlots * kReadDoubles, hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_CHECK(hipHostMalloc((void**)&g_read_flag[dv], sizeof(long) * kReadSlots, hipHostMallocMapped | hipHostMallocCoherent));
+    for (int i = 0; i < kReadSlots; ++i) {
+        g_read_flag[dv][i] = 0;
+        HIP_CHECK(hipEventCreateWithFlags(&g_read_ev[dv][i], hipEventDisableTiming));
+    }
+}
 int readback_start_impl(const double* dev_ptr, int n, hipStream_t st) {
     if (n < 1 || n > kReadDoubles) throw std::runtime_error("readback: 1..128 doubles");
     int dv = 0;
     HIP_CHECK(hipGetDevice(&dv));
     if (dv < 0 || dv >= kMaxDevices) throw std::runtime_error("device ordinal out of range");
     std::lock_guard<std::mutex> lock(g_read_mu);
-    if (!g_read_host[dv]) {
-        HIP_CHECK(hipHostMalloc((void**)&g_read_host[dv], sizeof(double) * kReadSlots * kReadDoubles));
-        for (int i = 0; i < kReadSlots; ++i) HIP_CHECK(hipEventCreateWithFlags(&g_read_ev[dv][i], hipEventDisableTiming));
-    }
+    ensure_read_ring(dv);
     const int slot = g_read_next[dv];
     g_read_next[dv] = (slot + 1) % kReadSlots;
     const unsigned gen = (g_read_gen[dv][slot] = (g_read_gen[dv][slot] + 1) & 0x3fffffu);
+    g_read_flagged[dv][slot] = false;
     HIP_CHECK(hipMemcpyAsync(g_read_host[dv] + slot * kReadDoubles, dev_ptr, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipEventRecord(g_read_ev[dv][slot], st));
+    return (int)((gen << 8) | (unsigned)slot);
+}
+// A slot that the DEVICE fills (dots_final_kernel): returns the ticket and the arguments of that kernel's result part
+int readback_reserve_flagged(int dv, double** out_dev, long** flag_dev, long* seq) {
+    std::lock_guard<std::mutex> lock(g_read_mu);
+    ensure_read_ring(dv);
+    const int slot = g_read_next[dv];
+    g_read_next[dv] = (slot + 1) % kReadSlots;
+    const unsigned gen = (g_read_gen[dv][slot] = (g_read_gen[dv][slot] + 1) & 0x3fffffu);
+    g_read_flagged[dv][slot] = true;
+    // (the word counts on: generation numbers wrap at 2^22, and a word left over from 2^22 x 16 read-backs ago is not a worry)
+    *seq = (long)gen | ((long)(slot + 1) << 32);
+    void *od = nullptr, *fd = nullptr;
+    HIP_CHECK(hipHostGetDevicePointer(&od, g_read_host[dv] + slot * kReadDoubles, 0));
+    HIP_CHECK(hipHostGetDevicePointer(&fd, g_read_flag[dv] + slot, 0));
+    *out_dev = static_cast<double*>(od);
+    *flag_dev = static_cast<long*>(fd);
     return (int)((gen << 8) | (unsigned)slot);
 }
 void readback_wait_impl(int ticket, double* out, int n) {
@@ -3416,13 +3604,20 @@ void readback_wait_impl(int ticket, double* out, int n) {
     if (ticket < 0 || slot >= kReadSlots || dv < 0 || dv >= kMaxDevices || n < 1 || n > kReadDoubles)
         throw std::runtime_error("readback: bad ticket");
     hipEvent_t ev;
+    bool flagged;
     {
         std::lock_guard<std::mutex> lock(g_read_mu);
         if (!g_read_host[dv] || gen == 0 || g_read_gen[dv][slot] != gen)
             throw std::runtime_error("readback: the slot was never started or has been reused since (16 later read-backs)");
         ev = g_read_ev[dv][slot];
+        flagged = g_read_flagged[dv][slot];
     }
-    HIP_CHECK(hipEventSynchronize(ev));
+    if (flagged) {
+        if (!poll_flag(g_read_flag[dv] + slot, (long)gen | ((long)(slot + 1) << 32), nullptr))
+            throw std::runtime_error("readback: the device never delivered the result");
+    } else {
+        HIP_CHECK(hipEventSynchronize(ev));
+    }
     std::lock_guard<std::mutex> lock(g_read_mu);
     if (g_read_gen[dv][slot] != gen) throw std::runtime_error("readback: the slot was reused while it was awaited");
     for (int i = 0; i < n; ++i) out[i] = g_read_host[dv][slot * kReadDoubles + i];
@@ -3434,10 +3629,13 @@ int current_device() {
     if (d < 0 || d >= kMaxDevices) throw std::runtime_error("device ordinal out of range");
     return d;
 }
+long g_dot_seq[kMaxDevices] = {0};
 void ensure_dot_ws(int d) {
     if (g_dot_ws[d]) return;
     HIP_CHECK(hipMalloc((void**)&g_dot_ws[d], sizeof(double) * (16 * kDotBlocks + 16)));
-    HIP_CHECK(hipHostMalloc((void**)&g_dot_host[d], sizeof(double) * 16));
+    // [0,16): results, [16]: the sequence word of dots_final_kernel (device-written: mapped and coherent)
+    HIP_CHECK(hipHostMalloc((void**)&g_dot_host[d], sizeof(double) * 24, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(g_dot_host[d], 0, sizeof(double) * 24);
 }
 
 template <int BM, int BN, bool AKC, bool BKC, int VEC, bool STREAM = false>
@@ -4057,6 +4255,7 @@ bool phase_gemm(const Gemm& g, bool akc, bool bkc, int64_t a_sm, int64_t a_sk, i
     const double dM = (double)g.M, dN = (double)g.N, dK = (double)g.K, dB = (double)nbatch;
     const double cost = 2.0 * dM * dN * dK * dB / 4.0e7 + 8.0 * (dM * dK + dK * dN + (g.beta != 0.0 ? 2.0 : 1.0) * dM * dN) * dB / 4.0e6;
     if (!phase_small(cost)) return false;
+    if (g.splitk_ws) { g_phase.ws = g.splitk_ws; g_phase.ws_doubles = g.splitk_ws_doubles; }     // (of THIS phase's engine: cleared by the flush)
     // deep products with enough 128 x 128 tiles for the LDS-DMA kernel (k-split over the chip) belong there, small as they may be
     {
         const long t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128) * nbatch;
@@ -4119,6 +4318,11 @@ bool phase_gemm(const Gemm& g, bool akc, bool bkc, int64_t a_sm, int64_t a_sk, i
     const PhaseRange rC = pbox(g.C, {{g.M, g.ldc}, {g.N, 1}, {g.nb1, g.c_b1}, {g.nb2, g.c_b2}});
     const PhaseRange rCin = (g.beta != 0.0 && k.Cin != g.C) ? pbox(k.Cin, {{g.M, g.ldc}, {g.N, 1}, {g.nb1, g.c_b1}, {g.nb2, g.c_b2}})
                                                            : PhaseRange{0, 0};
+    // (accumulation fusion: the product's output is ONE contiguous array written by one task — no main / tail pair — and it
+    // either overwrites it, beta = 0, or accumulates into it, beta = 1 with the beta term read from the output itself)
+    const bool dense_c = g.ldc == g.N && (g.nb2 == 1 || g.c_b2 == g.M * g.N) && (g.nb1 == 1 || g.c_b1 == g.nb2 * g.M * g.N);
+    const bool whole_dense = dense_c && (main_tiles == 0 || tail_tiles == 0) && (g.beta == 0.0 || (g.beta == 1.0 && k.Cin == g.C));
+    const signed char acc = g.beta == 1.0 ? 1 : 0;
     auto add = [&](long tile_begin, long ntiles, int nsplit, double share) {
         const long kt_per = (ktiles + nsplit - 1) / nsplit;
         k.kchunk = (int)std::max<long>(kt_per * BK, BK);
@@ -4138,9 +4342,11 @@ bool phase_gemm(const Gemm& g, bool akc, bool bkc, int64_t a_sm, int64_t a_sk, i
             PhaseRec& u = phase_push(PK_SPLITK, 0, ntiles * (BM * BN / 256), 0, 2.0, r);
             phase_reads(u, {rW, rCin});
             phase_writes(u, {rC});
+            if (whole_dense) { u.box = rC; u.acc = acc; }
         } else {
             phase_reads(t, {rCin});
             phase_writes(t, {rC});
+            if (whole_dense) { t.box = rC; t.acc = acc; }
         }
     };
     const double fmain = tiles > 0 ? (double)main_tiles / (double)tiles : 1.0;
@@ -4457,6 +4663,11 @@ void permute(const Permute& p, stream_t s) {
         PhaseRec& r = phase_push(kind, 0, nblk, lds, cost, t);
         phase_reads(r, {ri});
         phase_writes(r, {ro});
+        // (accumulation fusion: the output is one contiguous array starting at p.out, overwritten or accumulated into)
+        if (ro.hi - ro.lo == 8 * (uintptr_t)total && ro.lo == reinterpret_cast<uintptr_t>(p.out) && (p.beta == 0.0 || p.beta == 1.0)) {
+            r.box = ro;
+            r.acc = p.beta == 1.0 ? 1 : 0;
+        }
     };
     // tiled path: out unit-stride on the last dim, in unit-stride on another dim
     int q = -1;
@@ -4565,6 +4776,18 @@ static void launch_dots_stage2(int npairs, double* ws, int nb, double* out_dev, 
     HIP_CHECK(hipGetLastError());
 }
 
+// the last stage of a reduction the host waits for (dots_final_kernel), as a task of the open phase or a launch
+static void launch_dots_final(const DotsFinalK& k, double* ws, hipStream_t st) {
+    if (phase_open(st)) {
+        PhaseRec& t = phase_push(PK_DOTS_FINAL, 0, 1, 0, 1.0, k);
+        phase_reads(t, {prange(ws, 16L * kDotBlocks)});
+        // (the pinned destination is nobody else's: no range to declare; the task is ordered behind stage 1 through ws)
+        return;
+    }
+    PYMES_LAUNCH(dots_final_kernel, dim3(1), dim3(256), 0, st, k);
+    HIP_CHECK(hipGetLastError());
+}
+
 void dots(int npairs, const double* const* x, const double* const* y, const int64_t* n, double* out_host, stream_t s) {
     if (npairs <= 0) return;
     if (npairs > 16) throw std::runtime_error("dots: at most 16 pairs per call");
@@ -4572,10 +4795,14 @@ void dots(int npairs, const double* const* x, const double* const* y, const int6
     const int dv = current_device();
     ensure_dot_ws(dv);
     const int nb = launch_dots_stage1(npairs, x, y, n, g_dot_ws[dv], st);
-    double* out_dev = g_dot_ws[dv] + 16 * kDotBlocks;
-    launch_dots_stage2(npairs, g_dot_ws[dv], nb, out_dev, st);
-    HIP_CHECK(hipMemcpyAsync(g_dot_host[dv], out_dev, sizeof(double) * npairs, hipMemcpyDeviceToHost, st));
-    wait_idle(st);
+    // results and a sequence word straight into pinned memory, polled for (no copy, no stream synchronisation)
+    void* hd = nullptr;
+    HIP_CHECK(hipHostGetDevicePointer(&hd, g_dot_host[dv], 0));
+    const long seq = ++g_dot_seq[dv];
+    launch_dots_final(DotsFinalK{g_dot_ws[dv], static_cast<double*>(hd), reinterpret_cast<long*>(static_cast<double*>(hd) + 16), seq, nb, npairs},
+                      g_dot_ws[dv], st);
+    phase_flush();
+    if (!poll_flag(reinterpret_cast<const long*>(g_dot_host[dv] + 16), seq, st)) throw std::runtime_error("dots: the device never delivered the result");
     for (int i = 0; i < npairs; ++i) out_host[i] = g_dot_host[dv][i];
 }
 
@@ -4625,9 +4852,14 @@ int energy_norms_start(const double* f, const double* t1, const double* t2, cons
         else PYMES_LAUNCH(energy_norms_kernel<1>, dim3(nb), dim3(256), 0, st, k);
         HIP_CHECK(hipGetLastError());
     }
-    double* out_dev = g_dot_ws[dv] + 16 * kDotBlocks;
-    launch_dots_stage2(6, g_dot_ws[dv], nb, out_dev, st);
-    return readback_start_impl(out_dev, 6, st);
+    // the six sums straight into a slot of the pinned read-back ring, with the slot's sequence word behind them
+    double* out_pin = nullptr;
+    long* flag = nullptr;
+    long seq = 0;
+    const int ticket = readback_reserve_flagged(dv, &out_pin, &flag, &seq);
+    launch_dots_final(DotsFinalK{g_dot_ws[dv], out_pin, flag, seq, nb, 6}, g_dot_ws[dv], st);
+    phase_flush();
+    return ticket;
 }
 void energy_norms(const double* f, const double* t1, const double* t2, const double* Edir, const double* Eex,
                   const double* dt2, int no, int nv, double out_host[6], stream_t s) {
@@ -5171,6 +5403,8 @@ void rows_unpack(const double* Q, double* out, int64_t rows, int no, stream_t s)
         PhaseRec& t = phase_push(PK_ROWS_UNPACK, 0, grid_for(total), 0, cost, k);
         phase_reads(t, {prange(Q, total)});
         phase_writes(t, {prange(out, total)});
+        t.box = prange(out, total);
+        t.acc = 0;
         return;
     }
     PYMES_LAUNCH(rows_unpack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, k);
