@@ -379,6 +379,28 @@ int pymes_ccsd_sharded_finish(pymes_ctx* ctx, const double* f_dev, const double*
                               const double* dtc_dev, const pymes_shard_buffers* buffers, int* slot);
 int pymes_ccsd_sharded_energy(pymes_ctx* ctx, int slot, double* out_host /* [6], as pymes_energy_norms */);
 int pymes_ccsd_sharded_await(pymes_ctx* ctx, double* t2_dev, const pymes_shard_buffers* buffers);
+/* CCD / DCD (pymes/solver/ccd.py:93-150; the reference's UEG drivers, BASELINE config 4) as the same whole steps: the loop body
+ * of ccd.py:100-121 for this rank — ring products (their rows exchanged while the ladders run), ladders, the doubles residual
+ * of the rank's virtual pairs as compact tiles rc_dev.  There is no T1: nothing is dressed, no singles residual; of `buffers`
+ * only ETd, ETx, L, Tall and S are used (the others may be NULL).  The pass is completed by pymes_cc_update_pairs, the mixer
+ * and pymes_ccsd_sharded_finish / _energy / _await with f_dev = t1_dev = NULL.  flags: PYMES_DCD, PYMES_OWNER_TILES. */
+int pymes_ccd_sharded_residuals(pymes_ctx* ctx, const double* f_dev, double* t2_dev, const pymes_shard_buffers* buffers,
+                                uint32_t flags, double* rc_dev);
+/* OWNER TILES (flag PYMES_OWNER_TILES of pymes_ccsd_sharded_residuals / pymes_ccd_sharded_residuals).  In the pair-sharded
+ * tail rank q assembles R only for its virtual pairs P(a,b), a in [a0,a1), and reads of ETd / ETx just the tiles [(a,.),(b,.)]
+ * and [(b,.),(a,.)]: rows [0, a1 o) x columns [a0 o, a1 o) and rows [a0 o, a1 o) x columns [0, a0 o).  ONE all-to-all of those
+ * rectangles ((50,200) on 8 ranks: 1.06 GB per iteration on the wire instead of 2.33) replaces the two all-gathers.  The host
+ * program adds an all-to-all to its table —
+ *   alltoallv_start(user, send_dev, send_counts[world], recv_dev, recv_counts[world], stream, &ticket)
+ * counts in doubles, the pieces for / from rank 0, 1, ... contiguous in that order in send_dev / recv_dev (ncclSend / ncclRecv
+ * in a group, or MPI_Alltoallv with running offsets); ordering and tickets as for the other collectives — and hands over two
+ * staging buffers of pymes_owner_tile_sizes doubles.  The library packs and unpacks the rectangles itself. */
+#define PYMES_OWNER_TILES (1u << 21)
+typedef int (*pymes_alltoallv_fn)(void* user, const double* send_dev, const int64_t* send_counts, double* recv_dev,
+                                  const int64_t* recv_counts, void* stream, int64_t* ticket);
+int pymes_set_alltoallv(pymes_ctx* ctx, pymes_alltoallv_fn fn /* NULL removes it */);
+int pymes_owner_tile_sizes(pymes_ctx* ctx, int rank, int world, int64_t* send_doubles, int64_t* recv_doubles);
+int pymes_set_owner_tile_buffers(pymes_ctx* ctx, double* send_dev, double* recv_dev);
 /* CCSD.get_energy, ccsd.py:458-466: e_out = {one-body, direct, exchange}; f is the UNDRESSED Fock */
 int pymes_ccsd_energy(pymes_ctx* ctx, const double* f_dev, const double* t1_dev, const double* t2_dev,
                       double* e_out_host);

@@ -144,6 +144,10 @@ SIGNATURES = {
     "pymes_set_collectives": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pymes_shard_buffer_sizes": (C.c_int, [C.c_void_p, C.c_int, c_i64_p]),
     "pymes_ccsd_sharded_residuals": (C.c_int, [C.c_void_p] * 6 + [C.c_uint32, C.c_void_p]),
+    "pymes_ccd_sharded_residuals": (C.c_int, [C.c_void_p] * 4 + [C.c_uint32, C.c_void_p]),
+    "pymes_set_alltoallv": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pymes_owner_tile_sizes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_i64_p, c_i64_p]),
+    "pymes_set_owner_tile_buffers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "pymes_ccsd_sharded_finish": (C.c_int, [C.c_void_p] * 6 + [C.POINTER(C.c_int)]),
     "pymes_ccsd_sharded_energy": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "pymes_ccsd_sharded_await": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -169,6 +173,7 @@ SIGNATURES = {
 }
 
 PYMES_DCD, PYMES_USE_DRESSED, PYMES_SKIP_LADDER, PYMES_SYM_LADDER, PYMES_SYM_RINGS = 1, 2, 4, 8, 16
+PYMES_OWNER_TILES = 1 << 21
 PYMES_REUSE_LAYOUTS = 32
 PYMES_T1_ZERO = 1 << 20
 PYMES_SLAB_RINGS_ONLY, PYMES_SLAB_LADDERS_ONLY = 64, 128

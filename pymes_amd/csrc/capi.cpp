@@ -634,10 +634,13 @@ int pymes_shard_buffer_sizes(pymes_ctx* ctx, int world, int64_t* sizes) {
     });
 }
 namespace {
-pymes::Engine::ShardBuffers shard_buffers(const pymes_shard_buffers* b) {
+pymes::Engine::ShardBuffers shard_buffers(const pymes_shard_buffers* b, bool ccd = false) {
     if (!b) throw pymes::Error("null buffers");
-    for (const double* p : {b->ETd, b->ETx, b->L, b->QK, b->Tall, b->W, b->Xvv, b->P, b->R1, b->S})
+    for (const double* p : {b->ETd, b->ETx, b->L, b->Tall, b->S})
         if (!p) throw pymes::Error("null exchange buffer");
+    if (!ccd)
+        for (const double* p : {b->QK, b->W, b->Xvv, b->P, b->R1})
+            if (!p) throw pymes::Error("null exchange buffer");
     return pymes::Engine::ShardBuffers{b->ETd, b->ETx, b->L, b->QK, b->Tall, b->W, b->Xvv, b->P, b->R1, b->S};
 }
 }  // namespace
@@ -645,16 +648,34 @@ int pymes_ccsd_sharded_residuals(pymes_ctx* ctx, const double* f, double* fd, co
                                  const pymes_shard_buffers* buffers, uint32_t flags, double* rc) {
     return guarded([&] {
         need(f, "f"); need(fd, "fd"); need(t1, "t1"); need(t2, "t2"); need(rc, "rc");
-        if (flags & ~PYMES_DCD) throw pymes::Error("sharded step: flags is PYMES_DCD or 0");
+        if (flags & ~(PYMES_DCD | PYMES_OWNER_TILES)) throw pymes::Error("sharded step: flags are PYMES_DCD and PYMES_OWNER_TILES");
         E(ctx).ccsd_sharded_residuals(f, fd, t1, t2, shard_buffers(buffers), flags, rc);
     });
+}
+int pymes_ccd_sharded_residuals(pymes_ctx* ctx, const double* f, double* t2, const pymes_shard_buffers* buffers, uint32_t flags,
+                                double* rc) {
+    return guarded([&] {
+        need(f, "f"); need(t2, "t2"); need(rc, "rc");
+        if (flags & ~(PYMES_DCD | PYMES_OWNER_TILES)) throw pymes::Error("sharded step: flags are PYMES_DCD and PYMES_OWNER_TILES");
+        E(ctx).ccd_sharded_residuals(f, t2, shard_buffers(buffers, true), flags, rc);
+    });
+}
+int pymes_set_alltoallv(pymes_ctx* ctx, pymes_alltoallv_fn fn) {
+    return guarded([&] { E(ctx).set_alltoallv(fn); });
+}
+int pymes_owner_tile_sizes(pymes_ctx* ctx, int rank, int world, int64_t* send_doubles, int64_t* recv_doubles) {
+    return guarded([&] { E(ctx).owner_tile_sizes(rank, world, send_doubles, recv_doubles); });
+}
+int pymes_set_owner_tile_buffers(pymes_ctx* ctx, double* send_dev, double* recv_dev) {
+    return guarded([&] { E(ctx).set_owner_tile_buffers(send_dev, recv_dev); });
 }
 int pymes_ccsd_sharded_finish(pymes_ctx* ctx, const double* f, const double* t1, const double* tc, const double* dtc,
                               const pymes_shard_buffers* buffers, int* slot) {
     return guarded([&] {
-        need(f, "f"); need(t1, "t1"); need(tc, "tc");
+        need(tc, "tc");                  // (f, t1 NULL: CCD / DCD — no one-body energy, no T1 norm)
+        if ((f == nullptr) != (t1 == nullptr)) throw pymes::Error("sharded finish: f and t1 are given together or not at all");
         if (!slot) throw pymes::Error("null output");
-        *slot = E(ctx).ccsd_sharded_finish(f, t1, tc, dtc, shard_buffers(buffers));
+        *slot = E(ctx).ccsd_sharded_finish(f, t1, tc, dtc, shard_buffers(buffers, t1 == nullptr));
     });
 }
 int pymes_ccsd_sharded_energy(pymes_ctx* ctx, int slot, double* out) {
@@ -666,7 +687,7 @@ int pymes_ccsd_sharded_energy(pymes_ctx* ctx, int slot, double* out) {
 int pymes_ccsd_sharded_await(pymes_ctx* ctx, double* t2, const pymes_shard_buffers* buffers) {
     return guarded([&] {
         need(t2, "t2");
-        E(ctx).ccsd_sharded_await(t2, shard_buffers(buffers));
+        E(ctx).ccsd_sharded_await(t2, shard_buffers(buffers, true));
     });
 }
 int pymes_ccsd_energy(pymes_ctx* ctx, const double* f, const double* t1, const double* t2, double* e_out) {

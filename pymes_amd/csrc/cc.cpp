@@ -1643,6 +1643,72 @@ struct Hooks {
 int64_t chunk_of(int64_t n, int world) { return (n + world - 1) / world; }
 }  // namespace
 
+// ---- owner tiles: what rank `to` reads of the rows of a ring-product matrix that rank `from` computed (pymes_amd/dist.py,
+// owner_tile_plan: the same rectangles).  Rank q owns the pairs P(a,b), a in [a0,a1); its assembly reads the tiles
+// [(a,.),(b,.)] and [(b,.),(a,.)], b <= a: rows [0, a1 o) x columns [a0 o, a1 o) and rows [a0 o, a1 o) x columns [0, a0 o).
+std::vector<Engine::Rect> Engine::owner_tile_rects(int from, int to, int world) const {
+    std::vector<Rect> out;
+    if (from == to) return out;
+    const int64_t o = no, ov = o * nv, npp = static_cast<int64_t>(nv) * (nv + 1) / 2;
+    auto slab = [&](int64_t n, int r, int64_t& lo, int64_t& hi) {
+        const int64_t c = (n + world - 1) / world;
+        lo = std::min<int64_t>(r * c, n);
+        hi = std::min<int64_t>(lo + c, n);
+    };
+    int64_t q0, q1, r0, r1;
+    slab(npp, to, q0, q1);
+    if (q1 <= q0) return out;
+    const int64_t A0 = static_cast<int64_t>(a_of_pair_row(q0)) * o, A1 = static_cast<int64_t>(a_of_pair_row(q1 - 1) + 1) * o;
+    slab(ov, from, r0, r1);
+    if (std::min(r1, A1) > r0) out.push_back(Rect{r0, std::min(r1, A1), A0, A1});
+    if (A0 > 0 && std::min(r1, A1) > std::max(r0, A0)) out.push_back(Rect{std::max(r0, A0), std::min(r1, A1), 0, A0});
+    return out;
+}
+void Engine::owner_tile_sizes(int rank, int world, int64_t* send_doubles, int64_t* recv_doubles) const {
+    if (world < 1 || rank < 0 || rank >= world) throw Error("owner_tile_sizes: bad rank/world");
+    int64_t s = 0, r = 0;
+    for (int q = 0; q < world; ++q) {
+        for (const Rect& x : owner_tile_rects(rank, q, world)) s += 2 * (x.r1 - x.r0) * (x.c1 - x.c0);      // both matrices
+        for (const Rect& x : owner_tile_rects(q, rank, world)) r += 2 * (x.r1 - x.r0) * (x.c1 - x.c0);
+    }
+    if (send_doubles) *send_doubles = std::max<int64_t>(s, 1);
+    if (recv_doubles) *recv_doubles = std::max<int64_t>(r, 1);
+}
+int64_t Engine::owner_tiles_start(const ShardBuffers& b) {
+    if (!alltoallv_ || !xs_ || !xr_) throw Error("sharded step: owner tiles need pymes_set_alltoallv and pymes_set_owner_tile_buffers");
+    const int rank = coll_.rank, world = coll_.world;
+    const int64_t ov = static_cast<int64_t>(no) * nv;
+    std::vector<int64_t> ns(world, 0), nr(world, 0);
+    int64_t off = 0;
+    for (int q = 0; q < world; ++q)
+        for (double* m : {b.ETd, b.ETx})
+            for (const Rect& x : owner_tile_rects(rank, q, world)) {         // (small strided copies: tasks of ONE phase level)
+                const int64_t rows = x.r1 - x.r0, cols = x.c1 - x.c0;
+                copy(slice(slice(make_view(m, {x.r1, ov}), 0, x.r0, x.r1), 1, x.c0, x.c1), make_view(xs_ + off, {rows, cols}));
+                off += rows * cols;
+                ns[q] += rows * cols;
+            }
+    for (int p = 0; p < world; ++p)
+        for (const Rect& x : owner_tile_rects(p, rank, world)) nr[p] += 2 * (x.r1 - x.r0) * (x.c1 - x.c0);
+    dev::gemm_group_sync();
+    dev::phase_sync();
+    int64_t t = 0;
+    if (alltoallv_(coll_.user, xs_, ns.data(), xr_, nr.data(), stream, &t) != 0) throw Error("collective hook: alltoallv_start failed");
+    return t;
+}
+void Engine::owner_tiles_finish(const ShardBuffers& b) {
+    const int rank = coll_.rank, world = coll_.world;
+    const int64_t ov = static_cast<int64_t>(no) * nv;
+    int64_t off = 0;
+    for (int p = 0; p < world; ++p)
+        for (double* m : {b.ETd, b.ETx})
+            for (const Rect& x : owner_tile_rects(p, rank, world)) {
+                const int64_t rows = x.r1 - x.r0, cols = x.c1 - x.c0;
+                copy(make_view(xr_ + off, {rows, cols}), slice(slice(make_view(m, {x.r1, ov}), 0, x.r0, x.r1), 1, x.c0, x.c1));
+                off += rows * cols;
+            }
+}
+
 void Engine::ccsd_sharded_await(double* t2, const ShardBuffers& b) {
     if (!t2_in_flight_) return;
     if (!coll_set_) throw Error("sharded step: no collectives set (pymes_set_collectives)");
@@ -1668,6 +1734,7 @@ void Engine::ccsd_sharded_residuals(const double* f, double* fd, const double* t
     // PYMES_SLAB_RINGS_ONLY 64, PYMES_SLAB_LADDERS_ONLY 128
     const unsigned dcd = flags & 1u, kSlabRingsOnly = 64u, kSlabLaddersOnly = 128u;
     const unsigned slab = dcd | 2u | 8u | 16u;
+    const bool owner = (flags & kOwnerTiles) != 0;
     h.mark("begin");
     // K-sharded partial sums, all-reduced: the T1.V intermediates of the dressed Fock matrix (ccsd.py:163, this rank's chunk of
     // j).  What needs T1 only comes first: the all-gather of the new T2 that the previous pass left in flight is awaited — and
@@ -1700,8 +1767,13 @@ void Engine::ccsd_sharded_residuals(const double* f, double* fd, const double* t
     // of L never leave the rank — and the singles residual are computed
     residual_slab(fd, t2, b.ETd, b.ETx, b.L, rank, world, slab | kSlabRingsOnly, t1, b.QK, b.P);
     h.mark("ring products");
-    const int64_t tD = h.allgather(b.ETd, chunk_of(ov, world) * ov);
-    const int64_t tE = h.allgather(b.ETx, chunk_of(ov, world) * ov);
+    // rows of the ring products: two all-gathers of the whole matrices, or ONE all-to-all of the tiles each pair owner reads
+    int64_t tD = 0, tE = 0, tO = 0;
+    if (owner) tO = owner_tiles_start(b);
+    else {
+        tD = h.allgather(b.ETd, chunk_of(ov, world) * ov);
+        tE = h.allgather(b.ETx, chunk_of(ov, world) * ov);
+    }
     h.wait(tJ);
     residual_slab(fd, t2, b.ETd, b.ETx, b.L, rank, world, slab | kSlabLaddersOnly, t1, b.QK, b.P);
     h.mark("ladders, Q_kb");
@@ -1710,12 +1782,54 @@ void Engine::ccsd_sharded_residuals(const double* f, double* fd, const double* t
     const int64_t tV = h.allreduce(b.Xvv, v * v);
     singles_residual_partial(fd, t1, t2, b.R1, rank, world, true);    // :167 over this rank's chunk of the occupied index
     const int64_t tR = h.allreduce(b.R1, v * o);
-    for (int64_t t : {tD, tE, tQ, tV, tR}) h.wait(t);
+    if (owner) {
+        h.wait(tO);
+        owner_tiles_finish(b);
+    } else {
+        h.wait(tD);
+        h.wait(tE);
+    }
+    for (int64_t t : {tQ, tV, tR}) h.wait(t);
     h.mark("X_ac, singles residual, waits");
     int64_t r0, r1;
     pair_chunk(rank, world, r0, r1);
     if (r1 <= r0) dev::memset_zero(rc, sizeof(double) * 2 * o2, stream);       // a rank without pairs: one zero tile pair
     residual_finish_pairs(fd, t2, b.ETd, b.ETx, b.L, rc, slab, t1, b.QK, rank, world, b.Xvv);     // :171, this rank's pairs
+    h.mark("finish + assembly (pairs)");
+}
+
+void Engine::ccd_sharded_residuals(const double* f, double* t2, const ShardBuffers& b, unsigned flags, double* rc) {
+    if (!coll_set_) throw Error("sharded step: no collectives set (pymes_set_collectives)");
+    if (!dev::fused_pair_kernels_ok(no)) throw Error("sharded step: nocc too large for the pair-sharded tail");
+    const Hooks h{coll_, stream};
+    const int rank = coll_.rank, world = coll_.world;
+    const int64_t o = no, v = nv, ov = o * v, o2 = o * o;
+    const unsigned dcd = flags & 1u, kSlabRingsOnly = 64u, kSlabLaddersOnly = 128u;
+    const unsigned slab = dcd | 8u | 16u;                      // undressed blocks: CCD / DCD have no T1 (ccd.py:100-121)
+    const bool owner = (flags & kOwnerTiles) != 0;
+    h.mark("begin");
+    ccsd_sharded_await(t2, b);                                 // the new T2 the previous pass left in flight
+    residual_slab(f, t2, b.ETd, b.ETx, b.L, rank, world, slab | kSlabRingsOnly);
+    h.mark("ring products");
+    int64_t tD = 0, tE = 0, tO = 0;
+    if (owner) tO = owner_tiles_start(b);
+    else {
+        tD = h.allgather(b.ETd, chunk_of(ov, world) * ov);
+        tE = h.allgather(b.ETx, chunk_of(ov, world) * ov);
+    }
+    residual_slab(f, t2, b.ETd, b.ETx, b.L, rank, world, slab | kSlabLaddersOnly);      // the rows of L stay on the rank
+    if (owner) {
+        h.wait(tO);
+        owner_tiles_finish(b);
+    } else {
+        h.wait(tD);
+        h.wait(tE);
+    }
+    h.mark("ladders, waits");
+    int64_t r0, r1;
+    pair_chunk(rank, world, r0, r1);
+    if (r1 <= r0) dev::memset_zero(rc, sizeof(double) * 2 * o2, stream);
+    residual_finish_pairs(f, t2, b.ETd, b.ETx, b.L, rc, slab, nullptr, nullptr, rank, world, nullptr);
     h.mark("finish + assembly (pairs)");
 }
 
@@ -1734,7 +1848,8 @@ int Engine::ccsd_sharded_finish(const double* f, const double* t1, const double*
     // to the host on the side — nothing on this stream waits for the host.  The all-gather of the new T2 is only STARTED, after
     // that small all-reduce (a communicator runs its collectives in order: behind the 0.8-GB transfer the six numbers would
     // wait for it)
-    dev::energy_norms_pairs_dev(f, t1, tc, get_static("Edir"), get_static("Eex"), dtc, no, nv, r0, r1, rank == 0, b.S, stream);
+    dev::energy_norms_pairs_dev(f, t1, tc, get_static("Edir"), get_static("Eex"), dtc, no, nv, r0, r1, rank == 0 && t1 && f, b.S,
+                                stream);
     h.wait(h.allreduce(b.S, 6));
     const int slot = dev::readback_start(b.S, 6, stream);
     t2_ticket_ = h.allgather(b.Tall, c * 2 * o2);

@@ -261,12 +261,26 @@ class Engine {
     };
     void set_collectives(const Collectives* c);          // nullptr: none (single rank)
     bool has_collectives() const { return coll_set_; }
+    // Optional extension of the table: an all-to-all with per-peer counts (doubles), the pieces of `send` / `recv` contiguous
+    // in rank order.  With it and the two staging buffers (owner_tile_sizes) the rows of the ring products travel as the
+    // OWNER TILES of the pair-sharded tail — rank q reads of ETd / ETx only the tiles [(a,.),(b,.)] and [(b,.),(a,.)] of its
+    // pairs P(a,b) — instead of two all-gathers of the whole matrices (flag kOwnerTiles of the sharded residual steps).
+    typedef int (*alltoallv_fn)(void* user, const double* send, const int64_t* send_counts, double* recv,
+                                const int64_t* recv_counts, void* stream, int64_t* ticket);
+    void set_alltoallv(alltoallv_fn fn) { alltoallv_ = fn; }
+    void set_owner_tile_buffers(double* send, double* recv) { xs_ = send; xr_ = recv; }
+    void owner_tile_sizes(int rank, int world, int64_t* send_doubles, int64_t* recv_doubles) const;
+    static constexpr unsigned kOwnerTiles = 1u << 21;
     // ccsd.py:161-171 for this rank: dressed Fock + the dressed blocks of its slab, ring products (rows exchanged), ladders,
     // Q_kb, X_ac, R1 (all-reduced, left in b.R1), R2 of its virtual pairs as compact tiles rc [max(pairs,1)][2][o*o]; t2
     // [v,v,o,o] is the replicated array (completed from the exchange the previous ccsd_sharded_finish left in flight before
     // it is read).  Writes only b.* , fd and rc: a caller may enqueue it ahead of reading the previous energy.  flags: PYMES_DCD
     void ccsd_sharded_residuals(const double* f, double* fd, const double* t1, double* t2, const ShardBuffers& b,
                                 unsigned flags, double* rc);
+    // ccd.py:100-121 for this rank (no T1: nothing is dressed, no singles residual): ring products (rows exchanged while the
+    // ladders run), ladders, the doubles residual of the rank's pairs as compact tiles rc.  Of b only ETd, ETx, L, Tall, S
+    // are used.  ccsd_sharded_finish / _energy / _await with f = t1 = nullptr complete the pass.
+    void ccd_sharded_residuals(const double* f, double* t2, const ShardBuffers& b, unsigned flags, double* rc);
     // ccsd.py:189-197 + the hand-over of the new amplitudes: partial energies / norms of (t1, tc, dtc) all-reduced on the
     // device and copied to the host on the side (returns the read-back slot for ccsd_sharded_energy), tc into the exchange
     // buffer, all-gather of the new T2 started (awaited by the next ccsd_sharded_residuals or by ccsd_sharded_await)
@@ -310,6 +324,12 @@ class Engine {
     std::set<void*> user_allocs_;
     // exchange / staging buffers of ccsd_residuals (engine scratch, held from the first call to release_residual_buffers)
     Collectives coll_;
+    alltoallv_fn alltoallv_ = nullptr;
+    double *xs_ = nullptr, *xr_ = nullptr;
+    struct Rect { int64_t r0, r1, c0, c1; };
+    std::vector<Rect> owner_tile_rects(int from, int to, int world) const;
+    int64_t owner_tiles_start(const ShardBuffers& b);
+    void owner_tiles_finish(const ShardBuffers& b);
     bool coll_set_ = false, t2_in_flight_ = false;
     int64_t t2_ticket_ = 0;
     double *res_fd_ = nullptr, *res_ETd_ = nullptr, *res_ETx_ = nullptr, *res_L_ = nullptr, *res_QK_ = nullptr, *res_r1_ = nullptr,

@@ -1227,32 +1227,39 @@ __device__ __forceinline__ void dots_stage2_body(const Dots2K& k, const unsigned
     s = block_sum(s, sh);
     if (threadIdx.x == 0) k.out[pair] = s;
 }
-// The last stage of a reduction whose result the HOST waits for: ONE block sums the partial sums of all `npairs` reductions
-// (same order as dots_stage2: bit-identical), writes them straight into pinned host memory and then, behind a system-scope
-// fence, a sequence number the host polls for — no copy kernel, no event, no stream synchronisation between the device's last
-// store and the host's next launch (the DIIS round trip of an iteration: 40 us of idle device with hipStreamSynchronize).
+// The last stage of a reduction whose result the HOST waits for: one block per reduction sums its partial sums (the order of
+// dots_stage2: bit-identical) and writes the result straight into pinned host memory; the block that arrives last — a
+// counter of the launch's own, one of a ring of 64 that the last arriver leaves at zero again (launches of several streams
+// may interleave) — writes, behind a system-scope fence, the sequence number the host polls for.  No copy kernel, no event, no stream synchronisation between the device's last store and
+// the host's next launch (the DIIS round trip of an iteration: 40 us of idle device with hipStreamSynchronize).
 struct DotsFinalK {
     const double* partial;
-    double* out;             // device address of the pinned result slot
-    long* flag;              // ... and of its sequence word
+    double* out;                       // device address of the pinned result slot
+    long* flag;                        // ... and of its sequence word
+    unsigned int* arrivals;            // this launch's arrival counter (zero before, zero after)
+    unsigned int pad_;
     long seq;
     int nblocks, npairs;
 };
-__device__ __forceinline__ void dots_final_body(const DotsFinalK& k, double* sh) {
-    for (int pair = 0; pair < k.npairs; ++pair) {
-        double s = 0.0;
-        for (int i = threadIdx.x; i < k.nblocks; i += blockDim.x) s += k.partial[pair * kDotBlocks + i];
-        s = block_sum(s, sh);
-        if (threadIdx.x == 0) k.out[pair] = s;
-    }
+__device__ __forceinline__ void dots_final_body(const DotsFinalK& k, const unsigned vb, double* sh) {
+    const int pair = vb;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < k.nblocks; i += blockDim.x) s += k.partial[pair * kDotBlocks + i];
+    s = block_sum(s, sh);
     if (threadIdx.x == 0) {
+        k.out[pair] = s;
         __threadfence_system();
-        __hip_atomic_store(k.flag, k.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned int old = __hip_atomic_fetch_add(k.arrivals, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned int)k.npairs - 1u) {
+            __hip_atomic_store(k.arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(k.flag, k.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 __global__ void __launch_bounds__(256) dots_final_kernel(const DotsFinalK k) {
     __shared__ double sh[4];
-    dots_final_body(k, sh);
+    dots_final_body(k, blockIdx.x, sh);
 }
 __global__ void __launch_bounds__(256) dots_stage2_kernel(const double* __restrict__ partial, int nblocks,
                                                           double* __restrict__ out) {
@@ -3137,7 +3144,7 @@ __device__ __forceinline__ void phase_body(const PhaseK& ph) {
             else dots_stage1_body<1>(phase_args<DotsK>(args), vb, sh);
             break;
         case PK_DOTS2: dots_stage2_body(phase_args<Dots2K>(args), vb, sh); break;
-        case PK_DOTS_FINAL: dots_final_body(phase_args<DotsFinalK>(args), sh); break;
+        case PK_DOTS_FINAL: dots_final_body(phase_args<DotsFinalK>(args), vb, sh); break;
         case PK_ENERGY:
             if constexpr (HEAVY) {
                 if (sub) energy_norms_body<2>(phase_args<EnergyK>(args), vb, nblk, sh);
@@ -3206,7 +3213,9 @@ double* g_gram_host[kMaxDevices] = {nullptr};
 long g_live_allocs = 0;
 
 // ---- phase queue (host side of phase_kernel) ----------------------------------------------------------------------------
-struct PhaseRange { uintptr_t lo, hi; };
+// [lo, hi) in bytes; pitch != 0: only the rows [lo + i pitch, lo + i pitch + width) of it (a pitched 2-D box: two column
+// slices of the same rows — LS | LA of the packed ladder rows, the blocks of a stacked operand — do not overlap)
+struct PhaseRange { uintptr_t lo, hi; uintptr_t pitch = 0, width = 0; };
 inline PhaseRange prange(const void* p, long doubles) {
     const uintptr_t lo = reinterpret_cast<uintptr_t>(p);
     return PhaseRange{lo, p && doubles > 0 ? lo + 8 * (uintptr_t)doubles : lo};
@@ -3220,7 +3229,18 @@ inline PhaseRange pbox(const void* base, std::initializer_list<std::pair<long, l
         if (span < 0) lo += span; else hi += span;
     }
     const uintptr_t b = reinterpret_cast<uintptr_t>(base);
-    return PhaseRange{b + 8 * lo, b + 8 * (hi + 1 + slack)};
+    PhaseRange r{b + 8 * lo, b + 8 * (hi + 1 + slack)};
+    // exactly two extents above one, a unit stride and a larger positive pitch: rows of `w` doubles every `p`
+    long w = 0, pch = 0;
+    int nd = 0;
+    for (const auto& d : dims)
+        if (d.first > 1) {
+            ++nd;
+            if (d.second == 1) w = d.first;
+            else pch = d.second;
+        }
+    if (nd == 2 && w > 0 && pch > w + slack) { r.pitch = 8 * (uintptr_t)pch; r.width = 8 * (uintptr_t)(w + slack); }
+    return r;
 }
 struct PhaseRec {
     unsigned short kind = 0, sub = 0;
@@ -3299,7 +3319,14 @@ inline void phase_writes(PhaseRec& t, std::initializer_list<PhaseRange> ws) {
             t.w[t.nw++] = x;
         }
 }
-inline bool phase_overlap(const PhaseRange& a, const PhaseRange& b) { return a.lo < b.hi && b.lo < a.hi; }
+inline bool phase_overlap(const PhaseRange& a, const PhaseRange& b) {
+    if (!(a.lo < b.hi && b.lo < a.hi)) return false;
+    if (a.pitch != 0 && a.pitch == b.pitch) {       // column slices of rows with one pitch
+        const uintptr_t p = a.pitch, d = b.lo >= a.lo ? (b.lo - a.lo) % p : (p - (a.lo - b.lo) % p) % p;
+        if (d >= a.width && d + b.width <= p) return false;
+    }
+    return true;
+}
 inline bool phase_conflict(const PhaseRec& a, const PhaseRec& b) {       // a earlier, b later
     for (int i = 0; i < a.nw; ++i) {
         for (int j = 0; j < b.nw; ++j) if (phase_overlap(a.w[i], b.w[j])) return true;
@@ -3630,12 +3657,20 @@ int current_device() {
     return d;
 }
 long g_dot_seq[kMaxDevices] = {0};
+// arrival counters of dots_final_kernel: a ring of 64 per device, each on a line of its own; a launch takes the next one (the
+// last arriving block leaves it at zero; 64 later launches of the process on that device are far behind any launch in flight)
+constexpr int kArrivalSlots = 64;
+unsigned int* g_arrivals[kMaxDevices] = {nullptr};
+unsigned g_arrivals_next[kMaxDevices] = {0};
+std::mutex g_arrivals_mu;
 void ensure_dot_ws(int d) {
     if (g_dot_ws[d]) return;
     HIP_CHECK(hipMalloc((void**)&g_dot_ws[d], sizeof(double) * (16 * kDotBlocks + 16)));
     // [0,16): results, [16]: the sequence word of dots_final_kernel (device-written: mapped and coherent)
     HIP_CHECK(hipHostMalloc((void**)&g_dot_host[d], sizeof(double) * 24, hipHostMallocMapped | hipHostMallocCoherent));
     memset(g_dot_host[d], 0, sizeof(double) * 24);
+    HIP_CHECK(hipMalloc((void**)&g_arrivals[d], sizeof(unsigned int) * 32 * kArrivalSlots));
+    HIP_CHECK(hipMemset(g_arrivals[d], 0, sizeof(unsigned int) * 32 * kArrivalSlots));
 }
 
 template <int BM, int BN, bool AKC, bool BKC, int VEC, bool STREAM = false>
@@ -4777,14 +4812,20 @@ static void launch_dots_stage2(int npairs, double* ws, int nb, double* out_dev, 
 }
 
 // the last stage of a reduction the host waits for (dots_final_kernel), as a task of the open phase or a launch
-static void launch_dots_final(const DotsFinalK& k, double* ws, hipStream_t st) {
+static void launch_dots_final(DotsFinalK k, double* ws, hipStream_t st) {
+    {
+        const int dv = current_device();
+        std::lock_guard<std::mutex> lock(g_arrivals_mu);
+        k.arrivals = g_arrivals[dv] + 32 * (g_arrivals_next[dv]++ % kArrivalSlots);
+        k.pad_ = 0;
+    }
     if (phase_open(st)) {
-        PhaseRec& t = phase_push(PK_DOTS_FINAL, 0, 1, 0, 1.0, k);
+        PhaseRec& t = phase_push(PK_DOTS_FINAL, 0, k.npairs, 0, 1.0, k);
         phase_reads(t, {prange(ws, 16L * kDotBlocks)});
         // (the pinned destination is nobody else's: no range to declare; the task is ordered behind stage 1 through ws)
         return;
     }
-    PYMES_LAUNCH(dots_final_kernel, dim3(1), dim3(256), 0, st, k);
+    PYMES_LAUNCH(dots_final_kernel, dim3(k.npairs), dim3(256), 0, st, k);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -4799,7 +4840,8 @@ void dots(int npairs, const double* const* x, const double* const* y, const int6
     void* hd = nullptr;
     HIP_CHECK(hipHostGetDevicePointer(&hd, g_dot_host[dv], 0));
     const long seq = ++g_dot_seq[dv];
-    launch_dots_final(DotsFinalK{g_dot_ws[dv], static_cast<double*>(hd), reinterpret_cast<long*>(static_cast<double*>(hd) + 16), seq, nb, npairs},
+    launch_dots_final(DotsFinalK{g_dot_ws[dv], static_cast<double*>(hd), reinterpret_cast<long*>(static_cast<double*>(hd) + 16), nullptr, 0u, seq, nb,
+                                 npairs},
                       g_dot_ws[dv], st);
     phase_flush();
     if (!poll_flag(reinterpret_cast<const long*>(g_dot_host[dv] + 16), seq, st)) throw std::runtime_error("dots: the device never delivered the result");
@@ -4857,7 +4899,7 @@ int energy_norms_start(const double* f, const double* t1, const double* t2, cons
     long* flag = nullptr;
     long seq = 0;
     const int ticket = readback_reserve_flagged(dv, &out_pin, &flag, &seq);
-    launch_dots_final(DotsFinalK{g_dot_ws[dv], out_pin, flag, seq, nb, 6}, g_dot_ws[dv], st);
+    launch_dots_final(DotsFinalK{g_dot_ws[dv], out_pin, flag, nullptr, 0u, seq, nb, 6}, g_dot_ws[dv], st);
     phase_flush();
     return ticket;
 }

@@ -290,8 +290,36 @@ def exchange_rows_start(full, rank, world_size, ctx=None, label="allgather"):
         _fence_after(full)
         return _Done()
     c = full.shape[0] // world_size
-    mine = full[rank * c:(rank + 1) * c].clone()
+    # IN PLACE: the rank's rows are sent from where they lie in the gathered buffer (ncclAllGather with sendbuff = recvbuff +
+    # rank * count is the in-place form RCCL defines) — no send clone: at (50,200) on eight ranks 0.3 GB of copies per
+    # iteration, and in the one-rank rehearsal (PYMES_FORCE_SHARDED) the whole 2.6 GB twice, once into the clone and once
+    # "through the wire" back.  PYMES_ALLGATHER_CLONE=1 restores the separate send buffer.
+    mine = full[rank * c:(rank + 1) * c]
+    if os.environ.get("PYMES_ALLGATHER_CLONE"):
+        mine = mine.clone()
     return _Pending(dist.all_gather_into_tensor(full.view(-1), mine.view(-1), async_op=True), mine, label)
+
+
+def alltoall_start(send, send_n, recv, recv_n, ctx=None, label="owner tiles"):
+    """All-to-all of contiguous pieces (``send_n[q]`` doubles for rank q out of ``send``, ``recv_n[p]`` from rank p into ``recv``,
+    both in rank order): the exchange behind ``pymes_set_alltoallv``.  Asynchronous under RCCL (ncclSend / ncclRecv in a group),
+    blocking and staged through the host in the gloo rigs."""
+    import torch.distributed as dist
+    if not sharded():
+        return _Done()
+    trace.sent(label, 8 * sum(send_n))
+    if _STUB is not None:
+        return _Done()
+    if _staged(send):
+        _fence_before(send, ctx)
+        hs = send.cpu() if send.is_cuda else send
+        hr = recv.cpu() if recv.is_cuda else recv
+        dist.all_to_all_single(hr, hs, list(recv_n), list(send_n))
+        if recv.is_cuda:
+            recv.copy_(hr)
+        _fence_after(recv)
+        return _Done()
+    return _Pending(dist.all_to_all_single(recv, send, list(recv_n), list(send_n), async_op=True), (send, recv), label)
 
 
 # ---- the collective table of include/pymes_amd.h (pymes_collectives), filled with torch.distributed ------------------------------
@@ -353,6 +381,34 @@ class Collectives:
             t, name, _ = self._view(int(buf), int(chunk) * self.world)
             full = t.view(self.world, int(chunk))
             return self._ticket(exchange_rows_start(full, self.rank, self.world, self.ctx, label=self.LABELS.get(name, name)),
+                                ticket_p)
+        except BaseException as exc:
+            self.error = exc
+            return 1
+
+    def enable_owner_tiles(self, device):
+        """The optional all-to-all of the table (``pymes_set_alltoallv``) and the two staging buffers of the owner-tile
+        exchange (``pymes_owner_tile_sizes``): the rows of the ring products then travel as the tiles each pair owner reads
+        (flag PYMES_OWNER_TILES of the sharded residual steps)."""
+        import ctypes as C
+        import torch
+        ns, nr = C.c_int64(), C.c_int64()
+        self.ctx.lib.call("pymes_owner_tile_sizes", self.ctx.handle, self.rank, self.world, C.byref(ns), C.byref(nr))
+        self.xs = torch.zeros((int(ns.value),), dtype=torch.float64, device=device)
+        self.xr = torch.zeros((int(nr.value),), dtype=torch.float64, device=device)
+        a2a_t = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64), C.c_void_p,
+                            C.POINTER(C.c_int64))
+        self._a2a = a2a_t(self._alltoallv)
+        self.ctx.lib.call("pymes_set_alltoallv", self.ctx.handle, C.cast(self._a2a, C.c_void_p))
+        self.ctx.lib.call("pymes_set_owner_tile_buffers", self.ctx.handle, C.c_void_p(self.xs.data_ptr()), C.c_void_p(self.xr.data_ptr()))
+
+    def _alltoallv(self, user, send, send_counts, recv, recv_counts, stream, ticket_p):
+        try:
+            ns = [int(send_counts[q]) for q in range(self.world)]
+            nr = [int(recv_counts[q]) for q in range(self.world)]
+            if int(send) != self.xs.data_ptr() or int(recv) != self.xr.data_ptr() or sum(ns) > self.xs.numel() or sum(nr) > self.xr.numel():
+                raise ValueError("collective hook: all-to-all outside the owner-tile staging buffers")
+            return self._ticket(alltoall_start(self.xs[:sum(ns)], ns, self.xr[:sum(nr)], nr, self.ctx, label="ETd+ETx owner tiles"),
                                 ticket_p)
         except BaseException as exc:
             self.error = exc

@@ -159,6 +159,7 @@ class CCD:
             first = True
             shard = self._shard_setup(ctx, t2, sym and amps is None)     # one process per GPU (None for a single rank)
             self.pair_sharded = shard is not None
+            self.hooked = shard is not None and "coll" in shard      # ... as whole library steps with the collective table
             if shard is None:       # fixed buffers: the residual is replayed as a launch graph (run_replayable)
                 r2 = ctx.pool_get(t2.shape)
                 st = {"graph": None, "eager_passes": 0,
@@ -235,10 +236,27 @@ class CCD:
         sh = {"rank": rank, "world": world, "npp": npp, "lo": lo, "hi": hi, "cshape": (max(hi - lo, 1), 2, no * no)}
         sh["ETd_t"], sh["ETd"] = shared(no * nv, no * nv)
         sh["ETx_t"], sh["ETx"] = shared(no * nv, no * nv)
-        sh["L"] = ctx.zeros((pdist.padded_rows(npp, world), no * no))
+        if os.environ.get("PYMES_PY_SEQUENCED_CCD"):
+            sh["L"] = ctx.zeros((pdist.padded_rows(npp, world), no * no))
         sh["Tall_t"], sh["Tall"] = shared(npp, 2 * no * no)
         sh["Tc"] = self._compact(ctx, sh)
         ctx.pairs_pack(t2, sh["Tc"], rank, world)
+        if not os.environ.get("PYMES_PY_SEQUENCED_CCD"):
+            # the loop body as whole library steps with the collective table (pymes_ccd_sharded_residuals, then the finish /
+            # energy / await steps of CCSD with f = t1 = NULL): the sequence a torch-free host runs (include/pymes_amd.h;
+            # tests/test_collective_hook.py drives it with plain ctypes callbacks).  PYMES_PY_SEQUENCED_CCD=1 keeps the
+            # Python-sequenced form below.
+            from pymes_amd import _lib
+            sh["L_t"], sh["L"] = shared(npp, no * no)
+            sh["S_t"] = torch.zeros((8,), dtype=torch.float64, device=dev)
+            names = ("ETd", "ETx", "L", "Tall", "S")
+            sh["coll"] = pdist.Collectives(ctx, {k: sh[k + "_t"] for k in names}, rank, world)
+            ptr = {k: sh[k + "_t"].data_ptr() for k in names}
+            sh["bufs"] = _lib.ShardBuffers(ptr["ETd"], ptr["ETx"], ptr["L"], None, ptr["Tall"], None, None, None, None, ptr["S"])
+            sh["flags"] = _lib.PYMES_DCD if self.is_dcd else 0
+            if os.environ.get("PYMES_OWNER_TILES"):
+                sh["coll"].enable_owner_tiles(dev)
+                sh["flags"] |= _lib.PYMES_OWNER_TILES
         return sh
 
     @staticmethod
@@ -252,6 +270,8 @@ class CCD:
         from pymes_amd import dist as pdist
         from pymes_amd.device import DeviceArray
         rank, world = sh["rank"], sh["world"]
+        if "coll" in sh:
+            return self._hooked_iteration(ctx, sh, f_dev, t2, level_shift, delta)
         # ring products first: the all-gathers of their rows fly while the ladders (rows that stay on the rank) are computed
         pdist.trace.mark("begin")
         ctx.residual_slab(f_dev, t2, sh["ETd"], sh["ETx"], sh["L"], rank, world, is_dcd=self.is_dcd, part="rings")
@@ -287,6 +307,32 @@ class CCD:
             ctx.pool_put(dtc)
         sh["Tc"] = tc
         return e_dir, e_ex, np.sqrt(nt2), np.sqrt(nr2)
+
+    def _hooked_iteration(self, ctx, sh, f_dev, t2, level_shift, delta):
+        """ccd.py:100-132 for one rank of many as whole library steps (include/pymes_amd.h): residuals of the rank's pairs
+        (collectives called back for), update, mixer, the finish step (energies all-reduced on the device, the new compact T2
+        handed to its all-gather), the energy read-back, and the replicated T2 completed for the next pass."""
+        import ctypes as C
+        from pymes_amd import dist as pdist
+        rank, world, coll = sh["rank"], sh["world"], sh["coll"]
+        rc, dtc, tc = self._compact(ctx, sh), self._compact(ctx, sh), sh["Tc"]
+        coll.call("pymes_ccd_sharded_residuals", ctx.handle, C.c_void_p(f_dev.ptr), C.c_void_p(t2.ptr), C.byref(sh["bufs"]),
+                  sh["flags"], C.c_void_p(rc.ptr))
+        ctx.cc_update_pairs(tc, dtc, rc, level_shift, delta, rank, world)             # :123-124
+        ctx.pool_put(rc)
+        if self.is_diis:
+            tc = self.mixer.mix([dtc], [tc], release=ctx.pool_put, sharded=(0,), allreduce=pdist.allreduce_sum)[0]
+        slot = C.c_int()
+        coll.call("pymes_ccsd_sharded_finish", ctx.handle, None, None, C.c_void_p(tc.ptr), C.c_void_p(dtc.ptr), C.byref(sh["bufs"]),
+                  C.byref(slot))
+        en = (C.c_double * 6)()
+        ctx.lib.call("pymes_ccsd_sharded_energy", ctx.handle, slot.value, en)
+        coll.call("pymes_ccsd_sharded_await", ctx.handle, C.c_void_p(t2.ptr), C.byref(sh["bufs"]))
+        pdist.trace.mark("finish, update, DIIS, energy, T2 exchange")
+        if not self.is_diis:
+            ctx.pool_put(dtc)
+        sh["Tc"] = tc
+        return en[1], en[2], np.sqrt(en[3]), np.sqrt(en[4])
 
     # The reference's mixer is never reset: a second solve() on the same instance starts from the history of the first
     # (diis.py:16-112 keeps its lists, ccsd.py:42 creates the mixer once).  Device vectors cannot outlive their context:

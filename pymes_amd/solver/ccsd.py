@@ -115,17 +115,21 @@ class CCSD(ccd.CCD):
                 st["P_t"], st["P"] = reduced(ctx.slab_prepare_ws())
                 st["R1_t"], st["R1"] = reduced(nv * no)
                 st["R1"] = st["R1"].reshape(nv, no)
-                if st["pairs"] and not st["owner_tiles"]:
+                if st["pairs"] and not (st["owner_tiles"] and os.environ.get("PYMES_PY_OWNER_TILES")):
                     # the loop body as whole library steps (pymes_ccsd_sharded_residuals / _finish) that call back for their
                     # collectives (include/pymes_amd.h, pymes_collectives; pymes_amd/dist.py:Collectives fills the table with
-                    # torch.distributed): the sequence a host in any language would run.  (The owner-tile all-to-all and the
-                    # replicated tail of user amplitudes keep the Python-sequenced form below.)
+                    # torch.distributed): the sequence a host in any language would run — since round 6 with the owner-tile
+                    # all-to-all as well (pymes_set_alltoallv; PYMES_PY_OWNER_TILES=1 keeps the Python-sequenced form of it).
+                    # (The replicated tail of user amplitudes keeps the Python-sequenced form below.)
                     st["S_t"], st["S"] = reduced(8)
                     names = ("ETd", "ETx", "L", "QK", "Tall", "W", "Xvv", "P", "R1", "S")
                     st["coll"] = pdist.Collectives(ctx, {k: st[k + "_t"] for k in names}, rank, wsize)
                     st["bufs"] = _lib.ShardBuffers(*[st[k + "_t"].data_ptr() for k in names])
                     st["rc"] = self._compact(ctx, st)
                     st["flags"] = _lib.PYMES_DCD if self.is_dcd else 0
+                    if st["owner_tiles"]:
+                        st["coll"].enable_owner_tiles(dev)
+                        st["flags"] |= _lib.PYMES_OWNER_TILES
             else:
                 st["lad_rows"] = nv * nv
                 st["lad_t"], st["lad"] = shared(nv * nv, no * no)

@@ -17,6 +17,8 @@ from oracle.cases import synthetic_case
 START_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64))
 WAIT_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p)
 MARK_T = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p)
+A2A_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64), C.c_void_p,
+                    C.POINTER(C.c_int64))
 
 
 class Table(C.Structure):
@@ -45,6 +47,13 @@ class Rank:
         self.cbs = (START_T(self._allreduce), START_T(self._allgather), WAIT_T(self._wait), MARK_T(self._mark))
         self.table = Table(None, rank, world, *self.cbs)
         ctx.lib.call("pymes_set_collectives", ctx.handle, C.byref(self.table))
+        # the optional all-to-all of the table and the staging buffers of the owner-tile exchange (include/pymes_amd.h)
+        ns, nr = C.c_int64(), C.c_int64()
+        ctx.lib.call("pymes_owner_tile_sizes", ctx.handle, rank, world, C.byref(ns), C.byref(nr))
+        self.xs, self.xr = ctx.zeros((int(ns.value),)), ctx.zeros((int(nr.value),))
+        self.a2a = A2A_T(self._alltoallv)
+        ctx.lib.call("pymes_set_alltoallv", ctx.handle, C.cast(self.a2a, C.c_void_p))
+        ctx.lib.call("pymes_set_owner_tile_buffers", ctx.handle, C.c_void_p(self.xs.ptr), C.c_void_p(self.xr.ptr))
 
     # device memory by pointer: which buffer, which offset (doubles)
     def _locate(self, ptr):
@@ -90,6 +99,32 @@ class Rank:
         ticket[0] = len(self.log)
         return 0
 
+    def _alltoallv(self, user, send, send_counts, recv, recv_counts, stream, ticket):
+        """Blocking all-to-all through the host: every rank publishes its send buffer and counts, meets the others, and picks
+        the piece addressed to it out of each (pieces contiguous in rank order on both sides)."""
+        assert int(send) == self.xs.ptr and int(recv) == self.xr.ptr
+        ns = [int(send_counts[q]) for q in range(self.world)]
+        nr = [int(recv_counts[p]) for p in range(self.world)]
+        self.log.append(("alltoallv", "X", sum(ns), sum(nr)))
+        assert ns[self.rank] == 0 and nr[self.rank] == 0 and sum(ns) <= self.xs.size and sum(nr) <= self.xr.size
+        self.ctx.sync()
+        if self.world > 1:
+            self.published = (self.xs.get().ravel().copy(), ns)
+            self.barrier.wait()
+            got = []
+            for p, peer in enumerate(self.peers):
+                buf, counts = peer.published
+                off = sum(counts[:self.rank])
+                assert counts[self.rank] == nr[p]
+                got.append(buf[off:off + counts[self.rank]])
+            self.barrier.wait()
+            full = self.xr.get().ravel()
+            cat = np.concatenate(got) if got else np.zeros(0)
+            full[:cat.size] = cat
+            self.xr.set(full)
+        ticket[0] = len(self.log)
+        return 0
+
     def _wait(self, user, ticket, stream):
         self.log.append(("wait", int(ticket)))
         return 0
@@ -129,7 +164,7 @@ def single_rank(lib, no, nv, f, V, t1, t2, dt2, dcsd):
         ctx.close()
 
 
-def run_rank(rk, no, nv, f, t1, t2, dt2, dcsd, out):
+def run_rank(rk, no, nv, f, t1, t2, dt2, dcsd, out, owner=False):
     """The sequence of include/pymes_amd.h on one rank: residuals; finish (energies of the amplitudes as they stand + the
     exchange of the compact tiles); the energy read-back; await (the replicated array rebuilt from every rank's tiles)."""
     ctx, world, rank = rk.ctx, rk.world, rk.rank
@@ -141,7 +176,7 @@ def run_rank(rk, no, nv, f, t1, t2, dt2, dcsd, out):
     rc, tc, dtc = ctx.zeros(shape), ctx.zeros(shape), ctx.zeros(shape)
     ctx.pairs_pack(a2, tc, rank, world)
     ctx.pairs_pack(ctx.array(dt2), dtc, rank, world)
-    flags = _lib.PYMES_DCD if dcsd else 0
+    flags = (_lib.PYMES_DCD if dcsd else 0) | (_lib.PYMES_OWNER_TILES if owner else 0)
     rk.call("pymes_ccsd_sharded_residuals", C.c_void_p(fdev.ptr), C.c_void_p(fd.ptr), C.c_void_p(a1.ptr), C.c_void_p(a2.ptr),
             C.byref(rk.bufs), flags, C.c_void_p(rc.ptr))
     r1 = rk.arr["R1"].get()[:nv * no].reshape(nv, no).copy()
@@ -154,6 +189,79 @@ def run_rank(rk, no, nv, f, t1, t2, dt2, dcsd, out):
     rk.call("pymes_ccsd_sharded_await", C.c_void_p(back.ptr), C.byref(rk.bufs))
     rk.call("pymes_ccsd_sharded_await", C.c_void_p(back.ptr), C.byref(rk.bufs))        # nothing in flight any more: a no-op
     out[rank] = dict(r1=r1, rc=rc.get()[:max(hi - lo, 0)], lo=lo, hi=hi, en=np.array(en[:]), t2_back=back.get())
+
+
+def run_rank_ccd(rk, no, nv, f, t2, dt2, dcd, owner, out):
+    """CCD / DCD on one rank (pymes/solver/ccd.py:100-132): pymes_ccd_sharded_residuals; the finish, energy read-back and await
+    of the CCSD steps with f = t1 = NULL."""
+    ctx, world, rank = rk.ctx, rk.world, rk.rank
+    fdev, a2 = ctx.array(f), ctx.array(t2)
+    npp = nv * (nv + 1) // 2
+    c = -(-npp // world)
+    lo, hi = min(rank * c, npp), min(rank * c + c, npp)
+    shape = (max(hi - lo, 1), 2, no * no)
+    rc, tc, dtc = ctx.zeros(shape), ctx.zeros(shape), ctx.zeros(shape)
+    ctx.pairs_pack(a2, tc, rank, world)
+    ctx.pairs_pack(ctx.array(dt2), dtc, rank, world)
+    flags = (_lib.PYMES_DCD if dcd else 0) | (_lib.PYMES_OWNER_TILES if owner else 0)
+    rk.call("pymes_ccd_sharded_residuals", C.c_void_p(fdev.ptr), C.c_void_p(a2.ptr), C.byref(rk.bufs), flags, C.c_void_p(rc.ptr))
+    slot = C.c_int()
+    rk.call("pymes_ccsd_sharded_finish", None, None, C.c_void_p(tc.ptr), C.c_void_p(dtc.ptr), C.byref(rk.bufs), C.byref(slot))
+    en = (C.c_double * 6)()
+    rk.call("pymes_ccsd_sharded_energy", slot.value, en)
+    back = ctx.zeros(t2.shape)
+    rk.call("pymes_ccsd_sharded_await", C.c_void_p(back.ptr), C.byref(rk.bufs))
+    out[rank] = dict(rc=rc.get()[:max(hi - lo, 0)], lo=lo, hi=hi, en=np.array(en[:]), t2_back=back.get())
+
+
+def check_world_ccd(lib, world, dcd, owner, no=3, nv=7, tol=1e-12):
+    """CCD's N > 1 loop body through the collective table, torch-free: against the single-rank residual
+    (ccd.py:164-254) and energies; with the two all-gathers of the ring rows and with the owner-tile all-to-all."""
+    f, V, _, _ = synthetic_case(no, nv, seed=6, scale=0.3 if nv < 20 else 0.15)
+    _, t2, dt2 = amplitudes(no, nv, 11)
+    ctx = Context(no, nv, lib=lib)
+    try:
+        ctx.set_V_pqrs(V)
+        ctx.set_orbital_energies(f.diagonal()[:no].copy(), f.diagonal()[no:].copy())
+        fdev, a2 = ctx.array(f), ctx.array(t2)
+        r2 = ctx.empty(t2.shape)
+        ctx.doubles_residual(fdev, a2, r2, is_dcd=dcd, sym_ladder=True)
+        want_r2 = r2.get()
+        want_en = np.array(ctx.energy_norms(None, None, a2, ctx.array(dt2)))
+    finally:
+        ctx.close()
+    peers, barrier, out = [], threading.Barrier(world), {}
+    for r in range(world):
+        peers.append(Rank(lib, no, nv, f, V, r, world, peers, barrier))
+    try:
+        errors = []
+
+        def body(rk):
+            try:
+                run_rank_ccd(rk, no, nv, f, t2, dt2, dcd, owner, out)
+            except BaseException as exc:
+                errors.append(exc)
+                barrier.abort()
+        threads = [threading.Thread(target=body, args=(rk,)) for rk in peers]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(timeout=300)
+        assert not errors, errors
+        got_r2 = np.zeros_like(want_r2)
+        for r in range(world):
+            o = out[r]
+            assert np.abs(o["en"] - want_en).max() < tol * max(1.0, np.abs(want_en).max()), (o["en"], want_en)
+            assert np.abs(o["t2_back"] - t2).max() == 0.0
+            unpack(no, nv, o["lo"], o["rc"], got_r2)
+        assert np.abs(got_r2 - want_r2).max() < tol
+        seqs = [[e[:2] for e in rk.log if e[0] in ("allreduce", "allgather", "alltoallv")] for rk in peers]
+        assert all(s == seqs[0] for s in seqs)
+        ring = [("alltoallv", "X")] if owner else [("allgather", "ETd"), ("allgather", "ETx")]
+        assert seqs[0] == ring + [("allreduce", "S"), ("allgather", "Tall")]
+    finally:
+        for rk in peers:
+            rk.close()
 
 
 def unpack(no, nv, lo, tiles, full):
@@ -171,7 +279,7 @@ def unpack(no, nv, lo, tiles, full):
             full[b, a] = tile[1].reshape(no, no)
 
 
-def check_world(lib, world, dcsd, no=3, nv=7, tol=1e-12):
+def check_world(lib, world, dcsd, no=3, nv=7, tol=1e-12, owner=False):
     f, V, _, _ = synthetic_case(no, nv, seed=6, scale=0.3 if nv < 20 else 0.15)
     t1, t2, dt2 = amplitudes(no, nv, 11)
     want_r1, want_r2, want_en = single_rank(lib, no, nv, f, V, t1, t2, dt2, dcsd)
@@ -183,7 +291,7 @@ def check_world(lib, world, dcsd, no=3, nv=7, tol=1e-12):
 
         def body(rk):
             try:
-                run_rank(rk, no, nv, f, t1, t2, dt2, dcsd, out)
+                run_rank(rk, no, nv, f, t1, t2, dt2, dcsd, out, owner)
             except BaseException as exc:          # a rank that dies must not leave the others at the barrier
                 errors.append(exc)
                 barrier.abort()
@@ -203,10 +311,11 @@ def check_world(lib, world, dcsd, no=3, nv=7, tol=1e-12):
         assert np.abs(got_r2 - want_r2).max() < tol
         # the order of the collectives is the same on every rank (a communicator runs them in order), the big all-reduce of
         # the hole-ladder intermediate is waited for after the ring rows have been handed over, the new T2 goes last
-        seqs = [[e[:2] for e in rk.log if e[0] in ("allreduce", "allgather")] for rk in peers]
+        seqs = [[e[:2] for e in rk.log if e[0] in ("allreduce", "allgather", "alltoallv")] for rk in peers]
         assert all(s == seqs[0] for s in seqs)
-        assert seqs[0] == [("allreduce", "W"), ("allreduce", "P"), ("allreduce", "P"), ("allgather", "ETd"), ("allgather", "ETx"),
-                           ("allgather", "QK"), ("allreduce", "Xvv"), ("allreduce", "R1"), ("allreduce", "S"), ("allgather", "Tall")]
+        ring = [("alltoallv", "X")] if owner else [("allgather", "ETd"), ("allgather", "ETx")]
+        assert seqs[0] == [("allreduce", "W"), ("allreduce", "P"), ("allreduce", "P")] + ring + [
+            ("allgather", "QK"), ("allreduce", "Xvv"), ("allreduce", "R1"), ("allreduce", "S"), ("allgather", "Tall")]
         marks = [e[1] for e in peers[0].log if e[0] == "mark"]
         assert marks[0] == "begin" and "ring products" in marks and marks[-1] == "energy + norms (pairs)"
     finally:
@@ -217,6 +326,23 @@ def check_world(lib, world, dcsd, no=3, nv=7, tol=1e-12):
 @pytest.mark.parametrize("world,dcsd", [(1, False), (1, True), (2, False), (2, True), (3, False)])
 def test_sharded_steps_with_a_plain_table_host_logic(hostsim_lib, world, dcsd):
     check_world(hostsim_lib, world, dcsd)
+
+
+@pytest.mark.parametrize("world,dcd,owner", [(1, False, False), (1, True, True), (2, False, False), (2, True, True), (3, False, True),
+                                             (3, True, False)])
+def test_ccd_sharded_steps_with_a_plain_table_host_logic(hostsim_lib, world, dcd, owner):
+    check_world_ccd(hostsim_lib, world, dcd, owner)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ccsd_owner_tiles_with_a_plain_table_host_logic(hostsim_lib, world):
+    check_world(hostsim_lib, world, False, owner=True)
+
+
+@pytest.mark.gpu
+def test_ccd_sharded_steps_with_a_plain_table_gpu(gpu_lib):
+    check_world_ccd(gpu_lib, 1, False, False)
+    check_world_ccd(gpu_lib, 1, True, True, no=20, nv=80, tol=1e-11)
 
 
 @pytest.mark.gpu
@@ -244,6 +370,11 @@ def check_failures(lib):
             rk.call("pymes_ccsd_sharded_residuals", *args)
         with pytest.raises(PymesError, match="PYMES_DCD"):
             rk.call("pymes_ccsd_sharded_residuals", *args[:5], 64, args[6])
+        ctx.lib.call("pymes_set_alltoallv", ctx.handle, None)                   # no all-to-all in the table: owner tiles refuse
+        rk.fail = None
+        with pytest.raises(PymesError, match="owner tiles"):
+            rk.call("pymes_ccsd_sharded_residuals", *args[:5], _lib.PYMES_OWNER_TILES, args[6])
+        rk.fail = "allreduce"
         ctx.lib.call("pymes_set_collectives", ctx.handle, None)                  # table removed: the steps refuse
         with pytest.raises(PymesError, match="no collectives"):
             rk.call("pymes_ccsd_sharded_residuals", *args)

@@ -146,7 +146,7 @@ def _solver_worker(rank, world, port, libpath, out):
             s = CCD(no, delta_e=1e-10, is_dcd=dcd, is_diis=diis)
             with contextlib.redirect_stdout(io.StringIO()):
                 r = s.solve(f, V)
-            assert s.pair_sharded
+            assert s.pair_sharded and s.hooked          # (pymes_ccd_sharded_residuals + the finish / energy / await steps)
             res[("ccd", no, nv, dcd, diis)] = (float(r["ccd e"]), int(s.iterations), float(np.abs(r["t2 amp"]).sum()), 0.0)
         # owner-tile exchange (PYMES_OWNER_TILES=1): an all-to-all of the tiles each pair owner reads instead of the two
         # all-gathers of the ring-product rows — must give the very same numbers, bit for bit
@@ -158,7 +158,7 @@ def _solver_worker(rank, world, port, libpath, out):
                 s = CCSD(no, delta_e=1e-10, is_dcsd=dcsd, is_diis=diis)
                 with contextlib.redirect_stdout(io.StringIO()):
                     r = s.solve(f, V)
-                assert s.pair_sharded
+                assert s.pair_sharded and s.hooked      # (the all-to-all is a callback of the table too: pymes_set_alltoallv)
                 tiles[(no, nv, dcsd, diis)] = (float(r["ccsd e"]), int(s.iterations), float(np.abs(r["t2"]).sum()),
                                                float(np.abs(r["t2"] - r["t2"].transpose(1, 0, 3, 2)).max()))
             f, V, B, eps = synthetic_case(3, 7, seed=4, scale=0.3)
