@@ -12,6 +12,8 @@
  *           RCCL communicator and a communication stream of the host's own, ordered against the library's stream through
  *           events — the code a multi-GPU host runs unchanged with its rank and world (here: a communicator of one rank,
  *           all a one-GPU test box can hold)
+ *   mode 3  mode 2 with the OWNER-TILE exchange of the ring-product rows: the table's optional all-to-all (pymes_set_alltoallv,
+ *           ncclSend / ncclRecv in a group), two staging buffers, flag PYMES_OWNER_TILES
  * tests/test_capi_host.py compiles it with gcc (CPU: compiles and links against the library's symbols; GPU: runs it on
  * tests/golden-sized synthetic factors and compares every pass with the Python host and the oracle).
  *
@@ -36,7 +38,7 @@
     } while (0)
 
 /* a world of one rank: every collective is complete the moment it is "started" */
-static int calls[3];
+static int calls[4];
 static int one_rank_allreduce(void* user, double* buf, int64_t n, void* stream, int64_t* ticket) {
     (void)user; (void)buf; (void)n; (void)stream;
     *ticket = ++calls[0];
@@ -63,7 +65,7 @@ typedef struct {
     hipStream_t cs;
     hipEvent_t before[RING], done[RING];
     int64_t next;
-    int rank;
+    int rank, world;
 } rccl_host;
 static int rccl_order(rccl_host* h, void* stream, int64_t* ticket) {
     const int64_t t = h->next++;
@@ -87,6 +89,24 @@ static int rccl_allgather(void* user, double* buf, int64_t chunk, void* stream, 
     ++calls[1];
     return hipEventRecord(h->done[*ticket % RING], h->cs) != hipSuccess;
 }
+/* the optional all-to-all of the table (pymes_set_alltoallv: the owner tiles of the ring-product rows): counts in doubles, the
+ * pieces for / from rank 0, 1, ... contiguous in that order — ncclSend / ncclRecv pairs in one group */
+static int rccl_alltoallv(void* user, const double* send, const int64_t* ns, double* recv, const int64_t* nr, void* stream,
+                          int64_t* ticket) {
+    rccl_host* h = (rccl_host*)user;
+    if (rccl_order(h, stream, ticket)) return 1;
+    int64_t so = 0, ro = 0;
+    if (ncclGroupStart() != ncclSuccess) return 2;
+    for (int p = 0; p < h->world; ++p) {
+        if (ns[p] > 0 && ncclSend(send + so, (size_t)ns[p], ncclDouble, p, h->comm, h->cs) != ncclSuccess) return 2;
+        if (nr[p] > 0 && ncclRecv(recv + ro, (size_t)nr[p], ncclDouble, p, h->comm, h->cs) != ncclSuccess) return 2;
+        so += ns[p];
+        ro += nr[p];
+    }
+    if (ncclGroupEnd() != ncclSuccess) return 2;
+    ++calls[3];
+    return hipEventRecord(h->done[*ticket % RING], h->cs) != hipSuccess;
+}
 static int rccl_wait(void* user, int64_t ticket, void* stream) {
     rccl_host* h = (rccl_host*)user;
     ++calls[2];
@@ -95,6 +115,7 @@ static int rccl_wait(void* user, int64_t ticket, void* stream) {
 static int rccl_open(rccl_host* h) {
     int dev = 0;
     memset(h, 0, sizeof *h);
+    h->world = 1;
     if (hipSetDevice(0) != hipSuccess) return 1;
     if (ncclCommInitAll(&h->comm, 1, &dev) != ncclSuccess) return 2;       /* a multi-GPU host: ncclCommInitRank(rank, world, id) */
     if (hipStreamCreateWithFlags(&h->cs, hipStreamNonBlocking) != hipSuccess) return 3;
@@ -126,7 +147,7 @@ static double* dev_doubles(pymes_ctx* ctx, int64_t n) {
 
 int main(int argc, char** argv) {
     if (argc != 5) {
-        fprintf(stderr, "usage: %s <packed factors file> <passes> <dcsd 0|1> <mode 0|1|2>\n", argv[0]);
+        fprintf(stderr, "usage: %s <packed factors file> <passes> <dcsd 0|1> <mode 0|1|2|3>\n", argv[0]);
         return 2;
     }
     const char* path = argv[1];
@@ -154,7 +175,7 @@ int main(int argc, char** argv) {
     double e_mp2[2];
     CHECK(pymes_mp2(ctx, 0.0, t2, e_mp2));                                 /* ccsd.py:128 */
     printf("mp2 %.15e\n", e_mp2[0] + e_mp2[1]);
-    const uint32_t flags = dcsd ? PYMES_DCD : 0u;
+    uint32_t flags = dcsd ? PYMES_DCD : 0u;
     double out[6];
     if (mode == 0) {
         double* dt2 = dev_doubles(ctx, nt2);
@@ -174,7 +195,7 @@ int main(int argc, char** argv) {
         table.wait = one_rank_wait;
 #ifdef WITH_RCCL
         rccl_host rh;
-        if (mode == 2) {
+        if (mode >= 2) {
             const int rc = rccl_open(&rh);
             if (rc != 0) {
                 fprintf(stderr, "RCCL set-up failed at step %d\n", rc);
@@ -186,12 +207,21 @@ int main(int argc, char** argv) {
             table.wait = rccl_wait;
         }
 #else
-        if (mode == 2) {
-            fprintf(stderr, "mode 2 needs a build with -DWITH_RCCL\n");
+        if (mode >= 2) {
+            fprintf(stderr, "modes 2 and 3 need a build with -DWITH_RCCL\n");
             return 2;
         }
 #endif
         CHECK(pymes_set_collectives(ctx, &table));
+#ifdef WITH_RCCL
+        if (mode == 3) {
+            int64_t nsend = 0, nrecv = 0;
+            CHECK(pymes_owner_tile_sizes(ctx, table.rank, table.world, &nsend, &nrecv));
+            CHECK(pymes_set_alltoallv(ctx, rccl_alltoallv));
+            CHECK(pymes_set_owner_tile_buffers(ctx, dev_doubles(ctx, nsend), dev_doubles(ctx, nrecv)));
+            flags |= PYMES_OWNER_TILES;
+        }
+#endif
         int64_t sz[10];
         CHECK(pymes_shard_buffer_sizes(ctx, 1, sz));
         double* b[10];
@@ -211,10 +241,10 @@ int main(int argc, char** argv) {
             printf("pass %d %.15e %.15e %.15e\n", it + 1, out[0] + out[1] + out[2], out[3], out[4]);
         }
         CHECK(pymes_ccsd_sharded_await(ctx, t2, &bufs));
-        printf("collectives allreduce %d allgather %d wait %d\n", calls[0], calls[1], calls[2]);
+        printf("collectives allreduce %d allgather %d wait %d alltoallv %d\n", calls[0], calls[1], calls[2], calls[3]);
         CHECK(pymes_set_collectives(ctx, NULL));
 #ifdef WITH_RCCL
-        if (mode == 2) {
+        if (mode >= 2) {
             CHECK(pymes_ctx_sync(ctx));
             rccl_close(&rh);
         }

@@ -64,6 +64,7 @@ def lines_of(text):
             out[w[0]] = float(w[1])
         elif w[0] == "collectives":
             out["collectives"] = (int(w[2]), int(w[4]), int(w[6]))
+            out["alltoallv"] = int(w[8])
     return out
 
 
@@ -79,11 +80,16 @@ def test_c_host_runs_the_fixed_point(gpu_lib, tmp_path, dcsd):
     packed.write_factors(path, 2 * no, 0.0, eps, np.diag(eps), B)
     exe = build(str(tmp_path / "host_ccsd_rccl"), rccl=True)
     runs = []
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         r = subprocess.run([exe, path, str(passes), str(int(dcsd)), str(mode)], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr + r.stdout
         runs.append(lines_of(r.stdout))
-    plain, hooked, rccl = runs
+    plain, hooked, rccl, tiles = runs
+    # mode 3: the owner-tile exchange through the table's all-to-all (ncclSend / ncclRecv in a group; one call per pass, no
+    # all-gather of ETd / ETx): the same numbers
+    assert tiles.pop("alltoallv") == passes and rccl.pop("alltoallv") == 0 and hooked.pop("alltoallv") == 0
+    assert tiles["collectives"][1] == rccl["collectives"][1] - 2 * passes
+    assert {k: v for k, v in tiles.items() if k != "collectives"} == {k: v for k, v in rccl.items() if k != "collectives"}
     # the RCCL table (real ncclAllReduce / ncclAllGather on a communicator of one rank, event-ordered against the library's
     # stream) gives the numbers of the table that exchanges nothing, bit for bit
     assert rccl == hooked
