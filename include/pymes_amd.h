@@ -60,6 +60,10 @@ int pymes_dress_generation(pymes_ctx* ctx, uint64_t* n);
  * pymes_phase_enable: 1 on, 0 off, -1 as the environment says (PYMES_PHASE=0 off, =serial one task per level; default on) — per
  * calling thread.  pymes_phase_stats: tasks recorded / grids launched / levels / flushes by the calling thread so far. */
 int pymes_phase_enable(int mode);
+/* pymes_phase_hold(1): the calls that follow leave their small operations recorded instead of launching them when they return,
+ * so that operations of SEVERAL calls share levels (an iteration's two amplitude updates, pymes_cc_update_to, and the overlaps
+ * of its mixer); pymes_phase_hold(0) launches them.  Anything that synchronises or copies launches them first, held or not. */
+int pymes_phase_hold(int on);
 int pymes_phase_stats(int64_t* tasks, int64_t* launches, int64_t* levels, int64_t* flushes);
 
 /* ---- launch graphs (hipGraph): the loop body of a small, launch-bound solve is recorded once and replayed.

@@ -37,6 +37,7 @@ SIGNATURES = {
     "pymes_live_allocations": (C.c_int, [c_i64_p]),
     "pymes_dress_generation": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "pymes_phase_enable": (C.c_int, [C.c_int]),
+    "pymes_phase_hold": (C.c_int, [C.c_int]),
     "pymes_phase_stats": (C.c_int, [c_i64_p, c_i64_p, c_i64_p, c_i64_p]),
     "pymes_mem_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "pymes_graph_begin": (C.c_int, [C.c_void_p]),

@@ -34,7 +34,7 @@ int guarded(F&& f) {
     // the host program may order work of its own behind it)
     try {
         f();
-        dev::phase_sync();
+        dev::phase_call_end();
         return 0;
     } catch (const std::exception& ex) {
         g_err = ex.what();
@@ -144,6 +144,9 @@ int pymes_dress_generation(pymes_ctx* ctx, uint64_t* n) {
 }
 int pymes_phase_enable(int mode) {
     return guarded([&] { dev::phase_enable(mode); });
+}
+int pymes_phase_hold(int on) {
+    return guarded([&] { dev::phase_hold(on != 0); });
 }
 int pymes_phase_stats(int64_t* tasks, int64_t* launches, int64_t* levels, int64_t* flushes) {
     return guarded([&] {

@@ -114,6 +114,11 @@ void phase_sync();
 bool phase_pending();              // tasks are recorded and not yet launched (this thread)
 long phase_generation();           // number of non-empty phases launched so far (this thread)
 void phase_enable(int mode);
+// phase_hold(true): the end of a C-interface call (phase_call_end) leaves its tasks recorded, so that the tasks of several
+// calls share levels — the host's two amplitude updates and the DIIS overlaps of an iteration; phase_hold(false) launches
+// them.  Synchronisations, copies and unrecorded launches launch the recorded tasks first, held or not.
+void phase_hold(bool on);
+void phase_call_end();
 void phase_stats(long* tasks, long* launches, long* levels, long* flushes);     // counted per thread since its start
 
 // ---- strided copy / permutation:  out = alpha * in + beta * out ----------------

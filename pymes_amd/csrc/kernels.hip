@@ -3265,6 +3265,9 @@ struct PhaseQueue {
     long ws_cursor = 0;                // rolling sub-allocation of the split-K workspace among the tasks of a phase
     double* ws = nullptr;              // that workspace (the engine's; remembered from the products of the phase)
     long ws_doubles = 0;
+    bool hold = false;                 // dev::phase_hold: the end of a C-interface call does not launch what is recorded
+    bool log = false;                  // PYMES_PHASE_LOG
+    uintptr_t fuse_bytes = 2u << 20;   // PYMES_PHASE_FUSE_MB
     long tasks = 0, launches = 0, levels = 0, flushes = 0;      // statistics (dev::phase_stats)
     long fused = 0;                    // accumulation chains fused (phase_fuse_accumulations)
 };
@@ -3279,7 +3282,9 @@ inline bool phase_open(hipStream_t st) {
         const char* e = getenv("PYMES_PHASE");
         P.enabled = (e && e[0] == '0') ? 0 : 1;
         P.serial = e && !strcmp(e, "serial");
-        if (const char* m = getenv("PYMES_PHASE_MAX_US")) P.max_us = atof(m);
+        P.max_us = getenv("PYMES_PHASE_MAX_US") ? atof(getenv("PYMES_PHASE_MAX_US")) : 60.0;
+        P.log = getenv("PYMES_PHASE_LOG") != nullptr;
+        P.fuse_bytes = (uintptr_t)((getenv("PYMES_PHASE_FUSE_MB") ? atof(getenv("PYMES_PHASE_FUSE_MB")) : 2.0) * 1048576.0);
     }
     if (!P.enabled || P.flushing || g_prof.on) return false;
     if (!P.q.empty() && P.st != st) phase_flush();
@@ -3360,12 +3365,11 @@ inline double* phase_ws(double* ws, long ws_doubles, long need) {
 // only small arrays take part.
 void phase_fuse_accumulations(std::vector<PhaseRec>& q) {
     PhaseQueue& P = g_phase;
-    static const bool off = getenv("PYMES_PHASE_NO_FUSE") != nullptr;
     // (arrays up to 2 MB: a redirected member costs one write and one read of the array more.  Measured at (20,80), same box:
     // 1.486 ms without fusion, 1.478 with the cap at 2 MB — the six-term singles residual and its kin —, 1.512 at 8 MB (the
-    // 5-MB Q_kb + W_kb sum), 1.525 at 32 MB (the amplitude-sized sums of the finish); PYMES_PHASE_FUSE_MB overrides)
-    static const uintptr_t fuse_bytes = (uintptr_t)((getenv("PYMES_PHASE_FUSE_MB") ? atof(getenv("PYMES_PHASE_FUSE_MB")) : 2.0) * 1048576.0);
-    if (off || P.serial || !P.ws) return;
+    // 5-MB Q_kb + W_kb sum), 1.525 at 32 MB (the amplitude-sized sums of the finish); PYMES_PHASE_FUSE_MB overrides, 0 switches the fusion off)
+    const uintptr_t fuse_bytes = P.fuse_bytes;
+    if (fuse_bytes == 0 || P.serial || !P.ws) return;
     struct Group { PhaseRange box; int first; std::vector<int> members; bool open; };
     std::vector<Group> groups;
     auto touches = [](const PhaseRec& t, const PhaseRange& b) {
@@ -3476,8 +3480,7 @@ void phase_flush() {
         q[i].level = lev;
         nlev = std::max(nlev, lev + 1);
     }
-    static const bool log = getenv("PYMES_PHASE_LOG") != nullptr;      // one line per level: kind:blocks:cost of its tasks
-    if (log) {
+    if (P.log) {                      // PYMES_PHASE_LOG: one line per level, kind:blocks:cost of its tasks
         static const char* names[] = {"gemm", "splitk", "perm", "permT", "gemvC", "gemvF", "gemvR", "update", "lincomb", "dots1", "dots2",
                                       "energy", "tau", "packT", "unpackL", "ringops", "layouts", "assemble", "unpackR", "fockG", "fockGf",
                                       "fockFt", "fockFin", "traces", "dotsF"};
@@ -4425,9 +4428,17 @@ void phase_sync() {
 bool phase_pending() { return !g_phase.q.empty(); }
 long phase_generation() { return g_phase.flushes; }
 void phase_enable(int mode) {
+    gemm_group_flush();
     phase_sync();
-    g_phase.enabled = mode < 0 ? -1 : (mode ? 1 : 0);
+    g_phase.enabled = mode < 0 ? -1 : (mode ? 1 : 0);       // (-1: the environment is read again at the next operation)
     if (mode == 1) g_phase.serial = false;
+}
+void phase_hold(bool on) {
+    g_phase.hold = on;
+    if (!on) phase_sync();
+}
+void phase_call_end() {
+    if (!g_phase.hold) phase_sync();
 }
 void phase_stats(long* tasks, long* launches, long* levels, long* flushes) {
     if (tasks) *tasks = g_phase.tasks;

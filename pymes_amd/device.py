@@ -330,6 +330,20 @@ class Context:
         """Phase launches of the calling thread (include/pymes_amd.h): 1 on, 0 off, -1 as PYMES_PHASE says."""
         self.lib.call("pymes_phase_enable", int(mode))
 
+    def phase_hold(self):
+        """``with ctx.phase_hold():`` — the small operations of the calls inside are recorded together and launched level by
+        level when the block ends (include/pymes_amd.h, pymes_phase_hold)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def hold():
+            self.lib.call("pymes_phase_hold", 1)
+            try:
+                yield
+            finally:
+                self.lib.call("pymes_phase_hold", 0)
+        return hold()
+
     def phase_stats(self):
         """(tasks recorded, grids launched, levels, flushes) by the calling thread so far."""
         v = [C.c_int64() for _ in range(4)]

@@ -236,15 +236,15 @@ class CCD:
         sh = {"rank": rank, "world": world, "npp": npp, "lo": lo, "hi": hi, "cshape": (max(hi - lo, 1), 2, no * no)}
         sh["ETd_t"], sh["ETd"] = shared(no * nv, no * nv)
         sh["ETx_t"], sh["ETx"] = shared(no * nv, no * nv)
-        if os.environ.get("PYMES_PY_SEQUENCED_CCD"):
+        if os.environ.get("PYMES_PY_SEQUENCED"):
             sh["L"] = ctx.zeros((pdist.padded_rows(npp, world), no * no))
         sh["Tall_t"], sh["Tall"] = shared(npp, 2 * no * no)
         sh["Tc"] = self._compact(ctx, sh)
         ctx.pairs_pack(t2, sh["Tc"], rank, world)
-        if not os.environ.get("PYMES_PY_SEQUENCED_CCD"):
+        if not os.environ.get("PYMES_PY_SEQUENCED"):
             # the loop body as whole library steps with the collective table (pymes_ccd_sharded_residuals, then the finish /
             # energy / await steps of CCSD with f = t1 = NULL): the sequence a torch-free host runs (include/pymes_amd.h;
-            # tests/test_collective_hook.py drives it with plain ctypes callbacks).  PYMES_PY_SEQUENCED_CCD=1 keeps the
+            # tests/test_collective_hook.py drives it with plain ctypes callbacks).  PYMES_PY_SEQUENCED=1 keeps the
             # Python-sequenced form below.
             from pymes_amd import _lib
             sh["L_t"], sh["L"] = shared(npp, no * no)

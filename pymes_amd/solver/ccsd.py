@@ -115,11 +115,11 @@ class CCSD(ccd.CCD):
                 st["P_t"], st["P"] = reduced(ctx.slab_prepare_ws())
                 st["R1_t"], st["R1"] = reduced(nv * no)
                 st["R1"] = st["R1"].reshape(nv, no)
-                if st["pairs"] and not (st["owner_tiles"] and os.environ.get("PYMES_PY_OWNER_TILES")):
+                if st["pairs"] and not (st["owner_tiles"] and os.environ.get("PYMES_PY_SEQUENCED")):
                     # the loop body as whole library steps (pymes_ccsd_sharded_residuals / _finish) that call back for their
                     # collectives (include/pymes_amd.h, pymes_collectives; pymes_amd/dist.py:Collectives fills the table with
                     # torch.distributed): the sequence a host in any language would run — since round 6 with the owner-tile
-                    # all-to-all as well (pymes_set_alltoallv; PYMES_PY_OWNER_TILES=1 keeps the Python-sequenced form of it).
+                    # all-to-all as well (pymes_set_alltoallv; PYMES_PY_SEQUENCED=1 keeps the Python-sequenced form of it).
                     # (The replicated tail of user amplitudes keeps the Python-sequenced form below.)
                     st["S_t"], st["S"] = reduced(8)
                     names = ("ETd", "ETx", "L", "QK", "Tall", "W", "Xvv", "P", "R1", "S")
@@ -189,34 +189,38 @@ class CCSD(ccd.CCD):
         if not st.pop("residuals_in_flight", False):
             self._launch_residuals(st)
         mark("residuals (dressing, R1, R2)")
-        if self.is_diis:
-            # the DIIS history keeps the updated amplitudes (:176-183); the extrapolation goes back into the fixed buffers
-            t1n, t2n, dt1, dt2 = (ctx.pool_get(t1.shape), ctx.pool_get(t2.shape), ctx.pool_get(t1.shape),
-                                  ctx.pool_get(t2.shape))
-            ctx.cc_update_to(t1n, dt1, t1, r1, shift, self.delta)                     # :176-179
-            ctx.cc_update_to(t2n, dt2, t2, r2, shift, self.delta)
-        else:
-            t1n, t2n, dt1, dt2 = t1, t2, st["dt1"], st["dt2"]
-            ctx.cc_update(t1, dt1, r1, shift, self.delta)
-            ctx.cc_update(t2, dt2, r2, shift, self.delta)
-        if st["first"] and st["amps"] is not None:
-            np.copyto(st["amps"][0], t1n.get())     # the reference updates the caller's arrays in place
-            np.copyto(st["amps"][1], t2n.get())
-        st["first"] = False
-        mark("update")
-        if self.is_diis:
-            # :181-183; the mixer's log lines are printed (log_last) after the energy has been read back.  Default: overlaps
-            # reduced on the device, ONE synchronisation, the 7 x 7 algebra in C on this thread, extrapolation enqueued
-            # (pymes_diis_mix).  PYMES_DEVICE_DIIS=1: the whole step on the device (pymes_diis_step) — no round trip, and
-            # a few microseconds while a bound on |lambda_min| proves the inverse branch of diis.py:95; but a converging
-            # solve soon has overlaps below 1e-12, the reference's pseudo-inverse branch (:85-93) is then the one that is
-            # MEANT, and its eigen-decomposition on one wave costs 0.4 ms against 0.13 ms for the round trip (measured at
-            # (20,80), round 4).  PYMES_NUMPY_DIIS=1: numpy.linalg as the reference.
-            self.mixer.mix([dt1, dt2], [t1n, t2n], release=ctx.pool_put, out=[t1, t2], mark=mark, defer_log=True,
-                           on_device=bool(os.environ.get("PYMES_DEVICE_DIIS")),
-                           native=not os.environ.get("PYMES_NUMPY_DIIS"))
-        mark("DIIS extrapolation")
-        slot = ctx.energy_norms_start(st["f"], t1, t2, dt2)                            # :189-197, one pass, enqueued
+        # update, mixer and energy reduction as ONE held phase (include/pymes_amd.h, pymes_phase_hold): the two updates share a
+        # launch, and so do the extrapolations of T1 and T2 with nothing of the interpreter between them and the energy kernel;
+        # the overlaps' read-back inside the mixer launches what is recorded before it waits
+        with ctx.phase_hold():
+            if self.is_diis:
+                # the DIIS history keeps the updated amplitudes (:176-183); the extrapolation goes back into the fixed buffers
+                t1n, t2n, dt1, dt2 = (ctx.pool_get(t1.shape), ctx.pool_get(t2.shape), ctx.pool_get(t1.shape),
+                                      ctx.pool_get(t2.shape))
+                ctx.cc_update_to(t1n, dt1, t1, r1, shift, self.delta)                     # :176-179
+                ctx.cc_update_to(t2n, dt2, t2, r2, shift, self.delta)
+            else:
+                t1n, t2n, dt1, dt2 = t1, t2, st["dt1"], st["dt2"]
+                ctx.cc_update(t1, dt1, r1, shift, self.delta)
+                ctx.cc_update(t2, dt2, r2, shift, self.delta)
+            if st["first"] and st["amps"] is not None:
+                np.copyto(st["amps"][0], t1n.get())     # the reference updates the caller's arrays in place
+                np.copyto(st["amps"][1], t2n.get())
+            st["first"] = False
+            mark("update")
+            if self.is_diis:
+                # :181-183; the mixer's log lines are printed (log_last) after the energy has been read back.  Default: overlaps
+                # reduced on the device, ONE synchronisation, the 7 x 7 algebra in C on this thread, extrapolation enqueued
+                # (pymes_diis_mix).  PYMES_DEVICE_DIIS=1: the whole step on the device (pymes_diis_step) — no round trip, and
+                # a few microseconds while a bound on |lambda_min| proves the inverse branch of diis.py:95; but a converging
+                # solve soon has overlaps below 1e-12, the reference's pseudo-inverse branch (:85-93) is then the one that is
+                # MEANT, and its eigen-decomposition on one wave costs 0.4 ms against 0.13 ms for the round trip (measured at
+                # (20,80), round 4).  PYMES_NUMPY_DIIS=1: numpy.linalg as the reference.
+                self.mixer.mix([dt1, dt2], [t1n, t2n], release=ctx.pool_put, out=[t1, t2], mark=mark, defer_log=True,
+                               on_device=bool(os.environ.get("PYMES_DEVICE_DIIS")),
+                               native=not os.environ.get("PYMES_NUMPY_DIIS"))
+            mark("DIIS extrapolation")
+            slot = ctx.energy_norms_start(st["f"], t1, t2, dt2)                            # :189-197, one pass, enqueued
         # the next pass's residuals, behind the energy reduction: same variant as this pass's (T1 = 0 only ever changes after
         # the first pass from MP2, or never: a momentum-conserving system); recorded launch graphs only — the eager first
         # passes of a variant do their per-solve set-up work and stay where they were

@@ -275,6 +275,8 @@ void phase_sync() {}
 bool phase_pending() { return false; }
 long phase_generation() { return 0; }
 void phase_enable(int) {}
+void phase_hold(bool) {}
+void phase_call_end() {}
 void phase_stats(long* tasks, long* launches, long* levels, long* flushes) {
     if (tasks) *tasks = 0;
     if (launches) *launches = 0;

@@ -166,10 +166,30 @@ def _solver_worker(rank, world, port, libpath, out):
             with contextlib.redirect_stdout(io.StringIO()):
                 r = s.solve(f, V)
             tiles[("ccd", 3, 7, False, True)] = (float(r["ccd e"]), int(s.iterations), float(np.abs(r["t2 amp"]).sum()), 0.0)
+            # ... and the Python-sequenced forms of both (PYMES_PY_SEQUENCED=1: one library call per step, torch.distributed in
+            # between — what the whole steps with the collective table replaced): the same numbers again
+            os.environ["PYMES_PY_SEQUENCED"] = "1"
+            try:
+                f, V, B, eps = synthetic_case(3, 7, seed=3, scale=0.3)
+                s = CCSD(3, delta_e=1e-10)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    r = s.solve(f, V)
+                assert s.pair_sharded and not s.hooked
+                tiles[("py", 3, 7, False, True)] = (float(r["ccsd e"]), int(s.iterations), float(np.abs(r["t2"]).sum()),
+                                                    float(np.abs(r["t2"] - r["t2"].transpose(1, 0, 3, 2)).max()))
+                f, V, B, eps = synthetic_case(3, 7, seed=4, scale=0.3)
+                s = CCD(3, delta_e=1e-10)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    r = s.solve(f, V)
+                assert s.pair_sharded and not s.hooked
+                tiles[("pyccd", 3, 7, False, True)] = (float(r["ccd e"]), int(s.iterations), float(np.abs(r["t2 amp"]).sum()), 0.0)
+            finally:
+                del os.environ["PYMES_PY_SEQUENCED"]
         finally:
             del os.environ["PYMES_OWNER_TILES"]
         for key, val in tiles.items():
-            assert val == res[key], (key, val, res[key])
+            ref_key = (3, 7, False, True) if key[0] == "py" else (("ccd", 3, 7, False, True) if key[0] == "pyccd" else key)
+            assert val == res[ref_key], (key, val, res[ref_key])
         out[rank] = res
     finally:
         dist.destroy_process_group()

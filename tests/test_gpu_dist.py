@@ -103,6 +103,23 @@ def _worker_rccl(rank, port, out):
             assert s.pair_sharded and s.hooked
             res[f"syn_{no}_{nv}_{'dcsd' if dcsd else 'ccsd'}"] = (float(r["ccsd e"]), int(s.iterations), int(s.collective_calls))
             ints.ctx.close()
+        # the all-gathers are IN PLACE (sendbuff = recvbuff + rank * count); from a separate send buffer (PYMES_ALLGATHER_CLONE=1),
+        # with the owner-tile all-to-all (ncclSend / ncclRecv through torch's all_to_all_single) and for CCD (the whole steps
+        # of round 6: pymes_ccd_sharded_residuals + finish / energy / await): the same numbers
+        from pymes_amd.solver.ccd import CCD
+        f, V, B, eps = synthetic_case(4, 12, seed=0, scale=0.3)
+        for tag, env, kind in (("clone", {"PYMES_ALLGATHER_CLONE": "1"}, "ccsd"), ("tiles", {"PYMES_OWNER_TILES": "1"}, "ccsd"),
+                               ("ccd", {}, "ccd"), ("ccd_tiles", {"PYMES_OWNER_TILES": "1"}, "ccd")):
+            os.environ.update(env)
+            try:
+                s = CCD(4, delta_e=1e-10, device=0) if kind == "ccd" else CCSD(4, delta_e=1e-10, is_dcsd=True, device=0)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    r = s.solve(f, V)
+                assert s.pair_sharded and s.hooked
+                res["x_" + tag] = (float(r["ccd e" if kind == "ccd" else "ccsd e"]), int(s.iterations))
+            finally:
+                for k in env:
+                    del os.environ[k]
         out[0] = res
     finally:
         dist.destroy_process_group()
@@ -120,3 +137,8 @@ def test_forced_one_rank_rccl(gpu_lib):
     assert calls >= 10 * it                  # ten collectives per residual build + finish
     e, it, calls = out[0]["syn_4_12_dcsd"]
     assert abs(e - gold["syn_4_12"]["dcsd"]["e"]) < 1e-9 and it == gold["syn_4_12"]["dcsd"]["iterations"]
+    for tag in ("clone", "tiles"):
+        assert out[0]["x_" + tag] == (e, it), (tag, out[0]["x_" + tag], e, it)
+    for tag in ("ccd", "ccd_tiles"):
+        e2, it2 = out[0]["x_" + tag]
+        assert abs(e2 - gold["syn_4_12"]["ccd"]["e"]) < 1e-9 and it2 == gold["syn_4_12"]["ccd"]["iterations"]

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Short-K, HBM-streaming GEMM shapes of the T1 dressing at (50,200): achieved bandwidth per tile choice."""
+"""Short-K, HBM-streaming GEMM shapes of the T1 dressing at (50,200): achieved bandwidth of the launch the library chooses.
+(Rounds 2-4 swept tile shapes here through PYMES_GEMM_TILE; that knob left the library in round 5 with the choice it settled:
+the numbers quoted in DESIGN 5 / 6c are from those sweeps, this script measures the shipped choice only.)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -23,17 +25,13 @@ cases = [
 ]
 if os.environ.get("PROBE_ONLY"):
     cases = [c for c in cases if os.environ["PROBE_ONLY"] in c[0]]
-tiles = sys.argv[1:] or ["", "64x64", "128x64", "64x128", "128x128"]
+tiles = [""]
 for (label, spec, sa, sb, batch, beta) in cases:
     A, B = ctx.empty(sa), ctx.empty(sb)
     A.zero_(); B.zero_()
     out = ctx.contract(spec, A, B, batch=batch)
     nbytes = 8.0 * (np.prod(sa) + np.prod(sb) + np.prod(out.shape) * (2 if beta else 1))
     for tile in tiles:
-        if tile:
-            os.environ["PYMES_GEMM_TILE"] = tile
-        else:
-            os.environ.pop("PYMES_GEMM_TILE", None)
         ctx.contract(spec, A, B, out=out, beta=beta, batch=batch); ctx.sync(); ctx.prof_reset()
         for _ in range(5): ctx.contract(spec, A, B, out=out, beta=beta, batch=batch)
         ctx.sync(); q = ctx.prof_query()
