@@ -4,6 +4,8 @@
 #include <cstring>
 #include <exception>
 #include <algorithm>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -27,6 +29,10 @@ struct pymes_eom {
 
 namespace {
 thread_local std::string g_err;
+// EOM sigma handles alive per context: a context that is destroyed first takes the device side of its handles with
+// it (their hoisted arrays live in the engine's scratch pool); a later pymes_eom_sigma_destroy then only frees the host shell
+std::mutex g_eom_mu;
+std::set<pymes_eom*> g_eom_live;
 
 template <class F>
 int guarded(F&& f) {
@@ -89,6 +95,16 @@ int pymes_ctx_create(pymes_ctx** out, int device, int no, int nv, uint64_t works
 int pymes_ctx_destroy(pymes_ctx* ctx) {
     return guarded([&] {
         if (!ctx) return;
+        {
+            std::lock_guard<std::mutex> lock(g_eom_mu);
+            for (pymes_eom* h : g_eom_live)
+                if (h->ctx == ctx) {                 // the handle outlives its context: invalidate it while the engine is alive
+                    if (ctx->e) dev::set_device(ctx->e->device);
+                    delete h->s;
+                    h->s = nullptr;
+                    h->ctx = nullptr;
+                }
+        }
         delete ctx->e;
         delete ctx;
     });
@@ -886,6 +902,8 @@ int pymes_eom_sigma_prepare(pymes_ctx* ctx, const double* f_host, const double* 
         if (e.capturing()) throw pymes::Error("eom_sigma_prepare while a launch graph is being recorded");
         pymes::EomSigma* s = new pymes::EomSigma(e, f_host, t2, dressed != 0);
         *out = new pymes_eom{s, ctx};
+        std::lock_guard<std::mutex> lock(g_eom_mu);
+        g_eom_live.insert(*out);
     });
 }
 int pymes_eom_sigma_flags(pymes_eom* h, int* flags) {
@@ -916,8 +934,12 @@ int pymes_scratch_trim(pymes_ctx* ctx) {
 int pymes_eom_sigma_destroy(pymes_eom* h) {
     return guarded([&] {
         if (!h) return;
+        {
+            std::lock_guard<std::mutex> lock(g_eom_mu);
+            g_eom_live.erase(h);
+        }
         if (h->ctx && h->ctx->e) dev::set_device(h->ctx->e->device);
-        delete h->s;
+        delete h->s;                         // (null when the context went first: pymes_ctx_destroy)
         delete h;
     });
 }

@@ -1553,11 +1553,19 @@ void Engine::cc_update(double* t, double* dt, const double* r, double shift, dou
 void Engine::ccsd_residuals(const double* f, const double* t1, const double* t2, unsigned flags, double* r1, double* r2) {
     const int64_t o = no, v = nv, ov = o * v, npp = v * (v + 1) / 2;
     if (!res_ETd_) {
-        res_fd_ = scratch_get((o + v) * (o + v));
-        res_ETd_ = scratch_get(ov * ov);
-        res_ETx_ = scratch_get(ov * ov);
-        res_L_ = scratch_get(npp * o * o);
-        res_QK_ = scratch_get(ov * o * o);
+        // all five or none: a failed allocation in the middle must not leave a half-initialised set behind, and a
+        // launch graph that is being recorded cannot allocate (hipMalloc may synchronise)
+        if (capturing_) throw Error("ccsd_residuals: the staging buffers must exist before a launch graph is recorded (run one eager pass first)");
+        double* got[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        const int64_t want[5] = {(o + v) * (o + v), ov * ov, ov * ov, npp * o * o, ov * o * o};
+        try {
+            for (int i = 0; i < 5; ++i) got[i] = scratch_get(want[i]);
+        } catch (...) {
+            for (double* p : got)
+                if (p) scratch_put(p);
+            throw;
+        }
+        res_fd_ = got[0]; res_ETd_ = got[1]; res_ETx_ = got[2]; res_L_ = got[3]; res_QK_ = got[4];
     }
     const unsigned dcd = flags & 1u;                  // PYMES_DCD
     const unsigned sym = 8u | 16u;                    // PYMES_SYM_LADDER | PYMES_SYM_RINGS
@@ -1580,8 +1588,15 @@ void Engine::ccsd_iterate(const double* f, double* t1, double* t2, unsigned flag
                           double* dt2, double out[6]) {
     const int64_t o = no, v = nv;
     if (!res_r1_) {
-        res_r1_ = scratch_get(v * o);
-        res_r2_ = scratch_get(v * v * o * o);
+        if (capturing_) throw Error("ccsd_iterate: the staging buffers must exist before a launch graph is recorded");
+        double* r1 = scratch_get(v * o);
+        try {
+            res_r2_ = scratch_get(v * v * o * o);
+        } catch (...) {
+            scratch_put(r1);
+            throw;
+        }
+        res_r1_ = r1;
     }
     ccsd_residuals(f, t1, t2, flags, res_r1_, res_r2_);                       // ccsd.py:161-171
     cc_update_to(t1, dt1, t1, res_r1_, shift, delta, 2);                      // :176-179
@@ -1870,6 +1885,13 @@ void Engine::ccsd_sharded_energy(int slot, double out[6]) {
 }
 
 void Engine::release_residual_buffers() {
+    //  recorded graphs of ANY solver on this context replay into these buffers: they go back to the scratch pool —
+    // where a later request of the same size would alias them — only when the last recorded graph is gone (graph_destroy)
+    if (!graphs_.empty()) {
+        release_wanted_ = true;
+        return;
+    }
+    release_wanted_ = false;
     for (double** p : {&res_fd_, &res_ETd_, &res_ETx_, &res_L_, &res_QK_, &res_r1_, &res_r2_}) {
         if (*p) scratch_put(*p);
         *p = nullptr;

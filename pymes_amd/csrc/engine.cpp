@@ -254,6 +254,7 @@ void Engine::graph_destroy(dev::graph_t g) {
     dev::graph_destroy(g);
     graphs_.erase(it);
     graphs_dressing_.erase(g);
+    if (graphs_.empty() && release_wanted_) release_residual_buffers();
 }
 
 void Engine::exchange_asymmetry_V(double out[2]) {

@@ -338,6 +338,7 @@ class Engine {
     std::map<double*, int64_t> scratch_live_;
     std::set<dev::graph_t> graphs_;
     std::set<dev::graph_t> graphs_dressing_;     // recorded graphs whose replay dresses V again
+    bool release_wanted_ = false;                // release_residual_buffers while recorded graphs may still replay into them
     bool capturing_ = false;
     uint64_t dress_generation_ = 0, capture_generation_ = 0;
     double* V_[16] = {nullptr};      // undressed blocks (owned)

@@ -58,7 +58,7 @@ class _Sigma:
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
-        if h is not None and self.ctx.handle is not None:
+        if h is not None:        # (also after the context has gone: the library invalidated the handle then, this frees its shell)
             self.ctx.lib.call("pymes_eom_sigma_destroy", h)
 
     def _ctx_closing(self, ctx):

@@ -163,6 +163,55 @@ def test_dressed_handover_gpu(gpu_lib, monkeypatch):
     check_dressed_handover(gpu_lib, monkeypatch)
 
 
+# ---- handles that outlive their context; staging buffers released while a recorded graph still replays into them ----
+def check_handle_and_release_order(lib):
+    import ctypes as C
+    no, nv = 3, 6
+    f, V, _, _ = synthetic_case(no, nv, seed=1, scale=0.3)
+    rng = np.random.default_rng(2)
+    t1h = 0.05 * rng.standard_normal((nv, no))
+    x = 0.05 * rng.standard_normal((nv, nv, no, no))
+    t2h = x + x.transpose(1, 0, 3, 2)
+    ctx = Context(no, nv, lib=lib)
+    ctx.set_V_pqrs(V)
+    ctx.set_orbital_energies(f.diagonal()[:no].copy(), f.diagonal()[no:].copy())
+    fd, t1, t2 = ctx.array(f), ctx.array(t1h), ctx.array(t2h)
+    r1, r2 = ctx.empty(t1.shape), ctx.empty(t2.shape)
+    ctx.ccsd_residuals(fd, t1, t2, r1, r2)                       # eager: staging buffers allocated, statics built
+    want = r2.get()
+    if ctx.graphs_supported():
+        ctx.graph_begin()
+        ctx.ccsd_residuals(fd, t1, t2, r1, r2)
+        g = ctx.graph_end()
+        ctx.ccsd_release()                                       # another solver of the context finishing: must NOT free them yet
+        ctx.dress_V(t1, ("klij", "ijka", "ijak", "iajb", "iabj", "iabc", "abic", "iajk", "abcd", "abij", "ijab"))
+        h = C.c_void_p()
+        ctx.lib.call("pymes_eom_sigma_prepare", ctx.handle, _lib.host_ptr(np.ascontiguousarray(f)), C.c_void_p(t2.ptr), 1, C.byref(h))
+        r2.zero_()
+        ctx.graph_launch(g)                                      # replays into the staging buffers: nobody else got them
+        assert np.abs(r2.get() - want).max() < 1e-13
+        ctx.graph_destroy(g)                                     # now they go back to the pool
+    else:
+        ctx.dress_V(t1, ("klij", "ijka", "ijak", "iajb", "iabj", "iabc", "abic", "iajk", "abcd", "abij", "ijab"))
+        h = C.c_void_p()
+        ctx.lib.call("pymes_eom_sigma_prepare", ctx.handle, _lib.host_ptr(np.ascontiguousarray(f)), C.c_void_p(t2.ptr), 1, C.byref(h))
+    # the context goes first: the handle is invalidated, using it is an error, destroying it is fine
+    ctx.close()
+    flags = C.c_int()
+    with pytest.raises(PymesError, match="null EOM handle"):
+        lib.call("pymes_eom_sigma_flags", h, C.byref(flags))
+    lib.call("pymes_eom_sigma_destroy", h)
+
+
+def test_handle_and_release_order_host_logic(hostsim_lib):
+    check_handle_and_release_order(hostsim_lib)
+
+
+@pytest.mark.gpu
+def test_handle_and_release_order_gpu(gpu_lib):
+    check_handle_and_release_order(gpu_lib)
+
+
 # ---- a solve that ends with a speculative residual build in flight ----------------------------------------------------------
 @pytest.mark.gpu
 def test_solve_ends_with_residuals_in_flight(gpu_lib, monkeypatch):
