@@ -38,9 +38,9 @@ def reference_flops(no, nv, is_dcsd=False):
     return 2.0 * (doubles + dressing + singles)
 
 
-TRAFFIC_CSV = os.path.join("profiles", "r05", "bench_c3_pmc_hbm_traffic.csv")
+TRAFFIC_CSV = os.path.join("profiles", "r06", "bench_c3_pmc_hbm_traffic.csv")
 # workloads with committed counter passes: (nocc, nvirt) -> summary written by tools/profile_bench.sh
-TRAFFIC_CSVS = {(50, 200): TRAFFIC_CSV, (20, 80): os.path.join("profiles", "r05", "bench_c2_pmc_hbm_traffic.csv")}
+TRAFFIC_CSVS = {(50, 200): TRAFFIC_CSV, (20, 80): os.path.join("profiles", "r06", "bench_c2_pmc_hbm_traffic.csv")}
 
 
 def kernels_hash():

@@ -37,7 +37,7 @@ if [ "${PMC:-1}" = "1" ]; then
 fi
 # bench.py reads the counter summary from profiles/<round>/ (and accepts it only if its kernels.hip hash is the current one):
 # put this run's summary there on the box, so that the bench lines kept below carry `traffic`
-round=${ROUND:-r05}
+round=${ROUND:-r06}
 mkdir -p "profiles/$round"
 [ -f "$out/summary/bench_${tag}_pmc_hbm_traffic.csv" ] && cp "$out/summary/bench_${tag}_pmc_hbm_traffic.csv" "profiles/$round/"
 # the plain (unprofiled) bench line of the same workload, graph replay allowed
