@@ -38,6 +38,18 @@ step trace2 rocprofv3 --kernel-trace -d $out/tr2 -o run --output-format csv -- p
 python3 tools/trace_order.py $(find $out/tr2 -name "run_kernel_trace.csv") 8 > $out/bench_c2_dispatch_order.txt; rm -rf $out/tr2
 step clock rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d $out/pmc -o run --output-format csv -- python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-other-configs --events timed > $out/clock.log 2>&1
 python3 tools/dispatch_clock.py $(find $out/pmc -name "run_counter_collection.csv") 400 > $out/bench_c3_dispatch_clock.txt; rm -rf $out/pmc
+# round 6: phase launches — same-box A/B, the level structure of a (20,80) iteration, the boundary / counter / union probe
+{
+  for i in 1 2; do
+    for sz in "20 80 50" "7 50 100" "30 120 20"; do
+      echo "phase on : $(timeout -k 10 120 python3 tools/c2_prof.py $sz)"
+      echo "phase off: $(PYMES_PHASE=0 timeout -k 10 120 python3 tools/c2_prof.py $sz)"
+    done
+  done
+} > $out/phase_ab.txt 2>&1
+PYMES_PHASE_LOG=1 PYMES_NO_GRAPH=1 timeout -k 10 120 python3 tools/c2_prof.py 20 80 1 2> $out/phase_log.txt > /dev/null
+awk '/flush/{c++} {l[NR]=$0} END{start=0; n=0; for(i=NR;i>0;i--){ if(l[i] ~ /flush/){n++; if(n==9){start=i; break}} } for(i=start;i<=NR;i++) print l[i]}' $out/phase_log.txt > $out/phase_levels_20_80.txt; rm -f $out/phase_log.txt
+step probe_phase bash -c '/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/probe_phase tools/probe_phase.hip && /tmp/probe_phase' > $out/probe_phase_boundary_vs_counters.txt 2>&1
 # forced one-rank RCCL runs (the collective table on a real communicator) and the EOM traces
 PYMES_FORCE_SHARDED=1 step forced_c2 python3 bench.py --gpus 1 --nocc 20 --nvirt 80 --steps 5 --warmup 3 --no-cpu-baseline --no-other-configs > $out/forced_one_rank_rccl_c2.json 2>/dev/null
 PYMES_FORCE_SHARDED=1 step forced_c3 python3 bench.py --gpus 1 --steps 5 --warmup 3 --no-cpu-baseline --no-other-configs > $out/forced_one_rank_rccl.json 2>/dev/null

@@ -4,7 +4,7 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # find last t2_layouts and print from the previous one
 # (anchor of an iteration: the pair-layout kernel; with phase launches on it runs inside phase_kernel and the grouped
 # LDS-DMA launch of the ladder halves — one per iteration at the sizes this tool is used for — takes its place; argv[3] overrides)
-anchor = sys.argv[3] if len(sys.argv) > 3 else ('t2_layouts' if any('t2_layouts' in r['Kernel_Name'] for r in rows) else 'dgemm_glds_group_kernel')
+anchor = sys.argv[3] if len(sys.argv) > 3 else ('dgemm_glds_group_kernel' if any('phase_kernel' in r['Kernel_Name'] for r in rows) else 't2_layouts')
 idx = [i for i, r in enumerate(rows) if anchor in r['Kernel_Name']]
 # argv[2]: which iteration, counted from the end in t2_layouts launches (default 1: the last complete one; bench.py's
 # default run ends with an eager pass under per-GEMM events, its timed, graph-replayed steps come before that)
