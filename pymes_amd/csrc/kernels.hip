@@ -17,6 +17,7 @@
 #include <type_traits>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -3199,7 +3200,8 @@ struct Prof {
     std::vector<int> klass;          // 1: ran on the LDS-DMA 128x128 kernel
     std::vector<int> nk;             // GEMM kernel launches of the call (2 with a k-split tail)
     double flops = 0.0;
-} g_prof;
+};
+thread_local Prof g_prof;        // one context per host thread (include/pymes_amd.h): the events are that thread's stream's
 
 // per device ordinal (a process may hold contexts on several GPUs): reduction workspace [16*kDotBlocks + 16] on the
 // device, pinned result buffer [16] on the host, and "attribute set" flags of the kernels with > 64 KB of dynamic LDS
@@ -3210,7 +3212,7 @@ double* g_dot_host[kMaxDevices] = {nullptr};
 constexpr int kGramTiles = 64;
 double* g_gram_ws[kMaxDevices] = {nullptr};
 double* g_gram_host[kMaxDevices] = {nullptr};
-long g_live_allocs = 0;
+std::atomic<long> g_live_allocs{0};
 
 // ---- phase queue (host side of phase_kernel) ----------------------------------------------------------------------------
 // [lo, hi) in bytes; pitch != 0: only the rows [lo + i pitch, lo + i pitch + width) of it (a pitched 2-D box: two column

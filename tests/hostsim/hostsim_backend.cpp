@@ -8,6 +8,7 @@
 // package loader (pymes_amd/_lib.py) rejects any library whose pymes_backend() is not
 // "hip-gfx950".  It says nothing about the kernels themselves: those are tested on the
 // GPU (tests/test_gpu_*.py).
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -21,7 +22,7 @@ namespace dev {
 
 const char* backend_name() { return "hostsim"; }
 void set_device(int) {}
-static long g_live = 0;
+static std::atomic<long> g_live{0};      // contexts of several host threads share the allocator (tests/test_collective_hook.py)
 void* dmalloc(size_t bytes) {
     void* p = std::malloc(bytes ? bytes : 16);
     if (!p) throw std::runtime_error("hostsim: out of memory");
@@ -62,9 +63,9 @@ void stream_sync(stream_t) {}
 size_t mem_free_bytes() { return size_t(1) << 34; }
 size_t mem_total_bytes() { return size_t(1) << 35; }
 
-static long g_launches = 0;
-static double g_flops = 0;
-static bool g_prof = false;
+static thread_local long g_launches = 0;
+static thread_local double g_flops = 0;
+static thread_local bool g_prof = false;
 void prof_enable(bool on) { g_prof = on; }
 void prof_reset() { g_launches = 0; g_flops = 0; }
 void prof_query(int, long* l, long* nk, double* ms, double* f) { *l = g_launches; *nk = g_launches; *ms = 0.0; *f = g_flops; }
@@ -229,9 +230,9 @@ void exchange_asymmetry(const double* A, const double* B, const int64_t d[4], do
 }
 
 // read-backs: the simulator is synchronous — the values are copied at start and handed over at wait
-static double g_read_slots[16][128];
-static unsigned g_read_gen[16] = {0};
-static int g_read_next = 0;
+static thread_local double g_read_slots[16][128];      // (one context per host thread: a thread's tickets are its own)
+static thread_local unsigned g_read_gen[16] = {0};
+static thread_local int g_read_next = 0;
 // (ticket = slot | generation << 8, as the HIP backend: a reused or never-started slot is refused)
 int readback_start(const double* dev_ptr, int n, stream_t) {
     if (n < 1 || n > 128) throw std::runtime_error("readback: 1..128 doubles");
@@ -266,8 +267,8 @@ void lincomb(double* out, int nx, const double* const* x, const double* c, int64
 }
 
 // grouped launches: the simulator runs every product at once, so a group is only counted
-static long g_group_launches = 0, g_group_products = 0;
-static bool g_group_open = false;
+static thread_local long g_group_launches = 0, g_group_products = 0;      // per thread, as the device backend's group state
+static thread_local bool g_group_open = false;
 void gemm_group_begin(stream_t) { g_group_open = true; g_group_launches = g_group_products = 0; }
 void gemm_group_end() { g_group_open = false; }
 void gemm_group_sync() {}
