@@ -325,8 +325,8 @@ def main():
     ap.add_argument("--no-diis", action="store_true")
     ap.add_argument("--events", choices=("auto", "timed", "separate"), default="auto",
                     help="where the per-GEMM HIP events of `roofline` are taken: inside the timed steps (eager launches), "
-                         "or in a separate pass after them so that the timed steps can replay the launch graph; auto = "
-                         "separate for a single rank, timed for one process per GPU")
+                         "or in a separate pass after them so that the timed steps run as the solver runs them (launch graph, "
+                         "phase launches); auto = separate")
     ap.add_argument("--backend", default=os.environ.get("PYMES_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend; 'gloo' lets several ranks share one GPU in test rigs")
     ap.add_argument("--collective-timeout-s", type=float, default=300.0,
@@ -451,7 +451,9 @@ def main():
     # auto: a single rank times the loop body as the solver runs it (residual part replayed as a launch graph: one launch
     # instead of ~130, so the figure does not depend on how fast this box's host happens to enqueue) and takes the per-GEMM
     # events in a second, eager pass over the same number of steps
-    separate = args.events == "separate" or (args.events == "auto" and world == 1 and not sharded_run)
+    # (round 6: one process per GPU as well — events inside the timed steps switch the phase launches off, DESIGN 6f, and cost
+    # 0.1 ms of a 27-ms rank; "--events timed" keeps the old form)
+    separate = args.events != "timed"
     if separate:          # the launch graph of a variant is recorded on its second pass: keep that out of the timed steps
         for _ in range(max(0, 3 - args.warmup)):
             step()
