@@ -242,6 +242,14 @@ def check_davidson_golden(lib, monkeypatch, tag, device_form, reuse=True):
                 us, v, e = eom._ritz
                 eom._ritz = (us, v, e[::-1].copy())
                 assert min(eom.ritz_residuals(fd, Vd, res["t2"])[:1]) > 1e-2      # root 0's vector with the last root's energy
+                # ... and the second half of that certificate: the driver carried on to |dE| < 1e-12 leaves residuals below 1e-6
+                # and does not move the roots (the reference's, here) by more than 1e-7
+                tight = EOM_CCSD(no, n_excit=g["n_excit"])
+                tight.e_epsilon, tight.max_iter = 1e-12, 600
+                ee_t = tight.solve(fd, Vd, res["t2"])
+                rt = tight.ritz_residuals(fd, Vd, res["t2"])
+                assert max(rt) < 1e-6, rt
+                assert np.abs(np.array(ee_t) - np.array(g["ee"])).max() < 1e-7
             finally:
                 ints.ctx.close()
         else:
