@@ -55,5 +55,12 @@ PYMES_FORCE_SHARDED=1 step forced_c2 python3 bench.py --gpus 1 --nocc 20 --nvirt
 PYMES_FORCE_SHARDED=1 step forced_c3 python3 bench.py --gpus 1 --steps 5 --warmup 3 --no-cpu-baseline --no-other-configs > $out/forced_one_rank_rccl.json 2>/dev/null
 step eom_trace bash tools/trace_eom_many.sh > $out/trace_eom_many.log 2>&1
 step gsig_trace bash tools/trace_general_sigma.sh > $out/trace_general_sigma.log 2>&1
+step stub_trace bash tools/trace_stub8.sh > $out/trace_stub8.log 2>&1
+{
+  echo "# tools/probe_graph_edge.hip (in-kernel 100-MHz wall-clock stamps, host kept 2 ms ahead by a spinning kernel; 40 repetitions)"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/probe_graph_edge tools/probe_graph_edge.hip && timeout -k 10 120 /tmp/probe_graph_edge
+  echo "# tools/host_lead.py: a busy wait of D us in front of the update of every (20,80) pass (first call after the residual graph is launched)"
+  timeout -k 10 200 python3 tools/host_lead.py
+} > $out/probe_graph_edge_and_host_lead.txt 2>&1
 rm -rf gpurun_out/prof_c3/stats gpurun_out/prof_c3/pmc_* gpurun_out/prof_c2/stats gpurun_out/prof_c2/pmc_*
 echo done
