@@ -149,3 +149,66 @@ def test_hand_made_hazards(gpu_lib):
         assert np.abs(out1.get() - A @ B1).max() < 1e-12 and np.abs(out2.get() - X[3] @ B1).max() < 1e-12
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_overlapping_views(gpu_lib, seed):
+    """Forty products C <- alpha A B + beta C in ONE held phase on random pitched 2-D views of one buffer that overlap each
+    other at random (row slices, column slices of the same rows, partial overlaps; A or B may be the transposed reading of
+    a view) against the same sequence in numpy, one after the other: every read-after-write, write-after-read and write-
+    after-write pair the generator happens to produce must be found by the range analysis (pitch-aware boxes, accumulation
+    fusion included: beta = 1 chains into contiguous outputs occur)."""
+    from pymes_amd.device import DeviceArray
+    ctx = Context(2, 3, lib=gpu_lib, workspace_bytes=1 << 28)
+    rng = np.random.default_rng(100 + seed)
+    try:
+        total = 1 << 16
+        host = rng.standard_normal(total)
+        buf = ctx.array(host.copy())
+
+        def view(rows, cols):
+            """(offset, pitch) of a rows x cols box somewhere in the buffer; pitch == cols now and then (contiguous)."""
+            pitch = cols if rng.random() < 0.4 else cols + int(rng.integers(1, 40))
+            span = (rows - 1) * pitch + cols
+            # a handful of anchor offsets, so that boxes collide often
+            off = int(rng.choice([0, 64, 1000, 1024, 5000, 5003, 20000, 20016])) + int(rng.integers(0, 8)) * 2
+            assert off + span <= total
+            return off, pitch
+
+        def np_box(off, rows, cols, pitch):
+            idx = off + np.arange(rows)[:, None] * pitch + np.arange(cols)[None, :]
+            return idx
+
+        def dev(off):
+            return DeviceArray(ctx, buf.ptr + 8 * off, (1,), owned=False, keepalive=buf)
+
+        def disjoint(i1, i2):
+            return not np.intersect1d(i1.ravel(), i2.ravel()).size
+
+        ops, done = [], 0
+        before = ctx.phase_stats()
+        with ctx.phase_hold():
+            while done < 40:
+                M, N, K = int(rng.integers(3, 70)), int(rng.integers(3, 70)), int(rng.integers(3, 50))
+                ta, tb = rng.random() < 0.3, rng.random() < 0.3
+                (oa, pa), (ob, pb), (oc, pc) = view(*((K, M) if ta else (M, K))), view(*((N, K) if tb else (K, N))), view(M, N)
+                ia = np_box(oa, *((K, M) if ta else (M, K)), pa)
+                ib = np_box(ob, *((N, K) if tb else (K, N)), pb)
+                ic = np_box(oc, M, N, pc)
+                if not (disjoint(ia, ic) and disjoint(ib, ic)):
+                    continue                                # an output aliasing its own operands is undefined in any BLAS
+                A = host[ia].T if ta else host[ia]
+                B = host[ib].T if tb else host[ib]
+                # (scaled by the operands' size in the host model, so that forty chained products stay O(1))
+                alpha = float(rng.choice([-1.0, 0.5, 1.0])) / (np.sqrt(K) * max(1.0, np.abs(A).max()) * max(1.0, np.abs(B).max()))
+                beta = float(rng.choice([0.0, 1.0, 1.0, 0.5]))
+                ctx.dgemm(M, N, K, alpha, dev(oa), *((1, pa) if ta else (pa, 1)), dev(ob), *((1, pb) if tb else (pb, 1)),
+                          beta, dev(oc), pc)
+                host[ic] = alpha * (A @ B) + beta * host[ic]
+                done += 1
+        after = ctx.phase_stats()
+        assert after["tasks"] - before["tasks"] >= 40 and after["levels"] - before["levels"] >= 2
+        got = buf.get()
+        assert np.isfinite(host).all() and np.abs(got - host).max() < 1e-11 * max(1.0, np.abs(host).max()), np.abs(got - host).max()
+    finally:
+        ctx.close()
