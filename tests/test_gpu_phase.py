@@ -212,3 +212,96 @@ def test_random_overlapping_views(gpu_lib, seed):
         assert np.isfinite(host).all() and np.abs(got - host).max() < 1e-11 * max(1.0, np.abs(host).max()), np.abs(got - host).max()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_random_mixed_operations(gpu_lib, seed):
+    """The other recorded kinds next to the products: index permutations of 3- and 4-index arrays (both permutation kernels),
+    binary contractions that end in matrix-vector kernels, linear combinations, and overlaps read back in between —
+    fifty operations on contiguous arrays that overlap at random inside one buffer, in ONE held phase (an overlap read-back
+    launches what is recorded and the phase goes on), against the same sequence in numpy."""
+    from pymes_amd.device import DeviceArray
+    ctx = Context(3, 5, lib=gpu_lib, workspace_bytes=1 << 28)
+    rng = np.random.default_rng(500 + seed)
+    try:
+        total = 1 << 15
+        host = rng.standard_normal(total)
+        buf = ctx.array(host.copy())
+        anchors = [0, 96, 2000, 2048, 9000, 9008, 16000]
+
+        def place(n):
+            off = int(rng.choice(anchors)) + 2 * int(rng.integers(0, 6))
+            assert off + n <= total
+            return off
+
+        def dev(off, shape):
+            return DeviceArray(ctx, buf.ptr + 8 * off, tuple(shape), owned=False, keepalive=buf)
+
+        def hv(off, shape):
+            n = int(np.prod(shape))
+            return host[off:off + n].reshape(shape)
+
+        def apart(o1, n1, o2, n2):
+            return o1 + n1 <= o2 or o2 + n2 <= o1
+
+        done, dots_seen = 0, 0
+        with ctx.phase_hold():
+            while done < 50:
+                kind = rng.choice(["perm3", "perm4", "gemv", "lincomb", "dots", "gemm"])
+                if kind in ("perm3", "perm4"):
+                    nd = 3 if kind == "perm3" else 4
+                    shape = [int(rng.integers(2, 13)) for _ in range(nd)]
+                    perm = list(rng.permutation(nd))
+                    n = int(np.prod(shape))
+                    oi, oo = place(n), place(n)
+                    if not apart(oi, n, oo, n):
+                        continue
+                    li = "abcd"[:nd]
+                    lo = "".join(li[p] for p in perm)
+                    alpha, beta = float(rng.choice([1.0, -0.5])), float(rng.choice([0.0, 1.0]))
+                    out_shape = [shape[p] for p in perm]
+                    res = alpha * hv(oi, shape).transpose(perm) + beta * hv(oo, out_shape)
+                    ctx.permute(f"{li}->{lo}", dev(oi, shape), out=dev(oo, out_shape), alpha=alpha, beta=beta)
+                    host[oo:oo + n] = res.ravel()
+                elif kind == "gemv":
+                    M, K = int(rng.integers(4, 120)), int(rng.integers(4, 120))
+                    oa, ox, oy = place(M * K), place(K), place(M)
+                    if not (apart(oa, M * K, oy, M) and apart(ox, K, oy, M)):
+                        continue
+                    s = 1.0 / (np.sqrt(K) * max(1.0, np.abs(hv(oa, (M, K))).max()))
+                    res = s * (hv(oa, (M, K)) @ hv(ox, (K,)))
+                    ctx.contract("mk,k->m", dev(oa, (M, K)), dev(ox, (K,)), out=dev(oy, (M,)), alpha=s, beta=0.0)
+                    host[oy:oy + M] = res
+                elif kind == "lincomb":
+                    n, m = int(rng.integers(10, 1500)), int(rng.integers(1, 5))
+                    oo = place(n)
+                    offs = [place(n) for _ in range(m)]
+                    if not all(apart(o, n, oo, n) for o in offs):
+                        continue
+                    cs = [float(c) for c in rng.uniform(-0.7, 0.7, m)]
+                    res = sum(c * hv(o, (n,)) for c, o in zip(cs, offs))
+                    ctx.lincomb(dev(oo, (n,)), [dev(o, (n,)) for o in offs], cs)
+                    host[oo:oo + n] = res
+                elif kind == "dots":
+                    n = int(rng.integers(10, 3000))
+                    ox, oy = place(n), place(n)
+                    got = ctx.dots([dev(ox, (n,))], [dev(oy, (n,))])[0]
+                    want = float(hv(ox, (n,)) @ hv(oy, (n,)))
+                    assert abs(got - want) < 1e-10 * max(1.0, abs(want)), (done, got, want)
+                    dots_seen += 1
+                else:
+                    M, N, K = int(rng.integers(3, 60)), int(rng.integers(3, 60)), int(rng.integers(3, 40))
+                    oa, ob, oc = place(M * K), place(K * N), place(M * N)
+                    if not (apart(oa, M * K, oc, M * N) and apart(ob, K * N, oc, M * N)):
+                        continue
+                    A, B = hv(oa, (M, K)), hv(ob, (K, N))
+                    alpha = 1.0 / (np.sqrt(K) * max(1.0, np.abs(A).max()) * max(1.0, np.abs(B).max()))
+                    beta = float(rng.choice([0.0, 1.0]))
+                    res = alpha * (A @ B) + beta * hv(oc, (M, N))
+                    ctx.dgemm(M, N, K, alpha, dev(oa, (1,)), K, 1, dev(ob, (1,)), N, 1, beta, dev(oc, (1,)), N)
+                    host[oc:oc + M * N] = res.ravel()
+                done += 1
+        got = buf.get()
+        assert np.isfinite(host).all() and np.abs(got - host).max() < 1e-11 * max(1.0, np.abs(host).max()), np.abs(got - host).max()
+    finally:
+        ctx.close()
