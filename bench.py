@@ -20,6 +20,10 @@ import time
 
 import numpy as np
 
+# the pool's host driver supports dmabuf IPC only: without this RCCL's buffer exchange between the rank processes fails with
+# `hipIpcGetMemHandle: invalid argument` (set before anything initialises the GPU; a launcher's own setting wins)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
