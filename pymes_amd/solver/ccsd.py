@@ -230,7 +230,8 @@ class CCSD(ccd.CCD):
         if speculate:
             self._launch_residuals(st)
         e1, ed, ex, nt2, nr2, n1 = ctx.energy_norms_wait(slot)
-        mark("energy + norms (read-back)")
+        # (pipelined: the NEXT pass's residual segment has been enqueued in front of this wait and is charged to this mark)
+        mark("energy + norms (read-back) + the next pass's residuals, enqueued ahead" if speculate else "energy + norms (read-back)")
         if self.is_diis:
             self.mixer.log_last()
         was_zero = st["t1_zero"]
